@@ -1,0 +1,97 @@
+"""ctypes binding of libdsdenoise.so (include/dsd.h).  There is NO fallback: if the library is missing or
+does not load, importing the engine fails loudly - the product path never routes through a CPU/oracle
+implementation."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdsdenoise.so')
+
+DSD_ABI_VERSION = 1
+
+# every symbol include/dsd.h declares (tests check the .so exports exactly these)
+SYMBOLS = [
+    'dsd_abi_version', 'dsd_last_error', 'dsd_create', 'dsd_destroy', 'dsd_load_weights', 'dsd_set_schedule',
+    'dsd_get_schedule_table', 'dsd_set_spec_range', 'dsd_prepare', 'dsd_denoise', 'dsd_q_sample',
+    'dsd_sample_ddpm', 'dsd_p_sample', 'dsd_sample_plms', 'dsd_norm_spec', 'dsd_denorm_spec',
+    'dsd_set_use_graph', 'dsd_set_layer_tile', 'dsd_time_layer_kernel', 'dsd_device_bytes', 'dsd_get_layer_tile',
+]
+
+_fp = C.POINTER(C.c_float)
+_fpp = C.POINTER(C.c_void_p)
+
+
+class DsdConfig(C.Structure):
+    _fields_ = [('mel_bins', C.c_int32), ('residual_channels', C.c_int32), ('encoder_hidden', C.c_int32),
+                ('residual_layers', C.c_int32), ('dilation_cycle_length', C.c_int32)]
+
+
+class DsdWeights(C.Structure):
+    _fields_ = [
+        ('input_projection_w', C.c_void_p), ('input_projection_b', C.c_void_p),
+        ('mlp0_w', C.c_void_p), ('mlp0_b', C.c_void_p), ('mlp2_w', C.c_void_p), ('mlp2_b', C.c_void_p),
+        ('dilated_conv_w', _fpp), ('dilated_conv_b', _fpp),
+        ('diffusion_projection_w', _fpp), ('diffusion_projection_b', _fpp),
+        ('conditioner_projection_w', _fpp), ('conditioner_projection_b', _fpp),
+        ('output_projection_w', _fpp), ('output_projection_b', _fpp),
+        ('skip_projection_w', C.c_void_p), ('skip_projection_b', C.c_void_p),
+        ('final_projection_w', C.c_void_p), ('final_projection_b', C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and type the library.  Raises RuntimeError when it is absent - build it with
+    `python -m diffsinger_amd.build` (hipcc, gfx950)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(_LIB_PATH):
+        raise RuntimeError(f'{_LIB_PATH} not found: the HIP denoiser library is not built '
+                           f'(run `python -m diffsinger_amd.build`); there is no CPU fallback')
+    lib = C.CDLL(_LIB_PATH)
+    h = C.c_void_p
+    lib.dsd_abi_version.restype = C.c_int
+    lib.dsd_last_error.restype = C.c_char_p
+    lib.dsd_create.argtypes = [C.POINTER(DsdConfig), C.c_int, C.POINTER(h)]
+    lib.dsd_destroy.argtypes = [h]
+    lib.dsd_destroy.restype = None
+    lib.dsd_load_weights.argtypes = [h, C.POINTER(DsdWeights), C.c_void_p]
+    lib.dsd_set_schedule.argtypes = [h, C.POINTER(C.c_double), C.c_int32]
+    lib.dsd_get_schedule_table.argtypes = [h, C.c_int32, _fp, C.c_int32]
+    lib.dsd_set_spec_range.argtypes = [h, _fp, _fp]
+    lib.dsd_prepare.argtypes = [h, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+    lib.dsd_denoise.argtypes = [h, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
+    lib.dsd_q_sample.argtypes = [h, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dsd_sample_ddpm.argtypes = [h, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.dsd_p_sample.argtypes = [h, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.dsd_sample_plms.argtypes = [h, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.dsd_norm_spec.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dsd_denorm_spec.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dsd_set_use_graph.argtypes = [h, C.c_int32]
+    lib.dsd_set_layer_tile.argtypes = [h, C.c_int32]
+    lib.dsd_time_layer_kernel.argtypes = [h, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_void_p]
+    lib.dsd_device_bytes.argtypes = [h]
+    lib.dsd_device_bytes.restype = C.c_int64
+    lib.dsd_get_layer_tile.argtypes = [h]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ('dsd_abi_version',):
+            fn.restype = C.c_int
+    if lib.dsd_abi_version() != DSD_ABI_VERSION:
+        raise RuntimeError(f'libdsdenoise ABI {lib.dsd_abi_version()} != binding {DSD_ABI_VERSION}: rebuild')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = load().dsd_last_error()
+        raise RuntimeError(f'{what or "libdsdenoise"} failed ({rc}): {msg.decode() if msg else "?"}')

@@ -1,0 +1,35 @@
+"""Build libdsdenoise.so IN-TREE with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m diffsinger_amd.build [--force]
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(PKG, 'csrc', 'dsd.hip')]
+DEPS = SRC + [os.path.join(PKG, 'csrc', 'dsd_kernels.hpp'), os.path.join(os.path.dirname(PKG), 'include', 'dsd.h')]
+LIB = os.path.join(PKG, 'libdsdenoise.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC']
+
+
+def up_to_date() -> bool:
+    return os.path.isfile(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if up_to_date() and not force:
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc] + FLAGS + ['-o', LIB] + SRC
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

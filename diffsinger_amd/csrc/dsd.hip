@@ -1,0 +1,710 @@
+// dsd.hip - host side of libdsdenoise.so: handle, weight repacking, schedule tables, workspace, launch
+// sequencing of the K-step reverse loop (eager or as a cached hipGraph).  C ABI in include/dsd.h.
+#include "dsd_kernels.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/dsd.h"
+
+using namespace dsd;
+
+// ------------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(DSD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define DSD_TRY(expr)            \
+    do {                         \
+        int r_ = (expr);         \
+        if (r_ != DSD_OK) return r_; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------------------
+struct GraphKey {
+    int kind, B, T, k_step, interval, tile;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(kind, B, T, k_step, interval, tile) < std::tie(o.kind, o.B, o.T, o.k_step, o.interval, o.tile);
+    }
+};
+
+struct dsd_handle {
+    dsd_config cfg{};
+    int device = 0;
+    int L = 0, M = 0, nk_in = 0;
+    std::vector<int> dil;
+    bool has_weights = false, has_schedule = false, has_spec = false, prepared = false;
+    bool use_graph = true;
+    int layer_tile_req = 0;     // 0 auto, 32, 64
+    int64_t bytes = 0;       // device bytes owned: packed weights + tables (persistent)
+    int64_t bytes_ws = 0;    // ... + workspace of the prepared batch
+
+    // packed weights (device)
+    float4 *w1p = nullptr, *w2p = nullptr, *wcp = nullptr, *b1p = nullptr, *b2p = nullptr;
+    float4 *winp = nullptr, *binp = nullptr, *wsp = nullptr, *bsp = nullptr, *woutp = nullptr, *boutp = nullptr;
+    // raw copies for the step table
+    float *mlp0_w = nullptr, *mlp0_b = nullptr, *mlp2_w = nullptr, *mlp2_b = nullptr, *dp_w = nullptr, *dp_b = nullptr;
+    float* ds_table = nullptr;  // [n_table][L][C]
+    int n_table = 0;
+
+    // schedule (host fp32 tables, registration order of the reference)
+    std::vector<float> tab[12];
+    int n_sched = 0;
+    float *spec_min_d = nullptr, *spec_max_d = nullptr;
+
+    // workspace for the prepared batch
+    int B = 0, T = 0, TS = 0, ntile32 = 0, ntiles = 0;
+    int64_t cap_frames = 0;     // capacity (B*ntile32 tiles) the buffers were sized for
+    int cap_B = 0;
+    int64_t cap_spec = 0;
+    float *xa_base = nullptr, *xb_base = nullptr, *xa = nullptr, *xb = nullptr, *condT = nullptr;
+    float4 *cp = nullptr, *skip = nullptr;
+    float *xs = nullptr, *xtmp = nullptr, *ering[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* t_dev = nullptr;
+    const float** noise_cell = nullptr;
+
+    hipStream_t cap_stream = nullptr;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+};
+
+static const int kSlack = 64;   // floats of slack in front of / behind the x buffers (masked halo loads)
+
+template <typename T>
+static int dev_alloc(dsd_handle* h, T** p, size_t count, bool workspace = false) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess) return fail(DSD_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    *p = (T*)q;
+    (workspace ? h->bytes_ws : h->bytes) += (int64_t)(count * sizeof(T));
+    return DSD_OK;
+}
+template <typename T>
+static void dev_free(T*& p) {
+    if (p) (void)hipFree((void*)p);
+    p = nullptr;
+}
+
+static void drop_graphs(dsd_handle* h) {
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+}
+
+static void free_workspace(dsd_handle* h) {
+    drop_graphs(h);
+    dev_free(h->xa_base); dev_free(h->xb_base); dev_free(h->condT); dev_free(h->cp); dev_free(h->skip);
+    dev_free(h->xs); dev_free(h->xtmp);
+    for (auto& e : h->ering) dev_free(e);
+    dev_free(h->t_dev);
+    h->xa = h->xb = nullptr;
+    h->cap_frames = 0; h->cap_B = 0; h->cap_spec = 0;
+    h->bytes_ws = 0;
+    h->prepared = false;
+}
+
+extern "C" int dsd_abi_version(void) { return DSD_ABI_VERSION; }
+extern "C" const char* dsd_last_error(void) { return g_err.c_str(); }
+
+extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
+    if (!cfg || !out) return fail(DSD_ERR_INVALID, "dsd_create: null argument");
+    if (cfg->residual_channels != kC || cfg->encoder_hidden != kC)
+        return fail(DSD_ERR_INVALID, "dsd_create: this build supports residual_channels == hidden_size == %d (got %d, %d)",
+                    kC, cfg->residual_channels, cfg->encoder_hidden);
+    if (cfg->mel_bins < 1 || cfg->mel_bins > kMPad) return fail(DSD_ERR_INVALID, "dsd_create: mel_bins must be in 1..%d", kMPad);
+    if (cfg->residual_layers < 1 || cfg->residual_layers > 64) return fail(DSD_ERR_INVALID, "dsd_create: residual_layers must be in 1..64");
+    if (cfg->dilation_cycle_length < 1) return fail(DSD_ERR_INVALID, "dsd_create: dilation_cycle_length must be >= 1");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(DSD_ERR_INVALID, "dsd_create: device %d out of range (%d visible)", device, ndev);
+    dsd_handle* h = new dsd_handle();
+    h->cfg = *cfg;
+    h->device = device;
+    h->L = cfg->residual_layers;
+    h->M = cfg->mel_bins;
+    h->nk_in = (cfg->mel_bins + 7) / 8;
+    for (int l = 0; l < h->L; ++l) {
+        const int e = l % cfg->dilation_cycle_length;
+        if (e > 3) { delete h; return fail(DSD_ERR_INVALID, "dsd_create: dilation 2^%d exceeds the supported maximum %d", e, kHalo); }
+        h->dil.push_back(1 << e);
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // kernels that need more than 64 KiB of dynamic LDS must opt in
+        (void)hipFuncSetAttribute((const void*)k_layer<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>());
+        (void)hipFuncSetAttribute((const void*)k_layer<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>());
+        (void)hipFuncSetAttribute((const void*)k_layer<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
+        (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
+        (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_head<HEAD_PLMS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_head<HEAD_PLMS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
+    }
+    if (e != hipSuccess) { delete h; return fail(DSD_ERR_HIP, "dsd_create: %s", hipGetErrorString(e)); }
+    *out = h;
+    return DSD_OK;
+}
+
+extern "C" void dsd_destroy(dsd_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    free_workspace(h);
+    dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->b2p);
+    dev_free(h->winp); dev_free(h->binp); dev_free(h->wsp); dev_free(h->bsp); dev_free(h->woutp); dev_free(h->boutp);
+    dev_free(h->mlp0_w); dev_free(h->mlp0_b); dev_free(h->mlp2_w); dev_free(h->mlp2_b); dev_free(h->dp_w); dev_free(h->dp_b);
+    dev_free(h->ds_table); dev_free(h->spec_min_d); dev_free(h->spec_max_d);
+    dev_free(h->noise_cell);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    delete h;
+}
+
+extern "C" int dsd_set_use_graph(dsd_handle* h, int32_t enable) {
+    if (!h) return fail(DSD_ERR_INVALID, "null handle");
+    h->use_graph = enable != 0;
+    return DSD_OK;
+}
+
+extern "C" int dsd_set_layer_tile(dsd_handle* h, int32_t frames) {
+    if (!h) return fail(DSD_ERR_INVALID, "null handle");
+    if (frames != 0 && frames != 32 && frames != 64) return fail(DSD_ERR_INVALID, "dsd_set_layer_tile: frames must be 0, 32 or 64");
+    h->layer_tile_req = frames;
+    return DSD_OK;
+}
+
+extern "C" int64_t dsd_device_bytes(dsd_handle* h) { return h ? h->bytes + h->bytes_ws : 0; }
+
+static int layer_nb(const dsd_handle* h) {
+    if (h->layer_tile_req) return h->layer_tile_req / 32;
+    // 32-frame workgroups until there are enough of them to keep two resident per CU on all 256 CUs; beyond
+    // that 64-frame workgroups halve the weight traffic out of L2 per frame.
+    return (h->ntiles > 1024) ? 2 : 1;
+}
+extern "C" int dsd_get_layer_tile(dsd_handle* h) { return h ? 32 * layer_nb(h) : 0; }
+
+// ------------------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------------------
+static int pack_a(hipStream_t s, const float* src, float4* dst, int nw, int ntap, int nkc, int nmb, int split, int hi_base,
+                  int rows_valid, int cols_valid, int row_stride, int col_stride) {
+    PackParams p{src, (float*)dst, nw, nkc, nmb, ntap, split, hi_base, rows_valid, cols_valid, row_stride, col_stride};
+    const size_t n = (size_t)nw * ntap * nkc * nmb * 256;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_pack_a, dim3(blocks), dim3(256), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+static int pack_bias(hipStream_t s, const float* a, const float* b, float4* dst, int nw, int nmb, int split, int hi_base, int rows_valid) {
+    PackBiasParams p{a, b, (float*)dst, nw, nmb, split, hi_base, rows_valid};
+    hipLaunchKernelGGL(k_pack_bias, dim3((nw * nmb * 32 + 255) / 256), dim3(256), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+static int build_step_table(dsd_handle* h, int n, hipStream_t s) {
+    // ds_table[t][l][c] = diffusion_projection_l( mlp( SinusoidalPosEmb(t) ) )   (net.py:119-120, :67)
+    if (n <= h->n_table) return DSD_OK;
+    n = (n + 63) / 64 * 64;
+    HIP_TRY(hipStreamSynchronize(s));
+    drop_graphs(h);
+    if (h->ds_table) { h->bytes -= (int64_t)h->n_table * h->L * kC * 4; dev_free(h->ds_table); h->n_table = 0; }
+    DSD_TRY(dev_alloc(h, &h->ds_table, (size_t)n * h->L * kC));
+    float *E = nullptr, *H1 = nullptr, *H2 = nullptr;
+    HIP_TRY(hipMalloc((void**)&E, (size_t)kC * n * 4));
+    HIP_TRY(hipMalloc((void**)&H1, (size_t)4 * kC * n * 4));
+    HIP_TRY(hipMalloc((void**)&H2, (size_t)kC * n * 4));
+    const dim3 blk(64);
+    const int gx = (n + 63) / 64;
+    hipLaunchKernelGGL(k_step_embed, dim3(gx, kC), blk, 0, s, E, kC, n);
+    hipLaunchKernelGGL(k_small_gemm, dim3(gx, 4 * kC), blk, 0, s, h->mlp0_w, h->mlp0_b, E, H1, 4 * kC, kC, n, 1, (size_t)n, (size_t)1);
+    hipLaunchKernelGGL(k_small_gemm, dim3(gx, kC), blk, 0, s, h->mlp2_w, h->mlp2_b, H1, H2, kC, 4 * kC, n, 0, (size_t)n, (size_t)1);
+    // all layers' diffusion_projection stacked: rows m = l*C + c -> table[t][m]
+    hipLaunchKernelGGL(k_small_gemm, dim3(gx, h->L * kC), blk, 0, s, h->dp_w, h->dp_b, H2, h->ds_table, h->L * kC, kC, n, 0,
+                       (size_t)1, (size_t)h->L * kC);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(E); (void)hipFree(H1); (void)hipFree(H2);
+    if (e != hipSuccess) return fail(DSD_ERR_HIP, "step table: %s", hipGetErrorString(e));
+    h->n_table = n;
+    return DSD_OK;
+}
+
+extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* stream) {
+    if (!h || !w) return fail(DSD_ERR_INVALID, "dsd_load_weights: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int L = h->L, M = h->M;
+    if (!h->w1p) {
+        DSD_TRY(dev_alloc(h, &h->w1p, (size_t)L * 4 * 96 * 256));
+        DSD_TRY(dev_alloc(h, &h->w2p, (size_t)L * 4 * 32 * 256));
+        DSD_TRY(dev_alloc(h, &h->wcp, (size_t)L * 4 * 32 * 256));
+        DSD_TRY(dev_alloc(h, &h->b1p, (size_t)L * 4 * 4 * 8));
+        DSD_TRY(dev_alloc(h, &h->b2p, (size_t)L * 4 * 4 * 8));
+        DSD_TRY(dev_alloc(h, &h->winp, (size_t)4 * h->nk_in * 128));
+        DSD_TRY(dev_alloc(h, &h->binp, (size_t)4 * 2 * 8));
+        DSD_TRY(dev_alloc(h, &h->wsp, (size_t)4 * 32 * 128));
+        DSD_TRY(dev_alloc(h, &h->bsp, (size_t)4 * 2 * 8));
+        DSD_TRY(dev_alloc(h, &h->woutp, (size_t)32 * 3 * 64));
+        DSD_TRY(dev_alloc(h, &h->boutp, (size_t)3 * 8));
+        DSD_TRY(dev_alloc(h, &h->mlp0_w, (size_t)4 * kC * kC));
+        DSD_TRY(dev_alloc(h, &h->mlp0_b, (size_t)4 * kC));
+        DSD_TRY(dev_alloc(h, &h->mlp2_w, (size_t)4 * kC * kC));
+        DSD_TRY(dev_alloc(h, &h->mlp2_b, (size_t)kC));
+        DSD_TRY(dev_alloc(h, &h->dp_w, (size_t)L * kC * kC));
+        DSD_TRY(dev_alloc(h, &h->dp_b, (size_t)L * kC));
+        DSD_TRY(dev_alloc(h, &h->noise_cell, 1));
+    }
+    for (int l = 0; l < L; ++l) {
+        if (!w->dilated_conv_w[l] || !w->dilated_conv_b[l] || !w->diffusion_projection_w[l] || !w->diffusion_projection_b[l] ||
+            !w->conditioner_projection_w[l] || !w->conditioner_projection_b[l] || !w->output_projection_w[l] || !w->output_projection_b[l])
+            return fail(DSD_ERR_INVALID, "dsd_load_weights: null tensor in layer %d", l);
+        // gate rows [0,C) / filter rows [C,2C) split across waves so each wave owns matching pairs
+        DSD_TRY(pack_a(s, w->dilated_conv_w[l], h->w1p + (size_t)l * 4 * 96 * 256, 4, 3, 32, 4, 1, kC, 2 * kC, kC, 3 * kC, 3));
+        DSD_TRY(pack_a(s, w->conditioner_projection_w[l], h->wcp + (size_t)l * 4 * 32 * 256, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1));
+        DSD_TRY(pack_a(s, w->output_projection_w[l], h->w2p + (size_t)l * 4 * 32 * 256, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1));
+        DSD_TRY(pack_bias(s, w->dilated_conv_b[l], w->conditioner_projection_b[l], h->b1p + (size_t)l * 128, 4, 4, 1, kC, 2 * kC));
+        DSD_TRY(pack_bias(s, w->output_projection_b[l], nullptr, h->b2p + (size_t)l * 128, 4, 4, 1, kC, 2 * kC));
+        HIP_TRY(hipMemcpyAsync(h->dp_w + (size_t)l * kC * kC, w->diffusion_projection_w[l], (size_t)kC * kC * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->dp_b + (size_t)l * kC, w->diffusion_projection_b[l], (size_t)kC * 4, hipMemcpyDeviceToDevice, s));
+    }
+    DSD_TRY(pack_a(s, w->input_projection_w, h->winp, 4, 1, h->nk_in, 2, 0, 0, kC, M, M, 1));
+    DSD_TRY(pack_bias(s, w->input_projection_b, nullptr, h->binp, 4, 2, 0, 0, kC));
+    DSD_TRY(pack_a(s, w->skip_projection_w, h->wsp, 4, 1, 32, 2, 0, 0, kC, kC, kC, 1));
+    DSD_TRY(pack_bias(s, w->skip_projection_b, nullptr, h->bsp, 4, 2, 0, 0, kC));
+    DSD_TRY(pack_a(s, w->final_projection_w, h->woutp, 1, 1, 32, 3, 0, 0, M, kC, kC, 1));
+    DSD_TRY(pack_bias(s, w->final_projection_b, nullptr, h->boutp, 1, 3, 0, 0, M));
+    HIP_TRY(hipMemcpyAsync(h->mlp0_w, w->mlp0_w, (size_t)4 * kC * kC * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->mlp0_b, w->mlp0_b, (size_t)4 * kC * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->mlp2_w, w->mlp2_w, (size_t)4 * kC * kC * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->mlp2_b, w->mlp2_b, (size_t)kC * 4, hipMemcpyDeviceToDevice, s));
+    h->has_weights = true;
+    // the step table depends on the weights: rebuild for the range already known
+    const int n = std::max(h->n_table, std::max(h->n_sched, 64));
+    if (h->ds_table) { h->bytes -= (int64_t)h->n_table * h->L * kC * 4; dev_free(h->ds_table); }
+    h->n_table = 0;
+    DSD_TRY(build_step_table(h, n, s));
+    h->prepared = false;    // cached conditioner projections were made with the old weights
+    return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// schedule
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int dsd_set_schedule(dsd_handle* h, const double* betas, int32_t n) {
+    if (!h || !betas || n < 1) return fail(DSD_ERR_INVALID, "dsd_set_schedule: bad argument");
+    // float64 arithmetic, then cast: shallow_diffusion_tts.py:87-123
+    std::vector<double> al(n), ac(n), acp(n);
+    double run = 1.0;
+    for (int i = 0; i < n; ++i) {
+        al[i] = 1.0 - betas[i];
+        run *= al[i];
+        ac[i] = run;
+        acp[i] = i ? ac[i - 1] : 1.0;
+    }
+    for (auto& t : h->tab) t.assign(n, 0.f);
+    for (int i = 0; i < n; ++i) {
+        const double pv = betas[i] * (1.0 - acp[i]) / (1.0 - ac[i]);
+        h->tab[0][i] = (float)betas[i];
+        h->tab[1][i] = (float)ac[i];
+        h->tab[2][i] = (float)acp[i];
+        h->tab[3][i] = (float)std::sqrt(ac[i]);
+        h->tab[4][i] = (float)std::sqrt(1.0 - ac[i]);
+        h->tab[5][i] = (float)std::log(1.0 - ac[i]);
+        h->tab[6][i] = (float)std::sqrt(1.0 / ac[i]);
+        h->tab[7][i] = (float)std::sqrt(1.0 / ac[i] - 1.0);
+        h->tab[8][i] = (float)pv;
+        h->tab[9][i] = (float)std::log(std::max(pv, 1e-20));
+        h->tab[10][i] = (float)(betas[i] * std::sqrt(acp[i]) / (1.0 - ac[i]));
+        h->tab[11][i] = (float)((1.0 - acp[i]) * std::sqrt(al[i]) / (1.0 - ac[i]));
+    }
+    h->n_sched = n;
+    h->has_schedule = true;
+    drop_graphs(h);     // per-step scalars are baked into captured launches
+    if (h->has_weights) {
+        HIP_TRY(hipSetDevice(h->device));
+        DSD_TRY(build_step_table(h, n, nullptr));
+    }
+    return DSD_OK;
+}
+
+extern "C" int dsd_get_schedule_table(dsd_handle* h, int32_t which, float* out, int32_t n) {
+    if (!h || !out || which < 0 || which >= 12) return fail(DSD_ERR_INVALID, "dsd_get_schedule_table: bad argument");
+    if (!h->has_schedule || n != h->n_sched) return fail(DSD_ERR_STATE, "dsd_get_schedule_table: schedule has %d steps", h->n_sched);
+    std::memcpy(out, h->tab[which].data(), (size_t)n * sizeof(float));
+    return DSD_OK;
+}
+
+extern "C" int dsd_set_spec_range(dsd_handle* h, const float* spec_min, const float* spec_max) {
+    if (!h || !spec_min || !spec_max) return fail(DSD_ERR_INVALID, "dsd_set_spec_range: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->spec_min_d) {
+        DSD_TRY(dev_alloc(h, &h->spec_min_d, (size_t)kMPad));
+        DSD_TRY(dev_alloc(h, &h->spec_max_d, (size_t)kMPad));
+    }
+    HIP_TRY(hipMemcpy(h->spec_min_d, spec_min, (size_t)h->M * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->spec_max_d, spec_max, (size_t)h->M * 4, hipMemcpyHostToDevice));
+    h->has_spec = true;
+    return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// prepare: workspace + hoisted conditioner projection
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* cond, int64_t sb, int64_t sh, int64_t st, void* stream) {
+    if (!h || !cond) return fail(DSD_ERR_INVALID, "dsd_prepare: null argument");
+    if (!h->has_weights) return fail(DSD_ERR_STATE, "dsd_prepare: call dsd_load_weights first");
+    if (B < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsd_prepare: B and T must be positive (got %d, %d)", B, T);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int TS = (T + 31) / 32 * 32, ntile32 = TS / 32;
+    const int64_t ntiles = (int64_t)B * ntile32;
+    if (ntiles > (1 << 22)) return fail(DSD_ERR_INVALID, "dsd_prepare: batch too large (%lld tiles); split it", (long long)ntiles);
+    const int64_t spec = (int64_t)B * h->M * T;
+    if (ntiles > h->cap_frames || B > h->cap_B || spec > h->cap_spec) {
+        HIP_TRY(hipStreamSynchronize(s));
+        free_workspace(h);
+        const size_t xcount = (size_t)B * kC * TS + 2 * kSlack;
+        DSD_TRY(dev_alloc(h, &h->xa_base, xcount, true));
+        DSD_TRY(dev_alloc(h, &h->xb_base, xcount, true));
+        DSD_TRY(dev_alloc(h, &h->condT, (size_t)B * kC * TS, true));
+        DSD_TRY(dev_alloc(h, &h->cp, (size_t)h->L * ntiles * 4096, true));
+        DSD_TRY(dev_alloc(h, &h->skip, (size_t)ntiles * 2048, true));
+        DSD_TRY(dev_alloc(h, &h->xs, (size_t)spec, true));
+        DSD_TRY(dev_alloc(h, &h->xtmp, (size_t)spec, true));
+        for (auto& e : h->ering) DSD_TRY(dev_alloc(h, &e, (size_t)spec, true));
+        DSD_TRY(dev_alloc(h, &h->t_dev, (size_t)B, true));
+        HIP_TRY(hipMemsetAsync(h->xa_base, 0, xcount * 4, s));
+        HIP_TRY(hipMemsetAsync(h->xb_base, 0, xcount * 4, s));
+        h->xa = h->xa_base + kSlack;
+        h->xb = h->xb_base + kSlack;
+        h->cap_frames = ntiles; h->cap_B = B; h->cap_spec = spec;
+    }
+    h->B = B; h->T = T; h->TS = TS; h->ntile32 = ntile32; h->ntiles = (int)ntiles;
+
+    hipLaunchKernelGGL(k_cond_layout, dim3(ntile32, kC / 32, B), dim3(32, 8), 0, s, cond, h->condT, kC, T, TS, sb, sh, st);
+    HIP_TRY(hipGetLastError());
+    CondProjParams p{h->condT, h->wcp, h->b1p, h->cp, TS, ntile32, (int)ntiles};
+    hipLaunchKernelGGL(k_condproj, dim3((unsigned)ntiles, h->L), dim3(kThreads), kC * 32 * 4, s, p);
+    HIP_TRY(hipGetLastError());
+    h->prepared = true;
+    return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------------------
+static int launch_inproj(dsd_handle* h, const float* spec, hipStream_t s) {
+    InProjParams p{spec, h->xa, h->winp, h->binp, h->nk_in, h->M, h->T, h->TS, h->ntile32};
+    hipLaunchKernelGGL(k_inproj, dim3(h->ntiles), dim3(kThreads), kMPad * 32 * 4, s, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, hipStream_t s) {
+    const int nb = layer_nb(h);
+    LayerParams p{};
+    p.x_in = (l & 1) ? h->xb : h->xa;
+    p.x_out = (l & 1) ? h->xa : h->xb;
+    p.w1p = h->w1p + (size_t)l * 4 * 96 * 256;
+    p.w2p = h->w2p + (size_t)l * 4 * 32 * 256;
+    p.b2p = h->b2p + (size_t)l * 128;
+    p.cp = h->cp + (size_t)l * h->ntiles * 4096;
+    p.skip = h->skip;
+    p.ds = h->ds_table + (size_t)l * kC;
+    p.t_dev = t_dev;
+    p.t_uniform = t_uniform;
+    p.ds_tstride = h->L * kC;
+    p.T = h->T; p.TS = h->TS; p.ntile32 = h->ntile32;
+    p.tiles_per_utt = (h->ntile32 + nb - 1) / nb;
+    p.dil = h->dil[l];
+    p.first = (l == 0);
+    const dim3 grid((unsigned)(h->B * p.tiles_per_utt));
+    const bool last = (l == h->L - 1);
+    if (nb == 1) {
+        if (last) hipLaunchKernelGGL((k_layer<1, true>), grid, dim3(kThreads), layer_lds_bytes<1>(), s, p);
+        else hipLaunchKernelGGL((k_layer<1, false>), grid, dim3(kThreads), layer_lds_bytes<1>(), s, p);
+    } else {
+        if (last) hipLaunchKernelGGL((k_layer<2, true>), grid, dim3(kThreads), layer_lds_bytes<2>(), s, p);
+        else hipLaunchKernelGGL((k_layer<2, false>), grid, dim3(kThreads), layer_lds_bytes<2>(), s, p);
+    }
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+static HeadParams head_base(dsd_handle* h) {
+    HeadParams p{};
+    p.skip = h->skip; p.wsp = h->wsp; p.bsp = h->bsp; p.woutp = h->woutp; p.boutp = h->boutp;
+    p.winp = h->winp; p.binp = h->binp; p.x_next = h->xa;
+    p.sqrt_L = (float)std::sqrt((double)h->L);
+    p.nk_in = h->nk_in; p.M = h->M; p.T = h->T; p.TS = h->TS; p.ntile32 = h->ntile32;
+    p.noise_cell = h->noise_cell;
+    return p;
+}
+
+template <int MODE>
+static int launch_head(dsd_handle* h, const HeadParams& p, bool fuse, hipStream_t s) {
+    if (fuse) hipLaunchKernelGGL((k_head<MODE, true>), dim3(h->ntiles), dim3(kThreads), kHeadLdsBytes, s, p);
+    else hipLaunchKernelGGL((k_head<MODE, false>), dim3(h->ntiles), dim3(kThreads), kHeadLdsBytes, s, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+static int check_ready(dsd_handle* h, const char* who, bool need_sched) {
+    if (!h) return fail(DSD_ERR_INVALID, "%s: null handle", who);
+    if (!h->has_weights) return fail(DSD_ERR_STATE, "%s: weights not loaded", who);
+    if (!h->prepared) return fail(DSD_ERR_STATE, "%s: no batch prepared (dsd_prepare)", who);
+    if (need_sched && !h->has_schedule) return fail(DSD_ERR_STATE, "%s: schedule not set (dsd_set_schedule)", who);
+    return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// single evaluation
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int dsd_denoise(dsd_handle* h, const float* x, const int32_t* t, float* eps, void* stream) {
+    DSD_TRY(check_ready(h, "dsd_denoise", false));
+    if (!x || !t || !eps) return fail(DSD_ERR_INVALID, "dsd_denoise: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    int tmax = 0;
+    bool uniform = true;
+    for (int b = 0; b < h->B; ++b) {
+        if (t[b] < 0) return fail(DSD_ERR_INVALID, "dsd_denoise: negative step index");
+        tmax = std::max(tmax, (int)t[b]);
+        uniform = uniform && (t[b] == t[0]);
+    }
+    DSD_TRY(build_step_table(h, tmax + 1, s));
+    const int* t_dev = nullptr;
+    if (!uniform) {
+        HIP_TRY(hipMemcpyAsync(h->t_dev, t, (size_t)h->B * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));   // t is a caller-owned host array: do not reference it after return
+        t_dev = h->t_dev;
+    }
+    DSD_TRY(launch_inproj(h, x, s));
+    for (int l = 0; l < h->L; ++l) DSD_TRY(launch_layer(h, l, t[0], t_dev, s));
+    HeadParams p = head_base(h);
+    p.eps_out = eps;
+    return launch_head<HEAD_EPS>(h, p, false, s);
+}
+
+extern "C" int dsd_q_sample(dsd_handle* h, const float* x_start, const float* noise, int32_t t, float* out, void* stream) {
+    if (!h || !x_start || !noise || !out) return fail(DSD_ERR_INVALID, "dsd_q_sample: null argument");
+    if (!h->has_schedule) return fail(DSD_ERR_STATE, "dsd_q_sample: schedule not set");
+    if (!h->prepared) return fail(DSD_ERR_STATE, "dsd_q_sample: no batch prepared");
+    if (t < 0 || t >= h->n_sched) return fail(DSD_ERR_INVALID, "dsd_q_sample: t=%d outside the %d-step schedule", t, h->n_sched);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->B * h->M * h->T;
+    hipLaunchKernelGGL(k_qsample, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       x_start, noise, out, h->tab[3][t], h->tab[4][t], n);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsd_norm_spec(dsd_handle* h, const float* mel, float* x, void* stream) {
+    if (!h || !mel || !x) return fail(DSD_ERR_INVALID, "dsd_norm_spec: null argument");
+    if (!h->has_spec) return fail(DSD_ERR_STATE, "dsd_norm_spec: spec range not set");
+    if (!h->prepared) return fail(DSD_ERR_STATE, "dsd_norm_spec: no batch prepared");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_norm_spec, dim3((h->T + 31) / 32, h->B), dim3(256), 32 * (h->M + 1) * 4, (hipStream_t)stream, mel, x,
+                       h->spec_min_d, h->spec_max_d, h->M, h->T);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsd_denorm_spec(dsd_handle* h, const float* x, const float* mask, float* mel, void* stream) {
+    if (!h || !mel || !x) return fail(DSD_ERR_INVALID, "dsd_denorm_spec: null argument");
+    if (!h->has_spec) return fail(DSD_ERR_STATE, "dsd_denorm_spec: spec range not set");
+    if (!h->prepared) return fail(DSD_ERR_STATE, "dsd_denorm_spec: no batch prepared");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_denorm_spec, dim3((h->T + 31) / 32, h->B), dim3(256), 32 * (h->M + 1) * 4, (hipStream_t)stream, x, mask, mel,
+                       h->spec_min_d, h->spec_max_d, h->M, h->T);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// sampling loops
+// ------------------------------------------------------------------------------------------------------------
+// Enqueue the whole DDPM loop on stream s, operating on the internal spec buffer h->xs.
+static int enqueue_ddpm(dsd_handle* h, int k_step, hipStream_t s) {
+    const size_t bmt = (size_t)h->B * h->M * h->T;
+    DSD_TRY(launch_inproj(h, h->xs, s));
+    for (int j = 0; j < k_step; ++j) {
+        const int t = k_step - 1 - j;
+        for (int l = 0; l < h->L; ++l) DSD_TRY(launch_layer(h, l, t, nullptr, s));
+        HeadParams p = head_base(h);
+        p.x_base = h->xs; p.x_out = h->xs;
+        p.noise_off = (size_t)j * bmt;
+        p.sa = h->tab[6][t]; p.sb = h->tab[7][t]; p.c1 = h->tab[10][t]; p.c2 = h->tab[11][t];
+        // nonzero_mask * exp(0.5 * logvar): fp32 like the reference's [B,1,1,1] tensors (:165-166)
+        p.sigma = (t == 0) ? 0.f : std::exp(0.5f * h->tab[9][t]);
+        DSD_TRY(launch_head<HEAD_DDPM>(h, p, /*fuse next in-proj*/ t > 0, s));
+    }
+    return DSD_OK;
+}
+
+// get_x_pred coefficients (shallow_diffusion_tts.py:174-185), in fp32 like the reference
+static void plms_coef(const dsd_handle* h, int t, int interval, float* dA, float* cx, float* ce) {
+    const float a_t = h->tab[1][t];
+    const float a_prev = (t < interval) ? 1.0f : h->tab[1][std::max(t - interval, 0)];
+    const float a_t_sq = std::sqrt(a_t), a_prev_sq = std::sqrt(a_prev);
+    *dA = a_prev - a_t;
+    *cx = 1.0f / (a_t_sq * (a_t_sq + a_prev_sq));
+    *ce = 1.0f / (a_t_sq * (std::sqrt((1.0f - a_prev) * a_t) + std::sqrt((1.0f - a_t) * a_prev)));
+}
+
+static int enqueue_plms(dsd_handle* h, int k_step, int interval, hipStream_t s) {
+    DSD_TRY(launch_inproj(h, h->xs, s));
+    int hist = 0;           // len(noise_list), capped at 3 for the formula choice
+    int head_slot = 0;      // ring slot receiving the next stored eps
+    std::vector<int> ts;
+    for (int i = 0; i < k_step; i += interval) ts.push_back(i);
+    for (int n = (int)ts.size() - 1; n >= 0; --n) {
+        const int t = ts[n];
+        const bool more = n > 0;
+        float dA, cx, ce;
+        plms_coef(h, t, interval, &dA, &cx, &ce);
+        for (int l = 0; l < h->L; ++l) DSD_TRY(launch_layer(h, l, t, nullptr, s));
+        HeadParams p = head_base(h);
+        p.dA = dA; p.cx = cx; p.ce = ce;
+        float* slot = h->ering[head_slot & 3];
+        if (hist == 0) {
+            // warm-up (:188-192): x_pred from the raw eps, second evaluation at max(t - interval, 0)
+            p.order = PLMS_RAW; p.x_base = h->xs; p.x_out = h->xtmp; p.eps_out = slot;
+            DSD_TRY(launch_head<HEAD_PLMS>(h, p, true, s));
+            const int t_prev = std::max(t - interval, 0);
+            for (int l = 0; l < h->L; ++l) DSD_TRY(launch_layer(h, l, t_prev, nullptr, s));
+            HeadParams q = head_base(h);
+            q.dA = dA; q.cx = cx; q.ce = ce;
+            q.order = PLMS_HEUN; q.x_base = h->xs; q.x_out = h->xs; q.eps_out = nullptr; q.e1 = slot;
+            DSD_TRY(launch_head<HEAD_PLMS>(h, q, more, s));
+        } else {
+            p.order = (hist == 1) ? PLMS_AB2 : (hist == 2) ? PLMS_AB3 : PLMS_AB4;
+            p.x_base = h->xs; p.x_out = h->xs; p.eps_out = slot;
+            p.e1 = h->ering[(head_slot - 1) & 3]; p.e2 = h->ering[(head_slot - 2) & 3]; p.e3 = h->ering[(head_slot - 3) & 3];
+            DSD_TRY(launch_head<HEAD_PLMS>(h, p, more, s));
+        }
+        ++head_slot;
+        hist = std::min(hist + 1, 3);
+    }
+    return DSD_OK;
+}
+
+static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k_step, int interval, hipStream_t s) {
+    const size_t bmt = (size_t)h->B * h->M * h->T;
+    HIP_TRY(hipMemcpyAsync(h->xs, x, bmt * 4, hipMemcpyDeviceToDevice, s));
+    if (kind == 0) {
+        hipLaunchKernelGGL(k_set_cell, dim3(1), dim3(1), 0, s, h->noise_cell, noise);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!h->use_graph) {
+        DSD_TRY(kind == 0 ? enqueue_ddpm(h, k_step, s) : enqueue_plms(h, k_step, interval, s));
+    } else {
+        const GraphKey key{kind, h->B, h->T, k_step, interval, layer_nb(h)};
+        auto it = h->graphs.find(key);
+        if (it == h->graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            const int rc = (kind == 0) ? enqueue_ddpm(h, k_step, h->cap_stream) : enqueue_plms(h, k_step, interval, h->cap_stream);
+            const hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+            if (rc != DSD_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(DSD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            hipGraphExec_t ge = nullptr;
+            const hipError_t e2 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e2 != hipSuccess) return fail(DSD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2));
+            if (h->graphs.size() >= 8) drop_graphs(h);
+            it = h->graphs.emplace(key, ge).first;
+        }
+        HIP_TRY(hipGraphLaunch(it->second, s));
+    }
+    HIP_TRY(hipMemcpyAsync(x, h->xs, bmt * 4, hipMemcpyDeviceToDevice, s));
+    return DSD_OK;
+}
+
+extern "C" int dsd_sample_ddpm(dsd_handle* h, float* x, const float* noise, int32_t k_step, void* stream) {
+    DSD_TRY(check_ready(h, "dsd_sample_ddpm", true));
+    if (!x || !noise) return fail(DSD_ERR_INVALID, "dsd_sample_ddpm: null argument");
+    if (k_step < 1 || k_step > h->n_sched) return fail(DSD_ERR_INVALID, "dsd_sample_ddpm: k_step=%d outside 1..%d", k_step, h->n_sched);
+    HIP_TRY(hipSetDevice(h->device));
+    DSD_TRY(build_step_table(h, h->n_sched, (hipStream_t)stream));
+    return run_loop(h, 0, x, noise, k_step, 0, (hipStream_t)stream);
+}
+
+extern "C" int dsd_p_sample(dsd_handle* h, float* x, const float* noise, int32_t t, void* stream) {
+    DSD_TRY(check_ready(h, "dsd_p_sample", true));
+    if (!x || !noise) return fail(DSD_ERR_INVALID, "dsd_p_sample: null argument");
+    if (t < 0 || t >= h->n_sched) return fail(DSD_ERR_INVALID, "dsd_p_sample: t=%d outside the %d-step schedule", t, h->n_sched);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    DSD_TRY(build_step_table(h, h->n_sched, s));
+    hipLaunchKernelGGL(k_set_cell, dim3(1), dim3(1), 0, s, h->noise_cell, noise);
+    HIP_TRY(hipGetLastError());
+    DSD_TRY(launch_inproj(h, x, s));
+    for (int l = 0; l < h->L; ++l) DSD_TRY(launch_layer(h, l, t, nullptr, s));
+    HeadParams p = head_base(h);
+    p.x_base = x; p.x_out = x; p.noise_off = 0;
+    p.sa = h->tab[6][t]; p.sb = h->tab[7][t]; p.c1 = h->tab[10][t]; p.c2 = h->tab[11][t];
+    p.sigma = (t == 0) ? 0.f : std::exp(0.5f * h->tab[9][t]);
+    return launch_head<HEAD_DDPM>(h, p, false, s);
+}
+
+extern "C" int dsd_sample_plms(dsd_handle* h, float* x, int32_t k_step, int32_t interval, void* stream) {
+    DSD_TRY(check_ready(h, "dsd_sample_plms", true));
+    if (!x) return fail(DSD_ERR_INVALID, "dsd_sample_plms: null argument");
+    if (k_step < 1 || k_step > h->n_sched) return fail(DSD_ERR_INVALID, "dsd_sample_plms: k_step=%d outside 1..%d", k_step, h->n_sched);
+    if (interval < 1) return fail(DSD_ERR_INVALID, "dsd_sample_plms: interval must be >= 1");
+    HIP_TRY(hipSetDevice(h->device));
+    DSD_TRY(build_step_table(h, h->n_sched, (hipStream_t)stream));
+    return run_loop(h, 1, x, nullptr, k_step, interval, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// measurement hook
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int dsd_time_layer_kernel(dsd_handle* h, int32_t layer, int32_t t, int32_t iters, float* avg_ms, void* stream) {
+    DSD_TRY(check_ready(h, "dsd_time_layer_kernel", false));
+    if (!avg_ms || iters < 1 || layer < 0 || layer >= h->L || t < 0) return fail(DSD_ERR_INVALID, "dsd_time_layer_kernel: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    DSD_TRY(build_step_table(h, t + 1, s));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) DSD_TRY(launch_layer(h, layer, t, nullptr, s));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) DSD_TRY(launch_layer(h, layer, t, nullptr, s));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
+    return DSD_OK;
+}

@@ -1,0 +1,654 @@
+// dsd_kernels.hpp - hand-written gfx950 (CDNA4, wave64) kernels for the DiffNet denoiser + sampler epilogues.
+//
+// What is computed, and where the reference computes it (paths relative to the reference root):
+//   k_layer       one ResidualBlock (usr/diff/net.py:66-78) for a tile of frames, fully fused:
+//                 y = x + step_proj  ->  3-tap dilated conv as ONE K=768 contraction on fp32 MFMA, accumulators
+//                 pre-loaded with the hoisted conditioner projection  ->  sigmoid*tanh gate in registers
+//                 ->  1x1 output projection on fp32 MFMA  ->  (x + res)/sqrt(2) and skip accumulation.
+//   k_condproj    conditioner_projection of every layer (net.py:68), hoisted out of the K-step loop.
+//   k_inproj      input_projection + ReLU (net.py:116-118).
+//   k_head        sum(skip)/sqrt(L) -> skip_projection + ReLU -> output_projection (net.py:126-129) with the
+//                 sampler arithmetic fused as epilogue: p_sample (usr/diff/shallow_diffusion_tts.py:134-166) or
+//                 p_sample_plms (:168-204), and optionally the NEXT evaluation's input projection.
+//   k_step_embed / k_small_gemm   SinusoidalPosEmb + MLP + per-layer diffusion_projection (net.py:37-44,
+//                 94-98, 67; Mish usr/diff/diffusion.py:68-70) tabulated for every integer t once per model.
+//   k_qsample / k_norm_spec / k_denorm_spec   shallow_diffusion_tts.py:206-211, :278-282 (+ layout change :252/:271)
+//
+// Design notes (details in DESIGN.md):
+//   * all contractions use v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fmaf chain); D[i][j]: i = output
+//     channel, j = frame.  A (weights) is pre-packed in "fragment order" so that one global_load_dwordx4 per
+//     lane (1 KiB contiguous per wave) feeds 4 consecutive MFMAs; within an 8-deep k-chunk the lane half h
+//     supplies k = 4h + s at MFMA s, for A and B alike (a consistent permutation of the reduction order).
+//   * B (activations) lives in LDS as [channel][frame] with the frame axis contiguous: lanes 0-31 read 32
+//     consecutive floats (conflict-free ds_read_b32), the dilated taps are plain column offsets into a tile
+//     with an 8-frame zero halo on each side, exactly the conv's zero padding of y = x + step (net.py:69-71).
+//   * a wave owns gate rows AND the matching filter rows, so the gate never leaves registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kC = 256;        // residual_channels == encoder_hidden on this build
+constexpr int kHalo = 8;       // max dilation supported (dilation_cycle_length <= 4)
+constexpr int kMPad = 96;      // mel bins padded to 3 MFMA row blocks
+constexpr int kThreads = 256;  // 4 waves, one per SIMD
+
+// C/D fragment map of v_mfma_f32_32x32x2_f32: lane (j = lane & 31, h = lane >> 5), register r in [0,16)
+// holds D[row = (r & 3) + 8 (r >> 2) + 4 h][col = j].
+__device__ __forceinline__ int frag_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ void set4(f32x16& v, int q, float4 x) {
+    v[4 * q + 0] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+}
+__device__ __forceinline__ float4 get4(const f32x16& v, int q) {
+    return make_float4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// One 8-deep k-chunk: 4 MFMA steps x NMB row blocks x NB frame blocks.  bp = this lane's B base for the chunk
+// (row 4h of the chunk, column j); LD = LDS row stride in floats.
+template <int NMB, int NB, int LD>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NMB][NB], const float4 (&a)[NMB], const float* bp) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float b[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = bp[s * LD + nb * 32];
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) {
+            const float av = (s == 0) ? a[mb].x : (s == 1) ? a[mb].y : (s == 2) ? a[mb].z : a[mb].w;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(av, b[nb], acc[mb][nb]);
+        }
+    }
+}
+
+// K loop over `n` chunks.  A fragments stream straight from global/L2 into VGPRs (no LDS: a wave's weight rows
+// are not shared with the other waves), register double-buffered one chunk (16*NB MFMAs, >= 1024 cycles) ahead.
+// ap: lane-adjusted pointer to chunk 0 / row block 0; ASTRIDE: float4 between consecutive chunks; row block mb
+// at + mb*64.  bof(kc): this lane's LDS B pointer for chunk kc.
+template <int NMB, int NB, int LD, int ASTRIDE, typename BOff>
+__device__ __forceinline__ void gemm_k(f32x16 (&acc)[NMB][NB], const float4* __restrict__ ap, int n, BOff bof) {
+    float4 a0[NMB], a1[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) a0[mb] = ap[mb * 64];
+    int kc = 0;
+    for (; kc + 2 <= n; kc += 2) {
+        const float4* p1 = ap + (size_t)(kc + 1) * ASTRIDE;
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) a1[mb] = p1[mb * 64];
+        mma_chunk<NMB, NB, LD>(acc, a0, bof(kc));
+        const int k2 = (kc + 2 < n) ? kc + 2 : n - 1;
+        const float4* p2 = ap + (size_t)k2 * ASTRIDE;
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) a0[mb] = p2[mb * 64];
+        mma_chunk<NMB, NB, LD>(acc, a1, bof(kc + 1));
+    }
+    if (kc < n) mma_chunk<NMB, NB, LD>(acc, a0, bof(kc));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// residual layer
+// ------------------------------------------------------------------------------------------------------------
+struct LayerParams {
+    const float* x_in;      // [B][C][TS]
+    float* x_out;           // [B][C][TS]
+    const float4* w1p;      // dilated conv, packed [w4][kc96][mb4][lane64] float4
+    const float4* w2p;      // output projection, packed [w4][kc32][mb4][lane64]
+    const float4* b2p;      // output projection bias in fragment order [w4][mb4][h2][q4]
+    const float4* cp;       // hoisted conditioner projection (+ both biases) [tile32][w4][mb4][q4][lane64]
+    float4* skip;           // running skip sum [tile32][w4][mb2][q4][lane64]
+    const float* ds;        // step-projection table for this layer: ds[t * ds_tstride + c]
+    const int* t_dev;       // per-utterance step index, or nullptr -> t_uniform
+    int t_uniform, ds_tstride;
+    int T, TS, ntile32, tiles_per_utt, dil, first;
+};
+
+template <int NB>
+constexpr int layer_lds_bytes() { return (kC * (32 * NB + 2 * kHalo) + kC * 32 * NB) * (int)sizeof(float); }
+
+template <int NB, bool LAST>
+__global__ __launch_bounds__(kThreads, (NB == 1 ? 2 : 1)) void k_layer(const LayerParams p) {
+    constexpr int LD = 32 * NB + 2 * kHalo;   // y tile row stride (floats), 16-byte multiple
+    constexpr int GLD = 32 * NB;              // gate tile row stride
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ytile = smem;
+    float* gtile = smem + kC * LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / p.tiles_per_utt, tn = blockIdx.x % p.tiles_per_utt;
+    const int t0 = tn * 32 * NB;
+    const int tile0 = b * p.ntile32 + tn * NB;
+    const int tstep = p.t_dev ? p.t_dev[b] : p.t_uniform;
+    const float* __restrict__ dsl = p.ds + (size_t)tstep * p.ds_tstride;
+
+    // 1. accumulators start from the hoisted conditioner projection (+ conv bias + cond bias)
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const bool valid = (tn * NB + nb) < p.ntile32;
+        const float4* cpl = p.cp + ((size_t)(tile0 + nb) * 4 + w) * (4 * 4 * 64) + lane;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                set4(acc[mb][nb], q, valid ? cpl[(mb * 4 + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+
+    // 2. stage y = x + step_proj (zero outside [0,T): the conv's zero padding applies to y, net.py:69-71)
+    const float* __restrict__ xrow0 = p.x_in + (size_t)b * kC * p.TS;
+#pragma unroll
+    for (int it = 0; it < 8 * NB; ++it) {
+        const int idx = it * kThreads + tid;
+        const int row = idx / (8 * NB), q = idx % (8 * NB);
+        const int t = t0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < p.TS) v = *reinterpret_cast<const float4*>(xrow0 + (size_t)row * p.TS + t);
+        const float d = dsl[row];
+        v.x = (t + 0 < p.T) ? v.x + d : 0.f;
+        v.y = (t + 1 < p.T) ? v.y + d : 0.f;
+        v.z = (t + 2 < p.T) ? v.z + d : 0.f;
+        v.w = (t + 3 < p.T) ? v.w + d : 0.f;
+        *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 4 * q) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * kThreads + tid;
+        const int row = idx >> 2, part = idx & 3;
+        const int t = (part < 2) ? t0 - kHalo + 4 * part : t0 + 32 * NB + 4 * (part - 2);
+        const int col = (part < 2) ? 4 * part : kHalo + 32 * NB + 4 * (part - 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(xrow0 + (size_t)row * p.TS + t);
+        const float d = dsl[row];
+        const bool lo = t >= 0;
+        v.x = (lo && t + 0 < p.T) ? v.x + d : 0.f;
+        v.y = (lo && t + 1 < p.T) ? v.y + d : 0.f;
+        v.z = (lo && t + 2 < p.T) ? v.z + d : 0.f;
+        v.w = (lo && t + 3 < p.T) ? v.w + d : 0.f;
+        *reinterpret_cast<float4*>(ytile + row * LD + col) = v;
+    }
+    __syncthreads();
+
+    // 3. dilated conv: K = 3 taps x 256 channels = 96 chunks; tap k reads column offset (k-1)*dil
+    {
+        const float4* ap = p.w1p + (size_t)w * (96 * 256) + lane;
+        const float* yl = ytile + 4 * h * LD + kHalo + j;
+        const int d = p.dil;
+        gemm_k<4, NB, LD, 256>(acc, ap, 96, [&](int kc) { return yl + (kc & 31) * (8 * LD) + ((kc >> 5) - 1) * d; });
+    }
+
+    // 4. gate in registers: rows [64w,64w+64) are gates, their partners (row blocks 2,3) the filters (net.py:73-74)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float g = sigmoid_f(acc[pr][nb][r]) * tanh_f(acc[pr + 2][nb][r]);
+                gtile[(64 * w + 32 * pr + frag_row(r, h)) * GLD + 32 * nb + j] = g;
+            }
+    __syncthreads();
+
+    // 5. output projection (K = 256): row blocks 0,1 = residual rows, 2,3 = skip rows.  The last layer's
+    //    residual half is dead (net.py:126 only reads the skips) and is not computed.
+    constexpr int NMB2 = LAST ? 2 : 4;
+    constexpr int MB0 = LAST ? 2 : 0;
+    f32x16 acc2[NMB2][NB];
+#pragma unroll
+    for (int m = 0; m < NMB2; ++m) {
+        const int mb = MB0 + m;
+        const float4* bl = p.b2p + ((w * 4 + mb) * 2 + h) * 4;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) set4(acc2[m][nb], q, bl[q]);
+            if (mb >= 2 && !p.first && (tn * NB + nb) < p.ntile32) {
+                const float4* sl = p.skip + (((size_t)(tile0 + nb) * 4 + w) * 2 + (mb - 2)) * (4 * 64) + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 s = sl[q * 64];
+                    acc2[m][nb][4 * q + 0] += s.x; acc2[m][nb][4 * q + 1] += s.y;
+                    acc2[m][nb][4 * q + 2] += s.z; acc2[m][nb][4 * q + 3] += s.w;
+                }
+            }
+        }
+    }
+    {
+        const float4* ap = p.w2p + (size_t)w * (32 * 256) + MB0 * 64 + lane;
+        const float* gl = gtile + 4 * h * GLD + j;
+        gemm_k<NMB2, NB, GLD, 256>(acc2, ap, 32, [&](int kc) { return gl + kc * (8 * GLD); });
+    }
+
+    // 6. epilogue: x' = (x + residual) / sqrt(2)  (net.py:78), skip sum written back in fragment order
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        if ((tn * NB + nb) >= p.ntile32) continue;
+        if (!LAST) {
+            float* __restrict__ xo = p.x_out + (size_t)b * kC * p.TS + t0 + 32 * nb + j;
+            const float* __restrict__ xi = xrow0 + t0 + 32 * nb + j;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const size_t off = (size_t)(64 * w + 32 * mb + frag_row(r, h)) * p.TS;
+                    xo[off] = __fdiv_rn(xi[off] + acc2[mb][nb][r], 1.41421354f);
+                }
+        }
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            float4* sl = p.skip + (((size_t)(tile0 + nb) * 4 + w) * 2 + ms) * (4 * 64) + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sl[q * 64] = get4(acc2[(LAST ? 0 : 2) + ms][nb], q);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// hoisted conditioner projection: cp[l] = Wc_l * cond + bc_l + bd_l, written in accumulator-fragment order
+// ------------------------------------------------------------------------------------------------------------
+struct CondProjParams {
+    const float* condT;     // [B][H=256][TS], zero for t >= T
+    const float4* wcp;      // [L][w4][kc32][mb4][lane64]
+    const float4* b1p;      // [L][w4][mb4][h2][q4]  (dilated_conv.bias + conditioner_projection.bias)
+    float4* cp;             // [L][ntiles][w4][mb4][q4][lane64]
+    int TS, ntile32, ntiles_total;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void k_condproj(const CondProjParams p) {
+    constexpr int LD = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, l = blockIdx.y;
+    const int b = tile / p.ntile32, t0 = (tile % p.ntile32) * 32;
+    const float* src = p.condT + (size_t)b * kC * p.TS + t0;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * kThreads + tid, row = idx >> 3, q = idx & 7;
+        *reinterpret_cast<float4*>(smem + row * LD + 4 * q) =
+            *reinterpret_cast<const float4*>(src + (size_t)row * p.TS + 4 * q);
+    }
+    f32x16 acc[4][1];
+    const float4* bl = p.b1p + (((size_t)l * 4 + w) * 4) * 8 + h * 4;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) set4(acc[mb][0], q, bl[mb * 8 + q]);
+    __syncthreads();
+    const float4* ap = p.wcp + ((size_t)l * 4 + w) * (32 * 256) + lane;
+    const float* cl = smem + 4 * h * LD + j;
+    gemm_k<4, 1, LD, 256>(acc, ap, 32, [&](int kc) { return cl + kc * (8 * LD); });
+    float4* out = p.cp + (((size_t)l * p.ntiles_total + tile) * 4 + w) * (4 * 4 * 64) + lane;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[(mb * 4 + q) * 64] = get4(acc[mb][0], q);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// input projection + ReLU on a [kMPad][32] tile held in LDS (rows >= M are zero)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inproj_tile(const float* ptile, const float4* __restrict__ winp,
+                                            const float4* __restrict__ binp, int nk, float* __restrict__ xo_utt,
+                                            int TS, int t0, int w, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) set4(acc[mb][0], q, binp[((w * 2 + mb) * 2 + h) * 4 + q]);
+    const float4* ap = winp + (size_t)w * nk * 128 + lane;
+    const float* pl = ptile + 4 * h * 32 + j;
+    gemm_k<2, 1, 32, 128>(acc, ap, nk, [&](int kc) { return pl + kc * (8 * 32); });
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            xo_utt[(size_t)(64 * w + 32 * mb + frag_row(r, h)) * TS + t0 + j] = fmaxf(acc[mb][0][r], 0.f);
+}
+
+struct InProjParams {
+    const float* spec;      // [B][M][T]
+    float* x_out;           // [B][C][TS]
+    const float4* winp;     // [w4][nk][mb2][lane64]
+    const float4* binp;     // [w4][mb2][h2][q4]
+    int nk, M, T, TS, ntile32;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void k_inproj(const InProjParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / p.ntile32, t0 = (blockIdx.x % p.ntile32) * 32;
+    for (int idx = tid; idx < kMPad * 32; idx += kThreads) {
+        const int m = idx >> 5, t = t0 + (idx & 31);
+        smem[idx] = (m < p.M && t < p.T) ? p.spec[((size_t)b * p.M + m) * p.T + t] : 0.f;
+    }
+    __syncthreads();
+    inproj_tile(smem, p.winp, p.binp, p.nk, p.x_out + (size_t)b * kC * p.TS, p.TS, t0, w, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// head: skip reduction scale -> skip_projection + ReLU -> output_projection -> sampler epilogue (-> next in-proj)
+// ------------------------------------------------------------------------------------------------------------
+enum HeadMode { HEAD_EPS = 0, HEAD_DDPM = 1, HEAD_PLMS = 2 };
+enum PlmsOrder { PLMS_RAW = 0, PLMS_HEUN = 1, PLMS_AB2 = 2, PLMS_AB3 = 3, PLMS_AB4 = 4 };
+
+struct HeadParams {
+    const float4* skip;         // [tile32][w4][mb2][q4][lane64]
+    const float4* wsp;          // skip_projection packed [w4][kc32][mb2][lane64]
+    const float4* bsp;          // [w4][mb2][h2][q4]
+    const float4* woutp;        // final projection packed [kc32][mb3][lane64]
+    const float4* boutp;        // [mb3][h2][q4]
+    const float4* winp;         // input projection (fused next-eval in-proj)
+    const float4* binp;
+    float* x_next;              // [B][C][TS] (fused in-proj output)
+    float sqrt_L;
+    int nk_in, M, T, TS, ntile32;
+    // mode-specific tensors, all [B][M][T]
+    float* eps_out;             // HEAD_EPS: eps;  HEAD_PLMS: where to store this evaluation's eps (nullable)
+    const float* x_base;        // DDPM / PLMS: x_t the update is applied to
+    float* x_out;               // DDPM / PLMS: result (may alias x_base)
+    const float* const* noise_cell;   // DDPM: *noise_cell + noise_off = this step's N(0,1) draw
+    size_t noise_off;
+    const float* e1; const float* e2; const float* e3;   // PLMS history (most recent first)
+    // per-step scalars (fp32, computed on the host from the fp32 tables exactly like the reference's
+    // [B,1,1,1] tensor arithmetic)
+    float sa, sb, c1, c2, sigma;    // DDPM: sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, [t != 0] * exp(0.5 logvar)
+    float dA, cx, ce;               // PLMS get_x_pred: (a_prev - a_t), 1/(..), 1/(..)
+    int order;
+};
+
+template <int MODE, bool FUSE_INPROJ>
+__global__ __launch_bounds__(kThreads, 2) void k_head(const HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* stile = smem;                    // [256][32] scaled skip sum
+    float* htile = smem + kC * 32;          // [256][32] relu(skip_projection)
+    float* ptile = smem + 2 * kC * 32;      // [96][32]  next x (fused in-proj)
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int b = tile / p.ntile32, t0 = (tile % p.ntile32) * 32;
+
+    // x = sum(skip) / sqrt(L)   (net.py:126)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const float4* sl = p.skip + (((size_t)tile * 4 + w) * 2 + ms) * (4 * 64) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 s = sl[q * 64];
+            const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                stile[(64 * w + 32 * ms + frag_row(4 * q + e, h)) * 32 + j] = __fdiv_rn(v[e], p.sqrt_L);
+        }
+    }
+    __syncthreads();
+    // skip_projection + ReLU (net.py:127-128)
+    {
+        f32x16 acc[2][1];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) set4(acc[mb][0], q, p.bsp[((w * 2 + mb) * 2 + h) * 4 + q]);
+        const float4* ap = p.wsp + (size_t)w * (32 * 128) + lane;
+        const float* sl = stile + 4 * h * 32 + j;
+        gemm_k<2, 1, 32, 128>(acc, ap, 32, [&](int kc) { return sl + kc * (8 * 32); });
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                htile[(64 * w + 32 * mb + frag_row(r, h)) * 32 + j] = fmaxf(acc[mb][0][r], 0.f);
+    }
+    __syncthreads();
+    // output_projection (net.py:129): 96 padded rows on waves 0..2, then the sampler arithmetic on eps
+    if (w < 3) {
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) set4(acc[0][0], q, p.boutp[(w * 2 + h) * 4 + q]);
+        const float4* ap = p.woutp + (size_t)w * 64 + lane;
+        const float* hl = htile + 4 * h * 32 + j;
+        gemm_k<1, 1, 32, 192>(acc, ap, 32, [&](int kc) { return hl + kc * (8 * 32); });
+        const int t = t0 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * w + frag_row(r, h);
+            const bool ok = (m < p.M) && (t < p.T);
+            const size_t idx = ((size_t)b * p.M + m) * p.T + t;
+            const float eps = acc[0][0][r];
+            float xn = 0.f;
+            if (ok) {
+                if (MODE == HEAD_EPS) {
+                    p.eps_out[idx] = eps;
+                } else if (MODE == HEAD_DDPM) {
+                    // p_mean_variance + p_sample (shallow_diffusion_tts.py:134-166); no FMA contraction, the
+                    // reference rounds every product
+                    const float x = p.x_base[idx];
+                    const float z = (*p.noise_cell)[p.noise_off + idx];
+                    float x0 = __fsub_rn(__fmul_rn(p.sa, x), __fmul_rn(p.sb, eps));
+                    x0 = fminf(fmaxf(x0, -1.f), 1.f);
+                    const float mean = __fadd_rn(__fmul_rn(p.c1, x0), __fmul_rn(p.c2, x));
+                    xn = __fadd_rn(mean, __fmul_rn(p.sigma, z));
+                    p.x_out[idx] = xn;
+                } else {
+                    // p_sample_plms (shallow_diffusion_tts.py:168-204)
+                    float ep;
+                    if (p.order == PLMS_RAW) {
+                        ep = eps;
+                    } else if (p.order == PLMS_HEUN) {
+                        ep = __fmul_rn(__fadd_rn(p.e1[idx], eps), 0.5f);                 // (first + prev) / 2
+                    } else if (p.order == PLMS_AB2) {
+                        ep = __fmul_rn(__fsub_rn(__fmul_rn(3.f, eps), p.e1[idx]), 0.5f);
+                    } else if (p.order == PLMS_AB3) {
+                        ep = __fdiv_rn(__fadd_rn(__fsub_rn(__fmul_rn(23.f, eps), __fmul_rn(16.f, p.e1[idx])),
+                                                 __fmul_rn(5.f, p.e2[idx])), 12.f);
+                    } else {
+                        ep = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(55.f, eps), __fmul_rn(59.f, p.e1[idx])),
+                                                           __fmul_rn(37.f, p.e2[idx])), __fmul_rn(9.f, p.e3[idx])), 24.f);
+                    }
+                    if (p.eps_out) p.eps_out[idx] = eps;
+                    const float x = p.x_base[idx];
+                    const float delta = __fmul_rn(p.dA, __fsub_rn(__fmul_rn(p.cx, x), __fmul_rn(p.ce, ep)));
+                    xn = __fadd_rn(x, delta);
+                    p.x_out[idx] = xn;
+                }
+            }
+            if (FUSE_INPROJ) ptile[m * 32 + j] = ok ? xn : 0.f;
+        }
+    }
+    if (FUSE_INPROJ) {
+        __syncthreads();
+        inproj_tile(ptile, p.winp, p.binp, p.nk_in, p.x_next + (size_t)b * kC * p.TS, p.TS, t0, w, lane);
+    }
+}
+constexpr int kHeadLdsBytes = (2 * kC * 32 + kMPad * 32) * (int)sizeof(float);
+
+// ------------------------------------------------------------------------------------------------------------
+// weight packing (torch layouts -> fragment order).  One thread per packed float.
+// ------------------------------------------------------------------------------------------------------------
+// Generic A-operand pack: dst[(w, kc, mb, lane, s)] = src[row(w,mb,lane) * row_stride + col(kc,lane,s) * col_stride + tap]
+// rows: split == 1: mb < nmb/2 -> base_lo + (nmb/2*32)*w + 32*mb + i ; else base_hi + (nmb/2*32)*w + 32*(mb-nmb/2) + i
+//       split == 0: rows_per_wave*w + 32*mb + i
+struct PackParams {
+    const float* src; float* dst;
+    int nw, nkc, nmb;            // destination dims [nw][ntap*nkc][nmb][64][4]
+    int ntap;                    // taps (dilated conv: 3, else 1); kc_total = ntap * nkc
+    int split, hi_base;          // gate/filter or residual/skip split (hi rows start at hi_base)
+    int rows_valid, cols_valid;  // zero outside (padding)
+    int row_stride, col_stride;  // in floats: src[(row * row_stride) + col * col_stride + tap]
+};
+
+__global__ void k_pack_a(const PackParams p) {
+    const size_t n = (size_t)p.nw * p.ntap * p.nkc * p.nmb * 256;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int s = idx & 3, lane = (idx >> 2) & 63;
+        size_t r = idx >> 8;
+        const int mb = r % p.nmb; r /= p.nmb;
+        const int kct = r % (p.ntap * p.nkc); r /= (p.ntap * p.nkc);
+        const int w = (int)r;
+        const int tap = kct / p.nkc, kc = kct % p.nkc;
+        const int i = lane & 31, h = lane >> 5;
+        int row;
+        if (p.split) {
+            const int half = p.nmb / 2;
+            row = (mb < half) ? (half * 32) * w + 32 * mb + i : p.hi_base + (half * 32) * w + 32 * (mb - half) + i;
+        } else {
+            row = (p.nmb * 32) * w + 32 * mb + i;
+        }
+        const int col = 8 * kc + 4 * h + s;
+        float v = 0.f;
+        if (row < p.rows_valid && col < p.cols_valid) v = p.src[(size_t)row * p.row_stride + (size_t)col * p.col_stride + tap];
+        p.dst[idx] = v;
+    }
+}
+
+// Bias pack into accumulator-fragment order: dst[(w, mb, h, r)] = a[row] (+ b[row]); row mapping as above.
+struct PackBiasParams {
+    const float* a; const float* b; float* dst;
+    int nw, nmb, split, hi_base, rows_valid;
+};
+
+__global__ void k_pack_bias(const PackBiasParams p) {
+    const int n = p.nw * p.nmb * 2 * 16;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const int r = idx & 15, h = (idx >> 4) & 1;
+        int q = idx >> 5;
+        const int mb = q % p.nmb, w = q / p.nmb;
+        const int i = frag_row(r, h);
+        int row;
+        if (p.split) {
+            const int half = p.nmb / 2;
+            row = (mb < half) ? (half * 32) * w + 32 * mb + i : p.hi_base + (half * 32) * w + 32 * (mb - half) + i;
+        } else {
+            row = (p.nmb * 32) * w + 32 * mb + i;
+        }
+        float v = 0.f;
+        if (row < p.rows_valid) { v = p.a[row]; if (p.b) v += p.b[row]; }
+        p.dst[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// step-embedding table
+// ------------------------------------------------------------------------------------------------------------
+// E[k][n]: sinusoidal embedding of integer step n (net.py:37-44), stored [dim][N] (N contiguous)
+__global__ void k_step_embed(float* E, int dim, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (n >= N) return;
+    const int half = dim / 2;
+    const float scale = (float)(-(9.210340371976184 /* ln 1e4 */) / (double)(half - 1));
+    const int kk = (k < half) ? k : k - half;
+    const float f = expf((float)kk * scale);
+    const float arg = (float)n * f;
+    E[(size_t)k * N + n] = (k < half) ? sinf(arg) : cosf(arg);
+}
+
+// Y[m][n] = act(sum_k W[m][k] X[k][n] + bias[m]); X, Y with n contiguous unless out strides say otherwise.
+// act: 0 none, 1 Mish (x * tanh(softplus(x)), softplus threshold 20 as torch's default)
+__global__ void k_small_gemm(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ X,
+                             float* __restrict__ Y, int M, int K, int N, int act, size_t out_stride_m, size_t out_stride_n) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    const float* wr = W + (size_t)m * K;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(wr[k], X[(size_t)k * N + n], acc);
+    acc += bias[m];
+    if (act == 1) {
+        const float sp = (acc > 20.f) ? acc : log1pf(expf(acc));
+        acc = acc * tanhf(sp);
+    }
+    Y[(size_t)m * out_stride_m + (size_t)n * out_stride_n] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// layout / elementwise helpers
+// ------------------------------------------------------------------------------------------------------------
+// cond [B][H][T] with arbitrary element strides -> condT [B][H][TS] (frame axis contiguous, zero for t >= T)
+__global__ void k_cond_layout(const float* __restrict__ cond, float* __restrict__ out, int H, int T, int TS,
+                              int64_t sb, int64_t sh, int64_t st) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, h0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;     // 32 x 8
+    const float* src = cond + (size_t)b * sb;
+    if (st == 1 || sh != 1) {
+        // frame axis already fastest (or generic): read with tx along t
+        for (int k = ty; k < 32; k += 8) {
+            const int hh = h0 + k, t = t0 + tx;
+            tile[k][tx] = (hh < H && t < T) ? src[(int64_t)hh * sh + (int64_t)t * st] : 0.f;
+        }
+    } else {
+        // channel axis fastest (the reference's transposed view of [B,T,H]): read with tx along h, transpose in LDS
+        for (int k = ty; k < 32; k += 8) {
+            const int t = t0 + k, hh = h0 + tx;
+            tile[tx][k] = (hh < H && t < T) ? src[(int64_t)hh * sh + (int64_t)t * st] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int hh = h0 + k, t = t0 + tx;
+        if (hh < H && t < TS) out[((size_t)b * H + hh) * TS + t] = tile[k][tx];
+    }
+}
+
+// q_sample (shallow_diffusion_tts.py:206-211): out = a * x0 + b * z
+__global__ void k_qsample(const float* __restrict__ x0, const float* __restrict__ z, float* __restrict__ out,
+                          float a, float b, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = __fadd_rn(__fmul_rn(a, x0[i]), __fmul_rn(b, z[i]));
+}
+
+// norm_spec + transpose: mel [B][T][M] -> x [B][M][T]   ((x - min) / (max - min) * 2 - 1, :278-279)
+__global__ void k_norm_spec(const float* __restrict__ mel, float* __restrict__ x, const float* __restrict__ smin,
+                            const float* __restrict__ smax, int M, int T) {
+    extern __shared__ float tile[];                 // [32][M+1]
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int nt = min(32, T - t0);
+    const float* src = mel + ((size_t)b * T + t0) * M;
+    for (int i = threadIdx.x; i < nt * M; i += blockDim.x) {
+        const int tt = i / M, m = i % M;
+        const float lo = smin[m], hi = smax[m];
+        const float v = __fsub_rn(__fmul_rn(__fdiv_rn(__fsub_rn(src[i], lo), __fsub_rn(hi, lo)), 2.f), 1.f);
+        tile[tt * (M + 1) + m] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * 32; i += blockDim.x) {
+        const int m = i >> 5, tt = i & 31;
+        if (tt < nt) x[((size_t)b * M + m) * T + t0 + tt] = tile[tt * (M + 1) + m];
+    }
+}
+
+// denorm_spec + transpose: x [B][M][T] -> mel [B][T][M]   ((x + 1) / 2 * (max - min) + min, :281-282; * mask :273)
+__global__ void k_denorm_spec(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ mel,
+                              const float* __restrict__ smin, const float* __restrict__ smax, int M, int T) {
+    extern __shared__ float tile[];                 // [32][M+1]
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int nt = min(32, T - t0);
+    for (int i = threadIdx.x; i < M * 32; i += blockDim.x) {
+        const int m = i >> 5, tt = i & 31;
+        if (tt < nt) tile[tt * (M + 1) + m] = x[((size_t)b * M + m) * T + t0 + tt];
+    }
+    __syncthreads();
+    float* dst = mel + ((size_t)b * T + t0) * M;
+    for (int i = threadIdx.x; i < nt * M; i += blockDim.x) {
+        const int tt = i / M, m = i % M;
+        const float lo = smin[m], hi = smax[m];
+        float v = __fadd_rn(__fmul_rn(__fmul_rn(__fadd_rn(tile[tt * (M + 1) + m], 1.f), 0.5f), __fsub_rn(hi, lo)), lo);
+        if (mask) v = __fmul_rn(v, mask[(size_t)b * T + t0 + tt]);
+        dst[i] = v;
+    }
+}
+
+__global__ void k_set_cell(const float** cell, const float* value) { *cell = value; }
+
+}  // namespace dsd

@@ -1,0 +1,220 @@
+"""DenoiserEngine: thin owner of one `dsd_handle` (include/dsd.h).  torch is plumbing only: it provides the
+device tensors whose raw pointers, sizes and strides cross the C ABI, and the current HIP stream."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+STATE_KEYS_GLOBAL = ['input_projection', 'mlp.0', 'mlp.2', 'skip_projection', 'output_projection']
+STATE_KEYS_LAYER = ['dilated_conv', 'diffusion_projection', 'conditioner_projection', 'output_projection']
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class DenoiserEngine:
+    """Owns the packed weights, tables, workspace and cached hipGraphs for ONE device.
+
+    Mirrors the reference objects it stands behind: `DiffNet` parameters (usr/diff/net.py:91-105), the
+    `GaussianDiffusion` schedule buffers (usr/diff/shallow_diffusion_tts.py:103-126) and the inference loop
+    (:248-276)."""
+
+    def __init__(self, mel_bins: int, residual_channels: int, encoder_hidden: int, residual_layers: int,
+                 dilation_cycle_length: int, device):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('DenoiserEngine needs a HIP device (torch device type "cuda"); there is no CPU path')
+        self.M, self.L = mel_bins, residual_layers
+        cfg = _lib.DsdConfig(mel_bins, residual_channels, encoder_hidden, residual_layers, dilation_cycle_length)
+        h = C.c_void_p()
+        _lib.check(self.lib.dsd_create(C.byref(cfg), self.device.index or 0, C.byref(h)), 'dsd_create')
+        self._h = h
+        self.prepared_shape = None
+        self.n_sched = 0
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.dsd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights / tables ---------------------------------------------------------------------------------
+    def load_weights(self, state: Dict[str, torch.Tensor]):
+        """state: DiffNet state_dict (keys as in the reference, optionally already on the device)."""
+        L = self.L
+        keep = []
+
+        def dev(name):
+            t = state[name].detach().to(device=self.device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        w = _lib.DsdWeights()
+        w.input_projection_w, w.input_projection_b = dev('input_projection.weight'), dev('input_projection.bias')
+        w.mlp0_w, w.mlp0_b = dev('mlp.0.weight'), dev('mlp.0.bias')
+        w.mlp2_w, w.mlp2_b = dev('mlp.2.weight'), dev('mlp.2.bias')
+        arrays = []
+        for field, key in [('dilated_conv', 'dilated_conv'), ('diffusion_projection', 'diffusion_projection'),
+                           ('conditioner_projection', 'conditioner_projection'), ('output_projection', 'output_projection')]:
+            for suffix, part in (('_w', 'weight'), ('_b', 'bias')):
+                arr = (C.c_void_p * L)(*[dev(f'residual_layers.{l}.{key}.{part}') for l in range(L)])
+                arrays.append(arr)
+                setattr(w, field + suffix, C.cast(arr, C.POINTER(C.c_void_p)))
+        w.skip_projection_w, w.skip_projection_b = dev('skip_projection.weight'), dev('skip_projection.bias')
+        w.final_projection_w, w.final_projection_b = dev('output_projection.weight'), dev('output_projection.bias')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_load_weights(self._h, C.byref(w), _stream_ptr(self.device)), 'dsd_load_weights')
+            torch.cuda.current_stream(self.device).synchronize()    # sources may be freed after this
+        self.prepared_shape = None
+
+    def set_schedule(self, betas: np.ndarray):
+        b = np.ascontiguousarray(np.asarray(betas, dtype=np.float64))
+        _lib.check(self.lib.dsd_set_schedule(self._h, b.ctypes.data_as(C.POINTER(C.c_double)), len(b)), 'dsd_set_schedule')
+        self.n_sched = len(b)
+
+    def schedule_table(self, which: int) -> np.ndarray:
+        out = np.empty(self.n_sched, dtype=np.float32)
+        _lib.check(self.lib.dsd_get_schedule_table(self._h, which, out.ctypes.data_as(C.POINTER(C.c_float)), self.n_sched))
+        return out
+
+    def set_spec_range(self, spec_min: Sequence[float], spec_max: Sequence[float]):
+        lo = np.ascontiguousarray(np.asarray(spec_min, dtype=np.float32).reshape(-1))
+        hi = np.ascontiguousarray(np.asarray(spec_max, dtype=np.float32).reshape(-1))
+        if len(lo) != self.M or len(hi) != self.M:
+            raise ValueError(f'spec_min/spec_max must have {self.M} entries')
+        fp = C.POINTER(C.c_float)
+        _lib.check(self.lib.dsd_set_spec_range(self._h, lo.ctypes.data_as(fp), hi.ctypes.data_as(fp)), 'dsd_set_spec_range')
+
+    def set_use_graph(self, enable: bool):
+        _lib.check(self.lib.dsd_set_use_graph(self._h, int(bool(enable))))
+
+    def set_layer_tile(self, frames: int):
+        _lib.check(self.lib.dsd_set_layer_tile(self._h, int(frames)))
+
+    def layer_tile(self) -> int:
+        return self.lib.dsd_get_layer_tile(self._h)
+
+    def device_bytes(self) -> int:
+        return self.lib.dsd_device_bytes(self._h)
+
+    # -- batch ----------------------------------------------------------------------------------------------
+    def prepare(self, cond: torch.Tensor):
+        """cond [B,H,T] fp32 on the device, any strides (the reference passes a transposed view)."""
+        if cond.dim() != 3 or cond.dtype != torch.float32 or cond.device != self.device:
+            raise ValueError('cond must be a [B,H,T] fp32 tensor on the engine device')
+        B, H, T = cond.shape
+        sb, sh, st = cond.stride()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_prepare(self._h, B, T, cond.data_ptr(), sb, sh, st, _stream_ptr(self.device)), 'dsd_prepare')
+        self.prepared_shape = (B, T)
+
+    def _spec(self, x: torch.Tensor, name='x') -> torch.Tensor:
+        if self.prepared_shape is None:
+            raise RuntimeError('no batch prepared: call prepare(cond) first')
+        B, T = self.prepared_shape
+        if x.dim() == 4:
+            if x.shape[1] != 1:
+                raise ValueError(f'{name}: expected [B,1,M,T]')
+            x = x[:, 0]
+        if tuple(x.shape) != (B, self.M, T) or x.dtype != torch.float32 or x.device != self.device:
+            raise ValueError(f'{name}: expected fp32 [{B},{self.M},{T}] on {self.device}, got {tuple(x.shape)} {x.dtype} {x.device}')
+        return x
+
+    def denoise(self, x: torch.Tensor, t, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """eps_hat = DiffNet(x, t, cond) for the prepared cond.  x [B,M,T] or [B,1,M,T]; t: int or [B] ints."""
+        xs = self._spec(x).contiguous()
+        B = xs.shape[0]
+        if isinstance(t, torch.Tensor):
+            t = t.detach().cpu().reshape(-1).tolist()
+        if isinstance(t, int):
+            t = [t] * B
+        if len(t) != B:
+            raise ValueError('t must have one entry per utterance')
+        tarr = (C.c_int32 * B)(*[int(v) for v in t])
+        eps = out if out is not None else torch.empty_like(xs)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_denoise(self._h, xs.data_ptr(), tarr, eps.data_ptr(), _stream_ptr(self.device)), 'dsd_denoise')
+        return eps
+
+    def q_sample(self, x_start: torch.Tensor, noise: torch.Tensor, t: int) -> torch.Tensor:
+        xs, z = self._spec(x_start, 'x_start').contiguous(), self._spec(noise, 'noise').contiguous()
+        out = torch.empty_like(xs)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_q_sample(self._h, xs.data_ptr(), z.data_ptr(), int(t), out.data_ptr(), _stream_ptr(self.device)), 'dsd_q_sample')
+        return out
+
+    def sample_ddpm(self, x: torch.Tensor, noise: torch.Tensor, k_step: int) -> torch.Tensor:
+        """In place: x [B,M,T] contiguous goes from x_{k_step} to x_0.  noise [k_step,B,M,T] (or [k,B,1,M,T])."""
+        xs = self._spec(x)
+        if not xs.is_contiguous():
+            raise ValueError('x must be contiguous (it is updated in place)')
+        B, T = self.prepared_shape
+        if noise.dim() == 5:
+            noise = noise[:, :, 0]
+        if tuple(noise.shape) != (k_step, B, self.M, T) or not noise.is_contiguous() or noise.dtype != torch.float32 \
+                or noise.device != self.device:
+            raise ValueError(f'noise must be contiguous fp32 [{k_step},{B},{self.M},{T}] on {self.device}')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_sample_ddpm(self._h, xs.data_ptr(), noise.data_ptr(), int(k_step), _stream_ptr(self.device)), 'dsd_sample_ddpm')
+        return x
+
+    def p_sample(self, x: torch.Tensor, noise: torch.Tensor, t: int) -> torch.Tensor:
+        xs, z = self._spec(x), self._spec(noise, 'noise').contiguous()
+        if not xs.is_contiguous():
+            raise ValueError('x must be contiguous (it is updated in place)')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_p_sample(self._h, xs.data_ptr(), z.data_ptr(), int(t), _stream_ptr(self.device)), 'dsd_p_sample')
+        return x
+
+    def sample_plms(self, x: torch.Tensor, k_step: int, interval: int) -> torch.Tensor:
+        xs = self._spec(x)
+        if not xs.is_contiguous():
+            raise ValueError('x must be contiguous (it is updated in place)')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_sample_plms(self._h, xs.data_ptr(), int(k_step), int(interval), _stream_ptr(self.device)), 'dsd_sample_plms')
+        return x
+
+    def norm_spec(self, mel: torch.Tensor) -> torch.Tensor:
+        """mel [B,T,M] -> normalised x [B,M,T]."""
+        B, T = self.prepared_shape
+        mel = mel.contiguous()
+        if tuple(mel.shape) != (B, T, self.M) or mel.dtype != torch.float32 or mel.device != self.device:
+            raise ValueError(f'mel must be fp32 [{B},{T},{self.M}] on {self.device}')
+        out = torch.empty(B, self.M, T, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_norm_spec(self._h, mel.data_ptr(), out.data_ptr(), _stream_ptr(self.device)), 'dsd_norm_spec')
+        return out
+
+    def denorm_spec(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [B,M,T] -> de-normalised mel [B,T,M] (times mask [B,T] if given)."""
+        xs = self._spec(x).contiguous()
+        B, T = self.prepared_shape
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.float32).contiguous()
+            if tuple(mask.shape) != (B, T):
+                raise ValueError('mask must be [B,T]')
+            mptr = mask.data_ptr()
+        out = torch.empty(B, T, self.M, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_denorm_spec(self._h, xs.data_ptr(), mptr, out.data_ptr(), _stream_ptr(self.device)), 'dsd_denorm_spec')
+        return out
+
+    def time_layer_kernel(self, layer: int, t: int, iters: int) -> float:
+        """Average device milliseconds of one residual-layer kernel launch (HIP events on the launch stream)."""
+        ms = C.c_float(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_time_layer_kernel(self._h, layer, t, iters, C.byref(ms), _stream_ptr(self.device)), 'dsd_time_layer_kernel')
+        return float(ms.value)

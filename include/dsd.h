@@ -1,0 +1,147 @@
+/* dsd.h - C ABI of libdsdenoise.so: the DiffSinger/DiffSpeech diffusion-denoiser hot path on MI355X (gfx950).
+ *
+ * The reference (MoonInTheRiver/DiffSinger) is pure Python/PyTorch and has no FFI of its own; this is the
+ * boundary its hot path would bind if it had one.  Every entry point names the reference code it replaces
+ * (paths relative to the reference root).  Plain pointers and sizes only - no torch types.
+ *
+ * Conventions
+ *   - all tensors fp32, row-major contiguous unless strides are given; device pointers unless marked HOST
+ *   - "spec" tensors are [B][M][T] (the reference's [B,1,M,T] with the unit dim dropped), T innermost
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only ENQUEUES work
+ *     on it, there are no hidden device synchronisations; results are ordered like any other stream work
+ *   - return 0 on success, a negative dsd_status otherwise; dsd_last_error() gives the message (thread-local)
+ *   - ownership: the caller owns every tensor it passes; the handle owns only its packed weights, tables,
+ *     workspace and cached hipGraphs, all released by dsd_destroy()
+ *   - threading: one handle = one device = one caller at a time (not re-entrant); different handles are
+ *     independent (one per DP thread / DDP process: utils/pl_utils.py:81-164, :570)
+ */
+#ifndef DSD_H
+#define DSD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSD_ABI_VERSION 1
+
+typedef struct dsd_handle dsd_handle;
+
+typedef enum dsd_status {
+    DSD_OK = 0,
+    DSD_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    DSD_ERR_HIP = -2,          /* a HIP runtime call failed */
+    DSD_ERR_STATE = -3,        /* call order violated (weights / schedule / prepare missing) */
+    DSD_ERR_NOMEM = -4
+} dsd_status;
+
+/* The hparams DiffNet reads at construction (usr/diff/net.py:85-90) + audio_num_mel_bins (:82). */
+typedef struct dsd_config {
+    int32_t mel_bins;               /* M, <= 96                                  */
+    int32_t residual_channels;      /* C, must be 256 on this build              */
+    int32_t encoder_hidden;         /* H (cond width), must be 256 on this build */
+    int32_t residual_layers;        /* L, 1..64                                  */
+    int32_t dilation_cycle_length;  /* dilation of layer l = 2^(l % cycle), must stay <= 8 */
+} dsd_config;
+
+/* Device pointers to the DiffNet parameters in torch state_dict layout (usr/diff/net.py:91-105):
+ * conv weights [out][in][k], linear weights [out][in].  Per-layer arrays are HOST arrays of L device pointers. */
+typedef struct dsd_weights {
+    const float* input_projection_w;            /* [C][M][1]  */
+    const float* input_projection_b;            /* [C]        */
+    const float* mlp0_w;                        /* [4C][C]    */
+    const float* mlp0_b;                        /* [4C]       */
+    const float* mlp2_w;                        /* [C][4C]    */
+    const float* mlp2_b;                        /* [C]        */
+    const float* const* dilated_conv_w;         /* L x [2C][C][3] */
+    const float* const* dilated_conv_b;         /* L x [2C]       */
+    const float* const* diffusion_projection_w; /* L x [C][C]     */
+    const float* const* diffusion_projection_b; /* L x [C]        */
+    const float* const* conditioner_projection_w; /* L x [2C][H][1] */
+    const float* const* conditioner_projection_b; /* L x [2C]       */
+    const float* const* output_projection_w;    /* L x [2C][C][1] */
+    const float* const* output_projection_b;    /* L x [2C]       */
+    const float* skip_projection_w;             /* [C][C][1]  */
+    const float* skip_projection_b;             /* [C]        */
+    const float* final_projection_w;            /* [M][C][1]  (DiffNet.output_projection) */
+    const float* final_projection_b;            /* [M]        */
+} dsd_weights;
+
+int dsd_abi_version(void);
+const char* dsd_last_error(void);
+
+/* DiffNet.__init__ (usr/diff/net.py:82-105): validates the configuration and binds the handle to `device`. */
+int dsd_create(const dsd_config* cfg, int device, dsd_handle** out);
+void dsd_destroy(dsd_handle* h);
+
+/* Replaces nn.Module parameter ownership / load_state_dict (utils/__init__.py:178-209): repacks the torch
+ * tensors into MFMA-fragment order in handle-owned memory; the source tensors are not referenced afterwards. */
+int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* stream);
+
+/* GaussianDiffusion.__init__ schedule tables (usr/diff/shallow_diffusion_tts.py:87-123): float64 on the host,
+ * cast to fp32 exactly like the reference's register_buffer calls.  betas: HOST array of n doubles. */
+int dsd_set_schedule(dsd_handle* h, const double* betas, int32_t n);
+/* Copies one of the twelve fp32 tables back (HOST out[n]) for state_dict/buffer parity checks; `which` in
+ * registration order: 0 betas, 1 alphas_cumprod, 2 alphas_cumprod_prev, 3 sqrt_alphas_cumprod,
+ * 4 sqrt_one_minus_alphas_cumprod, 5 log_one_minus_alphas_cumprod, 6 sqrt_recip_alphas_cumprod,
+ * 7 sqrt_recipm1_alphas_cumprod, 8 posterior_variance, 9 posterior_log_variance_clipped,
+ * 10 posterior_mean_coef1, 11 posterior_mean_coef2. */
+int dsd_get_schedule_table(dsd_handle* h, int32_t which, float* out, int32_t n);
+
+/* spec_min / spec_max buffers (shallow_diffusion_tts.py:125-126): HOST arrays of M floats. */
+int dsd_set_spec_range(dsd_handle* h, const float* spec_min, const float* spec_max);
+
+/* Binds a batch: sizes the workspace for B utterances of T frames and evaluates every layer's
+ * conditioner_projection (usr/diff/net.py:68) ONCE - it does not depend on x or t, so it is hoisted out of
+ * the K-step loop.  cond is [B][H][T] addressed with element strides (the reference passes a transposed view
+ * of [B,T,H], shallow_diffusion_tts.py:238 -> strides (T*H, 1, H)).  cond is not referenced afterwards. */
+int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* cond,
+                int64_t stride_b, int64_t stride_h, int64_t stride_t, void* stream);
+
+/* DiffNet.forward(spec, diffusion_step, cond) (usr/diff/net.py:107-130) for the prepared batch.
+ * x, eps: [B][M][T]; t: HOST array of B step indices (may differ per utterance, as in p_losses :214-217). */
+int dsd_denoise(dsd_handle* h, const float* x, const int32_t* t, float* eps, void* stream);
+
+/* GaussianDiffusion.q_sample (shallow_diffusion_tts.py:206-211) with one t for the batch (:255):
+ * out = sqrt_alphas_cumprod[t] * x_start + sqrt_one_minus_alphas_cumprod[t] * noise, all [B][M][T]. */
+int dsd_q_sample(dsd_handle* h, const float* x_start, const float* noise, int32_t t, float* out, void* stream);
+
+/* The DDPM loop `for i in reversed(range(0, k_step)): x = p_sample(x, i, cond)` (shallow_diffusion_tts.py:
+ * 269-270, p_sample :159-166, p_mean_variance :149-157).  x [B][M][T] is updated in place from x_{k_step} to
+ * x_0; noise is [k_step][B][M][T], slice j feeds the j-th call (t = k_step-1-j), t = 0 included. */
+int dsd_sample_ddpm(dsd_handle* h, float* x, const float* noise, int32_t k_step, void* stream);
+
+/* One p_sample call (shallow_diffusion_tts.py:159-166) at step t: x [B][M][T] updated in place from x_t to
+ * x_{t-1}; noise [B][M][T] is the N(0,1) draw of `noise_like` (ignored by the arithmetic when t == 0). */
+int dsd_p_sample(dsd_handle* h, float* x, const float* noise, int32_t t, void* stream);
+
+/* The PNDM/PLMS loop `for i in reversed(range(0, k_step, interval)): x = p_sample_plms(x, i, interval, cond)`
+ * (shallow_diffusion_tts.py:261-267, p_sample_plms :168-204), noise_list reset at entry (:262). */
+int dsd_sample_plms(dsd_handle* h, float* x, int32_t k_step, int32_t interval, void* stream);
+
+/* norm_spec / denorm_spec (shallow_diffusion_tts.py:278-282) fused with the layout change of :252 / :271:
+ *   dsd_norm_spec:   mel [B][T][M] -> x [B][M][T],  (mel - min) / (max - min) * 2 - 1
+ *   dsd_denorm_spec: x [B][M][T] -> mel [B][T][M],  (x + 1) / 2 * (max - min) + min, optionally multiplied by
+ *                    mask [B][T] (the `mel2ph > 0` factor of :273; NULL = none). */
+int dsd_norm_spec(dsd_handle* h, const float* mel, float* x, void* stream);
+int dsd_denorm_spec(dsd_handle* h, const float* x, const float* mask, float* mel, void* stream);
+
+/* Options: 0 = eager launches (default 1 = replay the K-step loop as a cached hipGraph). */
+int dsd_set_use_graph(dsd_handle* h, int32_t enable);
+/* Frames per workgroup of the residual-layer kernel: 0 = choose from the batch size, 32 or 64. */
+int dsd_set_layer_tile(dsd_handle* h, int32_t frames);
+
+/* Measurement hook for bench.py's roofline object: average device time (ms, hipEvents on the stream the
+ * kernel is launched on) of `iters` launches of ONE residual-layer kernel (layer `layer`, step t) on the
+ * prepared batch.  Synchronises the stream (it is a measurement call, not part of the data path). */
+int dsd_time_layer_kernel(dsd_handle* h, int32_t layer, int32_t t, int32_t iters, float* avg_ms, void* stream);
+
+/* Introspection for tests: bytes of device memory owned by the handle; frames/workgroup currently selected. */
+int64_t dsd_device_bytes(dsd_handle* h);
+int dsd_get_layer_tile(dsd_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSD_H */

@@ -1,0 +1,39 @@
+"""CPU: the C-ABI library is built, loads, and exports exactly the symbols include/dsd.h declares.
+No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from diffsinger_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'dsd.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(dsd_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_is_built():
+    assert os.path.isfile(_lib.lib_path()), 'run python -m diffsinger_amd.build'
+
+
+def test_binding_lists_every_header_symbol():
+    assert _header_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_header_symbol():
+    lib = ctypes.CDLL(_lib.lib_path())
+    for name in _header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.dsd_abi_version() == _lib.DSD_ABI_VERSION
+
+
+def test_bad_config_is_rejected_without_a_device():
+    lib = _lib.load()
+    cfg = _lib.DsdConfig(80, 128, 256, 20, 1)          # residual_channels != 256: rejected before any HIP call
+    h = ctypes.c_void_p()
+    assert lib.dsd_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1
+    assert b'residual_channels' in lib.dsd_last_error()
+    assert lib.dsd_create(None, 0, ctypes.byref(h)) == -1
