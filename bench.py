@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py - the reference's headline metric on MI355X: mel-frames/s of the K=100 DDPM reverse loop.
+
+    python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+Workload (BASELINE.json configs[1]): DiffSpeech 80-bin denoiser (residual_channels 256, 20 layers, dilation
+cycle 1, linear beta schedule max_beta 0.06, 100 timesteps), K=100 full DDPM from a Gaussian start, batch of 8
+utterances x T=1024 frames PER GPU (weak scaling: utterances shard across ranks, no data-path collective, one
+RCCL gather of the finished mels).  Synthetic inputs (seeded N(0,1) cond / x_T / per-step noise) and seeded
+random-init weights - there are no checkpoints or datasets (no network).
+
+One "step" = one complete pass of the hot path over the batch: hoisted conditioner projection (dsd_prepare),
+the 100-step reverse loop (one hipGraph replay: 2100 kernel launches), de-normalisation to [B,T,80] and, for
+N > 1, the gather to rank 0.  Inputs are resident in HBM before the timed region.
+
+The JSON line also carries
+  roofline      for the dominant kernel (k_layer, one residual block): executed fp32 FLOPs per launch / average
+                launch duration measured live with HIP events on the launch stream, against the 157.3 TFLOP/s
+                dense fp32 MFMA peak (MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (oracle/diffnet_oracle.py, torch fp32 = the reference's own arithmetic) timed on
+                this box's host cores on a bounded sample of the same workload (a few of the 100 steps,
+                extrapolated - every step is identical work).
+  parity        max-abs error of the de-normalised mel on the golden case generated from the reference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PRESET = 'lj_ds_beta6'
+B_PER_GPU, T_FRAMES, K_STEPS = 8, 1024, 100
+F_LAYER_EXEC = 2 * 512 * 768 + 2 * 512 * 256          # executed FLOP / frame / layer launch (dilated conv + out proj)
+F_LAYER_REF = F_LAYER_EXEC + 2 * 512 * 256            # + the conditioner projection the reference recomputes per step
+F_EVAL_REF = 26_427_392                               # reference GEMM FLOP / frame / denoiser evaluation
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def build_model(device):
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from diffsinger_amd.synth import presets
+    pre = presets()[PRESET]
+    hparams.clear()
+    diffsinger_amd.use_preset(PRESET)
+    torch.manual_seed(1234)                            # reference default seed (configs/config_base.yaml:5)
+    net = diffsinger_amd.DIFF_DECODERS[pre['diff_decoder_type']](hparams)
+    torch.nn.init.normal_(net.output_projection.weight, std=0.02)      # reference zero-inits it (net.py:105)
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=pre['timesteps'], K_step=K_STEPS,
+                                          loss_type='l1', spec_min=pre['spec_min'], spec_max=pre['spec_max'])
+    return gd.to(device).eval(), pre
+
+
+def cpu_baseline(budget_s: float = 15.0):
+    """The oracle on the host cores: p_sample steps at the bench shape until ~budget_s of CPU work."""
+    from oracle import diffnet_oracle as O
+    from diffsinger_amd.synth import presets, make_inputs
+    pre = presets()[PRESET]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.NetConfig(80, 256, 256, 20, 1)
+    p = O.init_diffnet_params(cfg, 1234, 0.02)
+    sch = O.make_schedule(O.linear_beta_schedule(pre['timesteps'], pre['max_beta']))
+    inp = make_inputs(7, B_PER_GPU, T_FRAMES, n_noise=1)
+    x, cond, z = inp['x_T'], inp['cond'], inp['noise'][0]
+    t = torch.full((B_PER_GPU,), K_STEPS - 1, dtype=torch.long)
+    with torch.no_grad():
+        O.p_sample(p, cfg, sch, x, t, cond, z)         # warm-up (oneDNN primitive creation)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            x = O.p_sample(p, cfg, sch, x, t, cond, z)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 40:
+                break
+    sec_per_step = el / n
+    return {'value': B_PER_GPU * T_FRAMES / (sec_per_step * K_STEPS), 'unit': 'mel-frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} of {K_STEPS} DDPM steps (p_sample, B={B_PER_GPU}, T={T_FRAMES}) in {el:.1f}s on {cores} host threads, '
+                      f'extrapolated x{K_STEPS} (every step is identical work)',
+            'sec_per_ddpm_step': sec_per_step}
+
+
+def parity_check(device):
+    """Golden case generated from the reference (tests/golden/ddpm_lj_k100.npz): max-abs de-normalised mel error."""
+    from tests import helpers as H
+    from tests.gpu_helpers import run_hip_case
+    g = H.load_golden('ddpm_lj_k100')
+    out = run_hip_case('ddpm_lj_k100')
+    return {'case': 'ddpm_lj_k100 (B=2,T=96,K=100, fixture from the reference)', 'max_abs_mel_err': float(np.abs(out - g['out']).max()),
+            'tolerance': 1e-4}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tile', type=int, default=0, help='frames per workgroup of the layer kernel (0 auto, 32, 64)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus}: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    gd, pre = build_model(device)
+    from diffsinger_amd.dist import gather_mels
+    B, T, K, M = B_PER_GPU, T_FRAMES, K_STEPS, 80
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    cond = torch.randn(B, T, 256, device=device, generator=g).transpose(1, 2)        # [B,H,T] view, like the reference
+    x_T = torch.randn(B, 1, M, T, device=device, generator=g)
+    noise = torch.randn(K, B, 1, M, T, device=device, generator=g)
+    eng = gd._engine(cond)
+    eng.set_layer_tile(args.tile)
+
+    def step():
+        mel = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
+        if world > 1:
+            return gather_mels(mel, world * B, dst=0)
+        return mel
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    elt = torch.tensor([el], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
+    el = float(elt.item())
+    if rank == 0:
+        assert out is not None and bool(torch.isfinite(out).all()), 'non-finite mel'
+
+    # roofline of the dominant kernel: k_layer, measured live with HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        eng.prepare(cond)
+        ms = eng.time_layer_kernel(layer=3, t=50, iters=200)
+        frames = B * T
+        achieved = frames * F_LAYER_EXEC / (ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': f'k_layer<{eng.layer_tile() // 32},false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                'avg_launch_ms': ms, 'flop_per_launch': frames * F_LAYER_EXEC,
+                'achieved_ref_accounting': frames * F_LAYER_REF / (ms * 1e-3) / 1e12,
+                'note': 'achieved counts executed fp32 FLOPs of one residual-layer launch (K=768 dilated conv + K=256 output '
+                        'projection per frame); *_ref_accounting also credits the conditioner projection the reference '
+                        'recomputes every step and this path hoists out of the loop'}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ms_per_step = el / args.steps * 1e3
+        value = world * B * T * args.steps / el
+        res = {
+            'metric': 'mel-frames/sec (whole node) at K=100 DDPM, 80-bin, T=1024', 'value': value, 'unit': 'mel-frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[1]: DiffSpeech 80-bin, residual_channels=256, 20 layers, K=100 DDPM, '
+                                   f'batch={B} x T={T} per GPU', 'preset': PRESET, 'utterances_per_gpu': B, 'frames': T,
+                       'k_step': K, 'sampler': 'ddpm', 'layer_tile_frames': eng.layer_tile(), 'hipgraph': True,
+                       'sharding': 'utterances r::W, RCCL gather of mels to rank 0' if world > 1 else 'single GPU'},
+            'roofline': roof,
+            'model_tflops_ref_accounting': world * B * T * K * F_EVAL_REF * args.steps / el / 1e12,
+        }
+        try:
+            res['parity'] = parity_check(device)
+        except Exception as e:          # fixtures missing etc. - report, do not hide
+            res['parity'] = {'error': repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+            res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

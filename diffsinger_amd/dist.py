@@ -1,0 +1,77 @@
+"""Multi-GPU inference: utterances shard across ranks, one RCCL gather collates the finished mels.
+
+The path shards naturally: every op of the denoiser and sampler is per-utterance, so rank
+r takes utterances r, r+W, r+2W, ... (what the reference's DDP inference does with batches, tasks/tts/tts.py:
+85-88), runs the whole K-step loop with ZERO communication, and only the finished [n_local, T, M] mels are
+gathered to rank 0 - a flat gather over xGMI's direct peer links (each rank has its own link to the root; no
+ring).  The reference collates through the filesystem (tasks/tts/fs2.py:414-431); the gather is new.
+
+One process per GPU (`torch.distributed`, backend 'nccl' == RCCL on ROCm; 'gloo' on CPU for the tests)."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Utterance i -> rank i mod W."""
+    return list(range(rank, n_items, world))
+
+
+def unshard_order(n_items: int, world: int) -> List[int]:
+    """Position in the rank-major concatenation [rank0 items..., rank1 items..., ...] of each original item."""
+    order = []
+    for r in range(world):
+        order.extend(shard_indices(n_items, r, world))
+    inv = [0] * n_items
+    for pos, i in enumerate(order):
+        inv[i] = pos
+    return inv
+
+
+def gather_mels(local: torch.Tensor, n_items: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """local: this rank's [n_local, T, M] mels (all ranks the same T, M; n_local may differ by one).
+    Returns on `dst` the [n_items, T, M] tensor in ORIGINAL utterance order, None elsewhere.
+    One collective: ranks with fewer items pad to the maximum with zeros."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_max = (n_items + world - 1) // world
+    T, M = local.shape[1], local.shape[2]
+    buf = local
+    if local.shape[0] < n_max:
+        buf = torch.zeros(n_max, T, M, dtype=local.dtype, device=local.device)
+        buf[:local.shape[0]] = local
+    buf = buf.contiguous()
+    if rank == dst:
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.gather(buf, gather_list=parts, dst=dst, group=group)
+        out = torch.empty(n_items, T, M, dtype=local.dtype, device=local.device)
+        for r in range(world):
+            idx = shard_indices(n_items, r, world)
+            if idx:
+                out[idx] = parts[r][:len(idx)]
+        return out
+    dist.gather(buf, gather_list=None, dst=dst, group=group)
+    return None
+
+
+def sharded_inference(model, conds: Sequence[torch.Tensor], *, micro_batch: int = 16, group=None, dst: int = 0, **infer_kw):
+    """Run `model.inference` over a list of equal-length utterance conditioners [H,T] (already on this rank's
+    device), sharded r::W, in micro-batches, and gather the mels on `dst` in original order.
+    Per-batch keyword tensors (x_T, noise, fs2_mels, ...) are passed as callables `idx_list -> batched tensor`."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = shard_indices(len(conds), rank, world)
+    outs = []
+    for s in range(0, len(mine), micro_batch):
+        idx = mine[s:s + micro_batch]
+        cond = torch.stack([conds[i] for i in idx])
+        kw = {k: (v(idx) if callable(v) else v) for k, v in infer_kw.items()}
+        outs.append(model.inference(cond, **kw))
+    T = conds[0].shape[-1]
+    local = torch.cat(outs) if outs else torch.zeros(0, T, model.mel_bins, device=conds[0].device)
+    if world == 1:
+        return local
+    return gather_mels(local, len(conds), dst=dst, group=group)
