@@ -15,7 +15,8 @@ SYMBOLS = [
     'dsd_abi_version', 'dsd_last_error', 'dsd_create', 'dsd_destroy', 'dsd_load_weights', 'dsd_set_schedule',
     'dsd_get_schedule_table', 'dsd_set_spec_range', 'dsd_prepare', 'dsd_denoise', 'dsd_q_sample',
     'dsd_sample_ddpm', 'dsd_p_sample', 'dsd_sample_plms', 'dsd_norm_spec', 'dsd_denorm_spec',
-    'dsd_set_use_graph', 'dsd_set_layer_tile', 'dsd_time_layer_kernel', 'dsd_device_bytes', 'dsd_get_layer_tile',
+    'dsd_set_use_graph', 'dsd_set_layer_tile', 'dsd_time_layer_kernel', 'dsd_debug_layer_timeline', 'dsd_device_bytes',
+    'dsd_get_layer_tile',
 ]
 
 _fp = C.POINTER(C.c_float)
@@ -56,6 +57,9 @@ def load():
     if not os.path.isfile(_LIB_PATH):
         raise RuntimeError(f'{_LIB_PATH} not found: the HIP denoiser library is not built '
                            f'(run `python -m diffsinger_amd.build`); there is no CPU fallback')
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  One process must
+    # have ONE runtime: import torch first so that our library binds to the runtime torch's tensors live in.
+    import torch  # noqa: F401
     lib = C.CDLL(_LIB_PATH)
     h = C.c_void_p
     lib.dsd_abi_version.restype = C.c_int
@@ -78,6 +82,7 @@ def load():
     lib.dsd_set_use_graph.argtypes = [h, C.c_int32]
     lib.dsd_set_layer_tile.argtypes = [h, C.c_int32]
     lib.dsd_time_layer_kernel.argtypes = [h, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_void_p]
+    lib.dsd_debug_layer_timeline.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
     lib.dsd_device_bytes.argtypes = [h]
     lib.dsd_device_bytes.restype = C.c_int64
     lib.dsd_get_layer_tile.argtypes = [h]

@@ -65,7 +65,8 @@ struct dsd_handle {
     int64_t bytes_ws = 0;    // ... + workspace of the prepared batch
 
     // packed weights (device)
-    float4 *w1p = nullptr, *w2p = nullptr, *wcp = nullptr, *b1p = nullptr, *b2p = nullptr;
+    float4 *w1p = nullptr, *w2p = nullptr, *wcp = nullptr, *b1p = nullptr, *bskp = nullptr;
+    float *b2raw = nullptr, *bsum = nullptr;   // output_projection biases [L][2C]; sum over layers of their skip halves [C]
     float4 *winp = nullptr, *binp = nullptr, *wsp = nullptr, *bsp = nullptr, *woutp = nullptr, *boutp = nullptr;
     // raw copies for the step table
     float *mlp0_w = nullptr, *mlp0_b = nullptr, *mlp2_w = nullptr, *mlp2_b = nullptr, *dp_w = nullptr, *dp_b = nullptr;
@@ -175,7 +176,7 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     free_workspace(h);
-    dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->b2p);
+    dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->bskp); dev_free(h->b2raw); dev_free(h->bsum);
     dev_free(h->winp); dev_free(h->binp); dev_free(h->wsp); dev_free(h->bsp); dev_free(h->woutp); dev_free(h->boutp);
     dev_free(h->mlp0_w); dev_free(h->mlp0_b); dev_free(h->mlp2_w); dev_free(h->mlp2_b); dev_free(h->dp_w); dev_free(h->dp_b);
     dev_free(h->ds_table); dev_free(h->spec_min_d); dev_free(h->spec_max_d);
@@ -265,7 +266,9 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
         DSD_TRY(dev_alloc(h, &h->w2p, (size_t)L * 4 * 32 * 256));
         DSD_TRY(dev_alloc(h, &h->wcp, (size_t)L * 4 * 32 * 256));
         DSD_TRY(dev_alloc(h, &h->b1p, (size_t)L * 4 * 4 * 8));
-        DSD_TRY(dev_alloc(h, &h->b2p, (size_t)L * 4 * 4 * 8));
+        DSD_TRY(dev_alloc(h, &h->bskp, (size_t)4 * 2 * 8));
+        DSD_TRY(dev_alloc(h, &h->b2raw, (size_t)L * 2 * kC));
+        DSD_TRY(dev_alloc(h, &h->bsum, (size_t)kC));
         DSD_TRY(dev_alloc(h, &h->winp, (size_t)4 * h->nk_in * 128));
         DSD_TRY(dev_alloc(h, &h->binp, (size_t)4 * 2 * 8));
         DSD_TRY(dev_alloc(h, &h->wsp, (size_t)4 * 32 * 128));
@@ -289,10 +292,13 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
         DSD_TRY(pack_a(s, w->conditioner_projection_w[l], h->wcp + (size_t)l * 4 * 32 * 256, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1));
         DSD_TRY(pack_a(s, w->output_projection_w[l], h->w2p + (size_t)l * 4 * 32 * 256, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1));
         DSD_TRY(pack_bias(s, w->dilated_conv_b[l], w->conditioner_projection_b[l], h->b1p + (size_t)l * 128, 4, 4, 1, kC, 2 * kC));
-        DSD_TRY(pack_bias(s, w->output_projection_b[l], nullptr, h->b2p + (size_t)l * 128, 4, 4, 1, kC, 2 * kC));
+        HIP_TRY(hipMemcpyAsync(h->b2raw + (size_t)l * 2 * kC, w->output_projection_b[l], (size_t)2 * kC * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(h->dp_w + (size_t)l * kC * kC, w->diffusion_projection_w[l], (size_t)kC * kC * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(h->dp_b + (size_t)l * kC, w->diffusion_projection_b[l], (size_t)kC * 4, hipMemcpyDeviceToDevice, s));
     }
+    hipLaunchKernelGGL(k_sum_skip_bias, dim3(1), dim3(kC), 0, s, h->b2raw, h->bsum, L);
+    HIP_TRY(hipGetLastError());
+    DSD_TRY(pack_bias(s, h->bsum, nullptr, h->bskp, 4, 2, 0, 0, kC));
     DSD_TRY(pack_a(s, w->input_projection_w, h->winp, 4, 1, h->nk_in, 2, 0, 0, kC, M, M, 1));
     DSD_TRY(pack_bias(s, w->input_projection_b, nullptr, h->binp, 4, 2, 0, 0, kC));
     DSD_TRY(pack_a(s, w->skip_projection_w, h->wsp, 4, 1, 32, 2, 0, 0, kC, kC, kC, 1));
@@ -389,7 +395,7 @@ extern "C" int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* con
     if (ntiles > h->cap_frames || B > h->cap_B || spec > h->cap_spec) {
         HIP_TRY(hipStreamSynchronize(s));
         free_workspace(h);
-        const size_t xcount = (size_t)B * kC * TS + 2 * kSlack;
+        const size_t xcount = (size_t)ntiles * kC * 32 + 2 * kSlack;
         DSD_TRY(dev_alloc(h, &h->xa_base, xcount, true));
         DSD_TRY(dev_alloc(h, &h->xb_base, xcount, true));
         DSD_TRY(dev_alloc(h, &h->condT, (size_t)B * kC * TS, true));
@@ -426,14 +432,14 @@ static int launch_inproj(dsd_handle* h, const float* spec, hipStream_t s) {
     return DSD_OK;
 }
 
-static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, hipStream_t s) {
+static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, hipStream_t s, unsigned long long* dbg = nullptr) {
     const int nb = layer_nb(h);
     LayerParams p{};
     p.x_in = (l & 1) ? h->xb : h->xa;
     p.x_out = (l & 1) ? h->xa : h->xb;
     p.w1p = h->w1p + (size_t)l * 4 * 96 * 256;
     p.w2p = h->w2p + (size_t)l * 4 * 32 * 256;
-    p.b2p = h->b2p + (size_t)l * 128;
+    p.b2 = h->b2raw + (size_t)l * 2 * kC;
     p.cp = h->cp + (size_t)l * h->ntiles * 4096;
     p.skip = h->skip;
     p.ds = h->ds_table + (size_t)l * kC;
@@ -444,6 +450,7 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
     p.tiles_per_utt = (h->ntile32 + nb - 1) / nb;
     p.dil = h->dil[l];
     p.first = (l == 0);
+    p.dbg = dbg;
     const dim3 grid((unsigned)(h->B * p.tiles_per_utt));
     const bool last = (l == h->L - 1);
     if (nb == 1) {
@@ -459,7 +466,7 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
 
 static HeadParams head_base(dsd_handle* h) {
     HeadParams p{};
-    p.skip = h->skip; p.wsp = h->wsp; p.bsp = h->bsp; p.woutp = h->woutp; p.boutp = h->boutp;
+    p.skip = h->skip; p.wsp = h->wsp; p.bsp = h->bsp; p.bskp = h->bskp; p.woutp = h->woutp; p.boutp = h->boutp;
     p.winp = h->winp; p.binp = h->binp; p.x_next = h->xa;
     p.sqrt_L = (float)std::sqrt((double)h->L);
     p.nk_in = h->nk_in; p.M = h->M; p.T = h->T; p.TS = h->TS; p.ntile32 = h->ntile32;
@@ -706,5 +713,28 @@ extern "C" int dsd_time_layer_kernel(dsd_handle* h, int32_t layer, int32_t t, in
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
+    return DSD_OK;
+}
+
+// Debug hook: per-wave s_memtime stamps of ONE launch of layer `layer` (start, staged, conv done, gate done, out-proj
+// done, end) -> HOST out[blocks*4*8] (u64).  *n_blocks receives the grid size.
+extern "C" int dsd_debug_layer_timeline(dsd_handle* h, int32_t layer, int32_t t, uint64_t* out, int32_t max_blocks, int32_t* n_blocks,
+                                        void* stream) {
+    DSD_TRY(check_ready(h, "dsd_debug_layer_timeline", false));
+    if (!out || !n_blocks || layer < 0 || layer >= h->L || t < 0) return fail(DSD_ERR_INVALID, "dsd_debug_layer_timeline: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    DSD_TRY(build_step_table(h, t + 1, s));
+    const int nb = layer_nb(h);
+    const int blocks = h->B * ((h->ntile32 + nb - 1) / nb);
+    if (blocks > max_blocks) return fail(DSD_ERR_INVALID, "dsd_debug_layer_timeline: %d blocks > buffer %d", blocks, max_blocks);
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)blocks * 32 * 8));
+    for (int i = 0; i < 3; ++i) DSD_TRY(launch_layer(h, layer, t, nullptr, s));
+    DSD_TRY(launch_layer(h, layer, t, nullptr, s, d));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(out, d, (size_t)blocks * 32 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    *n_blocks = blocks;
     return DSD_OK;
 }

@@ -54,72 +54,145 @@ __device__ __forceinline__ float4 get4(const f32x16& v, int q) {
     return make_float4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
-// One 8-deep k-chunk: 4 MFMA steps x NMB row blocks x NB frame blocks.  bp = this lane's B base for the chunk
-// (row 4h of the chunk, column j); LD = LDS row stride in floats.
-template <int NMB, int NB, int LD>
-__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NMB][NB], const float4 (&a)[NMB], const float* bp) {
+// One 8-deep k-chunk: 4 MFMA steps x NMB row blocks x NB frame blocks, operands already in registers.
+template <int NMB, int NB>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NMB][NB], const float4 (&a)[NMB], const float (&b)[4][NB]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        float b[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b[nb] = bp[s * LD + nb * 32];
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb) {
             const float av = (s == 0) ? a[mb].x : (s == 1) ? a[mb].y : (s == 2) ? a[mb].z : a[mb].w;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(av, b[nb], acc[mb][nb]);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(av, b[s][nb], acc[mb][nb]);
         }
     }
 }
 
-// K loop over `n` chunks.  A fragments stream straight from global/L2 into VGPRs (no LDS: a wave's weight rows
-// are not shared with the other waves), register double-buffered one chunk (16*NB MFMAs, >= 1024 cycles) ahead.
+// K loop over `n` chunks, software-pipelined by hand.  Left alone, hipcc sinks the prefetch loads down to their first
+// use and exposes the L2 latency of every chunk, so every step is fenced with sched_barrier and, inside a step, the
+// loads of the NEXT operands are interleaved one-by-one behind the first MFMAs with sched_group_barrier (an MFMA
+// occupies the pipe for 64 cycles; the wave issues its global / LDS loads in that shadow).
+//   A fragments stream straight from global/L2 into VGPRs (no LDS: a wave's weight rows are not shared with the
+//   other waves), three register stages = two chunks (2 x 16*NB MFMAs >= 2048 cycles) ahead of use;
+//   B fragments (4*NB ds_read_b32 per chunk) two register stages = one chunk ahead.
 // ap: lane-adjusted pointer to chunk 0 / row block 0; ASTRIDE: float4 between consecutive chunks; row block mb
-// at + mb*64.  bof(kc): this lane's LDS B pointer for chunk kc.
+// at + mb*64.  bof(kc): this lane's LDS B pointer for chunk kc (row 4h of the chunk, column j); LD: LDS row stride.
+// Prefetches past the end are clamped to the last chunk (valid addresses, results unused).
+// run(acc, begin, end) may be called several times with begin a multiple of 6 (the register rotation period) so that
+// unrelated loads can be issued between two parts of one K loop without draining the pipeline.
+#define DSD_SB() __builtin_amdgcn_sched_barrier(0)
+// STAGES = register stages of the A stream (3 or 6): chunk kc+STAGES-1 is requested while chunk kc is multiplied.
+// All workgroups of an XCD walk the same weight stream in lock-step, so every chunk is a first touch of that L2:
+// the latency to hide is the Infinity-Cache / HBM one (~1-2 us), not an L2 hit - hence 5 chunks (>= 5k cycles) of
+// distance for the 16-MFMA chunks of the 32-frame kernels.
+template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff>
+struct GemmPipe {
+    static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
+    const float4* __restrict__ ap;
+    int n;
+    BOff bof;
+    float4 a[STAGES][NMB];
+    float b[2][4][NB];
+
+    __device__ __forceinline__ GemmPipe(const float4* ap_, int n_, BOff bof_) : ap(ap_), n(n_), bof(bof_) {}
+
+    __device__ __forceinline__ void lda(float4 (&dst)[NMB], int kc) {
+        const float4* p = ap + (size_t)((kc < n) ? kc : n - 1) * ASTRIDE;
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) dst[mb] = p[mb * 64];
+    }
+    __device__ __forceinline__ void ldb(float (&dst)[4][NB], int kc) {
+        const float* bp = bof((kc < n) ? kc : n - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) dst[s][nb] = bp[s * LD + nb * 32];
+    }
+    // interleave: {1 MFMA, 1 global load} x NMB, {1 MFMA, 1 LDS read} x 2NB, then the remaining MFMAs
+    __device__ __forceinline__ void pattern() {
+#pragma unroll
+        for (int i = 0; i < NMB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NMB * NB - NMB - 2 * NB, 0);
+    }
+    __device__ __forceinline__ void start() {
+#pragma unroll
+        for (int i = 0; i < STAGES - 1; ++i) lda(a[i], i);
+        ldb(b[0], 0);
+        DSD_SB();
+    }
+    template <int I>
+    __device__ __forceinline__ void step(f32x16 (&acc)[NMB][NB], int kc) {
+        lda(a[(I + STAGES - 1) % STAGES], kc + I + STAGES - 1);
+        ldb(b[(I + 1) & 1], kc + I + 1);
+        mma_chunk<NMB, NB>(acc, a[I % STAGES], b[I & 1]);
+        pattern();
+        DSD_SB();
+    }
+    // chunks [begin, end); begin must be a multiple of 6 (register rotation period); may be called repeatedly to
+    // place unrelated loads between two parts of one K loop without draining the pipeline
+    __device__ __forceinline__ void run(f32x16 (&acc)[NMB][NB], int begin, int end) {
+        for (int kc = begin; kc < end; kc += 6) {
+            step<0>(acc, kc);
+            if (kc + 1 >= end) break;
+            step<1>(acc, kc);
+            if (kc + 2 >= end) break;
+            step<2>(acc, kc);
+            if (kc + 3 >= end) break;
+            step<3>(acc, kc);
+            if (kc + 4 >= end) break;
+            step<4>(acc, kc);
+            if (kc + 5 >= end) break;
+            step<5>(acc, kc);
+        }
+    }
+};
+
 template <int NMB, int NB, int LD, int ASTRIDE, typename BOff>
 __device__ __forceinline__ void gemm_k(f32x16 (&acc)[NMB][NB], const float4* __restrict__ ap, int n, BOff bof) {
-    float4 a0[NMB], a1[NMB];
-#pragma unroll
-    for (int mb = 0; mb < NMB; ++mb) a0[mb] = ap[mb * 64];
-    int kc = 0;
-    for (; kc + 2 <= n; kc += 2) {
-        const float4* p1 = ap + (size_t)(kc + 1) * ASTRIDE;
-#pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) a1[mb] = p1[mb * 64];
-        mma_chunk<NMB, NB, LD>(acc, a0, bof(kc));
-        const int k2 = (kc + 2 < n) ? kc + 2 : n - 1;
-        const float4* p2 = ap + (size_t)k2 * ASTRIDE;
-#pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) a0[mb] = p2[mb * 64];
-        mma_chunk<NMB, NB, LD>(acc, a1, bof(kc + 1));
-    }
-    if (kc < n) mma_chunk<NMB, NB, LD>(acc, a0, bof(kc));
+    GemmPipe<NMB, NB, LD, ASTRIDE, 6, BOff> pipe(ap, n, bof);
+    pipe.start();
+    pipe.run(acc, 0, n);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // residual layer
 // ------------------------------------------------------------------------------------------------------------
+// x lives in a TILE-MAJOR internal layout [B * ntile32][C][32] (one 32 KiB block per 32-frame tile): a wave's 64
+// rows of a tile are 8 KiB contiguous, so tile loads and stores are whole-line, 1 KiB-per-instruction accesses.
 struct LayerParams {
-    const float* x_in;      // [B][C][TS]
-    float* x_out;           // [B][C][TS]
+    const float* x_in;      // [tiles][C][32]
+    float* x_out;           // [tiles][C][32]
     const float4* w1p;      // dilated conv, packed [w4][kc96][mb4][lane64] float4
     const float4* w2p;      // output projection, packed [w4][kc32][mb4][lane64]
-    const float4* b2p;      // output projection bias in fragment order [w4][mb4][h2][q4]
+    const float* b2;        // output projection bias [2C] (residual half used here; the skip half is summed over
+                            // layers once and added in the head)
     const float4* cp;       // hoisted conditioner projection (+ both biases) [tile32][w4][mb4][q4][lane64]
-    float4* skip;           // running skip sum [tile32][w4][mb2][q4][lane64]
+    float4* skip;           // running skip sum (without biases) [tile32][w4][mb2][q4][lane64]
     const float* ds;        // step-projection table for this layer: ds[t * ds_tstride + c]
     const int* t_dev;       // per-utterance step index, or nullptr -> t_uniform
     int t_uniform, ds_tstride;
     int T, TS, ntile32, tiles_per_utt, dil, first;
+    unsigned long long* dbg;   // optional per-wave phase timestamps [block][wave][8] (s_memtime), nullptr in production
 };
 
 template <int NB>
 constexpr int layer_lds_bytes() { return (kC * (32 * NB + 2 * kHalo) + kC * 32 * NB) * (int)sizeof(float); }
 
+__device__ __forceinline__ float f4at(const float4& v, int e) { return (e == 0) ? v.x : (e == 1) ? v.y : (e == 2) ? v.z : v.w; }
+
 template <int NB, bool LAST>
-__global__ __launch_bounds__(kThreads, (NB == 1 ? 2 : 1)) void k_layer(const LayerParams p) {
+__global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     constexpr int LD = 32 * NB + 2 * kHalo;   // y tile row stride (floats), 16-byte multiple
     constexpr int GLD = 32 * NB;              // gate tile row stride
+    constexpr int TILE = kC * 32;             // floats per 32-frame x tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ytile = smem;
     float* gtile = smem + kC * LD;
@@ -130,127 +203,184 @@ __global__ __launch_bounds__(kThreads, (NB == 1 ? 2 : 1)) void k_layer(const Lay
     const int b = blockIdx.x / p.tiles_per_utt, tn = blockIdx.x % p.tiles_per_utt;
     const int t0 = tn * 32 * NB;
     const int tile0 = b * p.ntile32 + tn * NB;
+    const int ntv = min(NB, p.ntile32 - tn * NB);         // valid 32-frame tiles of this workgroup
     const int tstep = p.t_dev ? p.t_dev[b] : p.t_uniform;
     const float* __restrict__ dsl = p.ds + (size_t)tstep * p.ds_tstride;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+    if (p.dbg) ts0 = __builtin_amdgcn_s_memtime();
 
-    // 1. accumulators start from the hoisted conditioner projection (+ conv bias + cond bias)
-    f32x16 acc[4][NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const bool valid = (tn * NB + nb) < p.ntile32;
-        const float4* cpl = p.cp + ((size_t)(tile0 + nb) * 4 + w) * (4 * 4 * 64) + lane;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                set4(acc[mb][nb], q, valid ? cpl[(mb * 4 + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-
-    // 2. stage y = x + step_proj (zero outside [0,T): the conv's zero padding applies to y, net.py:69-71)
-    const float* __restrict__ xrow0 = p.x_in + (size_t)b * kC * p.TS;
+    // 1. stage y = x + step_proj into LDS (zero outside [0,T): the conv's zero padding applies to y, net.py:69-71):
+    //    the tile itself with contiguous float4 loads, plus 8 halo frames from each neighbouring tile
+    const float* __restrict__ xt = p.x_in + (size_t)tile0 * TILE;
 #pragma unroll
     for (int it = 0; it < 8 * NB; ++it) {
-        const int idx = it * kThreads + tid;
-        const int row = idx / (8 * NB), q = idx % (8 * NB);
-        const int t = t0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < p.TS) v = *reinterpret_cast<const float4*>(xrow0 + (size_t)row * p.TS + t);
+        const int nbi = it >> 3;
+        const int rem = (it & 7) * kThreads + tid;
+        const int row = rem >> 3, q = rem & 7;
+        const int t = t0 + 32 * nbi + 4 * q;
+        const bool ok = nbi < ntv;
+        float4 v = *reinterpret_cast<const float4*>(xt + (ok ? nbi : 0) * TILE + row * 32 + 4 * q);
         const float d = dsl[row];
-        v.x = (t + 0 < p.T) ? v.x + d : 0.f;
-        v.y = (t + 1 < p.T) ? v.y + d : 0.f;
-        v.z = (t + 2 < p.T) ? v.z + d : 0.f;
-        v.w = (t + 3 < p.T) ? v.w + d : 0.f;
-        *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 4 * q) = v;
+        v.x = (ok && t + 0 < p.T) ? v.x + d : 0.f;
+        v.y = (ok && t + 1 < p.T) ? v.y + d : 0.f;
+        v.z = (ok && t + 2 < p.T) ? v.z + d : 0.f;
+        v.w = (ok && t + 3 < p.T) ? v.w + d : 0.f;
+        *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 32 * nbi + 4 * q) = v;
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int idx = it * kThreads + tid;
         const int row = idx >> 2, part = idx & 3;
-        const int t = (part < 2) ? t0 - kHalo + 4 * part : t0 + 32 * NB + 4 * (part - 2);
-        const int col = (part < 2) ? 4 * part : kHalo + 32 * NB + 4 * (part - 2);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(xrow0 + (size_t)row * p.TS + t);
+        const bool left = part < 2;
+        const int t = left ? t0 - kHalo + 4 * part : t0 + 32 * NB + 4 * (part - 2);
+        const int col = left ? 4 * part : kHalo + 32 * NB + 4 * (part - 2);
+        const bool have = left ? (tn * NB > 0) : (tn * NB + NB < p.ntile32);
+        const float* src = left ? xt - TILE + row * 32 + 24 + 4 * part : xt + NB * TILE + row * 32 + 4 * (part - 2);
+        float4 v = *reinterpret_cast<const float4*>(have ? src : xt + row * 32);
         const float d = dsl[row];
-        const bool lo = t >= 0;
-        v.x = (lo && t + 0 < p.T) ? v.x + d : 0.f;
-        v.y = (lo && t + 1 < p.T) ? v.y + d : 0.f;
-        v.z = (lo && t + 2 < p.T) ? v.z + d : 0.f;
-        v.w = (lo && t + 3 < p.T) ? v.w + d : 0.f;
+        v.x = (have && t + 0 < p.T) ? v.x + d : 0.f;
+        v.y = (have && t + 1 < p.T) ? v.y + d : 0.f;
+        v.z = (have && t + 2 < p.T) ? v.z + d : 0.f;
+        v.w = (have && t + 3 < p.T) ? v.w + d : 0.f;
         *reinterpret_cast<float4*>(ytile + row * LD + col) = v;
     }
     __syncthreads();
+    if (p.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
-    // 3. dilated conv: K = 3 taps x 256 channels = 96 chunks; tap k reads column offset (k-1)*dil
+    // 2. dilated conv: K = 3 taps x 256 channels = 96 chunks; tap k reads column offset (k-1)*dil.  The hoisted
+    //    conditioner projection (+ conv bias + cond bias) is fetched from HBM halfway through the loop, when the
+    //    memory system is idle, and added once the loop is done.
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    float4 cpv[4][NB][4];
     {
         const float4* ap = p.w1p + (size_t)w * (96 * 256) + lane;
         const float* yl = ytile + 4 * h * LD + kHalo + j;
         const int d = p.dil;
-        gemm_k<4, NB, LD, 256>(acc, ap, 96, [&](int kc) { return yl + (kc & 31) * (8 * LD) + ((kc >> 5) - 1) * d; });
+        auto bof = [&](int kc) { return yl + (kc & 31) * (8 * LD) + ((kc >> 5) - 1) * d; };
+        GemmPipe<4, NB, LD, 256, (NB == 1 ? 6 : 3), decltype(bof)> pipe(ap, 96, bof);
+        pipe.start();
+        pipe.run(acc, 0, 48);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float4* cpl = p.cp + ((size_t)(tile0 + ((nb < ntv) ? nb : 0)) * 4 + w) * (4 * 4 * 64) + lane;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cpv[mb][nb][q] = cpl[(mb * 4 + q) * 64];   // tiles past the end: unused columns
+        }
+        DSD_SB();
+        pipe.run(acc, 48, 96);
     }
+    if (p.dbg) ts2 = __builtin_amdgcn_s_memtime();
 
-    // 4. gate in registers: rows [64w,64w+64) are gates, their partners (row blocks 2,3) the filters (net.py:73-74)
+    // 3. gate in registers: rows [64w,64w+64) are gates, their partners (row blocks 2,3) the filters (net.py:73-74)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float g = sigmoid_f(acc[pr][nb][r]) * tanh_f(acc[pr + 2][nb][r]);
+                const float vg = f4at(cpv[pr][nb][r >> 2], r & 3), vf = f4at(cpv[pr + 2][nb][r >> 2], r & 3);
+                const float g = sigmoid_f(acc[pr][nb][r] + vg) * tanh_f(acc[pr + 2][nb][r] + vf);
                 gtile[(64 * w + 32 * pr + frag_row(r, h)) * GLD + 32 * nb + j] = g;
             }
     __syncthreads();
+    if (p.dbg) ts3 = __builtin_amdgcn_s_memtime();
 
-    // 5. output projection (K = 256): row blocks 0,1 = residual rows, 2,3 = skip rows.  The last layer's
-    //    residual half is dead (net.py:126 only reads the skips) and is not computed.
+    // 4. output projection (K = 256): row blocks 0,1 = residual rows, 2,3 = skip rows.  The last layer's
+    //    residual half is dead (net.py:126 only reads the skips) and is not computed.  x (row layout of the
+    //    transposed epilogue), the residual bias and the running skip sum are fetched behind the first chunks.
     constexpr int NMB2 = LAST ? 2 : 4;
     constexpr int MB0 = LAST ? 2 : 0;
     f32x16 acc2[NMB2][NB];
 #pragma unroll
-    for (int m = 0; m < NMB2; ++m) {
-        const int mb = MB0 + m;
-        const float4* bl = p.b2p + ((w * 4 + mb) * 2 + h) * 4;
+    for (int m = 0; m < NMB2; ++m)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) set4(acc2[m][nb], q, bl[q]);
-            if (mb >= 2 && !p.first && (tn * NB + nb) < p.ntile32) {
-                const float4* sl = p.skip + (((size_t)(tile0 + nb) * 4 + w) * 2 + (mb - 2)) * (4 * 64) + lane;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 s = sl[q * 64];
-                    acc2[m][nb][4 * q + 0] += s.x; acc2[m][nb][4 * q + 1] += s.y;
-                    acc2[m][nb][4 * q + 2] += s.z; acc2[m][nb][4 * q + 3] += s.w;
-                }
-            }
-        }
-    }
+            for (int r = 0; r < 16; ++r) acc2[m][nb][r] = 0.f;
+    float4 xrow[NB][8], skp[2][NB][4];
+    float brow[8];
     {
         const float4* ap = p.w2p + (size_t)w * (32 * 256) + MB0 * 64 + lane;
         const float* gl = gtile + 4 * h * GLD + j;
-        gemm_k<NMB2, NB, GLD, 256>(acc2, ap, 32, [&](int kc) { return gl + kc * (8 * GLD); });
+        auto bof = [&](int kc) { return gl + kc * (8 * GLD); };
+        GemmPipe<NMB2, NB, GLD, 256, (NB == 1 ? 6 : 3), decltype(bof)> pipe(ap, 32, bof);
+        pipe.start();
+        pipe.run(acc2, 0, 6);
+        if (!LAST) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) brow[it] = p.b2[64 * w + it * 8 + (lane >> 3)];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    xrow[nb][it] = reinterpret_cast<const float4*>(xt + ((nb < ntv) ? nb : 0) * TILE + 64 * w * 32)[it * 64 + lane];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) {
+                const float4* sl = p.skip + (((size_t)(tile0 + ((nb < ntv) ? nb : 0)) * 4 + w) * 2 + ms) * (4 * 64) + lane;
+                const bool keep = !p.first;     // layer 0 starts the sum (select, not multiply: the buffer may hold anything)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = sl[q * 64];
+                    skp[ms][nb][q] = make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
+                }
+            }
+        DSD_SB();
+        pipe.run(acc2, 6, 32);
     }
+    if (p.dbg) ts4 = __builtin_amdgcn_s_memtime();
 
-    // 6. epilogue: x' = (x + residual) / sqrt(2)  (net.py:78), skip sum written back in fragment order
+    // 5. epilogue: the residual is transposed through this wave's slice of the (now free) y tile into row layout,
+    //    x' = (x + (res + bias)) / sqrt(2)  (net.py:78) is formed there and the tile-major x_out is written as
+    //    contiguous 1 KiB-per-instruction float4 stores; the skip sum is written back in fragment order.
+    float* tw = ytile + w * (64 * 32 * NB);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        if ((tn * NB + nb) >= p.ntile32) continue;
+        if (nb >= ntv) continue;
         if (!LAST) {
-            float* __restrict__ xo = p.x_out + (size_t)b * kC * p.TS + t0 + 32 * nb + j;
-            const float* __restrict__ xi = xrow0 + t0 + 32 * nb + j;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const size_t off = (size_t)(64 * w + 32 * mb + frag_row(r, h)) * p.TS;
-                    xo[off] = __fdiv_rn(xi[off] + acc2[mb][nb][r], 1.41421354f);
-                }
+                for (int r = 0; r < 16; ++r) tw[nb * 2048 + (32 * mb + frag_row(r, h)) * 32 + j] = acc2[mb][nb][r];
+            __builtin_amdgcn_wave_barrier();
+            float* __restrict__ xo = p.x_out + (size_t)(tile0 + nb) * TILE + 64 * w * 32;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const float4 v = reinterpret_cast<const float4*>(tw + nb * 2048)[it * 64 + lane];
+                const float4 x = xrow[nb][it];
+                const float bv = brow[it];
+                float4 o;
+                o.x = __fdiv_rn(x.x + (v.x + bv), 1.41421354f);
+                o.y = __fdiv_rn(x.y + (v.y + bv), 1.41421354f);
+                o.z = __fdiv_rn(x.z + (v.z + bv), 1.41421354f);
+                o.w = __fdiv_rn(x.w + (v.w + bv), 1.41421354f);
+                reinterpret_cast<float4*>(xo)[it * 64 + lane] = o;
+            }
         }
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
             float4* sl = p.skip + (((size_t)(tile0 + nb) * 4 + w) * 2 + ms) * (4 * 64) + lane;
+            const int m = (LAST ? 0 : 2) + ms;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sl[q * 64] = get4(acc2[(LAST ? 0 : 2) + ms][nb], q);
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = get4(acc2[m][nb], q), s = skp[ms][nb][q];
+                sl[q * 64] = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
+            }
         }
+    }
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + w) * 8;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -300,8 +430,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_condproj(const CondProjParams p
 // input projection + ReLU on a [kMPad][32] tile held in LDS (rows >= M are zero)
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void inproj_tile(const float* ptile, const float4* __restrict__ winp,
-                                            const float4* __restrict__ binp, int nk, float* __restrict__ xo_utt,
-                                            int TS, int t0, int w, int lane) {
+                                            const float4* __restrict__ binp, int nk, float* __restrict__ xo_tile,
+                                            int w, int lane) {
     const int j = lane & 31, h = lane >> 5;
     f32x16 acc[2][1];
 #pragma unroll
@@ -315,12 +445,12 @@ __device__ __forceinline__ void inproj_tile(const float* ptile, const float4* __
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            xo_utt[(size_t)(64 * w + 32 * mb + frag_row(r, h)) * TS + t0 + j] = fmaxf(acc[mb][0][r], 0.f);
+            xo_tile[(64 * w + 32 * mb + frag_row(r, h)) * 32 + j] = fmaxf(acc[mb][0][r], 0.f);
 }
 
 struct InProjParams {
     const float* spec;      // [B][M][T]
-    float* x_out;           // [B][C][TS]
+    float* x_out;           // [tiles][C][32] (tile-major)
     const float4* winp;     // [w4][nk][mb2][lane64]
     const float4* binp;     // [w4][mb2][h2][q4]
     int nk, M, T, TS, ntile32;
@@ -336,7 +466,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_inproj(const InProjParams p) {
         smem[idx] = (m < p.M && t < p.T) ? p.spec[((size_t)b * p.M + m) * p.T + t] : 0.f;
     }
     __syncthreads();
-    inproj_tile(smem, p.winp, p.binp, p.nk, p.x_out + (size_t)b * kC * p.TS, p.TS, t0, w, lane);
+    inproj_tile(smem, p.winp, p.binp, p.nk, p.x_out + (size_t)blockIdx.x * (kC * 32), w, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -349,11 +479,12 @@ struct HeadParams {
     const float4* skip;         // [tile32][w4][mb2][q4][lane64]
     const float4* wsp;          // skip_projection packed [w4][kc32][mb2][lane64]
     const float4* bsp;          // [w4][mb2][h2][q4]
+    const float4* bskp;         // sum over layers of the skip-half output_projection biases, [w4][mb2][h2][q4]
     const float4* woutp;        // final projection packed [kc32][mb3][lane64]
     const float4* boutp;        // [mb3][h2][q4]
     const float4* winp;         // input projection (fused next-eval in-proj)
     const float4* binp;
-    float* x_next;              // [B][C][TS] (fused in-proj output)
+    float* x_next;              // [tiles][C][32] tile-major (fused in-proj output)
     float sqrt_L;
     int nk_in, M, T, TS, ntile32;
     // mode-specific tensors, all [B][M][T]
@@ -387,8 +518,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_head(const HeadParams p) {
         const float4* sl = p.skip + (((size_t)tile * 4 + w) * 2 + ms) * (4 * 64) + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 s = sl[q * 64];
-            const float v[4] = {s.x, s.y, s.z, s.w};
+            const float4 s = sl[q * 64], bs = p.bskp[((w * 2 + ms) * 2 + h) * 4 + q];
+            const float v[4] = {s.x + bs.x, s.y + bs.y, s.z + bs.z, s.w + bs.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 stile[(64 * w + 32 * ms + frag_row(4 * q + e, h)) * 32 + j] = __fdiv_rn(v[e], p.sqrt_L);
@@ -469,7 +600,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_head(const HeadParams p) {
     }
     if (FUSE_INPROJ) {
         __syncthreads();
-        inproj_tile(ptile, p.winp, p.binp, p.nk_in, p.x_next + (size_t)b * kC * p.TS, p.TS, t0, w, lane);
+        inproj_tile(ptile, p.winp, p.binp, p.nk_in, p.x_next + (size_t)tile * (kC * 32), w, lane);
     }
 }
 constexpr int kHeadLdsBytes = (2 * kC * 32 + kMPad * 32) * (int)sizeof(float);
@@ -647,6 +778,15 @@ __global__ void k_denorm_spec(const float* __restrict__ x, const float* __restri
         if (mask) v = __fmul_rn(v, mask[(size_t)b * T + t0 + tt]);
         dst[i] = v;
     }
+}
+
+// bsum[c] = sum_l b2[l][C + c]: the skip halves of all output_projection biases (added once, in the head)
+__global__ void k_sum_skip_bias(const float* __restrict__ b2all, float* __restrict__ bsum, int L) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= kC) return;
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += b2all[(size_t)l * 2 * kC + kC + c];
+    bsum[c] = acc;
 }
 
 __global__ void k_set_cell(const float** cell, const float* value) { *cell = value; }

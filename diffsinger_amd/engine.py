@@ -218,3 +218,14 @@ class DenoiserEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dsd_time_layer_kernel(self._h, layer, t, iters, C.byref(ms), _stream_ptr(self.device)), 'dsd_time_layer_kernel')
         return float(ms.value)
+
+    def layer_timeline(self, layer: int, t: int):
+        """Debug: per-wave shader-clock stamps [blocks, 4 waves, 8] of one launch of the layer kernel."""
+        import numpy as np
+        max_blocks = 1 << 16
+        out = np.zeros(max_blocks * 32, dtype=np.uint64)
+        n = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_debug_layer_timeline(self._h, layer, t, out.ctypes.data_as(C.POINTER(C.c_uint64)), max_blocks,
+                                                         C.byref(n), _stream_ptr(self.device)), 'dsd_debug_layer_timeline')
+        return out[:n.value * 32].reshape(n.value, 4, 8)

@@ -137,6 +137,11 @@ int dsd_set_layer_tile(dsd_handle* h, int32_t frames);
  * prepared batch.  Synchronises the stream (it is a measurement call, not part of the data path). */
 int dsd_time_layer_kernel(dsd_handle* h, int32_t layer, int32_t t, int32_t iters, float* avg_ms, void* stream);
 
+/* Debug hook: per-wave shader-clock stamps of one launch of layer `layer` (start, staged, conv done, gate done,
+ * out-proj done, end): HOST out[blocks*4*8] u64; *n_blocks = grid size.  Synchronises the stream. */
+int dsd_debug_layer_timeline(dsd_handle* h, int32_t layer, int32_t t, uint64_t* out, int32_t max_blocks, int32_t* n_blocks,
+                             void* stream);
+
 /* Introspection for tests: bytes of device memory owned by the handle; frames/workgroup currently selected. */
 int64_t dsd_device_bytes(dsd_handle* h);
 int dsd_get_layer_tile(dsd_handle* h);
