@@ -133,8 +133,10 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
 int dsd_set_layer_tile(dsd_handle* h, int32_t frames);
 
 /* Measurement hook for bench.py's roofline object: average device time (ms, hipEvents on the stream the
- * kernel is launched on) of `iters` launches of ONE residual-layer kernel (layer `layer`, step t) on the
- * prepared batch.  Synchronises the stream (it is a measurement call, not part of the data path). */
+ * kernels run on) per launch of `iters` residual-layer kernel launches (step t) on the prepared batch, replayed
+ * as nodes of one hipGraph exactly like the sampling loop issues them.  layer >= 0: that layer only; layer < 0:
+ * the non-last layers 0..L-2 in order, as in one denoiser evaluation.  The figure includes the inter-kernel
+ * dispatch gap (~1.3 us).  Synchronises the stream (a measurement call, not part of the data path). */
 int dsd_time_layer_kernel(dsd_handle* h, int32_t layer, int32_t t, int32_t iters, float* avg_ms, void* stream);
 
 /* Debug hook: per-wave shader-clock stamps of one launch of layer `layer` (start, staged, conv done, gate done,

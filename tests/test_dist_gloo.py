@@ -1,0 +1,91 @@
+"""CPU, world_size 2 over gloo: the utterance sharding + single-gather collation of diffsinger_amd/dist.py
+(SURVEY.md section 8e).  The per-rank "model" is a stand-in with the `inference(cond, **kw) -> [B,T,M]` surface of
+GaussianDiffusion: what is under test is the host logic (r::W sharding, micro-batching, padding of uneven
+shards, original-order reassembly), which is identical on RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffsinger_amd.dist import gather_mels, shard_indices, sharded_inference, unshard_order
+
+
+class _FakeSampler:
+    """mel[b, t, m] = mean(cond[b]) + 0.001 * m + x_T[b, 0, m, t]: depends on the utterance only, so the
+    gathered result can be checked against a single-process run."""
+    mel_bins = 5
+
+    def inference(self, cond, x_T=None):
+        B, H, T = cond.shape
+        base = cond.mean(dim=(1, 2))[:, None, None] + 0.001 * torch.arange(self.mel_bins)[None, None, :]
+        out = base.expand(B, T, self.mel_bins).clone()
+        if x_T is not None:
+            out = out + x_T[:, 0].transpose(1, 2)
+        return out
+
+
+def _inputs(n_items, T=7, H=4):
+    g = torch.Generator().manual_seed(11)
+    conds = [torch.randn(H, T, generator=g) for _ in range(n_items)]
+    x_T = torch.randn(n_items, 1, _FakeSampler.mel_bins, T, generator=g)
+    return conds, x_T
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_items, micro_batch, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        conds, x_T = _inputs(n_items)
+        out = sharded_inference(_FakeSampler(), conds, micro_batch=micro_batch, dst=0, x_T=lambda idx: x_T[idx])
+        if rank == 0:
+            q.put(out)
+        else:
+            assert out is None
+        # raw gather with uneven shards (rank 1 has one item fewer when n_items is odd)
+        mine = shard_indices(n_items, rank, world)
+        local = torch.stack([torch.full((3, 2), float(i)) for i in mine]) if mine else torch.zeros(0, 3, 2)
+        got = gather_mels(local, n_items, dst=0)
+        if rank == 0:
+            assert got.shape == (n_items, 3, 2)
+            assert torch.equal(got[:, 0, 0], torch.arange(n_items, dtype=torch.float32))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_items,micro_batch', [(5, 2), (8, 3), (1, 4)])
+def test_sharded_inference_world2_matches_single_process(n_items, micro_batch):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, micro_batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    conds, x_T = _inputs(n_items)
+    want = _FakeSampler().inference(torch.stack(conds), x_T=x_T)
+    assert torch.equal(got, want)
+
+
+def test_shard_maps_are_a_partition():
+    for n in (0, 1, 7, 16):
+        for w in (1, 2, 3, 8):
+            parts = [shard_indices(n, r, w) for r in range(w)]
+            flat = [i for p in parts for i in p]
+            assert sorted(flat) == list(range(n))
+            inv = unshard_order(n, w)
+            assert [flat[inv[i]] for i in range(n)] == list(range(n))
