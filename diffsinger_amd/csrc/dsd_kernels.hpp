@@ -122,12 +122,18 @@ struct GemmPipe {
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NMB * NB - NMB - 2 * NB, 0);
     }
-    __device__ __forceinline__ void start() {
+    // The A prefetch depends on nothing the kernel computes: start_a() may be issued long before the B tile is
+    // ready (before staging / before the gate), so the first-touch latency of the weight stream is off the critical path.
+    __device__ __forceinline__ void start_a() {
 #pragma unroll
         for (int i = 0; i < STAGES - 1; ++i) lda(a[i], i);
+        DSD_SB();
+    }
+    __device__ __forceinline__ void start_b() {
         ldb(b[0], 0);
         DSD_SB();
     }
+    __device__ __forceinline__ void start() { start_a(); start_b(); }
     template <int I>
     __device__ __forceinline__ void step(f32x16 (&acc)[NMB][NB], int kc) {
         lda(a[(I + STAGES - 1) % STAGES], kc + I + STAGES - 1);
@@ -209,40 +215,72 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
     if (p.dbg) ts0 = __builtin_amdgcn_s_memtime();
 
+    // 0. conv operand pipeline (its A prefetch is issued inside the staging block below)
+    const int dil = p.dil;
+    const float* yl = ytile + 4 * h * LD + kHalo + j;
+    auto bof1 = [&](int kc) { return yl + (kc & 31) * (8 * LD) + ((kc >> 5) - 1) * dil; };
+    GemmPipe<4, NB, LD, 256, (NB == 1 ? 6 : 3), decltype(bof1)> pipe1(p.w1p + (size_t)w * (96 * 256) + lane, 96, bof1);
+
     // 1. stage y = x + step_proj into LDS (zero outside [0,T): the conv's zero padding applies to y, net.py:69-71):
     //    the tile itself with contiguous float4 loads, plus 8 halo frames from each neighbouring tile
     const float* __restrict__ xt = p.x_in + (size_t)tile0 * TILE;
+    {
+        // all global loads of the tile and its halos are issued before the first LDS write (one latency, not twelve)
+        float4 xv[8 * NB], hv[4];
+        float dv[8 * NB], dh[4];
 #pragma unroll
-    for (int it = 0; it < 8 * NB; ++it) {
-        const int nbi = it >> 3;
-        const int rem = (it & 7) * kThreads + tid;
-        const int row = rem >> 3, q = rem & 7;
-        const int t = t0 + 32 * nbi + 4 * q;
-        const bool ok = nbi < ntv;
-        float4 v = *reinterpret_cast<const float4*>(xt + (ok ? nbi : 0) * TILE + row * 32 + 4 * q);
-        const float d = dsl[row];
-        v.x = (ok && t + 0 < p.T) ? v.x + d : 0.f;
-        v.y = (ok && t + 1 < p.T) ? v.y + d : 0.f;
-        v.z = (ok && t + 2 < p.T) ? v.z + d : 0.f;
-        v.w = (ok && t + 3 < p.T) ? v.w + d : 0.f;
-        *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 32 * nbi + 4 * q) = v;
-    }
+        for (int it = 0; it < 8 * NB; ++it) {
+            const int nbi = it >> 3;
+            const int rem = (it & 7) * kThreads + tid;
+            const int row = rem >> 3, q = rem & 7;
+            xv[it] = *reinterpret_cast<const float4*>(xt + ((nbi < ntv) ? nbi : 0) * TILE + row * 32 + 4 * q);
+            dv[it] = dsl[row];
+        }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = it * kThreads + tid;
-        const int row = idx >> 2, part = idx & 3;
-        const bool left = part < 2;
-        const int t = left ? t0 - kHalo + 4 * part : t0 + 32 * NB + 4 * (part - 2);
-        const int col = left ? 4 * part : kHalo + 32 * NB + 4 * (part - 2);
-        const bool have = left ? (tn * NB > 0) : (tn * NB + NB < p.ntile32);
-        const float* src = left ? xt - TILE + row * 32 + 24 + 4 * part : xt + NB * TILE + row * 32 + 4 * (part - 2);
-        float4 v = *reinterpret_cast<const float4*>(have ? src : xt + row * 32);
-        const float d = dsl[row];
-        v.x = (have && t + 0 < p.T) ? v.x + d : 0.f;
-        v.y = (have && t + 1 < p.T) ? v.y + d : 0.f;
-        v.z = (have && t + 2 < p.T) ? v.z + d : 0.f;
-        v.w = (have && t + 3 < p.T) ? v.w + d : 0.f;
-        *reinterpret_cast<float4*>(ytile + row * LD + col) = v;
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * kThreads + tid;
+            const int row = idx >> 2, part = idx & 3;
+            const bool left = part < 2;
+            const bool have = left ? (tn * NB > 0) : (tn * NB + NB < p.ntile32);
+            const float* src = left ? xt - TILE + row * 32 + 24 + 4 * part : xt + NB * TILE + row * 32 + 4 * (part - 2);
+            hv[it] = *reinterpret_cast<const float4*>(have ? src : xt + row * 32);
+            dh[it] = dsl[row];
+        }
+        DSD_SB();
+        // the conv's weight stream does not depend on x: its first chunks are requested BEHIND the tile loads (loads
+        // return in order; the start of a launch is a chip-wide ingest burst, ~11 B/cycle/CU) and land under the LDS writes
+        pipe1.start_a();
+#pragma unroll
+        for (int it = 0; it < 8 * NB; ++it) {
+            const int nbi = it >> 3;
+            const int rem = (it & 7) * kThreads + tid;
+            const int row = rem >> 3, q = rem & 7;
+            const int t = t0 + 32 * nbi + 4 * q;
+            const bool ok = nbi < ntv;
+            float4 v = xv[it];
+            const float d = dv[it];
+            v.x = (ok && t + 0 < p.T) ? v.x + d : 0.f;
+            v.y = (ok && t + 1 < p.T) ? v.y + d : 0.f;
+            v.z = (ok && t + 2 < p.T) ? v.z + d : 0.f;
+            v.w = (ok && t + 3 < p.T) ? v.w + d : 0.f;
+            *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 32 * nbi + 4 * q) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * kThreads + tid;
+            const int row = idx >> 2, part = idx & 3;
+            const bool left = part < 2;
+            const int t = left ? t0 - kHalo + 4 * part : t0 + 32 * NB + 4 * (part - 2);
+            const int col = left ? 4 * part : kHalo + 32 * NB + 4 * (part - 2);
+            const bool have = left ? (tn * NB > 0) : (tn * NB + NB < p.ntile32);
+            float4 v = hv[it];
+            const float d = dh[it];
+            v.x = (have && t + 0 < p.T) ? v.x + d : 0.f;
+            v.y = (have && t + 1 < p.T) ? v.y + d : 0.f;
+            v.z = (have && t + 2 < p.T) ? v.z + d : 0.f;
+            v.w = (have && t + 3 < p.T) ? v.w + d : 0.f;
+            *reinterpret_cast<float4*>(ytile + row * LD + col) = v;
+        }
     }
     __syncthreads();
     if (p.dbg) ts1 = __builtin_amdgcn_s_memtime();
@@ -259,12 +297,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
     float4 cpv[4][NB][4];
     {
-        const float4* ap = p.w1p + (size_t)w * (96 * 256) + lane;
-        const float* yl = ytile + 4 * h * LD + kHalo + j;
-        const int d = p.dil;
-        auto bof = [&](int kc) { return yl + (kc & 31) * (8 * LD) + ((kc >> 5) - 1) * d; };
-        GemmPipe<4, NB, LD, 256, (NB == 1 ? 6 : 3), decltype(bof)> pipe(ap, 96, bof);
-        pipe.start();
+        auto& pipe = pipe1;
+        pipe.start_b();
         pipe.run(acc, 0, 48);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -278,6 +312,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
         pipe.run(acc, 48, 96);
     }
     if (p.dbg) ts2 = __builtin_amdgcn_s_memtime();
+
+    // out-proj weight stream: first chunks requested before the gate arithmetic
+    constexpr int NMB2 = LAST ? 2 : 4;
+    constexpr int MB0 = LAST ? 2 : 0;
+    const float* gl = gtile + 4 * h * GLD + j;
+    auto bof2 = [&](int kc) { return gl + kc * (8 * GLD); };
+    GemmPipe<NMB2, NB, GLD, 256, (NB == 1 ? 6 : 3), decltype(bof2)> pipe2(p.w2p + (size_t)w * (32 * 256) + MB0 * 64 + lane, 32, bof2);
+    pipe2.start_a();
 
     // 3. gate in registers: rows [64w,64w+64) are gates, their partners (row blocks 2,3) the filters (net.py:73-74)
 #pragma unroll
@@ -296,8 +338,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     // 4. output projection (K = 256): row blocks 0,1 = residual rows, 2,3 = skip rows.  The last layer's
     //    residual half is dead (net.py:126 only reads the skips) and is not computed.  x (row layout of the
     //    transposed epilogue), the residual bias and the running skip sum are fetched behind the first chunks.
-    constexpr int NMB2 = LAST ? 2 : 4;
-    constexpr int MB0 = LAST ? 2 : 0;
     f32x16 acc2[NMB2][NB];
 #pragma unroll
     for (int m = 0; m < NMB2; ++m)
@@ -308,11 +348,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     float4 xrow[NB][8], skp[2][NB][4];
     float brow[8];
     {
-        const float4* ap = p.w2p + (size_t)w * (32 * 256) + MB0 * 64 + lane;
-        const float* gl = gtile + 4 * h * GLD + j;
-        auto bof = [&](int kc) { return gl + kc * (8 * GLD); };
-        GemmPipe<NMB2, NB, GLD, 256, (NB == 1 ? 6 : 3), decltype(bof)> pipe(ap, 32, bof);
-        pipe.start();
+        auto& pipe = pipe2;
+        pipe.start_b();
         pipe.run(acc2, 0, 6);
         if (!LAST) {
 #pragma unroll

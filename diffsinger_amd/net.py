@@ -72,6 +72,7 @@ class DiffNet(nn.Module):
         self._engine = None
         self._weights_tag = None
         self._cond_tag = None
+        self._cond_ref = None
 
     # -- engine management -----------------------------------------------------------------------------------
     def _tag(self):
@@ -90,16 +91,20 @@ class DiffNet(nn.Module):
         if tag != self._weights_tag:
             self._engine.load_weights(self.state_dict())
             self._weights_tag = tag
-            self._cond_tag = None
+            self._cond_tag = self._cond_ref = None
         return self._engine
 
     def bind_cond(self, cond: torch.Tensor) -> DenoiserEngine:
         """Hoist the conditioner projections for `cond` (once per utterance batch, not once per step)."""
         eng = self.engine()
+        # The projections are cached per cond TENSOR: same storage address, same version counter, same view.  The
+        # tensor is kept referenced while cached - otherwise the caching allocator may hand its address to a
+        # different conditioner (same pointer, version 0, same shape) and the stale projections would be reused.
         tag = (cond.data_ptr(), cond._version, tuple(cond.shape), cond.stride())
-        if tag != self._cond_tag or eng.prepared_shape != (cond.shape[0], cond.shape[2]):
+        if self._cond_ref is None or tag != self._cond_tag or eng.prepared_shape != (cond.shape[0], cond.shape[2]):
             eng.prepare(cond)
             self._cond_tag = tag
+            self._cond_ref = cond
         return eng
 
     def forward(self, spec, diffusion_step, cond):
