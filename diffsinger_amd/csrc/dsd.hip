@@ -262,18 +262,18 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
     hipStream_t s = (hipStream_t)stream;
     const int L = h->L, M = h->M;
     if (!h->w1p) {
-        DSD_TRY(dev_alloc(h, &h->w1p, (size_t)L * 4 * 96 * 256));
-        DSD_TRY(dev_alloc(h, &h->w2p, (size_t)L * 4 * 32 * 256));
-        DSD_TRY(dev_alloc(h, &h->wcp, (size_t)L * 4 * 32 * 256));
+        DSD_TRY(dev_alloc(h, &h->w1p, (size_t)L * 4 * 96 * 256 + kWeightSlack));
+        DSD_TRY(dev_alloc(h, &h->w2p, (size_t)L * 4 * 32 * 256 + kWeightSlack));
+        DSD_TRY(dev_alloc(h, &h->wcp, (size_t)L * 4 * 32 * 256 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->b1p, (size_t)L * 4 * 4 * 8));
         DSD_TRY(dev_alloc(h, &h->bskp, (size_t)4 * 2 * 8));
         DSD_TRY(dev_alloc(h, &h->b2raw, (size_t)L * 2 * kC));
         DSD_TRY(dev_alloc(h, &h->bsum, (size_t)kC));
-        DSD_TRY(dev_alloc(h, &h->winp, (size_t)4 * h->nk_in * 128));
+        DSD_TRY(dev_alloc(h, &h->winp, (size_t)4 * h->nk_in * 128 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->binp, (size_t)4 * 2 * 8));
-        DSD_TRY(dev_alloc(h, &h->wsp, (size_t)4 * 32 * 128));
+        DSD_TRY(dev_alloc(h, &h->wsp, (size_t)4 * 32 * 128 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->bsp, (size_t)4 * 2 * 8));
-        DSD_TRY(dev_alloc(h, &h->woutp, (size_t)32 * 3 * 64));
+        DSD_TRY(dev_alloc(h, &h->woutp, (size_t)32 * 3 * 64 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->boutp, (size_t)3 * 8));
         DSD_TRY(dev_alloc(h, &h->mlp0_w, (size_t)4 * kC * kC));
         DSD_TRY(dev_alloc(h, &h->mlp0_b, (size_t)4 * kC));
@@ -747,9 +747,27 @@ extern "C" int dsd_debug_layer_timeline(dsd_handle* h, int32_t layer, int32_t t,
     if (blocks > max_blocks) return fail(DSD_ERR_INVALID, "dsd_debug_layer_timeline: %d blocks > buffer %d", blocks, max_blocks);
     unsigned long long* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, (size_t)blocks * 32 * 8));
-    for (int i = 0; i < 3; ++i) DSD_TRY(launch_layer(h, layer, t, nullptr, s));
-    DSD_TRY(launch_layer(h, layer, t, nullptr, s, d));
-    HIP_TRY(hipStreamSynchronize(s));
+    // stamped launch as the LAST node of a small hipGraph (preceded by the layers that precede it in an evaluation),
+    // so the stamps see the cache / dispatch conditions of the sampling loop rather than those of eager launches
+    {
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = DSD_OK;
+        for (int l = std::max(0, layer - 3); l < layer && rc == DSD_OK; ++l) rc = launch_layer(h, l, t, nullptr, h->cap_stream);
+        if (rc == DSD_OK) rc = launch_layer(h, layer, t, nullptr, h->cap_stream, d);
+        const hipError_t ec = hipStreamEndCapture(h->cap_stream, &g);
+        if (rc != DSD_OK) { if (g) (void)hipGraphDestroy(g); (void)hipFree(d); return rc; }
+        if (ec != hipSuccess) { (void)hipFree(d); return fail(DSD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ec)); }
+        hipGraphExec_t ge = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) { (void)hipFree(d); return fail(DSD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ei)); }
+        hipError_t e = hipGraphLaunch(ge, s);
+        if (e == hipSuccess) e = hipGraphLaunch(ge, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipGraphExecDestroy(ge);
+        if (e != hipSuccess) { (void)hipFree(d); return fail(DSD_ERR_HIP, "dsd_debug_layer_timeline: %s", hipGetErrorString(e)); }
+    }
     HIP_TRY(hipMemcpy(out, d, (size_t)blocks * 32 * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d);
     *n_blocks = blocks;

@@ -35,6 +35,7 @@ constexpr int kC = 256;        // residual_channels == encoder_hidden on this bu
 constexpr int kHalo = 8;       // max dilation supported (dilation_cycle_length <= 4)
 constexpr int kMPad = 96;      // mel bins padded to 3 MFMA row blocks
 constexpr int kThreads = 256;  // 4 waves, one per SIMD
+constexpr int kWeightSlack = 8192;   // float4 of slack behind every packed weight buffer (A prefetch overrun: <= 5 chunks x 4 KiB + row blocks)
 
 // C/D fragment map of v_mfma_f32_32x32x2_f32: lane (j = lane & 31, h = lane >> 5), register r in [0,16)
 // holds D[row = (r & 3) + 8 (r >> 2) + 4 h][col = j].
@@ -88,21 +89,35 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NMB][NB], const float4 (
 template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff>
 struct GemmPipe {
     static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
-    const float4* __restrict__ ap;
+    __amdgpu_buffer_rsrc_t rsrc;   // buffer descriptor over this wave's A stream (wave-uniform base = chunk 0 / row block 0)
+    unsigned aoff;                 // this lane's byte offset inside a 1 KiB fragment row (lane * 16)
     int n;
     BOff bof;
     float4 a[STAGES][NMB];
     float b[2][4][NB];
 
-    __device__ __forceinline__ GemmPipe(const float4* ap_, int n_, BOff bof_) : ap(ap_), n(n_), bof(bof_) {}
+    __device__ __forceinline__ GemmPipe(const float4* abase_uniform, int lane, int n_, BOff bof_)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(abase_uniform), 0, 0x7ffffff0, 0x00020000)),
+          aoff((unsigned)lane * 16u), n(n_), bof(bof_) {}
 
+    // buffer_load_dwordx4 v, voffset(lane), rsrc, soffset(chunk) offset:imm(row block): the chunk walk is one SALU
+    // value, there is no per-lane 64-bit address arithmetic in the loop.  Prefetches run up to STAGES-1 chunks past
+    // the end of the stream: the weight buffers carry that much slack (kWeightSlack) and the values are never used.
     __device__ __forceinline__ void lda(float4 (&dst)[NMB], int kc) {
-        const float4* p = ap + (size_t)((kc < n) ? kc : n - 1) * ASTRIDE;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int soff = kc * (ASTRIDE * 16);
 #pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) dst[mb] = p[mb * 64];
+        for (int mb = 0; mb < NMB; ++mb) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff + mb * 1024, soff, 0);
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 f = __builtin_bit_cast(f32x4, v);      // whole-vector cast (element-wise bit_cast of v.x miscompiles)
+            dst[mb] = make_float4(f.x, f.y, f.z, f.w);
+        }
     }
-    __device__ __forceinline__ void ldb(float (&dst)[4][NB], int kc) {
-        const float* bp = bof((kc < n) ? kc : n - 1);
+    // B fragment of chunk 6*it + u (u is a compile-time constant at every call site, so the functor can fold the
+    // part of the address that depends on u into the ds_read immediate)
+    __device__ __forceinline__ void ldb(float (&dst)[4][NB], int it, int u) {
+        const float* bp = bof(it, u);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -130,14 +145,14 @@ struct GemmPipe {
         DSD_SB();
     }
     __device__ __forceinline__ void start_b() {
-        ldb(b[0], 0);
+        ldb(b[0], 0, 0);
         DSD_SB();
     }
     __device__ __forceinline__ void start() { start_a(); start_b(); }
     template <int I>
-    __device__ __forceinline__ void step(f32x16 (&acc)[NMB][NB], int kc) {
-        lda(a[(I + STAGES - 1) % STAGES], kc + I + STAGES - 1);
-        ldb(b[(I + 1) & 1], kc + I + 1);
+    __device__ __forceinline__ void step(f32x16 (&acc)[NMB][NB], int it) {
+        lda(a[(I + STAGES - 1) % STAGES], 6 * it + I + STAGES - 1);
+        ldb(b[(I + 1) & 1], it, I + 1);
         mma_chunk<NMB, NB>(acc, a[I % STAGES], b[I & 1]);
         pattern();
         DSD_SB();
@@ -145,25 +160,36 @@ struct GemmPipe {
     // chunks [begin, end); begin must be a multiple of 6 (register rotation period); may be called repeatedly to
     // place unrelated loads between two parts of one K loop without draining the pipeline
     __device__ __forceinline__ void run(f32x16 (&acc)[NMB][NB], int begin, int end) {
-        for (int kc = begin; kc < end; kc += 6) {
-            step<0>(acc, kc);
+        for (int it = begin / 6; 6 * it < end; ++it) {
+            const int kc = 6 * it;
+            step<0>(acc, it);
             if (kc + 1 >= end) break;
-            step<1>(acc, kc);
+            step<1>(acc, it);
             if (kc + 2 >= end) break;
-            step<2>(acc, kc);
+            step<2>(acc, it);
             if (kc + 3 >= end) break;
-            step<3>(acc, kc);
+            step<3>(acc, it);
             if (kc + 4 >= end) break;
-            step<4>(acc, kc);
+            step<4>(acc, it);
             if (kc + 5 >= end) break;
-            step<5>(acc, kc);
+            step<5>(acc, it);
         }
     }
 };
 
+// B functor of a plain [k][frame] LDS tile: chunk kc at base + kc * 8 rows (clamped: the prefetch of the chunk behind
+// the last one must stay inside the tile)
+struct TileB {
+    const float* base; int row8, n;
+    __device__ __forceinline__ const float* operator()(int it, int u) const {
+        const int kc = 6 * it + u;
+        return base + ((kc < n) ? kc : n - 1) * row8;
+    }
+};
+
 template <int NMB, int NB, int LD, int ASTRIDE, typename BOff>
-__device__ __forceinline__ void gemm_k(f32x16 (&acc)[NMB][NB], const float4* __restrict__ ap, int n, BOff bof) {
-    GemmPipe<NMB, NB, LD, ASTRIDE, 6, BOff> pipe(ap, n, bof);
+__device__ __forceinline__ void gemm_k(f32x16 (&acc)[NMB][NB], const float4* __restrict__ abase_uniform, int lane, int n, BOff bof) {
+    GemmPipe<NMB, NB, LD, ASTRIDE, 6, BOff> pipe(abase_uniform, lane, n, bof);
     pipe.start();
     pipe.run(acc, 0, n);
 }
@@ -176,7 +202,7 @@ __device__ __forceinline__ void gemm_k(f32x16 (&acc)[NMB][NB], const float4* __r
 struct LayerParams {
     const float* x_in;      // [tiles][C][32]
     float* x_out;           // [tiles][C][32]
-    const float4* w1p;      // dilated conv, packed [w4][kc96][mb4][lane64] float4
+    const float4* w1p;      // dilated conv, packed [w4][kc96 = 3 * k8 + tap][mb4][lane64] float4
     const float4* w2p;      // output projection, packed [w4][kc32][mb4][lane64]
     const float* b2;        // output projection bias [2C] (residual half used here; the skip half is summed over
                             // layers once and added in the head)
@@ -212,14 +238,17 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     const int ntv = min(NB, p.ntile32 - tn * NB);         // valid 32-frame tiles of this workgroup
     const int tstep = p.t_dev ? p.t_dev[b] : p.t_uniform;
     const float* __restrict__ dsl = p.ds + (size_t)tstep * p.ds_tstride;
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
     if (p.dbg) ts0 = __builtin_amdgcn_s_memtime();
 
     // 0. conv operand pipeline (its A prefetch is issued inside the staging block below)
+    // K order of the dilated conv: chunk kc = 3 * k8 + tap (the three taps of one 8-channel group are consecutive), so
+    // inside a 6-chunk rotation the B address is {tap base} + it * 16 rows + a compile-time constant
     const int dil = p.dil;
     const float* yl = ytile + 4 * h * LD + kHalo + j;
-    auto bof1 = [&](int kc) { return yl + (kc & 31) * (8 * LD) + ((kc >> 5) - 1) * dil; };
-    GemmPipe<4, NB, LD, 256, (NB == 1 ? 6 : 3), decltype(bof1)> pipe1(p.w1p + (size_t)w * (96 * 256) + lane, 96, bof1);
+    const float* ytap[3] = {yl - dil, yl, yl + dil};
+    auto bof1 = [&](int it, int u) { return ytap[u % 3] + it * (16 * LD) + (u / 3) * (8 * LD); };
+    GemmPipe<4, NB, LD, 256, (NB == 1 ? 6 : 3), decltype(bof1)> pipe1(p.w1p + (size_t)w * (96 * 256), lane, 96, bof1);
 
     // 1. stage y = x + step_proj into LDS (zero outside [0,T): the conv's zero padding applies to y, net.py:69-71):
     //    the tile itself with contiguous float4 loads, plus 8 halo frames from each neighbouring tile
@@ -247,6 +276,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
             dh[it] = dsl[row];
         }
         DSD_SB();
+        if (p.dbg) tsa = __builtin_amdgcn_s_memtime();
         // the conv's weight stream does not depend on x: its first chunks are requested BEHIND the tile loads (loads
         // return in order; the start of a launch is a chip-wide ingest burst, ~11 B/cycle/CU) and land under the LDS writes
         pipe1.start_a();
@@ -281,6 +311,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
             v.w = (have && t + 3 < p.T) ? v.w + d : 0.f;
             *reinterpret_cast<float4*>(ytile + row * LD + col) = v;
         }
+        if (p.dbg) tsb = __builtin_amdgcn_s_memtime();
     }
     __syncthreads();
     if (p.dbg) ts1 = __builtin_amdgcn_s_memtime();
@@ -317,8 +348,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     constexpr int NMB2 = LAST ? 2 : 4;
     constexpr int MB0 = LAST ? 2 : 0;
     const float* gl = gtile + 4 * h * GLD + j;
-    auto bof2 = [&](int kc) { return gl + kc * (8 * GLD); };
-    GemmPipe<NMB2, NB, GLD, 256, (NB == 1 ? 6 : 3), decltype(bof2)> pipe2(p.w2p + (size_t)w * (32 * 256) + MB0 * 64 + lane, 32, bof2);
+    const TileB bof2{gl, 8 * GLD, 32};
+    GemmPipe<NMB2, NB, GLD, 256, (NB == 1 ? 6 : 3), TileB> pipe2(p.w2p + (size_t)w * (32 * 256) + MB0 * 64, lane, 32, bof2);
     pipe2.start_a();
 
     // 3. gate in registers: rows [64w,64w+64) are gates, their partners (row blocks 2,3) the filters (net.py:73-74)
@@ -417,7 +448,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     }
     if (p.dbg && lane == 0) {
         unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + w) * 8;
-        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = __builtin_amdgcn_s_memtime();
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = __builtin_amdgcn_s_memtime(); d[6] = tsa; d[7] = tsb;
     }
 }
 
@@ -453,9 +484,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_condproj(const CondProjParams p
 #pragma unroll
         for (int q = 0; q < 4; ++q) set4(acc[mb][0], q, bl[mb * 8 + q]);
     __syncthreads();
-    const float4* ap = p.wcp + ((size_t)l * 4 + w) * (32 * 256) + lane;
+    const float4* ap = p.wcp + ((size_t)l * 4 + w) * (32 * 256);
     const float* cl = smem + 4 * h * LD + j;
-    gemm_k<4, 1, LD, 256>(acc, ap, 32, [&](int kc) { return cl + kc * (8 * LD); });
+    gemm_k<4, 1, LD, 256>(acc, ap, lane, 32, TileB{cl, 8 * LD, 32});
     float4* out = p.cp + (((size_t)l * p.ntiles_total + tile) * 4 + w) * (4 * 4 * 64) + lane;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -475,9 +506,9 @@ __device__ __forceinline__ void inproj_tile(const float* ptile, const float4* __
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) set4(acc[mb][0], q, binp[((w * 2 + mb) * 2 + h) * 4 + q]);
-    const float4* ap = winp + (size_t)w * nk * 128 + lane;
+    const float4* ap = winp + (size_t)w * nk * 128;
     const float* pl = ptile + 4 * h * 32 + j;
-    gemm_k<2, 1, 32, 128>(acc, ap, nk, [&](int kc) { return pl + kc * (8 * 32); });
+    gemm_k<2, 1, 32, 128>(acc, ap, lane, nk, TileB{pl, 8 * 32, nk});
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -570,9 +601,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_head(const HeadParams p) {
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) set4(acc[mb][0], q, p.bsp[((w * 2 + mb) * 2 + h) * 4 + q]);
-        const float4* ap = p.wsp + (size_t)w * (32 * 128) + lane;
+        const float4* ap = p.wsp + (size_t)w * (32 * 128);
         const float* sl = stile + 4 * h * 32 + j;
-        gemm_k<2, 1, 32, 128>(acc, ap, 32, [&](int kc) { return sl + kc * (8 * 32); });
+        gemm_k<2, 1, 32, 128>(acc, ap, lane, 32, TileB{sl, 8 * 32, 32});
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -585,9 +616,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_head(const HeadParams p) {
         f32x16 acc[1][1];
 #pragma unroll
         for (int q = 0; q < 4; ++q) set4(acc[0][0], q, p.boutp[(w * 2 + h) * 4 + q]);
-        const float4* ap = p.woutp + (size_t)w * 64 + lane;
+        const float4* ap = p.woutp + (size_t)w * 64;
         const float* hl = htile + 4 * h * 32 + j;
-        gemm_k<1, 1, 32, 192>(acc, ap, 32, [&](int kc) { return hl + kc * (8 * 32); });
+        gemm_k<1, 1, 32, 192>(acc, ap, lane, 32, TileB{hl, 8 * 32, 32});
         const int t = t0 + j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -665,7 +696,7 @@ __global__ void k_pack_a(const PackParams p) {
         const int mb = r % p.nmb; r /= p.nmb;
         const int kct = r % (p.ntap * p.nkc); r /= (p.ntap * p.nkc);
         const int w = (int)r;
-        const int tap = kct / p.nkc, kc = kct % p.nkc;
+        const int tap = kct % p.ntap, kc = kct / p.ntap;      // taps of one 8-deep k group are consecutive chunks
         const int i = lane & 31, h = lane >> 5;
         int row;
         if (p.split) {

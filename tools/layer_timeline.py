@@ -20,5 +20,6 @@ for layer in (3, 19):
     print('  start skew   : mean %.0f max %.0f' % (rel[:, :, 0].mean(), rel[:, :, 0].max()))
     for i, n in enumerate(['stage(cp+x->LDS,barrier)', 'conv K=768', 'gate+barrier', 'outproj K=256', 'epilogue']):
         print('  %-26s: mean %8.0f  min %8.0f  max %8.0f' % (n, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max()))
+    print('  stage split   : loads issued %.0f, last LDS write %.0f, barrier released %.0f (cycles after start, mean)' % ((ts[:, :, 6] - ts[:, :, 0]).mean(), (ts[:, :, 7] - ts[:, :, 0]).mean(), (ts[:, :, 1] - ts[:, :, 0]).mean()))
     print('  wave lifetime : mean %.0f ; last end %.0f' % ((rel[:, :, 5] - rel[:, :, 0]).mean(), rel[:, :, 5].max()))
     print('  layer ms (events):', eng.time_layer_kernel(layer, 50, 50))
