@@ -451,7 +451,7 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
     p.dil = h->dil[l];
     p.first = (l == 0);
     p.dbg = dbg;
-    const dim3 grid((unsigned)(h->B * p.tiles_per_utt));
+    const dim3 grid((unsigned)p.tiles_per_utt, (unsigned)h->B);
     const bool last = (l == h->L - 1);
     if (nb == 1) {
         if (last) hipLaunchKernelGGL((k_layer<1, true>), grid, dim3(kThreads), layer_lds_bytes<1>(), s, p);

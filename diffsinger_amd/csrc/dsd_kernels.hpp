@@ -139,9 +139,10 @@ struct GemmPipe {
     }
     // The A prefetch depends on nothing the kernel computes: start_a() may be issued long before the B tile is
     // ready (before staging / before the gate), so the first-touch latency of the weight stream is off the critical path.
+    template <int FROM = 0, int TO = STAGES - 1>
     __device__ __forceinline__ void start_a() {
 #pragma unroll
-        for (int i = 0; i < STAGES - 1; ++i) lda(a[i], i);
+        for (int i = FROM; i < TO; ++i) lda(a[i], i);
         DSD_SB();
     }
     __device__ __forceinline__ void start_b() {
@@ -230,95 +231,107 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     float* gtile = smem + kC * LD;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / p.tiles_per_utt, tn = blockIdx.x % p.tiles_per_utt;
-    const int t0 = tn * 32 * NB;
+    // grid = (tiles per utterance, utterances): no integer division on the way to the first load
+    const int b = blockIdx.y, tn = blockIdx.x;
     const int tile0 = b * p.ntile32 + tn * NB;
     const int ntv = min(NB, p.ntile32 - tn * NB);         // valid 32-frame tiles of this workgroup
-    const int tstep = p.t_dev ? p.t_dev[b] : p.t_uniform;
-    const float* __restrict__ dsl = p.ds + (size_t)tstep * p.ds_tstride;
+    const float* __restrict__ xt = p.x_in + (size_t)tile0 * TILE;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
     if (p.dbg) ts0 = __builtin_amdgcn_s_memtime();
 
-    // 0. conv operand pipeline (its A prefetch is issued inside the staging block below)
-    // K order of the dilated conv: chunk kc = 3 * k8 + tap (the three taps of one 8-channel group are consecutive), so
-    // inside a 6-chunk rotation the B address is {tap base} + it * 16 rows + a compile-time constant
+    // 1. Progressive staging.  y = x + step_proj goes to LDS (zero outside [0,T): the conv's zero padding applies to y,
+    //    net.py:69-71) in four 64-channel quarters; the conv's K order (chunk = 3 * k8 + tap) consumes the channels in
+    //    that same order, so only the FIRST quarter (8 KiB of the tile + 4 KiB of halo) and the first weight chunks are on
+    //    the critical path of the launch - the start of a launch is a chip-wide ingest burst (~10 B/cycle/CU) and the
+    //    whole 48 KiB would cost ~9 k cycles before the first MFMA.  Quarter q+1 is written (one barrier) 6 chunks before
+    //    the loop's B prefetch first touches it.
+    //    Thread tid reads bytes [16 tid, 16 tid + 16) of every 4 KiB slab: the tile is one linear 32 KiB block
+    //    (row = slab * 32 + tid / 8, columns 4 (tid & 7) .. +3); halo piece q covers rows 64 q + tid / 4.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xt), 0, 0x7ffffff0, 0x00020000);
+    float4 xv[NB][8], hv[4];
+    float dv[8], dh[4];
+    auto load_x = [&](int slab) {
+#pragma unroll
+        for (int nbi = 0; nbi < NB; ++nbi) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, tid * 16, ((nbi < ntv) ? nbi : 0) * (TILE * 4) + slab * 4096, 0);
+            const f32x4 f = __builtin_bit_cast(f32x4, v);
+            xv[nbi][slab] = make_float4(f.x, f.y, f.z, f.w);
+        }
+    };
+    load_x(0);
+    load_x(1);
+    DSD_SB();
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = tn * 32 * NB;
+    const int tstep = p.t_dev ? p.t_dev[b] : p.t_uniform;
+    const float* __restrict__ dsl = p.ds + (size_t)tstep * p.ds_tstride;
+    const int hpart = tid & 3;
+    const bool hleft = hpart < 2;
+    const bool hhave = hleft ? (tn * NB > 0) : (tn * NB + NB < p.ntile32);
+    auto load_h = [&](int q) {
+        const int row = 64 * q + (tid >> 2);
+        const float* src = hleft ? xt - TILE + row * 32 + 24 + 4 * hpart : xt + NB * TILE + row * 32 + 4 * (hpart - 2);
+        hv[q] = *reinterpret_cast<const float4*>(hhave ? src : xt + row * 32);
+        dh[q] = dsl[row];
+        dv[2 * q] = dsl[(2 * q) * 32 + (tid >> 3)];
+        dv[2 * q + 1] = dsl[(2 * q + 1) * 32 + (tid >> 3)];
+    };
+    load_h(0);
+    DSD_SB();
+
+    // conv operand pipeline.  K order of the dilated conv: chunk kc = 3 * k8 + tap (the three taps of one 8-channel group
+    // are consecutive), so inside a 6-chunk rotation the B address is {tap base} + it * 16 rows + a compile-time constant.
+    // Its weight stream does not depend on x: the first chunks are requested right behind the first quarter.
     const int dil = p.dil;
     const float* yl = ytile + 4 * h * LD + kHalo + j;
     const float* ytap[3] = {yl - dil, yl, yl + dil};
     auto bof1 = [&](int it, int u) { return ytap[u % 3] + it * (16 * LD) + (u / 3) * (8 * LD); };
     GemmPipe<4, NB, LD, 256, (NB == 1 ? 6 : 3), decltype(bof1)> pipe1(p.w1p + (size_t)w * (96 * 256), lane, 96, bof1);
+    constexpr int ST1 = (NB == 1 ? 6 : 3);
+    pipe1.template start_a<0, 2>();
+    if (p.dbg) tsa = __builtin_amdgcn_s_memtime();
 
-    // 1. stage y = x + step_proj into LDS (zero outside [0,T): the conv's zero padding applies to y, net.py:69-71):
-    //    the tile itself with contiguous float4 loads, plus 8 halo frames from each neighbouring tile
-    const float* __restrict__ xt = p.x_in + (size_t)tile0 * TILE;
-    {
-        // all global loads of the tile and its halos are issued before the first LDS write (one latency, not twelve)
-        float4 xv[8 * NB], hv[4];
-        float dv[8 * NB], dh[4];
+    auto write_quarter = [&](int q) {
 #pragma unroll
-        for (int it = 0; it < 8 * NB; ++it) {
-            const int nbi = it >> 3;
-            const int rem = (it & 7) * kThreads + tid;
-            const int row = rem >> 3, q = rem & 7;
-            xv[it] = *reinterpret_cast<const float4*>(xt + ((nbi < ntv) ? nbi : 0) * TILE + row * 32 + 4 * q);
-            dv[it] = dsl[row];
-        }
+        for (int sl = 2 * q; sl < 2 * q + 2; ++sl)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = it * kThreads + tid;
-            const int row = idx >> 2, part = idx & 3;
-            const bool left = part < 2;
-            const bool have = left ? (tn * NB > 0) : (tn * NB + NB < p.ntile32);
-            const float* src = left ? xt - TILE + row * 32 + 24 + 4 * part : xt + NB * TILE + row * 32 + 4 * (part - 2);
-            hv[it] = *reinterpret_cast<const float4*>(have ? src : xt + row * 32);
-            dh[it] = dsl[row];
-        }
-        DSD_SB();
-        if (p.dbg) tsa = __builtin_amdgcn_s_memtime();
-        // the conv's weight stream does not depend on x: its first chunks are requested BEHIND the tile loads (loads
-        // return in order; the start of a launch is a chip-wide ingest burst, ~11 B/cycle/CU) and land under the LDS writes
-        pipe1.start_a();
-#pragma unroll
-        for (int it = 0; it < 8 * NB; ++it) {
-            const int nbi = it >> 3;
-            const int rem = (it & 7) * kThreads + tid;
-            const int row = rem >> 3, q = rem & 7;
-            const int t = t0 + 32 * nbi + 4 * q;
-            const bool ok = nbi < ntv;
-            float4 v = xv[it];
-            const float d = dv[it];
-            v.x = (ok && t + 0 < p.T) ? v.x + d : 0.f;
-            v.y = (ok && t + 1 < p.T) ? v.y + d : 0.f;
-            v.z = (ok && t + 2 < p.T) ? v.z + d : 0.f;
-            v.w = (ok && t + 3 < p.T) ? v.w + d : 0.f;
-            *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 32 * nbi + 4 * q) = v;
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = it * kThreads + tid;
-            const int row = idx >> 2, part = idx & 3;
-            const bool left = part < 2;
-            const int t = left ? t0 - kHalo + 4 * part : t0 + 32 * NB + 4 * (part - 2);
-            const int col = left ? 4 * part : kHalo + 32 * NB + 4 * (part - 2);
-            const bool have = left ? (tn * NB > 0) : (tn * NB + NB < p.ntile32);
-            float4 v = hv[it];
-            const float d = dh[it];
-            v.x = (have && t + 0 < p.T) ? v.x + d : 0.f;
-            v.y = (have && t + 1 < p.T) ? v.y + d : 0.f;
-            v.z = (have && t + 2 < p.T) ? v.z + d : 0.f;
-            v.w = (have && t + 3 < p.T) ? v.w + d : 0.f;
+            for (int nbi = 0; nbi < NB; ++nbi) {
+                const int row = sl * 32 + (tid >> 3), c4 = tid & 7;
+                const int t = t0 + 32 * nbi + 4 * c4;
+                const bool ok = nbi < ntv;
+                float4 v = xv[nbi][sl];
+                const float d = dv[sl];
+                v.x = (ok && t + 0 < p.T) ? v.x + d : 0.f;
+                v.y = (ok && t + 1 < p.T) ? v.y + d : 0.f;
+                v.z = (ok && t + 2 < p.T) ? v.z + d : 0.f;
+                v.w = (ok && t + 3 < p.T) ? v.w + d : 0.f;
+                *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 32 * nbi + 4 * c4) = v;
+            }
+        {
+            const int row = 64 * q + (tid >> 2);
+            const int t = hleft ? t0 - kHalo + 4 * hpart : t0 + 32 * NB + 4 * (hpart - 2);
+            const int col = hleft ? 4 * hpart : kHalo + 32 * NB + 4 * (hpart - 2);
+            float4 v = hv[q];
+            const float d = dh[q];
+            v.x = (hhave && t + 0 < p.T) ? v.x + d : 0.f;
+            v.y = (hhave && t + 1 < p.T) ? v.y + d : 0.f;
+            v.z = (hhave && t + 2 < p.T) ? v.z + d : 0.f;
+            v.w = (hhave && t + 3 < p.T) ? v.w + d : 0.f;
             *reinterpret_cast<float4*>(ytile + row * LD + col) = v;
         }
-        if (p.dbg) tsb = __builtin_amdgcn_s_memtime();
-    }
+    };
+    write_quarter(0);
+    if (p.dbg) tsb = __builtin_amdgcn_s_memtime();
     __syncthreads();
     if (p.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
-    // 2. dilated conv: K = 3 taps x 256 channels = 96 chunks; tap k reads column offset (k-1)*dil.  The hoisted
-    //    conditioner projection (+ conv bias + cond bias) is fetched from HBM halfway through the loop, when the
-    //    memory system is idle, and added once the loop is done.
+    // 2. dilated conv: K = 3 taps x 256 channels = 96 chunks of 8; tap k reads column offset (k-1)*dil.  Channel quarter q
+    //    is chunks [24 q, 24 q + 24); it is written 6 chunks early (the B prefetch runs one chunk ahead).  The hoisted
+    //    conditioner projection (+ conv bias + cond bias) is fetched halfway through the loop, when the memory system is
+    //    idle, and added once the loop is done.
     f32x16 acc[4][NB];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -328,9 +341,22 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
     float4 cpv[4][NB][4];
     {
+        // every later quarter is requested one segment (18-24 chunks, ~20 k cycles) before it is written: few loads at a
+        // time, none of them in front of the first MFMA
+        auto load_quarter = [&](int q) { load_x(2 * q); load_x(2 * q + 1); load_h(q); DSD_SB(); };
         auto& pipe = pipe1;
+        pipe.template start_a<2, ST1 - 1>();
+        load_quarter(1);
         pipe.start_b();
-        pipe.run(acc, 0, 48);
+        pipe.run(acc, 0, 18);
+        write_quarter(1);
+        __syncthreads();
+        load_quarter(2);
+        pipe.run(acc, 18, 42);
+        write_quarter(2);
+        __syncthreads();
+        load_quarter(3);
+        pipe.run(acc, 42, 48);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const float4* cpl = p.cp + ((size_t)(tile0 + ((nb < ntv) ? nb : 0)) * 4 + w) * (4 * 4 * 64) + lane;
@@ -340,7 +366,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
                 for (int q = 0; q < 4; ++q) cpv[mb][nb][q] = cpl[(mb * 4 + q) * 64];   // tiles past the end: unused columns
         }
         DSD_SB();
-        pipe.run(acc, 48, 96);
+        pipe.run(acc, 48, 66);
+        write_quarter(3);
+        __syncthreads();
+        pipe.run(acc, 66, 96);
     }
     if (p.dbg) ts2 = __builtin_amdgcn_s_memtime();
 
@@ -427,11 +456,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
                 const float4 v = reinterpret_cast<const float4*>(tw + nb * 2048)[it * 64 + lane];
                 const float4 x = xrow[nb][it];
                 const float bv = brow[it];
+                // (x + residual) / sqrt(2) as a * (1/b) in fp32 - what torch's GPU kernel does for a scalar divisor
+                // (the CPU kernel divides: <= 1 ulp apart); a correctly-rounded fp32 divide is ~10 VALU ops per element
+                constexpr float kInvSqrt2 = 1.0f / 1.41421354f;
                 float4 o;
-                o.x = __fdiv_rn(x.x + (v.x + bv), 1.41421354f);
-                o.y = __fdiv_rn(x.y + (v.y + bv), 1.41421354f);
-                o.z = __fdiv_rn(x.z + (v.z + bv), 1.41421354f);
-                o.w = __fdiv_rn(x.w + (v.w + bv), 1.41421354f);
+                o.x = (x.x + (v.x + bv)) * kInvSqrt2;
+                o.y = (x.y + (v.y + bv)) * kInvSqrt2;
+                o.z = (x.z + (v.z + bv)) * kInvSqrt2;
+                o.w = (x.w + (v.w + bv)) * kInvSqrt2;
                 reinterpret_cast<float4*>(xo)[it * 64 + lane] = o;
             }
         }
@@ -447,7 +479,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
         }
     }
     if (p.dbg && lane == 0) {
-        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + w) * 8;
+        unsigned long long* d = p.dbg + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8;
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = __builtin_amdgcn_s_memtime(); d[6] = tsa; d[7] = tsb;
     }
 }
