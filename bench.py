@@ -16,10 +16,11 @@ N > 1, the gather to rank 0.  Inputs are resident in HBM before the timed region
 The JSON line also carries
   roofline      for the dominant kernel (k_layer, one residual block): executed fp32 FLOPs per launch / average
                 launch duration measured live with HIP events on the launch stream, against the 157.3 TFLOP/s
-                dense fp32 MFMA peak (MI355X_MICROARCH.md).
+                dense fp32 MFMA peak (MI355X_MICROARCH.md); `traffic` = HBM-side bytes per launch from the committed
+                rocprofv3 --pmc passes of the same kernel and shape (profiles/layer_pmc.json).
   cpu_baseline  the CPU oracle (oracle/diffnet_oracle.py, torch fp32 = the reference's own arithmetic) timed on
-                this box's host cores on a bounded sample of the same workload (a few of the 100 steps,
-                extrapolated - every step is identical work).
+                this box's host cores on a bounded sample of the same workload (up to all 100 steps within a
+                30 s budget; extrapolated only if the budget cuts it short - every step is identical work).
   parity        max-abs error of the de-normalised mel on the golden case generated from the reference.
 """
 from __future__ import annotations
@@ -70,7 +71,7 @@ def host_cpus() -> int:
     return n
 
 
-def cpu_baseline(budget_s: float = 12.0):
+def cpu_baseline(budget_s: float = 30.0):
     """The oracle on the host cores: p_sample steps at the bench shape until ~budget_s of CPU work."""
     from oracle import diffnet_oracle as O
     from diffsinger_amd.synth import presets, make_inputs
@@ -104,14 +105,29 @@ def cpu_baseline(budget_s: float = 12.0):
             x = O.p_sample(p, cfg, sch, x, t, cond, z)
             n += 1
             el = time.perf_counter() - t0
-            if el >= budget_s or n >= 40:
+            if el >= budget_s or n >= K_STEPS:
                 break
     sec_per_step = el / n
     return {'value': B_PER_GPU * T_FRAMES / (sec_per_step * K_STEPS), 'unit': 'mel-frames/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} of {K_STEPS} DDPM steps (p_sample, B={B_PER_GPU}, T={T_FRAMES}) in {el:.1f}s on {cores} host threads '
-                      f'(best of {cands}; {avail} CPUs available, os.cpu_count()={os.cpu_count()}), '
-                      f'extrapolated x{K_STEPS} (every step is identical work)',
+                      f'(best of {cands}; {avail} CPUs available, os.cpu_count()={os.cpu_count()})'
+                      + ('' if n >= K_STEPS else f', extrapolated x{K_STEPS}/{n} (every step is identical work)'),
             'sec_per_ddpm_step': sec_per_step}
+
+
+def pmc_traffic(kernel: str, frames: int):
+    """HBM-side bytes per launch of the layer kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of tools/gpu_pmc.sh at this very shape, corrected as MI355X_MICROARCH.md prescribes; reduced by
+    tools/pmc_summary.py).  PMC counters cannot be read from inside this process, so the figure comes from the profile
+    of the same kernel + shape committed under profiles/; None when there is no matching profile."""
+    path = os.path.join(ROOT, 'profiles', 'layer_pmc.json')
+    try:
+        js = json.load(open(path))
+        if js.get('frames') != frames or js.get('kernel_tag') != kernel:
+            return None, None
+        return float(js['hbm_bytes_per_launch']['total']), f"profiles/layer_pmc.json ({js.get('round', '?')}): " + js['hbm_bytes_per_launch']['note']
+    except Exception:
+        return None, None
 
 
 def parity_check(device):
@@ -192,8 +208,11 @@ def main():
         ms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
         frames = B * T
         achieved = frames * F_LAYER_EXEC / (ms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': f'k_layer<{eng.layer_tile() // 32},false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+        kname = f'k_layer<{eng.layer_tile() // 32},false>'
+        traffic, traffic_src = pmc_traffic(kname, frames)
+        roof = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+                'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': frames * 6144 + 2 * 1024 * 1024,
                 'avg_launch_ms': ms, 'flop_per_launch': frames * F_LAYER_EXEC,
                 'achieved_ref_accounting': frames * F_LAYER_REF / (ms * 1e-3) / 1e12,
                 'note': 'achieved counts executed fp32 FLOPs of one residual-layer launch (K=768 dilated conv + K=256 output '

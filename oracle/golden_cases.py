@@ -21,5 +21,8 @@ CASES = {
     # BASELINE config 4: PNDM/PLMS, 1000-step schedule, pndm_speedup 40 (26 evaluations) and the literal
     # 4-iteration case (pndm_speedup 250, 5 evaluations); reference runs per utterance (B=1 quirk)
     'plms_opencpop_i40': dict(preset='opencpop_ds1000', kind='plms', B=2, T=64, k_step=1000, interval=40, seed=106),
+    # row a15: the legacy class usr/diff/diffusion.py::GaussianDiffusion (DiffFsTask): cosine schedule, no K_step,
+    # Gaussian start, all `timesteps` steps
+    'ddpm_legacy_cosine': dict(preset='lj_ds_beta6', kind='ddpm', B=2, T=72, k_step=100, gaussian=True, legacy=True, seed=108),
     'plms_opencpop_i250': dict(preset='opencpop_ds1000', kind='plms', B=2, T=64, k_step=1000, interval=250, seed=107),
 }

@@ -45,7 +45,10 @@ def run_case(name: str):
     ref = Reference(pre['source'])
     hp = ref.hparams
     k_step = case.get('k_step', hp['K_step'])
-    net, gd = ref.build(WEIGHT_SEED, FINAL_PROJ_STD, hp['timesteps'], k_step, hp['spec_min'], hp['spec_max'])
+    if case.get('legacy'):
+        net, gd = ref.build_legacy(WEIGHT_SEED, FINAL_PROJ_STD, hp['timesteps'], hp['spec_min'], hp['spec_max'])
+    else:
+        net, gd = ref.build(WEIGHT_SEED, FINAL_PROJ_STD, hp['timesteps'], k_step, hp['spec_min'], hp['spec_max'])
     B, T = case['B'], case['T']
     kind = case['kind']
     n_noise = k_step if kind == 'ddpm' else 0
@@ -64,7 +67,10 @@ def run_case(name: str):
                 f = gd.norm_spec(inp['fs2_mel']).transpose(1, 2)[:, None, :, :]
                 x = gd.q_sample(x_start=f, t=torch.tensor([k_step - 1]).long(), noise=inp['q_noise'])
                 out['x_start'] = x.numpy()
-            x = ref.sample_ddpm(gd, x, cond, list(inp['noise']), k_step)
+            if case.get('legacy'):
+                x = ref.sample_ddpm_legacy(gd, x, cond, list(inp['noise']))
+            else:
+                x = ref.sample_ddpm(gd, x, cond, list(inp['noise']), k_step)
             out['x_final'] = x.numpy()
             out['out'] = gd.denorm_spec(x[:, 0].transpose(1, 2)).numpy()       # :271,:275
         elif kind == 'plms':

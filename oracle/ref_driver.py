@@ -63,6 +63,30 @@ class Reference:
                                         K_step=k_step, loss_type='l1', spec_min=spec_min, spec_max=spec_max).eval()
         return net, gd
 
+    def build_legacy(self, seed: int, final_proj_std: float, timesteps: int, spec_min, spec_max):
+        """usr/diff/diffusion.py::GaussianDiffusion (the class usr/task.py::DiffFsTask builds): cosine schedule, no K_step."""
+        torch = self.torch
+        import usr.diff.diffusion as legacy                # noqa: E402
+        self.legacy = legacy
+        torch.manual_seed(seed)
+        net = self.DiffNet(self.hparams['audio_num_mel_bins'])
+        if final_proj_std > 0:
+            torch.nn.init.normal_(net.output_projection.weight, std=final_proj_std)
+        enc = self.TokenTextEncoder(None, vocab_list=['a', 'b', 'c'], replace_oov=',')
+        gd = legacy.GaussianDiffusion(enc, self.hparams['audio_num_mel_bins'], net, timesteps=timesteps, loss_type='l1',
+                                      spec_min=spec_min, spec_max=spec_max).eval()
+        return net, gd
+
+    def sample_ddpm_legacy(self, gd, x, cond, noises):
+        torch = self.torch
+        q = list(noises)
+        self.legacy.noise_like = lambda shape, device, repeat=False: q.pop(0)
+        B = x.shape[0]
+        for i in reversed(range(0, gd.num_timesteps)):      # usr/diff/diffusion.py:317-318
+            x = gd.p_sample(x, torch.full((B,), i, dtype=torch.long), cond)
+        assert not q
+        return x
+
     def sample_ddpm(self, gd, x, cond, noises, k_step):
         torch = self.torch
         q = list(noises)

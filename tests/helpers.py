@@ -29,7 +29,9 @@ def oracle_params(cfg: O.NetConfig):
     return _PARAM_CACHE[key]
 
 
-def betas_for(pre):
+def betas_for(pre, case=None):
+    if case is not None and case.get('legacy'):      # usr/diff/diffusion.py:192-195: always cosine
+        return O.cosine_beta_schedule(pre['timesteps'])
     if pre['schedule_type'] == 'linear':
         return O.linear_beta_schedule(pre['timesteps'], pre['max_beta'])
     return O.cosine_beta_schedule(pre['timesteps'])
@@ -52,7 +54,7 @@ def case_setup(name):
 def run_oracle_case(name):
     case, pre, cfg, k_step, inp, smin, smax = case_setup(name)
     p = oracle_params(cfg)
-    sch = O.make_schedule(betas_for(pre))
+    sch = O.make_schedule(betas_for(pre, case))
     kind = case['kind']
     with torch.no_grad():
         if kind == 'denoise':

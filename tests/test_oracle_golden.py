@@ -26,7 +26,7 @@ def test_inputs_and_weights_rederive_bit_exact(name):
 def test_schedule_tables_bit_exact(name):
     g = H.load_golden(name)
     pre = H.presets()[CASES[name]['preset']]
-    sch = O.make_schedule(H.betas_for(pre))
+    sch = O.make_schedule(H.betas_for(pre, CASES[name]))
     for k, v in sch.items():
         np.testing.assert_array_equal(v.numpy(), g['sched_' + k], err_msg=k)
 

@@ -1,0 +1,117 @@
+"""Developer tool: reduce rocprofv3 --pmc passes (csv `*counter_collection.csv` or rocpd sqlite) over ONE kernel to
+per-dispatch averages, and derive the HBM traffic per launch for bench.py's `roofline.traffic`.
+
+    python tools/pmc_summary.py <dir with the pass outputs> <kernel substring> <out.txt> <out.json> [key=value ...]
+
+Units / corrections (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC slots"): FETCH_SIZE and WRITE_SIZE are reported in KiB;
+on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) coalesced reads at 64 bytes, i.e. reports half the
+bytes - every load of k_layer is a dwordx4 load, so it is doubled.  WRITE_SIZE is taken as reported (it equals the
+algorithmic x_out + skip bytes exactly).  Infinity-Cache hits are counted by both (they are fabric-side request counters)."""
+import csv
+import glob
+import json
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def from_csv(root, kern):
+    acc = defaultdict(list)
+    dur = defaultdict(list)
+    for path in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
+        with open(path, newline='') as f:
+            for row in csv.DictReader(f):
+                if kern not in row.get('Kernel_Name', ''):
+                    continue
+                name = row['Counter_Name']
+                acc[name].append(float(row['Counter_Value']))
+                try:
+                    dur[name].append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3)
+                except (KeyError, ValueError):
+                    pass
+    return acc, dur
+
+
+def from_db(root, kern):
+    acc = defaultdict(list)
+    dur = defaultdict(list)
+    for path in glob.glob(os.path.join(root, '**', '*.db'), recursive=True):
+        con = sqlite3.connect(path)
+        cur = con.cursor()
+        names = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+        cand = [n for n in names if n == 'counters_collection'] or [n for n in names if 'counter' in n.lower() or 'pmc' in n.lower()]
+        for tab in cand:
+            cols = [r[1] for r in cur.execute(f'pragma table_info("{tab}")')]
+            lc = {c.lower(): c for c in cols}
+            kcol = next((lc[c] for c in ('kernel_name', 'name') if c in lc), None)
+            ccol = next((lc[c] for c in ('counter_name', 'pmc_name', 'symbol') if c in lc), None)
+            vcol = next((lc[c] for c in ('value', 'counter_value') if c in lc), None)
+            if not (kcol and ccol and vcol):
+                continue
+            scol, ecol = lc.get('start'), lc.get('end')
+            q = f'select "{kcol}", "{ccol}", "{vcol}"' + (f', "{scol}", "{ecol}"' if scol and ecol else '') + f' from "{tab}"'
+            try:
+                rows = cur.execute(q).fetchall()
+            except sqlite3.Error:
+                continue
+            # one row per (dispatch, counter, [xcc/dimension]): sum the dimensions of one dispatch
+            per = defaultdict(float)
+            seen = {}
+            idcol = next((lc[c] for c in ('dispatch_id', 'id') if c in lc), None)
+            if idcol:
+                rows2 = cur.execute(f'select "{idcol}", "{kcol}", "{ccol}", "{vcol}"' + (f', "{scol}", "{ecol}"' if scol and ecol else '') + f' from "{tab}"').fetchall()
+                for r in rows2:
+                    if kern not in (r[1] or ''):
+                        continue
+                    per[(r[0], r[2])] += float(r[3])
+                    if len(r) > 5 and r[4] is not None:
+                        seen[(r[0], r[2])] = (r[5] - r[4]) / 1e3
+                for (did, cname), v in per.items():
+                    acc[cname].append(v)
+                    if (did, cname) in seen:
+                        dur[cname].append(seen[(did, cname)])
+            else:
+                for r in rows:
+                    if kern in (r[0] or ''):
+                        acc[r[1]].append(float(r[2]))
+            if acc:
+                break
+        con.close()
+    return acc, dur
+
+
+def main(root, kern, out_txt, out_json, *extras):
+    acc, dur = from_csv(root, kern)
+    src = 'csv'
+    if not acc:
+        acc, dur = from_db(root, kern)
+        src = 'rocpd sqlite'
+    if not acc:
+        raise SystemExit(f'no counters for kernel "{kern}" under {root}')
+    avg = {k: sum(v) / len(v) for k, v in acc.items()}
+    lines = [f'# rocprofv3 --pmc passes over {kern} ({src}), averages per dispatch; tools/gpu_pmc.sh',
+             '# FETCH_SIZE / WRITE_SIZE in KiB as reported (FETCH_SIZE under-reports wide reads by 2x on gfx950, MI355X_MICROARCH.md',
+             '# section HBM); SQ_* wave counters in quad-cycles summed over all waves, SQ_VALU_MFMA_BUSY_CYCLES in cycles']
+    for k in sorted(avg):
+        d = dur.get(k)
+        extra = f'   (n={len(acc[k])}' + (f', avg kernel duration under this pass {sum(d) / len(d):.1f} us)' if d else ')')
+        lines.append(f'{k:<36}{avg[k]:>16.1f}{extra}')
+    js = {'kernel': kern, 'source': src, 'counters': avg, 'n': {k: len(v) for k, v in acc.items()}}
+    for kv in extras:                       # e.g. frames=8192 kernel_tag='k_layer<1,false>' round=r01b
+        k, v = kv.split('=', 1)
+        js[k] = int(v) if v.isdigit() else v
+    if 'FETCH_SIZE' in avg and 'WRITE_SIZE' in avg:
+        fetch = avg['FETCH_SIZE'] * 1024 * 2
+        write = avg['WRITE_SIZE'] * 1024
+        js['hbm_bytes_per_launch'] = {'fetch_corrected': fetch, 'write': write, 'total': fetch + write,
+                                      'note': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024; '
+                                              'fabric-side counters: Infinity-Cache hits included'}
+        lines.append(f'# HBM-side traffic per launch: fetch {fetch / 1e6:.1f} MB (corrected x2) + write {write / 1e6:.1f} MB = {(fetch + write) / 1e6:.1f} MB')
+    open(out_txt, 'w').write('\n'.join(lines) + '\n')
+    json.dump(js, open(out_json, 'w'), indent=1)
+    print('\n'.join(lines))
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:])
