@@ -11,7 +11,13 @@ CONFIGS = {
 }
 KEYS = ['audio_num_mel_bins', 'keep_bins', 'hidden_size', 'residual_layers', 'residual_channels',
         'dilation_cycle_length', 'timesteps', 'K_step', 'max_beta', 'schedule_type', 'diff_loss_type',
-        'diff_decoder_type', 'pndm_speedup', 'gaussian_start', 'use_midi', 'spec_min', 'spec_max']
+        'diff_decoder_type', 'pndm_speedup', 'gaussian_start', 'use_midi', 'spec_min', 'spec_max',
+        # FastSpeech2 / FastSpeech2MIDI conditioner: modules/fastspeech/fs2.py, tts_modules.py
+        'enc_layers', 'dec_layers', 'enc_ffn_kernel_size', 'dec_ffn_kernel_size', 'num_heads', 'ffn_act', 'ffn_padding',
+        'use_pos_embed', 'rel_pos', 'encoder_type', 'decoder_type', 'dropout', 'use_pitch_embed', 'pitch_type', 'use_uv',
+        'pitch_norm', 'f0_mean', 'f0_std', 'pitch_ar', 'predictor_hidden', 'predictor_layers', 'predictor_kernel',
+        'predictor_dropout', 'predictor_grad', 'dur_predictor_layers', 'dur_predictor_kernel', 'dur_loss', 'cwt_hidden_size',
+        'cwt_std_scale', 'use_energy_embed', 'use_spk_id', 'use_spk_embed', 'use_split_spk_id', 'num_spk']
 
 CHILD = r'''
 import sys, json
