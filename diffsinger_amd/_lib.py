@@ -18,6 +18,9 @@ SYMBOLS = [
     'dsd_set_use_graph', 'dsd_set_layer_tile', 'dsd_time_layer_kernel', 'dsd_debug_layer_timeline', 'dsd_device_bytes',
     'dsd_get_layer_tile',
 ]
+# every symbol include/dsf.h declares (the FastSpeech2 conditioner ops)
+SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf_conv1d', 'dsf_layer_norm', 'dsf_attention',
+               'dsf_to_channel_major', 'dsf_from_channel_major']
 
 _fp = C.POINTER(C.c_float)
 _fpp = C.POINTER(C.c_void_p)
@@ -86,6 +89,17 @@ def load():
     lib.dsd_device_bytes.argtypes = [h]
     lib.dsd_device_bytes.restype = C.c_int64
     lib.dsd_get_layer_tile.argtypes = [h]
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.dsf_padded_frames.argtypes = [i32]
+    lib.dsf_padded_frames.restype = i32
+    lib.dsf_packed_floats.argtypes = [i32, i32, i32]
+    lib.dsf_packed_floats.restype = i64
+    lib.dsf_pack_weight.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.dsf_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp]
+    lib.dsf_layer_norm.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]
+    lib.dsf_attention.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.dsf_to_channel_major.argtypes = [vp, i64, i64, i64, vp, i32, i32, i32, vp]
+    lib.dsf_from_channel_major.argtypes = [vp, vp, i32, i32, i32, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('dsd_abi_version',):

@@ -11,7 +11,8 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(PKG, 'csrc', 'dsd.hip')]
-DEPS = SRC + [os.path.join(PKG, 'csrc', 'dsd_kernels.hpp'), os.path.join(os.path.dirname(PKG), 'include', 'dsd.h')]
+DEPS = SRC + [os.path.join(PKG, 'csrc', f) for f in ('dsd_kernels.hpp', 'fs2_kernels.hpp', 'fs2_abi.hpp')] + [
+    os.path.join(os.path.dirname(PKG), 'include', f) for f in ('dsd.h', 'dsf.h')]
 LIB = os.path.join(PKG, 'libdsdenoise.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC']
 

@@ -61,6 +61,7 @@ struct dsd_handle {
     bool has_weights = false, has_schedule = false, has_spec = false, prepared = false;
     bool use_graph = true;
     int layer_tile_req = 0;     // 0 auto, 32, 64
+    bool xcd_map = true;        // XCD-aware workgroup->tile map of k_layer (env DSD_XCD_MAP=0 restores the plain 2-D grid)
     int64_t bytes = 0;       // device bytes owned: packed weights + tables (persistent)
     int64_t bytes_ws = 0;    // ... + workspace of the prepared batch
 
@@ -147,6 +148,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     h->L = cfg->residual_layers;
     h->M = cfg->mel_bins;
     h->nk_in = (cfg->mel_bins + 7) / 8;
+    if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
         if (e > 3) { delete h; return fail(DSD_ERR_INVALID, "dsd_create: dilation 2^%d exceeds the supported maximum %d", e, kHalo); }
@@ -451,7 +453,10 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
     p.dil = h->dil[l];
     p.first = (l == 0);
     p.dbg = dbg;
-    const dim3 grid((unsigned)p.tiles_per_utt, (unsigned)h->B);
+    const int total = p.tiles_per_utt * h->B;
+    dim3 grid((unsigned)p.tiles_per_utt, (unsigned)h->B);
+    p.xcd_q = -1; p.xcd_r = 0;
+    if (h->xcd_map) { p.xcd_q = total / 8; p.xcd_r = total % 8; grid = dim3((unsigned)total); }
     const bool last = (l == h->L - 1);
     if (nb == 1) {
         if (last) hipLaunchKernelGGL((k_layer<1, true>), grid, dim3(kThreads), layer_lds_bytes<1>(), s, p);
@@ -773,3 +778,5 @@ extern "C" int dsd_debug_layer_timeline(dsd_handle* h, int32_t layer, int32_t t,
     *n_blocks = blocks;
     return DSD_OK;
 }
+
+#include "fs2_abi.hpp"

@@ -213,6 +213,7 @@ struct LayerParams {
     const int* t_dev;       // per-utterance step index, or nullptr -> t_uniform
     int t_uniform, ds_tstride;
     int T, TS, ntile32, tiles_per_utt, dil, first;
+    int xcd_q, xcd_r;       // XCD-aware workgroup map (1-D grid): total workgroups = 8 * xcd_q + xcd_r; xcd_q < 0 -> 2-D grid
     unsigned long long* dbg;   // optional per-wave phase timestamps [block][wave][8] (s_memtime), nullptr in production
 };
 
@@ -231,8 +232,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     float* gtile = smem + kC * LD;
 
     const int tid = threadIdx.x;
-    // grid = (tiles per utterance, utterances): no integer division on the way to the first load
-    const int b = blockIdx.y, tn = blockIdx.x;
+    // Workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  With the
+    // plain map neighbouring tiles land on different XCDs and every halo line (the neighbour's first / last 8 columns, one
+    // cache line per channel row) is fetched from the fabric a second time by the other L2 (~17 MB per launch at 8192
+    // frames, PMC FETCH_SIZE).  XCD-aware map: XCD x owns the CONTIGUOUS tile range [x q + min(x, r), ...), so both
+    // neighbours of a tile sit behind the same L2.  Placement is a speed matter only (results do not depend on it).
+    int b, tn;
+    if (p.xcd_q >= 0) {
+        const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
+        const int tl = xcd * p.xcd_q + min(xcd, p.xcd_r) + k;
+        b = tl / p.tiles_per_utt;
+        tn = tl - b * p.tiles_per_utt;
+    } else {
+        b = blockIdx.y; tn = blockIdx.x;     // grid = (tiles per utterance, utterances)
+    }
     const int tile0 = b * p.ntile32 + tn * NB;
     const int ntv = min(NB, p.ntile32 - tn * NB);         // valid 32-frame tiles of this workgroup
     const float* __restrict__ xt = p.x_in + (size_t)tile0 * TILE;
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
         }
     }
     if (p.dbg && lane == 0) {
-        unsigned long long* d = p.dbg + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8;
+        unsigned long long* d = p.dbg + (((size_t)b * p.tiles_per_utt + tn) * 4 + w) * 8;
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = __builtin_amdgcn_s_memtime(); d[6] = tsa; d[7] = tsb;
     }
 }

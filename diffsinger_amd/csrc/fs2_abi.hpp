@@ -1,0 +1,103 @@
+// fs2_abi.hpp - host side of the FastSpeech2 conditioner ops (C ABI in include/dsf.h); included at the end of dsd.hip so the
+// library stays one translation unit (shares the error string, the HIP_TRY macros and the operand-packing kernels).
+#include "fs2_kernels.hpp"
+
+#include "../../include/dsf.h"
+
+static inline int fs_ts(int T) { return (T + 31) / 32 * 32; }
+
+extern "C" int dsf_padded_frames(int32_t T) { return fs_ts(T); }
+
+extern "C" int64_t dsf_packed_floats(int32_t Co, int32_t Ci, int32_t KT) {
+    if (Co < 1 || Ci < 8 || (Ci % 8) || KT < 1) return -1;
+    const int64_t mt = (Co + 255) / 256;
+    return (mt * 4 * (int64_t)(Ci / 8) * KT * 2 * 64 + kWeightSlack) * 4;
+}
+
+extern "C" int dsf_pack_weight(const float* w, int32_t Co, int32_t Ci, int32_t KT, float* packed, void* stream) {
+    if (!w || !packed) return fail(DSD_ERR_INVALID, "dsf_pack_weight: null argument");
+    if (Co < 1 || Ci < 8 || (Ci % 8) || KT < 1 || KT > 2 * kFsHalo + 1 || !(KT & 1))
+        return fail(DSD_ERR_INVALID, "dsf_pack_weight: need Co >= 1, Ci a multiple of 8, odd kernel <= %d (got %d, %d, %d)", 2 * kFsHalo + 1, Co, Ci, KT);
+    const int mt = (Co + 255) / 256;
+    PackParams p{};
+    p.src = w; p.dst = packed;
+    p.nw = mt * 4; p.nkc = Ci / 8; p.nmb = 2; p.ntap = KT;
+    p.split = 0; p.hi_base = 0;
+    p.rows_valid = Co; p.cols_valid = Ci;
+    p.row_stride = Ci * KT; p.col_stride = KT;
+    const size_t n = (size_t)p.nw * p.ntap * p.nkc * p.nmb * 256;
+    hipLaunchKernelGGL(k_pack_a, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(packed + n, 0, (size_t)kWeightSlack * 16, (hipStream_t)stream));
+    return DSD_OK;
+}
+
+extern "C" int dsf_conv1d(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co,
+                          int32_t KT, int32_t T, float scale, int32_t act, const float* residual, const float* keep, void* stream) {
+    if (!in || !wpacked || !out) return fail(DSD_ERR_INVALID, "dsf_conv1d: null argument");
+    if (B < 1 || T < 1 || Co < 1 || Ci < 8 || (Ci % 8) || KT < 1 || KT > 2 * kFsHalo + 1 || !(KT & 1) || act < 0 || act > 2)
+        return fail(DSD_ERR_INVALID, "dsf_conv1d: bad shape (B=%d T=%d Ci=%d Co=%d K=%d act=%d)", B, T, Ci, Co, KT, act);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_fs_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
+        attr_done = true;
+    }
+    FsConvParams p{};
+    p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.keep = keep;
+    p.Ci = Ci; p.Co = Co; p.KT = KT; p.pad = (KT - 1) / 2; p.T = T; p.TS = fs_ts(T);
+    p.scale = scale; p.act = act;
+    const dim3 grid((unsigned)(p.TS / 32), (unsigned)B, (unsigned)((Co + 255) / 256));
+    hipLaunchKernelGGL((k_fs_conv<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_layer_norm(const float* in, const float* gamma, const float* beta, float* out, int32_t B, int32_t C, int32_t T,
+                              float eps, int32_t relu_in, const float* keep, void* stream) {
+    if (!in || !gamma || !beta || !out) return fail(DSD_ERR_INVALID, "dsf_layer_norm: null argument");
+    if (C != kC) return fail(DSD_ERR_INVALID, "dsf_layer_norm: this build normalises over %d channels (got %d)", kC, C);
+    if (B < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_layer_norm: bad shape");
+    FsLnParams p{};
+    p.in = in; p.out = out; p.gamma = gamma; p.beta = beta; p.keep = keep; p.T = T; p.TS = fs_ts(T); p.eps = eps; p.relu_in = relu_in;
+    hipLaunchKernelGGL(k_fs_ln, dim3((unsigned)(p.TS / 32), (unsigned)B), dim3(kThreads), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_attention(const float* qkv, const uint8_t* key_pad, float* out, int32_t B, int32_t C, int32_t heads, int32_t T,
+                             void* stream) {
+    if (!qkv || !out) return fail(DSD_ERR_INVALID, "dsf_attention: null argument");
+    if (B < 1 || T < 1 || heads < 1 || C != heads * 128)
+        return fail(DSD_ERR_INVALID, "dsf_attention: this build supports head_dim 128 (C=%d, heads=%d)", C, heads);
+    FsAttnParams p{};
+    p.qkv = qkv; p.key_pad = key_pad; p.out = out; p.C = C; p.T = T; p.TS = fs_ts(T);
+    p.scale = (float)std::sqrt(1.0 / 128.0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_fs_attn<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fs_attn_lds_bytes<128>());
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_fs_attn<128>), dim3((unsigned)(p.TS / 32), (unsigned)heads, (unsigned)B), dim3(64), fs_attn_lds_bytes<128>(),
+                       (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_to_channel_major(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_t, float* out, int32_t B,
+                                    int32_t C, int32_t T, void* stream) {
+    if (!x || !out || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_to_channel_major: bad argument");
+    const int TS = fs_ts(T);
+    hipLaunchKernelGGL(k_cond_layout, dim3((unsigned)(TS / 32), (unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0, (hipStream_t)stream,
+                       x, out, C, T, TS, stride_b, stride_c, stride_t);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_from_channel_major(const float* in, float* out, int32_t B, int32_t C, int32_t T, void* stream) {
+    if (!in || !out || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_from_channel_major: bad argument");
+    const int TS = fs_ts(T);
+    hipLaunchKernelGGL(k_fs_from_cm, dim3((unsigned)(TS / 32), (unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0, (hipStream_t)stream,
+                       in, out, C, T, TS);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}

@@ -1,0 +1,285 @@
+// fs2_kernels.hpp - gfx950 kernels for the FastSpeech2 / FastSpeech2MIDI conditioner + aux decoder (SURVEY.md section 8 row
+// f1: the caller of the diffusion hot path; it produces `cond` and the shallow-diffusion start).
+//
+// What is computed, and where the reference computes it (paths relative to the reference root):
+//   k_fs_conv   every Conv1d / Linear of the model as ONE fp32-MFMA contraction over (input channel, tap):
+//               MultiheadAttention in/out projections (modules/commons/common_layers.py:243-263 -> F.multi_head_attention_forward),
+//               TransformerFFNLayer ffn_1 (k = 9, 'SAME') * k^-0.5 -> gelu and ffn_2 (common_layers.py:486-522), the residual
+//               add + padding mask of EncSALayer (:565-588), the predictor convolutions + ReLU (modules/fastspeech/
+//               tts_modules.py:84-97, :198-209), mel_out (modules/fastspeech/fs2.py:233-237)
+//   k_fs_ln     LayerNorm over the channel axis (EncSALayer layer_norm1/2, FFTBlocks.layer_norm: eps 1e-5; predictor LayerNorm
+//               (dim=1): eps 1e-12, tts_modules.py:39-56), optionally times the padding mask
+//   k_fs_attn   softmax(q k^T + key_padding_mask) v per head (F.multi_head_attention_forward), flash-style: one wave per
+//               (utterance, head, 32-query tile), online softmax, S and P V on fp32 MFMA
+//   k_fs_from_cm  internal channel-major [B][C][TS] -> the reference's [B,T,C]
+//
+// Activations live channel-major [B][C][TS] (frame axis contiguous, TS = T rounded up to 32, ZERO in [T,TS)): exactly the
+// layout of the denoiser kernels, so every contraction reuses their operand pipeline (A = weights in MFMA-fragment order
+// streamed from L2, B = an LDS tile [channel][frame] whose taps are column offsets).
+#pragma once
+#include "dsd_kernels.hpp"
+
+namespace dsd {
+
+constexpr int kFsHalo = 8;                 // conv taps reach +-8 frames at most (kernel <= 17)
+constexpr int kFsLD = 32 + 2 * kFsHalo;    // LDS row stride of the staged input slab
+constexpr int kFsSlab = 256;               // input channels staged per pass
+
+enum FsAct { FS_ACT_NONE = 0, FS_ACT_RELU = 1, FS_ACT_GELU = 2 };
+
+struct FsConvParams {
+    const float* in;        // [B][Ci][TS]
+    const float4* wp;       // packed [mtile][w4][chunk = ci8 * KT + tap][NMB][lane64] float4 (k_pack_a, ntap = KT)
+    const float* bias;      // [Co] or nullptr
+    float* out;             // [B][Co][TS]
+    const float* res;       // residual [B][Co][TS] or nullptr (added after the activation)
+    const float* keep;      // [B][T], 1 = frame valid, 0 = padding; nullptr = no mask
+    int Ci, Co, KT, pad, T, TS;
+    float scale;            // multiplied in before the activation (TransformerFFNLayer: kernel_size ** -0.5)
+    int act;
+};
+
+struct FsTapB {             // B-operand functor of GemmPipe: chunk kc = ci8 * KT + tap of the staged slab
+    const float* base;      // slab + 4 h LD + halo + j - pad
+    int KT, n;
+    __device__ __forceinline__ const float* operator()(int it, int u) const {
+        int kc = 6 * it + u;
+        kc = (kc < n) ? kc : n - 1;
+        const int g = kc / KT, tap = kc - g * KT;
+        return base + g * (8 * kFsLD) + tap;
+    }
+};
+
+// out rows [256 mtile, 256 mtile + 256) x 32 frames per workgroup: 4 waves x 2 row blocks of 32
+template <int NMB>
+__global__ __launch_bounds__(kThreads, 2) void k_fs_conv(const FsConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [kFsSlab][kFsLD]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * 32, b = blockIdx.y, mt = blockIdx.z;
+    const int nchunk_total = (p.Ci / 8) * p.KT;
+    f32x16 acc[NMB][1];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][0][r] = 0.f;
+    const float* inb = p.in + (size_t)b * p.Ci * p.TS;
+    for (int c0 = 0; c0 < p.Ci; c0 += kFsSlab) {
+        const int nc = min(kFsSlab, p.Ci - c0);
+        // stage channels [c0, c0 + nc) x frames [t0 - 8, t0 + 40): 12 float4 per row, zero outside [0, TS)
+        for (int idx = tid; idx < nc * (kFsLD / 4); idx += kThreads) {
+            const int row = idx / (kFsLD / 4), g = idx - row * (kFsLD / 4);
+            const int t = t0 - kFsHalo + 4 * g;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + row) * p.TS + t);
+            *reinterpret_cast<float4*>(smem + row * kFsLD + 4 * g) = v;
+        }
+        __syncthreads();
+        const int nch = (nc / 8) * p.KT;
+        const float4* ap = p.wp + (((size_t)mt * 4 + w) * nchunk_total + (size_t)(c0 / 8) * p.KT) * (NMB * 64);
+        const FsTapB bof{smem + 4 * h * kFsLD + kFsHalo + j - p.pad, p.KT, nch};
+        gemm_k<NMB, 1, kFsLD, NMB * 64>(acc, ap, lane, nch, bof);
+        __syncthreads();
+    }
+    const int t = t0 + j;
+    const bool tv = t < p.T;
+    float kp = 1.f;
+    if (p.keep && tv) kp = p.keep[(size_t)b * p.T + t];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (mt * 4 + w) * (32 * NMB) + 32 * mb + frag_row(r, h);
+            if (row >= p.Co) continue;
+            const size_t o = ((size_t)b * p.Co + row) * p.TS + t;
+            float v = acc[mb][0][r];
+            if (p.bias) v += p.bias[row];
+            v *= p.scale;
+            if (p.act == FS_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == FS_ACT_GELU) v = v * 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+            if (p.res) v += p.res[o];
+            v *= kp;
+            p.out[o] = tv ? v : 0.f;
+        }
+}
+constexpr int kFsConvLdsBytes = kFsSlab * kFsLD * (int)sizeof(float);
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm over C = 256 channels of every frame column
+// ------------------------------------------------------------------------------------------------------------
+struct FsLnParams {
+    const float* in;        // [B][256][TS]
+    float* out;             // [B][256][TS]
+    const float* gamma;     // [256]
+    const float* beta;      // [256]
+    const float* keep;      // [B][T] or nullptr
+    int T, TS;
+    float eps;
+    int relu_in;            // apply ReLU to the input first (predictor: Conv1d -> ReLU -> LayerNorm)
+};
+
+__global__ __launch_bounds__(kThreads) void k_fs_ln(const FsLnParams p) {
+    __shared__ float red[8][32];
+    const int tid = threadIdx.x, tc = tid & 31, part = tid >> 5;
+    const int t = blockIdx.x * 32 + tc, b = blockIdx.y;
+    const float* src = p.in + ((size_t)b * kC + part * 32) * p.TS + t;
+    float v[32];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        float x = src[(size_t)i * p.TS];
+        if (p.relu_in) x = fmaxf(x, 0.f);
+        v[i] = x;
+        s += x;
+    }
+    red[part][tc] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mean += red[q][tc];
+    mean *= (1.f / kC);
+    __syncthreads();
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float e = v[i] - mean; d += e * e; }
+    red[part][tc] = d;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) var += red[q][tc];
+    var *= (1.f / kC);
+    const float rstd = 1.f / sqrtf(var + p.eps);
+    const bool tv = t < p.T;
+    float kp = 1.f;
+    if (p.keep && tv) kp = p.keep[(size_t)b * p.T + t];
+    float* dst = p.out + ((size_t)b * kC + part * 32) * p.TS + t;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int c = part * 32 + i;
+        const float y = ((v[i] - mean) * rstd * p.gamma[c] + p.beta[c]) * kp;
+        dst[(size_t)i * p.TS] = tv ? y : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// self-attention core: one wave per (32-query tile, head, utterance)
+// ------------------------------------------------------------------------------------------------------------
+struct FsAttnParams {
+    const float* qkv;               // [B][3C][TS]: q rows [0,C), k rows [C,2C), v rows [2C,3C); head hh = rows hh*HD..
+    const unsigned char* key_pad;   // [B][T], nonzero = padded key (key_padding_mask)
+    float* out;                     // [B][C][TS]
+    int C, T, TS;
+    float scale;                    // head_dim ** -0.5, applied to q like the reference (q * scaling before q k^T)
+};
+
+template <int HD>
+__global__ __launch_bounds__(64) void k_fs_attn(const FsAttnParams p) {
+    constexpr int NMB = HD / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* qt = smem;                       // [HD][32]
+    float* kt = qt + HD * 32;               // [HD][32]
+    float* vt = kt + HD * 32;               // [HD][33]
+    float* pt = vt + HD * 33;               // [32 keys][32 queries]
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int tq0 = blockIdx.x * 32, hh = blockIdx.y, b = blockIdx.z;
+    const float* qb = p.qkv + ((size_t)b * 3 * p.C + hh * HD) * p.TS;
+    const float* kb = qb + (size_t)p.C * p.TS;
+    const float* vb = kb + (size_t)p.C * p.TS;
+    for (int idx = lane; idx < HD * 8; idx += 64) {
+        const int row = idx >> 3, g = idx & 7;
+        float4 v = *reinterpret_cast<const float4*>(qb + (size_t)row * p.TS + tq0 + 4 * g);
+        v.x *= p.scale; v.y *= p.scale; v.z *= p.scale; v.w *= p.scale;
+        *reinterpret_cast<float4*>(qt + row * 32 + 4 * g) = v;
+    }
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mb][r] = 0.f;
+    for (int tk0 = 0; tk0 < p.T; tk0 += 32) {
+        __syncthreads();                    // previous tile's LDS reads are done
+        for (int idx = lane; idx < HD * 8; idx += 64) {
+            const int row = idx >> 3, g = idx & 7;
+            *reinterpret_cast<float4*>(kt + row * 32 + 4 * g) = *reinterpret_cast<const float4*>(kb + (size_t)row * p.TS + tk0 + 4 * g);
+            const float4 v = *reinterpret_cast<const float4*>(vb + (size_t)row * p.TS + tk0 + 4 * g);
+            float* d = vt + row * 33 + 4 * g;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        // S[tk][tq] = sum_d k[d][tk] q[d][tq]
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < HD / 8; ++c)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int d = 8 * c + 4 * h + st;
+                s = mfma32(kt[d * 32 + j], qt[d * 32 + j], s);
+            }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tk = tk0 + frag_row(r, h);
+            const bool dead = (tk >= p.T) || (p.key_pad && p.key_pad[(size_t)b * p.T + tk]);
+            s[r] = dead ? -INFINITY : s[r];
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = (s[r] == -INFINITY) ? 0.f : expf(s[r] - mn);
+            ps += e;
+            pt[frag_row(r, h) * 32 + j] = e;
+        }
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[mb][r] *= alpha;
+        __syncthreads();
+        // O[d][tq] += sum_tk v[d][tk] P[tk][tq]
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int tk = 8 * c + 4 * h + st;
+                const float bv = pt[tk * 32 + j];
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb) o[mb] = mfma32(vt[(32 * mb + j) * 33 + tk], bv, o[mb]);
+            }
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = (lt > 0.f) ? 1.f / lt : 0.f;
+    const int t = tq0 + j;
+    float* ob = p.out + ((size_t)b * p.C + hh * HD) * p.TS + t;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[(size_t)(32 * mb + frag_row(r, h)) * p.TS] = (t < p.T) ? o[mb][r] * inv : 0.f;
+}
+template <int HD>
+constexpr int fs_attn_lds_bytes() { return (2 * HD * 32 + HD * 33 + 32 * 32) * (int)sizeof(float); }
+
+// internal [B][C][TS] -> [B][T][C] (the reference's layout), 32 x 32 tiles through LDS
+__global__ void k_fs_from_cm(const float* __restrict__ in, float* __restrict__ out, int C, int T, int TS) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;     // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, t = t0 + tx;
+        tile[k][tx] = (c < C && t < TS) ? in[((size_t)b * C + c) * TS + t] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int t = t0 + k, c = c0 + tx;
+        if (t < T && c < C) out[((size_t)b * T + t) * C + c] = tile[tx][k];
+    }
+}
+
+}  // namespace dsd

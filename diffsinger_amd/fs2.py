@@ -1,0 +1,645 @@
+"""FastSpeech2 / FastSpeech2MIDI - the conditioner + aux decoder in front of the diffusion hot path (SURVEY.md section 8
+row f1) - as nn.Modules whose INFERENCE forward runs on the HIP kernels of libdsdenoise.so (include/dsf.h).
+
+Mirrors the reference module tree (paths relative to the reference root) name for name, so a reference checkpoint's
+`model.fs2.*` state_dict loads with strict=True and vice versa:
+
+    FastSpeech2 / FastSpeech2MIDI            modules/fastspeech/fs2.py:23-255, modules/diffsinger_midi/fs2.py:47-118
+    FastspeechEncoder / MIDIEncoder / Decoder, FFTBlocks, DurationPredictor, PitchPredictor, LengthRegulator
+                                              modules/fastspeech/tts_modules.py:58-356, modules/diffsinger_midi/fs2.py:10-37
+    EncSALayer, TransformerFFNLayer, MultiheadAttention, SinusoidalPositionalEmbedding
+                                              modules/commons/common_layers.py:88-147, 166-263, 486-588
+
+What runs where: every contraction (attention projections, the k=9 conv-FFN, predictor convolutions, mel_out), every
+LayerNorm and the softmax-attention core are HIP kernels on a channel-major [B][C][T] layout (>99.9 % of the FLOPs).  The
+index plumbing between them - embedding lookups, the length-regulator gather, padding masks, f0 quantisation - is data
+movement on [B,T,C] tensors and uses torch indexing ops on the device.  Inference only (training = row f3); no CPU path:
+the ops raise when the tensors are not on the MI355X.
+
+Not covered (raise NotImplementedError): speaker embeddings (use_spk_id / use_spk_embed), energy embedding, pitch_ar,
+pitch_type 'ph', dur_loss other than 'mse', ffn_padding 'LEFT', norm 'bn' - none is used by a shipped DiffSpeech / DiffSinger
+config."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from .hparams import hparams
+
+ACT = {'none': 0, 'relu': 1, 'gelu': 2}
+f0_bin = 256
+f0_mel_min = 1127 * np.log(1 + 50.0 / 700)
+f0_mel_max = 1127 * np.log(1 + 1100.0 / 700)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# thin wrappers over the C ABI (include/dsf.h).  Tensors in "cm" = channel-major [B][C][TS] fp32, TS = T up to 32.
+# --------------------------------------------------------------------------------------------------------------
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _need_hip(t: torch.Tensor, what: str):
+    if t.device.type != 'cuda':
+        raise RuntimeError(f'{what}: the FastSpeech2 HIP ops have no CPU path - move the module and its inputs to the MI355X')
+
+
+def padded_frames(T: int) -> int:
+    return (T + 31) // 32 * 32
+
+
+class PackedWeight:
+    """A Conv1d / Linear weight in MFMA-fragment order (dsf_pack_weight), re-packed when the parameter changes."""
+
+    def __init__(self):
+        self.tag = None
+        self.buf = None
+
+    def get(self, w: torch.Tensor) -> torch.Tensor:
+        tag = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+        if tag != self.tag:
+            _need_hip(w, 'weight')
+            lib = _lib.load()
+            w3 = w.detach().to(torch.float32).contiguous()
+            if w3.dim() == 2:
+                w3 = w3[:, :, None]
+            co, ci, k = w3.shape
+            n = lib.dsf_packed_floats(co, ci, k)
+            if n < 0:
+                raise ValueError(f'unsupported weight shape {tuple(w.shape)} (input channels must be a multiple of 8)')
+            buf = torch.empty(n, device=w.device, dtype=torch.float32)
+            with torch.cuda.device(w.device):
+                _lib.check(lib.dsf_pack_weight(w3.data_ptr(), co, ci, k, buf.data_ptr(), _stream(w.device)), 'dsf_pack_weight')
+                torch.cuda.current_stream(w.device).synchronize()       # w3 may be a temporary
+            self.buf, self.tag = buf, tag
+        return self.buf
+
+
+def conv1d_cm(x: torch.Tensor, T: int, weight: torch.Tensor, packed: PackedWeight, bias: Optional[torch.Tensor] = None, *,
+              scale: float = 1.0, act: str = 'none', residual: Optional[torch.Tensor] = None, keep: Optional[torch.Tensor] = None):
+    """y = act(scale * (W * x + bias)) (+ residual) (* keep): nn.Conv1d 'SAME' / nn.Linear on a cm tensor."""
+    _need_hip(x, 'conv1d')
+    lib = _lib.load()
+    B, Ci, TS = x.shape
+    Co = weight.shape[0]
+    K = weight.shape[2] if weight.dim() == 3 else 1
+    assert TS == padded_frames(T) and x.is_contiguous() and weight.shape[1] == Ci
+    out = torch.empty(B, Co, TS, device=x.device, dtype=torch.float32)
+    wp = packed.get(weight)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dsf_conv1d(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), B, Ci, Co, K, T,
+                                  float(scale), ACT[act], residual.data_ptr() if residual is not None else None,
+                                  keep.data_ptr() if keep is not None else None, _stream(x.device)), 'dsf_conv1d')
+    return out
+
+
+def layer_norm_cm(x: torch.Tensor, T: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *, relu_in: bool = False,
+                  keep: Optional[torch.Tensor] = None):
+    _need_hip(x, 'layer_norm')
+    lib = _lib.load()
+    B, Cc, TS = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dsf_layer_norm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), B, Cc, T, float(eps), int(relu_in),
+                                      keep.data_ptr() if keep is not None else None, _stream(x.device)), 'dsf_layer_norm')
+    return out
+
+
+def attention_cm(qkv: torch.Tensor, T: int, key_pad_u8: Optional[torch.Tensor], heads: int):
+    _need_hip(qkv, 'attention')
+    lib = _lib.load()
+    B, C3, TS = qkv.shape
+    out = torch.empty(B, C3 // 3, TS, device=qkv.device, dtype=torch.float32)
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.dsf_attention(qkv.data_ptr(), key_pad_u8.data_ptr() if key_pad_u8 is not None else None, out.data_ptr(), B, C3 // 3,
+                                     heads, T, _stream(qkv.device)), 'dsf_attention')
+    return out
+
+
+def to_cm(x_btc: torch.Tensor) -> torch.Tensor:
+    """[B,T,C] (any strides) -> channel-major [B][C][TS], zero in [T,TS)."""
+    _need_hip(x_btc, 'to_cm')
+    lib = _lib.load()
+    x_btc = x_btc.to(torch.float32)
+    B, T, Cc = x_btc.shape
+    out = torch.empty(B, Cc, padded_frames(T), device=x_btc.device, dtype=torch.float32)
+    sb, st, sc = x_btc.stride()
+    with torch.cuda.device(x_btc.device):
+        _lib.check(lib.dsf_to_channel_major(x_btc.data_ptr(), sb, sc, st, out.data_ptr(), B, Cc, T, _stream(x_btc.device)), 'dsf_to_channel_major')
+    return out
+
+
+def from_cm(x_cm: torch.Tensor, T: int) -> torch.Tensor:
+    _need_hip(x_cm, 'from_cm')
+    lib = _lib.load()
+    B, Cc, TS = x_cm.shape
+    out = torch.empty(B, T, Cc, device=x_cm.device, dtype=torch.float32)
+    with torch.cuda.device(x_cm.device):
+        _lib.check(lib.dsf_from_channel_major(x_cm.data_ptr(), out.data_ptr(), B, Cc, T, _stream(x_cm.device)), 'dsf_from_channel_major')
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# parameter containers with the reference's names (init follows the reference's initialisers)
+# --------------------------------------------------------------------------------------------------------------
+def Embedding(num_embeddings, embedding_dim, padding_idx=None):
+    m = nn.Embedding(num_embeddings, embedding_dim, padding_idx=padding_idx)       # common_layers.py:62-67
+    nn.init.normal_(m.weight, mean=0, std=embedding_dim ** -0.5)
+    if padding_idx is not None:
+        nn.init.constant_(m.weight[padding_idx], 0)
+    return m
+
+
+def Linear(in_features, out_features, bias=True):
+    m = nn.Linear(in_features, out_features, bias)                                  # common_layers.py:80-85
+    nn.init.xavier_uniform_(m.weight)
+    if bias:
+        nn.init.constant_(m.bias, 0.)
+    return m
+
+
+def make_positions(tensor, padding_idx):
+    mask = tensor.ne(padding_idx).int()                                             # utils/__init__.py:145-157
+    return (torch.cumsum(mask, dim=1).type_as(mask) * mask).long() + padding_idx
+
+
+class SinusoidalPositionalEmbedding(nn.Module):
+    """common_layers.py:88-147.  The table is a constant built on the host exactly like the reference builds it (torch CPU
+    ops at construction) and cached on the device; the lookup is an index_select."""
+
+    def __init__(self, embedding_dim, padding_idx, init_size=1024):
+        super().__init__()
+        self.embedding_dim, self.padding_idx = embedding_dim, padding_idx
+        self.weights = self.get_embedding(init_size, embedding_dim, padding_idx)
+        self.register_buffer('_float_tensor', torch.FloatTensor(1))
+
+    @staticmethod
+    def get_embedding(num_embeddings, embedding_dim, padding_idx=None):
+        half_dim = embedding_dim // 2
+        emb = math.log(10000) / (half_dim - 1)
+        emb = torch.exp(torch.arange(half_dim, dtype=torch.float) * -emb)
+        emb = torch.arange(num_embeddings, dtype=torch.float).unsqueeze(1) * emb.unsqueeze(0)
+        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1).view(num_embeddings, -1)
+        if embedding_dim % 2 == 1:
+            emb = torch.cat([emb, torch.zeros(num_embeddings, 1)], dim=1)
+        if padding_idx is not None:
+            emb[padding_idx, :] = 0
+        return emb
+
+    def forward(self, input, **kwargs):
+        bsz, seq_len = input.shape[:2]
+        max_pos = self.padding_idx + 1 + seq_len
+        if max_pos > self.weights.size(0):
+            self.weights = self.get_embedding(max_pos, self.embedding_dim, self.padding_idx)
+        self.weights = self.weights.to(self._float_tensor)
+        positions = make_positions(input, self.padding_idx)
+        return self.weights.index_select(0, positions.view(-1)).view(bsz, seq_len, -1).detach()
+
+
+class RelPositionalEncoding(nn.Module):
+    """espnet_positional_embedding.py:86-112 as FastspeechMIDIEncoder uses it (x * sqrt(d) + pe[:T], reversed positions)."""
+
+    def __init__(self, d_model, dropout_rate=0.0, max_len=5000):
+        super().__init__()
+        self.d_model, self.xscale, self.pe = d_model, math.sqrt(d_model), None
+        self.extend_pe(max_len)
+
+    def extend_pe(self, n):
+        if self.pe is not None and self.pe.size(1) >= n:
+            return
+        pe = torch.zeros(n, self.d_model)
+        position = torch.arange(n - 1, -1, -1.0, dtype=torch.float32).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, self.d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / self.d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.pe = pe.unsqueeze(0)
+
+    def forward(self, x):
+        self.extend_pe(x.size(1))
+        self.pe = self.pe.to(device=x.device, dtype=x.dtype)
+        return x * self.xscale + self.pe[:, :x.size(1)]
+
+
+class MultiheadAttention(nn.Module):
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.in_proj_weight = nn.Parameter(torch.Tensor(3 * embed_dim, embed_dim))
+        self.register_parameter('in_proj_bias', None)                               # bias=False (common_layers.py:557-559)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=False)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.xavier_uniform_(self.out_proj.weight)
+        self._pin, self._pout = PackedWeight(), PackedWeight()
+
+
+class TransformerFFNLayer(nn.Module):
+    def __init__(self, hidden_size, filter_size, padding='SAME', kernel_size=1, act='gelu'):
+        super().__init__()
+        if padding != 'SAME' or act not in ('gelu', 'relu'):
+            raise NotImplementedError(f'ffn_padding {padding} / ffn_act {act}')
+        self.kernel_size, self.act = kernel_size, act
+        self.ffn_1 = nn.Conv1d(hidden_size, filter_size, kernel_size, padding=kernel_size // 2)
+        self.ffn_2 = Linear(filter_size, hidden_size)
+        self._p1, self._p2 = PackedWeight(), PackedWeight()
+
+
+class EncSALayer(nn.Module):
+    def __init__(self, c, num_heads, kernel_size=9, padding='SAME', act='gelu'):
+        super().__init__()
+        self.c, self.num_heads = c, num_heads
+        self.layer_norm1 = nn.LayerNorm(c)
+        self.self_attn = MultiheadAttention(c, num_heads)
+        self.layer_norm2 = nn.LayerNorm(c)
+        self.ffn = TransformerFFNLayer(c, 4 * c, kernel_size=kernel_size, padding=padding, act=act)
+
+    def forward_cm(self, x, T, keep, pad_u8):
+        """EncSALayer.forward (common_layers.py:565-588), eval mode, on a cm tensor."""
+        a, f = self.self_attn, self.ffn
+        y = layer_norm_cm(x, T, self.layer_norm1.weight, self.layer_norm1.bias, 1e-5)
+        qkv = conv1d_cm(y, T, a.in_proj_weight, a._pin)
+        o = attention_cm(qkv, T, pad_u8, self.num_heads)
+        x = conv1d_cm(o, T, a.out_proj.weight, a._pout, residual=x, keep=keep)
+        y = layer_norm_cm(x, T, self.layer_norm2.weight, self.layer_norm2.bias, 1e-5)
+        hdn = conv1d_cm(y, T, f.ffn_1.weight, f._p1, f.ffn_1.bias, scale=f.kernel_size ** -0.5, act=f.act)
+        return conv1d_cm(hdn, T, f.ffn_2.weight, f._p2, f.ffn_2.bias, residual=x, keep=keep)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, hidden_size, kernel_size, num_heads):
+        super().__init__()
+        self.op = EncSALayer(hidden_size, num_heads, kernel_size=kernel_size, padding=hparams['ffn_padding'], act=hparams['ffn_act'])
+
+
+class FFTBlocks(nn.Module):
+    def __init__(self, hidden_size, num_layers, ffn_kernel_size=9, num_heads=2, use_pos_embed=True, use_last_norm=True):
+        super().__init__()
+        self.num_layers, self.hidden_size, self.use_pos_embed = num_layers, hidden_size, use_pos_embed
+        if use_pos_embed:
+            self.padding_idx = 0
+            self.pos_embed_alpha = nn.Parameter(torch.Tensor([1]))
+            self.embed_positions = SinusoidalPositionalEmbedding(hidden_size, 0, init_size=2000)
+        self.layers = nn.ModuleList([TransformerEncoderLayer(hidden_size, ffn_kernel_size, num_heads) for _ in range(num_layers)])
+        self.layer_norm = nn.LayerNorm(hidden_size) if use_last_norm else None
+
+    def forward_cm(self, x, padding_mask=None):
+        """FFTBlocks.forward (tts_modules.py:288-314), eval mode.  x [B,T,C] -> channel-major [B][C][TS] (and T, keep)."""
+        _need_hip(x, 'FFTBlocks')
+        T = x.shape[1]
+        padding_mask = x.abs().sum(-1).eq(0) if padding_mask is None else padding_mask
+        keep = (~padding_mask).float().contiguous()
+        pad_u8 = padding_mask.to(torch.uint8).contiguous()
+        if self.use_pos_embed:
+            x = x + self.pos_embed_alpha * self.embed_positions(x[..., 0])
+        xc = to_cm(x * keep[:, :, None])
+        for layer in self.layers:
+            xc = layer.op.forward_cm(xc, T, keep, pad_u8)
+        if self.layer_norm is not None:
+            xc = layer_norm_cm(xc, T, self.layer_norm.weight, self.layer_norm.bias, 1e-5, keep=keep)
+        return xc, T, keep
+
+    def forward(self, x, padding_mask=None, **kwargs):
+        xc, T, _ = self.forward_cm(x, padding_mask)
+        return from_cm(xc, T)
+
+
+class FastspeechEncoder(FFTBlocks):
+    def __init__(self, embed_tokens, hidden_size, num_layers, kernel_size, num_heads=2):
+        super().__init__(hidden_size, num_layers, kernel_size, num_heads=num_heads, use_pos_embed=False)
+        self.embed_tokens = embed_tokens
+        self.embed_scale = math.sqrt(hidden_size)
+        self.padding_idx = 0
+        if hparams.get('rel_pos'):
+            self.embed_positions = RelPositionalEncoding(hidden_size, dropout_rate=0.0)
+        else:
+            self.embed_positions = SinusoidalPositionalEmbedding(hidden_size, 0, init_size=2000)
+
+    def forward_embedding(self, txt_tokens):
+        x = self.embed_scale * self.embed_tokens(txt_tokens)
+        if hparams['use_pos_embed']:
+            if hparams.get('rel_pos'):
+                raise NotImplementedError('rel_pos without use_midi (the reference would scale the integer tokens)')
+            x = x + self.embed_positions(txt_tokens)
+        return x
+
+    def forward(self, txt_tokens):
+        return FFTBlocks.forward(self, self.forward_embedding(txt_tokens), txt_tokens.eq(self.padding_idx))
+
+
+class FastspeechMIDIEncoder(FastspeechEncoder):
+    def forward_embedding(self, txt_tokens, midi_embedding, midi_dur_embedding, slur_embedding):
+        x = self.embed_scale * self.embed_tokens(txt_tokens)
+        x = x + midi_embedding + midi_dur_embedding + slur_embedding
+        if hparams['use_pos_embed']:
+            if hparams.get('rel_pos'):
+                x = self.embed_positions(x)
+            else:
+                x = x + self.embed_positions(txt_tokens)
+        return x
+
+    def forward(self, txt_tokens, midi_embedding, midi_dur_embedding, slur_embedding):
+        x = self.forward_embedding(txt_tokens, midi_embedding, midi_dur_embedding, slur_embedding)
+        return FFTBlocks.forward(self, x, txt_tokens.eq(self.padding_idx))
+
+
+class FastspeechDecoder(FFTBlocks):
+    def __init__(self, hidden_size=None, num_layers=None, kernel_size=None, num_heads=None):
+        super().__init__(hparams['hidden_size'] if hidden_size is None else hidden_size,
+                         hparams['dec_layers'] if num_layers is None else num_layers,
+                         hparams['dec_ffn_kernel_size'] if kernel_size is None else kernel_size,
+                         num_heads=hparams['num_heads'] if num_heads is None else num_heads)
+
+
+class _PredLayerNorm(nn.LayerNorm):
+    """tts_modules.py:39-56: LayerNorm(nout, dim=1), eps 1e-12 (container; the arithmetic is k_fs_ln)."""
+
+    def __init__(self, nout, dim=-1):
+        super().__init__(nout, eps=1e-12)
+        self.dim = dim
+
+
+def _pred_convs(idim, n_layers, n_chans, kernel_size, dropout_rate, padding):
+    if padding != 'SAME':
+        raise NotImplementedError('ffn_padding LEFT')
+    return nn.ModuleList([nn.Sequential(
+        nn.ConstantPad1d(((kernel_size - 1) // 2, (kernel_size - 1) // 2), 0),
+        nn.Conv1d(idim if i == 0 else n_chans, n_chans, kernel_size, stride=1, padding=0),
+        nn.ReLU(), _PredLayerNorm(n_chans, dim=1), nn.Dropout(dropout_rate)) for i in range(n_layers)])
+
+
+def _run_pred_convs(convs, packs, xc, T, keep):
+    for seq, pk in zip(convs, packs):
+        conv, ln = seq[1], seq[3]
+        y = conv1d_cm(xc, T, conv.weight, pk, conv.bias)            # ReLU is fused into the LayerNorm kernel's load
+        xc = layer_norm_cm(y, T, ln.weight, ln.bias, 1e-12, relu_in=True, keep=keep)
+    return xc
+
+
+class DurationPredictor(nn.Module):
+    def __init__(self, idim, n_layers=2, n_chans=384, kernel_size=3, dropout_rate=0.1, offset=1.0, padding='SAME'):
+        super().__init__()
+        if hparams['dur_loss'] != 'mse':
+            raise NotImplementedError(f"dur_loss {hparams['dur_loss']}")
+        self.offset, self.kernel_size = offset, kernel_size
+        self.conv = _pred_convs(idim, n_layers, n_chans, kernel_size, dropout_rate, padding)
+        self.linear = nn.Linear(n_chans, 1)
+        self._packs = [PackedWeight() for _ in range(n_layers)]
+        self._plin = PackedWeight()
+
+    def _forward(self, xs, x_masks, is_inference):
+        """tts_modules.py:107-120.  xs [B,T,idim]; x_masks [B,T] bool (True = pad)."""
+        T = xs.shape[1]
+        keep = (~x_masks).float().contiguous()
+        xc = _run_pred_convs(self.conv, self._packs, to_cm(xs), T, keep)
+        y = from_cm(conv1d_cm(xc, T, self.linear.weight, self._plin, self.linear.bias, keep=keep), T)        # [B,T,1]
+        if is_inference:
+            dur = torch.clamp(torch.round(y.squeeze(-1).exp() - self.offset), min=0).long()                 # out2dur :122-131
+            return dur, y
+        return y.squeeze(-1)
+
+    def forward(self, xs, x_masks=None):
+        return self._forward(xs, x_masks, False)
+
+    def inference(self, xs, x_masks=None):
+        return self._forward(xs, x_masks, True)
+
+
+class LengthRegulator(nn.Module):
+    def forward(self, dur, dur_padding=None, alpha=1.0):
+        """tts_modules.py:158-186 (index arithmetic only)."""
+        dur = torch.round(dur.float() * alpha).long()
+        if dur_padding is not None:
+            dur = dur * (1 - dur_padding.long())
+        token_idx = torch.arange(1, dur.shape[1] + 1)[None, :, None].to(dur.device)
+        dur_cumsum = torch.cumsum(dur, 1)
+        dur_cumsum_prev = F.pad(dur_cumsum, [1, -1], mode='constant', value=0)
+        pos_idx = torch.arange(int(dur.sum(-1).max()))[None, None].to(dur.device)
+        token_mask = (pos_idx >= dur_cumsum_prev[:, :, None]) & (pos_idx < dur_cumsum[:, :, None])
+        return (token_idx * token_mask.long()).sum(1)
+
+
+class PitchPredictor(nn.Module):
+    def __init__(self, idim, n_layers=5, n_chans=384, odim=2, kernel_size=5, dropout_rate=0.1, padding='SAME'):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.conv = _pred_convs(idim, n_layers, n_chans, kernel_size, dropout_rate, padding)
+        self.linear = nn.Linear(n_chans, odim)
+        self.embed_positions = SinusoidalPositionalEmbedding(idim, 0, init_size=4096)
+        self.pos_embed_alpha = nn.Parameter(torch.Tensor([1]))
+        self._packs = [PackedWeight() for _ in range(n_layers)]
+        self._plin = PackedWeight()
+
+    def forward(self, xs):
+        """tts_modules.py:215-229.  xs [B,T,idim] -> [B,T,odim]."""
+        T = xs.shape[1]
+        xs = xs + self.pos_embed_alpha * self.embed_positions(xs[..., 0])
+        xc = _run_pred_convs(self.conv, self._packs, to_cm(xs), T, None)
+        return from_cm(conv1d_cm(xc, T, self.linear.weight, self._plin, self.linear.bias), T)
+
+
+class _HipLinear(nn.Linear):
+    """nn.Linear whose forward on [B,T,C] / [B,C] inputs runs through the conv kernel (K = 1)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._pack = PackedWeight()
+
+    def forward(self, x, act='none'):
+        x3 = x if x.dim() == 3 else x[:, None, :]
+        T = x3.shape[1]
+        y = from_cm(conv1d_cm(to_cm(x3), T, self.weight, self._pack, self.bias, act=act), T)
+        return y if x.dim() == 3 else y[:, 0, :]
+
+
+def denorm_f0(f0, uv, hp, pitch_padding=None):
+    if hp['pitch_norm'] == 'standard':                                      # utils/pitch_utils.py:64-77
+        f0 = f0 * hp['f0_std'] + hp['f0_mean']
+    if hp['pitch_norm'] == 'log':
+        f0 = 2 ** f0
+    if uv is not None and hp['use_uv']:
+        f0[uv > 0] = 0
+    if pitch_padding is not None:
+        f0[pitch_padding] = 0
+    return f0
+
+
+def norm_f0(f0, uv, hp):
+    if hp['pitch_norm'] == 'standard':                                      # utils/pitch_utils.py:32-40
+        f0 = (f0 - hp['f0_mean']) / hp['f0_std']
+    if hp['pitch_norm'] == 'log':
+        f0 = torch.log2(f0)
+    if uv is not None and hp['use_uv']:
+        f0[uv > 0] = 0
+    return f0
+
+
+def f0_to_coarse(f0):
+    f0_mel = 1127 * (1 + f0 / 700).log()                                    # utils/pitch_utils.py:21-30
+    f0_mel[f0_mel > 0] = (f0_mel[f0_mel > 0] - f0_mel_min) * (f0_bin - 2) / (f0_mel_max - f0_mel_min) + 1
+    f0_mel[f0_mel <= 1] = 1
+    f0_mel[f0_mel > f0_bin - 1] = f0_bin - 1
+    return (f0_mel + 0.5).long()
+
+
+class FastSpeech2(nn.Module):
+    def __init__(self, dictionary, out_dims=None):
+        super().__init__()
+        for k in ('use_spk_id', 'use_spk_embed', 'use_energy_embed', 'pitch_ar'):
+            if hparams.get(k):
+                raise NotImplementedError(f'hparams[{k!r}] is not supported by the HIP FastSpeech2')
+        if hparams['encoder_type'] != 'fft' or hparams['decoder_type'] != 'fft':
+            raise NotImplementedError('encoder_type / decoder_type other than fft')
+        self.dictionary = dictionary
+        n_vocab = dictionary if isinstance(dictionary, int) else len(dictionary)
+        self.padding_idx = 0 if isinstance(dictionary, int) else dictionary.pad()
+        self.enc_layers, self.dec_layers, self.hidden_size = hparams['enc_layers'], hparams['dec_layers'], hparams['hidden_size']
+        H = self.hidden_size
+        self.encoder_embed_tokens = Embedding(n_vocab, H, self.padding_idx)
+        self.encoder = self._build_encoder()
+        self.decoder = FastspeechDecoder(H, hparams['dec_layers'], hparams['dec_ffn_kernel_size'], hparams['num_heads'])
+        self.out_dims = hparams['audio_num_mel_bins'] if out_dims is None else out_dims
+        self.mel_out = Linear(H, self.out_dims, bias=True)
+        self._pmel = PackedWeight()
+        ph = hparams['predictor_hidden'] if hparams['predictor_hidden'] > 0 else H
+        self.dur_predictor = DurationPredictor(H, n_chans=ph, n_layers=hparams['dur_predictor_layers'],
+                                               dropout_rate=hparams['predictor_dropout'], padding=hparams['ffn_padding'],
+                                               kernel_size=hparams['dur_predictor_kernel'])
+        self.length_regulator = LengthRegulator()
+        if hparams['use_pitch_embed']:
+            self.pitch_embed = Embedding(300, H, self.padding_idx)
+            if hparams['pitch_type'] == 'cwt':
+                h = hparams['cwt_hidden_size']
+                odim = 10 + (1 if hparams['use_uv'] else 0)
+                self.cwt_predictor = nn.Sequential(
+                    _HipLinear(H, h),
+                    PitchPredictor(h, n_chans=ph, n_layers=hparams['predictor_layers'], dropout_rate=hparams['predictor_dropout'],
+                                   odim=odim, padding=hparams['ffn_padding'], kernel_size=hparams['predictor_kernel']))
+                self.cwt_stats_layers = nn.Sequential(_HipLinear(H, h), nn.ReLU(), _HipLinear(h, h), nn.ReLU(), _HipLinear(h, 2))
+            elif hparams['pitch_type'] == 'frame':
+                self.pitch_predictor = PitchPredictor(H, n_chans=ph, n_layers=hparams['predictor_layers'],
+                                                      dropout_rate=hparams['predictor_dropout'], odim=2,
+                                                      padding=hparams['ffn_padding'], kernel_size=hparams['predictor_kernel'])
+            else:
+                raise NotImplementedError(f"pitch_type {hparams['pitch_type']}")
+
+    def _build_encoder(self):
+        return FastspeechEncoder(self.encoder_embed_tokens, self.hidden_size, hparams['enc_layers'], hparams['enc_ffn_kernel_size'],
+                                 num_heads=hparams['num_heads'])
+
+    # -- forward (fs2.py:93-149) -------------------------------------------------------------------------------------
+    def _encode(self, txt_tokens, **kwargs):
+        return self.encoder(txt_tokens)
+
+    @torch.no_grad()
+    def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None, skip_decoder=False,
+                spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, **kwargs):
+        if not infer:
+            raise NotImplementedError('the HIP FastSpeech2 is inference-only (training = SURVEY section 8 row f3)')
+        ret = {}
+        encoder_out = self._encode(txt_tokens, **kwargs)                                        # [B,T_txt,H]
+        src_nonpadding = (txt_tokens > 0).float()[:, :, None]
+        dur_inp = encoder_out * src_nonpadding
+        mel2ph = self.add_dur(dur_inp, mel2ph, txt_tokens, ret)
+        decoder_inp = F.pad(encoder_out, [0, 0, 1, 0])
+        decoder_inp = torch.gather(decoder_inp, 1, mel2ph[..., None].repeat([1, 1, encoder_out.shape[-1]]))
+        tgt_nonpadding = (mel2ph > 0).float()[:, :, None]
+        pitch_inp = decoder_inp * tgt_nonpadding
+        if hparams['use_pitch_embed']:
+            decoder_inp = decoder_inp + self.add_pitch(pitch_inp, f0, uv, mel2ph, ret, encoder_out=encoder_out * src_nonpadding)
+        ret['decoder_inp'] = decoder_inp = decoder_inp * tgt_nonpadding
+        if skip_decoder:
+            return ret
+        ret['mel_out'] = self.run_decoder(decoder_inp, tgt_nonpadding, ret, infer=infer, **kwargs)
+        return ret
+
+    def add_dur(self, dur_input, mel2ph, txt_tokens, ret):
+        src_padding = txt_tokens == 0
+        if mel2ph is None:
+            dur, xs = self.dur_predictor.inference(dur_input, src_padding)
+            ret['dur'], ret['dur_choice'] = xs, dur
+            mel2ph = self.length_regulator(dur, src_padding).detach()
+        else:
+            ret['dur'] = self.dur_predictor(dur_input, src_padding)
+        ret['mel2ph'] = mel2ph
+        return mel2ph
+
+    def add_pitch(self, decoder_inp, f0, uv, mel2ph, ret, encoder_out=None):
+        """fs2.py:183-231, inference."""
+        pitch_padding = mel2ph == 0
+        given = f0 is not None
+        if hparams['pitch_type'] == 'cwt':
+            pitch_padding = None
+            ret['cwt'] = cwt_out = self.cwt_predictor[1](self.cwt_predictor[0](decoder_inp))
+            s = encoder_out[:, 0, :]
+            st = self.cwt_stats_layers
+            stats_out = st[4](st[2](st[0](s, act='relu'), act='relu'))
+            mean = ret['f0_mean'] = stats_out[:, 0]
+            std = ret['f0_std'] = stats_out[:, 1]
+            if f0 is None:
+                std = std * hparams['cwt_std_scale']
+                f0 = self.cwt2f0_norm(cwt_out[:, :, :10], mean, std, mel2ph)
+                if hparams['use_uv']:
+                    uv = cwt_out[:, :, -1] > 0
+        else:
+            ret['pitch_pred'] = pitch_pred = self.pitch_predictor(decoder_inp)
+            if f0 is None:
+                f0 = pitch_pred[:, :, 0]
+            if hparams['use_uv'] and uv is None:
+                uv = pitch_pred[:, :, 1] > 0
+        ret['f0_denorm'] = f0_denorm = denorm_f0(f0, uv, hparams, pitch_padding=pitch_padding)
+        if pitch_padding is not None and not given:
+            f0[pitch_padding] = 0           # the reference's in-place edit of the pitch_pred view (:225-226)
+        pitch = f0_to_coarse(f0_denorm)
+        return self.pitch_embed(pitch)
+
+    def run_decoder(self, decoder_inp, tgt_nonpadding, ret, infer, **kwargs):
+        xc, T, keep = self.decoder.forward_cm(decoder_inp)                                      # fs2.py:233-237
+        return from_cm(conv1d_cm(xc, T, self.mel_out.weight, self._pmel, self.mel_out.bias, keep=tgt_nonpadding[:, :, 0].contiguous()), T)
+
+    def cwt2f0_norm(self, cwt_spec, mean, std, mel2ph):
+        b = (torch.arange(0, 10, device=cwt_spec.device).float()[None, None, :] + 1 + 2.5) ** (-2.5)     # utils/cwt.py:118-125
+        rec = (cwt_spec * b).sum(-1)
+        rec = (rec - rec.mean(-1, keepdim=True)) / rec.std(-1, keepdim=True)
+        f0 = (rec * std[:, None] + mean[:, None]).exp()
+        f0 = torch.cat([f0] + [f0[:, -1:]] * (mel2ph.shape[1] - f0.shape[1]), 1)
+        return norm_f0(f0, None, hparams)
+
+    def out2mel(self, out):
+        return out
+
+    @staticmethod
+    def mel_norm(x):
+        return (x + 5.5) / (6.3 / 2) - 1
+
+    @staticmethod
+    def mel_denorm(x):
+        return (x + 1) * (6.3 / 2) - 5.5
+
+
+class FastSpeech2MIDI(FastSpeech2):
+    def __init__(self, dictionary, out_dims=None):
+        super().__init__(dictionary, out_dims)
+        self.midi_embed = Embedding(300, self.hidden_size, self.padding_idx)
+        self.midi_dur_layer = Linear(1, self.hidden_size)
+        self.is_slur_embed = Embedding(2, self.hidden_size)
+
+    def _build_encoder(self):
+        return FastspeechMIDIEncoder(self.encoder_embed_tokens, self.hidden_size, hparams['enc_layers'], hparams['enc_ffn_kernel_size'],
+                                     num_heads=hparams['num_heads'])
+
+    def _encode(self, txt_tokens, **kwargs):
+        """diffsinger_midi/fs2.py:61-67."""
+        midi_embedding = self.midi_embed(kwargs['pitch_midi'])
+        midi_dur_embedding, slur_embedding = 0, 0
+        if kwargs.get('midi_dur') is not None:
+            # Linear(1, H) on [B,T,1]: an outer product (input width 1 is no contraction)
+            midi_dur_embedding = kwargs['midi_dur'][:, :, None] * self.midi_dur_layer.weight[:, 0] + self.midi_dur_layer.bias
+        if kwargs.get('is_slur') is not None:
+            slur_embedding = self.is_slur_embed(kwargs['is_slur'])
+        return self.encoder(txt_tokens, midi_embedding, midi_dur_embedding, slur_embedding)

@@ -1,0 +1,61 @@
+/* dsf.h - C ABI of the FastSpeech2 / FastSpeech2MIDI conditioner ops in libdsdenoise.so (MI355X, gfx950).
+ *
+ * the step BEFORE the diffusion hot path - it produces `cond` (decoder_inp) and the aux-decoder
+ * mel the shallow diffusion starts from.  The reference (MoonInTheRiver/DiffSinger) computes it with torch nn modules and
+ * has no FFI; these are the operators its modules would bind.  Every entry point names the reference code it replaces
+ * (paths relative to the reference root).  Conventions as in dsd.h: fp32 device pointers, `stream` a hipStream_t as void*,
+ * work is only ENQUEUED, 0 on success / negative dsd_status otherwise with the message in dsd_last_error().
+ *
+ * Internal activation layout ("channel-major"): [B][C][TS], frame axis contiguous, TS = dsf_padded_frames(T) (T rounded
+ * up to a multiple of 32); every op writes ZERO to the frames [T, TS).  Stateless: the caller owns every buffer. */
+#ifndef DSF_H
+#define DSF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation codes of dsf_conv1d */
+#define DSF_ACT_NONE 0
+#define DSF_ACT_RELU 1
+#define DSF_ACT_GELU 2      /* erf form, F.gelu default (modules/commons/common_layers.py:512-513) */
+
+int32_t dsf_padded_frames(int32_t T);
+
+/* Replaces nn.Conv1d / nn.Linear parameter storage: a torch weight [Co][Ci][K] (Linear: K = 1) repacked into the MFMA
+ * A-operand fragment order the conv kernel streams.  dsf_packed_floats = floats the packed buffer must hold (or -1). */
+int64_t dsf_packed_floats(int32_t Co, int32_t Ci, int32_t K);
+int dsf_pack_weight(const float* w, int32_t Co, int32_t Ci, int32_t K, float* packed, void* stream);
+
+/* nn.Conv1d (stride 1, odd kernel K <= 17, 'SAME' zero padding) / nn.Linear with the element-wise tail fused:
+ *     y = act(scale * (W * x + bias)) ; y += residual ; y *= keep[b][t]
+ * covering MultiheadAttention's in/out projections (modules/commons/common_layers.py:243-263), TransformerFFNLayer
+ * (ffn_1 * K**-0.5 -> gelu, ffn_2; :486-522), the residual + padding mask of EncSALayer (:565-588), the predictor
+ * Conv1d + ReLU (modules/fastspeech/tts_modules.py:84-97, :198-209) and mel_out (modules/fastspeech/fs2.py:233-237).
+ * in [B][Ci][TS], out / residual [B][Co][TS], bias [Co] or NULL, keep [B][T] (1 valid / 0 padding) or NULL.
+ * Ci must be a multiple of 8.  `in` must be zero in [T, TS) (every dsf op guarantees that for its output). */
+int dsf_conv1d(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co, int32_t K,
+               int32_t T, float scale, int32_t act, const float* residual, const float* keep, void* stream);
+
+/* nn.LayerNorm over the channel axis (C = 256 on this build): EncSALayer.layer_norm1/2 and FFTBlocks.layer_norm (eps 1e-5,
+ * common_layers.py:70-77, tts_modules.py:276-281,:306-307), the predictor LayerNorm(dim=1) (eps 1e-12, tts_modules.py:39-56)
+ * with the preceding ReLU (relu_in = 1).  out = LN(in) * gamma + beta, times keep[b][t] if given. */
+int dsf_layer_norm(const float* in, const float* gamma, const float* beta, float* out, int32_t B, int32_t C, int32_t T, float eps,
+                   int32_t relu_in, const float* keep, void* stream);
+
+/* The attention core of F.multi_head_attention_forward as MultiheadAttention.forward calls it (common_layers.py:243-263):
+ * per head softmax((q * head_dim**-0.5) k^T + key_padding_mask) v.  qkv [B][3C][TS] (q | k | v rows, head h = rows
+ * [h*128, h*128+128) of each), key_pad [B][T] bytes (nonzero = padded key) or NULL, out [B][C][TS].  head_dim 128. */
+int dsf_attention(const float* qkv, const uint8_t* key_pad, float* out, int32_t B, int32_t C, int32_t heads, int32_t T, void* stream);
+
+/* Layout changes at the boundary: the reference's [B,T,C] tensors (any element strides) <-> channel-major. */
+int dsf_to_channel_major(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_t, float* out, int32_t B, int32_t C,
+                         int32_t T, void* stream);
+int dsf_from_channel_major(const float* in, float* out /* [B][T][C] contiguous */, int32_t B, int32_t C, int32_t T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSF_H */

@@ -262,8 +262,7 @@ def add_pitch(p, hp, decoder_inp, f0, uv, mel2ph, ret, encoder_out):
     if hp['pitch_type'] == 'ph' or hp.get('pitch_ar'):
         raise NotImplementedError('pitch_type ph / pitch_ar')
     pitch_padding = mel2ph == 0
-    ph = hp['predictor_hidden'] if hp['predictor_hidden'] > 0 else hp['hidden_size']
-    del ph
+    given_f0 = f0 is not None
     if hp['pitch_type'] == 'cwt':
         pitch_padding = None
         h = F.linear(decoder_inp, p['cwt_predictor.0.weight'], p['cwt_predictor.0.bias'])
@@ -285,8 +284,13 @@ def add_pitch(p, hp, decoder_inp, f0, uv, mel2ph, ret, encoder_out):
             f0 = pp[:, :, 0]
         if hp['use_uv'] and uv is None:
             uv = pp[:, :, 1] > 0
-    f0 = f0.clone()
     ret['f0_denorm'] = f0_denorm = denorm_f0(f0, uv, hp, pitch_padding=pitch_padding)
+    if pitch_padding is not None:
+        # fs2.py:225-226 `f0[pitch_padding] = 0`: when f0 is the view pitch_pred[:, :, 0] this zeroes ret['pitch_pred'] at the
+        # padded frames as a side effect (kept: the returned pitch_pred is compared too); a caller-supplied f0 is not touched here
+        if given_f0:
+            f0 = f0.clone()
+        f0[pitch_padding] = 0
     pitch = f0_to_coarse(f0_denorm.clone())
     ret['pitch_coarse'] = pitch
     return F.embedding(pitch, p['pitch_embed.weight'], 0)

@@ -9,10 +9,10 @@ from diffsinger_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    src = open(os.path.join(ROOT, 'include', 'dsd.h')).read()
+def _header_symbols(header='dsd.h', prefix='dsd_'):
+    src = open(os.path.join(ROOT, 'include', header)).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(dsd_[a-z0-9_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(' + prefix + r'[a-z0-9_]+)\s*\(', src)))
 
 
 def test_library_is_built():
@@ -28,6 +28,18 @@ def test_library_exports_every_header_symbol():
     for name in _header_symbols():
         assert hasattr(lib, name), name
     assert lib.dsd_abi_version() == _lib.DSD_ABI_VERSION
+
+
+def test_fs2_header_symbols_bound_and_exported():
+    assert _header_symbols('dsf.h', 'dsf_') == sorted(_lib.SYMBOLS_FS2)
+    lib = _lib.load()
+    for name in _lib.SYMBOLS_FS2:
+        assert hasattr(lib, name), name
+    assert lib.dsf_padded_frames(33) == 64
+    assert lib.dsf_packed_floats(256, 256, 9) == (4 * 32 * 9 * 2 * 64 + 8192) * 4
+    assert lib.dsf_packed_floats(80, 250, 1) == -1                      # input channels must be a multiple of 8
+    assert lib.dsf_conv1d(None, None, None, None, 1, 8, 8, 1, 1, 1.0, 0, None, None, None) == -1      # rejected before any HIP call
+    assert b'dsf_conv1d' in lib.dsd_last_error()
 
 
 def test_bad_config_is_rejected_without_a_device():
