@@ -61,6 +61,7 @@ struct dsd_handle {
     bool has_weights = false, has_schedule = false, has_spec = false, prepared = false;
     bool use_graph = true;
     int layer_tile_req = 0;     // 0 auto, 32, 64
+    bool wt_stores = true;      // write-through epilogue stores in k_layer (env DSD_WT_STORES=0: plain stores)
     bool xcd_map = true;        // XCD-aware workgroup->tile map of k_layer (env DSD_XCD_MAP=0 restores the plain 2-D grid)
     int64_t bytes = 0;       // device bytes owned: packed weights + tables (persistent)
     int64_t bytes_ws = 0;    // ... + workspace of the prepared batch
@@ -148,6 +149,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     h->L = cfg->residual_layers;
     h->M = cfg->mel_bins;
     h->nk_in = (cfg->mel_bins + 7) / 8;
+    if (const char* ev = std::getenv("DSD_WT_STORES")) h->wt_stores = (std::atoi(ev) != 0);  // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
@@ -455,6 +457,7 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
     p.dbg = dbg;
     const int total = p.tiles_per_utt * h->B;
     dim3 grid((unsigned)p.tiles_per_utt, (unsigned)h->B);
+    p.wt_stores = h->wt_stores ? 1 : 0;
     p.xcd_q = -1; p.xcd_r = 0;
     if (h->xcd_map) { p.xcd_q = total / 8; p.xcd_r = total % 8; grid = dim3((unsigned)total); }
     const bool last = (l == h->L - 1);

@@ -213,12 +213,30 @@ struct LayerParams {
     const int* t_dev;       // per-utterance step index, or nullptr -> t_uniform
     int t_uniform, ds_tstride;
     int T, TS, ntile32, tiles_per_utt, dil, first;
+    int wt_stores;          // 1: x_out / skip leave through write-through (sc1) stores
     int xcd_q, xcd_r;       // XCD-aware workgroup map (1-D grid): total workgroups = 8 * xcd_q + xcd_r; xcd_q < 0 -> 2-D grid
     unsigned long long* dbg;   // optional per-wave phase timestamps [block][wave][8] (s_memtime), nullptr in production
 };
 
 template <int NB>
 constexpr int layer_lds_bytes() { return (kC * (32 * NB + 2 * kHalo) + kC * 32 * NB) * (int)sizeof(float); }
+
+// 16-byte store, optionally WRITE-THROUGH (sc1): the line leaves the XCD's L2 as it is written instead of staying dirty until
+// the kernel boundary, where the runtime's agent-scope release would have to write back every dirty line of the launch first
+// (16.8 MB of x / skip per layer launch = 2.8-3.8 us on top of the 1.45 us boundary, MI355X_MICROARCH.md "boundary" row).
+// base: WAVE-UNIFORM pointer (it becomes the SGPR buffer descriptor), idx: this lane's float4 index behind it.
+template <bool WT>
+__device__ __forceinline__ void store16(float4* base_uniform, int idx, const float4& v) {
+    if (WT) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const f32x4_ f = {v.x, v.y, v.z, v.w};
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7ffffff0, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, f), r, idx * 16, 0, 16);     // aux 16 = sc1
+    } else {
+        base_uniform[idx] = v;
+    }
+}
 
 __device__ __forceinline__ float f4at(const float4& v, int e) { return (e == 0) ? v.x : (e == 1) ? v.y : (e == 2) ? v.z : v.w; }
 
@@ -477,17 +495,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
                 o.y = (x.y + (v.y + bv)) * kInvSqrt2;
                 o.z = (x.z + (v.z + bv)) * kInvSqrt2;
                 o.w = (x.w + (v.w + bv)) * kInvSqrt2;
-                reinterpret_cast<float4*>(xo)[it * 64 + lane] = o;
+                if (p.wt_stores) store16<true>(reinterpret_cast<float4*>(xo), it * 64 + lane, o);
+                else store16<false>(reinterpret_cast<float4*>(xo), it * 64 + lane, o);
             }
         }
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
-            float4* sl = p.skip + (((size_t)(tile0 + nb) * 4 + w) * 2 + ms) * (4 * 64) + lane;
+            float4* sl = p.skip + (((size_t)(tile0 + nb) * 4 + w) * 2 + ms) * (4 * 64);      // wave-uniform
             const int m = (LAST ? 0 : 2) + ms;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 a = get4(acc2[m][nb], q), s = skp[ms][nb][q];
-                sl[q * 64] = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
+                const float4 sv = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
+                if (p.wt_stores) store16<true>(sl, q * 64 + lane, sv);
+                else store16<false>(sl, q * 64 + lane, sv);
             }
         }
     }
