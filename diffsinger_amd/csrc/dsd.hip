@@ -1,6 +1,7 @@
 // dsd.hip - host side of libdsdenoise.so: handle, weight repacking, schedule tables, workspace, launch
 // sequencing of the K-step reverse loop (eager or as a cached hipGraph).  C ABI in include/dsd.h.
 #include "dsd_kernels.hpp"
+#include "dsd_loop.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -93,6 +94,15 @@ struct dsd_handle {
 
     hipStream_t cap_stream = nullptr;
     std::map<GraphKey, hipGraphExec_t> graphs;
+
+    // persistent K-step loop (dsd_loop.hpp): 1 = one kernel for the whole loop when the batch geometry allows it
+    int loop_mode = 1;
+    int n_cu = 0;               // workgroups that are certainly co-resident at 1 per CU
+    struct LoopPlan { HeadParams* evals = nullptr; int* eval_t = nullptr; int n_evals = 0; };
+    std::map<GraphKey, LoopPlan> plans;
+    unsigned* loop_flags = nullptr;   // [ntiles] + timeout word behind it
+    float* loop_halo = nullptr;       // [2][ntiles][2][256][8]
+    int loop_cap_tiles = 0;
 };
 
 static const int kSlack = 64;   // floats of slack in front of / behind the x buffers (masked halo loads)
@@ -115,6 +125,8 @@ static void dev_free(T*& p) {
 static void drop_graphs(dsd_handle* h) {
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
+    for (auto& kv : h->plans) { if (kv.second.evals) (void)hipFree(kv.second.evals); if (kv.second.eval_t) (void)hipFree(kv.second.eval_t); }
+    h->plans.clear();
 }
 
 static void free_workspace(dsd_handle* h) {
@@ -123,6 +135,8 @@ static void free_workspace(dsd_handle* h) {
     dev_free(h->xs); dev_free(h->xtmp);
     for (auto& e : h->ering) dev_free(e);
     dev_free(h->t_dev);
+    dev_free(h->loop_flags); dev_free(h->loop_halo);
+    h->loop_cap_tiles = 0;
     h->xa = h->xb = nullptr;
     h->cap_frames = 0; h->cap_B = 0; h->cap_spec = 0;
     h->bytes_ws = 0;
@@ -149,6 +163,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     h->L = cfg->residual_layers;
     h->M = cfg->mel_bins;
     h->nk_in = (cfg->mel_bins + 7) / 8;
+    if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);                // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_WT_STORES")) h->wt_stores = (std::atoi(ev) != 0);  // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
     for (int l = 0; l < h->L; ++l) {
@@ -157,6 +172,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         h->dil.push_back(1 << e);
     }
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
     if (e == hipSuccess) {
         // kernels that need more than 64 KiB of dynamic LDS must opt in
@@ -164,6 +180,8 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_layer<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>());
         (void)hipFuncSetAttribute((const void*)k_layer<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
+        (void)hipFuncSetAttribute((const void*)k_loop<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -630,6 +648,100 @@ static int enqueue_plms(dsd_handle* h, int k_step, int interval, hipStream_t s) 
     return DSD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// persistent loop (dsd_loop.hpp)
+// ------------------------------------------------------------------------------------------------------------
+// The per-evaluation head parameters, exactly what enqueue_ddpm / enqueue_plms bake into their launches.
+static void plan_evals(dsd_handle* h, int kind, int k_step, int interval, std::vector<HeadParams>& ev, std::vector<int>& ts_out) {
+    const size_t bmt = (size_t)h->B * h->M * h->T;
+    if (kind == 0) {
+        for (int j = 0; j < k_step; ++j) {
+            const int t = k_step - 1 - j;
+            HeadParams p = head_base(h);
+            p.x_base = h->xs; p.x_out = h->xs;
+            p.noise_off = (size_t)j * bmt;
+            p.sa = h->tab[6][t]; p.sb = h->tab[7][t]; p.c1 = h->tab[10][t]; p.c2 = h->tab[11][t];
+            p.sigma = (t == 0) ? 0.f : std::exp(0.5f * h->tab[9][t]);
+            ev.push_back(p); ts_out.push_back(t);
+        }
+        return;
+    }
+    int hist = 0, head_slot = 0;
+    std::vector<int> ts;
+    for (int i = 0; i < k_step; i += interval) ts.push_back(i);
+    for (int n = (int)ts.size() - 1; n >= 0; --n) {
+        const int t = ts[n];
+        float dA, cx, ce;
+        plms_coef(h, t, interval, &dA, &cx, &ce);
+        HeadParams p = head_base(h);
+        p.dA = dA; p.cx = cx; p.ce = ce;
+        float* slot = h->ering[head_slot & 3];
+        if (hist == 0) {
+            p.order = PLMS_RAW; p.x_base = h->xs; p.x_out = h->xtmp; p.eps_out = slot;
+            ev.push_back(p); ts_out.push_back(t);
+            HeadParams q = head_base(h);
+            q.dA = dA; q.cx = cx; q.ce = ce;
+            q.order = PLMS_HEUN; q.x_base = h->xs; q.x_out = h->xs; q.eps_out = nullptr; q.e1 = slot;
+            ev.push_back(q); ts_out.push_back(std::max(t - interval, 0));
+        } else {
+            p.order = (hist == 1) ? PLMS_AB2 : (hist == 2) ? PLMS_AB3 : PLMS_AB4;
+            p.x_base = h->xs; p.x_out = h->xs; p.eps_out = slot;
+            p.e1 = h->ering[(head_slot - 1) & 3]; p.e2 = h->ering[(head_slot - 2) & 3]; p.e3 = h->ering[(head_slot - 3) & 3];
+            ev.push_back(p); ts_out.push_back(t);
+        }
+        ++head_slot;
+        hist = std::min(hist + 1, 3);
+    }
+}
+
+// true when the prepared batch can run as the persistent loop: 32-frame tiles, a whole utterance fits the co-resident grid
+static bool loop_applicable(const dsd_handle* h) {
+    return h->loop_mode == 1 && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 && h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers;
+}
+
+static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hipStream_t s) {
+    const GraphKey key{kind, h->B, h->T, k_step, interval, 32};
+    auto it = h->plans.find(key);
+    if (it == h->plans.end()) {
+        std::vector<HeadParams> ev; std::vector<int> ts;
+        plan_evals(h, kind, k_step, interval, ev, ts);
+        dsd_handle::LoopPlan pl;
+        pl.n_evals = (int)ev.size();
+        HIP_TRY(hipMalloc((void**)&pl.evals, ev.size() * sizeof(HeadParams)));
+        HIP_TRY(hipMalloc((void**)&pl.eval_t, ts.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(pl.evals, ev.data(), ev.size() * sizeof(HeadParams), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(pl.eval_t, ts.data(), ts.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (h->plans.size() >= 8) drop_graphs(h);
+        it = h->plans.emplace(key, pl).first;
+    }
+    if (h->loop_cap_tiles < h->ntiles) {
+        dev_free(h->loop_flags); dev_free(h->loop_halo);
+        DSD_TRY(dev_alloc(h, &h->loop_flags, (size_t)h->ntiles + 64, true));
+        DSD_TRY(dev_alloc(h, &h->loop_halo, (size_t)2 * h->ntiles * 2 * kC * 8, true));
+        h->loop_cap_tiles = h->ntiles;
+    }
+    HIP_TRY(hipMemsetAsync(h->loop_flags, 0, ((size_t)h->ntiles + 64) * sizeof(unsigned), s));
+    LoopParams p{};
+    p.w1p = h->w1p; p.w2p = h->w2p; p.b2raw = h->b2raw; p.cp = h->cp; p.cp_lstride = (size_t)h->ntiles * 4096;
+    p.ds_table = h->ds_table;
+    p.L = h->L; p.T = h->T; p.TS = h->TS; p.ntile32 = h->ntile32; p.ntiles_total = h->ntiles;
+    for (int l = 0; l < h->L; ++l) p.dil[l] = (unsigned char)h->dil[l];
+    p.head = head_base(h);
+    p.evals = it->second.evals; p.eval_t = it->second.eval_t; p.n_evals = it->second.n_evals;
+    p.spec0 = h->xs;
+    p.flags = h->loop_flags; p.halo = h->loop_halo; p.tmo = h->loop_flags + h->ntiles;
+    // chunks of whole utterances, at most one workgroup per CU (all workgroups of a launch wait for each other)
+    const int utt_per_chunk = std::max(1, h->n_cu / h->ntile32);
+    for (int b0 = 0; b0 < h->B; b0 += utt_per_chunk) {
+        const int nb = std::min(utt_per_chunk, h->B - b0);
+        p.tile_base = b0 * h->ntile32; p.n_tiles = nb * h->ntile32;
+        if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
+        else hipLaunchKernelGGL((k_loop<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
+        HIP_TRY(hipGetLastError());
+    }
+    return DSD_OK;
+}
+
 static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k_step, int interval, hipStream_t s) {
     const size_t bmt = (size_t)h->B * h->M * h->T;
     HIP_TRY(hipMemcpyAsync(h->xs, x, bmt * 4, hipMemcpyDeviceToDevice, s));
@@ -637,7 +749,9 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
         hipLaunchKernelGGL(k_set_cell, dim3(1), dim3(1), 0, s, h->noise_cell, noise);
         HIP_TRY(hipGetLastError());
     }
-    if (!h->use_graph) {
+    if (loop_applicable(h)) {
+        DSD_TRY(run_persistent(h, kind, k_step, interval, s));
+    } else if (!h->use_graph) {
         DSD_TRY(kind == 0 ? enqueue_ddpm(h, k_step, s) : enqueue_plms(h, k_step, interval, s));
     } else {
         const GraphKey key{kind, h->B, h->T, k_step, interval, layer_nb(h)};
@@ -660,6 +774,24 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
     }
     HIP_TRY(hipMemcpyAsync(x, h->xs, bmt * 4, hipMemcpyDeviceToDevice, s));
     return DSD_OK;
+}
+
+extern "C" int dsd_set_loop_mode(dsd_handle* h, int32_t mode) {
+    if (!h || mode < 0 || mode > 1) return fail(DSD_ERR_INVALID, "dsd_set_loop_mode: mode must be 0 (per-layer kernels) or 1 (persistent loop)");
+    h->loop_mode = mode;
+    return DSD_OK;
+}
+
+extern "C" int dsd_get_loop_mode(dsd_handle* h) { return (h && h->prepared && loop_applicable(h)) ? 1 : 0; }
+
+extern "C" int dsd_loop_timeouts(dsd_handle* h, void* stream) {
+    if (!h) return fail(DSD_ERR_INVALID, "dsd_loop_timeouts: null handle");
+    if (!h->loop_flags) return 0;
+    unsigned v = 0;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(&v, h->loop_flags + h->ntiles, sizeof v, hipMemcpyDeviceToHost));
+    return (int)v;
 }
 
 extern "C" int dsd_sample_ddpm(dsd_handle* h, float* x, const float* noise, int32_t k_step, void* stream) {

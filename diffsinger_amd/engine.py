@@ -100,6 +100,21 @@ class DenoiserEngine:
     def set_use_graph(self, enable: bool):
         _lib.check(self.lib.dsd_set_use_graph(self._h, int(bool(enable))))
 
+    def set_loop_mode(self, mode: int):
+        """1 (default): the whole K-step loop as one persistent kernel when the batch allows it; 0: per-layer kernels."""
+        _lib.check(self.lib.dsd_set_loop_mode(self._h, int(mode)), 'dsd_set_loop_mode')
+
+    def loop_mode(self) -> int:
+        return self.lib.dsd_get_loop_mode(self._h)
+
+    def loop_timeouts(self) -> int:
+        """Synchronises; nonzero = an inter-workgroup wait of the persistent loop hit its spin bound (results invalid)."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.dsd_loop_timeouts(self._h, _stream_ptr(self.device))
+        if rc < 0:
+            _lib.check(rc, 'dsd_loop_timeouts')
+        return rc
+
     def set_layer_tile(self, frames: int):
         _lib.check(self.lib.dsd_set_layer_tile(self._h, int(frames)))
 

@@ -129,6 +129,17 @@ int dsd_denorm_spec(dsd_handle* h, const float* x, const float* mask, float* mel
 
 /* Options: 0 = eager launches (default 1 = replay the K-step loop as a cached hipGraph). */
 int dsd_set_use_graph(dsd_handle* h, int32_t enable);
+/* How the K-step loops run.  mode 1 (default): ONE persistent kernel for the whole loop whenever the prepared batch allows it
+ * (32-frame tiles, hipGraph mode on, one utterance's tiles <= the CU count) - every workgroup keeps its x tile and skip sum in
+ * registers across layers and steps and exchanges only the conv halo with its neighbours; larger batches run as chunks of
+ * whole utterances.  mode 0: one kernel per residual layer + head (a cached hipGraph, or eager launches, see above).  Both
+ * give bit-identical results.  dsd_get_loop_mode: 1 if the prepared batch would take the persistent path.
+ * dsd_loop_timeouts: synchronises the stream and returns the sticky timeout word of the persistent loop (0 = every
+ * inter-workgroup wait was satisfied; nonzero = a wait hit its spin bound and the results are invalid). */
+int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
+int dsd_get_loop_mode(dsd_handle* h);
+int dsd_loop_timeouts(dsd_handle* h, void* stream);
+
 /* Frames per workgroup of the residual-layer kernel: 0 = choose from the batch size, 32 or 64. */
 int dsd_set_layer_tile(dsd_handle* h, int32_t frames);
 

@@ -1,0 +1,72 @@
+"""GPU: the persistent K-step loop (csrc/dsd_loop.hpp: one kernel for the whole loop, x and the skip sum resident in
+registers, halo exchange between neighbouring workgroups) against the per-layer-kernel hipGraph path.  Same arithmetic in the
+same order -> BIT-identical; every inter-workgroup wait satisfied (no timeout); also against the reference fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(name, loop_mode):
+    from tests.gpu_helpers import build_hip
+    case, pre, cfg, k_step, inp, smin, smax = H.case_setup(name)
+    gd, _, _ = build_hip(case['preset'], k_step, legacy=bool(case.get('legacy')))
+    cond = inp['cond'].transpose(1, 2).contiguous().cuda().transpose(1, 2)
+    eng = gd._engine(cond)
+    eng.set_loop_mode(loop_mode)
+    with torch.no_grad():
+        if case['kind'] == 'plms':
+            out = gd.inference(cond, x_T=inp['x_T'].cuda(), K_step=k_step, pndm_speedup=case['interval'])
+        elif case['gaussian']:
+            out = gd.inference(cond, x_T=inp['x_T'].cuda(), noise=inp['noise'].cuda(), K_step=k_step, pndm_speedup=0)
+        else:
+            out = gd.inference(cond, fs2_mels=inp['fs2_mel'].cuda(), q_noise=inp['q_noise'].cuda(), noise=inp['noise'].cuda(),
+                               K_step=k_step, pndm_speedup=0, gaussian_start=False)
+    used = eng.loop_mode()
+    tmo = eng.loop_timeouts()
+    return out.cpu().numpy(), used, tmo
+
+
+@pytest.mark.parametrize('name', ['ddpm_lj_k100', 'shallow_opencpop_k60', 'shallow_popcs_k51', 'plms_opencpop_i40', 'plms_opencpop_i250'])
+def test_persistent_loop_equals_per_layer_kernels(name):
+    a, used_a, tmo_a = _run(name, 1)
+    b, used_b, _ = _run(name, 0)
+    assert used_a == 1 and used_b == 0
+    assert tmo_a == 0, 'an inter-workgroup wait timed out'
+    np.testing.assert_array_equal(a, b)
+    g = H.load_golden(name)['out']
+    scale = max(1.0, float(np.abs(g).max())) if 'plms' in name else 1.0
+    assert float(np.abs(a - g).max()) / scale <= 1e-4
+
+
+@pytest.mark.parametrize('B,T,K', [(8, 1024, 12), (5, 2048, 6), (3, 1000, 8)])
+def test_persistent_loop_full_width(B, T, K):
+    """Bench-size batches: 256 workgroups at once (8 x 1024), chunks of whole utterances (5 x 2048 -> 4 + 1), ragged T."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from diffsinger_amd.synth import presets
+    pre = presets()['opencpop_ds60_rel']                       # dilation cycle 4: halos up to 8 frames
+    hparams.clear()
+    diffsinger_amd.use_preset('opencpop_ds60_rel')
+    torch.manual_seed(3)
+    net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+    torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=100, K_step=K, loss_type='l1', spec_min=pre['spec_min'],
+                                          spec_max=pre['spec_max']).cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    cond = torch.randn(B, T, 256, device='cuda', generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, device='cuda', generator=g)
+    noise = torch.randn(K, B, 1, 80, T, device='cuda', generator=g)
+    eng = gd._engine(cond)
+    outs = []
+    for mode in (1, 0):
+        eng.set_loop_mode(mode)
+        with torch.no_grad():
+            outs.append(gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).cpu().numpy())
+        assert eng.loop_mode() == mode
+        assert eng.loop_timeouts() == 0
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert np.isfinite(outs[0]).all()
