@@ -103,6 +103,8 @@ struct dsd_handle {
     unsigned* loop_flags = nullptr;   // [ntiles] + timeout word behind it
     float* loop_halo = nullptr;       // [2][ntiles][2][256][8]
     int loop_cap_tiles = 0;
+    unsigned long long* loop_dbg = nullptr;   // debug: stamps of one phase (dsd_debug_loop_timeline)
+    int loop_dbg_phase = 0;
 };
 
 static const int kSlack = 64;   // floats of slack in front of / behind the x buffers (masked halo loads)
@@ -730,6 +732,7 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
     p.evals = it->second.evals; p.eval_t = it->second.eval_t; p.n_evals = it->second.n_evals;
     p.spec0 = h->xs;
     p.flags = h->loop_flags; p.halo = h->loop_halo; p.tmo = h->loop_flags + h->ntiles;
+    p.dbg = h->loop_dbg; p.dbg_phase = h->loop_dbg_phase;
     // chunks of whole utterances, at most one workgroup per CU (all workgroups of a launch wait for each other)
     const int utt_per_chunk = std::max(1, h->n_cu / h->ntile32);
     for (int b0 = 0; b0 < h->B; b0 += utt_per_chunk) {
@@ -792,6 +795,32 @@ extern "C" int dsd_loop_timeouts(dsd_handle* h, void* stream) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(&v, h->loop_flags + h->ntiles, sizeof v, hipMemcpyDeviceToHost));
     return (int)v;
+}
+
+// Debug hook: run the persistent DDPM loop once on the prepared batch (x, noise as for dsd_sample_ddpm) with per-wave shader-clock
+// stamps taken in phase `phase` (= evaluation * L + layer; pick a non-last layer): HOST out[n_wg * 4 * 8] u64 with, per wave,
+// {phase start, neighbours' flags seen, y tile staged, conv done, gate done, x' ready, halo published, phase end}.
+extern "C" int dsd_debug_loop_timeline(dsd_handle* h, float* x, const float* noise, int32_t k_step, int32_t phase, uint64_t* out,
+                                       int32_t max_wg, int32_t* n_wg, void* stream) {
+    DSD_TRY(check_ready(h, "dsd_debug_loop_timeline", true));
+    if (!x || !noise || !out || !n_wg) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: null argument");
+    if (!loop_applicable(h)) return fail(DSD_ERR_STATE, "dsd_debug_loop_timeline: the prepared batch does not take the persistent path");
+    if (h->ntiles > h->n_cu || h->ntiles > max_wg) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: needs a single-launch batch (%d tiles)", h->ntiles);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    DSD_TRY(build_step_table(h, h->n_sched, s));
+    HIP_TRY(hipMalloc((void**)&h->loop_dbg, (size_t)h->ntiles * 32 * 8));
+    HIP_TRY(hipMemsetAsync(h->loop_dbg, 0, (size_t)h->ntiles * 32 * 8, s));
+    h->loop_dbg_phase = phase;
+    const int rc = run_loop(h, 0, x, noise, k_step, 0, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(out, h->loop_dbg, (size_t)h->ntiles * 32 * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(h->loop_dbg);
+    h->loop_dbg = nullptr;
+    if (rc != DSD_OK) return rc;
+    if (e != hipSuccess) return fail(DSD_ERR_HIP, "dsd_debug_loop_timeline: %s", hipGetErrorString(e));
+    *n_wg = h->ntiles;
+    return DSD_OK;
 }
 
 extern "C" int dsd_sample_ddpm(dsd_handle* h, float* x, const float* noise, int32_t k_step, void* stream) {

@@ -44,6 +44,8 @@ struct LoopParams {
     float* halo;                // [2][ntiles_total][2 sides][256][8]
     unsigned* tmo;              // sticky timeout word, zero at launch
     int tile_base, n_tiles;     // this launch covers tiles [tile_base, tile_base + n_tiles)
+    unsigned long long* dbg;    // optional s_memtime stamps of phase dbg_phase: [workgroup][wave][8]
+    int dbg_phase;
 };
 
 constexpr int kLoopLdsBytes = (kC * (32 + 2 * kHalo) + 2 * kC * 32) * (int)sizeof(float);      // y tile + gate tile + scratch
@@ -102,44 +104,39 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
     __syncthreads();
     inproj_to_xreg();
 
+    // publish this tile's first / last 8 columns of x (xreg) as the halo of phase `phase`: write-through stores, EVERY storing
+    // wave drained, barrier, ONE relaxed agent-scope flag store.  Called as soon as x is known (behind the residual half of the
+    // output projection / behind the input projection), so the hop overlaps the skip half / the head of the neighbours.
+    auto publish = [&](unsigned phase) {
+        float* hb = p.halo + ((size_t)(phase & 1) * p.ntiles_total + tile) * (2 * kC * 8);
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(hb, 0, 0x7ffffff0, 0x00020000);
+        if (xc4 < 2 || xc4 >= 6) {
+            const int side = (xc4 >= 6) ? 1 : 0, c = xc4 & 1;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const f32x4_ f = {xreg[it].x, xreg[it].y, xreg[it].z, xreg[it].w};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, f), r, ((side * kC + xrow0 + 8 * it) * 8 + 4 * c) * 4, 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gu32*)(p.flags + tile), phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // debug stamps go straight to memory (held in registers they would cost 20 VGPRs for the whole kernel)
+    const bool stamp = p.dbg != nullptr;
+#define LOOP_STAMP(i) do { if (stamp && ph == (unsigned)p.dbg_phase && lane == 0) p.dbg[((size_t)tl * 4 + w) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
     unsigned ph = 0;
+    publish(0);
     for (int e = 0; e < p.n_evals; ++e) {
         const int t_e = p.eval_t[e];
         for (int l = 0; l < p.L; ++l, ++ph) {
             const bool last = (l == p.L - 1);
             const float* __restrict__ dsl = p.ds_table + ((size_t)t_e * p.L + l) * kC;
             const int dil = p.dil[l];
-
-            // (a) publish this tile's boundary columns of x for phase ph (write-through), then raise the flag
-            {
-                float* hb = p.halo + ((size_t)(ph & 1) * p.ntiles_total + tile) * (2 * kC * 8);
-                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                typedef float f32x4_ __attribute__((ext_vector_type(4)));
-                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(hb, 0, 0x7ffffff0, 0x00020000);
-                if (xc4 < 2 || xc4 >= 6) {
-                    const int side = (xc4 >= 6) ? 1 : 0, c = xc4 & 1;
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const f32x4_ f = {xreg[it].x, xreg[it].y, xreg[it].z, xreg[it].w};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, f), r, ((side * kC + xrow0 + 8 * it) * 8 + 4 * c) * 4, 0, 16);
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains before the flag
-            }
-            // (b) own columns of y = x + step_proj (zero at frames >= T: the conv's zero padding applies to y, net.py:69-71)
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = xrow0 + 8 * it, t = t0 + 4 * xc4;
-                const float d = dsl[row];
-                float4 v = xreg[it];
-                v.x = (t + 0 < T) ? v.x + d : 0.f;
-                v.y = (t + 1 < T) ? v.y + d : 0.f;
-                v.z = (t + 2 < T) ? v.z + d : 0.f;
-                v.w = (t + 3 < T) ? v.w + d : 0.f;
-                *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 4 * xc4) = v;
-            }
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store((gu32*)(p.flags + tile), ph + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            LOOP_STAMP(0);
 
             // (c) the weight stream does not depend on anything computed here: request its first chunks now
             const float* yl = ytile + 4 * h * LD + kHalo + j;
@@ -148,7 +145,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             GemmPipe<4, 1, LD, 256, 6, decltype(bof1)> pipe1(p.w1p + ((size_t)l * 4 + w) * (96 * 256), lane, 96, bof1);
             pipe1.template start_a<0, 5>();
 
-            // (d) wait until both neighbours have published phase ph (one lane per neighbour polls, relaxed, bounded)
+            // (d) both neighbours have published phase ph?  (they did so in the middle of their previous phase: normally no wait)
             if (w == 0 && lane < 2) {
                 const bool have = lane ? has_right : has_left;
                 if (have) {
@@ -162,9 +159,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 }
             }
             __syncthreads();
-            // (e) neighbours' columns -> halo columns of the y tile (thread = channel row)
+            LOOP_STAMP(1);
+            // (e1) request the neighbours' columns (thread = channel row; sc1 loads: the producer stored write-through)
+            float4 hv[2][2];
             {
-                const float d = dsl[tid];
                 const float* hbase = p.halo + (size_t)(ph & 1) * p.ntiles_total * (2 * kC * 8);
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
@@ -173,8 +171,32 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     const int off = (((tile + (side ? 1 : -1)) * 2 + (side ? 0 : 1)) * kC + tid) * 8 * 4;
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (have) v = ld16_sc1(hbase, off + 16 * g);
+                        hv[side][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (have) hv[side][g] = ld16_sc1(hbase, off + 16 * g);
+                    }
+                }
+            }
+            // (b) own columns of y = x + step_proj (zero at frames >= T: the conv's zero padding applies to y, net.py:69-71)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = xrow0 + 8 * it, t = t0 + 4 * xc4;
+                const float d = dsl[row];
+                float4 v = xreg[it];
+                v.x = (t + 0 < T) ? v.x + d : 0.f;
+                v.y = (t + 1 < T) ? v.y + d : 0.f;
+                v.z = (t + 2 < T) ? v.z + d : 0.f;
+                v.w = (t + 3 < T) ? v.w + d : 0.f;
+                *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 4 * xc4) = v;
+            }
+            // (e2) halo columns of the y tile
+            {
+                const float d = dsl[tid];
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const bool have = side ? has_right : has_left;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        float4 v = hv[side][g];
                         const int t = side ? t0 + 32 + 4 * g : t0 - kHalo + 4 * g;
                         v.x = (have && t + 0 < T) ? v.x + d : 0.f;
                         v.y = (have && t + 1 < T) ? v.y + d : 0.f;
@@ -185,6 +207,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 }
             }
             __syncthreads();
+            LOOP_STAMP(2);
 
             // (g) dilated conv, K = 768 (one contraction, taps are column offsets), cond projection fetched half way
             f32x16 acc[4][1];
@@ -219,12 +242,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     }
             };
             float* tw = xt + w * (64 * 32);
+            LOOP_STAMP(3);
             if (!last) {
-                // output projection, all four row blocks (0,1 residual, 2,3 skip)
+                // output projection, all four row blocks (0,1 residual, 2,3 skip) in one pass.  (Splitting it - residual rows
+                // first, halo published, skip rows behind - hides the hop but costs more in pipeline restart + second B pass
+                // than the hop itself: measured 135.3 vs 133.0 ms per 100-step loop, profiles/r01h.)
                 GemmPipe<4, 1, GLD, 256, 6, TileB> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
+                LOOP_STAMP(4);
                 f32x16 acc2[4][1];
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -237,6 +264,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 for (int it = 0; it < 8; ++it) brow[it] = p.b2raw[(size_t)l * 2 * kC + 64 * w + it * 8 + (lane >> 3)];
                 DSD_SB();
                 pipe2.run(acc2, 6, 32);
+                LOOP_STAMP(5);
                 // residual: accumulator fragments -> row layout through this wave's slice of the scratch; x' = (x + res + b) / sqrt(2)
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
@@ -257,7 +285,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     o.w = (x.w + (v.w + bv)) * kInvSqrt2;
                     xreg[it] = o;
                 }
-                __builtin_amdgcn_wave_barrier();
+                LOOP_STAMP(6);
+                publish(ph + 1u);
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -265,6 +294,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                         const float4 a = get4(acc2[2 + ms][0], q), s = skp[ms][q];
                         skp[ms][q] = (l == 0) ? a : make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
                     }
+                LOOP_STAMP(7);
             } else {
                 // last layer: only the skip half (net.py:126 reads the skips; the residual is dead)
                 GemmPipe<2, 1, GLD, 256, 6, TileB> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256) + 2 * 64, lane, 32, bof2);
@@ -297,6 +327,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
         float* htile = gtile;               // [256][32]
         float* ptile = xt;                  // [96][32]
         __syncthreads();                    // all waves are out of the last layer's out-proj (gate tile reads)
+        // weight streams of the head GEMMs are requested ahead of the barriers that gate their B tiles
+        const float* sl = stile + 4 * h * 32 + j;
+        GemmPipe<2, 1, 32, 128, 6, TileB> pipe_s(p.head.wsp + (size_t)w * (32 * 128), lane, 32, TileB{sl, 8 * 32, 32});
+        pipe_s.start_a();
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -314,67 +348,86 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) set4(acc[mb][0], q, p.head.bsp[((w * 2 + mb) * 2 + h) * 4 + q]);
-            const float4* ap = p.head.wsp + (size_t)w * (32 * 128);
-            const float* sl = stile + 4 * h * 32 + j;
-            gemm_k<2, 1, 32, 128>(acc, ap, lane, 32, TileB{sl, 8 * 32, 32});
+            pipe_s.start_b();
+            pipe_s.run(acc, 0, 32);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     htile[(64 * w + 32 * mb + frag_row(r, h)) * 32 + j] = fmaxf(acc[mb][0][r], 0.f);
         }
+        const float* hl = htile + 4 * h * 32 + j;
+        GemmPipe<1, 1, 32, 192, 6, TileB> pipe_o(p.head.woutp + (size_t)min(w, 2) * 64, lane, 32, TileB{hl, 8 * 32, 32});
+        if (w < 3) pipe_o.start_a();
         __syncthreads();
         if (w < 3) {
             f32x16 acc[1][1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) set4(acc[0][0], q, p.head.boutp[(w * 2 + h) * 4 + q]);
-            const float4* ap = p.head.woutp + (size_t)w * 64;
-            const float* hl = htile + 4 * h * 32 + j;
-            gemm_k<1, 1, 32, 192>(acc, ap, lane, 32, TileB{hl, 8 * 32, 32});
+            pipe_o.start_b();
+            pipe_o.run(acc, 0, 32);
             const int t = t0 + j;
+            // sampler arithmetic (p_sample :134-166 / p_sample_plms :168-204).  All global reads of the 16 elements are issued
+            // first (one workgroup per CU: nothing else would hide their latency), then the element-wise math, then the stores.
+            size_t idxs[16];
+            bool oks[16];
+            float xv[16], av[16], bv[16], cv[16];
+            const float* nz = nullptr;
+            if (MODE == HEAD_DDPM) nz = *hp.noise_cell + hp.noise_off;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 32 * w + frag_row(r, h);
-                const bool ok = (m < M) && (t < T);
-                const size_t idx = ((size_t)b * M + m) * T + t;
-                const float eps = acc[0][0][r];
-                float xn = 0.f;
-                if (ok) {
-                    if (MODE == HEAD_DDPM) {
-                        const float x = hp.x_base[idx];
-                        const float z = (*hp.noise_cell)[hp.noise_off + idx];
-                        float x0 = __fsub_rn(__fmul_rn(hp.sa, x), __fmul_rn(hp.sb, eps));
-                        x0 = fminf(fmaxf(x0, -1.f), 1.f);
-                        const float mean = __fadd_rn(__fmul_rn(hp.c1, x0), __fmul_rn(hp.c2, x));
-                        xn = __fadd_rn(mean, __fmul_rn(hp.sigma, z));
-                        hp.x_out[idx] = xn;
-                    } else {
-                        float ep;
-                        if (hp.order == PLMS_RAW) {
-                            ep = eps;
-                        } else if (hp.order == PLMS_HEUN) {
-                            ep = __fmul_rn(__fadd_rn(hp.e1[idx], eps), 0.5f);
-                        } else if (hp.order == PLMS_AB2) {
-                            ep = __fmul_rn(__fsub_rn(__fmul_rn(3.f, eps), hp.e1[idx]), 0.5f);
-                        } else if (hp.order == PLMS_AB3) {
-                            ep = __fdiv_rn(__fadd_rn(__fsub_rn(__fmul_rn(23.f, eps), __fmul_rn(16.f, hp.e1[idx])), __fmul_rn(5.f, hp.e2[idx])), 12.f);
-                        } else {
-                            ep = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(55.f, eps), __fmul_rn(59.f, hp.e1[idx])),
-                                                               __fmul_rn(37.f, hp.e2[idx])), __fmul_rn(9.f, hp.e3[idx])), 24.f);
-                        }
-                        if (hp.eps_out) hp.eps_out[idx] = eps;
-                        const float x = hp.x_base[idx];
-                        const float delta = __fmul_rn(hp.dA, __fsub_rn(__fmul_rn(hp.cx, x), __fmul_rn(hp.ce, ep)));
-                        xn = __fadd_rn(x, delta);
-                        hp.x_out[idx] = xn;
-                    }
+                oks[r] = (m < M) && (t < T);
+                idxs[r] = oks[r] ? ((size_t)b * M + m) * T + t : 0;
+                xv[r] = hp.x_base[idxs[r]];
+                av[r] = bv[r] = cv[r] = 0.f;
+                if (MODE == HEAD_DDPM) {
+                    av[r] = nz[idxs[r]];
+                } else {
+                    if (hp.order >= PLMS_HEUN) av[r] = hp.e1[idxs[r]];
+                    if (hp.order >= PLMS_AB3) bv[r] = hp.e2[idxs[r]];
+                    if (hp.order >= PLMS_AB4) cv[r] = hp.e3[idxs[r]];
                 }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * w + frag_row(r, h);
+                const bool ok = oks[r];
+                const size_t idx = idxs[r];
+                const float eps = acc[0][0][r];
+                const float x = xv[r];
+                float xn;
+                if (MODE == HEAD_DDPM) {
+                    float x0 = __fsub_rn(__fmul_rn(hp.sa, x), __fmul_rn(hp.sb, eps));
+                    x0 = fminf(fmaxf(x0, -1.f), 1.f);
+                    const float mean = __fadd_rn(__fmul_rn(hp.c1, x0), __fmul_rn(hp.c2, x));
+                    xn = __fadd_rn(mean, __fmul_rn(hp.sigma, av[r]));
+                } else {
+                    float ep;
+                    if (hp.order == PLMS_RAW) {
+                        ep = eps;
+                    } else if (hp.order == PLMS_HEUN) {
+                        ep = __fmul_rn(__fadd_rn(av[r], eps), 0.5f);
+                    } else if (hp.order == PLMS_AB2) {
+                        ep = __fmul_rn(__fsub_rn(__fmul_rn(3.f, eps), av[r]), 0.5f);
+                    } else if (hp.order == PLMS_AB3) {
+                        ep = __fdiv_rn(__fadd_rn(__fsub_rn(__fmul_rn(23.f, eps), __fmul_rn(16.f, av[r])), __fmul_rn(5.f, bv[r])), 12.f);
+                    } else {
+                        ep = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(55.f, eps), __fmul_rn(59.f, av[r])),
+                                                           __fmul_rn(37.f, bv[r])), __fmul_rn(9.f, cv[r])), 24.f);
+                    }
+                    if (ok && hp.eps_out) hp.eps_out[idx] = eps;
+                    const float delta = __fmul_rn(hp.dA, __fsub_rn(__fmul_rn(hp.cx, x), __fmul_rn(hp.ce, ep)));
+                    xn = __fadd_rn(x, delta);
+                }
+                if (ok) hp.x_out[idx] = xn;
                 ptile[m * 32 + j] = ok ? xn : 0.f;
             }
         }
         __syncthreads();
-        if (fuse) inproj_to_xreg();
+        if (fuse) { inproj_to_xreg(); publish(ph); }
     }
+#undef LOOP_STAMP
 }
 
 }  // namespace dsd

@@ -234,6 +234,21 @@ class DenoiserEngine:
             _lib.check(self.lib.dsd_time_layer_kernel(self._h, layer, t, iters, C.byref(ms), _stream_ptr(self.device)), 'dsd_time_layer_kernel')
         return float(ms.value)
 
+    def loop_timeline(self, x: torch.Tensor, noise: torch.Tensor, k_step: int, phase: int):
+        """Debug: per-wave shader-clock stamps [workgroups, 4 waves, 8] of one phase of the persistent DDPM loop."""
+        import numpy as np
+        xs = self._spec(x)
+        if noise.dim() == 5:
+            noise = noise[:, :, 0]
+        max_wg = 1 << 12
+        out = np.zeros(max_wg * 32, dtype=np.uint64)
+        n = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_debug_loop_timeline(self._h, xs.data_ptr(), noise.data_ptr(), int(k_step), int(phase),
+                                                        out.ctypes.data_as(C.POINTER(C.c_uint64)), max_wg, C.byref(n), _stream_ptr(self.device)),
+                       'dsd_debug_loop_timeline')
+        return out[:n.value * 32].reshape(n.value, 4, 8)
+
     def layer_timeline(self, layer: int, t: int):
         """Debug: per-wave shader-clock stamps [blocks, 4 waves, 8] of one launch of the layer kernel."""
         import numpy as np

@@ -155,6 +155,12 @@ int dsd_time_layer_kernel(dsd_handle* h, int32_t layer, int32_t t, int32_t iters
 int dsd_debug_layer_timeline(dsd_handle* h, int32_t layer, int32_t t, uint64_t* out, int32_t max_blocks, int32_t* n_blocks,
                              void* stream);
 
+/* Debug hook of the persistent loop: runs the DDPM loop (arguments as dsd_sample_ddpm) with per-wave shader-clock stamps taken in
+ * phase `phase` (= evaluation * L + layer, a non-last layer): HOST out[n_wg*4*8] u64 = {phase start, neighbours' flags seen,
+ * y tile staged, conv done, gate done, x' ready, halo published, phase end}.  Single-launch batches only.  Synchronises. */
+int dsd_debug_loop_timeline(dsd_handle* h, float* x, const float* noise, int32_t k_step, int32_t phase, uint64_t* out,
+                            int32_t max_wg, int32_t* n_wg, void* stream);
+
 /* Introspection for tests: bytes of device memory owned by the handle; frames/workgroup currently selected. */
 int64_t dsd_device_bytes(dsd_handle* h);
 int dsd_get_layer_tile(dsd_handle* h);

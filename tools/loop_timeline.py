@@ -1,0 +1,23 @@
+"""Developer tool (GPU): phase timeline of the persistent K-step loop from in-kernel s_memtime stamps."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+B, T, K = 8, 1024, 6
+dev = torch.device('cuda', 0)
+gd, pre = bench.build_model(dev)
+g = torch.Generator(device=dev).manual_seed(1)
+cond = torch.randn(B, T, 256, device=dev, generator=g).transpose(1, 2)
+x = torch.randn(B, 80, T, device=dev, generator=g)
+noise = torch.randn(K, B, 80, T, device=dev, generator=g)
+eng = gd._engine(cond)
+for phase in (43, 44, 63):
+    ts = eng.loop_timeline(x.clone(), noise, K, phase).astype(np.int64)
+    d = np.diff(ts[:, :, :8], axis=2)
+    names = ['wait for neighbours (+prefetch issue)', 'stage y (halo loads, own cols, barrier)', 'conv K=768', 'gate + barrier',
+             'out-proj K=256', 'residual transpose, x\'', 'publish (drain, barrier, flag) + skip sum']
+    print(f'phase {phase} (layer {phase % 20}): {ts.shape[0]} workgroups, shader-clock ticks')
+    for i, n in enumerate(names):
+        print('  %-42s: mean %8.0f  min %8.0f  max %8.0f' % (n, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max()))
+    print('  phase total: mean %.0f ; start skew across workgroups %.0f' % ((ts[:, :, 7] - ts[:, :, 0]).mean(), ts[:, :, 0].max() - ts[:, :, 0].min()))
+print('timeouts', eng.loop_timeouts())
