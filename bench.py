@@ -10,12 +10,14 @@ RCCL gather of the finished mels).  Synthetic inputs (seeded N(0,1) cond / x_T /
 random-init weights - there are no checkpoints or datasets (no network).
 
 One "step" = one complete pass of the hot path over the batch: hoisted conditioner projection (dsd_prepare),
-the 100-step reverse loop (one hipGraph replay: 2100 kernel launches), de-normalisation to [B,T,80] and, for
-N > 1, the gather to rank 0.  Inputs are resident in HBM before the timed region.
+the 100-step reverse loop (ONE persistent kernel launch, csrc/dsd_loop.hpp; fallback: one hipGraph replay of 2100
+per-layer launches), de-normalisation to [B,T,80] and, for N > 1, the gather to rank 0.  Inputs are resident in HBM
+before the timed region.
 
 The JSON line also carries
-  roofline      for the dominant kernel (k_layer, one residual block): executed fp32 FLOPs per launch / average
-                launch duration measured live with HIP events on the launch stream, against the 157.3 TFLOP/s
+  roofline      for the dominant kernel (k_loop: the whole loop; or k_layer, one residual block, on the fallback path):
+                executed fp32 FLOPs per launch / launch duration measured live with HIP events on the launch stream,
+                against the 157.3 TFLOP/s
                 dense fp32 MFMA peak (MI355X_MICROARCH.md); `traffic` = HBM-side bytes per launch from the committed
                 rocprofv3 --pmc passes of the same kernel and shape (profiles/layer_pmc.json).
   cpu_baseline  the CPU oracle (oracle/diffnet_oracle.py, torch fp32 = the reference's own arithmetic) timed on
@@ -42,6 +44,8 @@ B_PER_GPU, T_FRAMES, K_STEPS = 8, 1024, 100
 F_LAYER_EXEC = 2 * 512 * 768 + 2 * 512 * 256          # executed FLOP / frame / layer launch (dilated conv + out proj)
 F_LAYER_REF = F_LAYER_EXEC + 2 * 512 * 256            # + the conditioner projection the reference recomputes per step
 F_EVAL_REF = 26_427_392                               # reference GEMM FLOP / frame / denoiser evaluation
+L_LAYERS = 20
+F_EVAL_EXEC = (L_LAYERS - 1) * F_LAYER_EXEC + (F_LAYER_EXEC - 2 * 256 * 256) + 2 * (256 * 256 + 80 * 256 + 80 * 256)   # 21 053 440
 PEAK_FP32_MFMA_TFLOPS = 157.3
 
 
@@ -120,12 +124,13 @@ def pmc_traffic(kernel: str, frames: int):
     WRITE_SIZE runs of tools/gpu_pmc.sh at this very shape, corrected as MI355X_MICROARCH.md prescribes; reduced by
     tools/pmc_summary.py).  PMC counters cannot be read from inside this process, so the figure comes from the profile
     of the same kernel + shape committed under profiles/; None when there is no matching profile."""
-    path = os.path.join(ROOT, 'profiles', 'layer_pmc.json')
+    fname = 'loop_pmc.json' if kernel.startswith('k_loop') else 'layer_pmc.json'
+    path = os.path.join(ROOT, 'profiles', fname)
     try:
         js = json.load(open(path))
         if js.get('frames') != frames or js.get('kernel_tag') != kernel:
             return None, None
-        return float(js['hbm_bytes_per_launch']['total']), f"profiles/layer_pmc.json ({js.get('round', '?')}): " + js['hbm_bytes_per_launch']['note']
+        return float(js['hbm_bytes_per_launch']['total']), f"profiles/{fname} ({js.get('round', '?')}): " + js['hbm_bytes_per_launch']['note']
     except Exception:
         return None, None
 
@@ -201,23 +206,55 @@ def main():
     if rank == 0:
         assert out is not None and bool(torch.isfinite(out).all()), 'non-finite mel'
 
-    # roofline of the dominant kernel: k_layer, measured live with HIP events on the launch stream
+    # roofline of the dominant kernel, measured live with HIP events on the launch stream (torch's current stream IS the
+    # stream every dsd_* call is enqueued on).  Persistent path: the kernel is k_loop, ONE launch = the whole 100-step loop.
     roof = None
     if rank == 0:
         eng.prepare(cond)
-        ms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
         frames = B * T
-        achieved = frames * F_LAYER_EXEC / (ms * 1e-3) / 1e12
-        kname = f'k_layer<{eng.layer_tile() // 32},false>'
+        persistent = eng.loop_mode() == 1
+        if persistent:
+            xs = x_T[:, 0].contiguous().clone()
+            nz = noise[:, :, 0]
+            eng.sample_ddpm(xs, nz, K)                                       # warm (plan upload)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            ev0.record()
+            for _ in range(reps):
+                eng.sample_ddpm(xs, nz, K)
+            ev1.record()
+            ev1.synchronize()
+            assert eng.loop_timeouts() == 0, 'persistent loop: an inter-workgroup wait timed out'
+            ms = ev0.elapsed_time(ev1) / reps
+            flop = frames * K * F_EVAL_EXEC
+            achieved = flop / (ms * 1e-3) / 1e12
+            kname = 'k_loop<1>'
+            alg_bytes = K * (frames * (20 * 2048 + 2 * 320 + 320) + L_LAYERS * 2 * 1024 * 1024 + frames // 32 * L_LAYERS * 2 * 16384)
+            note = ('one launch = the whole K=100 reverse loop (100 x (20 residual layers + head + sampler update + next input '
+                    'projection)) for all frames; achieved counts executed fp32 FLOPs (21 053 440 / frame / evaluation: conditioner '
+                    'projection hoisted, dead residual half of the last layer dropped); the figure includes two 2.6 MB device copies '
+                    'and a flag memset around the launch; *_ref_accounting credits the reference 26 427 392 FLOP / frame / evaluation')
+            ref_acc = frames * K * F_EVAL_REF / (ms * 1e-3) / 1e12
+        else:
+            ms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
+            flop = frames * F_LAYER_EXEC
+            achieved = flop / (ms * 1e-3) / 1e12
+            kname = f'k_layer<{eng.layer_tile() // 32},false>'
+            alg_bytes = frames * 6144 + 2 * 1024 * 1024
+            note = ('achieved counts executed fp32 FLOPs of one residual-layer launch (K=768 dilated conv + K=256 output projection '
+                    'per frame); *_ref_accounting also credits the conditioner projection the reference recomputes every step')
+            ref_acc = frames * F_LAYER_REF / (ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(kname, frames)
         roof = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
-                'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': frames * 6144 + 2 * 1024 * 1024,
-                'avg_launch_ms': ms, 'flop_per_launch': frames * F_LAYER_EXEC,
-                'achieved_ref_accounting': frames * F_LAYER_REF / (ms * 1e-3) / 1e12,
-                'note': 'achieved counts executed fp32 FLOPs of one residual-layer launch (K=768 dilated conv + K=256 output '
-                        'projection per frame); *_ref_accounting also credits the conditioner projection the reference '
-                        'recomputes every step and this path hoists out of the loop'}
+                'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes,
+                'avg_launch_ms': ms, 'flop_per_launch': flop, 'achieved_ref_accounting': ref_acc, 'note': note}
+        if persistent:                      # the per-layer kernel of the fallback path, for comparison with earlier rounds
+            eng.set_loop_mode(0)
+            lms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
+            eng.set_loop_mode(1)
+            roof['per_layer_kernel_fallback'] = {'kernel': f'k_layer<{eng.layer_tile() // 32},false>', 'avg_launch_ms': lms,
+                                                 'achieved': frames * F_LAYER_EXEC / (lms * 1e-3) / 1e12}
     if world > 1:
         dist.barrier()
 
@@ -230,7 +267,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: DiffSpeech 80-bin, residual_channels=256, 20 layers, K=100 DDPM, '
                                    f'batch={B} x T={T} per GPU', 'preset': PRESET, 'utterances_per_gpu': B, 'frames': T,
-                       'k_step': K, 'sampler': 'ddpm', 'layer_tile_frames': eng.layer_tile(), 'hipgraph': True,
+                       'k_step': K, 'sampler': 'ddpm', 'layer_tile_frames': eng.layer_tile(),
+                       'loop': 'persistent kernel (k_loop)' if eng.loop_mode() == 1 else 'hipGraph of per-layer kernels',
                        'sharding': 'utterances r::W, RCCL gather of mels to rank 0' if world > 1 else 'single GPU'},
             'roofline': roof,
             'model_tflops_ref_accounting': world * B * T * K * F_EVAL_REF * args.steps / el / 1e12,

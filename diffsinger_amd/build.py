@@ -14,7 +14,10 @@ SRC = [os.path.join(PKG, 'csrc', 'dsd.hip')]
 DEPS = SRC + [os.path.join(PKG, 'csrc', f) for f in ('dsd_kernels.hpp', 'fs2_kernels.hpp', 'fs2_abi.hpp')] + [
     os.path.join(os.path.dirname(PKG), 'include', f) for f in ('dsd.h', 'dsf.h')]
 LIB = os.path.join(PKG, 'libdsdenoise.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC']
+# -ffp-contract=off: hipcc's default (fast) fuses a*b+c into FMA wherever it likes, also across the __fmul_rn / __fadd_rn
+# "intrinsics" (plain operators to the optimiser) - the sampler arithmetic must round every product like the reference's
+# tensor ops do, and the persistent loop and the per-layer kernels must stay bit-identical (explicit fmaf / MFMA are unaffected)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off']
 
 
 def up_to_date() -> bool:
