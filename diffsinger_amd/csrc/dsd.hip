@@ -91,6 +91,8 @@ struct dsd_handle {
     float *xs = nullptr, *xtmp = nullptr, *ering[4] = {nullptr, nullptr, nullptr, nullptr};
     int* t_dev = nullptr;
     const float** noise_cell = nullptr;
+    unsigned long long* seed_cell = nullptr;
+    unsigned long long noise_seed = 0;   // Philox seed used when a sampler is called without explicit noise (dsd_set_noise_seed)
 
     hipStream_t cap_stream = nullptr;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -204,7 +206,7 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     dev_free(h->winp); dev_free(h->binp); dev_free(h->wsp); dev_free(h->bsp); dev_free(h->woutp); dev_free(h->boutp);
     dev_free(h->mlp0_w); dev_free(h->mlp0_b); dev_free(h->mlp2_w); dev_free(h->mlp2_b); dev_free(h->dp_w); dev_free(h->dp_b);
     dev_free(h->ds_table); dev_free(h->spec_min_d); dev_free(h->spec_max_d);
-    dev_free(h->noise_cell);
+    dev_free(h->noise_cell); dev_free(h->seed_cell);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     delete h;
 }
@@ -306,6 +308,7 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
         DSD_TRY(dev_alloc(h, &h->dp_w, (size_t)L * kC * kC));
         DSD_TRY(dev_alloc(h, &h->dp_b, (size_t)L * kC));
         DSD_TRY(dev_alloc(h, &h->noise_cell, 1));
+        DSD_TRY(dev_alloc(h, &h->seed_cell, 1));
     }
     for (int l = 0; l < L; ++l) {
         if (!w->dilated_conv_w[l] || !w->dilated_conv_b[l] || !w->diffusion_projection_w[l] || !w->diffusion_projection_b[l] ||
@@ -498,7 +501,7 @@ static HeadParams head_base(dsd_handle* h) {
     p.winp = h->winp; p.binp = h->binp; p.x_next = h->xa;
     p.sqrt_L = (float)std::sqrt((double)h->L);
     p.nk_in = h->nk_in; p.M = h->M; p.T = h->T; p.TS = h->TS; p.ntile32 = h->ntile32;
-    p.noise_cell = h->noise_cell;
+    p.noise_cell = h->noise_cell; p.seed_cell = h->seed_cell;
     return p;
 }
 
@@ -594,7 +597,7 @@ static int enqueue_ddpm(dsd_handle* h, int k_step, hipStream_t s) {
         for (int l = 0; l < h->L; ++l) DSD_TRY(launch_layer(h, l, t, nullptr, s));
         HeadParams p = head_base(h);
         p.x_base = h->xs; p.x_out = h->xs;
-        p.noise_off = (size_t)j * bmt;
+        p.noise_off = (size_t)j * bmt; p.step_id = (unsigned)j;
         p.sa = h->tab[6][t]; p.sb = h->tab[7][t]; p.c1 = h->tab[10][t]; p.c2 = h->tab[11][t];
         // nonzero_mask * exp(0.5 * logvar): fp32 like the reference's [B,1,1,1] tensors (:165-166)
         p.sigma = (t == 0) ? 0.f : std::exp(0.5f * h->tab[9][t]);
@@ -661,7 +664,7 @@ static void plan_evals(dsd_handle* h, int kind, int k_step, int interval, std::v
             const int t = k_step - 1 - j;
             HeadParams p = head_base(h);
             p.x_base = h->xs; p.x_out = h->xs;
-            p.noise_off = (size_t)j * bmt;
+            p.noise_off = (size_t)j * bmt; p.step_id = (unsigned)j;
             p.sa = h->tab[6][t]; p.sb = h->tab[7][t]; p.c1 = h->tab[10][t]; p.c2 = h->tab[11][t];
             p.sigma = (t == 0) ? 0.f : std::exp(0.5f * h->tab[9][t]);
             ev.push_back(p); ts_out.push_back(t);
@@ -749,7 +752,8 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
     const size_t bmt = (size_t)h->B * h->M * h->T;
     HIP_TRY(hipMemcpyAsync(h->xs, x, bmt * 4, hipMemcpyDeviceToDevice, s));
     if (kind == 0) {
-        hipLaunchKernelGGL(k_set_cell, dim3(1), dim3(1), 0, s, h->noise_cell, noise);
+        hipLaunchKernelGGL(k_set_cell, dim3(1), dim3(1), 0, s, h->noise_cell, noise);       // nullptr selects the Philox draws
+        if (!noise) hipLaunchKernelGGL(k_set_seed, dim3(1), dim3(1), 0, s, h->seed_cell, h->noise_seed);
         HIP_TRY(hipGetLastError());
     }
     if (loop_applicable(h)) {
@@ -776,6 +780,21 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
         HIP_TRY(hipGraphLaunch(it->second, s));
     }
     HIP_TRY(hipMemcpyAsync(x, h->xs, bmt * 4, hipMemcpyDeviceToDevice, s));
+    return DSD_OK;
+}
+
+extern "C" int dsd_set_noise_seed(dsd_handle* h, uint64_t seed) {
+    if (!h) return fail(DSD_ERR_INVALID, "dsd_set_noise_seed: null handle");
+    h->noise_seed = seed;
+    return DSD_OK;
+}
+
+extern "C" int dsd_philox_normal(dsd_handle* h, uint64_t seed, int32_t step, float* out, int64_t n, void* stream) {
+    if (!h || !out || n < 1 || step < 0) return fail(DSD_ERR_INVALID, "dsd_philox_normal: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_philox_fill, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, out, (size_t)n,
+                       (unsigned long long)seed, (unsigned)step);
+    HIP_TRY(hipGetLastError());
     return DSD_OK;
 }
 
@@ -825,7 +844,7 @@ extern "C" int dsd_debug_loop_timeline(dsd_handle* h, float* x, const float* noi
 
 extern "C" int dsd_sample_ddpm(dsd_handle* h, float* x, const float* noise, int32_t k_step, void* stream) {
     DSD_TRY(check_ready(h, "dsd_sample_ddpm", true));
-    if (!x || !noise) return fail(DSD_ERR_INVALID, "dsd_sample_ddpm: null argument");
+    if (!x) return fail(DSD_ERR_INVALID, "dsd_sample_ddpm: null argument");
     if (k_step < 1 || k_step > h->n_sched) return fail(DSD_ERR_INVALID, "dsd_sample_ddpm: k_step=%d outside 1..%d", k_step, h->n_sched);
     HIP_TRY(hipSetDevice(h->device));
     DSD_TRY(build_step_table(h, h->n_sched, (hipStream_t)stream));
@@ -834,17 +853,18 @@ extern "C" int dsd_sample_ddpm(dsd_handle* h, float* x, const float* noise, int3
 
 extern "C" int dsd_p_sample(dsd_handle* h, float* x, const float* noise, int32_t t, void* stream) {
     DSD_TRY(check_ready(h, "dsd_p_sample", true));
-    if (!x || !noise) return fail(DSD_ERR_INVALID, "dsd_p_sample: null argument");
+    if (!x) return fail(DSD_ERR_INVALID, "dsd_p_sample: null argument");
     if (t < 0 || t >= h->n_sched) return fail(DSD_ERR_INVALID, "dsd_p_sample: t=%d outside the %d-step schedule", t, h->n_sched);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     DSD_TRY(build_step_table(h, h->n_sched, s));
     hipLaunchKernelGGL(k_set_cell, dim3(1), dim3(1), 0, s, h->noise_cell, noise);
+    if (!noise) hipLaunchKernelGGL(k_set_seed, dim3(1), dim3(1), 0, s, h->seed_cell, h->noise_seed);
     HIP_TRY(hipGetLastError());
     DSD_TRY(launch_inproj(h, x, s));
     for (int l = 0; l < h->L; ++l) DSD_TRY(launch_layer(h, l, t, nullptr, s));
     HeadParams p = head_base(h);
-    p.x_base = x; p.x_out = x; p.noise_off = 0;
+    p.x_base = x; p.x_out = x; p.noise_off = 0; p.step_id = 0;
     p.sa = h->tab[6][t]; p.sb = h->tab[7][t]; p.c1 = h->tab[10][t]; p.c2 = h->tab[11][t];
     p.sigma = (t == 0) ? 0.f : std::exp(0.5f * h->tab[9][t]);
     return launch_head<HEAD_DDPM>(h, p, false, s);

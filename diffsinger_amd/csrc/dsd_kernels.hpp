@@ -606,6 +606,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_inproj(const InProjParams p) {
 // ------------------------------------------------------------------------------------------------------------
 // head: skip reduction scale -> skip_projection + ReLU -> output_projection -> sampler epilogue (-> next in-proj)
 // ------------------------------------------------------------------------------------------------------------
+// Counter-based N(0,1) draws for p_sample's `noise_like` (usr/diff/shallow_diffusion_tts.py:38-41,:165) when the caller passes no
+// explicit noise: Philox4x32-10 keyed by the 64-bit seed, counter = (element index lo, hi, step, 0), Box-Muller on the first two
+// output words.  One draw per (step, element): the value does not depend on tiling, chunking or which kernel evaluates it.
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned step, unsigned long long idx) {
+    unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = step, c3 = 0u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u1 = (float)((c0 >> 8) + 1u) * 5.9604644775390625e-8f;      // (0, 1]
+    const float u2 = (float)(c1 >> 8) * 5.9604644775390625e-8f;             // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
 enum HeadMode { HEAD_EPS = 0, HEAD_DDPM = 1, HEAD_PLMS = 2 };
 enum PlmsOrder { PLMS_RAW = 0, PLMS_HEUN = 1, PLMS_AB2 = 2, PLMS_AB3 = 3, PLMS_AB4 = 4 };
 
@@ -625,8 +643,10 @@ struct HeadParams {
     float* eps_out;             // HEAD_EPS: eps;  HEAD_PLMS: where to store this evaluation's eps (nullable)
     const float* x_base;        // DDPM / PLMS: x_t the update is applied to
     float* x_out;               // DDPM / PLMS: result (may alias x_base)
-    const float* const* noise_cell;   // DDPM: *noise_cell + noise_off = this step's N(0,1) draw
+    const float* const* noise_cell;   // DDPM: *noise_cell + noise_off = this step's N(0,1) draw; *noise_cell == nullptr: Philox
     size_t noise_off;
+    const unsigned long long* seed_cell;   // Philox seed (device cell: cached graphs / plans stay valid when it changes)
+    unsigned step_id;                      // index of this p_sample call in the loop (Philox counter word)
     const float* e1; const float* e2; const float* e3;   // PLMS history (most recent first)
     // per-step scalars (fp32, computed on the host from the fp32 tables exactly like the reference's
     // [B,1,1,1] tensor arithmetic)
@@ -700,7 +720,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_head(const HeadParams p) {
                     // p_mean_variance + p_sample (shallow_diffusion_tts.py:134-166); no FMA contraction, the
                     // reference rounds every product
                     const float x = p.x_base[idx];
-                    const float z = (*p.noise_cell)[p.noise_off + idx];
+                    const float* nzb = *p.noise_cell;
+                    const float z = nzb ? nzb[p.noise_off + idx] : philox_normal(*p.seed_cell, p.step_id, idx);
                     float x0 = __fsub_rn(__fmul_rn(p.sa, x), __fmul_rn(p.sb, eps));
                     x0 = fminf(fmaxf(x0, -1.f), 1.f);
                     const float mean = __fadd_rn(__fmul_rn(p.c1, x0), __fmul_rn(p.c2, x));
@@ -924,5 +945,11 @@ __global__ void k_sum_skip_bias(const float* __restrict__ b2all, float* __restri
 }
 
 __global__ void k_set_cell(const float** cell, const float* value) { *cell = value; }
+__global__ void k_set_seed(unsigned long long* cell, unsigned long long value) { *cell = value; }
+
+// out[i] = the Philox N(0,1) draw of element i at step `step` (tests: the explicit-noise loop fed with these == the seeded loop)
+__global__ void k_philox_fill(float* out, size_t n, unsigned long long seed, unsigned step) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = philox_normal(seed, step, i);
+}
 
 }  // namespace dsd

@@ -15,7 +15,7 @@
 //     buffered by phase parity: a neighbour can be at most one phase ahead.  No grid-wide barrier anywhere.
 //   * all workgroups must be co-resident (they wait for each other): the host launches at most one workgroup per CU (112 KiB
 //     of LDS each) and splits larger batches into chunks of whole utterances; every spin is bounded and a timeout is sticky
-//     (the loop then finishes with garbage instead of hanging; the host reports it).
+//     (the loop then finishes instead of hanging, poisons the result with NaN and the host can read the timeout word).
 #pragma once
 #include "dsd_kernels.hpp"
 
@@ -373,7 +373,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             bool oks[16];
             float xv[16], av[16], bv[16], cv[16];
             const float* nz = nullptr;
-            if (MODE == HEAD_DDPM) nz = *hp.noise_cell + hp.noise_off;
+            unsigned long long seed = 0;
+            if (MODE == HEAD_DDPM) {
+                nz = *hp.noise_cell;
+                if (nz) nz += hp.noise_off; else seed = *hp.seed_cell;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 32 * w + frag_row(r, h);
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 xv[r] = hp.x_base[idxs[r]];
                 av[r] = bv[r] = cv[r] = 0.f;
                 if (MODE == HEAD_DDPM) {
-                    av[r] = nz[idxs[r]];
+                    av[r] = nz ? nz[idxs[r]] : philox_normal(seed, hp.step_id, idxs[r]);
                 } else {
                     if (hp.order >= PLMS_HEUN) av[r] = hp.e1[idxs[r]];
                     if (hp.order >= PLMS_AB3) bv[r] = hp.e2[idxs[r]];
@@ -428,6 +432,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
         if (fuse) { inproj_to_xreg(); publish(ph); }
     }
 #undef LOOP_STAMP
+    // a wait that hit its spin bound leaves garbage: make it LOUD - poison this tile of the result with NaN
+    if (timed_out()) {
+        float* xo = const_cast<float*>(p.spec0);
+        for (int idx = tid; idx < M * 32; idx += kThreads) {
+            const int m = idx >> 5, t = t0 + (idx & 31);
+            if (t < T) xo[((size_t)b * M + m) * T + t] = __builtin_nanf("");
+        }
+    }
 }
 
 }  // namespace dsd

@@ -174,14 +174,15 @@ class GaussianDiffusion(nn.Module):
     # -- the hot loop -------------------------------------------------------------------------------------------
     @torch.no_grad()
     def inference(self, cond, *, fs2_mels=None, x_T=None, noise=None, q_noise=None, K_step=None, pndm_speedup=None,
-                  gaussian_start=None, mel_mask=None, return_x=False):
+                  gaussian_start=None, mel_mask=None, return_x=False, noise_seed=None):
         """The inference branch of `forward` (:248-276) from `cond` on.
 
         cond      [B,H,T] fp32 on the device (any strides; the reference passes decoder_inp.transpose(1,2))
         fs2_mels  [B,T,M] aux-decoder mel for the shallow-diffusion start (q_sample at t = K_step-1)
         x_T       [B,1,M,T] explicit start (gaussian_start); drawn with torch.randn if neither is given
-        noise     [K,B,1,M,T] explicit per-step N(0,1) draws for DDPM (slice j <-> t = K-1-j); drawn here in
-                  the reference's order (one randn per step) when None
+        noise     [K,B,1,M,T] explicit per-step N(0,1) draws for DDPM (slice j <-> t = K-1-j).  None: the draws are made
+                  inside the kernel (Philox, seed = noise_seed or a value taken from torch's CPU generator) - nothing of
+                  size K*B*M*T is ever materialised
         Returns de-normalised mel [B,T,M] (times mel_mask [B,T] if given); with return_x also x_0 [B,1,M,T]."""
         eng = self._engine(cond)
         B, _, T = cond.shape
@@ -206,10 +207,12 @@ class GaussianDiffusion(nn.Module):
             eng.sample_plms(x, t, int(pndm_speedup))
         else:
             if noise is None:
-                noise = torch.empty(t, B, 1, M, T, device=dev)
-                for j in range(t):                                            # one draw per p_sample call (:165)
-                    noise[j].normal_()
-            eng.sample_ddpm(x, noise.reshape(t, B, M, T) if noise.dim() == 5 else noise, t)
+                # one N(0,1) draw per element per p_sample call (:165), generated inside the loop kernel: counter-based Philox
+                # keyed by a seed taken from torch's CPU generator (torch.manual_seed makes the whole loop reproducible)
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise_seed is None else int(noise_seed)
+                eng.sample_ddpm(x, None, t, seed=seed)
+            else:
+                eng.sample_ddpm(x, noise.reshape(t, B, M, T) if noise.dim() == 5 else noise, t)
         mel = eng.denorm_spec(x, mel_mask)                                    # :271-275
         return (mel, x[:, None]) if return_x else mel
 

@@ -170,27 +170,45 @@ class DenoiserEngine:
             _lib.check(self.lib.dsd_q_sample(self._h, xs.data_ptr(), z.data_ptr(), int(t), out.data_ptr(), _stream_ptr(self.device)), 'dsd_q_sample')
         return out
 
-    def sample_ddpm(self, x: torch.Tensor, noise: torch.Tensor, k_step: int) -> torch.Tensor:
-        """In place: x [B,M,T] contiguous goes from x_{k_step} to x_0.  noise [k_step,B,M,T] (or [k,B,1,M,T])."""
+    def sample_ddpm(self, x: torch.Tensor, noise: Optional[torch.Tensor], k_step: int, seed: Optional[int] = None) -> torch.Tensor:
+        """In place: x [B,M,T] contiguous goes from x_{k_step} to x_0.  noise [k_step,B,M,T] (or [k,B,1,M,T]) = the explicit
+        N(0,1) draws, or None: drawn inside the kernel (Philox4x32-10 keyed by `seed`, see include/dsd.h)."""
         xs = self._spec(x)
         if not xs.is_contiguous():
             raise ValueError('x must be contiguous (it is updated in place)')
         B, T = self.prepared_shape
-        if noise.dim() == 5:
-            noise = noise[:, :, 0]
-        if tuple(noise.shape) != (k_step, B, self.M, T) or not noise.is_contiguous() or noise.dtype != torch.float32 \
-                or noise.device != self.device:
-            raise ValueError(f'noise must be contiguous fp32 [{k_step},{B},{self.M},{T}] on {self.device}')
+        nptr = None
+        if noise is not None:
+            if noise.dim() == 5:
+                noise = noise[:, :, 0]
+            if tuple(noise.shape) != (k_step, B, self.M, T) or not noise.is_contiguous() or noise.dtype != torch.float32 \
+                    or noise.device != self.device:
+                raise ValueError(f'noise must be contiguous fp32 [{k_step},{B},{self.M},{T}] on {self.device}')
+            nptr = noise.data_ptr()
+        else:
+            _lib.check(self.lib.dsd_set_noise_seed(self._h, int(seed or 0) & 0xFFFFFFFFFFFFFFFF), 'dsd_set_noise_seed')
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.dsd_sample_ddpm(self._h, xs.data_ptr(), noise.data_ptr(), int(k_step), _stream_ptr(self.device)), 'dsd_sample_ddpm')
+            _lib.check(self.lib.dsd_sample_ddpm(self._h, xs.data_ptr(), nptr, int(k_step), _stream_ptr(self.device)), 'dsd_sample_ddpm')
         return x
 
-    def p_sample(self, x: torch.Tensor, noise: torch.Tensor, t: int) -> torch.Tensor:
-        xs, z = self._spec(x), self._spec(noise, 'noise').contiguous()
+    def philox_normal(self, seed: int, step: int, n: int) -> torch.Tensor:
+        """The in-kernel N(0,1) draws of p_sample call `step` for elements 0..n-1 (element = flat index into [B][M][T])."""
+        out = torch.empty(n, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_philox_normal(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), out.data_ptr(), n, _stream_ptr(self.device)),
+                       'dsd_philox_normal')
+        return out
+
+    def p_sample(self, x: torch.Tensor, noise: Optional[torch.Tensor], t: int, seed: Optional[int] = None) -> torch.Tensor:
+        xs = self._spec(x)
+        z = self._spec(noise, 'noise').contiguous() if noise is not None else None
         if not xs.is_contiguous():
             raise ValueError('x must be contiguous (it is updated in place)')
+        if z is None:
+            _lib.check(self.lib.dsd_set_noise_seed(self._h, int(seed or 0) & 0xFFFFFFFFFFFFFFFF), 'dsd_set_noise_seed')
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.dsd_p_sample(self._h, xs.data_ptr(), z.data_ptr(), int(t), _stream_ptr(self.device)), 'dsd_p_sample')
+            _lib.check(self.lib.dsd_p_sample(self._h, xs.data_ptr(), z.data_ptr() if z is not None else None, int(t), _stream_ptr(self.device)),
+                       'dsd_p_sample')
         return x
 
     def sample_plms(self, x: torch.Tensor, k_step: int, interval: int) -> torch.Tensor:

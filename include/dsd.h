@@ -109,8 +109,16 @@ int dsd_q_sample(dsd_handle* h, const float* x_start, const float* noise, int32_
 
 /* The DDPM loop `for i in reversed(range(0, k_step)): x = p_sample(x, i, cond)` (shallow_diffusion_tts.py:
  * 269-270, p_sample :159-166, p_mean_variance :149-157).  x [B][M][T] is updated in place from x_{k_step} to
- * x_0; noise is [k_step][B][M][T], slice j feeds the j-th call (t = k_step-1-j), t = 0 included. */
+ * x_0; noise is [k_step][B][M][T], slice j feeds the j-th call (t = k_step-1-j), t = 0 included (NULL: see dsd_set_noise_seed). */
 int dsd_sample_ddpm(dsd_handle* h, float* x, const float* noise, int32_t k_step, void* stream);
+
+/* noise == NULL in dsd_sample_ddpm / dsd_p_sample: the N(0,1) draws of `noise_like` (shallow_diffusion_tts.py:38-41) are generated
+ * in the kernel instead of read from HBM - Philox4x32-10 keyed by the seed set here, counter = (element index in [B][M][T],
+ * index of the p_sample call in the loop), Box-Muller on the first two output words.  The stream is a pure function of
+ * (seed, call index, element): independent of tiling, chunking and of which kernel path runs.  dsd_philox_normal writes the
+ * draws of one call index (out[n], element i <-> counter i) so that a caller / test can reproduce them. */
+int dsd_set_noise_seed(dsd_handle* h, uint64_t seed);
+int dsd_philox_normal(dsd_handle* h, uint64_t seed, int32_t step, float* out, int64_t n, void* stream);
 
 /* One p_sample call (shallow_diffusion_tts.py:159-166) at step t: x [B][M][T] updated in place from x_t to
  * x_{t-1}; noise [B][M][T] is the N(0,1) draw of `noise_like` (ignored by the arithmetic when t == 0). */
