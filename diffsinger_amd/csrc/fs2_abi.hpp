@@ -35,7 +35,7 @@ extern "C" int dsf_pack_weight(const float* w, int32_t Co, int32_t Ci, int32_t K
 extern "C" int dsf_conv1d(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co,
                           int32_t KT, int32_t T, float scale, int32_t act, const float* residual, const float* keep, void* stream) {
     if (!in || !wpacked || !out) return fail(DSD_ERR_INVALID, "dsf_conv1d: null argument");
-    if (B < 1 || T < 1 || Co < 1 || Ci < 8 || (Ci % 8) || KT < 1 || KT > 2 * kFsHalo + 1 || !(KT & 1) || act < 0 || act > 2)
+    if (B < 1 || T < 1 || Co < 1 || Ci < 8 || (Ci % 8) || KT < 1 || KT > 2 * kFsHalo + 1 || !(KT & 1) || act < 0 || act > 3)
         return fail(DSD_ERR_INVALID, "dsf_conv1d: bad shape (B=%d T=%d Ci=%d Co=%d K=%d act=%d)", B, T, Ci, Co, KT, act);
     static bool attr_done = false;
     if (!attr_done) {
@@ -98,6 +98,24 @@ extern "C" int dsf_from_channel_major(const float* in, float* out, int32_t B, in
     const int TS = fs_ts(T);
     hipLaunchKernelGGL(k_fs_from_cm, dim3((unsigned)(TS / 32), (unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0, (hipStream_t)stream,
                        in, out, C, T, TS);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_p_sample(float* x, const float* eps, const float* noise, int64_t n, float sqrt_recip_ac, float sqrt_recipm1_ac,
+                            float coef1, float coef2, float sigma, void* stream) {
+    if (!x || !eps || !noise || n < 1) return fail(DSD_ERR_INVALID, "dsf_p_sample: bad argument");
+    hipLaunchKernelGGL(k_fs_p_sample, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, eps, noise,
+                       sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, sigma, (size_t)n);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_denorm_spec(const float* x, const float* mask, float* mel, const float* spec_min, const float* spec_max, int32_t B,
+                               int32_t M, int32_t T, void* stream) {
+    if (!x || !mel || !spec_min || !spec_max || B < 1 || M < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_denorm_spec: bad argument");
+    hipLaunchKernelGGL(k_denorm_spec, dim3((unsigned)((T + 31) / 32), (unsigned)B), dim3(256), 32 * (M + 1) * 4, (hipStream_t)stream, x, mask, mel,
+                       spec_min, spec_max, M, T);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

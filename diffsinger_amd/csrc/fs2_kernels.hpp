@@ -25,7 +25,7 @@ constexpr int kFsHalo = 8;                 // conv taps reach +-8 frames at most
 constexpr int kFsLD = 32 + 2 * kFsHalo;    // LDS row stride of the staged input slab
 constexpr int kFsSlab = 256;               // input channels staged per pass
 
-enum FsAct { FS_ACT_NONE = 0, FS_ACT_RELU = 1, FS_ACT_GELU = 2 };
+enum FsAct { FS_ACT_NONE = 0, FS_ACT_RELU = 1, FS_ACT_GELU = 2, FS_ACT_MISH = 3 };
 
 struct FsConvParams {
     const float* in;        // [B][Ci][TS]
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_conv(const FsConvParams p) {
             v *= p.scale;
             if (p.act == FS_ACT_RELU) v = fmaxf(v, 0.f);
             else if (p.act == FS_ACT_GELU) v = v * 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+            else if (p.act == FS_ACT_MISH) v = v * tanhf((v > 20.f) ? v : log1pf(expf(v)));        // x * tanh(softplus(x)), usr/diff/diffusion.py:68-70
             if (p.res) v += p.res[o];
             v *= kp;
             p.out[o] = tv ? v : 0.f;
@@ -265,6 +266,19 @@ __global__ __launch_bounds__(64) void k_fs_attn(const FsAttnParams p) {
 }
 template <int HD>
 constexpr int fs_attn_lds_bytes() { return (2 * HD * 32 + HD * 33 + 32 * 32) * (int)sizeof(float); }
+
+// One ancestral step x_{t-1} = p_sample(x_t, eps) (usr/diff/shallow_diffusion_tts.py:134-166) for a denoiser that is not the fused
+// DiffNet (the `FFT` candidate decoder): the arithmetic of the DiffNet head epilogue as a stand-alone element-wise kernel.
+__global__ void k_fs_p_sample(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ z, float sa, float sb,
+                              float c1, float c2, float sigma, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float xv = x[i];
+        float x0 = __fsub_rn(__fmul_rn(sa, xv), __fmul_rn(sb, eps[i]));
+        x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, xv));
+        x[i] = __fadd_rn(mean, __fmul_rn(sigma, z[i]));
+    }
+}
 
 // internal [B][C][TS] -> [B][T][C] (the reference's layout), 32 x 32 tiles through LDS
 __global__ void k_fs_from_cm(const float* __restrict__ in, float* __restrict__ out, int C, int T, int TS) {

@@ -184,6 +184,9 @@ class GaussianDiffusion(nn.Module):
                   inside the kernel (Philox, seed = noise_seed or a value taken from torch's CPU generator) - nothing of
                   size K*B*M*T is ever materialised
         Returns de-normalised mel [B,T,M] (times mel_mask [B,T] if given); with return_x also x_0 [B,1,M,T]."""
+        if not isinstance(self.denoise_fn, DiffNet):
+            return self._inference_generic(cond, fs2_mels=fs2_mels, x_T=x_T, noise=noise, q_noise=q_noise, K_step=K_step,
+                                           pndm_speedup=pndm_speedup, gaussian_start=gaussian_start, mel_mask=mel_mask, return_x=return_x)
         eng = self._engine(cond)
         B, _, T = cond.shape
         M = self.mel_bins
@@ -215,6 +218,53 @@ class GaussianDiffusion(nn.Module):
                 eng.sample_ddpm(x, noise.reshape(t, B, M, T) if noise.dim() == 5 else noise, t)
         mel = eng.denorm_spec(x, mel_mask)                                    # :271-275
         return (mel, x[:, None]) if return_x else mel
+
+    @torch.no_grad()
+    def _inference_generic(self, cond, *, fs2_mels, x_T, noise, q_noise, K_step, pndm_speedup, gaussian_start, mel_mask, return_x):
+        """The DDPM loop (:269-270) for a denoise_fn that is not the fused DiffNet (the `FFT` candidate decoder, row f4): one
+        denoiser forward per step (HIP operators) + the p_sample update and denorm as stand-alone HIP kernels (include/dsf.h)."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        if cond.device.type != 'cuda':
+            raise RuntimeError('the HIP sampler has no CPU path')
+        if pndm_speedup is None:
+            pndm_speedup = hparams.get('pndm_speedup')
+        if pndm_speedup:
+            raise NotImplementedError('PLMS with a non-DiffNet denoiser')
+        B, _, T = cond.shape
+        M, dev = self.mel_bins, cond.device
+        t = self.K_step if K_step is None else K_step
+        if gaussian_start is None:
+            gaussian_start = bool(hparams.get('gaussian_start'))
+        x = None
+        if fs2_mels is not None:
+            zq = q_noise if q_noise is not None else torch.randn(B, 1, M, T, device=dev)
+            x0 = self.norm_spec(fs2_mels).transpose(1, 2)[:, None, :, :]
+            x = self.sqrt_alphas_cumprod[t - 1] * x0 + self.sqrt_one_minus_alphas_cumprod[t - 1] * zq       # :206-211, :255
+        if x_T is not None:
+            x = x_T.clone()
+        elif gaussian_start or x is None:
+            x = torch.randn(B, 1, M, T, device=dev)
+        x = x.contiguous().float()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        tab = [getattr(self, k).detach().cpu().numpy() for k in ('sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod',
+                                                                 'posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped')]
+        for j in range(t):
+            i = t - 1 - j
+            eps = self.denoise_fn(x, torch.full((B,), i, device=dev, dtype=torch.long), cond=cond).contiguous()
+            z = (noise[j] if noise is not None else torch.randn(B, 1, M, T, device=dev)).contiguous()
+            sigma = 0.0 if i == 0 else float(np.exp(np.float32(0.5) * tab[4][i]))
+            with torch.cuda.device(dev):
+                _lib.check(lib.dsf_p_sample(x.data_ptr(), eps.data_ptr(), z.data_ptr(), x.numel(), float(tab[0][i]), float(tab[1][i]),
+                                            float(tab[2][i]), float(tab[3][i]), sigma, stream), 'dsf_p_sample')
+        mel = torch.empty(B, T, M, device=dev, dtype=torch.float32)
+        mask = mel_mask.to(device=dev, dtype=torch.float32).contiguous() if mel_mask is not None else None
+        smin, smax = self.spec_min.reshape(-1).contiguous(), self.spec_max.reshape(-1).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(lib.dsf_denorm_spec(x.data_ptr(), mask.data_ptr() if mask is not None else None, mel.data_ptr(), smin.data_ptr(),
+                                           smax.data_ptr(), B, M, T, stream), 'dsf_denorm_spec')
+        return (mel, x) if return_x else mel
 
     def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None, infer=False,
                 **kwargs):

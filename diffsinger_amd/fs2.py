@@ -33,7 +33,7 @@ from torch import nn
 from . import _lib
 from .hparams import hparams
 
-ACT = {'none': 0, 'relu': 1, 'gelu': 2}
+ACT = {'none': 0, 'relu': 1, 'gelu': 2, 'mish': 3}
 f0_bin = 256
 f0_mel_min = 1127 * np.log(1 + 50.0 / 700)
 f0_mel_max = 1127 * np.log(1 + 1100.0 / 700)

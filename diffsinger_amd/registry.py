@@ -4,9 +4,15 @@ from __future__ import annotations
 
 from .net import DiffNet
 
+def _fft(hp):
+    from .candidate_decoder import FFT          # usr/diffsinger_task.py:25-26
+    return FFT(hp['hidden_size'], hp['dec_layers'], hp['dec_ffn_kernel_size'], hp['num_heads'])
+
+
 DIFF_DECODERS = {
     'wavenet': lambda hp: DiffNet(hp['audio_num_mel_bins']),
     'wavenet_hip': lambda hp: DiffNet(hp['audio_num_mel_bins']),
+    'fft': _fft,
 }
 
 
@@ -21,4 +27,6 @@ def register(*registries, override: bool = True):
         reg['wavenet_hip'] = DIFF_DECODERS['wavenet_hip']
         if override:
             reg['wavenet'] = DIFF_DECODERS['wavenet']
+            if 'fft' in reg:                    # usr/diffsinger_task.py registers the transformer candidate decoder too
+                reg['fft'] = DIFF_DECODERS['fft']
     return registries

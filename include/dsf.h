@@ -21,6 +21,7 @@ extern "C" {
 #define DSF_ACT_NONE 0
 #define DSF_ACT_RELU 1
 #define DSF_ACT_GELU 2      /* erf form, F.gelu default (modules/commons/common_layers.py:512-513) */
+#define DSF_ACT_MISH 3      /* x * tanh(softplus(x)), usr/diff/diffusion.py:68-70 (the step MLP of the FFT candidate denoiser) */
 
 int32_t dsf_padded_frames(int32_t T);
 
@@ -54,6 +55,15 @@ int dsf_attention(const float* qkv, const uint8_t* key_pad, float* out, int32_t 
 int dsf_to_channel_major(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_t, float* out, int32_t B, int32_t C,
                          int32_t T, void* stream);
 int dsf_from_channel_major(const float* in, float* out /* [B][T][C] contiguous */, int32_t B, int32_t C, int32_t T, void* stream);
+
+/* Sampler pieces for a denoise_fn that is not the fused DiffNet (the `FFT` candidate decoder, usr/diff/candidate_decoder.py:35-96;
+ * SURVEY section 8 row f4): one p_sample update (usr/diff/shallow_diffusion_tts.py:134-166: x0 = a x - b eps, clamp, posterior
+ * mean, + sigma z) in place on n contiguous floats with the fp32 table entries of step t passed by the host, and denorm_spec
+ * (:281-282) fused with the [B][M][T] -> [B,T,M] transpose and the optional `mel2ph > 0` mask (:271-273); spec_min/max: DEVICE [M]. */
+int dsf_p_sample(float* x, const float* eps, const float* noise, int64_t n, float sqrt_recip_ac, float sqrt_recipm1_ac, float coef1,
+                 float coef2, float sigma, void* stream);
+int dsf_denorm_spec(const float* x, const float* mask, float* mel, const float* spec_min, const float* spec_max, int32_t B, int32_t M,
+                    int32_t T, void* stream);
 
 #ifdef __cplusplus
 }
