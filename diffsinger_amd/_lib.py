@@ -20,7 +20,8 @@ SYMBOLS = [
 ]
 # every symbol include/dsf.h declares (the FastSpeech2 conditioner ops)
 SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf_conv1d', 'dsf_layer_norm', 'dsf_attention',
-               'dsf_to_channel_major', 'dsf_from_channel_major', 'dsf_p_sample', 'dsf_denorm_spec']
+               'dsf_to_channel_major', 'dsf_from_channel_major', 'dsf_p_sample', 'dsf_denorm_spec',
+               'dsf_conv1d_dilated', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad']
 
 _fp = C.POINTER(C.c_float)
 _fpp = C.POINTER(C.c_void_p)
@@ -108,6 +109,11 @@ def load():
     lib.dsf_from_channel_major.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.dsf_p_sample.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]
     lib.dsf_denorm_spec.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.dsf_conv1d_dilated.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.dsf_wgrad_workspace_floats.argtypes = [i32, i32, i32]
+    lib.dsf_wgrad_workspace_floats.restype = i64
+    lib.dsf_conv1d_wgrad.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.dsf_bias_grad.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('dsd_abi_version',):

@@ -24,7 +24,7 @@ namespace dsd {
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr int kLoopMaxLayers = 64;
-constexpr int kLoopSpinLimit = 1 << 18;
+constexpr int kLoopSpinLimit = 1 << 21;     // ~2-4 s of polling: far beyond any legitimate skew, still bounded
 
 struct LoopParams {
     const float4* w1p;          // [L][w4][kc96][mb4][lane64]

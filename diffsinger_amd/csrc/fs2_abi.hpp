@@ -32,11 +32,25 @@ extern "C" int dsf_pack_weight(const float* w, int32_t Co, int32_t Ci, int32_t K
     return DSD_OK;
 }
 
+static int fs_conv_launch(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co,
+                          int32_t KT, int32_t dil, int32_t T, float scale, int32_t act, const float* residual, const float* keep, void* stream);
+
 extern "C" int dsf_conv1d(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co,
                           int32_t KT, int32_t T, float scale, int32_t act, const float* residual, const float* keep, void* stream) {
+    return fs_conv_launch(in, wpacked, bias, out, B, Ci, Co, KT, 1, T, scale, act, residual, keep, stream);
+}
+
+extern "C" int dsf_conv1d_dilated(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co,
+                                  int32_t KT, int32_t dil, int32_t T, void* stream) {
+    return fs_conv_launch(in, wpacked, bias, out, B, Ci, Co, KT, dil, T, 1.0f, 0, nullptr, nullptr, stream);
+}
+
+static int fs_conv_launch(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co,
+                          int32_t KT, int32_t dil, int32_t T, float scale, int32_t act, const float* residual, const float* keep, void* stream) {
     if (!in || !wpacked || !out) return fail(DSD_ERR_INVALID, "dsf_conv1d: null argument");
-    if (B < 1 || T < 1 || Co < 1 || Ci < 8 || (Ci % 8) || KT < 1 || KT > 2 * kFsHalo + 1 || !(KT & 1) || act < 0 || act > 3)
-        return fail(DSD_ERR_INVALID, "dsf_conv1d: bad shape (B=%d T=%d Ci=%d Co=%d K=%d act=%d)", B, T, Ci, Co, KT, act);
+    if (B < 1 || T < 1 || Co < 1 || Ci < 8 || (Ci % 8) || KT < 1 || KT > 2 * kFsHalo + 1 || !(KT & 1) || act < 0 || act > 3 || dil < 1 ||
+        dil * (KT - 1) / 2 > kFsHalo)
+        return fail(DSD_ERR_INVALID, "dsf_conv1d: bad shape (B=%d T=%d Ci=%d Co=%d K=%d dil=%d act=%d)", B, T, Ci, Co, KT, dil, act);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_fs_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
@@ -44,7 +58,7 @@ extern "C" int dsf_conv1d(const float* in, const float* wpacked, const float* bi
     }
     FsConvParams p{};
     p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.keep = keep;
-    p.Ci = Ci; p.Co = Co; p.KT = KT; p.pad = (KT - 1) / 2; p.T = T; p.TS = fs_ts(T);
+    p.Ci = Ci; p.Co = Co; p.KT = KT; p.dil = dil; p.pad = dil * (KT - 1) / 2; p.T = T; p.TS = fs_ts(T);
     p.scale = scale; p.act = act;
     const dim3 grid((unsigned)(p.TS / 32), (unsigned)B, (unsigned)((Co + 255) / 256));
     hipLaunchKernelGGL((k_fs_conv<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
@@ -116,6 +130,40 @@ extern "C" int dsf_denorm_spec(const float* x, const float* mask, float* mel, co
     if (!x || !mel || !spec_min || !spec_max || B < 1 || M < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_denorm_spec: bad argument");
     hipLaunchKernelGGL(k_denorm_spec, dim3((unsigned)((T + 31) / 32), (unsigned)B), dim3(256), 32 * (M + 1) * 4, (hipStream_t)stream, x, mask, mel,
                        spec_min, spec_max, M, T);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+// ---- training operators ---------------------------------------------------------------------
+static const int kWgSplits = 16;
+
+extern "C" int64_t dsf_wgrad_workspace_floats(int32_t Co, int32_t Ci, int32_t KT) {
+    if (Co < 1 || Ci < 1 || (KT != 1 && KT != 3)) return -1;
+    return (int64_t)kWgSplits * Co * Ci * KT;
+}
+
+extern "C" int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, float* workspace, int32_t B, int32_t Ci, int32_t Co, int32_t KT,
+                                int32_t dil, int32_t T, int32_t accumulate, void* stream) {
+    if (!dy || !x || !dw || !workspace) return fail(DSD_ERR_INVALID, "dsf_conv1d_wgrad: null argument");
+    if (B < 1 || T < 1 || Co < 1 || Ci < 1 || (KT != 1 && KT != 3) || dil < 1 || dil * (KT - 1) / 2 > kFsHalo)
+        return fail(DSD_ERR_INVALID, "dsf_conv1d_wgrad: bad shape (B=%d T=%d Ci=%d Co=%d K=%d dil=%d); kernels 1 and 3 are supported", B, T, Ci, Co, KT, dil);
+    FsWgradParams p{};
+    p.dy = dy; p.x = x; p.part = workspace; p.B = B; p.Ci = Ci; p.Co = Co; p.dil = dil; p.pad = dil * (KT - 1) / 2; p.T = T; p.TS = fs_ts(T);
+    p.nsplit = kWgSplits;
+    const dim3 grid((unsigned)((Co + 127) / 128), (unsigned)((Ci + 63) / 64), (unsigned)kWgSplits);
+    if (KT == 1) hipLaunchKernelGGL((k_fs_wgrad<1>), grid, dim3(kThreads), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_fs_wgrad<3>), grid, dim3(kThreads), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    const size_t n = (size_t)Co * Ci * KT;
+    hipLaunchKernelGGL(k_fs_wgrad_reduce, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, workspace, dw, n,
+                       kWgSplits, accumulate);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, int32_t accumulate, void* stream) {
+    if (!dy || !db || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_bias_grad: bad argument");
+    hipLaunchKernelGGL(k_fs_bias_grad, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, dy, db, B, C, T, fs_ts(T), accumulate);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

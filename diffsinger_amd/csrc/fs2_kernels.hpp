@@ -34,19 +34,19 @@ struct FsConvParams {
     float* out;             // [B][Co][TS]
     const float* res;       // residual [B][Co][TS] or nullptr (added after the activation)
     const float* keep;      // [B][T], 1 = frame valid, 0 = padding; nullptr = no mask
-    int Ci, Co, KT, pad, T, TS;
+    int Ci, Co, KT, pad, dil, T, TS;     // pad = dil * (KT - 1) / 2 <= kFsHalo
     float scale;            // multiplied in before the activation (TransformerFFNLayer: kernel_size ** -0.5)
     int act;
 };
 
 struct FsTapB {             // B-operand functor of GemmPipe: chunk kc = ci8 * KT + tap of the staged slab
     const float* base;      // slab + 4 h LD + halo + j - pad
-    int KT, n;
+    int KT, dil, n;
     __device__ __forceinline__ const float* operator()(int it, int u) const {
         int kc = 6 * it + u;
         kc = (kc < n) ? kc : n - 1;
         const int g = kc / KT, tap = kc - g * KT;
-        return base + g * (8 * kFsLD) + tap;
+        return base + g * (8 * kFsLD) + tap * dil;
     }
 };
 
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_conv(const FsConvParams p) {
         __syncthreads();
         const int nch = (nc / 8) * p.KT;
         const float4* ap = p.wp + (((size_t)mt * 4 + w) * nchunk_total + (size_t)(c0 / 8) * p.KT) * (NMB * 64);
-        const FsTapB bof{smem + 4 * h * kFsLD + kFsHalo + j - p.pad, p.KT, nch};
+        const FsTapB bof{smem + 4 * h * kFsLD + kFsHalo + j - p.pad, p.KT, p.dil, nch};
         gemm_k<NMB, 1, kFsLD, NMB * 64>(acc, ap, lane, nch, bof);
         __syncthreads();
     }
@@ -278,6 +278,106 @@ __global__ void k_fs_p_sample(float* __restrict__ x, const float* __restrict__ e
         const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, xv));
         x[i] = __fadd_rn(mean, __fmul_rn(sigma, z[i]));
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient of a Conv1d / Linear (training):
+//     dW[co][ci][tap] = sum_b sum_t dy[b][co][t] * x[b][ci][t + tap * dil - pad]
+// A contraction over FRAMES: both operands are activations.  A workgroup owns a 128 (co) x 64 (ci) x KT tile of dW and one
+// of `nsplit` frame ranges; per 32-frame chunk it stages dy [128][32] and x [64][32 + 16] in LDS (odd row strides: the MFMA
+// operands are read ACROSS rows), D[i = co][j = ci] += A[i][k = t] B[k][j] on v_mfma_f32_32x32x2_f32.  Partial tiles go to
+// part[split][co][ci][tap]; k_fs_wgrad_reduce sums the splits in a fixed order (deterministic gradients, no float atomics).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kWgLdy = 33, kWgLdx = 49;
+struct FsWgradParams {
+    const float* dy;        // [B][Co][TS]
+    const float* x;         // [B][Ci][TS]
+    float* part;            // [nsplit][Co][Ci][KT]
+    int B, Ci, Co, dil, pad, T, TS, nsplit;
+};
+
+template <int KT>
+__global__ __launch_bounds__(kThreads, 2) void k_fs_wgrad(const FsWgradParams p) {
+    __shared__ float dyt[128 * kWgLdy];
+    __shared__ float xt[64 * kWgLdx];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 64, split = blockIdx.z;
+    const int tiles_per_utt = p.TS / 32, ntile = p.B * tiles_per_utt;
+    const int per = (ntile + p.nsplit - 1) / p.nsplit;
+    const int tile_lo = split * per, tile_hi = min(ntile, tile_lo + per);
+    f32x16 acc[KT][2];
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][nb][r] = 0.f;
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        const int b = tile / tiles_per_utt, t0 = (tile - b * tiles_per_utt) * 32;
+        __syncthreads();
+        // dy rows [co0, co0+128) x frames [t0, t0+32): 8 float4 per row
+        for (int idx = tid; idx < 128 * 8; idx += kThreads) {
+            const int row = idx >> 3, g = idx & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co0 + row < p.Co) v = *reinterpret_cast<const float4*>(p.dy + ((size_t)b * p.Co + co0 + row) * p.TS + t0 + 4 * g);
+            const int t = t0 + 4 * g;                       // frames >= T carry no gradient (whatever the buffer holds there)
+            float* d = dyt + row * kWgLdy + 4 * g;
+            d[0] = (t + 0 < p.T) ? v.x : 0.f; d[1] = (t + 1 < p.T) ? v.y : 0.f; d[2] = (t + 2 < p.T) ? v.z : 0.f; d[3] = (t + 3 < p.T) ? v.w : 0.f;
+        }
+        // x rows [ci0, ci0+64) x frames [t0-8, t0+40): 12 float4 per row, zero outside [0, TS)
+        for (int idx = tid; idx < 64 * 12; idx += kThreads) {
+            const int row = idx / 12, g = idx - row * 12;
+            const int t = t0 - kFsHalo + 4 * g;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci0 + row < p.Ci && t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(p.x + ((size_t)b * p.Ci + ci0 + row) * p.TS + t);
+            float* d = xt + row * kWgLdx + 4 * g;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        const float* ap = dyt + (32 * w + j) * kWgLdy + h;                        // A[i = co][k = t]: lane half h supplies t = 2 s + h
+        const float* bp = xt + j * kWgLdx + kFsHalo - p.pad + h;                  // B[k = t][j = ci]
+#pragma unroll 4
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const float a = ap[2 * s2];
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[k][nb] = mfma32(a, bp[nb * 32 * kWgLdx + 2 * s2 + k * p.dil], acc[k][nb]);
+        }
+    }
+    float* out = p.part + (size_t)split * p.Co * p.Ci * KT;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * w + frag_row(r, h), ci = ci0 + 32 * nb + j;
+                if (co < p.Co && ci < p.Ci) out[((size_t)co * p.Ci + ci) * KT + k] = acc[k][nb][r];
+            }
+}
+
+__global__ void k_fs_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, size_t n, int nsplit, int accumulate) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = accumulate ? dw[i] : 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+        dw[i] = s;
+    }
+}
+
+// db[c] = sum_b sum_t dy[b][c][t] (bias gradient): one wave per channel, fixed summation order
+__global__ void k_fs_bias_grad(const float* __restrict__ dy, float* __restrict__ db, int B, int C, int T, int TS, int accumulate) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* row = dy + ((size_t)b * C + c) * TS;
+        for (int t = lane; t < T; t += 64) s += row[t];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) db[c] = (accumulate ? db[c] : 0.f) + s;
 }
 
 // internal [B][C][TS] -> [B][T][C] (the reference's layout), 32 x 32 tiles through LDS

@@ -270,16 +270,38 @@ class GaussianDiffusion(nn.Module):
                 **kwargs):
         """:233-276.  Needs `self.fs2` (the reference's FastSpeech2) for the conditioner; the diffusion loop is
         `inference()`."""
-        if not infer:
-            raise NotImplementedError('training branch (p_losses) is outside the HIP hot path; train with the reference')
         if self.fs2 is None:
             raise RuntimeError('no FastSpeech2 attached (self.fs2): run inside the reference tree, pass fs2=, or call '
                                'inference(cond, ...) with a precomputed conditioner')
+        if not infer:
+            return self._forward_train(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, **kwargs)
         ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=False, infer=True, **kwargs)
         cond = ret['decoder_inp'].transpose(1, 2)
         ret['fs2_mel'] = ret['mel_out']
         mask = (mel2ph > 0).float() if mel2ph is not None else None           # :272-273
         ret['mel_out'] = self.inference(cond, fs2_mels=ret['mel_out'], mel_mask=mask)
+        return ret
+
+    def p_losses(self, x_start, t, cond, noise=None, nonpadding=None):
+        """:213-231 on the HIP training operators (diffsinger_amd/train.py)."""
+        from .train import p_losses
+        return p_losses(self, x_start, t, cond, noise=noise, nonpadding=nonpadding)
+
+    def _forward_train(self, txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, **kwargs):
+        """The training branch of forward (:233-247): fs2(skip_decoder=True) -> t ~ U[0, K_step) -> p_losses.  The reference's
+        FastSpeech2 (inside its tree) runs as it is, with its gradients; the HIP FastSpeech2 is inference-only and acts as a
+        frozen conditioner here."""
+        from .fs2 import FastSpeech2 as HipFS2
+        if isinstance(self.fs2, HipFS2):
+            with torch.no_grad():
+                ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=True, **kwargs)
+        else:
+            ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=False, **kwargs)
+        cond = ret['decoder_inp'].transpose(1, 2)
+        b = txt_tokens.shape[0]
+        t = torch.randint(0, self.K_step, (b,), device=txt_tokens.device).long()
+        x = self.norm_spec(ref_mels).transpose(1, 2)[:, None, :, :]
+        ret['diff_loss'] = self.p_losses(x, t, cond)
         return ret
 
     # -- element-wise helpers kept for API parity (buffers live on the module's device) -----------------------------

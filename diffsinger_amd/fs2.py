@@ -77,7 +77,7 @@ class PackedWeight:
             buf = torch.empty(n, device=w.device, dtype=torch.float32)
             with torch.cuda.device(w.device):
                 _lib.check(lib.dsf_pack_weight(w3.data_ptr(), co, ci, k, buf.data_ptr(), _stream(w.device)), 'dsf_pack_weight')
-                torch.cuda.current_stream(w.device).synchronize()       # w3 may be a temporary
+            w3.record_stream(torch.cuda.current_stream(w.device))        # w3 may be a temporary: keep its memory until the pack ran
             self.buf, self.tag = buf, tag
         return self.buf
 

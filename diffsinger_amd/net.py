@@ -6,8 +6,9 @@ reference state_dict loads with strict=True and vice versa), same RNG consumptio
 `torch.manual_seed(s); DiffNet(80)` gives the reference's initial weights), same call signature
 `forward(spec [B,1,M,T], diffusion_step [B], cond [B,H,T]) -> [B,1,M,T]`.
 
-Inference only: the HIP path has no backward.  Calling it with autograd enabled on parameters that require
-grad raises instead of silently running some other implementation (training = SURVEY section 8 row f3)."""
+Under torch.no_grad() the forward is the fused inference path (engine.py).  With autograd enabled on parameters that require
+grad it is the training path of diffsinger_amd/train.py (first slice): the same contractions as
+stand-alone HIP operators with hand-written data / weight gradients, element-wise glue through torch autograd."""
 from __future__ import annotations
 
 import torch
@@ -109,8 +110,10 @@ class DiffNet(nn.Module):
 
     def forward(self, spec, diffusion_step, cond):
         """:param spec: [B, 1, M, T]  :param diffusion_step: [B]  :param cond: [B, H, T]  :return: [B, 1, M, T]"""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('the HIP DiffNet is inference-only (no backward); wrap the call in torch.no_grad()')
+        if torch.is_grad_enabled() and (cond.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training (p_losses, usr/diff/shallow_diffusion_tts.py:213-231): the autograd path on the HIP conv / wgrad operators
+            from .train import diffnet_forward_train
+            return diffnet_forward_train(self, spec, diffusion_step.reshape(-1), cond)
         eng = self.bind_cond(cond)
         t = diffusion_step.reshape(-1)
         eps = eng.denoise(spec, t)

@@ -1,0 +1,162 @@
+"""Training path of the DiffNet denoiser (first slice): `p_losses` (usr/diff/shallow_diffusion_tts.py:
+213-231) with the forward AND backward contractions on the HIP operators of include/dsf.h.
+
+What is native: every Conv1d / Linear of DiffNet (usr/diff/net.py:91-105) in the forward pass, its data gradient (the same
+MFMA convolution kernel with the flipped, transposed weight) and its weight / bias gradients (`dsf_conv1d_wgrad`: a split-K
+contraction over frames on fp32 MFMA, reduced in a fixed order -> deterministic) - > 99 % of the FLOPs of a training step.
+What is torch: the element-wise glue between them (x + step, sigmoid * tanh, residual / skip sums, ReLU, the L1 loss) as
+ordinary autograd ops on the device, the step-embedding MLP on [B, C] vectors, and the optimiser.  DDP works unchanged on top
+(gradients are ordinary `.grad` tensors; the all-reduce is torch.distributed's, RCCL on ROCm).
+
+This is the functional slice of row f3, not yet the fused one: activations live channel-major [B][C][TS] (TS = T up to 32, zero
+tail) and every operator is its own launch.  Parity: gradients of all 15 M parameters against torch autograd on the CPU oracle
+(tests/test_gpu_train.py)."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .fs2 import PackedWeight, padded_frames
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _Conv1dCM(torch.autograd.Function):
+    """y = W * x + b on channel-major tensors [B][C][TS] with the zero-tail invariant; K in {1, 3}, dilation d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, T, dil, cache):
+        lib = _lib.load()
+        w3 = weight if weight.dim() == 3 else weight[:, :, None]
+        Co, Ci, K = w3.shape
+        B, _, TS = x.shape
+        x = x.contiguous()
+        out = torch.empty(B, Co, TS, device=x.device, dtype=torch.float32)
+        wp = cache['fwd'].get(weight)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.dsf_conv1d_dilated(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                              B, Ci, Co, K, dil, T, _stream(x.device)), 'dsf_conv1d_dilated')
+        ctx.save_for_backward(x, weight, bias if bias is not None else torch.empty(0, device=x.device))
+        ctx.T, ctx.dil, ctx.cache, ctx.has_bias = T, dil, cache, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight, bias = ctx.saved_tensors
+        T, dil, cache = ctx.T, ctx.dil, ctx.cache
+        w3 = weight if weight.dim() == 3 else weight[:, :, None]
+        Co, Ci, K = w3.shape
+        B, _, TS = x.shape
+        dy = dy.contiguous().clone()
+        if TS > T:
+            dy[:, :, T:] = 0                                    # the operators rely on the zero tail
+        dev = x.device
+        dx = dw = db = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                # data gradient = convolution of dy with W'[ci][co][k] = W[co][ci][K-1-k] (same dilation, same padding)
+                wt = cache.get('bwd_w')
+                tag = (weight.data_ptr(), weight._version)
+                if wt is None or cache.get('bwd_tag') != tag:
+                    wt = w3.detach().flip(2).transpose(0, 1).contiguous()
+                    cache['bwd_w'], cache['bwd_tag'] = wt, tag
+                wtp = cache['bwd'].get(wt)
+                dx = torch.empty(B, Ci, TS, device=dev, dtype=torch.float32)
+                _lib.check(lib.dsf_conv1d_dilated(dy.data_ptr(), wtp.data_ptr(), None, dx.data_ptr(), B, Co, Ci, K, dil, T, _stream(dev)),
+                           'dsf_conv1d_dilated (dgrad)')
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty(Co, Ci, K, device=dev, dtype=torch.float32)
+                ws = cache.get('ws')
+                n = lib.dsf_wgrad_workspace_floats(Co, Ci, K)
+                if ws is None or ws.numel() < n:
+                    ws = cache['ws'] = torch.empty(n, device=dev, dtype=torch.float32)
+                _lib.check(lib.dsf_conv1d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Ci, Co, K, dil, T, 0, _stream(dev)),
+                           'dsf_conv1d_wgrad')
+                dw = dw.reshape(weight.shape)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(Co, device=dev, dtype=torch.float32)
+                _lib.check(lib.dsf_bias_grad(dy.data_ptr(), db.data_ptr(), B, Co, T, 0, _stream(dev)), 'dsf_bias_grad')
+        return dx, dw, db, None, None, None
+
+
+class ConvCache:
+    """Per-layer cache of the packed forward / transposed weights and the split-K workspace."""
+
+    def __init__(self):
+        self.d = {'fwd': PackedWeight(), 'bwd': PackedWeight()}
+
+    def __call__(self, x, weight, bias, T, dil=1):
+        if weight.shape[1] % 8:
+            raise ValueError('input channels must be a multiple of 8')
+        return _Conv1dCM.apply(x, weight, bias, T, dil, self.d)
+
+
+def step_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    half = dim // 2                                                 # usr/diff/net.py:37-44
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half, device=t.device) * -e)
+    e = t[:, None] * e[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+    """DiffNet.forward (usr/diff/net.py:107-130) under autograd.  spec [B,1,M,T], diffusion_step [B], cond [B,H,T] -> [B,1,M,T]."""
+    if spec.device.type != 'cuda':
+        raise RuntimeError('the HIP training path has no CPU path')
+    B, _, M, T = spec.shape
+    TS = padded_frames(T)
+    caches = net.__dict__.setdefault('_train_caches', {})
+
+    def conv(name, x, mod, dil=1):
+        c = caches.get(name)
+        if c is None:
+            c = caches[name] = ConvCache()
+        return c(x, mod.weight, mod.bias, T, dil)
+
+    valid = (torch.arange(TS, device=spec.device) < T).float()[None, None, :]
+    pad = (0, TS - T)
+    xm = F.pad(spec[:, 0], pad)                                     # [B][M][TS], zero tail
+    cm = F.pad(cond, pad).contiguous()                              # [B][H][TS]
+    x = F.relu(conv('in', xm, net.input_projection)) * valid        # :116-118 (the tail must stay zero: conv padding applies to it)
+    d = step_embedding(diffusion_step, net.residual_channels)       # :119
+    h = F.linear(d, net.mlp[0].weight, net.mlp[0].bias)
+    d = F.linear(h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)      # :120 (Mish)
+    skip = None
+    C = net.residual_channels
+    for l, layer in enumerate(net.residual_layers):                 # ResidualBlock.forward :66-78
+        ds = F.linear(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)[:, :, None]
+        y = (x + ds) * valid
+        y = conv(f'l{l}.dc', y, layer.dilated_conv, layer.dilation) + conv(f'l{l}.cp', cm, layer.conditioner_projection)
+        y = (torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])) * valid
+        y = conv(f'l{l}.op', y, layer.output_projection)
+        x = ((x + y[:, :C]) / math.sqrt(2.0)) * valid
+        skip = y[:, C:] if skip is None else skip + y[:, C:]
+    x = (skip / math.sqrt(len(net.residual_layers))) * valid        # :126
+    x = F.relu(conv('sp', x, net.skip_projection)) * valid          # :127-128
+    x = conv('out', x, net.output_projection)                       # :129
+    return x[:, None, :, :T]
+
+
+def p_losses(gd, x_start: torch.Tensor, t: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tensor] = None,
+             nonpadding: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:213-231)."""
+    if noise is None:
+        noise = torch.randn_like(x_start)
+    shape = (x_start.shape[0], 1, 1, 1)
+    x_noisy = gd.sqrt_alphas_cumprod.gather(-1, t).reshape(shape) * x_start + \
+        gd.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(shape) * noise                    # q_sample :206-211
+    x_recon = diffnet_forward_train(gd.denoise_fn, x_noisy, t, cond)
+    if gd.loss_type == 'l1':
+        if nonpadding is not None:
+            return ((noise - x_recon).abs() * nonpadding.unsqueeze(1)).mean()
+        return (noise - x_recon).abs().mean()
+    if gd.loss_type == 'l2':
+        return F.mse_loss(noise, x_recon)
+    raise NotImplementedError(gd.loss_type)

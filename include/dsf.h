@@ -56,6 +56,22 @@ int dsf_to_channel_major(const float* x, int64_t stride_b, int64_t stride_c, int
                          int32_t T, void* stream);
 int dsf_from_channel_major(const float* in, float* out /* [B][T][C] contiguous */, int32_t B, int32_t C, int32_t T, void* stream);
 
+/* The same convolution with a dilation (kernel K odd, dil * (K-1)/2 <= 8): the DiffNet dilated_conv (usr/diff/net.py:62) as a
+ * stand-alone operator of the TRAINING path, and the data gradient of any of these convolutions (= the convolution with the
+ * flipped, transposed weight). */
+int dsf_conv1d_dilated(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co, int32_t K,
+                       int32_t dil, int32_t T, void* stream);
+
+/* Training: what autograd's conv1d / linear backward computes for the weight and the bias
+ * (torch/csrc/autograd: ConvolutionBackward, AddmmBackward) -
+ *     dw[co][ci][k] (+)= sum_b sum_t dy[b][co][t] * x[b][ci][t + k * dil - dil * (K-1)/2],   db[c] (+)= sum_b sum_t dy[b][c][t]
+ * dy [B][Co][TS], x [B][Ci][TS] channel-major (zero in [T,TS)), dw in torch layout [Co][Ci][K] (K = 1 or 3), workspace of
+ * dsf_wgrad_workspace_floats(Co, Ci, K) floats (split-K partials, reduced in a fixed order: deterministic). */
+int64_t dsf_wgrad_workspace_floats(int32_t Co, int32_t Ci, int32_t K);
+int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, float* workspace, int32_t B, int32_t Ci, int32_t Co, int32_t K, int32_t dil,
+                     int32_t T, int32_t accumulate, void* stream);
+int dsf_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, int32_t accumulate, void* stream);
+
 /* Sampler pieces for a denoise_fn that is not the fused DiffNet (the `FFT` candidate decoder, usr/diff/candidate_decoder.py:35-96;
  * SURVEY section 8 row f4): one p_sample update (usr/diff/shallow_diffusion_tts.py:134-166: x0 = a x - b eps, clamp, posterior
  * mean, + sigma z) in place on n contiguous floats with the fp32 table entries of step t passed by the host, and denorm_spec

@@ -74,12 +74,13 @@ for call in (lambda: ours(x, torch.tensor([3]), cond), lambda: gd_o.inference(co
         assert 'no CPU path' in str(e) or 'HIP' in str(e), e
     else:
         raise AssertionError('CPU call must raise')
+# the training branch exists (HIP operators with hand-written gradients, diffsinger_amd/train.py) but, like inference, only on the device
 try:
-    gd_o(torch.zeros(1, 3, dtype=torch.long), infer=False)
-except NotImplementedError:
-    pass
+    ours(x.requires_grad_(False), torch.tensor([3]), cond)            # autograd on, parameters require grad -> training path
+except RuntimeError as e:
+    assert 'no CPU path' in str(e), e
 else:
-    raise AssertionError('training branch must raise')
+    raise AssertionError('CPU training call must raise')
 print('DROPIN_OK')
 '''
 
