@@ -112,7 +112,7 @@ def load():
     lib.dsf_conv1d_dilated.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.dsf_wgrad_workspace_floats.argtypes = [i32, i32, i32]
     lib.dsf_wgrad_workspace_floats.restype = i64
-    lib.dsf_conv1d_wgrad.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.dsf_conv1d_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.dsf_bias_grad.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)

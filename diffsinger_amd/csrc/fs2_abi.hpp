@@ -139,16 +139,16 @@ static const int kWgSplits = 16;
 
 extern "C" int64_t dsf_wgrad_workspace_floats(int32_t Co, int32_t Ci, int32_t KT) {
     if (Co < 1 || Ci < 1 || (KT != 1 && KT != 3)) return -1;
-    return (int64_t)kWgSplits * Co * Ci * KT;
+    return (int64_t)kWgSplits * Co * Ci * KT + (int64_t)kWgSplits * Co;
 }
 
-extern "C" int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, float* workspace, int32_t B, int32_t Ci, int32_t Co, int32_t KT,
-                                int32_t dil, int32_t T, int32_t accumulate, void* stream) {
+extern "C" int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, float* db, float* workspace, int32_t B, int32_t Ci, int32_t Co,
+                                int32_t KT, int32_t dil, int32_t T, int32_t accumulate, void* stream) {
     if (!dy || !x || !dw || !workspace) return fail(DSD_ERR_INVALID, "dsf_conv1d_wgrad: null argument");
     if (B < 1 || T < 1 || Co < 1 || Ci < 1 || (KT != 1 && KT != 3) || dil < 1 || dil * (KT - 1) / 2 > kFsHalo)
         return fail(DSD_ERR_INVALID, "dsf_conv1d_wgrad: bad shape (B=%d T=%d Ci=%d Co=%d K=%d dil=%d); kernels 1 and 3 are supported", B, T, Ci, Co, KT, dil);
     FsWgradParams p{};
-    p.dy = dy; p.x = x; p.part = workspace; p.B = B; p.Ci = Ci; p.Co = Co; p.dil = dil; p.pad = dil * (KT - 1) / 2; p.T = T; p.TS = fs_ts(T);
+    p.dy = dy; p.x = x; p.part = workspace; p.part_b = db ? workspace + (size_t)kWgSplits * Co * Ci * KT : nullptr; p.B = B; p.Ci = Ci; p.Co = Co; p.dil = dil; p.pad = dil * (KT - 1) / 2; p.T = T; p.TS = fs_ts(T);
     p.nsplit = kWgSplits;
     const dim3 grid((unsigned)((Co + 127) / 128), (unsigned)((Ci + 63) / 64), (unsigned)kWgSplits);
     if (KT == 1) hipLaunchKernelGGL((k_fs_wgrad<1>), grid, dim3(kThreads), 0, (hipStream_t)stream, p);
@@ -157,6 +157,8 @@ extern "C" int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, floa
     const size_t n = (size_t)Co * Ci * KT;
     hipLaunchKernelGGL(k_fs_wgrad_reduce, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, workspace, dw, n,
                        kWgSplits, accumulate);
+    if (db) hipLaunchKernelGGL(k_fs_wgrad_reduce, dim3((unsigned)((Co + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.part_b, db, (size_t)Co,
+                               kWgSplits, accumulate);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

@@ -293,6 +293,7 @@ struct FsWgradParams {
     const float* dy;        // [B][Co][TS]
     const float* x;         // [B][Ci][TS]
     float* part;            // [nsplit][Co][Ci][KT]
+    float* part_b;          // [nsplit][Co] bias-gradient partials, or nullptr
     int B, Ci, Co, dil, pad, T, TS, nsplit;
 };
 
@@ -313,28 +314,48 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_wgrad(const FsWgradParams p)
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[k][nb][r] = 0.f;
-    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    // software pipeline: the global loads of tile i+1 are in flight while tile i is multiplied.
+    // thread tid stages dy rows (tid >> 3) + 32 q, float4 column (tid & 7) [q = 0..3] and x float4 tid + 256 q [q = 0..2]
+    float4 dv[4], xv[3];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};                  // bias gradient: row sums of the dy this thread stages
+    auto fetch = [&](int tile) {
         const int b = tile / tiles_per_utt, t0 = (tile - b * tiles_per_utt) * 32;
-        __syncthreads();
-        // dy rows [co0, co0+128) x frames [t0, t0+32): 8 float4 per row
-        for (int idx = tid; idx < 128 * 8; idx += kThreads) {
-            const int row = idx >> 3, g = idx & 7;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co0 + row < p.Co) v = *reinterpret_cast<const float4*>(p.dy + ((size_t)b * p.Co + co0 + row) * p.TS + t0 + 4 * g);
-            const int t = t0 + 4 * g;                       // frames >= T carry no gradient (whatever the buffer holds there)
-            float* d = dyt + row * kWgLdy + 4 * g;
-            d[0] = (t + 0 < p.T) ? v.x : 0.f; d[1] = (t + 1 < p.T) ? v.y : 0.f; d[2] = (t + 2 < p.T) ? v.z : 0.f; d[3] = (t + 3 < p.T) ? v.w : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = (tid >> 3) + 32 * q, g = tid & 7;
+            dv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co0 + row < p.Co) {
+                float4 v = *reinterpret_cast<const float4*>(p.dy + ((size_t)b * p.Co + co0 + row) * p.TS + t0 + 4 * g);
+                const int t = t0 + 4 * g;                   // frames >= T carry no gradient (whatever the buffer holds there)
+                v.x = (t + 0 < p.T) ? v.x : 0.f; v.y = (t + 1 < p.T) ? v.y : 0.f; v.z = (t + 2 < p.T) ? v.z : 0.f; v.w = (t + 3 < p.T) ? v.w : 0.f;
+                dv[q] = v;
+            }
         }
-        // x rows [ci0, ci0+64) x frames [t0-8, t0+40): 12 float4 per row, zero outside [0, TS)
-        for (int idx = tid; idx < 64 * 12; idx += kThreads) {
-            const int row = idx / 12, g = idx - row * 12;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = tid + 256 * q, row = idx / 12, g = idx - row * 12;
             const int t = t0 - kFsHalo + 4 * g;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci0 + row < p.Ci && t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(p.x + ((size_t)b * p.Ci + ci0 + row) * p.TS + t);
+            xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci0 + row < p.Ci && t >= 0 && t < p.TS) xv[q] = *reinterpret_cast<const float4*>(p.x + ((size_t)b * p.Ci + ci0 + row) * p.TS + t);
+        }
+    };
+    if (tile_lo < tile_hi) fetch(tile_lo);
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        __syncthreads();                                    // the previous tile's LDS reads are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* d = dyt + ((tid >> 3) + 32 * q) * kWgLdy + 4 * (tid & 7);
+            d[0] = dv[q].x; d[1] = dv[q].y; d[2] = dv[q].z; d[3] = dv[q].w;
+            bsum[q] += (dv[q].x + dv[q].y) + (dv[q].z + dv[q].w);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = tid + 256 * q, row = idx / 12, g = idx - row * 12;
             float* d = xt + row * kWgLdx + 4 * g;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            d[0] = xv[q].x; d[1] = xv[q].y; d[2] = xv[q].z; d[3] = xv[q].w;
         }
         __syncthreads();
+        if (tile + 1 < tile_hi) fetch(tile + 1);
         const float* ap = dyt + (32 * w + j) * kWgLdy + h;                        // A[i = co][k = t]: lane half h supplies t = 2 s + h
         const float* bp = xt + j * kWgLdx + kFsHalo - p.pad + h;                  // B[k = t][j = ci]
 #pragma unroll 4
@@ -357,6 +378,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_wgrad(const FsWgradParams p)
                 const int co = co0 + 32 * w + frag_row(r, h), ci = ci0 + 32 * nb + j;
                 if (co < p.Co && ci < p.Ci) out[((size_t)co * p.Ci + ci) * KT + k] = acc[k][nb][r];
             }
+    // bias-gradient partials: the 8 threads of a row sit in consecutive lanes; only the ci-tile-0 workgroups report
+    if (p.part_b && blockIdx.y == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float sb = bsum[q];
+            sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64); sb += __shfl_xor(sb, 4, 64);
+            const int row = co0 + (tid >> 3) + 32 * q;
+            if ((tid & 7) == 0 && row < p.Co) p.part_b[(size_t)split * p.Co + row] = sb;
+        }
+    }
 }
 
 __global__ void k_fs_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, size_t n, int nsplit, int accumulate) {

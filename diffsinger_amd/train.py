@@ -54,9 +54,10 @@ class _Conv1dCM(torch.autograd.Function):
         w3 = weight if weight.dim() == 3 else weight[:, :, None]
         Co, Ci, K = w3.shape
         B, _, TS = x.shape
-        dy = dy.contiguous().clone()
-        if TS > T:
-            dy[:, :, T:] = 0                                    # the operators rely on the zero tail
+        dy = dy.contiguous()
+        if TS > T and ctx.needs_input_grad[0]:
+            dy = dy.clone()
+            dy[:, :, T:] = 0                                    # the data-gradient convolution relies on the zero tail (wgrad masks it itself)
         dev = x.device
         dx = dw = db = None
         with torch.cuda.device(dev):
@@ -71,16 +72,19 @@ class _Conv1dCM(torch.autograd.Function):
                 dx = torch.empty(B, Ci, TS, device=dev, dtype=torch.float32)
                 _lib.check(lib.dsf_conv1d_dilated(dy.data_ptr(), wtp.data_ptr(), None, dx.data_ptr(), B, Co, Ci, K, dil, T, _stream(dev)),
                            'dsf_conv1d_dilated (dgrad)')
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
                 dw = torch.empty(Co, Ci, K, device=dev, dtype=torch.float32)
+                if want_db:
+                    db = torch.empty(Co, device=dev, dtype=torch.float32)       # fused into the weight-gradient kernel (row sums of dy)
                 ws = cache.get('ws')
                 n = lib.dsf_wgrad_workspace_floats(Co, Ci, K)
                 if ws is None or ws.numel() < n:
                     ws = cache['ws'] = torch.empty(n, device=dev, dtype=torch.float32)
-                _lib.check(lib.dsf_conv1d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Ci, Co, K, dil, T, 0, _stream(dev)),
-                           'dsf_conv1d_wgrad')
+                _lib.check(lib.dsf_conv1d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(),
+                                                B, Ci, Co, K, dil, T, 0, _stream(dev)), 'dsf_conv1d_wgrad')
                 dw = dw.reshape(weight.shape)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            elif want_db:
                 db = torch.empty(Co, device=dev, dtype=torch.float32)
                 _lib.check(lib.dsf_bias_grad(dy.data_ptr(), db.data_ptr(), B, Co, T, 0, _stream(dev)), 'dsf_bias_grad')
         return dx, dw, db, None, None, None

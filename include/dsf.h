@@ -68,8 +68,8 @@ int dsf_conv1d_dilated(const float* in, const float* wpacked, const float* bias,
  * dy [B][Co][TS], x [B][Ci][TS] channel-major (zero in [T,TS)), dw in torch layout [Co][Ci][K] (K = 1 or 3), workspace of
  * dsf_wgrad_workspace_floats(Co, Ci, K) floats (split-K partials, reduced in a fixed order: deterministic). */
 int64_t dsf_wgrad_workspace_floats(int32_t Co, int32_t Ci, int32_t K);
-int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, float* workspace, int32_t B, int32_t Ci, int32_t Co, int32_t K, int32_t dil,
-                     int32_t T, int32_t accumulate, void* stream);
+int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, float* db /* [Co] or NULL: fused bias gradient */, float* workspace, int32_t B,
+                     int32_t Ci, int32_t Co, int32_t K, int32_t dil, int32_t T, int32_t accumulate, void* stream);
 int dsf_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, int32_t accumulate, void* stream);
 
 /* Sampler pieces for a denoise_fn that is not the fused DiffNet (the `FFT` candidate decoder, usr/diff/candidate_decoder.py:35-96;
