@@ -5,23 +5,29 @@
 #include "../../include/dsf.h"
 
 static inline int fs_ts(int T) { return (T + 31) / 32 * 32; }
+// Row blocks per wave of k_fs_conv (fixes the packed weight layout).  4 (512 rows per workgroup, one workgroup per CU) was measured
+// SLOWER than 2 on the wide layers - FastSpeech2 forward 5.9 vs 5.2 ms, training step 16.8 vs 16.3 ms (profiles/r01s_*): with
+// unpipelined staging the second co-resident workgroup is what hides the slab loads.
+static inline int fs_nmb(int Co) { (void)Co; return 2; }
 
 extern "C" int dsf_padded_frames(int32_t T) { return fs_ts(T); }
 
 extern "C" int64_t dsf_packed_floats(int32_t Co, int32_t Ci, int32_t KT) {
     if (Co < 1 || Ci < 8 || (Ci % 8) || KT < 1) return -1;
-    const int64_t mt = (Co + 255) / 256;
-    return (mt * 4 * (int64_t)(Ci / 8) * KT * 2 * 64 + kWeightSlack) * 4;
+    const int nmb = fs_nmb(Co);
+    const int64_t mt = (Co + 128 * nmb - 1) / (128 * nmb);
+    return (mt * 4 * (int64_t)(Ci / 8) * KT * nmb * 64 + kWeightSlack) * 4;
 }
 
 extern "C" int dsf_pack_weight(const float* w, int32_t Co, int32_t Ci, int32_t KT, float* packed, void* stream) {
     if (!w || !packed) return fail(DSD_ERR_INVALID, "dsf_pack_weight: null argument");
     if (Co < 1 || Ci < 8 || (Ci % 8) || KT < 1 || KT > 2 * kFsHalo + 1 || !(KT & 1))
         return fail(DSD_ERR_INVALID, "dsf_pack_weight: need Co >= 1, Ci a multiple of 8, odd kernel <= %d (got %d, %d, %d)", 2 * kFsHalo + 1, Co, Ci, KT);
-    const int mt = (Co + 255) / 256;
+    const int nmb = fs_nmb(Co);
+    const int mt = (Co + 128 * nmb - 1) / (128 * nmb);
     PackParams p{};
     p.src = w; p.dst = packed;
-    p.nw = mt * 4; p.nkc = Ci / 8; p.nmb = 2; p.ntap = KT;
+    p.nw = mt * 4; p.nkc = Ci / 8; p.nmb = nmb; p.ntap = KT;
     p.split = 0; p.hi_base = 0;
     p.rows_valid = Co; p.cols_valid = Ci;
     p.row_stride = Ci * KT; p.col_stride = KT;
@@ -54,14 +60,17 @@ static int fs_conv_launch(const float* in, const float* wpacked, const float* bi
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_fs_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_fs_conv<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
         attr_done = true;
     }
     FsConvParams p{};
     p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.keep = keep;
     p.Ci = Ci; p.Co = Co; p.KT = KT; p.dil = dil; p.pad = dil * (KT - 1) / 2; p.T = T; p.TS = fs_ts(T);
     p.scale = scale; p.act = act;
-    const dim3 grid((unsigned)(p.TS / 32), (unsigned)B, (unsigned)((Co + 255) / 256));
-    hipLaunchKernelGGL((k_fs_conv<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
+    const int nmb = fs_nmb(Co);
+    const dim3 grid((unsigned)(p.TS / 32), (unsigned)B, (unsigned)((Co + 128 * nmb - 1) / (128 * nmb)));
+    if (nmb == 4) hipLaunchKernelGGL((k_fs_conv<4>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_fs_conv<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

@@ -50,9 +50,11 @@ struct FsTapB {             // B-operand functor of GemmPipe: chunk kc = ci8 * K
     }
 };
 
-// out rows [256 mtile, 256 mtile + 256) x 32 frames per workgroup: 4 waves x 2 row blocks of 32
+// out rows [128 NMB mtile, 128 NMB (mtile + 1)) x 32 frames per workgroup: 4 waves x NMB row blocks of 32.  NMB = 4 (wide layers,
+// Co >= 512): 16 MFMAs per 4 weight loads + 4 LDS reads like the denoiser's layer kernel, and the input slab is staged once per
+// 512 output rows; NMB = 2 keeps two workgroups per CU for the narrow ones.
 template <int NMB>
-__global__ __launch_bounds__(kThreads, 2) void k_fs_conv(const FsConvParams p) {
+__global__ __launch_bounds__(kThreads, NMB == 4 ? 1 : 2) void k_fs_conv(const FsConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [kFsSlab][kFsLD]
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -37,6 +37,7 @@ def test_fs2_header_symbols_bound_and_exported():
         assert hasattr(lib, name), name
     assert lib.dsf_padded_frames(33) == 64
     assert lib.dsf_packed_floats(256, 256, 9) == (4 * 32 * 9 * 2 * 64 + 8192) * 4
+    assert lib.dsf_packed_floats(1024, 256, 9) == (4 * 4 * 32 * 9 * 2 * 64 + 8192) * 4
     assert lib.dsf_packed_floats(80, 250, 1) == -1                      # input channels must be a multiple of 8
     assert lib.dsf_conv1d(None, None, None, None, 1, 8, 8, 1, 1, 1.0, 0, None, None, None) == -1      # rejected before any HIP call
     assert b'dsf_conv1d' in lib.dsd_last_error()
