@@ -21,7 +21,8 @@ SYMBOLS = [
 # every symbol include/dsf.h declares (the FastSpeech2 conditioner ops)
 SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf_conv1d', 'dsf_layer_norm', 'dsf_attention',
                'dsf_to_channel_major', 'dsf_from_channel_major', 'dsf_p_sample', 'dsf_denorm_spec',
-               'dsf_conv1d_dilated', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad']
+               'dsf_conv1d_dilated', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad',
+               'dsf_train_add_step', 'dsf_train_rowsum', 'dsf_train_gate', 'dsf_train_gate_bwd', 'dsf_train_res_skip', 'dsf_train_res_skip_bwd']
 
 _fp = C.POINTER(C.c_float)
 _fpp = C.POINTER(C.c_void_p)
@@ -114,6 +115,12 @@ def load():
     lib.dsf_wgrad_workspace_floats.restype = i64
     lib.dsf_conv1d_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.dsf_bias_grad.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    lib.dsf_train_add_step.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    lib.dsf_train_rowsum.argtypes = [vp, vp, i32, i32, vp]
+    lib.dsf_train_gate.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.dsf_train_gate_bwd.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    lib.dsf_train_res_skip.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.dsf_train_res_skip_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('dsd_abi_version',):

@@ -178,3 +178,60 @@ extern "C" int dsf_bias_grad(const float* dy, float* db, int32_t B, int32_t C, i
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }
+
+static inline dim3 ew_grid(size_t n4) { return dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 16384)); }
+
+extern "C" int dsf_train_add_step(const float* x, const float* step, float* y, int32_t B, int32_t C, int32_t T, void* stream) {
+    if (!x || !step || !y || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_train_add_step: bad argument");
+    const int TS = fs_ts(T);
+    const size_t n4 = (size_t)B * C * TS / 4;
+    hipLaunchKernelGGL(k_tr_add_step, ew_grid(n4), dim3(256), 0, (hipStream_t)stream, (const float4*)x, step, (float4*)y, C, T, TS, n4);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_train_rowsum(const float* g, float* out, int32_t rows, int32_t T, void* stream) {
+    if (!g || !out || rows < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_train_rowsum: bad argument");
+    hipLaunchKernelGGL(k_tr_rowsum, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, g, out, T, fs_ts(T));
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_train_gate(const float* a, float* g, int32_t B, int32_t C, int32_t T, void* stream) {
+    if (!a || !g || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_train_gate: bad argument");
+    const int TS = fs_ts(T);
+    const size_t n4 = (size_t)B * C * TS / 4;
+    hipLaunchKernelGGL(k_tr_gate, ew_grid(n4), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (float4*)g, C, T, TS, n4);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_train_gate_bwd(const float* a, const float* dg, float* da, int32_t B, int32_t C, int32_t T, void* stream) {
+    if (!a || !dg || !da || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_train_gate_bwd: bad argument");
+    const int TS = fs_ts(T);
+    const size_t n4 = (size_t)B * C * TS / 4;
+    hipLaunchKernelGGL(k_tr_gate_bwd, ew_grid(n4), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)dg, (float4*)da, C, T, TS, n4);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_train_res_skip(const float* x, const float* y, const float* skip, float* x_out, float* skip_out, int32_t B, int32_t C, int32_t T,
+                                  void* stream) {
+    if (!x || !y || !x_out || !skip_out || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_train_res_skip: bad argument");
+    const int TS = fs_ts(T);
+    const size_t n4 = (size_t)B * C * TS / 4;
+    hipLaunchKernelGGL(k_tr_res_skip, ew_grid(n4), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)y, (const float4*)skip,
+                       (float4*)x_out, (float4*)skip_out, C, T, TS, n4);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_train_res_skip_bwd(const float* dx_out, const float* dskip_out, float* dx, float* dy, int32_t B, int32_t C, int32_t T, void* stream) {
+    if (!dx_out || !dskip_out || !dx || !dy || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_train_res_skip_bwd: bad argument");
+    const int TS = fs_ts(T);
+    const size_t n4 = (size_t)B * C * TS / 4;
+    hipLaunchKernelGGL(k_tr_res_skip_bwd, ew_grid(n4), dim3(256), 0, (hipStream_t)stream, (const float4*)dx_out, (const float4*)dskip_out, (float4*)dx,
+                       (float4*)dy, C, T, TS, n4);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}

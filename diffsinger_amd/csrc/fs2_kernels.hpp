@@ -413,6 +413,106 @@ __global__ void k_fs_bias_grad(const float* __restrict__ dy, float* __restrict__
     if (lane == 0) db[c] = (accumulate ? db[c] : 0.f) + s;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// element-wise pieces of ResidualBlock.forward (usr/diff/net.py:66-78) for the training path, forward and backward, on
+// channel-major [B][C][TS] tensors (float4 along the frame axis; frames >= T are written as zero: the zero-tail invariant)
+// ------------------------------------------------------------------------------------------------------------
+// y = x + step[b][c] (net.py:69: `x + diffusion_step`), zero tail
+__global__ void k_tr_add_step(const float4* __restrict__ x, const float* __restrict__ step, float4* __restrict__ y, int C, int T, int TS, size_t n4) {
+    const int q = TS / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / q;                       // b * C + c
+        const int t = (int)(i - row * q) * 4;
+        const float d = step[row];
+        float4 v = x[i];
+        v.x = (t + 0 < T) ? v.x + d : 0.f; v.y = (t + 1 < T) ? v.y + d : 0.f; v.z = (t + 2 < T) ? v.z + d : 0.f; v.w = (t + 3 < T) ? v.w + d : 0.f;
+        y[i] = v;
+    }
+}
+// out[row] = sum_{t < T} g[row][t]  (gradient of the broadcast step projection); one wave per row, fixed order
+__global__ void k_tr_rowsum(const float* __restrict__ g, float* __restrict__ out, int T, int TS) {
+    const size_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    float s = 0.f;
+    for (int t = lane; t < T; t += 64) s += g[row * TS + t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[row] = s;
+}
+// g = sigmoid(a[:, :C]) * tanh(a[:, C:]) (net.py:73-74).  a [B][2C][TS] -> g [B][C][TS]
+__global__ void k_tr_gate(const float4* __restrict__ a, float4* __restrict__ g, int C, int T, int TS, size_t n4) {
+    const int q = TS / 4;
+    const size_t per_b = (size_t)C * q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per_b, r = i - b * per_b;
+        const int t = (int)(r % q) * 4;
+        const float4 va = a[b * 2 * per_b + r], vf = a[b * 2 * per_b + per_b + r];
+        float4 o;
+        o.x = (t + 0 < T) ? (1.f / (1.f + expf(-va.x))) * tanhf(vf.x) : 0.f;
+        o.y = (t + 1 < T) ? (1.f / (1.f + expf(-va.y))) * tanhf(vf.y) : 0.f;
+        o.z = (t + 2 < T) ? (1.f / (1.f + expf(-va.z))) * tanhf(vf.z) : 0.f;
+        o.w = (t + 3 < T) ? (1.f / (1.f + expf(-va.w))) * tanhf(vf.w) : 0.f;
+        g[i] = o;
+    }
+}
+// da[:, :C] = dg * tanh(f) * s (1 - s), da[:, C:] = dg * s * (1 - tanh(f)^2), s = sigmoid(gate)
+__global__ void k_tr_gate_bwd(const float4* __restrict__ a, const float4* __restrict__ dg, float4* __restrict__ da, int C, int T, int TS, size_t n4) {
+    const int q = TS / 4;
+    const size_t per_b = (size_t)C * q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per_b, r = i - b * per_b;
+        const int t = (int)(r % q) * 4;
+        const float4 va = a[b * 2 * per_b + r], vf = a[b * 2 * per_b + per_b + r], d = dg[i];
+        const float av[4] = {va.x, va.y, va.z, va.w}, fv[4] = {vf.x, vf.y, vf.z, vf.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        float oa[4], of[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sg = 1.f / (1.f + expf(-av[e])), th = tanhf(fv[e]);
+            const bool ok = t + e < T;
+            oa[e] = ok ? dv[e] * th * (sg * (1.f - sg)) : 0.f;
+            of[e] = ok ? dv[e] * sg * (1.f - th * th) : 0.f;
+        }
+        da[b * 2 * per_b + r] = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        da[b * 2 * per_b + per_b + r] = make_float4(of[0], of[1], of[2], of[3]);
+    }
+}
+// x' = (x + y[:, :C]) / sqrt(2), skip' = skip + y[:, C:] (net.py:76-78, :121-126); skip may be nullptr (first layer)
+__global__ void k_tr_res_skip(const float4* __restrict__ x, const float4* __restrict__ y, const float4* __restrict__ skip, float4* __restrict__ xo,
+                              float4* __restrict__ so, int C, int T, int TS, size_t n4) {
+    const int q = TS / 4;
+    const size_t per_b = (size_t)C * q;
+    const float s2 = 1.41421356237309504880f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per_b, r = i - b * per_b;
+        const int t = (int)(r % q) * 4;
+        const float4 vx = x[i], vr = y[b * 2 * per_b + r], vs = y[b * 2 * per_b + per_b + r];
+        float4 o, k = skip ? skip[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        o.x = (t + 0 < T) ? (vx.x + vr.x) / s2 : 0.f; o.y = (t + 1 < T) ? (vx.y + vr.y) / s2 : 0.f;
+        o.z = (t + 2 < T) ? (vx.z + vr.z) / s2 : 0.f; o.w = (t + 3 < T) ? (vx.w + vr.w) / s2 : 0.f;
+        k.x = (t + 0 < T) ? k.x + vs.x : 0.f; k.y = (t + 1 < T) ? k.y + vs.y : 0.f; k.z = (t + 2 < T) ? k.z + vs.z : 0.f; k.w = (t + 3 < T) ? k.w + vs.w : 0.f;
+        xo[i] = o;
+        so[i] = k;
+    }
+}
+// backward: dx = dxo / sqrt(2); dy[:, :C] = dxo / sqrt(2); dy[:, C:] = dso   (dskip_in = dso is passed through by the caller)
+__global__ void k_tr_res_skip_bwd(const float4* __restrict__ dxo, const float4* __restrict__ dso, float4* __restrict__ dx, float4* __restrict__ dy,
+                                  int C, int T, int TS, size_t n4) {
+    const int q = TS / 4;
+    const size_t per_b = (size_t)C * q;
+    const float s2 = 1.41421356237309504880f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per_b, r = i - b * per_b;
+        const int t = (int)(r % q) * 4;
+        const float4 d = dxo[i], ds = dso[i];
+        float4 o, k;
+        o.x = (t + 0 < T) ? d.x / s2 : 0.f; o.y = (t + 1 < T) ? d.y / s2 : 0.f; o.z = (t + 2 < T) ? d.z / s2 : 0.f; o.w = (t + 3 < T) ? d.w / s2 : 0.f;
+        k.x = (t + 0 < T) ? ds.x : 0.f; k.y = (t + 1 < T) ? ds.y : 0.f; k.z = (t + 2 < T) ? ds.z : 0.f; k.w = (t + 3 < T) ? ds.w : 0.f;
+        dx[i] = o;
+        dy[b * 2 * per_b + r] = o;
+        dy[b * 2 * per_b + per_b + r] = k;
+    }
+}
+
 // internal [B][C][TS] -> [B][T][C] (the reference's layout), 32 x 32 tiles through LDS
 __global__ void k_fs_from_cm(const float* __restrict__ in, float* __restrict__ out, int C, int T, int TS) {
     __shared__ float tile[32][33];

@@ -4,8 +4,9 @@
 What is native: every Conv1d / Linear of DiffNet (usr/diff/net.py:91-105) in the forward pass, its data gradient (the same
 MFMA convolution kernel with the flipped, transposed weight) and its weight / bias gradients (`dsf_conv1d_wgrad`: a split-K
 contraction over frames on fp32 MFMA, reduced in a fixed order -> deterministic) - > 99 % of the FLOPs of a training step.
-What is torch: the element-wise glue between them (x + step, sigmoid * tanh, residual / skip sums, ReLU, the L1 loss) as
-ordinary autograd ops on the device, the step-embedding MLP on [B, C] vectors, and the optimiser.  DDP works unchanged on top
+The element-wise pieces of the residual block (x + step, sigmoid * tanh gate, residual / skip update) are fused HIP kernels
+with hand-written backward too (`dsf_train_*`).  What is left to torch autograd: the sum of the two convolution outputs, the
+two ReLUs and the 1/sqrt(L) scale of the head, the step-embedding MLP on [B, C] vectors, the L1 loss, and the optimiser.  DDP works unchanged on top
 (gradients are ordinary `.grad` tensors; the all-reduce is torch.distributed's, RCCL on ROCm).
 
 This is the functional slice of row f3, not yet the fused one: activations live channel-major [B][C][TS] (TS = T up to 32, zero
@@ -90,6 +91,85 @@ class _Conv1dCM(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+def _ew(name, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args), name)
+
+
+class _AddStep(torch.autograd.Function):
+    """y = x + step[b][c] with the zero tail (usr/diff/net.py:69)."""
+
+    @staticmethod
+    def forward(ctx, x, step, T):
+        x, step = x.contiguous(), step.contiguous()
+        B, C, TS = x.shape
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _ew('dsf_train_add_step', x.data_ptr(), step.data_ptr(), y.data_ptr(), B, C, T, _stream(x.device))
+        ctx.T = T
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, C, TS = dy.shape
+        dstep = torch.empty(B, C, device=dy.device, dtype=torch.float32)
+        with torch.cuda.device(dy.device):
+            _ew('dsf_train_rowsum', dy.data_ptr(), dstep.data_ptr(), B * C, ctx.T, _stream(dy.device))
+        return dy, dstep, None
+
+
+class _Gate(torch.autograd.Function):
+    """g = sigmoid(a[:, :C]) * tanh(a[:, C:]) (net.py:73-74)."""
+
+    @staticmethod
+    def forward(ctx, a, T):
+        a = a.contiguous()
+        B, C2, TS = a.shape
+        g = torch.empty(B, C2 // 2, TS, device=a.device, dtype=torch.float32)
+        with torch.cuda.device(a.device):
+            _ew('dsf_train_gate', a.data_ptr(), g.data_ptr(), B, C2 // 2, T, _stream(a.device))
+        ctx.save_for_backward(a)
+        ctx.T = T
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        a, = ctx.saved_tensors
+        dg = dg.contiguous()
+        B, C2, TS = a.shape
+        da = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _ew('dsf_train_gate_bwd', a.data_ptr(), dg.data_ptr(), da.data_ptr(), B, C2 // 2, ctx.T, _stream(a.device))
+        return da, None
+
+
+class _ResSkip(torch.autograd.Function):
+    """x' = (x + y[:, :C]) / sqrt(2), skip' = skip + y[:, C:] (net.py:76-78; the skip list of :121-126 summed on the fly)."""
+
+    @staticmethod
+    def forward(ctx, x, y, skip, T):
+        x, y = x.contiguous(), y.contiguous()
+        B, C, TS = x.shape
+        xo, so = torch.empty_like(x), torch.empty_like(x)
+        sk = skip.contiguous() if skip is not None else None
+        with torch.cuda.device(x.device):
+            _ew('dsf_train_res_skip', x.data_ptr(), y.data_ptr(), sk.data_ptr() if sk is not None else None, xo.data_ptr(), so.data_ptr(), B, C, T,
+                _stream(x.device))
+        ctx.T, ctx.has_skip = T, skip is not None
+        return xo, so
+
+    @staticmethod
+    def backward(ctx, dxo, dso):
+        dxo, dso = dxo.contiguous(), dso.contiguous()
+        B, C, TS = dxo.shape
+        dx = torch.empty_like(dxo)
+        dy = torch.empty(B, 2 * C, TS, device=dxo.device, dtype=torch.float32)
+        with torch.cuda.device(dxo.device):
+            _ew('dsf_train_res_skip_bwd', dxo.data_ptr(), dso.data_ptr(), dx.data_ptr(), dy.data_ptr(), B, C, ctx.T, _stream(dxo.device))
+        return dx, dy, (dso if ctx.has_skip else None), None
+
+
 class ConvCache:
     """Per-layer cache of the packed forward / transposed weights and the split-K workspace."""
 
@@ -124,26 +204,23 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
             c = caches[name] = ConvCache()
         return c(x, mod.weight, mod.bias, T, dil)
 
-    valid = (torch.arange(TS, device=spec.device) < T).float()[None, None, :]
     pad = (0, TS - T)
     xm = F.pad(spec[:, 0], pad)                                     # [B][M][TS], zero tail
     cm = F.pad(cond, pad).contiguous()                              # [B][H][TS]
-    x = F.relu(conv('in', xm, net.input_projection)) * valid        # :116-118 (the tail must stay zero: conv padding applies to it)
+    x = F.relu(conv('in', xm, net.input_projection))                # :116-118 (every conv output has the zero tail; relu keeps it)
     d = step_embedding(diffusion_step, net.residual_channels)       # :119
     h = F.linear(d, net.mlp[0].weight, net.mlp[0].bias)
     d = F.linear(h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)      # :120 (Mish)
     skip = None
-    C = net.residual_channels
     for l, layer in enumerate(net.residual_layers):                 # ResidualBlock.forward :66-78
-        ds = F.linear(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)[:, :, None]
-        y = (x + ds) * valid
-        y = conv(f'l{l}.dc', y, layer.dilated_conv, layer.dilation) + conv(f'l{l}.cp', cm, layer.conditioner_projection)
-        y = (torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])) * valid
-        y = conv(f'l{l}.op', y, layer.output_projection)
-        x = ((x + y[:, :C]) / math.sqrt(2.0)) * valid
-        skip = y[:, C:] if skip is None else skip + y[:, C:]
-    x = (skip / math.sqrt(len(net.residual_layers))) * valid        # :126
-    x = F.relu(conv('sp', x, net.skip_projection)) * valid          # :127-128
+        ds = F.linear(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)
+        y = _AddStep.apply(x, ds, T)
+        a = conv(f'l{l}.dc', y, layer.dilated_conv, layer.dilation) + conv(f'l{l}.cp', cm, layer.conditioner_projection)
+        g = _Gate.apply(a, T)
+        y = conv(f'l{l}.op', g, layer.output_projection)
+        x, skip = _ResSkip.apply(x, y, skip, T)
+    x = skip / math.sqrt(len(net.residual_layers))                  # :126
+    x = F.relu(conv('sp', x, net.skip_projection))                  # :127-128
     x = conv('out', x, net.output_projection)                       # :129
     return x[:, None, :, :T]
 

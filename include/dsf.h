@@ -72,6 +72,19 @@ int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, float* db /* [C
                      int32_t Ci, int32_t Co, int32_t K, int32_t dil, int32_t T, int32_t accumulate, void* stream);
 int dsf_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, int32_t accumulate, void* stream);
 
+/* Element-wise pieces of ResidualBlock.forward (usr/diff/net.py:66-78) of the training path, forward and backward, on channel-major
+ * [B][C][TS] tensors (frames >= T are written as zero):
+ *   add_step      y = x + step[b][c]                                            (:69)   backward: dsf_train_rowsum over the frames
+ *   gate          g = sigmoid(a[:, :C]) * tanh(a[:, C:]),  a [B][2C][TS]          (:73-74) backward: da from dg and the saved a
+ *   res_skip      x' = (x + y[:, :C]) / sqrt(2),  skip' = skip + y[:, C:]         (:76-78, :121-126; skip NULL = first layer)
+ *                 backward: dx = dx'/sqrt(2), dy = [dx'/sqrt(2) ; dskip'] */
+int dsf_train_add_step(const float* x, const float* step, float* y, int32_t B, int32_t C, int32_t T, void* stream);
+int dsf_train_rowsum(const float* g, float* out, int32_t rows, int32_t T, void* stream);
+int dsf_train_gate(const float* a, float* g, int32_t B, int32_t C, int32_t T, void* stream);
+int dsf_train_gate_bwd(const float* a, const float* dg, float* da, int32_t B, int32_t C, int32_t T, void* stream);
+int dsf_train_res_skip(const float* x, const float* y, const float* skip, float* x_out, float* skip_out, int32_t B, int32_t C, int32_t T, void* stream);
+int dsf_train_res_skip_bwd(const float* dx_out, const float* dskip_out, float* dx, float* dy, int32_t B, int32_t C, int32_t T, void* stream);
+
 /* Sampler pieces for a denoise_fn that is not the fused DiffNet (the `FFT` candidate decoder, usr/diff/candidate_decoder.py:35-96;
  * SURVEY section 8 row f4): one p_sample update (usr/diff/shallow_diffusion_tts.py:134-166: x0 = a x - b eps, clamp, posterior
  * mean, + sigma z) in place on n contiguous floats with the fp32 table entries of step t passed by the host, and denorm_spec

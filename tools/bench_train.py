@@ -17,7 +17,30 @@ from diffsinger_amd.synth import presets
 F_FWD = 26_427_392          # GEMM FLOP / frame of one DiffNet forward (the conditioner projection is NOT hoisted in training)
 
 
-def run(B, T, reps, torch_conv=False):
+def reference_style_forward(net, spec, t, cond):
+    """What the reference's DiffNet.forward does (usr/diff/net.py:107-130), written with plain torch ops on the GPU: the timing
+    baseline "PyTorch-ROCm eager" (MIOpen / rocBLAS convolutions, one ATen kernel per element-wise op, torch.stack of the skips)."""
+    x = F.relu(F.conv1d(spec[:, 0], net.input_projection.weight, net.input_projection.bias))
+    d = train.step_embedding(t, net.residual_channels)
+    h = F.linear(d, net.mlp[0].weight, net.mlp[0].bias)
+    d = F.linear(h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)
+    skips = []
+    for layer in net.residual_layers:
+        ds = F.linear(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias).unsqueeze(-1)
+        c = F.conv1d(cond, layer.conditioner_projection.weight, layer.conditioner_projection.bias)
+        y = F.conv1d(x + ds, layer.dilated_conv.weight, layer.dilated_conv.bias, padding=layer.dilation, dilation=layer.dilation) + c
+        gate, filt = torch.chunk(y, 2, dim=1)
+        y = torch.sigmoid(gate) * torch.tanh(filt)
+        y = F.conv1d(y, layer.output_projection.weight, layer.output_projection.bias)
+        res, sk = torch.chunk(y, 2, dim=1)
+        x = (x + res) / (2.0 ** 0.5)
+        skips.append(sk)
+    x = torch.sum(torch.stack(skips), dim=0) / (len(net.residual_layers) ** 0.5)
+    x = F.relu(F.conv1d(x, net.skip_projection.weight, net.skip_projection.bias))
+    return F.conv1d(x, net.output_projection.weight, net.output_projection.bias)[:, None]
+
+
+def run(B, T, reps, torch_conv=False, reference_style=False):
     pre = presets()['lj_ds_beta6']
     hparams.clear()
     diffsinger_amd.use_preset('lj_ds_beta6')
@@ -38,9 +61,16 @@ def run(B, T, reps, torch_conv=False):
         cond = torch.randn(B, T, 256, device='cuda', generator=g).transpose(1, 2)
         t = torch.randint(0, 100, (B,), device='cuda', generator=g)
 
+        noise = torch.randn(B, 1, 80, T, device='cuda', generator=g)
+
         def step():
             net.zero_grad(set_to_none=True)
-            loss = gd.p_losses(x0, t, cond)
+            if reference_style:
+                shp = (B, 1, 1, 1)
+                xn = gd.sqrt_alphas_cumprod.gather(-1, t).reshape(shp) * x0 + gd.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(shp) * noise
+                loss = (noise - reference_style_forward(net, xn, t, cond.contiguous())).abs().mean()
+            else:
+                loss = gd.p_losses(x0, t, cond, noise=noise)
             loss.backward()
             return loss
         step(); step()
@@ -53,7 +83,9 @@ def run(B, T, reps, torch_conv=False):
     finally:
         train.ConvCache.__call__ = orig
     frames = B * T
-    print(json.dumps({'impl': 'torch conv1d (MIOpen) in the same graph' if torch_conv else 'HIP operators (dsf_conv1d_dilated / dsf_conv1d_wgrad)',
+    impl = ('reference-style PyTorch-ROCm eager graph (MIOpen convolutions, ATen element-wise ops)' if reference_style else
+            'torch conv1d (MIOpen) inside the HIP graph (fused glue kept)' if torch_conv else 'HIP operators (dsf_conv1d_dilated / dsf_conv1d_wgrad / dsf_train_*)')
+    print(json.dumps({'impl': impl,
                       'B': B, 'T': T, 'ms_per_step_fwd_bwd': sec * 1e3, 'frames_per_s': frames / sec,
                       'tflops_gemm': 3 * F_FWD * frames / sec / 1e12, 'loss': float(loss)}), flush=True)
     del gd, net
@@ -63,5 +95,6 @@ def run(B, T, reps, torch_conv=False):
 if __name__ == '__main__':
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     for B, T in ((8, 1024), (48, 512)):
-        run(B, T, reps, torch_conv=False)
+        run(B, T, reps)
         run(B, T, reps, torch_conv=True)
+        run(B, T, reps, reference_style=True)
