@@ -143,7 +143,10 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
  * whole utterances.  mode 0: one kernel per residual layer + head (a cached hipGraph, or eager launches, see above).  Both
  * give bit-identical results.  dsd_get_loop_mode: 1 if the prepared batch would take the persistent path.
  * dsd_loop_timeouts: synchronises the stream and returns the sticky timeout word of the persistent loop (0 = every
- * inter-workgroup wait was satisfied; nonzero = a wait hit its spin bound and the results are invalid). */
+ * inter-workgroup wait was satisfied; nonzero = a wait hit its spin bound; the affected tiles of x are then NaN).
+ * The persistent kernel needs all its workgroups resident at once (<= one per CU): run ONE such loop at a time per device - two
+ * handles sampling concurrently on different streams of the same GPU must use mode 0 (one handle per device, as the reference's
+ * DP / DDP runners do, is always safe). */
 int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
 int dsd_get_loop_mode(dsd_handle* h);
 int dsd_loop_timeouts(dsd_handle* h, void* stream);
