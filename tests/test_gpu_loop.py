@@ -70,3 +70,42 @@ def test_persistent_loop_full_width(B, T, K):
         assert eng.loop_timeouts() == 0
     np.testing.assert_array_equal(outs[0], outs[1])
     assert np.isfinite(outs[0]).all()
+
+
+def test_persistent_loop_under_concurrent_load():
+    """Hand-offs under UNEVEN load: a side stream keeps the chip busy with unrelated GEMMs (delays workgroup start-up, skews the
+    tiles, thrashes the L2s) while the persistent loop runs - results must stay bit-identical and no wait may time out."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from diffsinger_amd.synth import presets
+    pre = presets()['opencpop_ds60_rel']
+    hparams.clear()
+    diffsinger_amd.use_preset('opencpop_ds60_rel')
+    torch.manual_seed(4)
+    net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+    torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+    B, T, K = 6, 1024, 10
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=100, K_step=K, loss_type='l1', spec_min=pre['spec_min'],
+                                          spec_max=pre['spec_max']).cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(6)
+    cond = torch.randn(B, T, 256, device='cuda', generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, device='cuda', generator=g)
+    noise = torch.randn(K, B, 1, 80, T, device='cuda', generator=g)
+    eng = gd._engine(cond)
+    eng.set_loop_mode(1)
+    with torch.no_grad():
+        ref = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).cpu().numpy()
+    assert eng.loop_mode() == 1 and eng.loop_timeouts() == 0
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device='cuda')
+    big = torch.randn(64 * 1024 * 1024, device='cuda')
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                a = (a @ a).clamp_(-1, 1)          # MFMA-heavy
+                big.mul_(1.0001)                   # streams 256 MB through the L2s / HBM
+        with torch.no_grad():
+            out = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).cpu().numpy()
+        assert eng.loop_timeouts() == 0, 'an inter-workgroup wait timed out under load'
+        np.testing.assert_array_equal(out, ref, err_msg=f'repetition {rep}')
+    torch.cuda.synchronize()
