@@ -105,8 +105,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
     inproj_to_xreg();
 
     // publish this tile's first / last 8 columns of x (xreg) as the halo of phase `phase`: write-through stores, EVERY storing
-    // wave drained, barrier, ONE relaxed agent-scope flag store.  Called as soon as x is known (behind the residual half of the
-    // output projection / behind the input projection), so the hop overlaps the skip half / the head of the neighbours.
+    // wave drained, barrier, ONE relaxed agent-scope flag store.  Called as soon as x is known (behind the residual transpose of a
+    // layer / behind the input projection); the skip-sum update, the next phase's weight prefetch and own-column staging
+    // overlap the hop.
     auto publish = [&](unsigned phase) {
         float* hb = p.halo + ((size_t)(phase & 1) * p.ntiles_total + tile) * (2 * kC * 8);
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             GemmPipe<4, 1, LD, 256, 6, decltype(bof1)> pipe1(p.w1p + ((size_t)l * 4 + w) * (96 * 256), lane, 96, bof1);
             pipe1.template start_a<0, 5>();
 
-            // (d) both neighbours have published phase ph?  (they did so in the middle of their previous phase: normally no wait)
+            // (d) both neighbours have published phase ph?  (they did so at the end of their previous phase: the wait is the skew
+            //     between neighbouring workgroups, ~2 k cycles measured)
             if (w == 0 && lane < 2) {
                 const bool have = lane ? has_right : has_left;
                 if (have) {
