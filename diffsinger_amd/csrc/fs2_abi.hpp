@@ -100,7 +100,7 @@ extern "C" int dsf_attention(const float* qkv, const uint8_t* key_pad, float* ou
         (void)hipFuncSetAttribute((const void*)k_fs_attn<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fs_attn_lds_bytes<128>());
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_fs_attn<128>), dim3((unsigned)(p.TS / 32), (unsigned)heads, (unsigned)B), dim3(64), fs_attn_lds_bytes<128>(),
+    hipLaunchKernelGGL((k_fs_attn<128>), dim3((unsigned)(p.TS / 32), (unsigned)heads, (unsigned)B), dim3(kThreads), fs_attn_lds_bytes<128>(),
                        (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return DSD_OK;

@@ -9,8 +9,8 @@
 //               tts_modules.py:84-97, :198-209), mel_out (modules/fastspeech/fs2.py:233-237)
 //   k_fs_ln     LayerNorm over the channel axis (EncSALayer layer_norm1/2, FFTBlocks.layer_norm: eps 1e-5; predictor LayerNorm
 //               (dim=1): eps 1e-12, tts_modules.py:39-56), optionally times the padding mask
-//   k_fs_attn   softmax(q k^T + key_padding_mask) v per head (F.multi_head_attention_forward), flash-style: one wave per
-//               (utterance, head, 32-query tile), online softmax, S and P V on fp32 MFMA
+//   k_fs_attn   softmax(q k^T + key_padding_mask) v per head (F.multi_head_attention_forward), flash-style: one workgroup per
+//               (utterance, head, 32-query tile), its 4 waves split the keys; online softmax, S and P V on fp32 MFMA
 //   k_fs_from_cm  internal channel-major [B][C][TS] -> the reference's [B,T,C]
 //
 // Activations live channel-major [B][C][TS] (frame axis contiguous, TS = T rounded up to 32, ZERO in [T,TS)): exactly the
@@ -175,52 +175,90 @@ struct FsAttnParams {
     float scale;                    // head_dim ** -0.5, applied to q like the reference (q * scaling before q k^T)
 };
 
+// Workgroup = (32-query tile, head, utterance), 4 waves; wave w takes the key tiles w, w+4, ... with its own online-softmax state
+// and the four partial results are merged through LDS at the end.  Per key tile and wave:
+//   S[tk][tq] = sum_d k[d][tk] q[d][tq]   - q lives in registers for the whole kernel (it is the B operand: lane (tq, h) needs
+//               q[8c+4h+s][tq]), k goes global -> register directly (every element feeds exactly one MFMA: no reuse to stage for)
+//   P = exp(S - m) stays in registers too: the accumulator fragment a lane holds (tk = frag_row(r, h)) is exactly the B fragment
+//               the P V product wants from it (tk = 8c + 4h + s with r = 4c + s)
+//   O[d][tq] += sum_tk v[d][tk] P[tk][tq] - v is the A operand read ACROSS rows: staged in this wave's LDS slice [128][33]
+__device__ __forceinline__ float fs_ldg32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float4 fs_ldg128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    const f32x4_ f = __builtin_bit_cast(f32x4_, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
 template <int HD>
-__global__ __launch_bounds__(64) void k_fs_attn(const FsAttnParams p) {
-    constexpr int NMB = HD / 32;
+__global__ __launch_bounds__(kThreads, 2) void k_fs_attn(const FsAttnParams p) {
+    constexpr int NMB = HD / 32, LDV = 33;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* qt = smem;                       // [HD][32]
-    float* kt = qt + HD * 32;               // [HD][32]
-    float* vt = kt + HD * 32;               // [HD][33]
-    float* pt = vt + HD * 33;               // [32 keys][32 queries]
-    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* vt = smem + w * (HD * LDV);                  // this wave's V tile / merge slice
+    float* ml = smem + 4 * (HD * LDV);                  // [4 waves][32 queries][2] running max and sum
     const int tq0 = blockIdx.x * 32, hh = blockIdx.y, b = blockIdx.z;
     const float* qb = p.qkv + ((size_t)b * 3 * p.C + hh * HD) * p.TS;
     const float* kb = qb + (size_t)p.C * p.TS;
     const float* vb = kb + (size_t)p.C * p.TS;
-    for (int idx = lane; idx < HD * 8; idx += 64) {
-        const int row = idx >> 3, g = idx & 7;
-        float4 v = *reinterpret_cast<const float4*>(qb + (size_t)row * p.TS + tq0 + 4 * g);
-        v.x *= p.scale; v.y *= p.scale; v.z *= p.scale; v.w *= p.scale;
-        *reinterpret_cast<float4*>(qt + row * 32 + 4 * g) = v;
-    }
+    // buffer loads: wave-uniform descriptor + ONE per-lane offset + a scalar row offset per load - no per-load 64-bit address math
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qb), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kb), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, 0x7ffffff0, 0x00020000);
+    const int row_b = p.TS * 4;                                     // bytes per channel row
+    const int lk = (4 * h * p.TS + j) * 4;                          // lane part of a q / k element address: row 4h, column j
+    const int lv = ((lane >> 3) * p.TS + 4 * (lane & 7)) * 4;       // lane part of a v float4 address: row lane/8, column 4 (lane%8)
+    float qr[HD / 2];                                   // q[8c + 4h + s][tq0 + j] * scale, index 4c + s
+#pragma unroll
+    for (int i = 0; i < HD / 2; ++i) qr[i] = fs_ldg32(rq, lk + tq0 * 4, (8 * (i >> 2) + (i & 3)) * row_b) * p.scale;
     float m = -INFINITY, l = 0.f;
     f32x16 o[NMB];
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[mb][r] = 0.f;
-    for (int tk0 = 0; tk0 < p.T; tk0 += 32) {
-        __syncthreads();                    // previous tile's LDS reads are done
-        for (int idx = lane; idx < HD * 8; idx += 64) {
-            const int row = idx >> 3, g = idx & 7;
-            *reinterpret_cast<float4*>(kt + row * 32 + 4 * g) = *reinterpret_cast<const float4*>(kb + (size_t)row * p.TS + tk0 + 4 * g);
-            const float4 v = *reinterpret_cast<const float4*>(vb + (size_t)row * p.TS + tk0 + 4 * g);
-            float* d = vt + row * 33 + 4 * g;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-        __syncthreads();
-        // S[tk][tq] = sum_d k[d][tk] q[d][tq]
+    for (int tk0 = 32 * w; tk0 < p.T; tk0 += 128) {
+        // V tile -> registers in two halves (row idx >> 3, float4 column idx & 7): the first is requested before the S product and
+        // written to LDS behind it, the second is requested then and lands during the softmax arithmetic
+        constexpr int NV = HD / 16;
+        float4 vv[NV];
+        auto fetch_v = [&](int half) {
+#pragma unroll
+            for (int it = 0; it < NV; ++it) {
+                vv[it] = fs_ldg128(rv, lv + tk0 * 4, (half * NV + it) * 8 * row_b);
+            }
+        };
+        auto store_v = [&](int half) {
+#pragma unroll
+            for (int it = 0; it < NV; ++it) {
+                const int idx = (half * NV + it) * 64 + lane;
+                float* d = vt + (idx >> 3) * LDV + 4 * (idx & 7);
+                d[0] = vv[it].x; d[1] = vv[it].y; d[2] = vv[it].z; d[3] = vv[it].w;
+            }
+        };
+        fetch_v(0);
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll 4
-        for (int c = 0; c < HD / 8; ++c)
+        // k in groups of 16 loads (fenced: the scheduler would otherwise hoist all 64 loads and spill)
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int d = 8 * c + 4 * h + st;
-                s = mfma32(kt[d * 32 + j], qt[d * 32 + j], s);
+        for (int g16 = 0; g16 < HD / 32; ++g16) {
+            float kv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = 16 * g16 + u;
+                kv[u] = fs_ldg32(rk, lk + tk0 * 4, (8 * (i >> 2) + (i & 3)) * row_b);
             }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = mfma32(kv[u], qr[16 * g16 + u], s);
+            DSD_SB();
+        }
+        __builtin_amdgcn_wave_barrier();                // the previous tile's LDS reads of this wave are done (in-order LDS)
+        store_v(0);
+        fetch_v(1);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -235,9 +273,8 @@ __global__ __launch_bounds__(64) void k_fs_attn(const FsAttnParams p) {
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = (s[r] == -INFINITY) ? 0.f : expf(s[r] - mn);
-            ps += e;
-            pt[frag_row(r, h) * 32 + j] = e;
+            s[r] = (s[r] == -INFINITY) ? 0.f : expf(s[r] - mn);
+            ps += s[r];
         }
         l = l * alpha + ps;
         m = mn;
@@ -245,29 +282,53 @@ __global__ __launch_bounds__(64) void k_fs_attn(const FsAttnParams p) {
         for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[mb][r] *= alpha;
-        __syncthreads();
-        // O[d][tq] += sum_tk v[d][tk] P[tk][tq]
+        store_v(1);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const int tk = 8 * c + 4 * h + st;
-                const float bv = pt[tk * 32 + j];
+                const float bv = s[4 * c + st];         // P[tk][tq = j]: the very register this lane computed it in
 #pragma unroll
-                for (int mb = 0; mb < NMB; ++mb) o[mb] = mfma32(vt[(32 * mb + j) * 33 + tk], bv, o[mb]);
+                for (int mb = 0; mb < NMB; ++mb) o[mb] = mfma32(vt[(32 * mb + j) * LDV + tk], bv, o[mb]);
             }
     }
+    // merge the four waves: O = sum_w O_w exp(m_w - M) / sum_w l_w exp(m_w - M)
     const float lt = l + __shfl_xor(l, 32, 64);
-    const float inv = (lt > 0.f) ? 1.f / lt : 0.f;
-    const int t = tq0 + j;
-    float* ob = p.out + ((size_t)b * p.C + hh * HD) * p.TS + t;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ob[(size_t)(32 * mb + frag_row(r, h)) * p.TS] = (t < p.T) ? o[mb][r] * inv : 0.f;
+        for (int r = 0; r < 16; ++r) vt[(32 * mb + frag_row(r, h)) * LDV + j] = o[mb][r];
+    if (h == 0) { ml[(w * 32 + j) * 2] = m; ml[(w * 32 + j) * 2 + 1] = lt; }
+    __syncthreads();
+    float mw[4], sc[4], M = -INFINITY, L = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mw[q] = ml[(q * 32 + j) * 2]; M = fmaxf(M, mw[q]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = (mw[q] == -INFINITY) ? 0.f : expf(mw[q] - M);
+        L += ml[(q * 32 + j) * 2 + 1] * sc[q];
+    }
+    const float inv = (L > 0.f) ? 1.f / L : 0.f;
+    const int t = tq0 + j;
+    // wave w finishes the d rows [32 w, 32 w + 32) (HD = 128: one row block per wave)
+    float* ob = p.out + ((size_t)b * p.C + hh * HD) * p.TS + t;
+#pragma unroll
+    for (int mb = w; mb < NMB; mb += 4)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * mb + frag_row(r, h);
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += smem[q * (HD * LDV) + row * LDV + j] * sc[q];
+            ob[(size_t)row * p.TS] = (t < p.T) ? acc * inv : 0.f;
+        }
 }
 template <int HD>
-constexpr int fs_attn_lds_bytes() { return (2 * HD * 32 + HD * 33 + 32 * 32) * (int)sizeof(float); }
+constexpr int fs_attn_lds_bytes() { return (4 * HD * 33 + 4 * 32 * 2) * (int)sizeof(float); }
 
 // One ancestral step x_{t-1} = p_sample(x_t, eps) (usr/diff/shallow_diffusion_tts.py:134-166) for a denoiser that is not the fused
 // DiffNet (the `FFT` candidate decoder): the arithmetic of the DiffNet head epilogue as a stand-alone element-wise kernel.
