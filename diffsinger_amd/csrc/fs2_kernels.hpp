@@ -87,22 +87,29 @@ __global__ __launch_bounds__(kThreads, NMB == 4 ? 1 : 2) void k_fs_conv(const Fs
     const bool tv = t < p.T;
     float kp = 1.f;
     if (p.keep && tv) kp = p.keep[(size_t)b * p.T + t];
+    // epilogue: all the bias / residual reads are issued first (clamped row index, no branches between them), then the
+    // arithmetic, then the stores - two workgroups per CU are not enough to hide 32 dependent load -> store round trips
+    float bv[NMB][16], rv[NMB][16];
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (mt * 4 + w) * (32 * NMB) + 32 * mb + frag_row(r, h);
-            if (row >= p.Co) continue;
-            const size_t o = ((size_t)b * p.Co + row) * p.TS + t;
-            float v = acc[mb][0][r];
-            if (p.bias) v += p.bias[row];
-            v *= p.scale;
+            const int rc = (row < p.Co) ? row : 0;
+            bv[mb][r] = p.bias ? p.bias[rc] : 0.f;
+            rv[mb][r] = p.res ? p.res[((size_t)b * p.Co + rc) * p.TS + t] : 0.f;
+        }
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (mt * 4 + w) * (32 * NMB) + 32 * mb + frag_row(r, h);
+            float v = (acc[mb][0][r] + bv[mb][r]) * p.scale;
             if (p.act == FS_ACT_RELU) v = fmaxf(v, 0.f);
             else if (p.act == FS_ACT_GELU) v = v * 0.5f * (1.f + erff(v * 0.70710678118654752440f));
             else if (p.act == FS_ACT_MISH) v = v * tanhf((v > 20.f) ? v : log1pf(expf(v)));        // x * tanh(softplus(x)), usr/diff/diffusion.py:68-70
-            if (p.res) v += p.res[o];
-            v *= kp;
-            p.out[o] = tv ? v : 0.f;
+            v = (v + rv[mb][r]) * kp;
+            if (row < p.Co) p.out[((size_t)b * p.Co + row) * p.TS + t] = tv ? v : 0.f;
         }
 }
 constexpr int kFsConvLdsBytes = kFsSlab * kFsLD * (int)sizeof(float);
