@@ -13,8 +13,6 @@ reference does; stand-alone pass `fs2=` or call `inference()` with a precomputed
 from __future__ import annotations
 
 from collections import deque
-from typing import Optional
-
 import numpy as np
 import torch
 from torch import nn
@@ -223,7 +221,6 @@ class GaussianDiffusion(nn.Module):
     def _inference_generic(self, cond, *, fs2_mels, x_T, noise, q_noise, K_step, pndm_speedup, gaussian_start, mel_mask, return_x):
         """The DDPM loop (:269-270) for a denoise_fn that is not the fused DiffNet (the `FFT` candidate decoder, row f4): one
         denoiser forward per step (HIP operators) + the p_sample update and denorm as stand-alone HIP kernels (include/dsf.h)."""
-        import ctypes as C
         from . import _lib
         lib = _lib.load()
         if cond.device.type != 'cuda':

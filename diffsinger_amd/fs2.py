@@ -21,7 +21,6 @@ pitch_type 'ph', dur_loss other than 'mse', ffn_padding 'LEFT', norm 'bn' - none
 config."""
 from __future__ import annotations
 
-import ctypes as C
 import math
 from typing import Optional
 

@@ -1,8 +1,7 @@
 """Developer tool (GPU): hunt for run-to-run nondeterminism of the persistent loop on the fixture cases."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from tests import helpers as H
+import numpy as np
 from tests.test_gpu_loop import _run
 
 names = sys.argv[1:] or ['plms_opencpop_i40', 'plms_opencpop_i250', 'shallow_opencpop_k60']
