@@ -45,7 +45,15 @@ struct FsTapB {             // B-operand functor of GemmPipe: chunk kc = ci8 * K
     __device__ __forceinline__ const float* operator()(int it, int u) const {
         int kc = 6 * it + u;
         kc = (kc < n) ? kc : n - 1;
-        const int g = kc / KT, tap = kc - g * KT;
+        // chunk -> (8-channel group, tap): constant divisors for the kernel sizes the models use (a uniform branch instead of a
+        // software integer division in front of every 8 MFMAs)
+        int g;
+        if (KT == 1) g = kc;
+        else if (KT == 3) g = kc / 3;
+        else if (KT == 9) g = kc / 9;
+        else if (KT == 5) g = kc / 5;
+        else g = kc / KT;
+        const int tap = kc - g * KT;
         return base + g * (8 * kFsLD) + tap * dil;
     }
 };

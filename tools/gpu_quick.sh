@@ -1,9 +1,11 @@
-# GPU box: quick iteration loop - parity tests, layer timeline, layer sweep, short bench (no CPU baseline)
+# GPU box: quick check of the operator families outside the persistent loop - FastSpeech2 / FFT decoder / training tests + their benches
+set -x
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; T=${1:-q}
-mkdir -p $R/gpurun_out/$T; cd $R
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/$T/pytest.log
-timeout 200 python tools/layer_timeline.py 8 1024 32 > gpurun_out/$T/timeline.log 2>&1
-timeout 200 python tools/layer_sweep.py > gpurun_out/$T/sweep.log 2>&1
-timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err
-tail -3 gpurun_out/$T/pytest.log; cat gpurun_out/$T/timeline.log gpurun_out/$T/sweep.log; cat gpurun_out/$T/bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'], d['roofline']['avg_launch_ms'], d.get('parity'))"
+R=$GRAFT_REPO_ROOT; TAG=${1:-q}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+timeout 600 python -m pytest tests/test_gpu_fs2.py tests/test_fft_decoder.py tests/test_gpu_train.py -m gpu -q 2>&1 | tail -4 > $O/pytest.txt
+timeout 300 python tools/bench_fs2.py 20 > $O/fs2_forward.jsonl 2> $O/fs2_forward.err
+timeout 400 python tools/bench_train.py 5 > $O/train_step.jsonl 2> $O/train_step.err
+tail -2 $O/pytest.txt; cat $O/fs2_forward.jsonl | cut -c1-140; cat $O/train_step.jsonl | cut -c1-200
