@@ -24,6 +24,9 @@ SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf
                'dsf_conv1d_dilated', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad',
                'dsf_train_add_step', 'dsf_train_rowsum', 'dsf_train_gate', 'dsf_train_gate_bwd', 'dsf_train_res_skip', 'dsf_train_res_skip_bwd']
 
+# every symbol include/dsv.h declares (the HiFi-GAN / NSF-HiFi-GAN generator ops)
+SYMBOLS_VOC = ['dsv_padded_samples', 'dsv_packed_floats', 'dsv_pack_weight', 'dsv_pad_rows', 'dsv_conv1d', 'dsv_noise_conv', 'dsv_sine_source']
+
 _fp = C.POINTER(C.c_float)
 _fpp = C.POINTER(C.c_void_p)
 
@@ -121,6 +124,15 @@ def load():
     lib.dsf_train_gate_bwd.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_train_res_skip.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_train_res_skip_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.dsv_padded_samples.argtypes = [i32]
+    lib.dsv_padded_samples.restype = i32
+    lib.dsv_packed_floats.argtypes = [i32, i32, i32]
+    lib.dsv_packed_floats.restype = i64
+    lib.dsv_pack_weight.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.dsv_pad_rows.argtypes = [vp, vp, i64, i32, vp]
+    lib.dsv_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, f32, i32, vp]
+    lib.dsv_noise_conv.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.dsv_sine_source.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, f32, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('dsd_abi_version',):

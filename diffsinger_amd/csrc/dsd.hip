@@ -964,3 +964,4 @@ extern "C" int dsd_debug_layer_timeline(dsd_handle* h, int32_t layer, int32_t t,
 }
 
 #include "fs2_abi.hpp"
+#include "voc_abi.hpp"

@@ -1,0 +1,106 @@
+// voc_abi.hpp - host side of the HiFi-GAN / NSF-HiFi-GAN generator ops (C ABI in include/dsv.h); included at the end of dsd.hip so
+// the library stays one translation unit (shares the error string, the HIP_TRY macros and the operand-packing kernel).
+#include "voc_kernels.hpp"
+
+#include "../../include/dsv.h"
+
+static inline int voc_ls(int L) { return (L + 31) / 32 * 32; }
+
+extern "C" int32_t dsv_padded_samples(int32_t L) { return voc_ls(L); }
+
+extern "C" int64_t dsv_packed_floats(int32_t rows, int32_t Ci, int32_t KT) {
+    if (rows < 1 || Ci < 1 || KT < 1) return -1;
+    const int64_t nrb = (rows + 31) / 32, ci8 = (Ci + 7) / 8;
+    return (nrb * ci8 * KT * 64 + kWeightSlack) * 4;
+}
+
+extern "C" int dsv_pack_weight(const float* w, int32_t rows, int32_t Ci, int32_t KT, float* packed, void* stream) {
+    if (!w || !packed) return fail(DSD_ERR_INVALID, "dsv_pack_weight: null argument");
+    if (rows < 1 || Ci < 1 || KT < 1) return fail(DSD_ERR_INVALID, "dsv_pack_weight: bad shape (rows=%d Ci=%d K=%d)", rows, Ci, KT);
+    PackParams p{};
+    p.src = w; p.dst = packed;
+    p.nw = (rows + 31) / 32; p.nkc = (Ci + 7) / 8; p.nmb = 1; p.ntap = KT;
+    p.split = 0; p.hi_base = 0;
+    p.rows_valid = rows; p.cols_valid = Ci;
+    p.row_stride = Ci * KT; p.col_stride = KT;
+    const size_t n = (size_t)p.nw * p.ntap * p.nkc * p.nmb * 256;
+    hipLaunchKernelGGL(k_pack_a, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(packed + n, 0, (size_t)kWeightSlack * 16, (hipStream_t)stream));
+    return DSD_OK;
+}
+
+extern "C" int dsv_pad_rows(const float* in, float* out, int64_t R, int32_t L, void* stream) {
+    if (!in || !out || R < 1 || R > 65535 || L < 1) return fail(DSD_ERR_INVALID, "dsv_pad_rows: bad argument");
+    const int LS = voc_ls(L);
+    hipLaunchKernelGGL(k_voc_pad_rows, dim3((unsigned)((LS + 255) / 256), (unsigned)R), dim3(256), 0, (hipStream_t)stream, in, out, L, LS);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+template <int NB, int WT>
+static void voc_conv_launch(const VocConvParams& p, int B, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_voc_conv<NB, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, voc_lds_bytes<NB, WT>());
+        attr_done = true;
+    }
+    constexpr int WR = 4 / WT, SPAN = voc_span<NB, WT>();
+    const size_t lds = (size_t)voc_lds_bytes<NB, WT>();
+    const dim3 grid((unsigned)((p.LSi + SPAN - 1) / SPAN), (unsigned)B, (unsigned)((p.rows + 32 * WR - 1) / (32 * WR)));
+    hipLaunchKernelGGL((k_voc_conv<NB, WT>), grid, dim3(kThreads), lds, s, p);
+}
+
+extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t rows, int32_t KT,
+                          int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in,
+                          float divide, int32_t act, void* stream) {
+    if (!in || !wpacked || !out) return fail(DSD_ERR_INVALID, "dsv_conv1d: null argument");
+    if (B < 1 || B > 65535 || Ci < 1 || rows < 1 || KT < 1 || dil < 1 || L_in < 1 || up < 1 || (rows % up) || pad < 0 || pad > kVocHalo ||
+        (KT - 1) * dil - pad > kVocHalo || (KT - 1) * dil - pad < 0 || act < 0 || act > 1 || divide == 0.f || (int64_t)L_in * up > (1 << 30))
+        return fail(DSD_ERR_INVALID, "dsv_conv1d: bad shape (B=%d Ci=%d rows=%d K=%d pad=%d dil=%d L=%d up=%d act=%d); taps must stay within +-%d samples",
+                    B, Ci, rows, KT, pad, dil, L_in, up, act, kVocHalo);
+    VocConvParams p{};
+    p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.sum_in = sum_in;
+    p.Ci = Ci; p.rows = rows; p.KT = KT; p.pad = pad; p.dil = dil;
+    p.Li = L_in; p.LSi = voc_ls(L_in); p.U = up; p.Lo = L_in * up; p.LSo = voc_ls(p.Lo);
+    p.pre_slope = pre_slope; p.divide = divide; p.act = act;
+    // narrow layers: one row block, the four waves split 512 samples; 64 rows: 2 x 2; wide (low-rate) layers: four row blocks x 32 samples
+    if (rows <= 32) voc_conv_launch<4, 4>(p, B, (hipStream_t)stream);
+    else if (rows <= 64) voc_conv_launch<2, 2>(p, B, (hipStream_t)stream);
+    else voc_conv_launch<1, 1>(p, B, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsv_noise_conv(const float* har, const float* w, const float* bias, float* out, int32_t B, int32_t C, int32_t K, int32_t stride,
+                              int32_t pad, int32_t L_har, int32_t L_out, void* stream) {
+    if (!har || !w || !out) return fail(DSD_ERR_INVALID, "dsv_noise_conv: null argument");
+    if (B < 1 || B > 65535 || C < 1 || C > 65535 || K < 1 || stride < 1 || pad < 0 || L_har < 1 || L_out < 1 ||
+        (int64_t)(L_har + 2 * pad - K) / stride + 1 != L_out)
+        return fail(DSD_ERR_INVALID, "dsv_noise_conv: bad shape (B=%d C=%d K=%d stride=%d pad=%d L_har=%d L_out=%d)", B, C, K, stride, pad, L_har, L_out);
+    const int LSo = voc_ls(L_out);
+    hipLaunchKernelGGL(k_voc_noise_conv, dim3((unsigned)((LSo + 255) / 256), (unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream, har, w, bias,
+                       out, C, K, stride, pad, L_har, voc_ls(L_har), L_out, LSo);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsv_sine_source(const float* f0, const float* rand_ini, const float* noise, const float* lin_w, const float* lin_b, float* sines_ws,
+                               float* har, int32_t B, int32_t T, int32_t up, int32_t H, float sample_rate, float sine_amp, float noise_std,
+                               float voiced_threshold, void* stream) {
+    if (!f0 || !rand_ini || !noise || !lin_w || !lin_b || !sines_ws || !har) return fail(DSD_ERR_INVALID, "dsv_sine_source: null argument");
+    if (B < 1 || B > 65535 || T < 1 || up < 1 || H < 1 || H > 64 || !(sample_rate > 0.f) || (int64_t)T * up > (1 << 30))
+        return fail(DSD_ERR_INVALID, "dsv_sine_source: bad shape (B=%d T=%d up=%d H=%d sr=%g)", B, T, up, H, (double)sample_rate);
+    const int L = T * up, LS = voc_ls(L);
+    VocSineParams sp{};
+    sp.f0 = f0; sp.rand_ini = rand_ini; sp.sw = sines_ws; sp.T = T; sp.up = up; sp.L = L; sp.H = H; sp.sr = sample_rate; sp.sine_amp = sine_amp;
+    hipLaunchKernelGGL(k_voc_sine, dim3((unsigned)H, (unsigned)B), dim3(256), 0, (hipStream_t)stream, sp);
+    HIP_TRY(hipGetLastError());
+    VocSourceParams mp{};
+    mp.f0 = f0; mp.sw = sines_ws; mp.noise = noise; mp.lin_w = lin_w; mp.lin_b = lin_b; mp.har = har;
+    mp.T = T; mp.up = up; mp.L = L; mp.LS = LS; mp.H = H;
+    mp.noise_std = noise_std; mp.sine_amp = sine_amp; mp.voiced_threshold = voiced_threshold;
+    hipLaunchKernelGGL(k_voc_source, dim3((unsigned)((LS + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, mp);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}

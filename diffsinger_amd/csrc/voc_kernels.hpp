@@ -1,0 +1,325 @@
+// voc_kernels.hpp - gfx950 kernels of the HiFi-GAN / NSF-HiFi-GAN generator (the step AFTER the
+// diffusion hot path, mel [B,80,T] (+ f0 [B,T]) -> waveform [B,1,T*hop]).
+//
+// What is computed, and where the reference computes it (paths relative to the reference root):
+//   k_voc_conv        every Conv1d AND every ConvTranspose1d of HifiGanGenerator.forward (modules/hifigan/hifigan.py:144-169) and of
+//                     ResBlock1 / ResBlock2 (:30-92) as one fp32-MFMA contraction over (input channel, tap), with the element-wise
+//                     neighbours fused: the leaky_relu in FRONT of the convolution (applied while the input tile is staged), the
+//                     bias, the residual `xt + x`, the running sum over the parallel resblocks `xs += ...`, the `/ num_kernels`,
+//                     the harmonic-source add `x + x_source` and the final tanh.
+//                     A transposed convolution (stride u, kernel k, padding (k-u)/2) is the SAME kernel: its polyphase form is a
+//                     stride-1 convolution at the INPUT rate with u * Co output rows (row = co * u + phase), whose rows are written
+//                     interleaved - out[co][q * u + phase] (a "pixel shuffle" in the store addresses, no scatter, no zero stuffing).
+//   k_voc_sine        SineGen._f02sine + forward (modules/parallel_wavegan/models/source.py:45-77, :101-137): per (utterance,
+//                     harmonic) the phase is a cumulative sum over the SAMPLE axis; two block scans in fp64 (the reference's CPU
+//                     cumsum accumulates in double too)
+//   k_voc_source      uv / noise mix of SineGen.forward (:124-135) + SourceModuleHnNSF's Linear(9 -> 1) + tanh (:518-531)
+//   k_voc_noise_conv  the strided Conv1d(1 -> C, kernel 2s, stride s) of noise_convs (hifigan.py:124-130): har [B,1,L] -> [B,C,L/s]
+//   k_voc_pad_rows    [R][L] contiguous -> [R][LS] (row stride padded to 32, zero tail)
+//
+// Activations live channel-major [B][C][LS] like everywhere in this library (sample axis contiguous, LS = L rounded up to 32,
+// ZERO in [L, LS)).  The generator is narrow (128 -> 64 -> 32 -> 16 -> 8 channels on the shipped config) and LONG (up to 256
+// samples per mel frame), the opposite of the denoiser: a wave therefore owns ONE 32-row block and NB consecutive 32-sample
+// blocks (the weight fragment it streams from L2 is reused NB times), and the four waves of a workgroup split the time axis
+// when the layer has fewer than 128 rows.  Rows are padded to 32 with zero weights (the 8- and 16-channel layers waste MFMA
+// issue slots; they are bound by their HBM traffic, not by the matrix pipe).
+#pragma once
+#include "dsd_kernels.hpp"
+
+namespace dsd {
+
+constexpr int kVocHalo = 28;               // taps reach +-25 samples (kernel 11, dilation 5); multiple of 4 for the float4 staging
+constexpr int kVocLdsBudget = 72 * 1024;   // two workgroups per CU
+
+template <int NB, int WT> constexpr int voc_span() { return 32 * NB * WT; }                    // samples per workgroup
+template <int NB, int WT> constexpr int voc_ld() { return voc_span<NB, WT>() + 2 * kVocHalo; }  // LDS row stride
+template <int NB, int WT> constexpr int voc_slab() {                                          // input channels staged per pass
+    const int s = kVocLdsBudget / (voc_ld<NB, WT>() * 4) / 8 * 8;
+    return s > 256 ? 256 : s;
+}
+template <int NB, int WT> constexpr int voc_lds_bytes() { return voc_slab<NB, WT>() * voc_ld<NB, WT>() * 4; }
+
+enum VocAct { VOC_ACT_NONE = 0, VOC_ACT_TANH = 1 };
+
+struct VocConvParams {
+    const float* in;        // [B][Ci][LSi]
+    const float4* wp;       // packed [row block 32][chunk = ci8 * KT + tap][lane64] float4 (k_pack_a, nmb = 1)
+    const float* bias;      // [Co] or nullptr
+    float* out;             // [B][Co][LSo],  Co = rows / U
+    const float* res;       // [B][Co][LSo] or nullptr: added after the bias
+    const float* sum_in;    // [B][Co][LSo] or nullptr: running sum the result is added TO
+    int Ci, rows, KT, pad, dil;
+    int Li, LSi, U, Lo, LSo;
+    float pre_slope;        // leaky_relu slope applied to the input (1 = identity)
+    float divide;           // the result is divided by this (1 = no division)
+    int act;
+};
+
+template <int LD>
+struct VocTapB {            // B-operand functor of GemmPipe: chunk kc = ci8 * KT + tap of the staged slab
+    const float* base;      // slab + 4 h LD + halo + this wave's first sample + j - pad
+    int KT, dil, n;
+    __device__ __forceinline__ const float* operator()(int it, int u) const {
+        int kc = 6 * it + u;
+        kc = (kc < n) ? kc : n - 1;
+        int g;                                  // constant divisors for the kernel sizes of the shipped configs
+        if (KT == 1) g = kc;
+        else if (KT == 3) g = kc / 3;
+        else if (KT == 7) g = kc / 7;
+        else if (KT == 11) g = kc / 11;
+        else g = kc / KT;
+        const int tap = kc - g * KT;
+        return base + g * (8 * LD) + tap * dil;
+    }
+};
+
+__device__ __forceinline__ float voc_lrelu(float v, float slope) { return (v > 0.f) ? v : v * slope; }
+
+// Workgroup = WR = 4 / WT row blocks of 32 x (WT * NB * 32) samples of one utterance.  Wave w: row block (w % WR), time part (w / WR).
+template <int NB, int WT>
+__global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p) {
+    constexpr int LD = voc_ld<NB, WT>(), SPAN = voc_span<NB, WT>(), SLAB = voc_slab<NB, WT>(), WR = 4 / WT;
+    constexpr int NCOL4 = LD / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [SLAB][LD]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w % WR, wt = w / WR;
+    const int t0 = blockIdx.x * SPAN, b = blockIdx.y;
+    const int rb = blockIdx.z * WR + wr;                             // this wave's 32-row block
+    const int nrb = (p.rows + 31) / 32;
+    const int rbc = (rb < nrb) ? rb : nrb - 1;                       // waves past the last block walk valid memory and store nothing
+    const int ci8 = (p.Ci + 7) / 8;
+    const int nchunk_total = ci8 * p.KT;
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+    const float* inb = p.in + (size_t)b * p.Ci * p.LSi;
+    const float slope = p.pre_slope;
+    for (int c0 = 0; c0 < p.Ci; c0 += SLAB) {
+        const int nc = min(SLAB, p.Ci - c0);
+        const int nc8 = (nc + 7) / 8 * 8;                            // rows [nc, nc8) are staged as zeros (their weights are zero too)
+        // stage channels [c0, c0 + nc) x samples [t0 - halo, t0 + SPAN + halo), zero outside [0, LSi), leaky_relu applied here
+        for (int idx = tid; idx < nc8 * NCOL4; idx += kThreads) {
+            const int row = idx / NCOL4, g = idx - row * NCOL4;
+            const int t = t0 - kVocHalo + 4 * g;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nc && t >= 0 && t < p.LSi) {
+                v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + row) * p.LSi + t);
+                v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+            }
+            *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
+        }
+        __syncthreads();
+        const int nch = (nc8 / 8) * p.KT;
+        const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
+        const VocTapB<LD> bof{smem + 4 * h * LD + kVocHalo + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch};
+        gemm_k<1, NB, LD, 64>(acc, ap, lane, nch, bof);
+        __syncthreads();
+    }
+    if (rb >= nrb) return;
+    const int U = p.U, Co = p.rows / U;
+    const int q0 = t0 + wt * (32 * NB) + j;                          // input-rate sample index of frame block 0
+    if ((U & 3) == 0) {
+        // rows 8 rg + 4 h + (0..3) of this lane are 4 consecutive phases of ONE output channel: 16-byte accesses
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int q = q0 + 32 * nb;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = rb * 32 + 8 * rg + 4 * h;
+                const int co = row / U, ph = row - co * U;
+                const int n = q * U + ph;
+                if (row >= p.rows || n >= p.LSo) continue;
+                const size_t o = ((size_t)b * Co + co) * p.LSo + n;
+                const float bv = p.bias ? p.bias[co] : 0.f;
+                float4 v = get4(acc[0][nb], rg);
+                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                if (p.res) { const float4 r4 = *reinterpret_cast<const float4*>(p.res + o); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+                if (p.sum_in) { const float4 s4 = *reinterpret_cast<const float4*>(p.sum_in + o); v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w; }
+                if (p.divide != 1.f) { v.x = v.x / p.divide; v.y = v.y / p.divide; v.z = v.z / p.divide; v.w = v.w / p.divide; }
+                if (p.act == VOC_ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+                if (n + 0 >= p.Lo) v.x = 0.f;
+                if (n + 1 >= p.Lo) v.y = 0.f;
+                if (n + 2 >= p.Lo) v.z = 0.f;
+                if (n + 3 >= p.Lo) v.w = 0.f;
+                *reinterpret_cast<float4*>(p.out + o) = v;
+            }
+        }
+        return;
+    }
+    // general phase count (1: plain convolution, lanes j write consecutive samples; 2: two channels x two phases per register quad)
+    float bv[16];
+    int cov[16], phv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rb * 32 + frag_row(r, h);
+        const int rc = (row < p.rows) ? row : 0;
+        cov[r] = rc / U;
+        phv[r] = rc - cov[r] * U;
+        bv[r] = p.bias ? p.bias[cov[r]] : 0.f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int q = q0 + 32 * nb;
+        float rv[16], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                               // all the reads first
+            const int n = q * U + phv[r];
+            const bool ok = (rb * 32 + frag_row(r, h) < p.rows) && n < p.LSo;
+            const size_t o = ((size_t)b * Co + cov[r]) * p.LSo + (ok ? n : 0);
+            rv[r] = (p.res && ok) ? p.res[o] : 0.f;
+            sv[r] = (p.sum_in && ok) ? p.sum_in[o] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = q * U + phv[r];
+            const bool ok = (rb * 32 + frag_row(r, h) < p.rows) && n < p.LSo;
+            float v = acc[0][nb][r] + bv[r];
+            if (p.res) v += rv[r];
+            if (p.sum_in) v = sv[r] + v;
+            if (p.divide != 1.f) v = v / p.divide;
+            if (p.act == VOC_ACT_TANH) v = tanhf(v);
+            if (ok) p.out[((size_t)b * Co + cov[r]) * p.LSo + n] = (n < p.Lo) ? v : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// NSF harmonic source
+// ------------------------------------------------------------------------------------------------------------
+struct VocSineParams {
+    const float* f0;        // [B][T] frame-rate f0 in Hz (0 = unvoiced)
+    const float* rand_ini;  // [B][H] initial phases (column 0 is ignored: the fundamental starts at phase 0, source.py:59-60)
+    float* sw;              // [B][H][L] sin(2 pi phase) * sine_amp
+    int T, up, L, H;
+    float sr, sine_amp;
+};
+
+// torch's `x % 1` on fp32 (aten remainder: fmod, then + divisor when the signs differ)
+__device__ __forceinline__ float voc_mod1(float a) {
+    float m = fmodf(a, 1.f);
+    if (m != 0.f && m < 0.f) m += 1.f;
+    return m;
+}
+
+// exclusive scan of one double per thread over the 256 threads of the block (in place in `part`)
+__device__ __forceinline__ void voc_block_scan(double* part, int tid) {
+    __syncthreads();
+    if (tid == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) { const double v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+}
+
+// One workgroup per (harmonic, utterance); thread k owns the k-th contiguous piece of the sample axis.
+//   rad[i]   = (f0_up[i] * (h+1) / sr) % 1, rad[0] += rand_ini                                   source.py:52-60
+//   over[i]  = cumsum(rad)[i] % 1 ; shift[i] = -1 where over[i] < over[i-1]                        :64-70
+//   phase[i] = cumsum(rad + shift)[i] ; sw = sin(phase * 2 * pi) * sine_amp                        :72-73, :121
+// Both cumulative sums accumulate in fp64 and are rounded to fp32 per element, like aten's CPU cumsum on a float tensor.
+__global__ __launch_bounds__(256) void k_voc_sine(const VocSineParams p) {
+    __shared__ double part1[256];
+    __shared__ double part2[256];
+    const int tid = threadIdx.x, hidx = blockIdx.x, b = blockIdx.y;
+    const int per = (p.L + 255) / 256;
+    const int i0 = min(p.L, tid * per), i1 = min(p.L, i0 + per);
+    const float mult = (float)(hidx + 1);
+    const float ini = (hidx == 0) ? 0.f : p.rand_ini[(size_t)b * p.H + hidx];
+    const float* f0b = p.f0 + (size_t)b * p.T;
+    auto rad_at = [&](int i) -> float {
+        float f = f0b[i / p.up];
+        if (hidx > 0) f = f * mult;
+        float r = voc_mod1(f / p.sr);
+        if (i == 0) r = r + ini;
+        return r;
+    };
+    double s1 = 0.0;
+    for (int i = i0; i < i1; ++i) s1 += (double)rad_at(i);
+    part1[tid] = s1;
+    voc_block_scan(part1, tid);
+    const double base1 = part1[tid];
+    double c = base1, s2 = 0.0;
+    float over_prev = voc_mod1((float)c);
+    for (int i = i0; i < i1; ++i) {
+        const float r = rad_at(i);
+        c += (double)r;
+        const float over = voc_mod1((float)c);
+        const float shift = (i > 0 && (over - over_prev) < 0.f) ? -1.f : 0.f;
+        s2 += (double)(r + shift);
+        over_prev = over;
+    }
+    part2[tid] = s2;
+    voc_block_scan(part2, tid);
+    c = base1;
+    double c2 = part2[tid];
+    over_prev = voc_mod1((float)c);
+    float* dst = p.sw + ((size_t)b * p.H + hidx) * p.L;
+    for (int i = i0; i < i1; ++i) {
+        const float r = rad_at(i);
+        c += (double)r;
+        const float over = voc_mod1((float)c);
+        const float shift = (i > 0 && (over - over_prev) < 0.f) ? -1.f : 0.f;
+        c2 += (double)(r + shift);
+        over_prev = over;
+        const float ph = (float)c2;
+        dst[i] = sinf(ph * 2.f * 3.14159265358979323846f) * p.sine_amp;
+    }
+}
+
+struct VocSourceParams {
+    const float* f0;        // [B][T]
+    const float* sw;        // [B][H][L]
+    const float* noise;     // [B][L][H] standard normal draws (torch.randn_like(sine_waves), source.py:131)
+    const float* lin_w;     // [H]   m_source.l_linear.weight[0]
+    const float* lin_b;     // [1]
+    float* har;             // [B][LS]
+    int T, up, L, LS, H;
+    float noise_std, sine_amp, voiced_threshold;
+};
+
+__global__ __launch_bounds__(256) void k_voc_source(const VocSourceParams p) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= p.LS) return;
+    float out = 0.f;
+    if (i < p.L) {
+        const float f = p.f0[(size_t)b * p.T + i / p.up];
+        const float uv = (f > p.voiced_threshold) ? 1.f : 0.f;
+        const float namp = uv * p.noise_std + ((1.f - uv) * p.sine_amp) / 3.f;      // source.py:129, evaluated left to right in fp32
+        float acc = 0.f;
+        for (int hh = 0; hh < p.H; ++hh) {
+            const float s = p.sw[((size_t)b * p.H + hh) * p.L + i] * uv + namp * p.noise[((size_t)b * p.L + i) * p.H + hh];
+            acc += s * p.lin_w[hh];
+        }
+        out = tanhf(acc + p.lin_b[0]);
+    }
+    p.har[(size_t)b * p.LS + i] = out;
+}
+
+// xs[b][c][n] = bias[c] + sum_j w[c][j] * har[b][n * s - pad + j]     (zero outside [0, Lh))
+__global__ __launch_bounds__(256) void k_voc_noise_conv(const float* __restrict__ har, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int C, int K, int s, int pad, int Lh, int LSh, int Lo, int LSo) {
+    const int n = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (n >= LSo) return;
+    float v = 0.f;
+    if (n < Lo) {
+        const float* hb = har + (size_t)b * LSh;
+        const float* wc = w + (size_t)c * K;
+        const int i0 = n * s - pad;
+        for (int jj = 0; jj < K; ++jj) {
+            const int i = i0 + jj;
+            if (i >= 0 && i < Lh) v += wc[jj] * hb[i];
+        }
+        v += bias ? bias[c] : 0.f;
+    }
+    out[((size_t)b * C + c) * LSo + n] = v;
+}
+
+__global__ __launch_bounds__(256) void k_voc_pad_rows(const float* __restrict__ in, float* __restrict__ out, int L, int LS) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const size_t r = blockIdx.y;
+    if (t < LS) out[r * LS + t] = (t < L) ? in[r * L + t] : 0.f;
+}
+
+}  // namespace dsd

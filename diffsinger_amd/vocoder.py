@@ -1,0 +1,361 @@
+"""HiFi-GAN / NSF-HiFi-GAN generator - the vocoder behind the diffusion hot path - as an
+nn.Module whose forward runs on the HIP kernels of libdsdenoise.so (include/dsv.h).
+
+Mirrors the reference module tree (paths relative to the reference root) name for name, so the `model_gen` / `generator`
+state_dict of a reference checkpoint loads with strict=True, before or after remove_weight_norm():
+
+    HifiGanGenerator, ResBlock1, ResBlock2        modules/hifigan/hifigan.py:30-92, :104-179
+    SourceModuleHnNSF, SineGen                    modules/parallel_wavegan/models/source.py:7-137, :484-531
+    HifiGAN.spec2wav (the registered vocoder)     vocoders/hifigan.py:40-69
+
+What runs where: every Conv1d / ConvTranspose1d with the leaky_relu in front of it and the residual / resblock-sum /
+`/ num_kernels` / source add / tanh behind it is ONE launch of k_voc_conv (fp32 MFMA); the sine source (two cumulative
+sums over the sample axis, sin, uv / noise mix, Linear + tanh) and the strided noise convolutions are their own kernels.
+torch is used for buffers, the one-time weight preparation (weight-norm fold, polyphase form of the transposed
+convolutions) and the random draws of the source module.  Inference only; no CPU path: forward raises when the tensors
+are not on the MI355X."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+LRELU_SLOPE = 0.1
+
+
+def padded_samples(L: int) -> int:
+    return (L + 31) // 32 * 32
+
+
+def get_padding(kernel_size: int, dilation: int = 1) -> int:
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+def polyphase_weight(w: torch.Tensor, stride: int, padding: int):
+    """ConvTranspose1d weight [Ci][Co][k] (stride u, padding p, k - 2 p == u) -> (W' [Co * u][Ci][K'], pad') such that
+        out[co][u q + r] = sum_ci sum_t W'[co * u + r][ci][t] * in[ci][q + t - pad']
+    i.e. the stride-1 convolution at the input rate that dsv_conv1d evaluates with up = u.  Output phase r is reached by
+    the taps j = (r + p) % u + u m, each reading input sample q + (r + p) // u - m."""
+    ci, co, k = w.shape
+    u, p = int(stride), int(padding)
+    if k - 2 * p != u:
+        raise NotImplementedError(f'ConvTranspose1d with kernel {k}, stride {u}, padding {p}: only kernel - 2 * padding == stride (the HiFi-GAN '
+                                  f'upsamplers) is supported')
+    taps = []                                                        # (r, j, delta)
+    for r in range(u):
+        s = r + p
+        m = 0
+        while (s % u) + u * m < k:
+            taps.append((r, (s % u) + u * m, s // u - m))
+            m += 1
+    dmin = min(t[2] for t in taps)
+    dmax = max(t[2] for t in taps)
+    kk = dmax - dmin + 1
+    wp = torch.zeros(co, u, ci, kk, dtype=w.dtype, device=w.device)
+    for r, j, d in taps:
+        wp[:, r, :, d - dmin] = w[:, :, j].t()
+    return wp.reshape(co * u, ci, kk).contiguous(), -dmin
+
+
+class _HipOps:
+    """The C ABI of include/dsv.h on torch device tensors (buffers in, buffers out).  There is no other implementation in the
+    package: tests swap in a torch restatement of the header's formulas to check the orchestration on CPU."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    @staticmethod
+    def _s(dev) -> int:
+        return torch.cuda.current_stream(dev).cuda_stream
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return t.data_ptr() if t is not None else None
+
+    def pack(self, w: torch.Tensor) -> torch.Tensor:
+        rows, ci, k = w.shape
+        n = self.lib.dsv_packed_floats(rows, ci, k)
+        buf = torch.empty(n, device=w.device, dtype=torch.float32)
+        w = w.contiguous()
+        with torch.cuda.device(w.device):
+            _lib.check(self.lib.dsv_pack_weight(w.data_ptr(), rows, ci, k, buf.data_ptr(), self._s(w.device)), 'dsv_pack_weight')
+        w.record_stream(torch.cuda.current_stream(w.device))
+        return buf
+
+    def pad_rows(self, x: torch.Tensor) -> torch.Tensor:
+        B, C, L = x.shape
+        out = torch.empty(B, C, padded_samples(L), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.dsv_pad_rows(x.data_ptr(), out.data_ptr(), B * C, L, self._s(x.device)), 'dsv_pad_rows')
+        return out
+
+    def conv(self, x, L_in, wp, bias, rows, ci, k, pad, dil, up=1, pre_slope=1.0, residual=None, sum_in=None, divide=1.0, act=0):
+        B = x.shape[0]
+        assert x.shape[1] == ci and x.shape[2] == padded_samples(L_in) and x.is_contiguous()
+        out = torch.empty(B, rows // up, padded_samples(L_in * up), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.dsv_conv1d(x.data_ptr(), wp.data_ptr(), self._p(bias), out.data_ptr(), B, ci, rows, k, pad, dil, L_in, up,
+                                           float(pre_slope), self._p(residual), self._p(sum_in), float(divide), int(act), self._s(x.device)),
+                       'dsv_conv1d')
+        return out
+
+    def noise_conv(self, har, L_har, w, bias, stride, pad, L_out):
+        B = har.shape[0]
+        C, K = w.shape
+        out = torch.empty(B, C, padded_samples(L_out), device=har.device, dtype=torch.float32)
+        with torch.cuda.device(har.device):
+            _lib.check(self.lib.dsv_noise_conv(har.data_ptr(), w.data_ptr(), self._p(bias), out.data_ptr(), B, C, K, stride, pad, L_har, L_out,
+                                               self._s(har.device)), 'dsv_noise_conv')
+        return out
+
+    def sine_source(self, f0, rand_ini, noise, lin_w, lin_b, up, sr, sine_amp, noise_std, thr):
+        B, T = f0.shape
+        H = rand_ini.shape[1]
+        L = T * up
+        ws = torch.empty(B, H, L, device=f0.device, dtype=torch.float32)
+        har = torch.empty(B, padded_samples(L), device=f0.device, dtype=torch.float32)
+        with torch.cuda.device(f0.device):
+            _lib.check(self.lib.dsv_sine_source(f0.data_ptr(), rand_ini.data_ptr(), noise.data_ptr(), lin_w.data_ptr(), lin_b.data_ptr(),
+                                                ws.data_ptr(), har.data_ptr(), B, T, up, H, float(sr), float(sine_amp), float(noise_std),
+                                                float(thr), self._s(f0.device)), 'dsv_sine_source')
+        return har
+
+
+class _WNConv(nn.Module):
+    """Parameter holder of weight_norm(Conv1d / ConvTranspose1d): weight_g / weight_v / bias as a checkpoint stores them
+    (torch.nn.utils.weight_norm, dim 0), or weight / bias after remove_weight_norm()."""
+
+    def __init__(self, wshape, nbias):
+        super().__init__()
+        self.weight_g = nn.Parameter(torch.ones(wshape[0], 1, 1))
+        self.weight_v = nn.Parameter(torch.randn(wshape) * 0.01)
+        self.bias = nn.Parameter(torch.zeros(nbias))
+
+    def remove_weight_norm(self):
+        if hasattr(self, 'weight_g'):
+            w = torch._weight_norm(self.weight_v.detach(), self.weight_g.detach(), 0)
+            del self.weight_g
+            del self.weight_v
+            self.weight = nn.Parameter(w)
+
+    def plain_weight(self) -> torch.Tensor:
+        if hasattr(self, 'weight_g'):
+            return torch._weight_norm(self.weight_v.detach(), self.weight_g.detach(), 0)
+        return self.weight.detach()
+
+    def tag(self):
+        ps = ([self.weight_g, self.weight_v] if hasattr(self, 'weight_g') else [self.weight]) + [self.bias]
+        return tuple((p.data_ptr(), p._version, p.device) for p in ps)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # a state saved AFTER remove_weight_norm() holds `weight`: switch this holder to the plain form before the strict load
+        if prefix + 'weight' in state_dict and hasattr(self, 'weight_g'):
+            self.remove_weight_norm()
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class _PlainConv(nn.Module):
+    def __init__(self, wshape):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(wshape) * 0.01)
+        self.bias = nn.Parameter(torch.zeros(wshape[0]))
+
+
+class _ResBlock(nn.Module):
+    """ResBlock1 (convs1 / convs2, hifigan.py:30-66) or ResBlock2 (convs, :69-92): parameters only."""
+
+    def __init__(self, kind: str, ch: int, k: int, dils):
+        super().__init__()
+        self.kind, self.k, self.dils = kind, k, tuple(dils)
+        if kind == '1':
+            self.convs1 = nn.ModuleList([_WNConv((ch, ch, k), ch) for _ in dils])
+            self.convs2 = nn.ModuleList([_WNConv((ch, ch, k), ch) for _ in dils])
+        else:
+            self.convs = nn.ModuleList([_WNConv((ch, ch, k), ch) for _ in dils])
+
+    def remove_weight_norm(self):
+        for m in self.modules():
+            if isinstance(m, _WNConv):
+                m.remove_weight_norm()
+
+
+class _Linear(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(o, i) * 0.1)
+        self.bias = nn.Parameter(torch.zeros(o))
+
+
+class _Source(nn.Module):
+    """SourceModuleHnNSF (source.py:484-531): l_linear is its only parameter."""
+
+    def __init__(self, harmonic_num):
+        super().__init__()
+        self.l_linear = _Linear(harmonic_num + 1, 1)
+
+
+class HifiGanGenerator(nn.Module):
+    """modules/hifigan/hifigan.py:104-179.  forward(x [B,80,T], f0 [B,T] or None) -> [B,1,T*prod(upsample_rates)]."""
+
+    def __init__(self, h, c_out=1):
+        super().__init__()
+        self.h = h
+        self.num_kernels = len(h['resblock_kernel_sizes'])
+        self.num_upsamples = len(h['upsample_rates'])
+        c0 = h['upsample_initial_channel']
+        self.use_pitch_embed = bool(h.get('use_pitch_embed', False))
+        if self.use_pitch_embed:
+            self.harmonic_num = 8
+            self.m_source = _Source(self.harmonic_num)
+            self.noise_convs = nn.ModuleList()
+        self.conv_pre = _WNConv((c0, 80, 7), c0)
+        self.ups = nn.ModuleList()
+        rates, ksz = list(h['upsample_rates']), list(h['upsample_kernel_sizes'])
+        ch = c0
+        for i, (u, k) in enumerate(zip(rates, ksz)):
+            ch = c0 // (2 ** (i + 1))
+            self.ups.append(_WNConv((ch * 2, ch, k), ch))
+            if self.use_pitch_embed:
+                if i + 1 < len(rates):
+                    s = int(np.prod(rates[i + 1:]))
+                    self.noise_convs.append(_PlainConv((ch, 1, s * 2)))
+                else:
+                    self.noise_convs.append(_PlainConv((ch, 1, 1)))
+        self.resblocks = nn.ModuleList()
+        for i in range(len(rates)):
+            ch = c0 // (2 ** (i + 1))
+            for k, d in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
+                self.resblocks.append(_ResBlock(str(h['resblock']), ch, k, d))
+        self.conv_post = _WNConv((c_out, ch, 7), c_out)
+        self.c_out = c_out
+        self._ops = None
+        self._packed = {}
+
+    def remove_weight_norm(self):
+        for m in self.modules():
+            if isinstance(m, _WNConv):
+                m.remove_weight_norm()
+
+    # ---- weight preparation (cached per parameter version) ---------------------------------------------------------------
+    def _prep(self, key: str, conv: _WNConv, transposed_stride: int = 0, transposed_pad: int = 0):
+        tag = conv.tag()
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        w = conv.plain_weight().to(torch.float32)
+        pad = None
+        if transposed_stride:
+            w, pad = polyphase_weight(w, transposed_stride, transposed_pad)
+        rows, ci, k = w.shape
+        entry = dict(wp=self._ops.pack(w), rows=rows, ci=ci, k=k, pad=pad, bias=conv.bias.detach().to(torch.float32).contiguous())
+        self._packed[key] = (tag, entry)
+        return entry
+
+    def _conv(self, key, conv, x, L, dil=1, **kw):
+        e = self._prep(key, conv)
+        return self._ops.conv(x, L, e['wp'], e['bias'], e['rows'], e['ci'], e['k'], get_padding(e['k'], dil), dil, **kw)
+
+    def _resblock(self, idx: int, x, L, sum_in, divide):
+        """One ResBlock on x; its last convolution also adds the block output into `sum_in` (xs += ...) and divides."""
+        rb = self.resblocks[idx]
+        n = len(rb.dils)
+        for q, d in enumerate(rb.dils):
+            last = q == n - 1
+            if rb.kind == '1':                                       # hifigan.py:54-61
+                xt = self._conv(f'rb{idx}.c1.{q}', rb.convs1[q], x, L, dil=d, pre_slope=LRELU_SLOPE)
+                x = self._conv(f'rb{idx}.c2.{q}', rb.convs2[q], xt, L, dil=1, pre_slope=LRELU_SLOPE, residual=x,
+                               sum_in=sum_in if last else None, divide=divide if last else 1.0)
+            else:                                                    # hifigan.py:82-87
+                x = self._conv(f'rb{idx}.c.{q}', rb.convs[q], x, L, dil=d, pre_slope=LRELU_SLOPE, residual=x,
+                               sum_in=sum_in if last else None, divide=divide if last else 1.0)
+        return x
+
+    @torch.no_grad()
+    def forward(self, x, f0=None, *, rand_ini: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """x [B,80,T] mel; f0 [B,T] Hz (NSF) or None.  rand_ini [B,9] / noise [B,T*hop,9]: the source module's draws
+        (torch.rand / torch.randn_like in SineGen, source.py:57, :131); drawn from torch's generator on x's device when
+        omitted, in the reference's order."""
+        if self._ops is None:
+            if x.device.type != 'cuda':
+                raise RuntimeError('HifiGanGenerator: the HIP vocoder has no CPU path - move the module and its inputs to the MI355X')
+            self._ops = _HipOps()
+        ops = self._ops
+        h = self.h
+        rates, ksz = list(h['upsample_rates']), list(h['upsample_kernel_sizes'])
+        B, M, T = x.shape
+        x = x.to(torch.float32).contiguous()
+        har = None
+        hop = int(np.prod(rates))
+        if f0 is not None:
+            if not self.use_pitch_embed:
+                raise ValueError('f0 given but the generator was built without use_pitch_embed')
+            if hop & (hop - 1):
+                raise NotImplementedError('nearest f0 upsampling is index // hop here: exact for power-of-two hop sizes only')
+            f0 = f0.to(torch.float32).contiguous()
+            H = self.harmonic_num + 1
+            Lh = T * hop
+            if rand_ini is None:
+                rand_ini = torch.rand(B, H, device=x.device)
+            if noise is None:
+                noise = torch.randn(B, Lh, H, device=x.device)
+                torch.randn(B, Lh, 1, device=x.device)               # SourceModuleHnNSF draws its (unused) noise branch too, source.py:529
+            lin = self.m_source.l_linear
+            har = ops.sine_source(f0, rand_ini.to(torch.float32).contiguous(), noise.to(torch.float32).contiguous(),
+                                  lin.weight.detach().reshape(-1).contiguous(), lin.bias.detach().contiguous(), hop,
+                                  h['audio_sample_rate'], 0.1, 0.003, 0.0)
+        L = T
+        x = ops.pad_rows(x)
+        x = self._conv('pre', self.conv_pre, x, L)
+        for i, (u, k) in enumerate(zip(rates, ksz)):
+            xs = None
+            if har is not None:                                      # hifigan.py:158-160
+                nc = self.noise_convs[i]
+                if i + 1 < len(rates):
+                    s = int(np.prod(rates[i + 1:]))
+                    xs = ops.noise_conv(har, T * hop, nc.weight.detach()[:, 0].contiguous(), nc.bias.detach().contiguous(), s, s // 2, L * u)
+                else:
+                    xs = ops.noise_conv(har, T * hop, nc.weight.detach()[:, 0].contiguous(), nc.bias.detach().contiguous(), 1, 0, L * u)
+            e = self._prep(f'ups{i}', self.ups[i], transposed_stride=u, transposed_pad=(k - u) // 2)
+            x = ops.conv(x, L, e['wp'], e['bias'], e['rows'], e['ci'], e['k'], e['pad'], 1, up=u, pre_slope=LRELU_SLOPE, residual=xs)
+            L = L * u
+            acc = None
+            for j in range(self.num_kernels):                        # xs = rb0(x); xs += rb1(x); ...; x = xs / num_kernels
+                last = j == self.num_kernels - 1
+                acc = self._resblock(i * self.num_kernels + j, x, L, acc, float(self.num_kernels) if last else 1.0)
+            x = acc
+        e = self._prep('post', self.conv_post)
+        x = ops.conv(x, L, e['wp'], e['bias'], e['rows'], e['ci'], e['k'], 3, 1, pre_slope=0.01, act=1)     # F.leaky_relu default slope, tanh
+        return x[:, :, :L].contiguous()
+
+
+class HifiGAN:
+    """vocoders/hifigan.py:40-69 without the checkpoint discovery: wraps a loaded generator; spec2wav(mel [T,80], f0=[T]) -> wav [T*hop]
+    as a numpy array.  `use_nsf` mirrors hparams['use_nsf']."""
+
+    def __init__(self, model: HifiGanGenerator, device='cuda', use_nsf: bool = False):
+        self.model = model.eval().to(device)
+        self.device = torch.device(device)
+        self.use_nsf = use_nsf
+
+    @classmethod
+    def from_state_dict(cls, config: dict, state: dict, device='cuda', use_nsf: bool = False):
+        """load_model (vocoders/hifigan.py:17-32): strict load of a weight-normed checkpoint state, then remove_weight_norm()."""
+        model = HifiGanGenerator(config)
+        model.load_state_dict(state, strict=True)
+        model.remove_weight_norm()
+        return cls(model, device, use_nsf)
+
+    def spec2wav(self, mel, **kwargs):
+        with torch.no_grad():
+            c = torch.as_tensor(mel, dtype=torch.float32).unsqueeze(0).transpose(2, 1).to(self.device)
+            f0 = kwargs.get('f0')
+            if f0 is not None and self.use_nsf:
+                f0 = torch.as_tensor(f0, dtype=torch.float32)[None, :].to(self.device)
+                y = self.model(c, f0).view(-1)
+            else:
+                y = self.model(c).view(-1)
+        return y.cpu().numpy()

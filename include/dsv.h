@@ -1,0 +1,72 @@
+/* dsv.h - C ABI of the HiFi-GAN / NSF-HiFi-GAN generator ops in libdsdenoise.so (MI355X, gfx950).
+ *
+ * the step AFTER the diffusion hot path - mel [B,80,T] (+ f0 [B,T]) -> waveform [B,1,T*hop].
+ * The reference (MoonInTheRiver/DiffSinger) computes it with torch nn modules (modules/hifigan/hifigan.py:104-179,
+ * modules/parallel_wavegan/models/source.py:7-137, :484-531, called from vocoders/hifigan.py:55-69) and has no FFI; these are
+ * the operators its modules would bind.  Every entry point names the reference code it replaces (paths relative to the
+ * reference root).  Conventions as in dsd.h: fp32 device pointers, `stream` a hipStream_t as void*, work is only ENQUEUED,
+ * 0 on success / negative dsd_status otherwise with the message in dsd_last_error().
+ *
+ * Activation layout ("channel-major"): [B][C][LS], sample axis contiguous, LS = dsv_padded_samples(L) (L rounded up to a
+ * multiple of 32); every op writes ZERO to the samples [L, LS) and expects that of its inputs.  Stateless: the caller owns
+ * every buffer. */
+#ifndef DSV_H
+#define DSV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSV_ACT_NONE 0
+#define DSV_ACT_TANH 1      /* torch.tanh after conv_post, modules/hifigan/hifigan.py:167-168 */
+
+int32_t dsv_padded_samples(int32_t L);
+
+/* Replaces the parameter storage of a Conv1d / ConvTranspose1d AFTER remove_weight_norm() (hifigan.py:171-179): a
+ * convolution weight [rows][Ci][K] repacked into the MFMA A-operand fragment order dsv_conv1d streams (rows padded to 32,
+ * Ci to 8, with zeros).  dsv_packed_floats = floats the packed buffer must hold (or -1).
+ * For ConvTranspose1d(Ci, Co, k, stride u, padding (k-u)/2) the caller passes the polyphase form: rows = Co * u,
+ * row co * u + r holds the taps that reach output phase r (see dsv_conv1d). */
+int64_t dsv_packed_floats(int32_t rows, int32_t Ci, int32_t K);
+int dsv_pack_weight(const float* w, int32_t rows, int32_t Ci, int32_t K, float* packed, void* stream);
+
+/* [R][L] contiguous rows -> [R][LS] padded rows with a zero tail (the mel [B,80,T] entering conv_pre, hifigan.py:151). */
+int dsv_pad_rows(const float* in, float* out, int64_t R, int32_t L, void* stream);
+
+/* One convolution of the generator with its element-wise neighbours fused - Conv1d / ConvTranspose1d of
+ * HifiGanGenerator.forward (hifigan.py:144-169), ResBlock1.forward (:54-61), ResBlock2.forward (:82-87):
+ *     y[row][q] = sum_ci sum_k  W[row][ci][k] * leaky_relu(in[ci][q + k * dil - pad], pre_slope)      (zero outside [0, L_in))
+ *     co = row / up, phase = row % up, n = q * up + phase                                              (up = 1: plain Conv1d)
+ *     v = y + bias[co] ; v += residual[co][n] ; v = sum_in[co][n] + v ; v = v / divide ; v = act(v)  -> out[co][n]
+ * in [B][Ci][LS(L_in)]; out / residual / sum_in [B][rows / up][LS(L_in * up)]; bias [rows / up]; residual, sum_in, bias may be
+ * NULL; pre_slope 1 = no activation in front, divide 1 = none.  Taps must stay within +-28 samples (pad <= 28 and
+ * (K-1) * dil - pad <= 28: kernel 11 at dilation 5 reaches 25).
+ * Covers: `leaky_relu -> convs1[i]`, `leaky_relu -> convs2[i] -> + x` (residual), the last conv of resblock j adding into
+ * the running `xs` (sum_in) and the last one also doing `/ num_kernels` (divide), `leaky_relu -> ups[i] (+ x_source)`
+ * (up = stride, residual = the noise_convs output), conv_pre, and `leaky_relu(0.01) -> conv_post -> tanh`. */
+int dsv_conv1d(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t rows, int32_t K,
+               int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in,
+               float divide, int32_t act, void* stream);
+
+/* noise_convs[i] (hifigan.py:124-130, :158-160): the strided Conv1d(1 -> C, kernel K, stride, padding) over the harmonic
+ * source.  har [B][LS(L_har)], w [C][K] (the torch weight [C][1][K]), bias [C] or NULL, out [B][C][LS(L_out)];
+ * L_out must equal (L_har + 2 * pad - K) / stride + 1. */
+int dsv_noise_conv(const float* har, const float* w, const float* bias, float* out, int32_t B, int32_t C, int32_t K, int32_t stride,
+                   int32_t pad, int32_t L_har, int32_t L_out, void* stream);
+
+/* torch.nn.Upsample(scale_factor = up) of f0 + SourceModuleHnNSF.forward (source.py:518-531) = SineGen.forward (:101-137,
+ * _f02sine :45-77, flag_for_pulse False) -> Linear(H, 1) -> tanh.  The module's random draws are INPUTS (the caller draws them
+ * with whatever generator it must match): rand_ini [B][H] uniform [0,1) (column 0 is ignored), noise [B][L][H] standard
+ * normal, L = T * up.  f0 [B][T] Hz (<= voiced_threshold = unvoiced), lin_w [H], lin_b [1]; sines_ws: workspace of
+ * B * H * L floats; har [B][LS(L)] = the merged harmonic source (the module's `noise` output is never used by the generator).
+ * Both cumulative sums over the sample axis accumulate in fp64, as aten's CPU cumsum does for float tensors. */
+int dsv_sine_source(const float* f0, const float* rand_ini, const float* noise, const float* lin_w, const float* lin_b, float* sines_ws,
+                    float* har, int32_t B, int32_t T, int32_t up, int32_t H, float sample_rate, float sine_amp, float noise_std,
+                    float voiced_threshold, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSV_H */

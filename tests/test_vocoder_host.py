@@ -1,0 +1,127 @@
+"""CPU: the host side of the HIP vocoder (row f2) - parameter tree, weight-norm fold, polyphase form of the transposed
+convolutions, the call sequence into include/dsv.h - checked against the oracle / the reference fixtures with the header's
+formulas standing in for the kernels (tests/voc_helpers.py).  The kernels themselves are checked on the GPU
+(tests/test_gpu_vocoder.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from diffsinger_amd import _lib
+from diffsinger_amd.vocoder import HifiGanGenerator, polyphase_weight
+from oracle import hifigan_oracle as HO
+from oracle.make_golden_hifigan import CASES, CONFIG, inputs
+from tests.voc_helpers import HeaderFormulaOps, chunked_sine, draws_like_reference
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('u,k', [(8, 16), (2, 4), (4, 8), (5, 11), (3, 9), (1, 3)])
+def test_polyphase_form_equals_conv_transpose(u, k):
+    g = torch.Generator().manual_seed(u * 100 + k)
+    ci, co, L, B = 6, 5, 19, 2
+    w = torch.randn(ci, co, k, generator=g)
+    x = torch.randn(B, ci, L, generator=g)
+    p = (k - u) // 2
+    ref = F.conv_transpose1d(x, w, None, stride=u, padding=p)
+    wp, pad = polyphase_weight(w, u, p)
+    assert wp.shape[0] == co * u and wp.shape[1] == ci
+    y = F.conv1d(F.pad(x, (pad, wp.shape[2] - 1 - pad)), wp)
+    y = y.reshape(B, co, u, L).permute(0, 1, 3, 2).reshape(B, co, L * u)
+    assert ref.shape == y.shape
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_polyphase_rejects_other_paddings():
+    with pytest.raises(NotImplementedError):
+        polyphase_weight(torch.zeros(4, 4, 16), 8, 3)
+
+
+def test_chunked_scan_reproduces_the_reference_sine_generator():
+    """The two-pass fp64 block scan of k_voc_sine (numpy model) against SineGen through the oracle: same excitation."""
+    B, T, up = 2, 24, 256
+    g = torch.Generator().manual_seed(3)
+    f0 = torch.rand(B, T, generator=g) * 300 + 80
+    f0[0, 5:9] = 0
+    f0[1, 20:] = 0
+    torch.manual_seed(11)
+    f0u = F.interpolate(f0[:, None], scale_factor=float(up), mode='nearest').transpose(1, 2)
+    sines, uv = HO.sine_gen(f0u, 24000)
+    rand_ini, noise = draws_like_reference(11, B, T * up)
+    sw = torch.from_numpy(chunked_sine(f0.numpy(), rand_ini.numpy(), up, 24000.0, 0.1)).permute(0, 2, 1)
+    namp = uv * 0.003 + (1 - uv) * 0.1 / 3
+    mine = sw * uv + namp * noise
+    assert float((mine - sines).abs().max()) < 2e-6
+
+
+def _build(case, weight_norm):
+    h = dict(CONFIG, use_pitch_embed=case['nsf'])
+    p = HO.synth_generator_params(h, case['seed'] + 1000)
+    m = HifiGanGenerator(h)
+    if weight_norm:                                                   # a checkpoint as saved: weight_g / weight_v
+        sd = {}
+        for k, v in p.items():
+            if k.endswith('.weight') and not k.startswith(('noise_convs', 'm_source')):
+                sd[k[:-7] + '.weight_v'] = v.clone()
+                sd[k[:-7] + '.weight_g'] = v.flatten(1).norm(dim=1).reshape(-1, 1, 1).clone()
+            else:
+                sd[k] = v.clone()
+        m.load_state_dict(sd, strict=True)
+        assert any(k.endswith('weight_g') for k in m.state_dict())
+    else:
+        m.load_state_dict(p, strict=True)                             # a state saved after remove_weight_norm()
+        assert not any(k.endswith('weight_g') for k in m.state_dict())
+        assert sorted(m.state_dict()) == sorted(p)
+    return h, p, m
+
+
+@pytest.mark.parametrize('name', ['hifigan_plain', 'hifigan_nsf'])
+@pytest.mark.parametrize('weight_norm', [False, True])
+def test_host_orchestration_matches_reference_fixture(name, weight_norm):
+    case = CASES[name]
+    h, p, m = _build(case, weight_norm)
+    if weight_norm:
+        m.remove_weight_norm()
+    m._ops = HeaderFormulaOps()
+    mel, f0 = inputs(case)
+    kw = {}
+    if f0 is not None:
+        kw['rand_ini'], kw['noise'] = draws_like_reference(case['seed'], case['B'], case['T'] * 256)
+    wav = m(mel, f0, **kw)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'))['wav']
+    assert wav.shape == g.shape
+    err = float(np.abs(wav.numpy() - g).max())
+    assert err < 5e-5, err
+
+
+def test_state_dict_names_match_the_reference_layout():
+    h = dict(CONFIG, use_pitch_embed=True)
+    m = HifiGanGenerator(h)
+    names = set(m.state_dict())
+    assert 'conv_pre.weight_g' in names and 'ups.3.weight_v' in names and 'resblocks.11.convs2.2.bias' in names
+    assert 'noise_convs.0.weight' in names and 'm_source.l_linear.weight' in names
+    m.remove_weight_norm()
+    assert sorted(m.state_dict()) == sorted(HO.generator_shapes(h))
+    for k, shp in HO.generator_shapes(h).items():
+        assert tuple(m.state_dict()[k].shape) == tuple(shp), k
+
+
+def test_no_cpu_path():
+    m = HifiGanGenerator(dict(CONFIG, use_pitch_embed=False))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        m(torch.zeros(1, 80, 8))
+
+
+def test_dsv_header_symbols_bound_and_exported():
+    from tests.test_abi import _header_symbols
+    assert _header_symbols('dsv.h', 'dsv_') == sorted(_lib.SYMBOLS_VOC)
+    lib = _lib.load()
+    for name in _lib.SYMBOLS_VOC:
+        assert hasattr(lib, name), name
+    assert lib.dsv_padded_samples(33) == 64
+    assert lib.dsv_packed_floats(8, 8, 11) == (1 * 1 * 11 * 64 + 8192) * 4
+    assert lib.dsv_packed_floats(512, 128, 3) == (16 * 16 * 3 * 64 + 8192) * 4
+    assert lib.dsv_conv1d(None, None, None, None, 1, 8, 8, 1, 0, 1, 8, 1, 1.0, None, None, 1.0, 0, None) == -1     # rejected before any HIP call
+    assert b'dsv_conv1d' in lib.dsd_last_error()
