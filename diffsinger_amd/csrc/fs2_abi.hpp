@@ -235,3 +235,25 @@ extern "C" int dsf_train_res_skip_bwd(const float* dx_out, const float* dskip_ou
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }
+
+// ---- PitchExtractor pieces ----------------------------------------------------------------------
+extern "C" int dsf_channel_affine(const float* x, const float* a, const float* b, const float* keep, float* y, int32_t B, int32_t C, int32_t T,
+                                  void* stream) {
+    if (!x || !a || !b || !y || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_channel_affine: bad argument");
+    const int TS = fs_ts(T);
+    const size_t n4 = (size_t)B * C * TS / 4;
+    hipLaunchKernelGGL(k_fs_affine, ew_grid(n4), dim3(256), 0, (hipStream_t)stream, (const float4*)x, a, b, keep, (float4*)y, C, T, TS, n4);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_group_norm(const float* x, const float* gamma, const float* beta, const float* residual, float* y, int32_t B, int32_t C,
+                              int32_t groups, int32_t T, float eps, int32_t relu, void* stream) {
+    if (!x || !gamma || !beta || !y) return fail(DSD_ERR_INVALID, "dsf_group_norm: null argument");
+    if (B < 1 || B > 65535 || C < 1 || groups < 1 || (C % groups) || T < 1)
+        return fail(DSD_ERR_INVALID, "dsf_group_norm: bad shape (B=%d C=%d groups=%d T=%d)", B, C, groups, T);
+    hipLaunchKernelGGL(k_fs_group_norm, dim3((unsigned)groups, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, residual, y, C, groups,
+                       T, fs_ts(T), eps, relu);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}

@@ -605,4 +605,74 @@ __global__ void k_fs_from_cm(const float* __restrict__ in, float* __restrict__ o
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// PitchExtractor pieces (modules/fastspeech/pe.py, SURVEY section 8 row f2: mel -> f0 for the NSF vocoder)
+// ------------------------------------------------------------------------------------------------------------
+// y = (x * a[c] + b[c]) * keep[b][t]: BatchNorm1d in eval mode (alpha = gamma / sqrt(var + eps), beta' = beta - mean * alpha, what aten's
+// batch_norm_cpu_transform_input evaluates) followed by Prenet's `* nonpadding_mask` (pe.py:33-35); zero tail.
+__global__ void k_fs_affine(const float4* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ keep,
+                            float4* __restrict__ y, int C, int T, int TS, size_t n4) {
+    const int q = TS / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / q;                       // bb * C + c
+        const int t = (int)(i - row * q) * 4;
+        const int c = (int)(row % C);
+        const size_t bb = row / C;
+        const float al = a[c], be = b[c];
+        const float4 v = x[i];
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r = 0.f;
+            if (t + e < T) {
+                r = o[e] * al + be;
+                if (keep) r *= keep[bb * T + t + e];
+            }
+            o[e] = r;
+        }
+        y[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__device__ __forceinline__ float fs_block_sum(float v, float* red) {     // 256 threads; every thread gets the total
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// nn.GroupNorm(G, C) over [B][C][T] (statistics over the C/G channels x T frames of a group - ALL T frames, ConvStacks applies no
+// mask, pe.py:98-108), then ReLU and the residual `x + x_` of ConvStacks.forward; one workgroup per (group, utterance); zero tail.
+__global__ __launch_bounds__(256) void k_fs_group_norm(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ res, float* __restrict__ y, int C, int G, int T, int TS, float eps,
+                                                      int relu) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, bb = blockIdx.y, tid = threadIdx.x;
+    const int cg = C / G;
+    const size_t base = ((size_t)bb * C + (size_t)g * cg) * TS;
+    const int n = cg * T;
+    float s = 0.f;
+    for (int i = tid; i < n; i += 256) { const int c = i / T, t = i - c * T; s += x[base + (size_t)c * TS + t]; }
+    const float mean = fs_block_sum(s, red) / (float)n;
+    float d = 0.f;
+    for (int i = tid; i < n; i += 256) { const int c = i / T, t = i - c * T; const float e = x[base + (size_t)c * TS + t] - mean; d += e * e; }
+    const float var = fs_block_sum(d, red) / (float)n;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const int nn = cg * TS;
+    for (int i = tid; i < nn; i += 256) {
+        const int c = i / TS, t = i - c * TS;
+        const size_t o = base + (size_t)c * TS + t;
+        float v = 0.f;
+        if (t < T) {
+            const int ch = g * cg + c;
+            v = (x[o] - mean) * rstd * gamma[ch] + beta[ch];
+            if (relu) v = fmaxf(v, 0.f);
+            if (res) v = res[o] + v;
+        }
+        y[o] = v;
+    }
+}
+
 }  // namespace dsd

@@ -94,6 +94,16 @@ int dsf_p_sample(float* x, const float* eps, const float* noise, int64_t n, floa
 int dsf_denorm_spec(const float* x, const float* mask, float* mel, const float* spec_min, const float* spec_max, int32_t B, int32_t M,
                     int32_t T, void* stream);
 
+/* PitchExtractor (modules/fastspeech/pe.py:119-148; SURVEY section 8 row f2: mel -> f0 for the NSF vocoder) beyond the operators above:
+ *   channel_affine  y = (x * a[c] + b[c]) * keep[b][t]: nn.BatchNorm1d in eval mode folded to a = gamma / sqrt(var + eps),
+ *                   b = beta - mean * a, and Prenet's `* nonpadding_mask` (pe.py:12-17, :33-35); keep may be NULL
+ *   group_norm      nn.GroupNorm(groups, C) of ConvBlock (pe.py:55-56, :72-75; statistics over C/groups channels x all T frames), then
+ *                   ReLU (relu = 1) and ConvStacks' residual `x + x_` (pe.py:105-106; residual may be NULL)
+ * x, y, residual channel-major [B][C][TS]; a, b, gamma, beta [C]. */
+int dsf_channel_affine(const float* x, const float* a, const float* b, const float* keep, float* y, int32_t B, int32_t C, int32_t T, void* stream);
+int dsf_group_norm(const float* x, const float* gamma, const float* beta, const float* residual, float* y, int32_t B, int32_t C, int32_t groups,
+                   int32_t T, float eps, int32_t relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
