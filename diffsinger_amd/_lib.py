@@ -26,7 +26,8 @@ SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf
                'dsf_channel_affine', 'dsf_group_norm']
 
 # every symbol include/dsv.h declares (the HiFi-GAN / NSF-HiFi-GAN generator ops)
-SYMBOLS_VOC = ['dsv_padded_samples', 'dsv_packed_floats', 'dsv_pack_weight', 'dsv_pad_rows', 'dsv_conv1d', 'dsv_noise_conv', 'dsv_sine_source']
+SYMBOLS_VOC = ['dsv_padded_samples', 'dsv_packed_floats', 'dsv_pack_weight', 'dsv_pad_rows', 'dsv_conv1d', 'dsv_noise_conv', 'dsv_sine_source',
+               'dsv_fold_factor', 'dsv_set_fold', 'dsv_conv1d_folded']
 
 _fp = C.POINTER(C.c_float)
 _fpp = C.POINTER(C.c_void_p)
@@ -134,6 +135,10 @@ def load():
     lib.dsv_pack_weight.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.dsv_pad_rows.argtypes = [vp, vp, i64, i32, vp]
     lib.dsv_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, f32, i32, vp]
+    lib.dsv_fold_factor.argtypes = [i32, i32, i32, i32]
+    lib.dsv_fold_factor.restype = i32
+    lib.dsv_set_fold.argtypes = [i32]
+    lib.dsv_conv1d_folded.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, f32, i32, vp]
     lib.dsv_noise_conv.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.dsv_sine_source.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, f32, vp]
     for name in SYMBOLS:

@@ -72,6 +72,61 @@ extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bi
     return DSD_OK;
 }
 
+static int g_voc_fold = -1;      // -1: read DSV_FOLD from the environment on first use (default on)
+
+extern "C" int dsv_set_fold(int32_t on) { g_voc_fold = on ? 1 : 0; return DSD_OK; }
+
+extern "C" int32_t dsv_fold_factor(int32_t Co, int32_t Ci, int32_t K, int32_t dil) {
+    if (g_voc_fold < 0) {
+        const char* e = getenv("DSV_FOLD");
+        g_voc_fold = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!g_voc_fold || Co < 1 || Ci < 1 || Ci > kFoldMaxCi || K < 1 || !(K & 1) || dil < 1) return 1;
+    const int F = (Co <= 8) ? 4 : (Co <= 16) ? 2 : 1;
+    if (F == 1) return 1;
+    const int pad = (K - 1) * dil / 2, KT = K + F - 1;
+    const int maxcol = (254 + dil) * F + dil + 30 + (KT - 1) * dil - pad;           // last LDS column a lane can read (see k_voc_conv_fold)
+    const int LD = (F == 4) ? fold_ld<4>() : fold_ld<2>();
+    if (pad > kVocHalo - 3 || maxcol >= LD) return 1;
+    return F;
+}
+
+template <int F>
+static void voc_fold_launch(const VocFoldParams& p, int B, hipStream_t s) {
+    static bool attr_done = false;
+    const size_t lds = (size_t)fold_lds_bytes<F>();
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_voc_conv_fold<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int fd = F * p.dil;
+    const int groups = (p.LS + fd - 1) / fd;
+    const int cols = groups * p.dil;
+    const dim3 grid((unsigned)((cols + kFoldCols - 1) / kFoldCols), (unsigned)B);
+    hipLaunchKernelGGL((k_voc_conv_fold<F>), grid, dim3(kThreads), lds, s, p);
+}
+
+extern "C" int dsv_conv1d_folded(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co, int32_t K,
+                                 int32_t F, int32_t dil, int32_t L, float pre_slope, const float* residual, const float* sum_in, float divide,
+                                 int32_t act, void* stream) {
+    if (!in || !wpacked || !out) return fail(DSD_ERR_INVALID, "dsv_conv1d_folded: null argument");
+    if (B < 1 || B > 65535 || L < 1 || act < 0 || act > 1 || divide == 0.f || (F != 2 && F != 4) || Co < 1 || Co * F > 32 || Ci < 1 || Ci > kFoldMaxCi ||
+        K < 1 || !(K & 1) || dil < 1)
+        return fail(DSD_ERR_INVALID, "dsv_conv1d_folded: bad shape (B=%d Ci=%d Co=%d K=%d F=%d dil=%d L=%d act=%d)", B, Ci, Co, K, F, dil, L, act);
+    const int pad = (K - 1) * dil / 2, KT = K + F - 1;
+    const int maxcol = (254 + dil) * F + dil + 30 + (KT - 1) * dil - pad;
+    if (pad > kVocHalo - 3 || maxcol >= ((F == 4) ? fold_ld<4>() : fold_ld<2>()))
+        return fail(DSD_ERR_INVALID, "dsv_conv1d_folded: kernel %d at dilation %d does not fit the staged tile (ask dsv_fold_factor first)", K, dil);
+    VocFoldParams p{};
+    p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.sum_in = sum_in;
+    p.Ci = Ci; p.Co = Co; p.KT = KT; p.pad = pad; p.dil = dil; p.L = L; p.LS = voc_ls(L);
+    p.pre_slope = pre_slope; p.divide = divide; p.act = act;
+    if (F == 4) voc_fold_launch<4>(p, B, (hipStream_t)stream);
+    else voc_fold_launch<2>(p, B, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
 extern "C" int dsv_noise_conv(const float* har, const float* w, const float* bias, float* out, int32_t B, int32_t C, int32_t K, int32_t stride,
                               int32_t pad, int32_t L_har, int32_t L_out, void* stream) {
     if (!har || !w || !out) return fail(DSD_ERR_INVALID, "dsv_noise_conv: null argument");

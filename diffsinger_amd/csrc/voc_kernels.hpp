@@ -187,6 +187,224 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Narrow layers (Co <= 16): F output samples folded into the 32 MFMA rows
+// ------------------------------------------------------------------------------------------------------------
+// With 8 (16) output channels a 32-row MFMA tile multiplies 75 % (50 %) zeros.  Here row = co * F + e computes output sample
+// pos(c) + e * dil of channel co (F = 4 for Co <= 8, 2 for Co <= 16), column c stands for the sample group
+//     pos(c) = (c / dil) * F * dil + c % dil
+// (the F * dil samples [g F dil, (g+1) F dil) are the dil phases x F steps of group g: every sample is produced exactly once),
+// and the reduction index is (ci, s) with the F shifted copies of the filter in the A operand (a banded Toeplitz block,
+// built on the host: W'[co F + e][ci][s] = w[co][ci][s - e], K' = K + F - 1 taps):
+//     out[co][pos(c) + e dil] = sum_ci sum_s W'[co F + e][ci][s] * in[ci][pos(c) + s dil - pad]
+// The MFMA count per output sample drops by F * K / (K + F - 1) (3.1x for K = 11, F = 4), all 32 rows carry work.
+// GemmPipe with a lane-specific B offset per frame block (pos is not linear in the column index once dil > 1).
+template <int NB, int LD, typename BOff>
+struct GemmPipeOff {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned aoff;
+    int n;
+    BOff bof;
+    int boff[NB];
+    float4 a[6][1];
+    float b[2][4][NB];
+
+    __device__ __forceinline__ GemmPipeOff(const float4* abase_uniform, int lane, int n_, BOff bof_, const int (&boff_)[NB])
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(abase_uniform), 0, 0x7ffffff0, 0x00020000)),
+          aoff((unsigned)lane * 16u), n(n_), bof(bof_) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) boff[nb] = boff_[nb];
+    }
+    __device__ __forceinline__ void lda(float4 (&dst)[1], int kc) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kc * (64 * 16), 0);
+        const f32x4 f = __builtin_bit_cast(f32x4, v);
+        dst[0] = make_float4(f.x, f.y, f.z, f.w);
+    }
+    __device__ __forceinline__ void ldb(float (&dst)[4][NB], int it, int u) {
+        const float* bp = bof(it, u);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) dst[s][nb] = bp[s * LD + boff[nb]];
+    }
+    __device__ __forceinline__ void pattern() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - 1 - 2 * NB, 0);
+    }
+    __device__ __forceinline__ void start() {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) lda(a[i], i);
+        DSD_SB();
+        ldb(b[0], 0, 0);
+        DSD_SB();
+    }
+    template <int I>
+    __device__ __forceinline__ void step(f32x16 (&acc)[1][NB], int it) {
+        lda(a[(I + 5) % 6], 6 * it + I + 5);
+        ldb(b[(I + 1) & 1], it, I + 1);
+        mma_chunk<1, NB>(acc, a[I % 6], b[I & 1]);
+        pattern();
+        DSD_SB();
+    }
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][NB], int end) {
+        for (int it = 0; 6 * it < end; ++it) {
+            const int kc = 6 * it;
+            step<0>(acc, it);
+            if (kc + 1 >= end) break;
+            step<1>(acc, it);
+            if (kc + 2 >= end) break;
+            step<2>(acc, it);
+            if (kc + 3 >= end) break;
+            step<3>(acc, it);
+            if (kc + 4 >= end) break;
+            step<4>(acc, it);
+            if (kc + 5 >= end) break;
+            step<5>(acc, it);
+        }
+    }
+};
+
+constexpr int kFoldCols = 256;             // columns (sample groups) per workgroup: 4 waves x 2 blocks of 32
+template <int F> constexpr int fold_ld() { return 260 * F + 80; }          // LDS row stride (bound in dsv_conv1d_folded)
+constexpr int kFoldMaxCi = 16;
+template <int F> constexpr int fold_lds_bytes() { return kFoldMaxCi * fold_ld<F>() * 4; }
+
+struct VocFoldParams {
+    const float* in;        // [B][Ci][LS]
+    const float4* wp;       // packed W' [32 rows][chunk = ci8 * KT + s][lane64] float4
+    const float* bias;      // [Co] or nullptr
+    float* out;             // [B][Co][LS]
+    const float* res;
+    const float* sum_in;
+    int Ci, Co, KT, pad, dil, L, LS;         // KT = K + F - 1 (folded taps), pad = the convolution's own padding
+    float pre_slope, divide;
+    int act;
+};
+
+struct VocFoldB {
+    const float* base;      // slab + 4 h LD + (pos(column block 0) - t_org - pad)
+    int KT, dil, n, ld8;
+    __device__ __forceinline__ const float* operator()(int it, int u) const {
+        int kc = 6 * it + u;
+        kc = (kc < n) ? kc : n - 1;
+        int g;                                  // folded tap counts of the shipped kernels 3 / 7 / 11 with F = 4 and F = 2
+        if (KT == 14) g = kc / 14;
+        else if (KT == 10) g = kc / 10;
+        else if (KT == 6) g = kc / 6;
+        else if (KT == 12) g = kc / 12;
+        else if (KT == 8) g = kc / 8;
+        else if (KT == 4) g = kc / 4;
+        else g = kc / KT;
+        const int s = kc - g * KT;
+        return base + g * ld8 + s * dil;
+    }
+};
+
+template <int F>
+__global__ __launch_bounds__(kThreads, 2) void k_voc_conv_fold(const VocFoldParams p) {
+    constexpr int NB = 2, LD = fold_ld<F>(), NCOL4 = LD / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [nc8][LD]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = blockIdx.x * kFoldCols, b = blockIdx.y;
+    const int dil = p.dil, fd = F * dil;
+    const int t_org = ((cb / dil) * fd - kVocHalo) & ~3;             // first staged sample (may be negative), 16-byte aligned
+    const int nc8 = (p.Ci + 7) / 8 * 8;
+    const float* inb = p.in + (size_t)b * p.Ci * p.LS;
+    const float slope = p.pre_slope;
+    for (int idx = tid; idx < nc8 * NCOL4; idx += kThreads) {
+        const int row = idx / NCOL4, g = idx - row * NCOL4;
+        const int t = t_org + 4 * g;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < p.Ci && t >= 0 && t < p.LS) {
+            v = *reinterpret_cast<const float4*>(inb + (size_t)row * p.LS + t);
+            v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+        }
+        *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
+    }
+    __syncthreads();
+    int pos[NB], boff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int c = cb + w * (32 * NB) + nb * 32 + j;
+        const int grp = c / dil;
+        pos[nb] = grp * fd + (c - grp * dil);
+        boff[nb] = pos[nb] - pos[0];
+    }
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+    const int nch = (nc8 / 8) * p.KT;
+    const VocFoldB bof{smem + 4 * h * LD + (pos[0] - t_org - p.pad), p.KT, dil, nch, 8 * LD};
+    GemmPipeOff<NB, LD, VocFoldB> pipe(p.wp, lane, nch, bof, boff);
+    pipe.start();
+    pipe.run(acc, nch);
+    const int Co = p.Co;
+    if (dil == 1 && F == 4) {
+        // rows 8 rg + 4 h + (0..3) = channel 2 rg + h, steps e = 0..3 = four consecutive samples from pos = 4 c: 16-byte accesses
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int co = 2 * rg + h, n = pos[nb];
+                if (co >= Co || n >= p.LS) continue;
+                const size_t o = ((size_t)b * Co + co) * p.LS + n;
+                const float bv = p.bias ? p.bias[co] : 0.f;
+                float4 v = get4(acc[0][nb], rg);
+                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                if (p.res) { const float4 r4 = *reinterpret_cast<const float4*>(p.res + o); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+                if (p.sum_in) { const float4 s4 = *reinterpret_cast<const float4*>(p.sum_in + o); v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w; }
+                if (p.divide != 1.f) { v.x = v.x / p.divide; v.y = v.y / p.divide; v.z = v.z / p.divide; v.w = v.w / p.divide; }
+                if (p.act == VOC_ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+                if (n + 0 >= p.L) v.x = 0.f;
+                if (n + 1 >= p.L) v.y = 0.f;
+                if (n + 2 >= p.L) v.z = 0.f;
+                if (n + 3 >= p.L) v.w = 0.f;
+                *reinterpret_cast<float4*>(p.out + o) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float rv[16], sv[16], bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                               // all the reads first
+            const int row = frag_row(r, h);
+            const int co = row / F, e = row - co * F;
+            const int n = pos[nb] + e * dil;
+            const bool ok = co < Co && n < p.LS;
+            const size_t o = ((size_t)b * Co + (ok ? co : 0)) * p.LS + (ok ? n : 0);
+            bv[r] = (p.bias && ok) ? p.bias[co] : 0.f;
+            rv[r] = (p.res && ok) ? p.res[o] : 0.f;
+            sv[r] = (p.sum_in && ok) ? p.sum_in[o] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = frag_row(r, h);
+            const int co = row / F, e = row - co * F;
+            const int n = pos[nb] + e * dil;
+            const bool ok = co < Co && n < p.LS;
+            float v = acc[0][nb][r] + bv[r];
+            if (p.res) v += rv[r];
+            if (p.sum_in) v = sv[r] + v;
+            if (p.divide != 1.f) v = v / p.divide;
+            if (p.act == VOC_ACT_TANH) v = tanhf(v);
+            if (ok) p.out[((size_t)b * Co + co) * p.LS + n] = (n < p.L) ? v : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // NSF harmonic source
 // ------------------------------------------------------------------------------------------------------------
 struct VocSineParams {

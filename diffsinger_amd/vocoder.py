@@ -61,6 +61,16 @@ def polyphase_weight(w: torch.Tensor, stride: int, padding: int):
     return wp.reshape(co * u, ci, kk).contiguous(), -dmin
 
 
+def fold_weight(w: torch.Tensor, F: int) -> torch.Tensor:
+    """Conv1d weight [Co][Ci][K] -> the F shifted copies dsv_conv1d_folded multiplies: W'[co * F + e][ci][s] = w[co][ci][s - e]
+    (K + F - 1 taps; row co * F + e computes the output sample e dilation steps behind the column's first one)."""
+    co, ci, k = w.shape
+    wf = torch.zeros(co, F, ci, k + F - 1, dtype=w.dtype, device=w.device)
+    for e in range(F):
+        wf[:, e, :, e:e + k] = w
+    return wf.reshape(co * F, ci, k + F - 1).contiguous()
+
+
 class _HipOps:
     """The C ABI of include/dsv.h on torch device tensors (buffers in, buffers out).  There is no other implementation in the
     package: tests swap in a torch restatement of the header's formulas to check the orchestration on CPU."""
@@ -101,6 +111,19 @@ class _HipOps:
             _lib.check(self.lib.dsv_conv1d(x.data_ptr(), wp.data_ptr(), self._p(bias), out.data_ptr(), B, ci, rows, k, pad, dil, L_in, up,
                                            float(pre_slope), self._p(residual), self._p(sum_in), float(divide), int(act), self._s(x.device)),
                        'dsv_conv1d')
+        return out
+
+    def fold_factor(self, co, ci, k, dil) -> int:
+        return int(self.lib.dsv_fold_factor(co, ci, k, dil))
+
+    def conv_folded(self, x, L, wp, bias, co, ci, k, F, dil, pre_slope=1.0, residual=None, sum_in=None, divide=1.0, act=0):
+        B = x.shape[0]
+        assert x.shape[1] == ci and x.shape[2] == padded_samples(L) and x.is_contiguous()
+        out = torch.empty(B, co, padded_samples(L), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.dsv_conv1d_folded(x.data_ptr(), wp.data_ptr(), self._p(bias), out.data_ptr(), B, ci, co, k, F, dil, L,
+                                                  float(pre_slope), self._p(residual), self._p(sum_in), float(divide), int(act),
+                                                  self._s(x.device)), 'dsv_conv1d_folded')
         return out
 
     def noise_conv(self, har, L_har, w, bias, stride, pad, L_out):
@@ -146,6 +169,9 @@ class _WNConv(nn.Module):
         if hasattr(self, 'weight_g'):
             return torch._weight_norm(self.weight_v.detach(), self.weight_g.detach(), 0)
         return self.weight.detach()
+
+    def wshape(self):
+        return tuple(self.weight_v.shape if hasattr(self, 'weight_g') else self.weight.shape)
 
     def tag(self):
         ps = ([self.weight_g, self.weight_v] if hasattr(self, 'weight_g') else [self.weight]) + [self.bias]
@@ -241,8 +267,8 @@ class HifiGanGenerator(nn.Module):
                 m.remove_weight_norm()
 
     # ---- weight preparation (cached per parameter version) ---------------------------------------------------------------
-    def _prep(self, key: str, conv: _WNConv, transposed_stride: int = 0, transposed_pad: int = 0):
-        tag = conv.tag()
+    def _prep(self, key: str, conv: _WNConv, transposed_stride: int = 0, transposed_pad: int = 0, fold: int = 1):
+        tag = conv.tag() + (fold,)
         hit = self._packed.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
@@ -250,13 +276,20 @@ class HifiGanGenerator(nn.Module):
         pad = None
         if transposed_stride:
             w, pad = polyphase_weight(w, transposed_stride, transposed_pad)
+        elif fold > 1:
+            w = fold_weight(w, fold)
         rows, ci, k = w.shape
         entry = dict(wp=self._ops.pack(w), rows=rows, ci=ci, k=k, pad=pad, bias=conv.bias.detach().to(torch.float32).contiguous())
         self._packed[key] = (tag, entry)
         return entry
 
     def _conv(self, key, conv, x, L, dil=1, **kw):
-        e = self._prep(key, conv)
+        """One 'same'-padded Conv1d with its fused neighbours; the narrow layers take the folded kernel when the library offers it."""
+        co, ci, k = conv.wshape()
+        F = self._ops.fold_factor(co, ci, k, dil)
+        e = self._prep(key, conv, fold=F)
+        if F > 1:
+            return self._ops.conv_folded(x, L, e['wp'], e['bias'], co, ci, k, F, dil, **kw)
         return self._ops.conv(x, L, e['wp'], e['bias'], e['rows'], e['ci'], e['k'], get_padding(e['k'], dil), dil, **kw)
 
     def _resblock(self, idx: int, x, L, sum_in, divide):
@@ -327,8 +360,7 @@ class HifiGanGenerator(nn.Module):
                 last = j == self.num_kernels - 1
                 acc = self._resblock(i * self.num_kernels + j, x, L, acc, float(self.num_kernels) if last else 1.0)
             x = acc
-        e = self._prep('post', self.conv_post)
-        x = ops.conv(x, L, e['wp'], e['bias'], e['rows'], e['ci'], e['k'], 3, 1, pre_slope=0.01, act=1)     # F.leaky_relu default slope, tanh
+        x = self._conv('post', self.conv_post, x, L, pre_slope=0.01, act=1)                                  # F.leaky_relu default slope, tanh
         return x[:, :, :L].contiguous()
 
 

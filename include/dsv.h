@@ -50,6 +50,21 @@ int dsv_conv1d(const float* in, const float* wpacked, const float* bias, float* 
                int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in,
                float divide, int32_t act, void* stream);
 
+/* The same convolution (up = 1, 'same' padding pad = (K-1) * dil / 2, K odd) for the NARROW layers, Co <= 16 - the 16- and 8-channel
+ * resblocks and conv_post of the shipped generator: F output samples are folded into the 32 MFMA rows so that no row multiplies
+ * zeros.  dsv_fold_factor returns the F the library wants for such a layer (4: Co <= 8, 2: Co <= 16, 1: use dsv_conv1d; also 1
+ * after dsv_set_fold(0) or with DSV_FOLD=0 in the environment - the A/B switch of the measurement).  The caller packs, with
+ * dsv_pack_weight(rows = Co * F, Ci, K + F - 1), the F shifted copies of the filter
+ *     W'[co * F + e][ci][s] = w[co][ci][s - e]   (0 <= s - e < K, else 0)
+ * and the kernel evaluates, with pos(c) = (c / dil) * F * dil + c % dil,
+ *     out[co][pos(c) + e * dil] = sum_ci sum_s W'[co * F + e][ci][s] * leaky_relu(in[ci][pos(c) + s * dil - pad])   + the same fused tail
+ * which is the convolution of dsv_conv1d sample for sample (every output sample is produced by exactly one (c, e)). */
+int32_t dsv_fold_factor(int32_t Co, int32_t Ci, int32_t K, int32_t dil);
+int dsv_set_fold(int32_t on);
+int dsv_conv1d_folded(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t Co, int32_t K,
+                      int32_t F, int32_t dil, int32_t L, float pre_slope, const float* residual, const float* sum_in, float divide,
+                      int32_t act, void* stream);
+
 /* noise_convs[i] (hifigan.py:124-130, :158-160): the strided Conv1d(1 -> C, kernel K, stride, padding) over the harmonic
  * source.  har [B][LS(L_har)], w [C][K] (the torch weight [C][1][K]), bias [C] or NULL, out [B][C][LS(L_out)];
  * L_out must equal (L_har + 2 * pad - K) / stride + 1. */

@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 import torch
 
-from diffsinger_amd.vocoder import HifiGAN, HifiGanGenerator, _HipOps, padded_samples, polyphase_weight
+from diffsinger_amd import _lib
+from diffsinger_amd.vocoder import HifiGAN, HifiGanGenerator, _HipOps, fold_weight, padded_samples, polyphase_weight
 from oracle import hifigan_oracle as HO
 from oracle.make_golden_hifigan import CASES, CONFIG, inputs
 from tests.voc_helpers import HeaderFormulaOps, draws_like_reference
@@ -62,6 +63,62 @@ def test_conv1d_matches_header_formula(c):
     err = float((got - want).abs().max())
     print('conv err', err)
     assert err < 1e-5, err
+
+
+FOLD_CASES = [
+    dict(ci=8, co=8, k=11, dil=5, L=3000, res=True, acc=True, div=3.0),                     # stage-4 resblock tail, F = 4, scattered stores
+    dict(ci=8, co=8, k=3, dil=1, L=1000, res=True),                                         # F = 4, 16-byte store path
+    dict(ci=8, co=8, k=7, dil=3, L=513),
+    dict(ci=8, co=8, k=11, dil=1, L=1025, res=True, acc=True),
+    dict(ci=16, co=16, k=11, dil=5, L=2000, res=True),                                      # F = 2
+    dict(ci=16, co=16, k=7, dil=1, L=700, res=True, acc=True, div=3.0),
+    dict(ci=16, co=16, k=3, dil=3, L=100),
+    dict(ci=8, co=1, k=7, dil=1, L=2000, slope=0.01, act=1),                                 # conv_post -> tanh
+    dict(ci=12, co=5, k=5, dil=2, L=300),                                                    # ragged channel counts, even dilation
+]
+
+
+@pytest.fixture
+def fold_on():
+    lib = _lib.load()
+    lib.dsv_set_fold(1)
+    yield lib
+    lib.dsv_set_fold(1)
+
+
+@pytest.mark.parametrize('c', FOLD_CASES, ids=lambda c: f"ci{c['ci']}co{c['co']}k{c['k']}d{c['dil']}L{c['L']}")
+def test_folded_conv_matches_the_plain_convolution(c, fold_on):
+    """dsv_conv1d_folded against the PLAIN convolution formula (original weights), not against its own folded restatement."""
+    g = torch.Generator().manual_seed(c['co'] * 1000 + c['L'])
+    B, L = 2, c['L']
+    w = torch.randn(c['co'], c['ci'], c['k'], generator=g) / (c['ci'] * c['k']) ** 0.5
+    bias = torch.randn(c['co'], generator=g)
+    x = _cm(torch.randn(B, c['ci'], L, generator=g), L)
+    res = _cm(torch.randn(B, c['co'], L, generator=g), L) if c.get('res') else None
+    acc = _cm(torch.randn(B, c['co'], L, generator=g), L) if c.get('acc') else None
+    kw = dict(pre_slope=c.get('slope', 0.1), divide=c.get('div', 1.0), act=c.get('act', 0))
+    want = HeaderFormulaOps().conv(x, L, w, bias, c['co'], c['ci'], c['k'], (c['k'] - 1) * c['dil'] // 2, c['dil'], residual=res, sum_in=acc, **kw)
+    ops = _HipOps()
+    F = ops.fold_factor(c['co'], c['ci'], c['k'], c['dil'])
+    assert F == (4 if c['co'] <= 8 else 2)
+    d = lambda t: None if t is None else t.to(DEV)
+    got = ops.conv_folded(d(x), L, ops.pack(fold_weight(w, F).to(DEV)), d(bias), c['co'], c['ci'], c['k'], F, c['dil'], residual=d(res),
+                          sum_in=d(acc), **kw).cpu()
+    assert got.shape == want.shape
+    if got.shape[2] > L:
+        assert float(got[:, :, L:].abs().max()) == 0.0
+    err = float((got - want).abs().max())
+    print('folded conv err', err)
+    assert err < 1e-5, err
+
+
+def test_fold_switch():
+    lib = _lib.load()
+    lib.dsv_set_fold(0)
+    assert lib.dsv_fold_factor(8, 8, 11, 5) == 1
+    lib.dsv_set_fold(1)
+    assert lib.dsv_fold_factor(8, 8, 11, 5) == 4 and lib.dsv_fold_factor(16, 16, 3, 1) == 2 and lib.dsv_fold_factor(32, 32, 3, 1) == 1
+    assert lib.dsv_fold_factor(8, 32, 3, 1) == 1                                             # more input channels than the folded tile stages
 
 
 @pytest.mark.parametrize('ci,co,u,k,L', [(128, 64, 8, 16, 37), (64, 32, 8, 16, 300), (32, 16, 2, 4, 1000), (16, 8, 2, 4, 3001), (24, 8, 4, 8, 100)])
@@ -142,8 +199,9 @@ def _generator(case, weight_norm=False):
 
 
 @pytest.mark.parametrize('name', ['hifigan_plain', 'hifigan_nsf'])
-@pytest.mark.parametrize('weight_norm', [False, True])
-def test_generator_matches_reference_fixture(name, weight_norm):
+@pytest.mark.parametrize('weight_norm,fold', [(False, 1), (True, 1), (False, 0)])
+def test_generator_matches_reference_fixture(name, weight_norm, fold, fold_on):
+    fold_on.dsv_set_fold(fold)                                        # narrow stages on the folded kernel (default) / on dsv_conv1d
     case = CASES[name]
     h, p, m = _generator(case, weight_norm)
     mel, f0 = inputs(case)

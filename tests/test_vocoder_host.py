@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from diffsinger_amd import _lib
-from diffsinger_amd.vocoder import HifiGanGenerator, polyphase_weight
+from diffsinger_amd.vocoder import HifiGanGenerator, fold_weight, polyphase_weight
 from oracle import hifigan_oracle as HO
 from oracle.make_golden_hifigan import CASES, CONFIG, inputs
 from tests.voc_helpers import HeaderFormulaOps, chunked_sine, draws_like_reference
@@ -32,6 +32,16 @@ def test_polyphase_form_equals_conv_transpose(u, k):
     y = y.reshape(B, co, u, L).permute(0, 1, 3, 2).reshape(B, co, L * u)
     assert ref.shape == y.shape
     torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('F,k', [(4, 11), (2, 7), (4, 3)])
+def test_fold_weight_rows_are_shifted_filters(F, k):
+    w = torch.randn(3, 5, k)
+    wf = fold_weight(w, F)
+    assert wf.shape == (3 * F, 5, k + F - 1)
+    for e in range(F):
+        assert torch.equal(wf[e::F, :, e:e + k], w)
+        assert float(wf[e::F, :, :e].abs().sum()) == 0.0 and float(wf[e::F, :, e + k:].abs().sum()) == 0.0
 
 
 def test_polyphase_rejects_other_paddings():
@@ -78,13 +88,14 @@ def _build(case, weight_norm):
 
 
 @pytest.mark.parametrize('name', ['hifigan_plain', 'hifigan_nsf'])
-@pytest.mark.parametrize('weight_norm', [False, True])
-def test_host_orchestration_matches_reference_fixture(name, weight_norm):
+@pytest.mark.parametrize('weight_norm,fold', [(False, True), (True, True), (False, False)])
+def test_host_orchestration_matches_reference_fixture(name, weight_norm, fold):
     case = CASES[name]
     h, p, m = _build(case, weight_norm)
     if weight_norm:
         m.remove_weight_norm()
     m._ops = HeaderFormulaOps()
+    m._ops.fold = fold                                                # the narrow stages through the folded formula / the plain one
     mel, f0 = inputs(case)
     kw = {}
     if f0 is not None:
@@ -124,4 +135,5 @@ def test_dsv_header_symbols_bound_and_exported():
     assert lib.dsv_packed_floats(8, 8, 11) == (1 * 1 * 11 * 64 + 8192) * 4
     assert lib.dsv_packed_floats(512, 128, 3) == (16 * 16 * 3 * 64 + 8192) * 4
     assert lib.dsv_conv1d(None, None, None, None, 1, 8, 8, 1, 0, 1, 8, 1, 1.0, None, None, 1.0, 0, None) == -1     # rejected before any HIP call
+    assert lib.dsv_fold_factor(8, 8, 11, 5) in (1, 4) and lib.dsv_fold_factor(64, 64, 11, 5) == 1
     assert b'dsv_conv1d' in lib.dsd_last_error()

@@ -46,6 +46,50 @@ class HeaderFormulaOps:
         out[:, :, :Lo] = v
         return out
 
+    fold = True                                                       # mirrors dsv_fold_factor / dsv_set_fold
+
+    def fold_factor(self, co, ci, k, dil):
+        if not self.fold or ci > 16 or (k - 1) * dil // 2 > 25:
+            return 1
+        return 4 if co <= 8 else 2 if co <= 16 else 1
+
+    def conv_folded(self, x, L, wp, bias, co, ci, k, F, dil, pre_slope=1.0, residual=None, sum_in=None, divide=1.0, act=0):
+        """The formula of dsv_conv1d_folded, literally: columns c, pos(c), the F rows per channel, gathered inputs."""
+        assert wp.shape == (co * F, ci, k + F - 1)
+        LS = padded_samples(L)
+        assert x.shape[2] == LS and float(x[:, :, L:].abs().sum()) == 0.0
+        pad, KT, fd = (k - 1) * dil // 2, k + F - 1, F * dil
+        xin = x[:, :, :L]
+        if pre_slope != 1.0:
+            xin = torch.where(xin > 0, xin, xin * pre_slope)
+        groups = (LS + fd - 1) // fd
+        c = torch.arange(groups * dil)
+        pos = (c // dil) * fd + c % dil
+        idx = pos[None, :] + (torch.arange(KT) * dil)[:, None] - pad                   # [KT][cols]
+        valid = ((idx >= 0) & (idx < L)).float()
+        xg = xin[:, :, idx.clamp(0, L - 1)] * valid                                    # [B][ci][KT][cols]
+        y = torch.einsum('rcs,bcsn->brn', wp, xg)                                      # [B][co * F][cols]
+        B = x.shape[0]
+        full = torch.zeros(B, co, groups * fd)
+        hits = torch.zeros(groups * fd)
+        for e in range(F):
+            n = pos + e * dil
+            full[:, :, n] = y[:, e::F, :]
+            hits[n] += 1
+        assert bool((hits == 1).all())                                                 # every sample produced exactly once
+        v = full[:, :, :L] + (bias[None, :, None] if bias is not None else 0.0)
+        if residual is not None:
+            v = v + residual[:, :, :L]
+        if sum_in is not None:
+            v = sum_in[:, :, :L] + v
+        if divide != 1.0:
+            v = v / divide
+        if act == 1:
+            v = torch.tanh(v)
+        out = torch.zeros(B, co, LS)
+        out[:, :, :L] = v
+        return out
+
     def noise_conv(self, har, L_har, w, bias, stride, pad, L_out):
         y = F.conv1d(har[:, None, :L_har], w[:, None, :], bias, stride=stride, padding=pad)
         assert y.shape[2] == L_out

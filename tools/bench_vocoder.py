@@ -12,7 +12,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from diffsinger_amd.vocoder import HifiGanGenerator, _HipOps, get_padding, padded_samples
+from diffsinger_amd import _lib
+from diffsinger_amd.vocoder import HifiGanGenerator, _HipOps, fold_weight, get_padding, padded_samples
 
 CONFIG = dict(resblock='1', upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=128,
               resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], audio_sample_rate=24000)
@@ -79,9 +80,20 @@ def main():
         m = m.to(dev).eval()
         mel = torch.randn(B, 80, T, device=dev)
         f0 = (torch.rand(B, T, device=dev) * 300 + 80) if nsf else None
-        sec, wav = timed(lambda: m(mel, f0), reps)
+        lib = _lib.load()
+        ri, nz = (torch.rand(B, 9, device=dev), torch.randn(B, T * 256, 9, device=dev)) if nsf else (None, None)
+
+        def run(fold):                                                # narrow stages on the folded kernel (1, default) or on k_voc_conv (0)
+            lib.dsv_set_fold(fold)
+            fixed = m(mel, f0, rand_ini=ri, noise=nz)
+            sec_, wav_ = timed(lambda: m(mel, f0), reps)
+            return sec_, wav_, fixed
+
+        sec0, _, wav0 = run(0)
+        sec, wav, wav1 = run(1)
         assert wav.shape == (B, 1, T * 256) and bool(torch.isfinite(wav).all())
-        rec = {'impl': 'HIP generator (dsv_conv1d & co.)', 'nsf': nsf, 'B': B, 'T_mel': T, 'samples': T * 256, 'ms_per_forward': sec * 1e3,
+        rec = {'impl': 'HIP generator (dsv_conv1d & co.)', 'nsf': nsf, 'ms_per_forward_narrow_layers_unfolded': sec0 * 1e3,
+               'max_abs_diff_folded_vs_unfolded': float((wav1 - wav0).abs().max()), 'B': B, 'T_mel': T, 'samples': T * 256, 'ms_per_forward': sec * 1e3,
                'mel_frames_per_s': B * T / sec, 'x_realtime_24k': B * T * 256 / 24000 / sec, 'flop_per_frame': flops_per_frame(h),
                'tflops': B * T * flops_per_frame(h) / sec / 1e12}
         if not nsf:
@@ -115,6 +127,21 @@ def main():
         print(json.dumps({'kernel': 'k_voc_conv (k=11, d=5, +residual)', 'stage': i + 1, 'channels': ch, 'samples_per_utt': L, 'ms': ms,
                           'GBps_algorithmic': byt / ms / 1e6, 'frac_hbm_8TBps': byt / ms / 1e6 / 8000, 'tflops_useful': fl / ms / 1e9,
                           'note': 'includes the torch.empty of the output and the ctypes call (eager)'}), flush=True)
+        F = ops.fold_factor(ch, ch, 11, 5)
+        if F > 1:
+            for kk, dd in ((11, 5), (11, 1), (3, 1)):
+                wf = ops.pack(fold_weight(torch.randn(ch, ch, kk, device=dev) / (ch * kk) ** 0.5, F))
+                ops.conv_folded(x, L, wf, b, ch, ch, kk, F, dd, pre_slope=0.1, residual=x)
+                ev[0].record()
+                for _ in range(20):
+                    ops.conv_folded(x, L, wf, b, ch, ch, kk, F, dd, pre_slope=0.1, residual=x)
+                ev[1].record()
+                torch.cuda.synchronize()
+                ms = ev[0].elapsed_time(ev[1]) / 20
+                fl = 2 * B * L * ch * ch * kk
+                print(json.dumps({'kernel': f'k_voc_conv_fold<{F}> (k={kk}, d={dd}, +residual)', 'stage': i + 1, 'channels': ch, 'samples_per_utt': L,
+                                  'ms': ms, 'GBps_algorithmic': byt / ms / 1e6, 'frac_hbm_8TBps': byt / ms / 1e6 / 8000,
+                                  'tflops_useful': fl / ms / 1e9}), flush=True)
 
 
 if __name__ == '__main__':

