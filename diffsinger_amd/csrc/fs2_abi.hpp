@@ -257,3 +257,26 @@ extern "C" int dsf_group_norm(const float* x, const float* gamma, const float* b
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }
+
+// ---- optimiser ---------------------------------------------------------------------------------
+extern "C" int dsf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, int64_t step, const float* grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n < 1 || step < 1) return fail(DSD_ERR_INVALID, "dsf_adamw_step: bad argument");
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return fail(DSD_ERR_INVALID, "dsf_adamw_step: ranges must be 16-byte aligned");
+    if (!(lr >= 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps >= 0))
+        return fail(DSD_ERR_INVALID, "dsf_adamw_step: bad hyper-parameters (lr=%g betas=%g,%g eps=%g)", lr, beta1, beta2, eps);
+    AdamWParams a{};
+    a.p = p; a.g = g; a.m = m; a.v = v; a.gscale = grad_scale; a.n = (size_t)n;
+    // the scalars exactly as torch.optim.AdamW forms them in double before handing them to its fp32 kernels
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    a.decay = (float)(1.0 - lr * weight_decay);
+    a.one_minus_b1 = (float)(1.0 - beta1);
+    a.b2 = (float)beta2;
+    a.one_minus_b2 = (float)(1.0 - beta2);
+    a.bc2_sqrt = (float)std::sqrt(bc2);
+    a.eps = (float)eps;
+    a.neg_step_size = (float)(-(lr / bc1));
+    hipLaunchKernelGGL(k_adamw, ew_grid((size_t)(n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}

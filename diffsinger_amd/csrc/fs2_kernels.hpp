@@ -675,4 +675,49 @@ __global__ __launch_bounds__(256) void k_fs_group_norm(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// optimiser step of the training path
+// ------------------------------------------------------------------------------------------------------------
+// torch.optim.AdamW (usr/diffspeech_task.py:40-46; amsgrad off) on ONE flat fp32 range - a rank's shard of the flattened parameters
+// after the gradient reduce-scatter - in one pass: 16 B read per moment / parameter / gradient, 12 B written back per element.
+//   g' = g * gscale[0]                   (1/world of the summed gradients times the clip_grad_norm_ coefficient; a DEVICE scalar: no host sync)
+//   p *= decay ; m += (g' - m) (1 - b1) ; v = v b2 + ((1 - b2) g') g' ; p += -step_size * (m / (sqrt(v) / bc2_sqrt + eps))
+struct AdamWParams {
+    float* p; const float* g; float* m; float* v;
+    const float* gscale;
+    size_t n;
+    float decay, one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, neg_step_size;
+};
+
+__device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, const AdamWParams& a, float gs) {
+    g = g * gs;
+    p = p * a.decay;
+    m = m + (g - m) * a.one_minus_b1;
+    v = v * a.b2 + (a.one_minus_b2 * g) * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p + a.neg_step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void k_adamw(const AdamWParams a) {
+    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    const size_t n4 = a.n / 4;
+    float4* p4 = reinterpret_cast<float4*>(a.p);
+    const float4* g4 = reinterpret_cast<const float4*>(a.g);
+    float4* m4 = reinterpret_cast<float4*>(a.m);
+    float4* v4 = reinterpret_cast<float4*>(a.v);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 p = p4[i], m = m4[i], v = v4[i];
+        const float4 g = g4[i];
+        adamw_one(p.x, g.x, m.x, v.x, a, gs); adamw_one(p.y, g.y, m.y, v.y, a, gs);
+        adamw_one(p.z, g.z, m.z, v.z, a, gs); adamw_one(p.w, g.w, m.w, v.w, a, gs);
+        p4[i] = p; m4[i] = m; v4[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {               // tail of a range that is not a multiple of 4
+        const size_t i = n4 * 4 + threadIdx.x;
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        adamw_one(p, a.g[i], m, v, a, gs);
+        a.p[i] = p; a.m[i] = m; a.v[i] = v;
+    }
+}
+
 }  // namespace dsd

@@ -62,7 +62,8 @@ class PackedWeight:
         self.buf = None
 
     def get(self, w: torch.Tensor) -> torch.Tensor:
-        tag = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+        from .train_dist import param_generation                   # raw-pointer optimiser steps do not bump torch's version counters
+        tag = (w.data_ptr(), w._version, tuple(w.shape), w.device, param_generation())
         if tag != self.tag:
             _need_hip(w, 'weight')
             lib = _lib.load()

@@ -77,7 +77,8 @@ class DiffNet(nn.Module):
 
     # -- engine management -----------------------------------------------------------------------------------
     def _tag(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        from .train_dist import param_generation                 # raw-pointer optimiser steps do not bump torch's version counters
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (param_generation(),)
 
     def engine(self) -> DenoiserEngine:
         """The per-device HIP engine, (re)packing the weights whenever a parameter tensor changed."""

@@ -65,7 +65,8 @@ class _Conv1dCM(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 # data gradient = convolution of dy with W'[ci][co][k] = W[co][ci][K-1-k] (same dilation, same padding)
                 wt = cache.get('bwd_w')
-                tag = (weight.data_ptr(), weight._version)
+                from .train_dist import param_generation
+                tag = (weight.data_ptr(), weight._version, param_generation())
                 if wt is None or cache.get('bwd_tag') != tag:
                     wt = w3.detach().flip(2).transpose(0, 1).contiguous()
                     cache['bwd_w'], cache['bwd_tag'] = wt, tag

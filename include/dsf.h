@@ -94,6 +94,14 @@ int dsf_p_sample(float* x, const float* eps, const float* noise, int64_t n, floa
 int dsf_denorm_spec(const float* x, const float* mask, float* mel, const float* spec_min, const float* spec_max, int32_t B, int32_t M,
                     int32_t T, void* stream);
 
+/* Training, the optimiser step: torch.optim.AdamW as the tasks build it (usr/diffspeech_task.py:40-46, tasks/tts/tts.py:43-49; amsgrad off)
+ * on ONE flat, 16-byte aligned fp32 range of n elements - the whole flattened parameter vector, or a rank's shard of it after the
+ * gradient reduce-scatter (diffsinger_amd/train_dist.py) - fused into one pass.  `step` is the 1-based step count (bias corrections
+ * 1 - beta^step are formed in double like torch does); grad_scale: DEVICE pointer to one float the gradient is multiplied by first
+ * (1/world * the clip_grad_norm_ coefficient, utils/pl_utils.py:1165-1168) or NULL. */
+int dsf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step, const float* grad_scale, void* stream);
+
 /* PitchExtractor (modules/fastspeech/pe.py:119-148; SURVEY section 8 row f2: mel -> f0 for the NSF vocoder) beyond the operators above:
  *   channel_affine  y = (x * a[c] + b[c]) * keep[b][t]: nn.BatchNorm1d in eval mode folded to a = gamma / sqrt(var + eps),
  *                   b = beta - mean * a, and Prenet's `* nonpadding_mask` (pe.py:12-17, :33-35); keep may be NULL
