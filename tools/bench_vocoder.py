@@ -62,10 +62,14 @@ def flops_per_frame(h):
 
 
 def main():
+    """Order: everything on the HIP kernels first (each line is flushed at once), the PyTorch-ROCm eager baseline LAST - on a fresh box its
+    first call pays MIOpen's kernel search for ~40 convolution shapes, which can take longer than the rest of this tool together."""
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     dev = torch.device('cuda', 0)
     B, T = 8, 1024
     torch.manual_seed(1)
+    lib = _lib.load()
+    plain = None
     for nsf in (False, True):
         h = dict(CONFIG, use_pitch_embed=nsf)
         m = HifiGanGenerator(h)
@@ -80,7 +84,6 @@ def main():
         m = m.to(dev).eval()
         mel = torch.randn(B, 80, T, device=dev)
         f0 = (torch.rand(B, T, device=dev) * 300 + 80) if nsf else None
-        lib = _lib.load()
         ri, nz = (torch.rand(B, 9, device=dev), torch.randn(B, T * 256, 9, device=dev)) if nsf else (None, None)
 
         def run(fold):                                                # narrow stages on the folded kernel (1, default) or on k_voc_conv (0)
@@ -92,20 +95,25 @@ def main():
         sec0, _, wav0 = run(0)
         sec, wav, wav1 = run(1)
         assert wav.shape == (B, 1, T * 256) and bool(torch.isfinite(wav).all())
-        rec = {'impl': 'HIP generator (dsv_conv1d & co.)', 'nsf': nsf, 'ms_per_forward_narrow_layers_unfolded': sec0 * 1e3,
-               'max_abs_diff_folded_vs_unfolded': float((wav1 - wav0).abs().max()), 'B': B, 'T_mel': T, 'samples': T * 256, 'ms_per_forward': sec * 1e3,
-               'mel_frames_per_s': B * T / sec, 'x_realtime_24k': B * T * 256 / 24000 / sec, 'flop_per_frame': flops_per_frame(h),
-               'tflops': B * T * flops_per_frame(h) / sec / 1e12}
+        print(json.dumps({'impl': 'HIP generator (dsv_conv1d & co.)', 'nsf': nsf, 'B': B, 'T_mel': T, 'samples': T * 256, 'ms_per_forward': sec * 1e3,
+                          'ms_per_forward_narrow_layers_unfolded': sec0 * 1e3, 'max_abs_diff_folded_vs_unfolded': float((wav1 - wav0).abs().max()),
+                          'mel_frames_per_s': B * T / sec, 'x_realtime_24k': B * T * 256 / 24000 / sec, 'flop_per_frame': flops_per_frame(h),
+                          'tflops': B * T * flops_per_frame(h) / sec / 1e12}), flush=True)
         if not nsf:
-            sd = {k: v.detach() for k, v in m.state_dict().items()}
-            with torch.no_grad():
-                sec_t, wav_t = timed(lambda: torch_generator(sd, h, mel), max(2, reps // 2))
-            rec['max_abs_diff_vs_torch_rocm'] = float((wav - wav_t).abs().max())
-            print(json.dumps({'impl': 'reference-style PyTorch-ROCm eager generator (MIOpen + ATen)', 'nsf': nsf, 'B': B, 'T_mel': T,
-                              'ms_per_forward': sec_t * 1e3, 'mel_frames_per_s': B * T / sec_t}), flush=True)
-        print(json.dumps(rec), flush=True)
+            plain = (m, h, mel, wav)
     # one resblock convolution (kernel 11, dilation 5, leaky_relu in front, residual behind) per stage: bytes = read x + read residual + write
     ops = _HipOps()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def launch_ms(fn):
+        fn()
+        ev[0].record()
+        for _ in range(20):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / 20
+
     rate = 1
     for i, u in enumerate(CONFIG['upsample_rates']):
         rate *= u
@@ -113,35 +121,31 @@ def main():
         L = T * rate
         x = torch.randn(B, ch, padded_samples(L), device=dev)
         x[:, :, L:] = 0
-        w = ops.pack(torch.randn(ch, ch, 11, device=dev) / (ch * 11) ** 0.5)
         b = torch.zeros(ch, device=dev)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        ops.conv(x, L, w, b, ch, ch, 11, 25, 5, pre_slope=0.1, residual=x)
-        ev[0].record()
-        for _ in range(20):
-            ops.conv(x, L, w, b, ch, ch, 11, 25, 5, pre_slope=0.1, residual=x)
-        ev[1].record()
-        torch.cuda.synchronize()
-        ms = ev[0].elapsed_time(ev[1]) / 20
-        byt, fl = 3 * B * ch * L * 4, 2 * B * L * ch * ch * 11
-        print(json.dumps({'kernel': 'k_voc_conv (k=11, d=5, +residual)', 'stage': i + 1, 'channels': ch, 'samples_per_utt': L, 'ms': ms,
-                          'GBps_algorithmic': byt / ms / 1e6, 'frac_hbm_8TBps': byt / ms / 1e6 / 8000, 'tflops_useful': fl / ms / 1e9,
-                          'note': 'includes the torch.empty of the output and the ctypes call (eager)'}), flush=True)
-        F = ops.fold_factor(ch, ch, 11, 5)
-        if F > 1:
-            for kk, dd in ((11, 5), (11, 1), (3, 1)):
-                wf = ops.pack(fold_weight(torch.randn(ch, ch, kk, device=dev) / (ch * kk) ** 0.5, F))
-                ops.conv_folded(x, L, wf, b, ch, ch, kk, F, dd, pre_slope=0.1, residual=x)
-                ev[0].record()
-                for _ in range(20):
-                    ops.conv_folded(x, L, wf, b, ch, ch, kk, F, dd, pre_slope=0.1, residual=x)
-                ev[1].record()
-                torch.cuda.synchronize()
-                ms = ev[0].elapsed_time(ev[1]) / 20
-                fl = 2 * B * L * ch * ch * kk
-                print(json.dumps({'kernel': f'k_voc_conv_fold<{F}> (k={kk}, d={dd}, +residual)', 'stage': i + 1, 'channels': ch, 'samples_per_utt': L,
-                                  'ms': ms, 'GBps_algorithmic': byt / ms / 1e6, 'frac_hbm_8TBps': byt / ms / 1e6 / 8000,
-                                  'tflops_useful': fl / ms / 1e9}), flush=True)
+        byt = 3 * B * ch * L * 4
+        for kk, dd in ((11, 5), (11, 1), (3, 1)):
+            wraw = torch.randn(ch, ch, kk, device=dev) / (ch * kk) ** 0.5
+            w = ops.pack(wraw)
+            pad = (kk - 1) * dd // 2
+            ms = launch_ms(lambda: ops.conv(x, L, w, b, ch, ch, kk, pad, dd, pre_slope=0.1, residual=x))
+            fl = 2 * B * L * ch * ch * kk
+            rec = {'stage': i + 1, 'channels': ch, 'samples_per_utt': L, 'k': kk, 'dil': dd, 'k_voc_conv_ms': ms,
+                   'k_voc_conv_GBps': byt / ms / 1e6, 'k_voc_conv_tflops_useful': fl / ms / 1e9}
+            F = ops.fold_factor(ch, ch, kk, dd)
+            if F > 1:
+                wf = ops.pack(fold_weight(wraw, F))
+                ms = launch_ms(lambda: ops.conv_folded(x, L, wf, b, ch, ch, kk, F, dd, pre_slope=0.1, residual=x))
+                rec.update({'fold': F, 'k_voc_conv_fold_ms': ms, 'k_voc_conv_fold_GBps': byt / ms / 1e6, 'frac_hbm_8TBps': byt / ms / 1e6 / 8000,
+                            'k_voc_conv_fold_tflops_useful': fl / ms / 1e9})
+            rec['note'] = 'per launch incl. the torch.empty of the output and the ctypes call (eager); bytes = input + residual + output'
+            print(json.dumps(rec), flush=True)
+    m, h, mel, wav = plain
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        sec_t, wav_t = timed(lambda: torch_generator(sd, h, mel), max(2, reps // 2))
+    print(json.dumps({'impl': 'reference-style PyTorch-ROCm eager generator (MIOpen + ATen)', 'nsf': False, 'B': B, 'T_mel': T,
+                      'ms_per_forward': sec_t * 1e3, 'mel_frames_per_s': B * T / sec_t,
+                      'max_abs_diff_hip_vs_torch_rocm': float((wav - wav_t).abs().max())}), flush=True)
 
 
 if __name__ == '__main__':
