@@ -39,7 +39,7 @@ def data(n):
     return torch.randn(n, 7, generator=g) * 3, torch.randn(n, 3, generator=g)
 
 
-def reference_run(n, steps, clip):
+def reference_run(n, steps, clip, return_opt=False):
     m = make_model()
     opt = torch.optim.AdamW(m.parameters(), **HP)
     sched = torch.optim.lr_scheduler.StepLR(opt, 2, gamma=0.5)
@@ -52,6 +52,8 @@ def reference_run(n, steps, clip):
         opt.step()
         opt.zero_grad()
         sched.step()
+    if return_opt:
+        return [p.detach().clone() for p in m.parameters()], [opt.state[p]['exp_avg'].clone() for p in m.parameters()]
     return [p.detach().clone() for p in m.parameters()]
 
 
@@ -87,7 +89,11 @@ def _worker(rank, world, port, n, steps, clip, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         params, opt = sharded_run(rank, world, n, steps, clip)
-        q.put((rank, [p.numpy() for p in params], float(opt.last_grad_norm) if clip else None))     # by value: the worker may exit first
+        from diffsinger_amd.ckpt import adamw_state_from_sharded
+        sd = adamw_state_from_sharded(opt)                            # collective: the moments of all shards gathered on rank 0
+        assert (sd is None) == (rank != 0)
+        moments = [sd['state'][i]['exp_avg'].numpy() for i in range(len(params))] if rank == 0 else None
+        q.put((rank, [p.numpy() for p in params], float(opt.last_grad_norm) if clip else None, moments))     # by value: the worker may exit first
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -106,8 +112,10 @@ def test_world2_matches_full_batch_adamw(clip):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    want = reference_run(n, steps, clip)
+    want, want_m = reference_run(n, steps, clip, return_opt=True)
     got.sort(key=lambda t: t[0])
+    for a, w in zip(got[0][3], want_m):                               # the gathered first moments are torch.optim.AdamW's
+        assert a.shape == tuple(w.shape) and float(abs(torch.from_numpy(a) - w).max()) < 1e-6
     for a, b in zip(got[0][1], got[1][1]):
         assert (a == b).all()                                         # every rank ends with the same parameters
     for a, w in zip(got[0][1], want):
