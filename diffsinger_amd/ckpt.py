@@ -17,7 +17,7 @@ from __future__ import annotations
 import glob
 import os
 import re
-from typing import Dict, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .fs2 import Linear, PackedWeight, PitchPredictor, _need_hip, _stream, conv1d_cm, denorm_f0, from_cm, padded_frames, to_cm
+from .fs2 import Linear, PackedWeight, PitchPredictor, _need_hip, _stream, conv1d_cm, denorm_f0, from_cm, to_cm
 from .hparams import hparams
 
 

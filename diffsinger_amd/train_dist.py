@@ -24,7 +24,6 @@ fp32 summation order; the world-2 gloo test checks that against torch.optim.Adam
 update itself: on the device it is the HIP kernel, and tests inject a torch restatement through `_update`."""
 from __future__ import annotations
 
-import math
 from typing import Callable, Iterable, Optional
 
 import torch

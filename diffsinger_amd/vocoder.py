@@ -16,7 +16,7 @@ convolutions) and the random draws of the source module.  Inference only; no CPU
 are not on the MI355X."""
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 import torch
