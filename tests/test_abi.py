@@ -50,3 +50,23 @@ def test_bad_config_is_rejected_without_a_device():
     assert lib.dsd_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1
     assert b'residual_channels' in lib.dsd_last_error()
     assert lib.dsd_create(None, 0, ctypes.byref(h)) == -1
+
+
+def test_cxx_host_example_builds_against_the_header(tmp_path):
+    """examples/dsd_example.cpp: a torch-free, Python-free host of the C ABI compiles and links against include/dsd.h + the .so
+    (and refuses to run without a device; on the GPU box tools/gpu_round2_first.sh runs it)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.isfile(hipcc):
+        import pytest
+        pytest.skip('no hipcc')
+    exe = os.path.join(tmp_path, 'dsd_example')
+    lib_dir = os.path.dirname(_lib.lib_path())
+    res = subprocess.run([hipcc, '-O1', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'dsd_example.cpp'), '-L', lib_dir,
+                          '-ldsdenoise', f'-Wl,-rpath,{lib_dir}', '-o', exe], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    import torch
+    if not torch.cuda.is_available():
+        run = subprocess.run([exe, '1', '32', '2'], capture_output=True, text=True)
+        assert run.returncode != 0 and 'hipSetDevice' in run.stderr
