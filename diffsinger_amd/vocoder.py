@@ -364,14 +364,98 @@ class HifiGanGenerator(nn.Module):
         return x[:, :, :L].contiguous()
 
 
-class HifiGAN:
-    """vocoders/hifigan.py:40-69 without the checkpoint discovery: wraps a loaded generator; spec2wav(mel [T,80], f0=[T]) -> wav [T*hop]
-    as a numpy array.  `use_nsf` mirrors hparams['use_nsf']."""
+VOCODERS = {}
 
-    def __init__(self, model: HifiGanGenerator, device='cuda', use_nsf: bool = False):
+
+def register_vocoder(cls):
+    """vocoders/base_vocoder.py:5-8."""
+    VOCODERS[cls.__name__.lower()] = cls
+    VOCODERS[cls.__name__] = cls
+    return cls
+
+
+def get_vocoder_cls(hp):
+    """vocoders/base_vocoder.py:11-19: a registered name, or a dotted `package.Class` path (the shipped configs say
+    `vocoder: vocoders.hifigan.HifiGAN`; inside the reference tree that import then finds the class `register_vocoders` rebound)."""
+    import importlib
+    if hp['vocoder'] in VOCODERS:
+        return VOCODERS[hp['vocoder']]
+    pkg, cls_name = hp['vocoder'].rsplit('.', 1)
+    if cls_name in VOCODERS and pkg in ('vocoders.hifigan', 'diffsinger_amd.vocoder'):
+        return VOCODERS[cls_name]
+    return getattr(importlib.import_module(pkg), cls_name)
+
+
+def register_vocoders(*registries, modules=()):
+    """Rebind HifiGAN in the reference's registry (vocoders.base_vocoder.VOCODERS) and, for configs that name the class by its dotted
+    path, in the modules that export it:   register_vocoders(vocoders.base_vocoder.VOCODERS, modules=[vocoders.hifigan])"""
+    for reg in registries:
+        reg['hifigan'] = reg['HifiGAN'] = HifiGAN
+    for mod in modules:
+        mod.HifiGAN = HifiGAN
+    return registries
+
+
+def load_model(config_path, checkpoint_path, device=None):
+    """vocoders/hifigan.py:17-32: (generator, config, device) from a checkpoint directory's config + weights.  `.yaml` configs hold the
+    training run's flattened hparams and the state under ['state_dict']['model_gen']; `.json` configs are the official release
+    (['generator'])."""
+    import json
+
+    import yaml
+    if device is None:
+        device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+    ckpt_dict = torch.load(checkpoint_path, map_location='cpu')
+    if '.yaml' in config_path:
+        with open(config_path) as f:
+            config = yaml.safe_load(f)
+        if config.get('base_config'):
+            raise NotImplementedError('vocoder config.yaml with a base_config chain: flatten it (the reference saves the merged hparams)')
+        state = ckpt_dict['state_dict']['model_gen']
+    elif '.json' in config_path:
+        with open(config_path) as f:
+            config = json.load(f)
+        state = ckpt_dict['generator']
+    else:
+        raise ValueError(config_path)
+    config.setdefault('use_pitch_embed', False)
+    model = HifiGanGenerator(config)
+    model.load_state_dict(state, strict=True)
+    model.remove_weight_norm()
+    model = model.eval().to(device)
+    print(f'| Loaded model parameters from {checkpoint_path}.')
+    print(f'| HifiGAN device: {device}.')
+    return model, config, device
+
+
+@register_vocoder
+class HifiGAN:
+    """vocoders/hifigan.py:40-69.  HifiGAN() discovers the checkpoint like the reference does (hparams['vocoder_ckpt']: config.yaml +
+    newest model_ckpt_steps_*.ckpt, else config.json + generator_v1) and reads hparams['use_nsf']; HifiGAN(model, device, use_nsf)
+    wraps a generator that is already loaded.  spec2wav(mel [T,80], f0=[T]) -> wav [T*hop] as a numpy array."""
+
+    def __init__(self, model: Optional[HifiGanGenerator] = None, device=None, use_nsf: Optional[bool] = None):
+        from .hparams import hparams
+        if model is None:
+            import glob
+            import os
+            import re
+            base_dir = hparams['vocoder_ckpt']
+            config_path = f'{base_dir}/config.yaml'
+            if os.path.exists(config_path):
+                ckpt = sorted(glob.glob(f'{base_dir}/model_ckpt_steps_*.ckpt'),
+                              key=lambda x: int(re.findall(rf'{re.escape(base_dir)}/model_ckpt_steps_(\d+).ckpt', x)[0]))[-1]
+                print('| load HifiGAN: ', ckpt)
+            else:
+                config_path, ckpt = f'{base_dir}/config.json', f'{base_dir}/generator_v1'
+                if not os.path.exists(config_path):
+                    raise FileNotFoundError(f'no config.yaml / config.json under {base_dir}')
+            model, self.config, device = load_model(config_path, ckpt, device)
+        if device is None:
+            device = 'cuda'
         self.model = model.eval().to(device)
         self.device = torch.device(device)
-        self.use_nsf = use_nsf
+        self.use_nsf = bool(hparams.get('use_nsf')) if use_nsf is None else use_nsf
 
     @classmethod
     def from_state_dict(cls, config: dict, state: dict, device='cuda', use_nsf: bool = False):

@@ -137,3 +137,38 @@ def test_dsv_header_symbols_bound_and_exported():
     assert lib.dsv_conv1d(None, None, None, None, 1, 8, 8, 1, 0, 1, 8, 1, 1.0, None, None, 1.0, 0, None) == -1     # rejected before any HIP call
     assert lib.dsv_fold_factor(8, 8, 11, 5) in (1, 4) and lib.dsv_fold_factor(64, 64, 11, 5) == 1
     assert b'dsv_conv1d' in lib.dsd_last_error()
+
+
+def test_vocoder_registry_and_checkpoint_discovery(tmp_path, capsys):
+    """HifiGAN() finds config.yaml + the newest model_ckpt_steps_*.ckpt under hparams['vocoder_ckpt'] like vocoders/hifigan.py:40-54,
+    loads the weight-normed `model_gen` state strictly and folds the weight norm; the registry mirrors vocoders/base_vocoder.py."""
+    import yaml
+    from diffsinger_amd import hparams
+    from diffsinger_amd import vocoder as V
+    h = dict(CONFIG, use_pitch_embed=True)
+    p = HO.synth_generator_params(h, 5)
+    sd = {}
+    for k, v in p.items():
+        if k.endswith('.weight') and not k.startswith(('noise_convs', 'm_source')):
+            sd[k[:-7] + '.weight_v'] = v.clone()
+            sd[k[:-7] + '.weight_g'] = v.flatten(1).norm(dim=1).reshape(-1, 1, 1).clone()
+        else:
+            sd[k] = v.clone()
+    with open(os.path.join(tmp_path, 'config.yaml'), 'w') as f:
+        yaml.safe_dump(h, f)
+    for step in (9000, 120000, 40000):
+        torch.save({'state_dict': {'model_gen': sd if step == 120000 else {}}}, os.path.join(tmp_path, f'model_ckpt_steps_{step}.ckpt'))
+    hparams.clear()
+    hparams.update(vocoder_ckpt=str(tmp_path), use_nsf=True, vocoder='vocoders.hifigan.HifiGAN')
+    voc = V.get_vocoder_cls(hparams)(device='cpu')
+    assert isinstance(voc, V.HifiGAN) and voc.use_nsf and voc.config['upsample_rates'] == [8, 8, 2, 2]
+    assert 'model_ckpt_steps_120000.ckpt' in capsys.readouterr().out
+    got = voc.model.state_dict()
+    assert sorted(got) == sorted(p)
+    assert float((got['ups.2.weight'] - p['ups.2.weight']).abs().max()) < 1e-6
+    assert V.VOCODERS['hifigan'] is V.HifiGAN and V.get_vocoder_cls({'vocoder': 'HifiGAN'}) is V.HifiGAN
+    reg, mod = {}, type('m', (), {})()
+    V.register_vocoders(reg, modules=[mod])
+    assert reg['HifiGAN'] is V.HifiGAN and reg['hifigan'] is V.HifiGAN and mod.HifiGAN is V.HifiGAN
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        voc.spec2wav(np.zeros((8, 80), np.float32))
