@@ -25,6 +25,7 @@ from torch import nn
 from . import _lib
 
 LRELU_SLOPE = 0.1
+MAX_REACH = 28        # kVocHalo of csrc/voc_kernels.hpp: taps may reach +-28 samples
 
 
 def padded_samples(L: int) -> int:
@@ -286,6 +287,9 @@ class HifiGanGenerator(nn.Module):
     def _conv(self, key, conv, x, L, dil=1, **kw):
         """One 'same'-padded Conv1d with its fused neighbours; the narrow layers take the folded kernel when the library offers it."""
         co, ci, k = conv.wshape()
+        if get_padding(k, dil) > MAX_REACH:
+            raise NotImplementedError(f'Conv1d kernel {k} at dilation {dil} reaches {get_padding(k, dil)} samples; the vocoder kernels stage +-{MAX_REACH} '
+                                      f'(kernel 11 at dilation 5 = 25, the shipped generators)')
         F = self._ops.fold_factor(co, ci, k, dil)
         e = self._prep(key, conv, fold=F)
         if F > 1:

@@ -172,3 +172,46 @@ def test_vocoder_registry_and_checkpoint_discovery(tmp_path, capsys):
     assert reg['HifiGAN'] is V.HifiGAN and reg['hifigan'] is V.HifiGAN and mod.HifiGAN is V.HifiGAN
     with pytest.raises(RuntimeError, match='no CPU path'):
         voc.spec2wav(np.zeros((8, 80), np.float32))
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(resblock='2', upsample_rates=[8, 8, 4], upsample_kernel_sizes=[16, 16, 8], upsample_initial_channel=64, resblock_kernel_sizes=[3, 5, 7],
+         resblock_dilation_sizes=[[1, 2], [2, 6], [3, 9]], nsf=False),                        # a "v3"-style generator: ResBlock2, hop 256 in 3 stages
+    dict(resblock='1', upsample_rates=[4, 4, 4, 2], upsample_kernel_sizes=[8, 8, 8, 4], upsample_initial_channel=256, resblock_kernel_sizes=[3, 7, 11],
+         resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], nsf=True),                # wider, hop 128, NSF
+], ids=['resblock2_hop256', 'wide_hop128_nsf'])
+def test_other_generator_configs_through_the_header_formulas(cfg):
+    """Configurations beyond the shipped configs/tts/hifigan.yaml: the orchestration (ResBlock2 wiring, other strides / widths, which
+    layers fold) against the oracle, on CPU with the header formulas standing in for the kernels."""
+    cfg = dict(cfg)
+    nsf = cfg.pop('nsf')
+    h = dict(cfg, use_pitch_embed=nsf, audio_sample_rate=24000)
+    p = HO.synth_generator_params(h, 77)
+    m = HifiGanGenerator(h)
+    m.load_state_dict(p, strict=True)
+    m._ops = HeaderFormulaOps()
+    g = torch.Generator().manual_seed(4)
+    B, T = 2, 11
+    hop = int(np.prod(cfg['upsample_rates']))
+    mel = torch.randn(B, 80, T, generator=g)
+    f0, kw = None, {}
+    if nsf:
+        f0 = torch.rand(B, T, generator=g) * 300 + 80
+        f0[1, 7:] = 0
+        kw['rand_ini'], kw['noise'] = draws_like_reference(123, B, T * hop)
+    torch.manual_seed(123)
+    with torch.no_grad():
+        want = HO.generator(p, h, mel, f0)
+    got = m(mel, f0, **kw)
+    assert got.shape == want.shape == (B, 1, T * hop)
+    assert float((got - want).abs().max()) < 5e-5
+
+
+def test_taps_beyond_the_staged_window_are_refused():
+    """The official v3 generator uses kernel 7 at dilation 12 (reach 36 > 28 staged samples): the module says so instead of being wrong."""
+    h = dict(CONFIG, resblock='2', resblock_kernel_sizes=[7], resblock_dilation_sizes=[[3, 12]], use_pitch_embed=False)
+    m = HifiGanGenerator(h)
+    m.remove_weight_norm()
+    m._ops = HeaderFormulaOps()
+    with pytest.raises(NotImplementedError, match='reaches 36'):
+        m(torch.zeros(1, 80, 4))
