@@ -24,6 +24,10 @@ The JSON line also carries
                 this box's host cores on a bounded sample of the same workload (up to all 100 steps within a
                 30 s budget; extrapolated only if the budget cuts it short - every step is identical work).
   parity        max-abs error of the de-normalised mel on the golden case generated from the reference.
+
+`--row vocoder` benches the row BEHIND the path instead (HiFi-GAN generator, 8 x 1024 mel frames -> 8 x 262 144
+samples per GPU) with the same contract: one JSON line, roofline of its dominant kernel, the CPU oracle timed beside it.  The default
+(no --row) is the headline metric above and nothing else.
 """
 from __future__ import annotations
 
@@ -145,6 +149,144 @@ def parity_check(device):
             'tolerance': 1e-4}
 
 
+VOC_CONFIG = dict(resblock='1', upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=128,
+                  resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], audio_sample_rate=24000,
+                  use_pitch_embed=False)          # configs/tts/hifigan.yaml
+PEAK_HBM_GBPS = 8000.0
+
+
+def vocoder_flop_per_frame(h) -> int:
+    c0, f, rate, ch = h['upsample_initial_channel'], 2 * 80 * h['upsample_initial_channel'] * 7, 1, 0
+    for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
+        ch = c0 // 2 ** (i + 1)
+        rate *= u
+        f += rate * 2 * (2 * ch) * ch * (k // u)
+        for kk, dd in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
+            f += rate * len(dd) * 2 * 2 * ch * ch * kk
+    return f + rate * 2 * ch * 7
+
+
+def cpu_baseline_vocoder(budget_s: float = 20.0):
+    """The generator oracle (oracle/hifigan_oracle.py = the reference's own torch arithmetic) on the host cores, one utterance of 256 mel
+    frames at a time until ~budget_s of CPU work."""
+    from oracle import hifigan_oracle as HO
+    p = HO.synth_generator_params(VOC_CONFIG, 1234)
+    T = 256
+    mel = torch.randn(1, 80, T, generator=torch.Generator().manual_seed(7))
+    avail = host_cpus()
+    cores = min(avail, 32)
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        HO.generator(p, VOC_CONFIG, mel)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            HO.generator(p, VOC_CONFIG, mel)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 64:
+                break
+    return {'value': n * T / el, 'unit': 'mel-frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} forwards of 1 x {T} mel frames (oracle/hifigan_oracle.generator, plain path) in {el:.1f}s on {cores} host threads '
+                      f'({avail} CPUs available)'}
+
+
+def main_vocoder(args):
+    """Row f2: `steps` forwards of the HIP HiFi-GAN generator over 8 x 1024 mel frames per GPU (replicas: the row has no exchange step)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    from diffsinger_amd.vocoder import HifiGanGenerator, _HipOps, fold_weight, padded_samples
+    h = VOC_CONFIG
+    m = HifiGanGenerator(h)
+    m.remove_weight_norm()
+    g = torch.Generator().manual_seed(1234)
+    with torch.no_grad():                                 # seeded fan-in scaled weights: a live signal path
+        for n, p in m.named_parameters():
+            if n.endswith('weight'):
+                p.copy_(torch.randn(p.shape, generator=g) / (p[0].numel() if not n.startswith('ups') else p.shape[0] * 2) ** 0.5)
+    m = m.to(device).eval()
+    B, T = B_PER_GPU, T_FRAMES
+    mel = torch.randn(B, 80, T, device=device, generator=torch.Generator(device=device).manual_seed(1234 + rank))
+    for _ in range(max(1, args.warmup)):
+        wav = m(mel)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = m(mel)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    elt = torch.tensor([el], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
+    el = float(elt.item())
+    assert wav.shape == (B, 1, T * 256) and bool(torch.isfinite(wav).all()), 'bad waveform'
+    if rank == 0:
+        # dominant kernel: the resblock convolutions of the 8-channel stage (18 of the 76 launches, the longest time axis).  One launch
+        # of k_voc_conv_fold<4> (kernel 11, dilation 1, leaky_relu in front, residual behind) timed with events on the launch stream.
+        ops = _HipOps()
+        ch, L = 8, T * 256
+        x = torch.randn(B, ch, padded_samples(L), device=device)
+        x[:, :, L:] = 0
+        bias = torch.zeros(ch, device=device)
+        F = ops.fold_factor(ch, ch, 11, 1)
+        wraw = torch.randn(ch, ch, 11, device=device) / (ch * 11) ** 0.5
+        if F > 1:
+            wp = ops.pack(fold_weight(wraw, F))
+            launch = lambda: ops.conv_folded(x, L, wp, bias, ch, ch, 11, F, 1, pre_slope=0.1, residual=x)
+            kname = f'k_voc_conv_fold<{F}>'
+        else:
+            wp = ops.pack(wraw)
+            launch = lambda: ops.conv(x, L, wp, bias, ch, ch, 11, 5, 1, pre_slope=0.1, residual=x)
+            kname = 'k_voc_conv<4,4>'
+        launch()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(20):
+            launch()
+        ev1.record()
+        ev1.synchronize()
+        ms = ev0.elapsed_time(ev1) / 20
+        alg_bytes = 3 * B * ch * L * 4                      # input + residual + output, once each
+        flop = 2 * B * L * ch * ch * 11
+        gbps = alg_bytes / (ms * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'kernel': kname, 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS, 'traffic': None,
+                'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms, 'flop_per_launch': flop, 'useful_tflops': flop / (ms * 1e-3) / 1e12,
+                'note': 'one resblock convolution of the 8-channel stage (kernel 11): 14.7 flop/B, so 8 TB/s of HBM bounds it at 117 TFLOP/s and the '
+                        'fp32 MFMA peak, after the (K+F-1)/K tap padding of the folded kernel, at 124 - the two roofs coincide; launch time incl. the '
+                        'torch.empty of the output and the ctypes call (eager).  No PMC pass of this kernel is committed yet'}
+        fpf = vocoder_flop_per_frame(h)
+        value = world * B * T * args.steps / el
+        res = {'metric': 'mel-frames/sec (whole node) through the HiFi-GAN generator, 80-bin mel -> 24 kHz waveform, hop 256, T=1024', 'value': value,
+               'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': f'SURVEY 8 row f2: HifiGanGenerator of configs/tts/hifigan.yaml (128 -> 8 channels, x256), batch={B} x T={T} mel '
+                                      f'frames per GPU -> {B} x {T * 256} samples', 'narrow_layers': 'folded (k_voc_conv_fold)' if F > 1 else 'unfolded',
+                          'sharding': 'replicas (no exchange step in this row)'},
+               'roofline': roof, 'model_tflops': world * B * T * fpf * args.steps / el / 1e12, 'flop_per_mel_frame': fpf,
+               'x_realtime_24k': value * 256 / 24000}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline_vocoder()
+            res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -152,7 +294,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tile', type=int, default=0, help='frames per workgroup of the layer kernel (0 auto, 32, 64)')
+    ap.add_argument('--row', choices=['path', 'vocoder'], default='path', help='path: the headline hot path (default); vocoder: SURVEY 8 row f2')
     args = ap.parse_args()
+    if args.row == 'vocoder':
+        return main_vocoder(args)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -1,0 +1,31 @@
+"""CPU: bench.py's command line (the driver's contract flags + the per-row switch) and the pieces of it that run without a device."""
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, cwd=ROOT)
+
+
+def test_flags_and_loud_failure_without_a_device():
+    r = _run('--help')
+    assert r.returncode == 0
+    for flag in ('--gpus', '--steps', '--warmup', '--row'):
+        assert flag in r.stdout
+    if not torch.cuda.is_available():
+        for extra in ([], ['--row', 'vocoder']):
+            r = _run('--steps', '1', '--warmup', '0', *extra)
+            assert r.returncode != 0 and 'needs an MI355X' in (r.stderr + r.stdout)      # no CPU fallback for the product path
+
+
+def test_vocoder_row_accounting_and_cpu_leg():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.vocoder_flop_per_frame(bench.VOC_CONFIG) == 38_510_592
+    cb = bench.cpu_baseline_vocoder(budget_s=1.0)
+    assert cb['kind'] == 'port' and cb['unit'] == 'mel-frames/s' and cb['value'] > 0 and cb['cores'] >= 1 and 'forwards' in cb['sample']
