@@ -14,6 +14,7 @@ timeout 300 python tools/bench_vocoder.py 5 > $O/vocoder.jsonl 2> $O/vocoder.err
 timeout 300 python bench.py --steps 3 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err
 timeout 200 python bench.py --row vocoder --steps 10 --warmup 2 > $O/bench_vocoder_row.json 2> $O/bench_vocoder_row.err
 /opt/rocm/bin/hipcc -O2 -I include examples/dsd_example.cpp -L diffsinger_amd -ldsdenoise -Wl,-rpath,$R/diffsinger_amd -o /tmp/dsd_example && timeout 120 /tmp/dsd_example 8 1024 100 > $O/cxx_example.json 2> $O/cxx_example.err
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_split_probe tools/mfma_split_probe.hip && timeout 60 /tmp/mfma_split_probe > $O/mfma_split_probe.jsonl 2> $O/mfma_split_probe.err
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_voc -o voc -- python $R/tools/bench_vocoder_quick.py > $O/prof_voc.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/prof_voc/*.db $O/prof_voc/*/*.db 2>/dev/null | head -1) > $O/vocoder_kernel_stats.txt 2>> $O/prof_voc.log
@@ -22,4 +23,4 @@ python $R/tools/pmc_summary.py $O/pmc_voc 'k_voc_conv_fold<4>' $O/voc_fold_pmc.t
 rm -rf $O/prof_voc
 find $O/pmc_voc -name '*.db' -delete
 du -sh $O
-tail -8 $O/pytest_gpu.txt; cat $O/cxx_example.json; cut -c1-700 $O/bench_vocoder_row.json; cut -c1-300 $O/vocoder.jsonl | head -20; cat $O/bench_n1.json | cut -c1-600; head -14 $O/vocoder_kernel_stats.txt | cut -c1-180
+tail -8 $O/pytest_gpu.txt; cat $O/cxx_example.json; cat $O/mfma_split_probe.jsonl; cut -c1-700 $O/bench_vocoder_row.json; cut -c1-300 $O/vocoder.jsonl | head -20; cat $O/bench_n1.json | cut -c1-600; head -14 $O/vocoder_kernel_stats.txt | cut -c1-180
