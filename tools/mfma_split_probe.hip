@@ -95,6 +95,23 @@ __global__ __launch_bounds__(256) void k_rate(float* out, uint64_t* cycles, int 
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// weight-stream ceiling: every workgroup (4 waves, one per SIMD) walks the SAME `bytes`-long buffer front to back, 1 KiB per wave per load
+// (lane * 16 B), `unroll` loads in flight - the access pattern of the layer kernels' A operand (all CUs of an XCD in near lock-step on
+// one weight stream).  Aggregate GB/s = what the L2s can hand the CUs for such a stream; the split scheme needs ~4x today's rate.
+__global__ __launch_bounds__(256) void k_wstream(const float4* w, float* out, size_t n4_per_wave_pass, int passes) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ps = 0; ps < passes; ++ps) {
+        const float4* base = w + (size_t)wave * n4_per_wave_pass + lane;                  // each wave its own quarter (its own rows)
+#pragma unroll 8
+        for (size_t i = 0; i < n4_per_wave_pass; i += 64) {
+            const float4 v = base[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main() {
@@ -136,6 +153,23 @@ int main() {
         const double flop_equiv = (double)blocks * 4 /*waves*/ * iters * 4 /*acc*/ * 2.0 * 32 * 32 * 16;   // fp32-equivalent FLOPs
         std::printf("{\"probe\": \"rate\", \"impl\": \"%s\", \"ms\": %.3f, \"fp32_equivalent_tflops\": %.1f, \"counter_ticks_per_K16_block_per_accumulator\": %.1f}\n",
                     rnames[mode], ms, flop_equiv / (ms * 1e-3) / 1e12, cyc / iters / 4);
+    }
+    // weight-stream ceiling: 2 MB (one layer's fp32 weights) and 3 MB (the same as three bf16 planes), 256 workgroups = one per CU
+    for (size_t mb : {2, 3}) {
+        const size_t bytes = mb << 20, n4 = bytes / 16, per_wave = n4 / 4;
+        float4* dw; CK(hipMalloc((void**)&dw, bytes)); CK(hipMemset(dw, 0, bytes));
+        const int passes = 200;
+        hipLaunchKernelGGL(k_wstream, dim3(256), dim3(256), 0, 0, dw, dout, per_wave, 2);
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_wstream, dim3(256), dim3(256), 0, 0, dw, dout, per_wave, passes);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double total = (double)bytes * passes * 256;
+        std::printf("{\"probe\": \"weight_stream\", \"buffer_MB\": %zu, \"workgroups\": 256, \"ms\": %.3f, \"aggregate_TBps\": %.2f, \"GBps_per_CU\": %.1f, "
+                    "\"note\": \"k_loop streams 2 MB per layer per CU in ~63 us (32 GB/s/CU, 8.2 TB/s aggregate); the 6-product split needs 3 MB in ~25 us (120 GB/s/CU)\"}\n",
+                    mb, ms, total / (ms * 1e-3) / 1e12, (double)bytes * passes / (ms * 1e-3) / 1e9);
+        CK(hipFree(dw));
     }
     return 0;
 }
