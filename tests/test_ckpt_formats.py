@@ -29,10 +29,10 @@ def test_save_and_load_follow_the_reference_layout(tmp_path, capsys):
     assert raw['global_step'] == 100 and all(k.startswith('model.') for k in raw['state_dict'])
     m2 = make_model()
     used = CK.load_ckpt(m2, str(tmp_path), 'model')
-    assert used.endswith('model_ckpt_steps_100.ckpt') and float(m2[0].bias[0]) == 100.0
+    assert used.endswith('model_ckpt_steps_100.ckpt') and float(m2[0].bias.detach()[0]) == 100.0
     assert "| load 'model' from" in capsys.readouterr().out
     CK.load_ckpt(m2, os.path.join(tmp_path, 'model_ckpt_steps_9.ckpt'), 'model')       # a file instead of a directory
-    assert float(m2[0].bias[0]) == 9.0
+    assert float(m2[0].bias.detach()[0]) == 9.0
 
 
 def test_missing_and_mismatched(tmp_path):
