@@ -23,7 +23,7 @@ SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf
                'dsf_to_channel_major', 'dsf_from_channel_major', 'dsf_p_sample', 'dsf_denorm_spec',
                'dsf_conv1d_dilated', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad',
                'dsf_train_add_step', 'dsf_train_rowsum', 'dsf_train_gate', 'dsf_train_gate_bwd', 'dsf_train_res_skip', 'dsf_train_res_skip_bwd',
-               'dsf_channel_affine', 'dsf_group_norm', 'dsf_adamw_step']
+               'dsf_channel_affine', 'dsf_group_norm', 'dsf_adamw_step', 'dsf_split_conv1d_probe']
 
 # every symbol include/dsv.h declares (the HiFi-GAN / NSF-HiFi-GAN generator ops)
 SYMBOLS_VOC = ['dsv_padded_samples', 'dsv_packed_floats', 'dsv_pack_weight', 'dsv_pad_rows', 'dsv_conv1d', 'dsv_noise_conv', 'dsv_sine_source',
@@ -127,6 +127,7 @@ def load():
     lib.dsf_train_res_skip.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_train_res_skip_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_adamw_step.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp, vp]
+    lib.dsf_split_conv1d_probe.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(C.c_float), vp]
     lib.dsf_channel_affine.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_group_norm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.dsv_padded_samples.argtypes = [i32]
