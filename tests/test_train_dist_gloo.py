@@ -2,7 +2,7 @@
 flat parameter / gradient buffers, gradient reduce-scatter, clip coefficient from one all-reduced float, AdamW on the rank's shard,
 parameter all-gather - against what the reference computes: torch.optim.AdamW + clip_grad_norm_ on the gradient of the FULL batch
 (= DDP's averaged gradient).  The fused HIP kernel is replaced by a torch restatement of torch.optim.AdamW's single-tensor update
-(injected through `_update`, tests only); the kernel itself is checked on the GPU (tests/test_gpu_train_dist.py)."""
+(injected through `_update`, tests only); the kernel itself is checked on the GPU (tests/test_gpu_zz_train_dist.py)."""
 import math
 import os
 import socket

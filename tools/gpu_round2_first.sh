@@ -1,5 +1,5 @@
 # GPU box, FIRST call of the next round: what round 1 wrote after its GPU minutes were spent and could not measure.
-#   1. the whole -m gpu suite (incl. tests/test_gpu_train_dist.py, marked xfail(strict=False) until this run: XPASS expected)
+#   1. the whole -m gpu suite (incl. tests/test_gpu_zz_*.py: the optimiser kernel and the split-precision prototype, marked xfail(strict=False) until this run: XPASS expected)
 #   2. the vocoder bench in full (per-stage k_voc_conv vs k_voc_conv_fold launches, NSF, PyTorch-ROCm baseline last)
 #   3. rocprofv3 kernel stats of the vocoder forward and PMC traffic of its two convolution kernels (separate --pmc pass)
 # usage: bash tools/gpu_round2_first.sh <tag>          (~4-5 GPU-minutes)
