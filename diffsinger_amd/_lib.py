@@ -127,7 +127,7 @@ def load():
     lib.dsf_train_res_skip.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_train_res_skip_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_adamw_step.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp, vp]
-    lib.dsf_split_conv1d_probe.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(C.c_float), vp]
+    lib.dsf_split_conv1d_probe.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp]
     lib.dsf_channel_affine.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_group_norm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.dsv_padded_samples.argtypes = [i32]

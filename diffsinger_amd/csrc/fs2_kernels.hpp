@@ -817,4 +817,112 @@ __global__ __launch_bounds__(kThreads, 1) void k_split_conv(const SplitConvParam
     }
 }
 
+// The same convolution with the hand-pinned operand pipeline of GemmPipe transplanted: three register stages of the weight stream (chunk
+// kc + 2 is requested while chunk kc is multiplied: 2 x 768 MFMA cycles ahead), the B fragment one chunk ahead, and inside a step the 12
+// weight loads and 3 LDS reads interleaved one-by-one behind the first MFMAs with sched_group_barrier.  Rotation period 6 (3 weight stages
+// x 2 B buffers), so chunk = 6 it + I has a compile-time tap (I % 3) and channel group 2 it + I / 3.
+struct SplitPipe {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned aoff;
+    const u16* btap[3];          // this lane's B row of tap 0 / 1 / 2 (plane 0, channel group 0)
+    uint4 a[3][4][3];
+    bf16x8_t b[2][3];
+
+    __device__ __forceinline__ SplitPipe(const uint4* wave_base, int lane, const u16* ysm, int j, int h, int dil)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u) {
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) btap[tp] = ysm + (j + kHalo + (tp - 1) * dil) * kSplitRS + 8 * h;
+    }
+    __device__ __forceinline__ void lda(uint4 (&dst)[4][3], int kc) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int kcc = (kc < 48) ? kc : 47;                              // prefetches past the end re-read the last chunk
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kcc * 12288 + (mb * 3 + pl) * 1024, 0);
+                dst[mb][pl] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+    }
+    template <int I>
+    __device__ __forceinline__ void ldb(bf16x8_t (&dst)[3], int it) {         // chunk 6 it + I
+        const int itc = (6 * it + I < 48) ? it : 7;
+        const u16* bp = btap[I % 3] + (2 * itc + I / 3) * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bp + pl * (kSplitFrames * kSplitRS)));
+    }
+    __device__ __forceinline__ void pattern() {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+    }
+    template <int I>
+    __device__ __forceinline__ void step(f32x16 (&acc)[4], int it) {
+        lda(a[(I + 2) % 3], 6 * it + I + 2);
+        if (I == 5) ldb<0>(b[0], it + 1); else ldb<(I + 1) % 6>(b[(I + 1) & 1], it);
+        constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[I % 3][mb][TI[q]]), b[I & 1][TJ[q]], acc[mb], 0, 0, 0);
+        pattern();
+        DSD_SB();
+    }
+};
+
+__global__ __launch_bounds__(kThreads, 1) void k_split_conv_p(const SplitConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) u16 ysm[];          // [3][48][264]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * 32, b = blockIdx.y;
+    SplitPipe pipe(p.wp + (size_t)w * (48 * 4 * 3 * 64), lane, ysm, j, h, p.dil);
+    pipe.lda(pipe.a[0], 0);                                            // the weight stream does not depend on the tile: request it first
+    pipe.lda(pipe.a[1], 1);
+    DSD_SB();
+    const float* inb = p.in + (size_t)b * kC * p.TS;
+    for (int idx = tid; idx < kC * (kSplitFrames / 4); idx += kThreads) {
+        const int c = idx / (kSplitFrames / 4), g = idx - c * (kSplitFrames / 4);
+        const int t = t0 - kHalo + 4 * g;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(inb + (size_t)c * p.TS + t);
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u16 a0, a1, a2;
+            split3_bf16(ve[e], a0, a1, a2);
+            const int o = (4 * g + e) * kSplitRS + c;
+            ysm[o] = a0; ysm[kSplitFrames * kSplitRS + o] = a1; ysm[2 * kSplitFrames * kSplitRS + o] = a2;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    pipe.ldb<0>(pipe.b[0], 0);
+    DSD_SB();
+    for (int it = 0; it < 8; ++it) {
+        pipe.step<0>(acc, it); pipe.step<1>(acc, it); pipe.step<2>(acc, it);
+        pipe.step<3>(acc, it); pipe.step<4>(acc, it); pipe.step<5>(acc, it);
+    }
+    const int t = t0 + j;
+    if (t < p.TS) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                p.out[((size_t)b * 512 + 128 * w + 32 * mb + frag_row(r, h)) * p.TS + t] = (t < p.T) ? acc[mb][r] : 0.f;
+    }
+}
+
 }  // namespace dsd

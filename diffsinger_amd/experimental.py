@@ -30,9 +30,9 @@ def pack_split_weight(w: torch.Tensor) -> torch.Tensor:
     return x.reshape(4, 48, 4, 3, 64, 8).contiguous()
 
 
-def split_conv1d(x_cm: torch.Tensor, wplanes: torch.Tensor, T: int, dil: int, iters: int = 1, timed: bool = False):
+def split_conv1d(x_cm: torch.Tensor, wplanes: torch.Tensor, T: int, dil: int, iters: int = 1, timed: bool = False, variant: int = 0):
     """x_cm [B][256][TS] fp32 on the device, wplanes from pack_split_weight (on the device) -> out [B][512][TS] (and the average launch
-    time in ms when timed)."""
+    time in ms when timed).  variant 0: compiler-scheduled two-stage pipeline; 1: hand-pinned three-stage operand pipeline."""
     if x_cm.device.type != 'cuda':
         raise RuntimeError('split_conv1d: no CPU path')
     lib = _lib.load()
@@ -41,6 +41,6 @@ def split_conv1d(x_cm: torch.Tensor, wplanes: torch.Tensor, T: int, dil: int, it
     out = torch.empty(B, 512, TS, device=x_cm.device, dtype=torch.float32)
     ms = C.c_float(0.0)
     with torch.cuda.device(x_cm.device):
-        _lib.check(lib.dsf_split_conv1d_probe(x_cm.data_ptr(), wplanes.data_ptr(), out.data_ptr(), B, T, dil, iters, C.byref(ms) if timed else None,
+        _lib.check(lib.dsf_split_conv1d_probe(x_cm.data_ptr(), wplanes.data_ptr(), out.data_ptr(), B, T, dil, variant, iters, C.byref(ms) if timed else None,
                                               torch.cuda.current_stream(x_cm.device).cuda_stream), 'dsf_split_conv1d_probe')
     return (out, float(ms.value)) if timed else out

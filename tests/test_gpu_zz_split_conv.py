@@ -8,8 +8,9 @@ pytestmark = [pytest.mark.gpu, pytest.mark.xfail(reason='split-precision prototy
 DEV = 'cuda:0'
 
 
+@pytest.mark.parametrize('variant', [0, 1], ids=['compiler_scheduled', 'hand_pipelined'])
 @pytest.mark.parametrize('B,T,dil', [(2, 70, 4), (3, 96, 1), (1, 200, 8)])
-def test_split_conv_is_fp32_class(B, T, dil):
+def test_split_conv_is_fp32_class(B, T, dil, variant):
     from diffsinger_amd.experimental import pack_split_weight, split_conv1d
     from diffsinger_amd.fs2 import padded_frames
     g = torch.Generator().manual_seed(T)
@@ -19,7 +20,7 @@ def test_split_conv_is_fp32_class(B, T, dil):
     x[:, :, :T] = torch.randn(B, 256, T, generator=g) * 1.5
     want = F.conv1d(x[:, :, :T].double(), w.double(), None, padding=dil, dilation=dil)
     fp32 = F.conv1d(x[:, :, :T], w, None, padding=dil, dilation=dil)
-    got = split_conv1d(x.to(DEV), pack_split_weight(w).to(DEV), T, dil).cpu()
+    got = split_conv1d(x.to(DEV), pack_split_weight(w).to(DEV), T, dil, variant=variant).cpu()
     assert float(got[:, :, T:].abs().sum()) == 0.0
     err, err32 = float((got[:, :, :T] - want).abs().max()), float((fp32 - want).abs().max())
     print(f'split conv err vs fp64 {err:.3e} (torch fp32 conv {err32:.3e})')
@@ -30,7 +31,10 @@ def test_split_conv_rate_at_the_bench_shape():
     from diffsinger_amd.experimental import pack_split_weight, split_conv1d
     w = torch.randn(512, 256, 3) * (256 * 3) ** -0.5
     x = torch.randn(8, 256, 1024, device=DEV)
-    out, ms = split_conv1d(x, pack_split_weight(w).to(DEV), 1024, 1, iters=50, timed=True)
-    tf = 2 * 512 * 768 * 8192 / (ms * 1e-3) / 1e12
-    print(f'k_split_conv: {ms * 1e3:.1f} us per launch at 8 x 1024 frames = {tf:.1f} fp32-equivalent TFLOP/s (the fp32 conv inside k_layer: ~104 k cycles, ~135 TFLOP/s)')
-    assert bool(torch.isfinite(out).all()) and ms > 0
+    wp = pack_split_weight(w).to(DEV)
+    for variant, name in ((0, 'k_split_conv (compiler-scheduled)'), (1, 'k_split_conv_p (hand-pinned pipeline)')):
+        out, ms = split_conv1d(x, wp, 1024, 1, iters=50, timed=True, variant=variant)
+        tf = 2 * 512 * 768 * 8192 / (ms * 1e-3) / 1e12
+        print(f'{name}: {ms * 1e3:.1f} us per launch at 8 x 1024 frames = {tf:.1f} fp32-equivalent TFLOP/s '
+              f'(the fp32 conv inside k_layer: ~104 k cycles = ~43 us, ~150 TFLOP/s of this shape)')
+        assert bool(torch.isfinite(out).all()) and ms > 0
