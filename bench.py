@@ -295,6 +295,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tile', type=int, default=0, help='frames per workgroup of the layer kernel (0 auto, 32, 64)')
     ap.add_argument('--row', choices=['path', 'vocoder'], default='path', help='path: the headline hot path (default); vocoder: SURVEY 8 row f2')
+    ap.add_argument('--split', action='store_true', help='EXPERIMENT: residual layers as six bf16 plane products per fp32 product (fp32-class accuracy) '
+                                                          'on the bf16 matrix pipe; per-layer kernel path; the JSON line says so in dtype / config')
     args = ap.parse_args()
     if args.row == 'vocoder':
         return main_vocoder(args)
@@ -323,6 +325,8 @@ def main():
     noise = torch.randn(K, B, 1, M, T, device=device, generator=g)
     eng = gd._engine(cond)
     eng.set_layer_tile(args.tile)
+    if args.split:
+        eng.set_split_mode(True)
 
     def step():
         mel = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
@@ -384,14 +388,18 @@ def main():
             ms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
             flop = frames * F_LAYER_EXEC
             achieved = flop / (ms * 1e-3) / 1e12
-            kname = f'k_layer<{eng.layer_tile() // 32},false>'
-            alg_bytes = frames * 6144 + 2 * 1024 * 1024
+            kname = 'k_layer_split<false>' if args.split else f'k_layer<{eng.layer_tile() // 32},false>'
+            alg_bytes = frames * 6144 + (3 if args.split else 2) * 1024 * 1024
             note = ('achieved counts executed fp32 FLOPs of one residual-layer launch (K=768 dilated conv + K=256 output projection '
                     'per frame); *_ref_accounting also credits the conditioner projection the reference recomputes every step')
+            if args.split:
+                note += ('; EXPERIMENT: every fp32 product is six bf16 plane products on v_mfma_f32_32x32x16_bf16 - peak = the dense bf16 MFMA '
+                         'peak / 6 in fp32-equivalent FLOPs')
             ref_acc = frames * F_LAYER_REF / (ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(kname, frames)
-        roof = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+        peak = 2500.0 / 6 if args.split else PEAK_FP32_MFMA_TFLOPS
+        roof = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': peak,
+                'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                 'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': ms, 'flop_per_launch': flop, 'achieved_ref_accounting': ref_acc, 'note': note}
         if persistent:                      # the per-layer kernel of the fallback path, for comparison with earlier rounds
@@ -409,7 +417,9 @@ def main():
         res = {
             'metric': 'mel-frames/sec (whole node) at K=100 DDPM, 80-bin, T=1024', 'value': value, 'unit': 'mel-frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 as 3 exact bf16 planes, 6 plane products per product, f32 accumulate (EXPERIMENT --split)' if args.split else 'f32',
+            'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: DiffSpeech 80-bin, residual_channels=256, 20 layers, K=100 DDPM, '
                                    f'batch={B} x T={T} per GPU', 'preset': PRESET, 'utterances_per_gpu': B, 'frames': T,
                        'k_step': K, 'sampler': 'ddpm', 'layer_tile_frames': eng.layer_tile(),

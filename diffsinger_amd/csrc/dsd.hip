@@ -2,6 +2,7 @@
 // sequencing of the K-step reverse loop (eager or as a cached hipGraph).  C ABI in include/dsd.h.
 #include "dsd_kernels.hpp"
 #include "dsd_loop.hpp"
+#include "dsd_split.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -107,6 +108,10 @@ struct dsd_handle {
     int loop_cap_tiles = 0;
     unsigned long long* loop_dbg = nullptr;   // debug: stamps of one phase (dsd_debug_loop_timeline)
     int loop_dbg_phase = 0;
+
+    // EXPERIMENT (dsd_split.hpp): residual layers on the bf16 matrix pipe with fp32-class accuracy; per-layer kernel path only
+    bool split_mode = false;
+    uint4 *w1s = nullptr, *w2s = nullptr;     // bf16 weight planes in 32x32x16 fragment order, [L][4][48|16][4][3][64]
 };
 
 static const int kSlack = 64;   // floats of slack in front of / behind the x buffers (masked halo loads)
@@ -170,6 +175,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);                // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_WT_STORES")) h->wt_stores = (std::atoi(ev) != 0);  // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
+    if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
         if (e > 3) { delete h; return fail(DSD_ERR_INVALID, "dsd_create: dilation 2^%d exceeds the supported maximum %d", e, kHalo); }
@@ -202,6 +208,7 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     free_workspace(h);
+    dev_free(h->w1s); dev_free(h->w2s);
     dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->bskp); dev_free(h->b2raw); dev_free(h->bsum);
     dev_free(h->winp); dev_free(h->binp); dev_free(h->wsp); dev_free(h->bsp); dev_free(h->woutp); dev_free(h->boutp);
     dev_free(h->mlp0_w); dev_free(h->mlp0_b); dev_free(h->mlp2_w); dev_free(h->mlp2_b); dev_free(h->dp_w); dev_free(h->dp_b);
@@ -227,6 +234,7 @@ extern "C" int dsd_set_layer_tile(dsd_handle* h, int32_t frames) {
 extern "C" int64_t dsd_device_bytes(dsd_handle* h) { return h ? h->bytes + h->bytes_ws : 0; }
 
 static int layer_nb(const dsd_handle* h) {
+    if (h->split_mode) return 1;               // the split-precision layer kernel exists for 32-frame tiles only
     if (h->layer_tile_req) return h->layer_tile_req / 32;
     // 32-frame workgroups until there are enough of them to keep two resident per CU on all 256 CUs; beyond
     // that 64-frame workgroups halve the weight traffic out of L2 per frame.
@@ -281,6 +289,9 @@ static int build_step_table(dsd_handle* h, int n, hipStream_t s) {
     h->n_table = n;
     return DSD_OK;
 }
+
+static void split_kernel_attrs();
+static int pack_split_planes(dsd_handle* h, hipStream_t s);
 
 extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* stream) {
     if (!h || !w) return fail(DSD_ERR_INVALID, "dsd_load_weights: null argument");
@@ -337,6 +348,7 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
     HIP_TRY(hipMemcpyAsync(h->mlp2_w, w->mlp2_w, (size_t)4 * kC * kC * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->mlp2_b, w->mlp2_b, (size_t)kC * 4, hipMemcpyDeviceToDevice, s));
     h->has_weights = true;
+    if (h->split_mode) { split_kernel_attrs(); DSD_TRY(pack_split_planes(h, s)); }
     // the step table depends on the weights: rebuild for the range already known
     const int n = std::max(h->n_table, std::max(h->n_sched, 64));
     if (h->ds_table) { h->bytes -= (int64_t)h->n_table * h->L * kC * 4; dev_free(h->ds_table); }
@@ -484,6 +496,14 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
     p.xcd_q = -1; p.xcd_r = 0;
     if (h->xcd_map) { p.xcd_q = total / 8; p.xcd_r = total % 8; grid = dim3((unsigned)total); }
     const bool last = (l == h->L - 1);
+    if (h->split_mode) {
+        p.w1p = reinterpret_cast<const float4*>(h->w1s + (size_t)l * 4 * 48 * 12 * 64);
+        p.w2p = reinterpret_cast<const float4*>(h->w2s + (size_t)l * 4 * 16 * 12 * 64);
+        if (last) hipLaunchKernelGGL((k_layer_split<true>), grid, dim3(kThreads), kSplitLayerLdsBytes, s, p);
+        else hipLaunchKernelGGL((k_layer_split<false>), grid, dim3(kThreads), kSplitLayerLdsBytes, s, p);
+        HIP_TRY(hipGetLastError());
+        return DSD_OK;
+    }
     if (nb == 1) {
         if (last) hipLaunchKernelGGL((k_layer<1, true>), grid, dim3(kThreads), layer_lds_bytes<1>(), s, p);
         else hipLaunchKernelGGL((k_layer<1, false>), grid, dim3(kThreads), layer_lds_bytes<1>(), s, p);
@@ -701,7 +721,7 @@ static void plan_evals(dsd_handle* h, int kind, int k_step, int interval, std::v
 
 // true when the prepared batch can run as the persistent loop: 32-frame tiles, a whole utterance fits the co-resident grid
 static bool loop_applicable(const dsd_handle* h) {
-    return h->loop_mode == 1 && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 && h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers;
+    return h->loop_mode == 1 && !h->split_mode && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 && h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers;
 }
 
 static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hipStream_t s) {
@@ -797,6 +817,51 @@ extern "C" int dsd_philox_normal(dsd_handle* h, uint64_t seed, int32_t step, flo
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }
+
+static void split_kernel_attrs() {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_layer_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLayerLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_layer_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLayerLdsBytes);
+        attr_done = true;
+    }
+}
+
+// bf16 weight planes of the split-precision layer kernel, derived on the device from the fp32 fragment-order weights
+static int pack_split_planes(dsd_handle* h, hipStream_t s) {
+    const int L = h->L;
+    if (!h->w1s) {
+        DSD_TRY(dev_alloc(h, &h->w1s, (size_t)L * 4 * 48 * 12 * 64 + kWeightSlack));
+        DSD_TRY(dev_alloc(h, &h->w2s, (size_t)L * 4 * 16 * 12 * 64 + kWeightSlack));
+        HIP_TRY(hipMemsetAsync(h->w1s + (size_t)L * 4 * 48 * 12 * 64, 0, (size_t)kWeightSlack * 16, s));
+        HIP_TRY(hipMemsetAsync(h->w2s + (size_t)L * 4 * 16 * 12 * 64, 0, (size_t)kWeightSlack * 16, s));
+    }
+    for (int l = 0; l < L; ++l) {
+        hipLaunchKernelGGL(k_pack_split, dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256),
+                           reinterpret_cast<su16*>(h->w1s + (size_t)l * 4 * 48 * 12 * 64), 4, 16, 3);
+        hipLaunchKernelGGL(k_pack_split, dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256),
+                           reinterpret_cast<su16*>(h->w2s + (size_t)l * 4 * 16 * 12 * 64), 4, 16, 1);
+    }
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsd_set_split_mode(dsd_handle* h, int32_t on, void* stream) {
+    if (!h || on < 0 || on > 1) return fail(DSD_ERR_INVALID, "dsd_set_split_mode: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (on && !h->split_mode) {
+        split_kernel_attrs();
+        if (h->has_weights) DSD_TRY(pack_split_planes(h, (hipStream_t)stream));
+    }
+    if ((on != 0) != h->split_mode) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        drop_graphs(h);                                   // captured graphs hold the other layer kernel
+    }
+    h->split_mode = on != 0;
+    return DSD_OK;
+}
+
+extern "C" int dsd_get_split_mode(dsd_handle* h) { return (h && h->split_mode) ? 1 : 0; }
 
 extern "C" int dsd_set_loop_mode(dsd_handle* h, int32_t mode) {
     if (!h || mode < 0 || mode > 1) return fail(DSD_ERR_INVALID, "dsd_set_loop_mode: mode must be 0 (per-layer kernels) or 1 (persistent loop)");

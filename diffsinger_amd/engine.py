@@ -107,6 +107,15 @@ class DenoiserEngine:
     def loop_mode(self) -> int:
         return self.lib.dsd_get_loop_mode(self._h)
 
+    def set_split_mode(self, on: bool):
+        """EXPERIMENT (csrc/dsd_split.hpp; default off): the residual layers as six bf16 plane products per fp32
+        product on the bf16 matrix pipe (fp32-class accuracy).  Uses the per-layer kernel path while it is on."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_set_split_mode(self._h, int(bool(on)), _stream_ptr(self.device)), 'dsd_set_split_mode')
+
+    def split_mode(self) -> int:
+        return self.lib.dsd_get_split_mode(self._h)
+
     def loop_timeouts(self) -> int:
         """Synchronises; nonzero = an inter-workgroup wait of the persistent loop hit its spin bound (results invalid)."""
         with torch.cuda.device(self.device):

@@ -148,6 +148,13 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
  * handles sampling concurrently on different streams of the same GPU must use mode 0 (one handle per device, as the reference's
  * DP / DDP runners do, is always safe). */
 int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
+
+/* EXPERIMENT (csrc/dsd_split.hpp; default off, env DSD_SPLIT=1 turns it on at creation): the residual layers on
+ * the bf16 matrix pipe with fp32-class accuracy - every fp32 operand is the exact sum of three bf16 planes, the six plane products
+ * with i + j <= 2 are accumulated in fp32 (2.7x the fp32 MFMA rate).  Applies to the per-layer kernel path (the persistent loop is
+ * bypassed while it is on, 32-frame tiles); in / head / sampler kernels are unchanged.  Enqueues the weight-plane packing on `stream`. */
+int dsd_set_split_mode(dsd_handle* h, int32_t on, void* stream);
+int dsd_get_split_mode(dsd_handle* h);
 int dsd_get_loop_mode(dsd_handle* h);
 int dsd_loop_timeouts(dsd_handle* h, void* stream);
 
