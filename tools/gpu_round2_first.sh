@@ -1,8 +1,11 @@
 # GPU box, FIRST call of the next round: what round 1 wrote after its GPU minutes were spent and could not measure.
-#   1. the whole -m gpu suite (incl. tests/test_gpu_zz_*.py: the optimiser kernel and the split-precision prototype, marked xfail(strict=False) until this run: XPASS expected)
-#   2. the vocoder bench in full (per-stage k_voc_conv vs k_voc_conv_fold launches, NSF, PyTorch-ROCm baseline last)
-#   3. rocprofv3 kernel stats of the vocoder forward and PMC traffic of its two convolution kernels (separate --pmc pass)
-# usage: bash tools/gpu_round2_first.sh <tag>          (~4-5 GPU-minutes)
+#   1. the verified -m gpu suite (113 tests), then the never-run kernels (tests/test_gpu_zz_*.py: fused AdamW, split-precision conv prototype,
+#      split-precision residual layer) with DSD_RUN_UNVERIFIED=1, one process per file
+#   2. bench.py (headline), bench.py --row vocoder (row f2 under the bench contract), bench.py --split (EXPERIMENT: layers on the bf16 pipe)
+#   3. tools/bench_vocoder.py in full (per-stage k_voc_conv vs k_voc_conv_fold launches, NSF, PyTorch-ROCm baseline last)
+#   4. the torch-free C++ host example; tools/mfma_split_probe (accuracy / matrix-pipe rate / weight-stream ceiling of the split scheme)
+#   5. rocprofv3 kernel stats of the vocoder forward and a PMC pass over its folded convolution kernel (separate --pmc run)
+# usage: bash tools/gpu_round2_first.sh <tag>          (~6-8 GPU-minutes)
 set -x
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=${1:-r02a}
