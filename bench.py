@@ -25,7 +25,8 @@ The JSON line also carries
                 30 s budget; extrapolated only if the budget cuts it short - every step is identical work).
   parity        max-abs error of the de-normalised mel on the golden case generated from the reference.
 
-`--row vocoder` benches the row BEHIND the path instead (HiFi-GAN generator, 8 x 1024 mel frames -> 8 x 262 144
+`--row vocoder` / `--row train` bench a row AROUND the path instead (f2 below; f3: one p_losses forward + backward of the denoiser,
+8 x 1024 frames per GPU, CPU autograd on the oracle beside it).  `--row vocoder` benches the row BEHIND the path (HiFi-GAN generator, 8 x 1024 mel frames -> 8 x 262 144
 samples per GPU) with the same contract: one JSON line, roofline of its dominant kernel, the CPU oracle timed beside it.  The default
 (no --row) is the headline metric above and nothing else.
 """
@@ -287,6 +288,139 @@ def main_vocoder(args):
         dist.destroy_process_group()
 
 
+F_TRAIN_FWD = 26_427_392                                   # GEMM FLOP / frame of one DiffNet forward in training (conditioner projection not hoisted)
+
+
+def cpu_baseline_train(budget_s: float = 20.0):
+    """torch autograd on the oracle (the reference's own arithmetic and graph) on the host cores: p_losses forward + backward on
+    1 x 256 frames at a time until ~budget_s."""
+    from oracle import diffnet_oracle as O
+    from diffsinger_amd.synth import presets
+    pre = presets()[PRESET]
+    cfg = O.NetConfig(80, 256, 256, 20, 1)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.init_diffnet_params(cfg, 1234, 0.02).items()}
+    sch = O.make_schedule(O.linear_beta_schedule(pre['timesteps'], pre['max_beta']))
+    g = torch.Generator().manual_seed(7)
+    B, T = 1, 256
+    x0 = torch.clamp(torch.randn(B, 1, 80, T, generator=g) * 0.5, -1, 1)
+    noise = torch.randn(B, 1, 80, T, generator=g)
+    cond = torch.randn(B, 256, T, generator=g)
+    t = torch.tensor([37])
+    avail = host_cpus()
+    cores = min(avail, 32)
+    torch.set_num_threads(cores)
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        loss = (noise - O.diffnet_forward(p, cfg, O.q_sample(sch, x0, t, noise), t, cond)).abs().mean()
+        loss.backward()
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {'value': n * B * T / el, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} p_losses forward + backward steps of {B} x {T} frames (torch autograd on oracle/diffnet_oracle.py) in {el:.1f}s on {cores} host '
+                      f'threads ({avail} CPUs available)'}
+
+
+def main_train(args):
+    """Row f3: `steps` x (q_sample + DiffNet forward + L1 + backward) on the HIP training operators, 8 x 1024 frames per GPU (no optimiser,
+    no gradient exchange: replicas)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    gd, pre = build_model(device)
+    gd.train()
+    net = gd.denoise_fn
+    B, T = B_PER_GPU, T_FRAMES
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    x0 = torch.randn(B, 1, 80, T, device=device, generator=g).clamp(-1, 1)
+    cond = torch.randn(B, T, 256, device=device, generator=g).transpose(1, 2)
+    t = torch.randint(0, K_STEPS, (B,), device=device, generator=g)
+    noise = torch.randn(B, 1, 80, T, device=device, generator=g)
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        loss = gd.p_losses(x0, t, cond, noise=noise)
+        loss.backward()
+        return loss
+
+    for _ in range(max(1, args.warmup)):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    elt = torch.tensor([el], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
+    el = float(elt.item())
+    assert bool(torch.isfinite(loss)), 'non-finite loss'
+    if rank == 0:
+        # dominant kernel: k_fs_conv<2> as the dilated convolution (256 -> 512, k = 3), forward; one launch timed with events on the launch stream
+        from diffsinger_amd.fs2 import PackedWeight, padded_frames
+        from diffsinger_amd import _lib
+        lib = _lib.load()
+        w = torch.randn(512, 256, 3, device=device) * (256 * 3) ** -0.5
+        x = torch.randn(B, 256, padded_frames(T), device=device)
+        out = torch.empty(B, 512, padded_frames(T), device=device)
+        wp = PackedWeight().get(w)
+        sptr = torch.cuda.current_stream(device).cuda_stream
+        launch = lambda: _lib.check(lib.dsf_conv1d_dilated(x.data_ptr(), wp.data_ptr(), None, out.data_ptr(), B, 256, 512, 3, 1, T, sptr), 'dsf_conv1d_dilated')
+        launch()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(20):
+            launch()
+        ev1.record()
+        ev1.synchronize()
+        ms = ev0.elapsed_time(ev1) / 20
+        flop = 2 * 512 * 768 * B * T
+        achieved = flop / (ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': 'k_fs_conv<2>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_launch_ms': ms, 'flop_per_launch': flop,
+                'algorithmic_bytes_per_launch': 4 * B * T * (256 + 512) + 4 * 512 * 768,
+                'note': 'the dilated convolution of one residual block, forward (its data gradient is the same kernel with the flipped, transposed weight); '
+                        'eager launch incl. the ctypes call.  No PMC pass of this kernel is committed yet'}
+        value = world * B * T * args.steps / el
+        res = {'metric': 'frames/sec (whole node) through one denoiser training step: q_sample + DiffNet forward + L1 + backward, T=1024', 'value': value,
+               'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': f'SURVEY 8 row f3: GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:213-231) of the DiffSpeech denoiser, '
+                                      f'batch={B} x T={T} per GPU, forward + backward on the HIP training operators', 'preset': PRESET,
+                          'optimizer': 'not included (diffsinger_amd/train_dist.py)', 'sharding': 'replicas (no gradient exchange in this bench)'},
+               'roofline': roof, 'model_tflops_gemm': world * B * T * 3 * F_TRAIN_FWD * args.steps / el / 1e12}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline_train()
+            res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -294,12 +428,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tile', type=int, default=0, help='frames per workgroup of the layer kernel (0 auto, 32, 64)')
-    ap.add_argument('--row', choices=['path', 'vocoder'], default='path', help='path: the headline hot path (default); vocoder: SURVEY 8 row f2')
+    ap.add_argument('--row', choices=['path', 'vocoder', 'train'], default='path',
+                    help='path: the headline hot path (default); vocoder: SURVEY 8 row f2; train: row f3 (denoiser p_losses forward + backward)')
     ap.add_argument('--split', action='store_true', help='EXPERIMENT: residual layers as six bf16 plane products per fp32 product (fp32-class accuracy) '
                                                           'on the bf16 matrix pipe; per-layer kernel path; the JSON line says so in dtype / config')
     args = ap.parse_args()
     if args.row == 'vocoder':
         return main_vocoder(args)
+    if args.row == 'train':
+        return main_train(args)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
