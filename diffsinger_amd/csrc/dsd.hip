@@ -863,6 +863,28 @@ extern "C" int dsd_set_split_mode(dsd_handle* h, int32_t on, void* stream) {
 
 extern "C" int dsd_get_split_mode(dsd_handle* h) { return (h && h->split_mode) ? 1 : 0; }
 
+// Debug hook: ONE residual layer (the fp32 kernel, or the split-precision one while that mode is on) on a caller-supplied input, results
+// in logical layout - for layer-level parity tests and error localisation.  x_in / x_out / skip_out: DEVICE [B][C][TS] (TS = T up to 32;
+// x_out is not written for the last layer).  Uses the prepared batch's cp; overwrites the handle's x and skip work buffers.
+extern "C" int dsd_debug_layer(dsd_handle* h, int32_t layer, int32_t t, const float* x_in, float* x_out, float* skip_out, void* stream) {
+    DSD_TRY(check_ready(h, "dsd_debug_layer", false));
+    if (!x_in || !skip_out || layer < 0 || layer >= h->L || t < 0 || (!x_out && layer != h->L - 1))
+        return fail(DSD_ERR_INVALID, "dsd_debug_layer: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    DSD_TRY(build_step_table(h, t + 1, s));
+    float* xin = (layer & 1) ? h->xb : h->xa;
+    float* xout = (layer & 1) ? h->xa : h->xb;
+    hipLaunchKernelGGL(k_dbg_to_tiles, dim3((unsigned)h->ntiles), dim3(256), 0, s, x_in, xin, h->TS, h->ntile32, 1);
+    HIP_TRY(hipMemsetAsync(h->skip, 0, (size_t)h->ntiles * 2048 * sizeof(float4), s));
+    DSD_TRY(launch_layer(h, layer, t, nullptr, s));
+    if (x_out && layer != h->L - 1)
+        hipLaunchKernelGGL(k_dbg_to_tiles, dim3((unsigned)h->ntiles), dim3(256), 0, s, x_out, xout, h->TS, h->ntile32, 0);
+    hipLaunchKernelGGL(k_dbg_skip_to_logical, dim3((unsigned)h->ntiles), dim3(256), 0, s, h->skip, skip_out, h->TS, h->ntile32);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
 extern "C" int dsd_set_loop_mode(dsd_handle* h, int32_t mode) {
     if (!h || mode < 0 || mode > 1) return fail(DSD_ERR_INVALID, "dsd_set_loop_mode: mode must be 0 (per-layer kernels) or 1 (persistent loop)");
     h->loop_mode = mode;

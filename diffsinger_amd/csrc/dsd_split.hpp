@@ -335,4 +335,27 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer_split(const LayerParams p
     }
 }
 
+// ---- debug plumbing (dsd_debug_layer): logical [B][C][TS] <-> the layer kernels' images ------------------------------------------------
+// x: tile-major [tile = b * ntile32 + tn][C][32]
+__global__ void k_dbg_to_tiles(const float* __restrict__ x, float* __restrict__ xt, int TS, int ntile32, int to_tiles) {
+    const int tile = blockIdx.x, b = tile / ntile32, tn = tile - b * ntile32;
+    for (int idx = threadIdx.x; idx < kC * 32; idx += blockDim.x) {
+        const int c = idx >> 5, f = idx & 31;
+        const size_t lo = ((size_t)b * kC + c) * TS + tn * 32 + f, ti = (size_t)tile * kC * 32 + idx;
+        if (to_tiles) xt[ti] = x[lo]; else const_cast<float*>(x)[lo] = xt[ti];
+    }
+}
+// skip sum: fragment order [tile][wave 4][ms 2][q 4][lane 64] float4 -> logical; element (q, lane = (j, h), s) is channel
+// 64 w + 32 ms + frag_row(4 q + s, h) at frame j
+__global__ void k_dbg_skip_to_logical(const float4* __restrict__ skip, float* __restrict__ out, int TS, int ntile32) {
+    const int tile = blockIdx.x, b = tile / ntile32, tn = tile - b * ntile32;
+    for (int idx = threadIdx.x; idx < 4 * 2 * 4 * 64; idx += blockDim.x) {
+        const int lane = idx & 63, q = (idx >> 6) & 3, ms = (idx >> 8) & 1, w = idx >> 9;
+        const float4 v = skip[(size_t)tile * 2048 + idx];
+        const int j = lane & 31, h = lane >> 5;
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+        for (int e = 0; e < 4; ++e) out[((size_t)b * kC + 64 * w + 32 * ms + frag_row(4 * q + e, h)) * TS + tn * 32 + j] = ve[e];
+    }
+}
+
 }  // namespace dsd

@@ -116,6 +116,21 @@ class DenoiserEngine:
     def split_mode(self) -> int:
         return self.lib.dsd_get_split_mode(self._h)
 
+    def debug_layer(self, layer: int, t: int, x_in: torch.Tensor):
+        """Debug: one residual layer on x_in [B,C,T] with the prepared batch's conditioner projection -> (x_out [B,C,T] or None for the
+        last layer, skip [B,C,T]).  The fp32 kernel, or the split-precision one while set_split_mode(True)."""
+        B, Cc, T = x_in.shape
+        TS = (T + 31) // 32 * 32
+        xi = torch.zeros(B, Cc, TS, device=self.device, dtype=torch.float32)
+        xi[:, :, :T] = x_in
+        xo = torch.zeros_like(xi)
+        sk = torch.zeros_like(xi)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_debug_layer(self._h, int(layer), int(t), xi.data_ptr(), xo.data_ptr(), sk.data_ptr(), _stream_ptr(self.device)),
+                       'dsd_debug_layer')
+        last = layer == self.L - 1
+        return (None if last else xo[:, :, :T]), sk[:, :, :T]
+
     def loop_timeouts(self) -> int:
         """Synchronises; nonzero = an inter-workgroup wait of the persistent loop hit its spin bound (results invalid)."""
         with torch.cuda.device(self.device):

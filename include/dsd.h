@@ -155,6 +155,12 @@ int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
  * bypassed while it is on, 32-frame tiles); in / head / sampler kernels are unchanged.  Enqueues the weight-plane packing on `stream`. */
 int dsd_set_split_mode(dsd_handle* h, int32_t on, void* stream);
 int dsd_get_split_mode(dsd_handle* h);
+
+/* Debug hook: ONE residual layer (usr/diff/net.py:66-78; the fp32 kernel, or the split-precision one while that mode is on) on a
+ * caller-supplied input with the prepared batch's conditioner projection and step t, results in logical layout - layer-level parity
+ * tests and error localisation.  x_in, x_out, skip_out: DEVICE [B][C][TS], TS = T rounded up to 32 (x_out may be NULL for the last
+ * layer, which computes skips only).  Overwrites the handle's x / skip work buffers. */
+int dsd_debug_layer(dsd_handle* h, int32_t layer, int32_t t, const float* x_in, float* x_out, float* skip_out, void* stream);
 int dsd_get_loop_mode(dsd_handle* h);
 int dsd_loop_timeouts(dsd_handle* h, void* stream);
 

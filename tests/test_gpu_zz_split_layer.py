@@ -23,6 +23,43 @@ def test_golden_cases_with_split_layers(name, tol):
     assert e_split < tol
 
 
+@pytest.mark.parametrize('layer', [0, 3, 19])
+def test_one_layer_against_the_oracle_layer_fp32_and_split(layer):
+    """Layer-level parity through dsd_debug_layer: the verified fp32 kernel (this also validates the debug plumbing) and the split kernel
+    against the oracle's residual layer on the same x, cond and step; on a mismatch the per-row-block / per-frame-column error table says
+    where (which wave's rows, interior vs halo columns)."""
+    from oracle import diffnet_oracle as O
+    pre = H.presets()['lj_ds_beta6']
+    cfg = H.net_config(pre)
+    gd, _, _ = build_hip('lj_ds_beta6', 100)
+    p = {k: v.detach().cpu() for k, v in gd.denoise_fn.state_dict().items()}
+    g = torch.Generator().manual_seed(layer)
+    B, T, t = 2, 100, 37
+    x = torch.randn(B, 256, T, generator=g)
+    cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
+    with torch.no_grad():
+        d_emb = O.step_mlp(p, cfg, torch.full((B,), t))
+        want_x, want_skip = O.residual_layer(p, cfg, layer, x, cond, d_emb)
+    want_skip = want_skip - p[f'residual_layers.{layer}.output_projection.bias'][256:, None]       # the kernels add the skip biases once, in the head
+    eng = gd._engine(cond.cuda())
+    eng.prepare(cond.cuda())
+    eng.set_loop_mode(0)
+    for split in (False, True):
+        eng.set_split_mode(split)
+        xo, sk = eng.debug_layer(layer, t, x.cuda())
+        errs = {'skip': (sk.cpu() - want_skip).abs()}
+        if xo is not None:
+            errs['x_out'] = (xo.cpu() - want_x).abs()
+        for name, e in errs.items():
+            worst = float(e.max())
+            per_rb = e.reshape(B, 8, 32, T).amax(dim=(0, 2, 3)).tolist()
+            per_col = e.amax(dim=(0, 1))
+            print(f'layer {layer} {"split" if split else "fp32 "} {name}: max {worst:.3e}; per 32-row block {[f"{v:.1e}" for v in per_rb]}; '
+                  f'first/last tile columns {float(per_col[:8].max()):.1e} / {float(per_col[-8:].max()):.1e}')
+            assert worst < 2e-5, (name, split, worst)
+    eng.set_split_mode(False)
+
+
 def test_split_layer_launch_time_next_to_fp32():
     gd, _, _ = build_hip('lj_ds_beta6', 100)
     g = torch.Generator().manual_seed(1)
