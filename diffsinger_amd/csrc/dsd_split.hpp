@@ -26,6 +26,7 @@ constexpr int kSpRS = 264;                              // bf16 per frame row: 2
 constexpr int kSpYFrames = 32 + 2 * kHalo;              // 48
 constexpr int kSpYPlane = kSpYFrames * kSpRS;           // elements per y plane
 constexpr int kSpGPlane = 32 * kSpRS;                   // elements per gate plane
+constexpr int kSplitStages1 = 6;                        // weight-stream register stages of the conv (5 chunks x 768 MFMA cycles ahead)
 constexpr int kSplitLayerLdsBytes = (3 * kSpYPlane + 3 * kSpGPlane) * 2;        // 126 720 B
 
 __device__ __forceinline__ void sp_split3(float x, su16& a, su16& b, su16& c) {
@@ -58,17 +59,19 @@ __global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ d
     }
 }
 
-// Operand pipeline: three register stages of the weight stream (chunk kc + 2 requested while chunk kc is multiplied), B one chunk ahead,
+// Operand pipeline: STAGES (3 or 6) register stages of the weight stream (chunk kc + STAGES - 1 requested while chunk kc is multiplied; every
+// chunk is a first touch of the XCD's L2, the fp32 kernels needed ~5 k cycles of distance), B one chunk ahead,
 // loads interleaved one-by-one behind the first MFMAs of a step.  NMB row blocks starting at MB0 (the last layer computes the skip half only).
 // TAPS = 3: chunk = 3 g + tap, B row of tap from btap[tap]; TAPS = 1: chunk = g.
-template <int NMB, int MB0, int TAPS>
+template <int NMB, int MB0, int TAPS, int STAGES>
 struct SplitPipeL {
+    static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned aoff;
     int n;
     const su16* btap[TAPS];
     int bplane;                  // elements between the planes of the B tile
-    uint4 a[3][NMB][3];
+    uint4 a[STAGES][NMB][3];
     sbf16x8 b[2][3];
 
     __device__ __forceinline__ SplitPipeL(const uint4* wave_base, int lane, int n_, int bplane_)
@@ -107,8 +110,8 @@ struct SplitPipeL {
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMB - 3 * NMB - 3, 0);
     }
     __device__ __forceinline__ void start_a() {
-        lda(a[0], 0);
-        lda(a[1], 1);
+#pragma unroll
+        for (int i = 0; i < STAGES - 1; ++i) lda(a[i], i);
         DSD_SB();
     }
     __device__ __forceinline__ void start_b() {
@@ -117,14 +120,14 @@ struct SplitPipeL {
     }
     template <int I>
     __device__ __forceinline__ void step(f32x16 (&acc)[NMB], int it) {
-        lda(a[(I + 2) % 3], 6 * it + I + 2);
+        lda(a[(I + STAGES - 1) % STAGES], 6 * it + I + STAGES - 1);
         if (I == 5) ldb<0>(b[0], it + 1); else ldb<(I + 1) % 6>(b[(I + 1) & 1], it);
         constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // smallest plane products first
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
             for (int mb = 0; mb < NMB; ++mb)
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8, a[I % 3][mb][TI[q]]), b[I & 1][TJ[q]], acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8, a[I % STAGES][mb][TI[q]]), b[I & 1][TJ[q]], acc[mb], 0, 0, 0);
         pattern();
         DSD_SB();
     }
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer_split(const LayerParams p
     const float* __restrict__ dsl = p.ds + (size_t)tstep * p.ds_tstride;
 
     // weight streams do not depend on the tile: request the first chunks of the conv before anything else
-    SplitPipeL<4, 0, 3> pipe1(reinterpret_cast<const uint4*>(p.w1p) + (size_t)w * (48 * 12 * 64), lane, 48, kSpYPlane);
+    SplitPipeL<4, 0, 3, kSplitStages1> pipe1(reinterpret_cast<const uint4*>(p.w1p) + (size_t)w * (48 * 12 * 64), lane, 48, kSpYPlane);
     pipe1.start_a();
 
     // 1. stage y = x + step_proj (zero outside [0, T): the conv pads y) as three bf16 planes, frame-major.
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer_split(const LayerParams p
     // out-proj weight stream: first chunks requested before the gate arithmetic
     constexpr int NMB2 = LAST ? 2 : 4;
     constexpr int MB0 = LAST ? 2 : 0;
-    SplitPipeL<NMB2, MB0, 1> pipe2(reinterpret_cast<const uint4*>(p.w2p) + (size_t)w * (16 * 12 * 64), lane, 16, kSpGPlane);
+    SplitPipeL<NMB2, MB0, 1, 3> pipe2(reinterpret_cast<const uint4*>(p.w2p) + (size_t)w * (16 * 12 * 64), lane, 16, kSpGPlane);
     pipe2.start_a();
 
     // 3. gate in registers (rows [64 w, 64 w + 64) are gates, row blocks 2,3 their filters, net.py:73-74), written as bf16 planes

@@ -284,19 +284,20 @@ extern "C" int dsf_adamw_step(float* p, const float* g, float* m, float* v, int6
 // ---- EXPERIMENT: split-precision convolution prototype; not used by any product path ---------------------
 extern "C" int dsf_split_conv1d_probe(const float* in, const void* wplanes, float* out, int32_t B, int32_t T, int32_t dil, int32_t variant,
                                       int32_t iters, float* avg_ms, void* stream) {
-    if (!in || !wplanes || !out || B < 1 || B > 65535 || T < 1 || dil < 1 || dil > kHalo || iters < 1 || variant < 0 || variant > 1)
+    if (!in || !wplanes || !out || B < 1 || B > 65535 || T < 1 || dil < 1 || dil > kHalo || iters < 1 || variant < 0 || variant > 2)
         return fail(DSD_ERR_INVALID, "dsf_split_conv1d_probe: bad argument");
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_split_conv, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_split_conv_p, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_split_conv_p<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_split_conv_p<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
         attr_done = true;
     }
     SplitConvParams p{};
     p.in = in; p.wp = reinterpret_cast<const uint4*>(wplanes); p.out = out; p.T = T; p.TS = fs_ts(T); p.dil = dil;
     const dim3 grid((unsigned)(p.TS / 32), (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
-    void (*kern)(const SplitConvParams) = variant ? k_split_conv_p : k_split_conv;
+    void (*kern)(const SplitConvParams) = (variant == 2) ? k_split_conv_p<6> : (variant == 1) ? k_split_conv_p<3> : k_split_conv;
     if (!avg_ms) {
         for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(kThreads), kSplitLdsBytes, s, p);
         HIP_TRY(hipGetLastError());

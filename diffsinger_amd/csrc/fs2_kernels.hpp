@@ -821,11 +821,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_split_conv(const SplitConvParam
 // kc + 2 is requested while chunk kc is multiplied: 2 x 768 MFMA cycles ahead), the B fragment one chunk ahead, and inside a step the 12
 // weight loads and 3 LDS reads interleaved one-by-one behind the first MFMAs with sched_group_barrier.  Rotation period 6 (3 weight stages
 // x 2 B buffers), so chunk = 6 it + I has a compile-time tap (I % 3) and channel group 2 it + I / 3.
+template <int STAGES>
 struct SplitPipe {
+    static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned aoff;
     const u16* btap[3];          // this lane's B row of tap 0 / 1 / 2 (plane 0, channel group 0)
-    uint4 a[3][4][3];
+    uint4 a[STAGES][4][3];
     bf16x8_t b[2][3];
 
     __device__ __forceinline__ SplitPipe(const uint4* wave_base, int lane, const u16* ysm, int j, int h, int dil)
@@ -866,27 +868,28 @@ struct SplitPipe {
     }
     template <int I>
     __device__ __forceinline__ void step(f32x16 (&acc)[4], int it) {
-        lda(a[(I + 2) % 3], 6 * it + I + 2);
+        lda(a[(I + STAGES - 1) % STAGES], 6 * it + I + STAGES - 1);
         if (I == 5) ldb<0>(b[0], it + 1); else ldb<(I + 1) % 6>(b[(I + 1) & 1], it);
         constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[I % 3][mb][TI[q]]), b[I & 1][TJ[q]], acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[I % STAGES][mb][TI[q]]), b[I & 1][TJ[q]], acc[mb], 0, 0, 0);
         pattern();
         DSD_SB();
     }
 };
 
+template <int STAGES>
 __global__ __launch_bounds__(kThreads, 1) void k_split_conv_p(const SplitConvParams p) {
     extern __shared__ __attribute__((aligned(16))) u16 ysm[];          // [3][48][264]
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * 32, b = blockIdx.y;
-    SplitPipe pipe(p.wp + (size_t)w * (48 * 4 * 3 * 64), lane, ysm, j, h, p.dil);
-    pipe.lda(pipe.a[0], 0);                                            // the weight stream does not depend on the tile: request it first
-    pipe.lda(pipe.a[1], 1);
+    SplitPipe<STAGES> pipe(p.wp + (size_t)w * (48 * 4 * 3 * 64), lane, ysm, j, h, p.dil);
+#pragma unroll
+    for (int i = 0; i < STAGES - 1; ++i) pipe.lda(pipe.a[i], i);       // the weight stream does not depend on the tile: request it first
     DSD_SB();
     const float* inb = p.in + (size_t)b * kC * p.TS;
     for (int idx = tid; idx < kC * (kSplitFrames / 4); idx += kThreads) {
@@ -909,11 +912,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_split_conv_p(const SplitConvPar
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    pipe.ldb<0>(pipe.b[0], 0);
+    pipe.template ldb<0>(pipe.b[0], 0);
     DSD_SB();
     for (int it = 0; it < 8; ++it) {
-        pipe.step<0>(acc, it); pipe.step<1>(acc, it); pipe.step<2>(acc, it);
-        pipe.step<3>(acc, it); pipe.step<4>(acc, it); pipe.step<5>(acc, it);
+        pipe.template step<0>(acc, it); pipe.template step<1>(acc, it); pipe.template step<2>(acc, it);
+        pipe.template step<3>(acc, it); pipe.template step<4>(acc, it); pipe.template step<5>(acc, it);
     }
     const int t = t0 + j;
     if (t < p.TS) {

@@ -32,7 +32,7 @@ def pack_split_weight(w: torch.Tensor) -> torch.Tensor:
 
 def split_conv1d(x_cm: torch.Tensor, wplanes: torch.Tensor, T: int, dil: int, iters: int = 1, timed: bool = False, variant: int = 0):
     """x_cm [B][256][TS] fp32 on the device, wplanes from pack_split_weight (on the device) -> out [B][512][TS] (and the average launch
-    time in ms when timed).  variant 0: compiler-scheduled two-stage pipeline; 1: hand-pinned three-stage operand pipeline."""
+    time in ms when timed).  variant 0: compiler-scheduled two-stage pipeline; 1 / 2: hand-pinned operand pipeline with three / six weight stages."""
     if x_cm.device.type != 'cuda':
         raise RuntimeError('split_conv1d: no CPU path')
     lib = _lib.load()

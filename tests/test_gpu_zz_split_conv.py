@@ -8,7 +8,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.xfail(reason='split-precision prototy
 DEV = 'cuda:0'
 
 
-@pytest.mark.parametrize('variant', [0, 1], ids=['compiler_scheduled', 'hand_pipelined'])
+@pytest.mark.parametrize('variant', [0, 1, 2], ids=['compiler_scheduled', 'hand_pipelined_3_stages', 'hand_pipelined_6_stages'])
 @pytest.mark.parametrize('B,T,dil', [(2, 70, 4), (3, 96, 1), (1, 200, 8)])
 def test_split_conv_is_fp32_class(B, T, dil, variant):
     from diffsinger_amd.experimental import pack_split_weight, split_conv1d
@@ -32,7 +32,8 @@ def test_split_conv_rate_at_the_bench_shape():
     w = torch.randn(512, 256, 3) * (256 * 3) ** -0.5
     x = torch.randn(8, 256, 1024, device=DEV)
     wp = pack_split_weight(w).to(DEV)
-    for variant, name in ((0, 'k_split_conv (compiler-scheduled)'), (1, 'k_split_conv_p (hand-pinned pipeline)')):
+    for variant, name in ((0, 'k_split_conv (compiler-scheduled)'), (1, 'k_split_conv_p<3> (hand-pinned, 3 weight stages)'),
+                          (2, 'k_split_conv_p<6> (hand-pinned, 6 weight stages)')):
         out, ms = split_conv1d(x, wp, 1024, 1, iters=50, timed=True, variant=variant)
         tf = 2 * 512 * 768 * 8192 / (ms * 1e-3) / 1e12
         print(f'{name}: {ms * 1e3:.1f} us per launch at 8 x 1024 frames = {tf:.1f} fp32-equivalent TFLOP/s '
