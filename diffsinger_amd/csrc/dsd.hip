@@ -875,7 +875,7 @@ extern "C" int dsd_debug_layer(dsd_handle* h, int32_t layer, int32_t t, const fl
     DSD_TRY(build_step_table(h, t + 1, s));
     float* xin = (layer & 1) ? h->xb : h->xa;
     float* xout = (layer & 1) ? h->xa : h->xb;
-    hipLaunchKernelGGL(k_dbg_to_tiles, dim3((unsigned)h->ntiles), dim3(256), 0, s, x_in, xin, h->TS, h->ntile32, 1);
+    hipLaunchKernelGGL(k_dbg_to_tiles, dim3((unsigned)h->ntiles), dim3(256), 0, s, const_cast<float*>(x_in), xin, h->TS, h->ntile32, 1);
     HIP_TRY(hipMemsetAsync(h->skip, 0, (size_t)h->ntiles * 2048 * sizeof(float4), s));
     DSD_TRY(launch_layer(h, layer, t, nullptr, s));
     if (x_out && layer != h->L - 1)

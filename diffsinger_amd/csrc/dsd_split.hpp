@@ -340,12 +340,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer_split(const LayerParams p
 
 // ---- debug plumbing (dsd_debug_layer): logical [B][C][TS] <-> the layer kernels' images ------------------------------------------------
 // x: tile-major [tile = b * ntile32 + tn][C][32]
-__global__ void k_dbg_to_tiles(const float* __restrict__ x, float* __restrict__ xt, int TS, int ntile32, int to_tiles) {
+__global__ void k_dbg_to_tiles(float* __restrict__ x, float* __restrict__ xt, int TS, int ntile32, int to_tiles) {
     const int tile = blockIdx.x, b = tile / ntile32, tn = tile - b * ntile32;
     for (int idx = threadIdx.x; idx < kC * 32; idx += blockDim.x) {
         const int c = idx >> 5, f = idx & 31;
         const size_t lo = ((size_t)b * kC + c) * TS + tn * 32 + f, ti = (size_t)tile * kC * 32 + idx;
-        if (to_tiles) xt[ti] = x[lo]; else const_cast<float*>(x)[lo] = xt[ti];
+        if (to_tiles) xt[ti] = x[lo]; else x[lo] = xt[ti];
     }
 }
 // skip sum: fragment order [tile][wave 4][ms 2][q 4][lane 64] float4 -> logical; element (q, lane = (j, h), s) is channel
