@@ -421,6 +421,126 @@ def main_train(args):
         dist.destroy_process_group()
 
 
+def _fs2_setup(B, T_txt, frames_per_phone, device, seed=7):
+    """DiffSpeech FastSpeech2 (preset lj_ds_beta6) with seeded weights and teacher-forced inputs: B x T_txt phones x frames_per_phone frames."""
+    import diffsinger_amd
+    from diffsinger_amd import fs2, hparams
+    hparams.clear()
+    diffsinger_amd.use_preset(PRESET)
+    torch.manual_seed(1234)
+    m = fs2.FastSpeech2(63, 80).eval()
+    g = torch.Generator().manual_seed(seed)
+    tok = torch.randint(1, 63, (B, T_txt), generator=g)
+    T = T_txt * frames_per_phone
+    mel2ph = (torch.arange(T) // frames_per_phone + 1)[None].repeat(B, 1)
+    kw = dict(mel2ph=mel2ph, f0=torch.rand(B, T, generator=g) * 2 + 6.5, uv=torch.zeros(B, T))
+    return m, dict(hparams), tok, kw
+
+
+def cpu_baseline_fs2(budget_s: float = 20.0):
+    """The FastSpeech2 oracle (oracle/fs2_oracle.py = the reference's own torch arithmetic) on the host cores, 1 x 256 frames at a time."""
+    from oracle import fs2_oracle as FO
+    m, hp, tok, kw = _fs2_setup(1, 32, 8, 'cpu')
+    p = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v.detach().clone()) for k, v in m.state_dict().items()}
+    avail = host_cpus()
+    cores = min(avail, 32)
+    torch.set_num_threads(cores)
+    T = kw['mel2ph'].shape[1]
+    with torch.no_grad():
+        run = lambda: FO.fs2_forward(p, hp, tok, **{k: v.clone() for k, v in kw.items()})
+        run()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            run()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 4096:
+                break
+    return {'value': n * T / el, 'unit': 'mel-frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} forwards of 1 x {T} mel frames (oracle/fs2_oracle.fs2_forward, teacher-forced) in {el:.1f}s on {cores} host threads '
+                      f'({avail} CPUs available)'}
+
+
+def main_fs2(args):
+    """Row f1: `steps` teacher-forced forwards of the HIP FastSpeech2 over 8 x 1024 mel frames per GPU (replicas: no exchange step in this row)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    B, T = B_PER_GPU, T_FRAMES
+    m, hp, tok, kw = _fs2_setup(B, T // 8, 8, device, seed=7 + rank)
+    m = m.to(device)
+    tok = tok.to(device)
+    kw = {k: v.to(device) for k, v in kw.items()}
+
+    def step():
+        return m(tok, infer=True, **{k: (v.clone() if k == 'f0' else v) for k, v in kw.items()})
+
+    for _ in range(max(1, args.warmup)):
+        r = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    elt = torch.tensor([el], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
+    el = float(elt.item())
+    assert r['mel_out'].shape == (B, T, 80) and bool(torch.isfinite(r['mel_out']).all()), 'bad mel'
+    if rank == 0:
+        # dominant kernel: k_fs_conv<2> as the k = 9 conv of the feed-forward block (256 -> 1024), one launch timed with events on the launch stream
+        from diffsinger_amd.fs2 import conv1d_cm, PackedWeight, padded_frames
+        w = torch.randn(1024, 256, 9, device=device) * (256 * 9) ** -0.5
+        bias = torch.zeros(1024, device=device)
+        x = torch.randn(B, 256, padded_frames(T), device=device)
+        pk = PackedWeight()
+        launch = lambda: conv1d_cm(x, T, w, pk, bias, scale=9 ** -0.5, act='gelu')
+        launch()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(20):
+            launch()
+        ev1.record()
+        ev1.synchronize()
+        ms = ev0.elapsed_time(ev1) / 20
+        flop = 2 * 1024 * 256 * 9 * B * T
+        achieved = flop / (ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': 'k_fs_conv<2>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_launch_ms': ms, 'flop_per_launch': flop,
+                'algorithmic_bytes_per_launch': 4 * B * T * (256 + 1024) + 4 * 1024 * 256 * 9,
+                'note': 'ffn_1 of TransformerFFNLayer (Conv1d 256 -> 1024, k = 9, * k**-0.5, gelu fused): the largest contraction of the model; eager launch '
+                        'incl. the output allocation and the ctypes call.  No PMC pass of this kernel is committed yet'}
+        value = world * B * T * args.steps / el
+        res = {'metric': 'mel-frames/sec (whole node) through FastSpeech2 (encoder, predictors, length regulator, decoder, mel_out), teacher-forced, T=1024',
+               'value': value, 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': f'SURVEY 8 row f1: FastSpeech2 of {PRESET} (4 + 4 FFT blocks, hidden 256), batch={B} x {T // 8} phones x 8 frames = '
+                                      f'{T} mel frames per GPU, mel2ph / f0 / uv supplied', 'preset': PRESET, 'sharding': 'replicas (no exchange step in this row)'},
+               'roofline': roof}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline_fs2()
+            res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -428,8 +548,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tile', type=int, default=0, help='frames per workgroup of the layer kernel (0 auto, 32, 64)')
-    ap.add_argument('--row', choices=['path', 'vocoder', 'train'], default='path',
-                    help='path: the headline hot path (default); vocoder: SURVEY 8 row f2; train: row f3 (denoiser p_losses forward + backward)')
+    ap.add_argument('--row', choices=['path', 'vocoder', 'train', 'fs2'], default='path',
+                    help='path: the headline hot path (default); vocoder: SURVEY 8 row f2; train: row f3 (denoiser p_losses forward + backward); '
+                         'fs2: row f1 (FastSpeech2 forward, teacher-forced)')
     ap.add_argument('--split', action='store_true', help='EXPERIMENT: residual layers as six bf16 plane products per fp32 product (fp32-class accuracy) '
                                                           'on the bf16 matrix pipe; per-layer kernel path; the JSON line says so in dtype / config')
     args = ap.parse_args()
@@ -437,6 +558,8 @@ def main():
         return main_vocoder(args)
     if args.row == 'train':
         return main_train(args)
+    if args.row == 'fs2':
+        return main_fs2(args)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -18,7 +18,7 @@ def test_flags_and_loud_failure_without_a_device():
     for flag in ('--gpus', '--steps', '--warmup', '--row'):
         assert flag in r.stdout
     if not torch.cuda.is_available():
-        for extra in ([], ['--row', 'vocoder'], ['--row', 'train'], ['--split']):
+        for extra in ([], ['--row', 'vocoder'], ['--row', 'train'], ['--row', 'fs2'], ['--split']):
             r = _run('--steps', '1', '--warmup', '0', *extra)
             assert r.returncode != 0 and 'needs an MI355X' in (r.stderr + r.stdout)      # no CPU fallback for the product path
 
@@ -29,5 +29,7 @@ def test_vocoder_row_accounting_and_cpu_leg():
     assert bench.vocoder_flop_per_frame(bench.VOC_CONFIG) == 38_510_592
     cb = bench.cpu_baseline_vocoder(budget_s=1.0)
     assert cb['kind'] == 'port' and cb['unit'] == 'mel-frames/s' and cb['value'] > 0 and cb['cores'] >= 1 and 'forwards' in cb['sample']
+    cf = bench.cpu_baseline_fs2(budget_s=1.0)
+    assert cf['kind'] == 'port' and cf['value'] > 0 and 'teacher-forced' in cf['sample']
     ct = bench.cpu_baseline_train(budget_s=1.0)
     assert ct['kind'] == 'port' and ct['unit'] == 'frames/s' and ct['value'] > 0 and 'forward + backward' in ct['sample']

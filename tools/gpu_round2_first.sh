@@ -19,6 +19,7 @@ timeout 300 python tools/bench_vocoder.py 5 > $O/vocoder.jsonl 2> $O/vocoder.err
 timeout 300 python bench.py --steps 3 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err
 timeout 200 python bench.py --row vocoder --steps 10 --warmup 2 > $O/bench_vocoder_row.json 2> $O/bench_vocoder_row.err
 timeout 300 python bench.py --row train --steps 5 --warmup 2 > $O/bench_train_row.json 2> $O/bench_train_row.err
+timeout 200 python bench.py --row fs2 --steps 20 --warmup 3 > $O/bench_fs2_row.json 2> $O/bench_fs2_row.err
 timeout 300 python bench.py --split --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_split_experiment.json 2> $O/bench_split_experiment.err
 /opt/rocm/bin/hipcc -O2 -I include examples/dsd_example.cpp -L diffsinger_amd -ldsdenoise -Wl,-rpath,$R/diffsinger_amd -o /tmp/dsd_example && timeout 120 /tmp/dsd_example 8 1024 100 > $O/cxx_example.json 2> $O/cxx_example.err
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_split_probe tools/mfma_split_probe.hip && timeout 60 /tmp/mfma_split_probe > $O/mfma_split_probe.jsonl 2> $O/mfma_split_probe.err
@@ -30,4 +31,4 @@ python $R/tools/pmc_summary.py $O/pmc_voc 'k_voc_conv_fold<4>' $O/voc_fold_pmc.t
 rm -rf $O/prof_voc
 find $O/pmc_voc -name '*.db' -delete
 du -sh $O
-tail -8 $O/pytest_gpu.txt; for f in $O/test_gpu_zz_*.txt; do echo == $f; grep -E 'err|TFLOP|us per|XPASS|XFAIL|passed|failed|xfailed|xpassed|Error' $f | cut -c1-220 | tail -14; done; cat $O/cxx_example.json; cut -c1-900 $O/bench_split_experiment.json; cat $O/mfma_split_probe.jsonl; cut -c1-700 $O/bench_vocoder_row.json; cut -c1-700 $O/bench_train_row.json; cut -c1-300 $O/vocoder.jsonl | head -20; cat $O/bench_n1.json | cut -c1-600; head -14 $O/vocoder_kernel_stats.txt | cut -c1-180
+tail -8 $O/pytest_gpu.txt; for f in $O/test_gpu_zz_*.txt; do echo == $f; grep -E 'err|TFLOP|us per|XPASS|XFAIL|passed|failed|xfailed|xpassed|Error' $f | cut -c1-220 | tail -14; done; cat $O/cxx_example.json; cut -c1-900 $O/bench_split_experiment.json; cat $O/mfma_split_probe.jsonl; cut -c1-700 $O/bench_vocoder_row.json; cut -c1-700 $O/bench_train_row.json; cut -c1-700 $O/bench_fs2_row.json; cut -c1-300 $O/vocoder.jsonl | head -20; cat $O/bench_n1.json | cut -c1-600; head -14 $O/vocoder_kernel_stats.txt | cut -c1-180
