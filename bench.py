@@ -150,6 +150,46 @@ def parity_check(device):
             'tolerance': 1e-4}
 
 
+def _row_setup():
+    """Process / device / process-group setup shared by the --row benches (same launch contract as the headline run)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    return world, rank, device, dist
+
+
+def _row_time(step, args, world, device, dist):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks.  Returns
+    (seconds, last result)."""
+    out = None
+    for _ in range(max(1, args.warmup)):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    elt = torch.tensor([el], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
+    return float(elt.item()), out
+
+
 VOC_CONFIG = dict(resblock='1', upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=128,
                   resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], audio_sample_rate=24000,
                   use_pitch_embed=False)          # configs/tts/hifigan.yaml
@@ -193,17 +233,7 @@ def cpu_baseline_vocoder(budget_s: float = 20.0):
 
 def main_vocoder(args):
     """Row f2: `steps` forwards of the HIP HiFi-GAN generator over 8 x 1024 mel frames per GPU (replicas: the row has no exchange step)."""
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    world, rank, device, dist = _row_setup()
     from diffsinger_amd.vocoder import HifiGanGenerator, _HipOps, fold_weight, padded_samples
     h = VOC_CONFIG
     m = HifiGanGenerator(h)
@@ -216,24 +246,7 @@ def main_vocoder(args):
     m = m.to(device).eval()
     B, T = B_PER_GPU, T_FRAMES
     mel = torch.randn(B, 80, T, device=device, generator=torch.Generator(device=device).manual_seed(1234 + rank))
-    for _ in range(max(1, args.warmup)):
-        wav = m(mel)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wav = m(mel)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    elt = torch.tensor([el], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
-    el = float(elt.item())
+    el, wav = _row_time(lambda: m(mel), args, world, device, dist)
     assert wav.shape == (B, 1, T * 256) and bool(torch.isfinite(wav).all()), 'bad waveform'
     if rank == 0:
         # dominant kernel: the resblock convolutions of the 8-channel stage (18 of the 76 launches, the longest time axis).  One launch
@@ -332,17 +345,7 @@ def cpu_baseline_train(budget_s: float = 20.0):
 def main_train(args):
     """Row f3: `steps` x (q_sample + DiffNet forward + L1 + backward) on the HIP training operators, 8 x 1024 frames per GPU (no optimiser,
     no gradient exchange: replicas)."""
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    world, rank, device, dist = _row_setup()
     gd, pre = build_model(device)
     gd.train()
     net = gd.denoise_fn
@@ -359,24 +362,7 @@ def main_train(args):
         loss.backward()
         return loss
 
-    for _ in range(max(1, args.warmup)):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    elt = torch.tensor([el], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
-    el = float(elt.item())
+    el, loss = _row_time(step, args, world, device, dist)
     assert bool(torch.isfinite(loss)), 'non-finite loss'
     if rank == 0:
         # dominant kernel: k_fs_conv<2> as the dilated convolution (256 -> 512, k = 3), forward; one launch timed with events on the launch stream
@@ -463,17 +449,7 @@ def cpu_baseline_fs2(budget_s: float = 20.0):
 
 def main_fs2(args):
     """Row f1: `steps` teacher-forced forwards of the HIP FastSpeech2 over 8 x 1024 mel frames per GPU (replicas: no exchange step in this row)."""
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    world, rank, device, dist = _row_setup()
     B, T = B_PER_GPU, T_FRAMES
     m, hp, tok, kw = _fs2_setup(B, T // 8, 8, device, seed=7 + rank)
     m = m.to(device)
@@ -483,24 +459,7 @@ def main_fs2(args):
     def step():
         return m(tok, infer=True, **{k: (v.clone() if k == 'f0' else v) for k, v in kw.items()})
 
-    for _ in range(max(1, args.warmup)):
-        r = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    elt = torch.tensor([el], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
-    el = float(elt.item())
+    el, r = _row_time(step, args, world, device, dist)
     assert r['mel_out'].shape == (B, T, 80) and bool(torch.isfinite(r['mel_out']).all()), 'bad mel'
     if rank == 0:
         # dominant kernel: k_fs_conv<2> as the k = 9 conv of the feed-forward block (256 -> 1024), one launch timed with events on the launch stream
