@@ -197,7 +197,8 @@ class _ResBlock(nn.Module):
 
     def __init__(self, kind: str, ch: int, k: int, dils):
         super().__init__()
-        self.kind, self.k, self.dils = kind, k, tuple(dils)
+        dils = tuple(dils)[:3 if kind == '1' else 2]                 # ResBlock1 builds exactly three conv pairs, ResBlock2 exactly two convs
+        self.kind, self.k, self.dils = kind, k, dils
         if kind == '1':
             self.convs1 = nn.ModuleList([_WNConv((ch, ch, k), ch) for _ in dils])
             self.convs2 = nn.ModuleList([_WNConv((ch, ch, k), ch) for _ in dils])

@@ -32,7 +32,7 @@ def get_padding(kernel_size, dilation=1):
 
 
 def resblock1(p, pre, x, k, dils):
-    for i, d in enumerate(dils):                                   # hifigan.py:54-61
+    for i, d in enumerate(dils[:3]):                               # hifigan.py:54-61; the module builds exactly three conv pairs (:34-50)
         xt = F.leaky_relu(x, LRELU_SLOPE)
         xt = F.conv1d(xt, _weight(p, f'{pre}convs1.{i}'), p[f'{pre}convs1.{i}.bias'], padding=get_padding(k, d), dilation=d)
         xt = F.leaky_relu(xt, LRELU_SLOPE)
@@ -42,7 +42,7 @@ def resblock1(p, pre, x, k, dils):
 
 
 def resblock2(p, pre, x, k, dils):
-    for i, d in enumerate(dils):                                   # hifigan.py:82-87
+    for i, d in enumerate(dils[:2]):                               # hifigan.py:82-87; the module builds exactly TWO convs, dilation[0] and [1] (:71-79)
         xt = F.leaky_relu(x, LRELU_SLOPE)
         xt = F.conv1d(xt, _weight(p, f'{pre}convs.{i}'), p[f'{pre}convs.{i}.bias'], padding=get_padding(k, d), dilation=d)
         x = xt + x
@@ -132,7 +132,7 @@ def generator_shapes(h, c_out=1):
             pre = f'resblocks.{i * nk + j}.'
             names = ('convs1', 'convs2') if h['resblock'] == '1' else ('convs',)
             for nm in names:
-                for q in range(len(dd)):
+                for q in range(min(len(dd), 3 if h['resblock'] == '1' else 2)):
                     s[f'{pre}{nm}.{q}.weight'], s[f'{pre}{nm}.{q}.bias'] = (ch, ch, kk), (ch,)
     s['conv_post.weight'], s['conv_post.bias'] = (c_out, ch, 7), (c_out,)
     return s

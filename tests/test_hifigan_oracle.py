@@ -23,7 +23,7 @@ if not hasattr(scipy.signal, 'kaiser'):                   # modules/parallel_wav
     scipy.signal.kaiser = scipy.signal.windows.kaiser
 from modules.hifigan.hifigan import HifiGanGenerator
 h = dict(ref.hparams)
-h.update(use_pitch_embed=%(nsf)r, audio_sample_rate=24000, upsample_initial_channel=64)
+h.update(use_pitch_embed=%(nsf)r, audio_sample_rate=24000, upsample_initial_channel=64, resblock=%(resblock)r)
 torch.manual_seed(11)
 m = HifiGanGenerator(h).eval()
 g = torch.Generator().manual_seed(5)
@@ -51,9 +51,10 @@ print('HIFIGAN_EQUAL_OK', float(a.abs().max()))
 
 
 @pytest.mark.skipif(not reference_available(), reason='/root/reference not mounted')
+@pytest.mark.parametrize('resblock', ['1', '2'])
 @pytest.mark.parametrize('nsf', [False, True])
-def test_hifigan_oracle_bit_equal_to_live_reference(nsf):
-    res = subprocess.run([sys.executable, '-c', CHILD % dict(root=ROOT, nsf=nsf)], capture_output=True, text=True)
+def test_hifigan_oracle_bit_equal_to_live_reference(nsf, resblock):
+    res = subprocess.run([sys.executable, '-c', CHILD % dict(root=ROOT, nsf=nsf, resblock=resblock)], capture_output=True, text=True)
     assert 'HIFIGAN_EQUAL_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
