@@ -471,6 +471,10 @@ class HifiGAN:
         return cls(model, device, use_nsf)
 
     def spec2wav(self, mel, **kwargs):
+        from .hparams import hparams
+        if hparams.get('vocoder_denoise_c', 0.0) > 0:
+            raise NotImplementedError("hparams['vocoder_denoise_c'] > 0: the spectral-subtraction post-filter (vocoders/vocoder_utils.denoise, librosa STFT on "
+                                      "the host) is not part of this package - run it on the returned waveform")
         with torch.no_grad():
             c = torch.as_tensor(mel, dtype=torch.float32).unsqueeze(0).transpose(2, 1).to(self.device)
             f0 = kwargs.get('f0')
