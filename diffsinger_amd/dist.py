@@ -75,3 +75,35 @@ def sharded_inference(model, conds: Sequence[torch.Tensor], *, micro_batch: int 
     if world == 1:
         return local
     return gather_mels(local, len(conds), dst=dst, group=group)
+
+
+def gather_ragged(local: Sequence[torch.Tensor], n_items: int, dst: int = 0, group=None):
+    """Collate per-utterance 1-D results of DIFFERENT lengths (waveforms of the vocoder stage, f0 tracks) sharded r::W: this rank's
+    tensors in shard order -> on `dst` the list of n_items tensors in ORIGINAL utterance order, None elsewhere.  Two collectives: the
+    lengths (one int64 gather), then one gather of the payloads padded to the longest - the reference writes one file per utterance
+    from every rank instead (tasks/tts/fs2.py:414-431)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_max = (n_items + world - 1) // world
+    dev = local[0].device if len(local) else torch.device('cpu')
+    dtype = local[0].dtype if len(local) else torch.float32
+    lens = torch.zeros(n_max, dtype=torch.int64, device=dev)
+    for i, t in enumerate(local):
+        lens[i] = t.numel()
+    all_lens = [torch.empty_like(lens) for _ in range(world)] if rank == dst else None
+    dist.gather(lens, gather_list=all_lens, dst=dst, group=group)
+    longest = lens.max().reshape(1)
+    dist.all_reduce(longest, op=dist.ReduceOp.MAX, group=group)
+    L = int(longest.item())
+    buf = torch.zeros(n_max, L, dtype=dtype, device=dev)
+    for i, t in enumerate(local):
+        buf[i, :t.numel()] = t.reshape(-1)
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, gather_list=parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = [None] * n_items
+    for r in range(world):
+        for k, i in enumerate(shard_indices(n_items, r, world)):
+            out[i] = parts[r][k, :int(all_lens[r][k])].clone()
+    return out

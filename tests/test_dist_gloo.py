@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from diffsinger_amd.dist import gather_mels, shard_indices, sharded_inference, unshard_order
+from diffsinger_amd.dist import gather_mels, gather_ragged, shard_indices, sharded_inference, unshard_order
 
 
 class _FakeSampler:
@@ -58,6 +58,14 @@ def _worker(rank, world, port, n_items, micro_batch, q):
         if rank == 0:
             assert got.shape == (n_items, 3, 2)
             assert torch.equal(got[:, 0, 0], torch.arange(n_items, dtype=torch.float32))
+        # ragged 1-D results (waveforms): utterance i has 5 + 3 i samples, all equal to i
+        wavs = gather_ragged([torch.full((5 + 3 * i,), float(i)) for i in mine], n_items, dst=0)
+        if rank == 0:
+            assert len(wavs) == n_items
+            for i, wv in enumerate(wavs):
+                assert wv.shape == (5 + 3 * i,) and bool((wv == float(i)).all())
+        else:
+            assert wavs is None
     finally:
         dist.barrier()
         dist.destroy_process_group()
