@@ -1,6 +1,7 @@
 """Build container only (skipped where /root/reference is absent): the oracle restatement against the
 LIVE reference on a configuration the goldens do not cover (narrow model, dilation cycle 2, cosine
-schedule, per-step comparison of p_sample / q_sample / p_sample_plms)."""
+schedule, per-step comparison of p_sample / q_sample / p_sample_plms; p_losses and the gradients of all parameters, with and
+without the non-padding mask - the oracle of the training row)."""
 import os
 import subprocess
 import sys
@@ -55,6 +56,20 @@ with torch.no_grad():
         xr = gd.p_sample_plms(xr, tt, 8, cb)
         xo = O.p_sample_plms(p, cfg, sch, xo, tt, 8, cb, hist)
         assert torch.equal(xr, xo), i
+# training (row f3): p_losses and the gradient of EVERY parameter - the reference module under autograd vs torch autograd on the oracle
+for nonpad in (None, (torch.rand(B, T, generator=g) > 0.2).float()):
+    tt = torch.tensor([49, 7, 0])
+    net.zero_grad()
+    loss_r = gd.p_losses(x, tt, cond, noise=z, nonpadding=nonpad)
+    loss_r.backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    diff = z - O.diffnet_forward(po, cfg, O.q_sample(sch, x, tt, z), tt, cond)
+    loss_o = (diff.abs() * nonpad.unsqueeze(1)).mean() if nonpad is not None else diff.abs().mean()
+    loss_o.backward()
+    assert torch.equal(loss_r.detach(), loss_o.detach()), (float(loss_r), float(loss_o))
+    for k, v in net.named_parameters():
+        assert v.grad is not None and po[k].grad is not None, k
+        assert torch.equal(v.grad, po[k].grad), (k, float((v.grad - po[k].grad).abs().max()))
 print('REFERENCE_EQUAL_OK')
 '''
 
