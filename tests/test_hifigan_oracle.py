@@ -30,6 +30,10 @@ g = torch.Generator().manual_seed(5)
 with torch.no_grad():
     for v in m.parameters():                              # init_weights is N(0, 0.01): make the signal path non-trivial
         v.add_(0.05 * torch.randn(v.shape, generator=g))
+from diffsinger_amd.vocoder import HifiGanGenerator as HipGen            # the HIP module's parameter tree == the reference module's
+mine = HipGen(h)
+assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == {k: tuple(v.shape) for k, v in m.state_dict().items()}
+mine.load_state_dict(m.state_dict(), strict=True)
 B, T = 2, 37
 mel = torch.randn(B, 80, T, generator=g)
 f0 = None
