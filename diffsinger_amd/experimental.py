@@ -1,7 +1,7 @@
 """EXPERIMENTS - nothing here is on a product path ("beyond the fp32-MFMA ceiling").
 
 split-precision convolution: the denoiser's dilated Conv1d(256 -> 512, 3) as an fp32-accurate GEMM on the bf16 matrix pipe
-(`dsf_split_conv1d_probe`, csrc/fs2_kernels.hpp k_split_conv): host-side weight packing and the call wrapper."""
+(`dsf_split_conv1d_probe`, csrc/dsd_split.hpp k_split_conv): host-side weight packing and the call wrapper."""
 from __future__ import annotations
 
 import ctypes as C

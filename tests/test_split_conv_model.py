@@ -1,4 +1,4 @@
-"""CPU: lane-level numpy model of the split-precision convolution prototype (csrc/fs2_kernels.hpp k_split_conv + the host packing of
+"""CPU: lane-level numpy model of the split-precision convolution prototype (csrc/dsd_split.hpp k_split_conv + the host packing of
 diffsinger_amd/experimental.py) - the staging into [plane][frame][channel], the fragment-order weight planes, the six plane products per
 chunk, the accumulator map - against F.conv1d.  The only hardware fact it assumes is the one every MFMA kernel here relies on (A row /
 B column = lane & 31, C/D fragment map); the k order inside an instruction cancels because packing and LDS read use the same one."""
