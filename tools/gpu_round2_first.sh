@@ -26,7 +26,8 @@ timeout 300 python bench.py --split --steps 3 --warmup 1 --no-cpu-baseline > $O/
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_voc -o voc -- python $R/tools/bench_vocoder_quick.py > $O/prof_voc.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/prof_voc/*.db $O/prof_voc/*/*.db 2>/dev/null | head -1) > $O/vocoder_kernel_stats.txt 2>> $O/prof_voc.log
-timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE -d $O/pmc_voc/fetch -o fetch -- python $R/tools/bench_vocoder_quick.py > $O/pmc_voc.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/pmc_voc/fetch -o fetch -- python $R/tools/bench_vocoder_quick.py > $O/pmc_voc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d $O/pmc_voc/write -o write -- python $R/tools/bench_vocoder_quick.py > $O/pmc_voc_write.log 2>&1
 python $R/tools/pmc_summary.py $O/pmc_voc 'k_voc_conv_fold<4>' $O/voc_fold_pmc.txt $O/voc_fold_pmc.json frames=8192 'kernel_tag=k_voc_conv_fold<4>' round=$TAG > $O/pmc_voc_summary.log 2>&1
 rm -rf $O/prof_voc
 find $O/pmc_voc -name '*.db' -delete
