@@ -1,13 +1,18 @@
 #!/usr/bin/env python
 """bench.py - the reference's headline metric on MI355X: mel-frames/s of the K=100 DDPM reverse loop.
 
-    python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): DiffSpeech 80-bin denoiser (residual_channels 256, 20 layers, dilation
-cycle 1, linear beta schedule max_beta 0.06, 100 timesteps), K=100 full DDPM from a Gaussian start, batch of 8
-utterances x T=1024 frames PER GPU (weak scaling: utterances shard across ranks, no data-path collective, one
-RCCL gather of the finished mels).  Synthetic inputs (seeded N(0,1) cond / x_T / per-step noise) and seeded
-random-init weights - there are no checkpoints or datasets (no network).
+N > 1: one rank per GPU over RCCL.  Either the driver launches the ranks (python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, with no launcher around it, `python bench.py --gpus N` starts them itself
+with that same command line.
+
+Workload at N = 1 (BASELINE.json configs[1], `--config 2`): DiffSpeech 80-bin denoiser (residual_channels 256, 20 layers, dilation
+cycle 1, linear beta schedule max_beta 0.06, 100 timesteps), K=100 full DDPM from a Gaussian start, batch of 8 utterances x T=1024 frames.
+Workload at N > 1 (BASELINE.json configs[4], `--config 5`, also available at N = 1): the SAME 512 utterances x T=2048, K=100, at every N
+(strong scaling): rank r takes utterances r::W, runs them in micro-batches of 16 with no data-path collective, one RCCL gather collates the
+finished mels on rank 0; value = 512 x 2048 frames / max-over-ranks wall time.  Synthetic inputs (seeded N(0,1) cond / x_T / per-step noise)
+and seeded random-init weights - there are no checkpoints or datasets (no network).
 
 One "step" = one complete pass of the hot path over the batch: hoisted conditioner projection (dsd_prepare),
 the 100-step reverse loop (ONE persistent kernel launch, csrc/dsd_loop.hpp; fallback: one hipGraph replay of 2100
@@ -510,49 +515,50 @@ def main():
     ap.add_argument('--row', choices=['path', 'vocoder', 'train', 'fs2'], default='path',
                     help='path: the headline hot path (default); vocoder: SURVEY 8 row f2; train: row f3 (denoiser p_losses forward + backward); '
                          'fs2: row f1 (FastSpeech2 forward, teacher-forced)')
+    ap.add_argument('--config', type=int, choices=[2, 5], default=0,
+                    help='BASELINE configuration of the headline run: 2 = configs[1] (8 x T=1024 per GPU; the default at --gpus 1), 5 = configs[4] '
+                         '(512 utterances x T=2048 sharded across the GPUs, strong scaling; the default at --gpus > 1)')
     ap.add_argument('--split', action='store_true', help='EXPERIMENT: residual layers as six bf16 plane products per fp32 product (fp32-class accuracy) '
                                                           'on the bf16 matrix pipe; per-layer kernel path; the JSON line says so in dtype / config')
     args = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return self_launch(args)
     if args.row == 'vocoder':
         return main_vocoder(args)
     if args.row == 'train':
         return main_train(args)
     if args.row == 'fs2':
         return main_fs2(args)
+    return main_path(args)
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f'--gpus {args.gpus}: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...')
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
-    gd, pre = build_model(device)
-    from diffsinger_amd.dist import gather_mels
-    B, T, K, M = B_PER_GPU, T_FRAMES, K_STEPS, 80
-    g = torch.Generator(device=device).manual_seed(1234 + rank)
-    cond = torch.randn(B, T, 256, device=device, generator=g).transpose(1, 2)        # [B,H,T] view, like the reference
-    x_T = torch.randn(B, 1, M, T, device=device, generator=g)
-    noise = torch.randn(K, B, 1, M, T, device=device, generator=g)
-    eng = gd._engine(cond)
-    eng.set_layer_tile(args.tile)
-    if args.split:
-        eng.set_split_mode(True)
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU, exactly the command line
+    the driver uses - torch.distributed.run, rendezvous on 127.0.0.1) and pass their output through; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not os.environ.get('DSD_BENCH_SPAWN_ANYWAY'):          # (the variable lets the CPU suite exercise the spawn itself)
+        raise SystemExit(f'bench.py --gpus {n}: needs an MI355X node with at least {n} visible devices (torch sees {have})')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench.py: launching ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
-    def step():
-        mel = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
-        if world > 1:
-            return gather_mels(mel, world * B, dst=0)
-        return mel
 
+CFG5_UTTS, CFG5_T, CFG5_MICRO = 512, 2048, 16         # BASELINE configs[4]: 512 synthetic utterances x T=2048, K=100
+
+
+def _time_steps(step, args, world, device, dist):
+    """The bench contract: W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; max over ranks."""
+    out = None
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -570,12 +576,78 @@ def main():
     elt = torch.tensor([el], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(elt, op=dist.ReduceOp.MAX)
-    el = float(elt.item())
+    return float(elt.item()), out
+
+
+def main_path(args):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit(f'bench.py needs an MI355X (no CPU fallback for the product path) [rank {rank} of {world}]')
+    if args.gpus != world:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f'rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} devices are visible')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == 'nccl'
+    cfg = args.config or (5 if world > 1 else 2)
+
+    gd, pre = build_model(device)
+    from diffsinger_amd.dist import sharded_inference, shard_indices
+    K, M = K_STEPS, 80
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    if cfg == 2:
+        # BASELINE configs[1]: batch of 8 x T=1024 on this GPU.  TWO conditioner tensors alternate from step to step, so that every timed
+        # step really contains dsd_prepare (cond re-layout + the hoisted conditioner projection k_condproj): DiffNet.bind_cond skips it
+        # when it is handed the very tensor it prepared last
+        B, T = B_PER_GPU, T_FRAMES
+        conds = [torch.randn(B, T, 256, device=device, generator=g).transpose(1, 2) for _ in range(2)]     # [B,H,T] views, like the reference
+        x_T = torch.randn(B, 1, M, T, device=device, generator=g)
+        noise = torch.randn(K, B, 1, M, T, device=device, generator=g)
+        frames_per_step = world * B * T
+        count = [0]
+
+        def step():
+            count[0] += 1
+            return gd.inference(conds[count[0] & 1], x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
+        cond = conds[0]
+    else:
+        # BASELINE configs[4]: the SAME 512 utterances x T=2048 at every N (strong scaling): rank r takes utterances r::W
+        # (tasks/tts/tts.py:85-88), runs them in micro-batches of 16 with zero communication, ONE RCCL gather collates the mels on rank 0
+        # (the reference collates through the filesystem, tasks/tts/fs2.py:414-431)
+        B, T = CFG5_MICRO, CFG5_T
+        mine = shard_indices(CFG5_UTTS, rank, world)
+        gens = {i: torch.Generator(device=device).manual_seed(50_000 + i) for i in mine}
+        utt_conds = [None] * CFG5_UTTS
+        for i in mine:                                   # utterance i's conditioner depends on i only, not on the sharding
+            utt_conds[i] = torch.randn(T, 256, device=device, generator=gens[i]).t()
+        x_T = torch.randn(B, 1, M, T, device=device, generator=g)
+        noise = torch.randn(K, B, 1, M, T, device=device, generator=g)          # 1.05 GB, shared by the micro-batches
+        frames_per_step = CFG5_UTTS * T
+
+        def step():
+            return sharded_inference(gd, utt_conds, micro_batch=B, dst=0, x_T=lambda idx: x_T[:len(idx)],
+                                     noise=lambda idx: noise[:, :len(idx)].contiguous() if len(idx) < B else noise, K_step=K, pndm_speedup=0)
+        cond = torch.stack([utt_conds[i] for i in mine[:B]])
+    eng = gd._engine(cond)
+    eng.set_layer_tile(args.tile)
+    if args.split:
+        eng.set_split_mode(True)
+
+    el, out = _time_steps(step, args, world, device, dist)
     if rank == 0:
         assert out is not None and bool(torch.isfinite(out).all()), 'non-finite mel'
+        assert out.shape == ((CFG5_UTTS, T, M) if cfg == 5 else (B, T, M)), out.shape
 
     # roofline of the dominant kernel, measured live with HIP events on the launch stream (torch's current stream IS the
-    # stream every dsd_* call is enqueued on).  Persistent path: the kernel is k_loop, ONE launch = the whole 100-step loop.
+    # stream every dsd_* call is enqueued on).  Persistent path: the kernel is k_loop, ONE launch = the whole 100-step loop
+    # for one chunk of whole utterances (at most one workgroup per CU).
     roof = None
     if rank == 0:
         eng.prepare(cond)
@@ -593,16 +665,20 @@ def main():
             ev1.record()
             ev1.synchronize()
             assert eng.loop_timeouts() == 0, 'persistent loop: an inter-workgroup wait timed out'
-            ms = ev0.elapsed_time(ev1) / reps
-            flop = frames * K * F_EVAL_EXEC
+            launches = eng.loop_launches()
+            ms = ev0.elapsed_time(ev1) / reps / launches
+            frames_l = frames // launches
+            flop = frames_l * K * F_EVAL_EXEC
             achieved = flop / (ms * 1e-3) / 1e12
             kname = 'k_loop<1>'
-            alg_bytes = K * (frames * (20 * 2048 + 2 * 320 + 320) + L_LAYERS * 2 * 1024 * 1024 + frames // 32 * L_LAYERS * 2 * 16384)
-            note = ('one launch = the whole K=100 reverse loop (100 x (20 residual layers + head + sampler update + next input '
-                    'projection)) for all frames; achieved counts executed fp32 FLOPs (21 053 440 / frame / evaluation: conditioner '
-                    'projection hoisted, dead residual half of the last layer dropped); the figure includes two 2.6 MB device copies '
-                    'and a flag memset around the launch; *_ref_accounting credits the reference 26 427 392 FLOP / frame / evaluation')
-            ref_acc = frames * K * F_EVAL_REF / (ms * 1e-3) / 1e12
+            alg_bytes = K * (frames_l * (20 * 2048 + 2 * 320 + 320) + L_LAYERS * 2 * 1024 * 1024 + frames_l // 32 * L_LAYERS * 2 * 16384)
+            note = (f'one launch = the whole K=100 reverse loop (100 x (20 residual layers + head + sampler update + next input '
+                    f'projection)) for {frames_l} frames ({launches} launch(es) per batch of {B} x {T}); achieved counts executed fp32 FLOPs '
+                    '(21 053 440 / frame / evaluation: conditioner projection hoisted, dead residual half of the last layer dropped); the figure '
+                    'includes two device copies of the spec tensor and a flag memset around the launch; *_ref_accounting credits the reference '
+                    '26 427 392 FLOP / frame / evaluation')
+            ref_acc = frames_l * K * F_EVAL_REF / (ms * 1e-3) / 1e12
+            frames_k = frames_l
         else:
             ms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
             flop = frames * F_LAYER_EXEC
@@ -615,13 +691,14 @@ def main():
                 note += ('; EXPERIMENT: every fp32 product is six bf16 plane products on v_mfma_f32_32x32x16_bf16 - peak = the dense bf16 MFMA '
                          'peak / 6 in fp32-equivalent FLOPs')
             ref_acc = frames * F_LAYER_REF / (ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(kname, frames)
+            frames_k = frames
+        traffic, traffic_src = pmc_traffic(kname, frames_k)
         peak = 2500.0 / 6 if args.split else PEAK_FP32_MFMA_TFLOPS
         roof = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': peak,
                 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                 'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': ms, 'flop_per_launch': flop, 'achieved_ref_accounting': ref_acc, 'note': note}
-        if persistent:                      # the per-layer kernel of the fallback path, for comparison with earlier rounds
+        if persistent and cfg == 2:         # the per-layer kernel of the fallback path, for comparison with earlier rounds
             eng.set_loop_mode(0)
             lms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
             eng.set_loop_mode(1)
@@ -632,26 +709,33 @@ def main():
 
     if rank == 0:
         ms_per_step = el / args.steps * 1e3
-        value = world * B * T * args.steps / el
+        value = frames_per_step * args.steps / el
+        if cfg == 2:
+            workload = (f'BASELINE configs[1]: DiffSpeech 80-bin, residual_channels=256, 20 layers, K=100 DDPM, batch={B} x T={T} per GPU')
+            conf = {'workload': workload, 'preset': PRESET, 'utterances_per_gpu': B, 'frames': T}
+        else:
+            workload = (f'BASELINE configs[4]: {CFG5_UTTS} synthetic utterances x T={T}, DiffSpeech 80-bin denoiser, K=100 DDPM, the same set at every N, '
+                        f'sharded r::W across {world} GPU(s) in micro-batches of {B}, one RCCL gather of the mels to rank 0')
+            conf = {'workload': workload, 'preset': PRESET, 'utterances_total': CFG5_UTTS, 'utterances_per_gpu': len(mine), 'frames': T, 'micro_batch': B}
+        conf.update({'k_step': K, 'sampler': 'ddpm', 'layer_tile_frames': eng.layer_tile(),
+                     'loop': 'persistent kernel (k_loop)' if eng.loop_mode() == 1 else 'hipGraph of per-layer kernels',
+                     'timed_step': 'dsd_prepare (cond re-layout + hoisted conditioner projection, fresh cond every step) + K-step loop + denorm'
+                                   + (' + gather' if world > 1 else ''),
+                     'sharding': f'utterances r::W, RCCL gather of mels to rank 0 (backend {dist.get_backend()}, world {dist.get_world_size()})'
+                                 if world > 1 else 'single GPU'})
         res = {
-            'metric': 'mel-frames/sec (whole node) at K=100 DDPM, 80-bin, T=1024', 'value': value, 'unit': 'mel-frames/s',
+            'metric': f'mel-frames/sec (whole node) at K=100 DDPM, 80-bin, T={T}', 'value': value, 'unit': 'mel-frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'weak' if cfg == 2 else 'strong', 'vs_baseline': None,
             'dtype': 'f32 as 3 exact bf16 planes, 6 plane products per product, f32 accumulate (EXPERIMENT --split)' if args.split else 'f32',
-            'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[1]: DiffSpeech 80-bin, residual_channels=256, 20 layers, K=100 DDPM, '
-                                   f'batch={B} x T={T} per GPU', 'preset': PRESET, 'utterances_per_gpu': B, 'frames': T,
-                       'k_step': K, 'sampler': 'ddpm', 'layer_tile_frames': eng.layer_tile(),
-                       'loop': 'persistent kernel (k_loop)' if eng.loop_mode() == 1 else 'hipGraph of per-layer kernels',
-                       'sharding': 'utterances r::W, RCCL gather of mels to rank 0' if world > 1 else 'single GPU'},
-            'roofline': roof,
-            'model_tflops_ref_accounting': world * B * T * K * F_EVAL_REF * args.steps / el / 1e12,
+            'data': 'synthetic', 'config': conf, 'roofline': roof,
+            'model_tflops_ref_accounting': frames_per_step * K * F_EVAL_REF * args.steps / el / 1e12,
         }
         try:
             res['parity'] = parity_check(device)
         except Exception as e:          # fixtures missing etc. - report, do not hide
             res['parity'] = {'error': repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and cfg == 2 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
             res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
         print(json.dumps(res), flush=True)

@@ -8,7 +8,7 @@ import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdsdenoise.so')
 
-DSD_ABI_VERSION = 1
+DSD_ABI_VERSION = 2
 
 # every symbol include/dsd.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
@@ -17,14 +17,14 @@ SYMBOLS = [
     'dsd_sample_ddpm', 'dsd_p_sample', 'dsd_sample_plms', 'dsd_norm_spec', 'dsd_denorm_spec',
     'dsd_set_use_graph', 'dsd_set_layer_tile', 'dsd_time_layer_kernel', 'dsd_debug_layer_timeline', 'dsd_device_bytes',
     'dsd_get_layer_tile', 'dsd_set_loop_mode', 'dsd_get_loop_mode', 'dsd_loop_timeouts', 'dsd_debug_loop_timeline', 'dsd_set_noise_seed', 'dsd_philox_normal',
-    'dsd_set_split_mode', 'dsd_get_split_mode', 'dsd_debug_layer',
+    'dsd_set_split_mode', 'dsd_get_split_mode', 'dsd_debug_layer', 'dsd_loop_launches', 'dsd_p_sample_ex',
 ]
 # every symbol include/dsf.h declares (the FastSpeech2 conditioner ops)
 SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf_conv1d', 'dsf_layer_norm', 'dsf_attention',
                'dsf_to_channel_major', 'dsf_from_channel_major', 'dsf_p_sample', 'dsf_denorm_spec',
                'dsf_conv1d_dilated', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad',
                'dsf_train_add_step', 'dsf_train_rowsum', 'dsf_train_gate', 'dsf_train_gate_bwd', 'dsf_train_res_skip', 'dsf_train_res_skip_bwd',
-               'dsf_channel_affine', 'dsf_group_norm', 'dsf_adamw_step', 'dsf_split_conv1d_probe']
+               'dsf_channel_affine', 'dsf_group_norm', 'dsf_adamw_step']
 
 # every symbol include/dsv.h declares (the HiFi-GAN / NSF-HiFi-GAN generator ops)
 SYMBOLS_VOC = ['dsv_padded_samples', 'dsv_packed_floats', 'dsv_pack_weight', 'dsv_pad_rows', 'dsv_conv1d', 'dsv_noise_conv', 'dsv_sine_source',
@@ -100,6 +100,8 @@ def load():
     lib.dsd_set_loop_mode.argtypes = [h, C.c_int32]
     lib.dsd_get_loop_mode.argtypes = [h]
     lib.dsd_loop_timeouts.argtypes = [h, C.c_void_p]
+    lib.dsd_loop_launches.argtypes = [h]
+    lib.dsd_p_sample_ex.argtypes = [h, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p]
     lib.dsd_set_split_mode.argtypes = [h, C.c_int32, C.c_void_p]
     lib.dsd_get_split_mode.argtypes = [h]
     lib.dsd_debug_layer.argtypes = [h, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -131,7 +133,6 @@ def load():
     lib.dsf_train_res_skip.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_train_res_skip_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_adamw_step.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp, vp]
-    lib.dsf_split_conv1d_probe.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp]
     lib.dsf_channel_affine.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_group_norm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.dsv_padded_samples.argtypes = [i32]

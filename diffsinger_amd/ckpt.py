@@ -30,7 +30,21 @@ def newest_ckpt(base_dir: str) -> Optional[str]:
     return paths[-1] if paths else None
 
 
-def load_ckpt(cur_model, ckpt_base_dir, prefix_in_ckpt='model', force=True, strict=True):
+def _torch_load(path, trusted: bool = True):
+    """A reference trainer checkpoint carries non-tensor objects (numpy scalars in `checkpoint_callback_best`, optimizer / scheduler
+    dicts): torch >= 2.6 refuses to unpickle those under its default `weights_only=True`.  The reference's own `torch.load(path,
+    map_location='cpu')` (utils/__init__.py:191) predates that switch and always unpickled everything - `trusted=True` (default) keeps
+    that behaviour; pass `trusted=False` for files of unknown origin: tensors-only loading, with a clear error if the file needs more."""
+    if trusted:
+        return torch.load(path, map_location='cpu', weights_only=False)
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as e:
+        raise RuntimeError(f'{path}: not loadable with weights_only=True ({type(e).__name__}: {str(e)[:200]}); a reference trainer checkpoint '
+                           f'holds pickled non-tensor objects - pass trusted=True only if you trust the file') from e
+
+
+def load_ckpt(cur_model, ckpt_base_dir, prefix_in_ckpt='model', force=True, strict=True, trusted=True):
     """Same contract as the reference's utils.load_ckpt (including its messages and the assert when nothing is found and force)."""
     if os.path.isfile(ckpt_base_dir):
         base_dir, checkpoint_path = os.path.dirname(ckpt_base_dir), ckpt_base_dir
@@ -42,7 +56,7 @@ def load_ckpt(cur_model, ckpt_base_dir, prefix_in_ckpt='model', force=True, stri
             assert False, e_msg
         print(e_msg)
         return None
-    state_dict = torch.load(checkpoint_path, map_location='cpu')['state_dict']
+    state_dict = _torch_load(checkpoint_path, trusted)['state_dict']
     state_dict = {k[len(prefix_in_ckpt) + 1:]: v for k, v in state_dict.items() if k.startswith(f'{prefix_in_ckpt}.')}
     if not strict:
         cur = cur_model.state_dict()
@@ -116,6 +130,9 @@ def adamw_state_to_sharded(opt, sd: dict):
     opt.step_count = steps.pop() if steps else 0
     g = sd['param_groups'][0]
     opt.lr, opt.betas, opt.eps, opt.weight_decay = g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']
+    # torch's lr schedulers store the un-decayed rate as `initial_lr` in the group; `lr` is already decayed.  A StepLR built on this
+    # optimiser afterwards must start from the base rate (else it decays twice): diffsinger_amd.train_dist.StepLR reads `base_lr`.
+    opt.base_lr = g.get('initial_lr', g['lr'])
 
 
 # ---- offline aux-decoder mels -----------------------------------------------------------------------------------------------

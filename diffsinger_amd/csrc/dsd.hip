@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -98,6 +99,12 @@ struct dsd_handle {
     hipStream_t cap_stream = nullptr;
     std::map<GraphKey, hipGraphExec_t> graphs;
 
+    // pinned host staging ring for the small per-call HOST arrays (dsd_denoise's t[B], dsd_p_sample_ex's coefficients): the caller's
+    // array is copied into a slot on the host, the H2D copy from pinned memory is truly asynchronous - no stream synchronisation
+    struct PinRing { char* base = nullptr; size_t slot = 0; int next = 0; hipEvent_t ev[8] = {}; bool used[8] = {}; } pin;
+    float* coef_dev = nullptr;  // [cap_B][5] per-utterance p_sample coefficients (dsd_p_sample_ex)
+    float* eps_tmp = nullptr;   // [cap_spec] eps of dsd_p_sample_ex
+
     // persistent K-step loop (dsd_loop.hpp): 1 = one kernel for the whole loop when the batch geometry allows it
     int loop_mode = 1;
     int n_cu = 0;               // workgroups that are certainly co-resident at 1 per CU
@@ -131,6 +138,34 @@ static void dev_free(T*& p) {
     p = nullptr;
 }
 
+static const int kPinSlots = 8;
+// A slot of at least `bytes` of pinned host memory; blocks only if the copy that last read this slot (kPinSlots calls ago) is still
+// in flight.  pin_release records the event that marks the slot's H2D copy on `s`.
+static int pin_acquire(dsd_handle* h, size_t bytes, char** out, int* slot) {
+    auto& r = h->pin;
+    if (bytes > r.slot) {
+        for (int i = 0; i < kPinSlots; ++i)
+            if (r.used[i]) { HIP_TRY(hipEventSynchronize(r.ev[i])); r.used[i] = false; }
+        if (r.base) (void)hipHostFree(r.base);
+        r.base = nullptr;
+        r.slot = (bytes + 4095) / 4096 * 4096;
+        HIP_TRY(hipHostMalloc((void**)&r.base, r.slot * kPinSlots, hipHostMallocDefault));
+        for (int i = 0; i < kPinSlots; ++i)
+            if (!r.ev[i]) HIP_TRY(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+    }
+    const int i = r.next;
+    r.next = (r.next + 1) % kPinSlots;
+    if (r.used[i]) { HIP_TRY(hipEventSynchronize(r.ev[i])); r.used[i] = false; }
+    *out = r.base + (size_t)i * r.slot;
+    *slot = i;
+    return DSD_OK;
+}
+static int pin_release(dsd_handle* h, int slot, hipStream_t s) {
+    HIP_TRY(hipEventRecord(h->pin.ev[slot], s));
+    h->pin.used[slot] = true;
+    return DSD_OK;
+}
+
 static void drop_graphs(dsd_handle* h) {
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
@@ -143,7 +178,7 @@ static void free_workspace(dsd_handle* h) {
     dev_free(h->xa_base); dev_free(h->xb_base); dev_free(h->condT); dev_free(h->cp); dev_free(h->skip);
     dev_free(h->xs); dev_free(h->xtmp);
     for (auto& e : h->ering) dev_free(e);
-    dev_free(h->t_dev);
+    dev_free(h->t_dev); dev_free(h->coef_dev); dev_free(h->eps_tmp);
     dev_free(h->loop_flags); dev_free(h->loop_halo);
     h->loop_cap_tiles = 0;
     h->xa = h->xb = nullptr;
@@ -215,6 +250,8 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     dev_free(h->ds_table); dev_free(h->spec_min_d); dev_free(h->spec_max_d);
     dev_free(h->noise_cell); dev_free(h->seed_cell);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->pin.base) (void)hipHostFree(h->pin.base);
+    for (auto& e : h->pin.ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -444,6 +481,7 @@ extern "C" int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* con
         DSD_TRY(dev_alloc(h, &h->xtmp, (size_t)spec, true));
         for (auto& e : h->ering) DSD_TRY(dev_alloc(h, &e, (size_t)spec, true));
         DSD_TRY(dev_alloc(h, &h->t_dev, (size_t)B, true));
+        DSD_TRY(dev_alloc(h, &h->coef_dev, (size_t)B * 5, true));
         HIP_TRY(hipMemsetAsync(h->xa_base, 0, xcount * 4, s));
         HIP_TRY(hipMemsetAsync(h->xb_base, 0, xcount * 4, s));
         h->xa = h->xa_base + kSlack;
@@ -559,8 +597,13 @@ extern "C" int dsd_denoise(dsd_handle* h, const float* x, const int32_t* t, floa
     DSD_TRY(build_step_table(h, tmax + 1, s));
     const int* t_dev = nullptr;
     if (!uniform) {
-        HIP_TRY(hipMemcpyAsync(h->t_dev, t, (size_t)h->B * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));   // t is a caller-owned host array: do not reference it after return
+        // t is a caller-owned host array: it is copied into a pinned staging slot here, so it is not referenced after return and
+        // the H2D copy is asynchronous - no stream synchronisation
+        char* pin = nullptr; int slot = 0;
+        DSD_TRY(pin_acquire(h, (size_t)h->B * 4, &pin, &slot));
+        std::memcpy(pin, t, (size_t)h->B * 4);
+        HIP_TRY(hipMemcpyAsync(h->t_dev, pin, (size_t)h->B * 4, hipMemcpyHostToDevice, s));
+        DSD_TRY(pin_release(h, slot, s));
         t_dev = h->t_dev;
     }
     DSD_TRY(launch_inproj(h, x, s));
@@ -719,6 +762,17 @@ static void plan_evals(dsd_handle* h, int kind, int k_step, int interval, std::v
     }
 }
 
+// ONE persistent loop at a time per device: all workgroups of a k_loop launch wait for each other, so two such launches on two
+// streams of one GPU (two handles = two models of one process, or one handle driven from two streams) could each hold part of the
+// CUs and starve the other into its timeout.  Every persistent launch therefore waits (on the device, hipStreamWaitEvent) for the
+// previous persistent launch of this process on the same device when that one went to a DIFFERENT stream, and records the event
+// the next one will wait for.  The loop fills the chip anyway, so the serialisation costs nothing.
+static const int kMaxDevices = 64;
+static std::mutex g_loop_mu[kMaxDevices];
+static hipEvent_t g_loop_ev[kMaxDevices];
+static hipStream_t g_loop_stream[kMaxDevices];
+static bool g_loop_has[kMaxDevices];
+
 // true when the prepared batch can run as the persistent loop: 32-frame tiles, a whole utterance fits the co-resident grid
 static bool loop_applicable(const dsd_handle* h) {
     return h->loop_mode == 1 && !h->split_mode && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 && h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers;
@@ -758,12 +812,26 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
     p.dbg = h->loop_dbg; p.dbg_phase = h->loop_dbg_phase;
     // chunks of whole utterances, at most one workgroup per CU (all workgroups of a launch wait for each other)
     const int utt_per_chunk = std::max(1, h->n_cu / h->ntile32);
+    const int dv = (h->device >= 0 && h->device < kMaxDevices) ? h->device : 0;
+    std::lock_guard<std::mutex> guard(g_loop_mu[dv]);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool guarded = (cap == hipStreamCaptureStatusNone);
+    if (guarded) {
+        if (!g_loop_ev[dv]) HIP_TRY(hipEventCreateWithFlags(&g_loop_ev[dv], hipEventDisableTiming));
+        if (g_loop_has[dv] && g_loop_stream[dv] != s) HIP_TRY(hipStreamWaitEvent(s, g_loop_ev[dv], 0));
+    }
     for (int b0 = 0; b0 < h->B; b0 += utt_per_chunk) {
         const int nb = std::min(utt_per_chunk, h->B - b0);
         p.tile_base = b0 * h->ntile32; p.n_tiles = nb * h->ntile32;
         if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         else hipLaunchKernelGGL((k_loop<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         HIP_TRY(hipGetLastError());
+    }
+    if (guarded) {
+        HIP_TRY(hipEventRecord(g_loop_ev[dv], s));
+        g_loop_stream[dv] = s;
+        g_loop_has[dv] = true;
     }
     return DSD_OK;
 }
@@ -893,6 +961,12 @@ extern "C" int dsd_set_loop_mode(dsd_handle* h, int32_t mode) {
 
 extern "C" int dsd_get_loop_mode(dsd_handle* h) { return (h && h->prepared && loop_applicable(h)) ? 1 : 0; }
 
+extern "C" int dsd_loop_launches(dsd_handle* h) {
+    if (!h || !h->prepared || !loop_applicable(h)) return 0;
+    const int utt_per_chunk = std::max(1, h->n_cu / h->ntile32);
+    return (h->B + utt_per_chunk - 1) / utt_per_chunk;
+}
+
 extern "C" int dsd_loop_timeouts(dsd_handle* h, void* stream) {
     if (!h) return fail(DSD_ERR_INVALID, "dsd_loop_timeouts: null handle");
     if (!h->loop_flags) return 0;
@@ -955,6 +1029,37 @@ extern "C" int dsd_p_sample(dsd_handle* h, float* x, const float* noise, int32_t
     p.sa = h->tab[6][t]; p.sb = h->tab[7][t]; p.c1 = h->tab[10][t]; p.c2 = h->tab[11][t];
     p.sigma = (t == 0) ? 0.f : std::exp(0.5f * h->tab[9][t]);
     return launch_head<HEAD_DDPM>(h, p, false, s);
+}
+
+// p_sample with everything the reference's signature allows (shallow_diffusion_tts.py:159-166): a step index PER UTTERANCE,
+// clip_denoised on / off, and noise either per utterance or one [M][T] draw repeated over the batch (repeat_noise, noise_like :38-41).
+// = DiffNet evaluation with t[B] (the per-layer kernels) + one element-wise kernel with per-utterance coefficients.
+extern "C" int dsd_p_sample_ex(dsd_handle* h, float* x, const float* noise, const int32_t* t, int32_t clip_denoised, int32_t repeat_noise,
+                               void* stream) {
+    DSD_TRY(check_ready(h, "dsd_p_sample_ex", true));
+    if (!x || !noise || !t) return fail(DSD_ERR_INVALID, "dsd_p_sample_ex: null argument");
+    for (int b = 0; b < h->B; ++b)
+        if (t[b] < 0 || t[b] >= h->n_sched) return fail(DSD_ERR_INVALID, "dsd_p_sample_ex: t[%d]=%d outside the %d-step schedule", b, t[b], h->n_sched);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t bmt = (size_t)h->B * h->M * h->T;
+    if (!h->eps_tmp) DSD_TRY(dev_alloc(h, &h->eps_tmp, (size_t)h->cap_spec, true));
+    DSD_TRY(dsd_denoise(h, x, t, h->eps_tmp, stream));
+    char* pin = nullptr; int slot = 0;
+    DSD_TRY(pin_acquire(h, (size_t)h->B * 5 * 4, &pin, &slot));
+    float* c = reinterpret_cast<float*>(pin);
+    for (int b = 0; b < h->B; ++b) {
+        const int tt = t[b];
+        c[5 * b + 0] = h->tab[6][tt]; c[5 * b + 1] = h->tab[7][tt]; c[5 * b + 2] = h->tab[10][tt]; c[5 * b + 3] = h->tab[11][tt];
+        c[5 * b + 4] = (tt == 0) ? 0.f : std::exp(0.5f * h->tab[9][tt]);
+    }
+    HIP_TRY(hipMemcpyAsync(h->coef_dev, pin, (size_t)h->B * 5 * 4, hipMemcpyHostToDevice, s));
+    DSD_TRY(pin_release(h, slot, s));
+    const size_t per = (size_t)h->M * h->T;
+    hipLaunchKernelGGL(k_psample_ex, dim3((unsigned)std::min<size_t>((bmt + 255) / 256, 8192)), dim3(256), 0, s, x, h->eps_tmp, noise, h->coef_dev,
+                       per, bmt, clip_denoised ? 1 : 0, repeat_noise ? (size_t)0 : per);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
 }
 
 extern "C" int dsd_sample_plms(dsd_handle* h, float* x, int32_t k_step, int32_t interval, void* stream) {

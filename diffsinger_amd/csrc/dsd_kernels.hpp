@@ -895,6 +895,23 @@ __global__ void k_qsample(const float* __restrict__ x0, const float* __restrict_
 }
 
 // norm_spec + transpose: mel [B][T][M] -> x [B][M][T]   ((x - min) / (max - min) * 2 - 1, :278-279)
+// p_mean_variance + p_sample (shallow_diffusion_tts.py:134-166) as a stand-alone element-wise kernel with PER-UTTERANCE coefficients
+// coef[b] = {sqrt_recip_ac, sqrt_recipm1_ac, posterior_mean_coef1, posterior_mean_coef2, [t != 0] * exp(0.5 logvar)} at t[b];
+// clip = clip_denoised; z_bstride = 0 repeats one [M][T] draw over the batch (repeat_noise).  Every product rounded like the
+// reference's tensor ops (the file is compiled with -ffp-contract=off).
+__global__ void k_psample_ex(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ z, const float* __restrict__ coef,
+                             size_t per_utt, size_t n, int clip, size_t z_bstride) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per_utt, r = i - b * per_utt;
+        const float* c = coef + 5 * b;
+        const float xv = x[i];
+        float x0 = __fsub_rn(__fmul_rn(c[0], xv), __fmul_rn(c[1], eps[i]));
+        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        const float mean = __fadd_rn(__fmul_rn(c[2], x0), __fmul_rn(c[3], xv));
+        x[i] = __fadd_rn(mean, __fmul_rn(c[4], z[b * z_bstride + r]));
+    }
+}
+
 __global__ void k_norm_spec(const float* __restrict__ mel, float* __restrict__ x, const float* __restrict__ smin,
                             const float* __restrict__ smax, int M, int T) {
     extern __shared__ float tile[];                 // [32][M+1]

@@ -14,7 +14,6 @@
 //      8 consecutive channels of one frame = one ds_read_b128 per plane, conflict-free.  The k order inside an MFMA is whatever the
 //      hardware defines - A and B use the same (h, e) -> channel map, so it cancels.
 // First version: the whole y tile is staged before the first MFMA (no progressive quarters), 2-byte LDS writes in the staging pass.
-// At the end of the file: the stand-alone convolution prototypes of the same arithmetic (k_split_conv, k_split_conv_p; dsf_split_conv1d_probe).
 #pragma once
 #include "dsd_kernels.hpp"
 
@@ -359,214 +358,6 @@ __global__ void k_dbg_skip_to_logical(const float4* __restrict__ skip, float* __
         const int j = lane & 31, h = lane >> 5;
         const float ve[4] = {v.x, v.y, v.z, v.w};
         for (int e = 0; e < 4; ++e) out[((size_t)b * kC + 64 * w + 32 * ms + frag_row(4 * q + e, h)) * TS + tn * 32 + j] = ve[e];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (not on any product path): the dilated conv of the denoiser as an fp32-accurate GEMM on the bf16 matrix pipe
-// ------------------------------------------------------------------------------------------------------------
-// DESIGN section 10 "beyond the fp32-MFMA ceiling".  out[512][32 frames] = W[512][256 x 3 taps] * y per workgroup; every fp32 operand is
-// the exact sum of three bf16 planes and the six plane products with i + j <= 2 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16
-// (192 cycles per K = 16 instead of 512 on the fp32 MFMA).  Correctness-first prototype with the operand layouts the real kernel would
-// use - weights as planes in fragment order (packed on the host, tests/ and diffsinger_amd/experimental.py), the y tile as
-// [plane][frame][channel] bf16 in LDS with a padded 528-byte frame stride read with ds_read_b128 - and a plain two-stage register
-// pipeline left to the compiler's scheduler.  What it is for: parity of the split arithmetic on the hardware and a first rate with real
-// operand traffic, before the layer kernels are rebuilt around it.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned short u16;
-
-constexpr int kSplitRS = 264;                         // bf16 per frame row: 256 channels + 8 pad (528 B: conflict-free b128 reads)
-constexpr int kSplitFrames = 32 + 2 * kHalo;          // 48 staged frames
-constexpr int kSplitLdsBytes = 3 * kSplitFrames * kSplitRS * 2;
-
-struct SplitConvParams {
-    const float* in;        // [B][256][TS] fp32, zero in [T, TS)
-    const uint4* wp;        // [wave 4][chunk 48 = 16 k16 x 3 taps][row block 4][plane 3][lane 64] x 8 bf16
-    float* out;             // [B][512][TS]
-    int T, TS, dil;
-};
-
-__device__ __forceinline__ void split3_bf16(float x, u16& a, u16& b, u16& c) {
-    const __bf16 p0 = (__bf16)x;
-    const float r1 = x - (float)p0;
-    const __bf16 p1 = (__bf16)r1;
-    const __bf16 p2 = (__bf16)(r1 - (float)p1);
-    a = __builtin_bit_cast(u16, p0); b = __builtin_bit_cast(u16, p1); c = __builtin_bit_cast(u16, p2);
-}
-
-__global__ __launch_bounds__(kThreads, 1) void k_split_conv(const SplitConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) u16 ysm[];          // [3][48][264]
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t0 = blockIdx.x * 32, b = blockIdx.y;
-    const float* inb = p.in + (size_t)b * kC * p.TS;
-    for (int idx = tid; idx < kC * (kSplitFrames / 4); idx += kThreads) {
-        const int c = idx / (kSplitFrames / 4), g = idx - c * (kSplitFrames / 4);
-        const int t = t0 - kHalo + 4 * g;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(inb + (size_t)c * p.TS + t);
-        const float ve[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            u16 a0, a1, a2;
-            split3_bf16(ve[e], a0, a1, a2);
-            const int o = (4 * g + e) * kSplitRS + c;
-            ysm[o] = a0; ysm[kSplitFrames * kSplitRS + o] = a1; ysm[2 * kSplitFrames * kSplitRS + o] = a2;
-        }
-    }
-    __syncthreads();
-    f32x16 acc[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    const uint4* wl = p.wp + (size_t)w * (48 * 4 * 3 * 64) + lane;
-    uint4 a[2][4][3];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[0][mb][pl] = wl[(mb * 3 + pl) * 64];
-#pragma unroll 2
-    for (int kc = 0; kc < 48; ++kc) {
-        const int cur = kc & 1;
-        if (kc + 1 < 48) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[cur ^ 1][mb][pl] = wl[((size_t)(kc + 1) * 12 + mb * 3 + pl) * 64];
-        }
-        const int k16 = kc / 3, tap = kc - 3 * k16;
-        const int frow = j + kHalo + (tap - 1) * p.dil;
-        bf16x8_t bv[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            bv[pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ysm + (pl * kSplitFrames + frow) * kSplitRS + 16 * k16 + 8 * h));
-        // six plane products, smallest first; consecutive MFMAs go to different accumulators
-        constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[cur][mb][TI[q]]), bv[TJ[q]], acc[mb], 0, 0, 0);
-    }
-    const int t = t0 + j;
-    if (t < p.TS) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                p.out[((size_t)b * 512 + 128 * w + 32 * mb + frag_row(r, h)) * p.TS + t] = (t < p.T) ? acc[mb][r] : 0.f;
-    }
-}
-
-// The same convolution with the hand-pinned operand pipeline of GemmPipe transplanted: three register stages of the weight stream (chunk
-// kc + 2 is requested while chunk kc is multiplied: 2 x 768 MFMA cycles ahead), the B fragment one chunk ahead, and inside a step the 12
-// weight loads and 3 LDS reads interleaved one-by-one behind the first MFMAs with sched_group_barrier.  Rotation period 6 (3 weight stages
-// x 2 B buffers), so chunk = 6 it + I has a compile-time tap (I % 3) and channel group 2 it + I / 3.
-template <int STAGES>
-struct SplitPipe {
-    static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned aoff;
-    const u16* btap[3];          // this lane's B row of tap 0 / 1 / 2 (plane 0, channel group 0)
-    uint4 a[STAGES][4][3];
-    bf16x8_t b[2][3];
-
-    __device__ __forceinline__ SplitPipe(const uint4* wave_base, int lane, const u16* ysm, int j, int h, int dil)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u) {
-#pragma unroll
-        for (int tp = 0; tp < 3; ++tp) btap[tp] = ysm + (j + kHalo + (tp - 1) * dil) * kSplitRS + 8 * h;
-    }
-    __device__ __forceinline__ void lda(uint4 (&dst)[4][3], int kc) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const int kcc = (kc < 48) ? kc : 47;                              // prefetches past the end re-read the last chunk
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kcc * 12288 + (mb * 3 + pl) * 1024, 0);
-                dst[mb][pl] = make_uint4(v.x, v.y, v.z, v.w);
-            }
-    }
-    template <int I>
-    __device__ __forceinline__ void ldb(bf16x8_t (&dst)[3], int it) {         // chunk 6 it + I
-        const int itc = (6 * it + I < 48) ? it : 7;
-        const u16* bp = btap[I % 3] + (2 * itc + I / 3) * 16;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) dst[pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bp + pl * (kSplitFrames * kSplitRS)));
-    }
-    __device__ __forceinline__ void pattern() {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
-    }
-    template <int I>
-    __device__ __forceinline__ void step(f32x16 (&acc)[4], int it) {
-        lda(a[(I + STAGES - 1) % STAGES], 6 * it + I + STAGES - 1);
-        if (I == 5) ldb<0>(b[0], it + 1); else ldb<(I + 1) % 6>(b[(I + 1) & 1], it);
-        constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[I % STAGES][mb][TI[q]]), b[I & 1][TJ[q]], acc[mb], 0, 0, 0);
-        pattern();
-        DSD_SB();
-    }
-};
-
-template <int STAGES>
-__global__ __launch_bounds__(kThreads, 1) void k_split_conv_p(const SplitConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) u16 ysm[];          // [3][48][264]
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t0 = blockIdx.x * 32, b = blockIdx.y;
-    SplitPipe<STAGES> pipe(p.wp + (size_t)w * (48 * 4 * 3 * 64), lane, ysm, j, h, p.dil);
-#pragma unroll
-    for (int i = 0; i < STAGES - 1; ++i) pipe.lda(pipe.a[i], i);       // the weight stream does not depend on the tile: request it first
-    DSD_SB();
-    const float* inb = p.in + (size_t)b * kC * p.TS;
-    for (int idx = tid; idx < kC * (kSplitFrames / 4); idx += kThreads) {
-        const int c = idx / (kSplitFrames / 4), g = idx - c * (kSplitFrames / 4);
-        const int t = t0 - kHalo + 4 * g;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(inb + (size_t)c * p.TS + t);
-        const float ve[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            u16 a0, a1, a2;
-            split3_bf16(ve[e], a0, a1, a2);
-            const int o = (4 * g + e) * kSplitRS + c;
-            ysm[o] = a0; ysm[kSplitFrames * kSplitRS + o] = a1; ysm[2 * kSplitFrames * kSplitRS + o] = a2;
-        }
-    }
-    __syncthreads();
-    f32x16 acc[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    pipe.template ldb<0>(pipe.b[0], 0);
-    DSD_SB();
-    for (int it = 0; it < 8; ++it) {
-        pipe.template step<0>(acc, it); pipe.template step<1>(acc, it); pipe.template step<2>(acc, it);
-        pipe.template step<3>(acc, it); pipe.template step<4>(acc, it); pipe.template step<5>(acc, it);
-    }
-    const int t = t0 + j;
-    if (t < p.TS) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                p.out[((size_t)b * 512 + 128 * w + 32 * mb + frag_row(r, h)) * p.TS + t] = (t < p.T) ? acc[mb][r] : 0.f;
     }
 }
 

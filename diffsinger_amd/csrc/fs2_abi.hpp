@@ -280,42 +280,3 @@ extern "C" int dsf_adamw_step(float* p, const float* g, float* m, float* v, int6
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }
-
-// ---- EXPERIMENT: split-precision convolution prototype; not used by any product path ---------------------
-extern "C" int dsf_split_conv1d_probe(const float* in, const void* wplanes, float* out, int32_t B, int32_t T, int32_t dil, int32_t variant,
-                                      int32_t iters, float* avg_ms, void* stream) {
-    if (!in || !wplanes || !out || B < 1 || B > 65535 || T < 1 || dil < 1 || dil > kHalo || iters < 1 || variant < 0 || variant > 2)
-        return fail(DSD_ERR_INVALID, "dsf_split_conv1d_probe: bad argument");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_split_conv, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_split_conv_p<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_split_conv_p<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
-        attr_done = true;
-    }
-    SplitConvParams p{};
-    p.in = in; p.wp = reinterpret_cast<const uint4*>(wplanes); p.out = out; p.T = T; p.TS = fs_ts(T); p.dil = dil;
-    const dim3 grid((unsigned)(p.TS / 32), (unsigned)B);
-    hipStream_t s = (hipStream_t)stream;
-    void (*kern)(const SplitConvParams) = (variant == 2) ? k_split_conv_p<6> : (variant == 1) ? k_split_conv_p<3> : k_split_conv;
-    if (!avg_ms) {
-        for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(kThreads), kSplitLdsBytes, s, p);
-        HIP_TRY(hipGetLastError());
-        return DSD_OK;
-    }
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    hipLaunchKernelGGL(kern, grid, dim3(kThreads), kSplitLdsBytes, s, p);                  // warm
-    HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(kThreads), kSplitLdsBytes, s, p);
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *avg_ms = ms / (float)iters;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    HIP_TRY(hipGetLastError());
-    return DSD_OK;
-}

@@ -7,9 +7,10 @@ infer=True) -> dict` with 'mel_out' / 'fs2_mel', `q_sample`, `p_sample`, `p_samp
 `denorm_spec`, `cwt2f0_norm`, `out2mel`.  Added: `inference(cond, ...)` - the K-step loop with the RNG made
 explicit - which `forward(infer=True)` delegates to (BASELINE.json north_star).
 
-Out of scope (raises): the training branch (`p_losses`).  `self.fs2` (FastSpeech2, the
-caller of the hot path, row f1) is not re-implemented: inside the reference tree it is built exactly like the
-reference does; stand-alone pass `fs2=` or call `inference()` with a precomputed `cond`."""
+The training branch (`p_losses`, `forward(infer=False)`) runs on the HIP training operators
+(`diffsinger_amd/train.py`).  `self.fs2` (FastSpeech2, the caller of the hot path, row f1): inside the reference tree it is built
+exactly like the reference does; stand-alone pass `fs2=` (the HIP `diffsinger_amd.fs2.FastSpeech2(.MIDI)`) or call `inference()`
+with a precomputed `cond`."""
 from __future__ import annotations
 
 from collections import deque
@@ -125,17 +126,20 @@ class GaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def p_sample(self, x, t, cond, clip_denoised=True, repeat_noise=False, noise=None):
-        """:159-166.  One ancestral step; returns a new tensor like the reference."""
-        if not clip_denoised or repeat_noise:
-            raise NotImplementedError('only the inference loop configuration (clip_denoised=True, repeat_noise=False)')
+        """:159-166.  One ancestral step; returns a new tensor like the reference.  t: [B] long tensor - one step index per utterance,
+        equal or not (the sampling loop passes torch.full((B,), i)); clip_denoised / repeat_noise as in the reference (noise_like
+        :38-41: with repeat_noise ONE [1,1,M,T] draw serves the whole batch).  `noise` makes the draw explicit."""
         eng = self._engine(cond)
-        tt = t.reshape(-1)
-        if not bool((tt == tt[0]).all()):
-            raise NotImplementedError('p_sample: the sampling loop uses one t for the whole batch')
-        if noise is None:
-            noise = torch.randn(x.shape, device=x.device)       # noise_like(:38-41), drawn at every step
+        tt = t.reshape(-1).tolist()
+        if len(tt) == 1:
+            tt = tt * x.shape[0]
+        if noise is None:                                       # noise_like(:38-41), drawn at every step, t = 0 included
+            noise = torch.randn((1, *x.shape[1:]) if repeat_noise else x.shape, device=x.device)
         out = x.clone().contiguous()
-        eng.p_sample(out, noise, int(tt[0]))
+        if clip_denoised and not repeat_noise and all(v == tt[0] for v in tt):
+            eng.p_sample(out, noise, int(tt[0]))                # the configuration of the sampling loop: fused into the head kernel
+        else:
+            eng.p_sample_ex(out, noise, tt, clip_denoised=clip_denoised, repeat_noise=repeat_noise)
         return out
 
     @torch.no_grad()
@@ -316,15 +320,27 @@ class GaussianDiffusion(nn.Module):
 
 
 class OfflineGaussianDiffusion(GaussianDiffusion):
-    """:291-323 - aux mel supplied through ref_mels[1], DDPM only."""
+    """:291-323 - `ref_mels = [target mel, offline aux mel]`: FastSpeech2 runs with skip_decoder=True, infer=True in BOTH branches
+    (:295-296), the diffusion is trained on ref_mels[0] (:300-305) and sampling starts from q_sample of the OFFLINE aux mel
+    ref_mels[1] (:306-313), DDPM only (:318-319), `gaussian_start` honoured (:314-317), no `mel2ph > 0` mask on the output."""
 
     def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None, infer=False,
                 **kwargs):
-        if not infer:
-            raise NotImplementedError('training branch (p_losses) is outside the HIP hot path; train with the reference')
         if self.fs2 is None:
             raise RuntimeError('no FastSpeech2 attached (self.fs2)')
-        ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=True, **kwargs)
+        from .fs2 import FastSpeech2 as HipFS2
+        if isinstance(self.fs2, HipFS2) and not infer:          # the HIP FastSpeech2 has no autograd: a frozen conditioner in training
+            with torch.no_grad():
+                ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=True, **kwargs)
+        else:
+            ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=True, **kwargs)
         cond = ret['decoder_inp'].transpose(1, 2)
-        ret['mel_out'] = self.inference(cond, fs2_mels=ref_mels[1], pndm_speedup=0)
+        fs2_mels, target = ref_mels[1], ref_mels[0]
+        if not infer:
+            b = txt_tokens.shape[0]
+            t = torch.randint(0, self.K_step, (b,), device=txt_tokens.device).long()
+            x = self.norm_spec(target).transpose(1, 2)[:, None, :, :]
+            ret['diff_loss'] = self.p_losses(x, t, cond)
+        else:
+            ret['mel_out'] = self.inference(cond, fs2_mels=fs2_mels, pndm_speedup=0)
         return ret

@@ -31,10 +31,13 @@ def unshard_order(n_items: int, world: int) -> List[int]:
     return inv
 
 
-def gather_mels(local: torch.Tensor, n_items: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+def gather_mels(local: torch.Tensor, n_items: int, dst: int = 0, group=None, order: str = 'original') -> Optional[torch.Tensor]:
     """local: this rank's [n_local, T, M] mels (all ranks the same T, M; n_local may differ by one).
     Returns on `dst` the [n_items, T, M] tensor in ORIGINAL utterance order, None elsewhere.
-    One collective: ranks with fewer items pad to the maximum with zeros."""
+    One collective into ONE receive buffer [W, n_max, T, M] (the gather list is its W slices; ranks with fewer items pad to the maximum
+    with zeros).  Utterance i = k W + r sits at [r][k], so the original order is the transposed view [n_max, W] flattened: one strided copy
+    (`order='original'`), or no copy at all for a consumer that indexes the view itself (`order='view'` returns that [n_max, W, T, M] view;
+    entry [k][r] is utterance k W + r, entries with k W + r >= n_items are padding)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_max = (n_items + world - 1) // world
@@ -45,14 +48,12 @@ def gather_mels(local: torch.Tensor, n_items: int, dst: int = 0, group=None) -> 
         buf[:local.shape[0]] = local
     buf = buf.contiguous()
     if rank == dst:
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.gather(buf, gather_list=parts, dst=dst, group=group)
-        out = torch.empty(n_items, T, M, dtype=local.dtype, device=local.device)
-        for r in range(world):
-            idx = shard_indices(n_items, r, world)
-            if idx:
-                out[idx] = parts[r][:len(idx)]
-        return out
+        recv = torch.empty(world, n_max, T, M, dtype=local.dtype, device=local.device)
+        dist.gather(buf, gather_list=list(recv.unbind(0)), dst=dst, group=group)
+        view = recv.transpose(0, 1)
+        if order == 'view':
+            return view
+        return view.reshape(n_max * world, T, M)[:n_items]
     dist.gather(buf, gather_list=None, dst=dst, group=group)
     return None
 
@@ -70,23 +71,31 @@ def sharded_inference(model, conds: Sequence[torch.Tensor], *, micro_batch: int 
         cond = torch.stack([conds[i] for i in idx])
         kw = {k: (v(idx) if callable(v) else v) for k, v in infer_kw.items()}
         outs.append(model.inference(cond, **kw))
-    T = conds[0].shape[-1]
-    local = torch.cat(outs) if outs else torch.zeros(0, T, model.mel_bins, device=conds[0].device)
+    some = next(c for c in conds if c is not None)          # a rank only needs ITS utterances' conditioners; the others may be None
+    T = some.shape[-1]
+    local = torch.cat(outs) if outs else torch.zeros(0, T, model.mel_bins, device=some.device)
     if world == 1:
         return local
     return gather_mels(local, len(conds), dst=dst, group=group)
 
 
-def gather_ragged(local: Sequence[torch.Tensor], n_items: int, dst: int = 0, group=None):
+def _collective_device(group=None) -> torch.device:
+    """Where a tensor has to live to take part in a collective of this group: the current HIP device under RCCL, the host under gloo."""
+    return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+
+
+def gather_ragged(local: Sequence[torch.Tensor], n_items: int, dst: int = 0, group=None, device=None, dtype=None):
     """Collate per-utterance 1-D results of DIFFERENT lengths (waveforms of the vocoder stage, f0 tracks) sharded r::W: this rank's
-    tensors in shard order -> on `dst` the list of n_items tensors in ORIGINAL utterance order, None elsewhere.  Two collectives: the
-    lengths (one int64 gather), then one gather of the payloads padded to the longest - the reference writes one file per utterance
-    from every rank instead (tasks/tts/fs2.py:414-431)."""
+    tensors in shard order -> on `dst` the list of n_items tensors in ORIGINAL utterance order, None elsewhere.  Three collectives: the
+    lengths (one int64 gather), the longest length (one all-reduce), then one gather of the payloads padded to the longest - the reference
+    writes one file per utterance from every rank instead (tasks/tts/fs2.py:414-431).  A rank WITHOUT items (n_items < world) still takes
+    part: its buffers live on `device` (default: the current HIP device under RCCL, the host under gloo) with `dtype` (default float32;
+    pass it when the payloads are not float32 - every rank must use the same dtype)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_max = (n_items + world - 1) // world
-    dev = local[0].device if len(local) else torch.device('cpu')
-    dtype = local[0].dtype if len(local) else torch.float32
+    dev = torch.device(device) if device is not None else (local[0].device if len(local) else _collective_device(group))
+    dtype = dtype if dtype is not None else (local[0].dtype if len(local) else torch.float32)
     lens = torch.zeros(n_max, dtype=torch.int64, device=dev)
     for i, t in enumerate(local):
         lens[i] = t.numel()

@@ -107,6 +107,10 @@ class DenoiserEngine:
     def loop_mode(self) -> int:
         return self.lib.dsd_get_loop_mode(self._h)
 
+    def loop_launches(self) -> int:
+        """k_loop launches per sampling call for the prepared batch (chunks of whole utterances); 0 = not on the persistent path."""
+        return self.lib.dsd_loop_launches(self._h)
+
     def set_split_mode(self, on: bool):
         """EXPERIMENT (csrc/dsd_split.hpp; default off): the residual layers as six bf16 plane products per fp32
         product on the bf16 matrix pipe (fp32-class accuracy).  Uses the per-layer kernel path while it is on."""
@@ -233,6 +237,31 @@ class DenoiserEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dsd_p_sample(self._h, xs.data_ptr(), z.data_ptr() if z is not None else None, int(t), _stream_ptr(self.device)),
                        'dsd_p_sample')
+        return x
+
+    def p_sample_ex(self, x: torch.Tensor, noise: torch.Tensor, t, clip_denoised: bool = True, repeat_noise: bool = False) -> torch.Tensor:
+        """In place: one p_sample call with a step index PER UTTERANCE, optional clamp, and noise [B,M,T] or - repeat_noise - one
+        [M,T] draw shared by the batch (usr/diff/shallow_diffusion_tts.py:159-166, noise_like :38-41)."""
+        xs = self._spec(x)
+        if not xs.is_contiguous():
+            raise ValueError('x must be contiguous (it is updated in place)')
+        B, T = self.prepared_shape
+        if isinstance(t, torch.Tensor):
+            t = t.detach().cpu().reshape(-1).tolist()
+        if isinstance(t, int):
+            t = [t] * B
+        if len(t) != B:
+            raise ValueError('t must have one entry per utterance')
+        if repeat_noise:
+            z = noise.reshape(-1, self.M, T)[0].contiguous()
+            if z.dtype != torch.float32 or z.device != self.device:
+                raise ValueError('noise must be fp32 on the engine device')
+        else:
+            z = self._spec(noise, 'noise').contiguous()
+        tarr = (C.c_int32 * B)(*[int(v) for v in t])
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_p_sample_ex(self._h, xs.data_ptr(), z.data_ptr(), tarr, int(bool(clip_denoised)), int(bool(repeat_noise)),
+                                                _stream_ptr(self.device)), 'dsd_p_sample_ex')
         return x
 
     def sample_plms(self, x: torch.Tensor, k_step: int, interval: int) -> torch.Tensor:

@@ -33,11 +33,23 @@ class GaussianDiffusion(_ShallowGaussianDiffusion):
                               return_x=return_x)
 
     def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None, infer=False):
-        if not infer:
-            raise NotImplementedError('training branch (p_losses) is outside the HIP hot path; train with the reference')
         if self.fs2 is None:
             raise RuntimeError('no FastSpeech2 attached (self.fs2): run inside the reference tree, pass fs2=, or call '
                                'sample(cond) with a precomputed conditioner')
+        if not infer:
+            # :296-311 - t ~ U[0, num_timesteps), L1 / L2 on the predicted noise with the `mel2ph != 0` non-padding factor
+            from .fs2 import FastSpeech2 as HipFS2
+            if isinstance(self.fs2, HipFS2):                    # the HIP FastSpeech2 has no autograd: a frozen conditioner here
+                with torch.no_grad():
+                    ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=True)
+            else:
+                ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=False)
+            cond = ret['decoder_inp'].transpose(1, 2)
+            b = txt_tokens.shape[0]
+            t = torch.randint(0, self.num_timesteps, (b,), device=txt_tokens.device).long()
+            x = self.norm_spec(ref_mels).transpose(1, 2)[:, None, :, :]
+            ret['diff_loss'] = self.p_losses(x, t, cond, nonpadding=(mel2ph != 0).float())
+            return ret
         ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=infer)
         cond = ret['decoder_inp'].transpose(1, 2)
         ret['mel_out'] = self.sample(cond)

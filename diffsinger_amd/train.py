@@ -229,6 +229,10 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
 def p_losses(gd, x_start: torch.Tensor, t: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tensor] = None,
              nonpadding: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:213-231)."""
+    from .net import DiffNet
+    if not isinstance(gd.denoise_fn, DiffNet):
+        raise NotImplementedError(f'p_losses: training is implemented for the DiffNet denoiser (diff_decoder_type "wavenet"); '
+                                  f'{type(gd.denoise_fn).__name__} is inference-only here')
     if noise is None:
         noise = torch.randn_like(x_start)
     shape = (x_start.shape[0], 1, 1, 1)

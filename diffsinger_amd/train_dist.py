@@ -59,6 +59,10 @@ class ShardedAdamW:
     Do NOT wrap the model in DDP as well: the exchange happens here, after backward."""
 
     ALIGN = 64          # floats: shard boundaries stay 256-byte aligned
+    # Known difference from torch.optim.AdamW: every parameter's .grad is a permanent view of the (zeroed) flat gradient, so a parameter
+    # that receives NO gradient in a step (an unused branch; fs2.decoder / mel_out under skip_decoder=True) is updated with g = 0 -
+    # its moments decay and, with weight_decay > 0, so does the weight - whereas torch skips grad=None parameters entirely (no decay,
+    # no state entry).  Hand this optimiser only the parameters the step really trains (the denoiser's), as train.py / the tests do.
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                  clip_grad_norm: Optional[float] = None, group=None, _update: Optional[Callable] = None):
@@ -113,8 +117,8 @@ class ShardedAdamW:
         else:
             g_shard = self.flat_g[lo:lo + self.shard]
         gscale = torch.full((1,), 1.0 / self.world, device=g_shard.device, dtype=torch.float32)
-        if self.clip is not None:
-            sq = (g_shard * g_shard).sum().reshape(1)
+        if self.clip is not None and self.clip > 0:                   # the reference clips only when clip_grad_norm > 0 (utils/pl_utils.py:1165-1168;
+            sq = (g_shard * g_shard).sum().reshape(1)                 # configs/config_base.yaml ships clip_grad_norm: 0 = no clipping)
             if self.world > 1:
                 dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
             total_norm = sq.sqrt() / self.world                       # norm of the AVERAGED gradient (what DDP hands clip_grad_norm_)
@@ -129,7 +133,7 @@ class ShardedAdamW:
 
     # ---- checkpointing: the state is 1/W of torch.optim.AdamW's; gather it to write a reference-compatible optimizer state ------
     def state_dict(self):
-        return {'step': self.step_count, 'exp_avg_shard': self.exp_avg, 'exp_avg_sq_shard': self.exp_avg_sq, 'rank': self.rank,
+        return {'step': self.step_count, 'exp_avg_shard': self.exp_avg.clone(), 'exp_avg_sq_shard': self.exp_avg_sq.clone(), 'rank': self.rank,
                 'world': self.world, 'lr': self.lr}
 
     def load_state_dict(self, sd):
@@ -138,6 +142,8 @@ class ShardedAdamW:
         self.step_count = int(sd['step'])
         self.exp_avg.copy_(sd['exp_avg_shard'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq_shard'])
+        if 'lr' in sd:
+            self.lr = float(sd['lr'])
 
 
 class StepLR:
@@ -145,7 +151,8 @@ class StepLR:
     (`scheduler.step(global_step // accumulate_grad_batches)`): lr = base * gamma ** (step // step_size)."""
 
     def __init__(self, optimizer: ShardedAdamW, step_size: int, gamma: float = 0.5):
-        self.opt, self.base, self.step_size, self.gamma = optimizer, optimizer.lr, step_size, gamma
+        # base rate: the un-decayed `initial_lr` of a resumed torch state (ckpt.adamw_state_to_sharded) if there is one, else the current rate
+        self.opt, self.base, self.step_size, self.gamma = optimizer, getattr(optimizer, 'base_lr', optimizer.lr), step_size, gamma
 
     def step(self, global_step: int):
         self.opt.lr = self.base * self.gamma ** (global_step // self.step_size)

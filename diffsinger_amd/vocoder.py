@@ -410,7 +410,8 @@ def load_model(config_path, checkpoint_path, device=None):
     import yaml
     if device is None:
         device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
-    ckpt_dict = torch.load(checkpoint_path, map_location='cpu')
+    from .ckpt import _torch_load
+    ckpt_dict = _torch_load(checkpoint_path, trusted=True)         # the reference's own torch.load (vocoders/hifigan.py:19) unpickles everything
     if '.yaml' in config_path:
         with open(config_path) as f:
             config = yaml.safe_load(f)

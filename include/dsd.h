@@ -7,8 +7,12 @@
  * Conventions
  *   - all tensors fp32, row-major contiguous unless strides are given; device pointers unless marked HOST
  *   - "spec" tensors are [B][M][T] (the reference's [B,1,M,T] with the unit dim dropped), T innermost
- *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only ENQUEUES work
- *     on it, there are no hidden device synchronisations; results are ordered like any other stream work
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every data-path call only ENQUEUES work
+ *     on it and returns; results are ordered like any other stream work.  The exceptions, all outside the steady state:
+ *     dsd_prepare synchronises the stream when (and only when) the workspace has to GROW (more tiles / utterances than any
+ *     batch before: the old buffers may still be in use), the first call that needs a larger step table does (one-time
+ *     table build), and the calls documented as measurement / debug hooks do.  Small HOST arrays (dsd_denoise's t[B]) are
+ *     copied into a pinned staging ring inside the call: the caller's array is not referenced after return and nothing waits
  *   - return 0 on success, a negative dsd_status otherwise; dsd_last_error() gives the message (thread-local)
  *   - ownership: the caller owns every tensor it passes; the handle owns only its packed weights, tables,
  *     workspace and cached hipGraphs, all released by dsd_destroy()
@@ -24,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DSD_ABI_VERSION 1
+#define DSD_ABI_VERSION 2
 
 typedef struct dsd_handle dsd_handle;
 
@@ -123,6 +127,11 @@ int dsd_philox_normal(dsd_handle* h, uint64_t seed, int32_t step, float* out, in
 /* One p_sample call (shallow_diffusion_tts.py:159-166) at step t: x [B][M][T] updated in place from x_t to
  * x_{t-1}; noise [B][M][T] is the N(0,1) draw of `noise_like` (ignored by the arithmetic when t == 0). */
 int dsd_p_sample(dsd_handle* h, float* x, const float* noise, int32_t t, void* stream);
+/* The same call with everything the reference's signature `p_sample(x, t, cond, clip_denoised=True, repeat_noise=False)` allows:
+ * t = HOST array of B step indices (one per utterance, as the [B] tensor of the reference), clip_denoised 0 / 1 (the clamp of
+ * p_mean_variance :153-154), repeat_noise 1: noise is ONE [M][T] draw used for every utterance (noise_like :38-41), else [B][M][T]. */
+int dsd_p_sample_ex(dsd_handle* h, float* x, const float* noise, const int32_t* t, int32_t clip_denoised, int32_t repeat_noise,
+                    void* stream);
 
 /* The PNDM/PLMS loop `for i in reversed(range(0, k_step, interval)): x = p_sample_plms(x, i, interval, cond)`
  * (shallow_diffusion_tts.py:261-267, p_sample_plms :168-204), noise_list reset at entry (:262). */
@@ -144,10 +153,14 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
  * give bit-identical results.  dsd_get_loop_mode: 1 if the prepared batch would take the persistent path.
  * dsd_loop_timeouts: synchronises the stream and returns the sticky timeout word of the persistent loop (0 = every
  * inter-workgroup wait was satisfied; nonzero = a wait hit its spin bound; the affected tiles of x are then NaN).
- * The persistent kernel needs all its workgroups resident at once (<= one per CU): run ONE such loop at a time per device - two
- * handles sampling concurrently on different streams of the same GPU must use mode 0 (one handle per device, as the reference's
- * DP / DDP runners do, is always safe). */
+ * The persistent kernel needs all its workgroups resident at once (<= one per CU), so only ONE such loop may run on a device at
+ * a time.  Inside one process the library enforces that itself: a persistent launch waits on the device (hipStreamWaitEvent) for
+ * the previous persistent launch of any handle on the same GPU that went to a different stream - two handles / two streams sampling
+ * "concurrently" are serialised (each loop fills the chip anyway), never starved into the timeout.  Two PROCESSES sharing one GPU
+ * cannot see each other: use mode 0 there (one process per device, as the reference's DDP runner does, is always safe).
+ * dsd_loop_launches: k_loop launches per sampling call for the prepared batch (chunks of whole utterances; 0 = not on that path). */
 int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
+int dsd_loop_launches(dsd_handle* h);
 
 /* EXPERIMENT (csrc/dsd_split.hpp; default off, env DSD_SPLIT=1 turns it on at creation): the residual layers on
  * the bf16 matrix pipe with fp32-class accuracy - every fp32 operand is the exact sum of three bf16 planes, the six plane products

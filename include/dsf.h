@@ -112,17 +112,6 @@ int dsf_channel_affine(const float* x, const float* a, const float* b, const flo
 int dsf_group_norm(const float* x, const float* gamma, const float* beta, const float* residual, float* y, int32_t B, int32_t C, int32_t groups,
                    int32_t T, float eps, int32_t relu, void* stream);
 
-/* EXPERIMENT, not used by any product path ("beyond the fp32-MFMA ceiling"): the denoiser's dilated convolution
- * (usr/diff/net.py:62: Conv1d(256 -> 512, 3, dilation, padding = dilation), no bias) evaluated as an fp32-ACCURATE GEMM on the bf16
- * matrix pipe - every fp32 operand is the exact sum of three bf16 planes, the six plane products with i + j <= 2 are accumulated in
- * fp32.  in [B][256][TS] channel-major, out [B][512][TS]; wplanes: the weight as bf16 planes in fragment order
- * [wave 4][chunk 48 = 16 channel groups x 3 taps][row block 4][plane 3][lane 64][8] (diffsinger_amd/experimental.py packs it: lane
- * (i, h), element e of wave w, row block mb = W[128 w + 32 mb + i][16 g + 8 h + e][tap]).  variant 0: plain two-stage register pipeline
- * left to the compiler; 1 / 2: the hand-pinned operand pipeline of the layer kernels with three / six register stages of the weight stream.  iters launches; avg_ms (HOST, may be
- * NULL): average launch time from events on `stream` (synchronises).  Prototypes to measure, not product kernels. */
-int dsf_split_conv1d_probe(const float* in, const void* wplanes, float* out, int32_t B, int32_t T, int32_t dil, int32_t variant, int32_t iters,
-                           float* avg_ms, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

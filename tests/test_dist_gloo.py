@@ -66,6 +66,17 @@ def _worker(rank, world, port, n_items, micro_batch, q):
                 assert wv.shape == (5 + 3 * i,) and bool((wv == float(i)).all())
         else:
             assert wavs is None
+        # the single receive buffer as a view: entry [k][r] = utterance k W + r
+        view = gather_mels(local, n_items, dst=0, order='view')
+        if rank == 0:
+            n_max = (n_items + world - 1) // world
+            assert view.shape == (n_max, world, 3, 2) and view.untyped_storage().nbytes() == n_max * world * 3 * 2 * 4
+            for i in range(n_items):
+                assert float(view[i // world, i % world, 0, 0]) == float(i)
+        # more ranks than items: a rank without items still takes part, with explicit device / dtype (float64 payloads here)
+        few = gather_ragged([torch.full((4,), 7.0, dtype=torch.float64)] if rank == 0 else [], 1, dst=0, dtype=torch.float64)
+        if rank == 0:
+            assert len(few) == 1 and few[0].dtype == torch.float64 and bool((few[0] == 7.0).all())
     finally:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,7 +1,8 @@
-"""GPU: the EXPERIMENTAL split-precision layer kernel (csrc/dsd_split.hpp, opt-in via dsd_set_split_mode) - the reference-generated golden
-cases with the residual layers evaluated as six bf16 plane products per fp32 product, and the per-layer launch time next to the fp32 kernel.
-NOT YET RUN ON HARDWARE (written after the round's GPU minutes were spent; its lane-level model is tests/test_split_layer_model.py):
-xfail(strict=False) until it has."""
+"""GPU: the OPT-IN split-precision layer kernel (csrc/dsd_split.hpp, dsd_set_split_mode; never the default, never the headline dtype) -
+the reference-generated golden cases with the residual layers evaluated as six bf16 plane products per fp32 product, single layers
+against the oracle's layer, and the per-layer launch time next to the fp32 kernel.  First run on the MI355X in round 2
+(profiles/r02a_pytest_gpu_zz_split_layer.txt: errors equal to the fp32 kernels', 51 vs 72 us per launch); its lane-level model is
+tests/test_split_layer_model.py."""
 import numpy as np
 import pytest
 import torch
@@ -9,17 +10,20 @@ import torch
 from tests import helpers as H
 from tests.gpu_helpers import build_hip, run_hip_case
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(reason='split-precision layer kernel not yet run on hardware', strict=False)]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('name,tol', [('denoise_lj', 2e-5), ('denoise_opencpop', 2e-5), ('ddpm_lj_k100', 2e-5), ('shallow_opencpop_k60', 2e-5),
-                                      ('plms_opencpop_i40', 5e-5)])
+                                      ('plms_opencpop_i40', 2e-5)])
 def test_golden_cases_with_split_layers(name, tol):
     g = H.load_golden(name)
     fp32 = run_hip_case(name, use_graph=True)
     out = run_hip_case(name, use_graph=True, split=True)
-    e_split, e_fp32 = float(np.abs(out - g['out']).max()), float(np.abs(fp32 - g['out']).max())
-    print(f'{name}: max-abs error vs the reference fixture: split layers {e_split:.3e}, fp32 layers {e_fp32:.3e}')
+    # PLMS has no clamp: with untrained weights x_0 grows to O(100), so - like every PLMS parity test here - the error
+    # is graded relative to max|mel| of the fixture
+    scale = float(np.abs(g['out']).max()) if name.startswith('plms') else 1.0
+    e_split, e_fp32 = float(np.abs(out - g['out']).max()) / scale, float(np.abs(fp32 - g['out']).max()) / scale
+    print(f'{name}: max-abs error vs the reference fixture (/ {scale:.3g}): split layers {e_split:.3e}, fp32 layers {e_fp32:.3e}')
     assert e_split < tol
 
 

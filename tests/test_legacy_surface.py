@@ -35,9 +35,23 @@ def test_signature_and_schedule():
     np.testing.assert_array_equal(gd2.betas.numpy(), np.linspace(1e-4, 0.06, 100).astype(np.float32))
 
 
-def test_no_cpu_path_and_no_training():
+def test_no_cpu_path_and_loud_failure_without_fastspeech2():
     gd, _ = _build()
     with pytest.raises(RuntimeError):
         gd.sample(torch.zeros(1, 256, 8))                # parameters on the CPU: the HIP engine refuses
-    with pytest.raises(NotImplementedError):
-        gd(torch.zeros(1, 4, dtype=torch.long), infer=False)
+    with pytest.raises(RuntimeError, match='no FastSpeech2 attached'):
+        gd(torch.zeros(1, 4, dtype=torch.long), infer=False)      # both branches of forward need self.fs2 (tests/test_gpu_surfaces.py runs them)
+
+
+def test_p_losses_says_so_for_an_inference_only_denoiser():
+    """the registered 'fft' candidate decoder has no training path - a clear NotImplementedError, not an AttributeError."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from diffsinger_amd.synth import presets
+    pre = presets()['lj_ds_beta6']
+    hparams.clear()
+    diffsinger_amd.use_preset('lj_ds_beta6')
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, torch.nn.Identity(), timesteps=10, K_step=10, loss_type='l1', spec_min=pre['spec_min'],
+                                          spec_max=pre['spec_max'])
+    with pytest.raises(NotImplementedError, match='inference-only'):
+        gd.p_losses(torch.zeros(1, 1, 80, 8), torch.zeros(1, dtype=torch.long), torch.zeros(1, 256, 8))

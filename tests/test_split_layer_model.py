@@ -2,7 +2,7 @@
 chain, frame-major bf16-plane staging of y with its halo and masks, the conv and output-projection plane GEMMs with their B addressing,
 the gate written as planes, row ownership of the waves) against the oracle's residual layer (= the reference's arithmetic).  What is
 NOT modelled is what k_layer_split copies verbatim from the verified k_layer: the fragment-order cp / skip images and the x' epilogue.
-The GPU tests of the kernel (tests/test_gpu_zz_split_layer.py) have not run on hardware yet; this is the desk check that precedes them."""
+The GPU tests of the kernel are tests/test_gpu_split_layer.py; this is the desk check that precedes them."""
 import math
 
 import numpy as np

@@ -2,7 +2,7 @@
 flat parameter / gradient buffers, gradient reduce-scatter, clip coefficient from one all-reduced float, AdamW on the rank's shard,
 parameter all-gather - against what the reference computes: torch.optim.AdamW + clip_grad_norm_ on the gradient of the FULL batch
 (= DDP's averaged gradient).  The fused HIP kernel is replaced by a torch restatement of torch.optim.AdamW's single-tensor update
-(injected through `_update`, tests only); the kernel itself is checked on the GPU (tests/test_gpu_zz_train_dist.py)."""
+(injected through `_update`, tests only); the kernel itself is checked on the GPU (tests/test_gpu_train_dist.py)."""
 import math
 import os
 import socket
@@ -124,14 +124,36 @@ def test_world2_matches_full_batch_adamw(clip):
         assert got[0][2] > clip                                       # the clip was active in the last step
 
 
-@pytest.mark.parametrize('clip', [None, 1.0])
-def test_single_process_matches_adamw(clip):
+@pytest.mark.parametrize('clip', [None, 1.0, 0, 0.0])         # 0 = the reference's 'no clipping' (configs/config_base.yaml clip_grad_norm: 0;
+def test_single_process_matches_adamw(clip):                   # utils/pl_utils.py:1165-1168 clips only when > 0): the parameters must MOVE
     params, opt = sharded_run(0, 1, 12, 5, clip)
     want = reference_run(12, 5, clip)
     for a, w in zip(params, want):
         assert float((a - w).abs().max()) < 2e-6
+    start = [p.detach().clone() for p in make_model().parameters()]
+    assert all(float((a - b).abs().max()) > 1e-4 for a, b in zip(params, start))     # training really happened (clip 0 must not zero the gradient)
     sd = opt.state_dict()
     assert sd['step'] == 5 and sd['exp_avg_shard'].numel() == opt.shard
+    assert sd['exp_avg_shard'].data_ptr() != opt.exp_avg.data_ptr()                   # a snapshot, not a live reference
+    opt.lr = 123.0
+    opt.load_state_dict(sd)
+    assert opt.lr == sd['lr'] != 123.0
+
+
+def test_steplr_base_after_resuming_a_decayed_torch_state():
+    """adamw_state_to_sharded takes the UN-decayed `initial_lr` a torch scheduler left in the param group as the StepLR base."""
+    from diffsinger_amd.ckpt import adamw_state_from_sharded, adamw_state_to_sharded
+    _, opt = sharded_run(0, 1, 12, 2, None)
+    sd = adamw_state_from_sharded(opt)
+    sd['param_groups'][0]['initial_lr'] = HP['lr']
+    sd['param_groups'][0]['lr'] = HP['lr'] * 0.25                                     # what StepLR(2, 0.5) leaves after 4 steps
+    m2 = make_model()
+    opt2 = ShardedAdamW(m2.parameters(), _update=torch_adamw_update, **HP)
+    adamw_state_to_sharded(opt2, sd)
+    assert opt2.lr == HP['lr'] * 0.25
+    sched = StepLR(opt2, 2, gamma=0.5)
+    sched.step(4)
+    assert abs(opt2.lr - HP['lr'] * 0.25) < 1e-12                                     # not decayed twice
 
 
 def test_no_cpu_path_for_the_fused_step():

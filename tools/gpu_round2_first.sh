@@ -18,6 +18,7 @@ for f in tests/test_gpu_zz_*.py; do DSD_RUN_UNVERIFIED=1 timeout 300 python -m p
 timeout 300 python tools/bench_vocoder.py 5 > $O/vocoder.jsonl 2> $O/vocoder.err
 timeout 120 python tools/bench_pe.py 20 > $O/pe_forward.jsonl 2> $O/pe_forward.err
 timeout 300 python bench.py --steps 3 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 200 python tools/shape_sweep.py 2 > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
 timeout 200 python bench.py --row vocoder --steps 10 --warmup 2 > $O/bench_vocoder_row.json 2> $O/bench_vocoder_row.err
 timeout 300 python bench.py --row train --steps 5 --warmup 2 > $O/bench_train_row.json 2> $O/bench_train_row.err
 timeout 200 python bench.py --row fs2 --steps 20 --warmup 3 > $O/bench_fs2_row.json 2> $O/bench_fs2_row.err
@@ -33,4 +34,4 @@ python $R/tools/pmc_summary.py $O/pmc_voc 'k_voc_conv_fold<4>' $O/voc_fold_pmc.t
 rm -rf $O/prof_voc
 find $O/pmc_voc -name '*.db' -delete
 du -sh $O
-tail -8 $O/pytest_gpu.txt; for f in $O/test_gpu_zz_*.txt; do echo == $f; grep -E 'err|TFLOP|us per|XPASS|XFAIL|passed|failed|xfailed|xpassed|Error' $f | cut -c1-220 | tail -14; done; cat $O/cxx_example.json; cut -c1-900 $O/bench_split_experiment.json; cat $O/mfma_split_probe.jsonl; cut -c1-700 $O/bench_vocoder_row.json; cut -c1-700 $O/bench_train_row.json; cut -c1-700 $O/bench_fs2_row.json; cut -c1-300 $O/vocoder.jsonl | head -20; cat $O/pe_forward.jsonl; cat $O/bench_n1.json | cut -c1-600; head -14 $O/vocoder_kernel_stats.txt | cut -c1-180
+tail -8 $O/pytest_gpu.txt; for f in $O/test_gpu_zz_*.txt; do echo == $f; grep -E 'err|TFLOP|us per|XPASS|XFAIL|passed|failed|xfailed|xpassed|Error' $f | cut -c1-220 | tail -14; done; cat $O/cxx_example.json; cut -c1-900 $O/bench_split_experiment.json; cat $O/mfma_split_probe.jsonl; cut -c1-700 $O/bench_vocoder_row.json; cut -c1-700 $O/bench_train_row.json; cut -c1-700 $O/bench_fs2_row.json; cut -c1-300 $O/vocoder.jsonl | head -20; cat $O/pe_forward.jsonl; cat $O/bench_n1.json | cut -c1-600; cat $O/shape_sweep.jsonl; tail -3 $O/shape_sweep.err; head -14 $O/vocoder_kernel_stats.txt | cut -c1-180
