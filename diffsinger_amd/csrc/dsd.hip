@@ -2,6 +2,7 @@
 // sequencing of the K-step reverse loop (eager or as a cached hipGraph).  C ABI in include/dsd.h.
 #include "dsd_kernels.hpp"
 #include "dsd_loop.hpp"
+#include "dsd_lat.hpp"
 #include "dsd_split.hpp"
 
 #include <cmath>
@@ -105,8 +106,12 @@ struct dsd_handle {
     float* coef_dev = nullptr;  // [cap_B][5] per-utterance p_sample coefficients (dsd_p_sample_ex)
     float* eps_tmp = nullptr;   // [cap_spec] eps of dsd_p_sample_ex
 
-    // persistent K-step loop (dsd_loop.hpp): 1 = one kernel for the whole loop when the batch geometry allows it
-    int loop_mode = 1;
+    // how the K-step loops run: 0 per-layer kernels (k_layer); 1 the persistent loop (dsd_loop.hpp) whenever the batch geometry allows
+    // it; 2 (default) automatic - row-split latency kernels (dsd_lat.hpp) for batches that fill less than half the chip, else the
+    // persistent loop unless its whole-utterance chunking wastes more of the chip than the per-layer kernels would; 3 latency kernels
+    int loop_mode = 2;
+    int lat_req = -1;           // row split of the latency kernels: -1 by batch size, 0 never, 2 / 4 / 8 forced (env DSD_LAT_G)
+    float* gbuf = nullptr;      // [ntiles][C][32] gate tiles between k_lat_conv and k_lat_out
     int n_cu = 0;               // workgroups that are certainly co-resident at 1 per CU
     struct LoopPlan { HeadParams* evals = nullptr; int* eval_t = nullptr; int n_evals = 0; };
     std::map<GraphKey, LoopPlan> plans;
@@ -176,7 +181,7 @@ static void drop_graphs(dsd_handle* h) {
 static void free_workspace(dsd_handle* h) {
     drop_graphs(h);
     dev_free(h->xa_base); dev_free(h->xb_base); dev_free(h->condT); dev_free(h->cp); dev_free(h->skip);
-    dev_free(h->xs); dev_free(h->xtmp);
+    dev_free(h->xs); dev_free(h->xtmp); dev_free(h->gbuf);
     for (auto& e : h->ering) dev_free(e);
     dev_free(h->t_dev); dev_free(h->coef_dev); dev_free(h->eps_tmp);
     dev_free(h->loop_flags); dev_free(h->loop_halo);
@@ -208,6 +213,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     h->M = cfg->mel_bins;
     h->nk_in = (cfg->mel_bins + 7) / 8;
     if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);                // developer switch (A/B timing)
+    if (const char* ev = std::getenv("DSD_LAT_G")) h->lat_req = std::atoi(ev);                 // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_WT_STORES")) h->wt_stores = (std::atoi(ev) != 0);  // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
@@ -270,8 +276,19 @@ extern "C" int dsd_set_layer_tile(dsd_handle* h, int32_t frames) {
 
 extern "C" int64_t dsd_device_bytes(dsd_handle* h) { return h ? h->bytes + h->bytes_ws : 0; }
 
+// Row split G of the latency kernels for the prepared batch, 0 = not on that path.  Automatic mode: the largest G in {8, 4, 2} that
+// still gives every workgroup a CU of its own - i.e. only batches that leave at least half of the chip idle.
+static int lat_g(const dsd_handle* h) {
+    if (h->split_mode || h->layer_tile_req || h->lat_req == 0 || h->loop_mode < 2) return 0;
+    int g = (8 * h->ntiles <= h->n_cu) ? 8 : (4 * h->ntiles <= h->n_cu) ? 4 : (2 * h->ntiles <= h->n_cu) ? 2 : 0;
+    if (h->loop_mode == 3 && g == 0) g = 2;
+    if (g && (h->lat_req == 2 || h->lat_req == 4 || h->lat_req == 8)) g = h->lat_req;
+    return g;
+}
+
 static int layer_nb(const dsd_handle* h) {
     if (h->split_mode) return 1;               // the split-precision layer kernel exists for 32-frame tiles only
+    if (lat_g(h)) return 1;
     if (h->layer_tile_req) return h->layer_tile_req / 32;
     // 32-frame workgroups until there are enough of them to keep two resident per CU on all 256 CUs; beyond
     // that 64-frame workgroups halve the weight traffic out of L2 per frame.
@@ -477,6 +494,7 @@ extern "C" int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* con
         DSD_TRY(dev_alloc(h, &h->condT, (size_t)B * kC * TS, true));
         DSD_TRY(dev_alloc(h, &h->cp, (size_t)h->L * ntiles * 4096, true));
         DSD_TRY(dev_alloc(h, &h->skip, (size_t)ntiles * 2048, true));
+        DSD_TRY(dev_alloc(h, &h->gbuf, (size_t)ntiles * kC * 32, true));
         DSD_TRY(dev_alloc(h, &h->xs, (size_t)spec, true));
         DSD_TRY(dev_alloc(h, &h->xtmp, (size_t)spec, true));
         for (auto& e : h->ering) DSD_TRY(dev_alloc(h, &e, (size_t)spec, true));
@@ -509,7 +527,33 @@ static int launch_inproj(dsd_handle* h, const float* spec, hipStream_t s) {
     return DSD_OK;
 }
 
+template <int G>
+static void launch_lat(const LatParams& p, hipStream_t s) {
+    const dim3 grid((unsigned)lat_grid(p.ntiles, G));
+    hipLaunchKernelGGL((k_lat_conv<G>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
+    hipLaunchKernelGGL((k_lat_out<G>), grid, dim3(kThreads), kLatOutLdsBytes, s, p);
+}
+
 static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, hipStream_t s, unsigned long long* dbg = nullptr) {
+    if (const int G = lat_g(h)) {
+        // latency mode (dsd_lat.hpp): the layer as two kernels whose workgroups split the output rows of a tile G ways
+        LatParams q{};
+        q.x_in = (l & 1) ? h->xb : h->xa;
+        q.x_out = (l & 1) ? h->xa : h->xb;
+        q.gbuf = h->gbuf;
+        q.w1p = h->w1p + (size_t)l * 4 * 96 * 256;
+        q.w2p = h->w2p + (size_t)l * 4 * 32 * 256;
+        q.b2 = h->b2raw + (size_t)l * 2 * kC;
+        q.cp = h->cp + (size_t)l * h->ntiles * 4096;
+        q.skip = h->skip;
+        q.ds = h->ds_table + (size_t)l * kC;
+        q.t_dev = t_dev; q.t_uniform = t_uniform; q.ds_tstride = h->L * kC;
+        q.T = h->T; q.ntile32 = h->ntile32; q.ntiles = h->ntiles; q.dil = h->dil[l];
+        q.first = (l == 0); q.last = (l == h->L - 1);
+        if (G == 8) launch_lat<8>(q, s); else if (G == 4) launch_lat<4>(q, s); else launch_lat<2>(q, s);
+        HIP_TRY(hipGetLastError());
+        return DSD_OK;
+    }
     const int nb = layer_nb(h);
     LayerParams p{};
     p.x_in = (l & 1) ? h->xb : h->xa;
@@ -775,7 +819,18 @@ static bool g_loop_has[kMaxDevices];
 
 // true when the prepared batch can run as the persistent loop: 32-frame tiles, a whole utterance fits the co-resident grid
 static bool loop_applicable(const dsd_handle* h) {
-    return h->loop_mode == 1 && !h->split_mode && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 && h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers;
+    if (!((h->loop_mode == 1 || h->loop_mode == 2) && !h->split_mode && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 &&
+          h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers)) return false;
+    if (h->loop_mode == 2) {
+        if (lat_g(h)) return false;
+        // chunks of whole utterances may leave much of the chip idle (T = 5000: 157 tiles per launch on 256 CUs); the per-layer kernels
+        // have no such constraint, only the wave quantisation of their grid, and cost ~5 % more at equal occupancy
+        const int upc = std::max(1, h->n_cu / h->ntile32), chunks = (h->B + upc - 1) / upc;
+        const double u_p = (double)h->ntiles / ((double)chunks * h->n_cu);
+        const double u_l = 0.95 * (double)h->ntiles / ((double)((h->ntiles + h->n_cu - 1) / h->n_cu) * h->n_cu);
+        if (u_l > u_p) return false;
+    }
+    return true;
 }
 
 static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hipStream_t s) {
@@ -849,7 +904,7 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
     } else if (!h->use_graph) {
         DSD_TRY(kind == 0 ? enqueue_ddpm(h, k_step, s) : enqueue_plms(h, k_step, interval, s));
     } else {
-        const GraphKey key{kind, h->B, h->T, k_step, interval, layer_nb(h)};
+        const GraphKey key{kind, h->B, h->T, k_step, interval, layer_nb(h) + 100 * lat_g(h)};
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -954,10 +1009,19 @@ extern "C" int dsd_debug_layer(dsd_handle* h, int32_t layer, int32_t t, const fl
 }
 
 extern "C" int dsd_set_loop_mode(dsd_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 1) return fail(DSD_ERR_INVALID, "dsd_set_loop_mode: mode must be 0 (per-layer kernels) or 1 (persistent loop)");
+    if (!h || mode < 0 || mode > 3)
+        return fail(DSD_ERR_INVALID, "dsd_set_loop_mode: mode must be 0 (per-layer kernels), 1 (persistent loop), 2 (automatic) or 3 (latency kernels)");
     h->loop_mode = mode;
     return DSD_OK;
 }
+
+extern "C" int dsd_set_lat_split(dsd_handle* h, int32_t g) {
+    if (!h || !(g == -1 || g == 0 || g == 2 || g == 4 || g == 8)) return fail(DSD_ERR_INVALID, "dsd_set_lat_split: g must be -1 (by batch size), 0, 2, 4 or 8");
+    h->lat_req = g;
+    return DSD_OK;
+}
+
+extern "C" int dsd_get_lat_split(dsd_handle* h) { return (h && h->prepared) ? lat_g(h) : 0; }
 
 extern "C" int dsd_get_loop_mode(dsd_handle* h) { return (h && h->prepared && loop_applicable(h)) ? 1 : 0; }
 
@@ -978,23 +1042,26 @@ extern "C" int dsd_loop_timeouts(dsd_handle* h, void* stream) {
 }
 
 // Debug hook: run the persistent DDPM loop once on the prepared batch (x, noise as for dsd_sample_ddpm) with per-wave shader-clock
-// stamps taken in phase `phase` (= evaluation * L + layer; pick a non-last layer): HOST out[n_wg * 4 * 8] u64 with, per wave,
-// {phase start, neighbours' flags seen, y tile staged, conv done, gate done, x' ready, halo published, phase end}.
+// stamps taken in phase `phase` (= evaluation * L + layer; pick a non-last layer): HOST out[n_wg * 4 * 16] u64 with, per wave,
+// [0..7] {phase start, neighbours' flags seen, y tile staged, conv done, gate done, x' ready, halo published, phase end} and
+// [8..15] the HEAD of that evaluation {last layer done, skip tile scaled + staged, skip projection done, its ReLU tile visible, final
+// projection done (waves 0-2), sampler update stored, barrier, next input projection + halo published}.
 extern "C" int dsd_debug_loop_timeline(dsd_handle* h, float* x, const float* noise, int32_t k_step, int32_t phase, uint64_t* out,
                                        int32_t max_wg, int32_t* n_wg, void* stream) {
     DSD_TRY(check_ready(h, "dsd_debug_loop_timeline", true));
     if (!x || !noise || !out || !n_wg) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: null argument");
     if (!loop_applicable(h)) return fail(DSD_ERR_STATE, "dsd_debug_loop_timeline: the prepared batch does not take the persistent path");
+    if (k_step < 2 || phase / h->L >= k_step - 1) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: pick a phase of an evaluation that is not the last");
     if (h->ntiles > h->n_cu || h->ntiles > max_wg) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: needs a single-launch batch (%d tiles)", h->ntiles);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     DSD_TRY(build_step_table(h, h->n_sched, s));
-    HIP_TRY(hipMalloc((void**)&h->loop_dbg, (size_t)h->ntiles * 32 * 8));
-    HIP_TRY(hipMemsetAsync(h->loop_dbg, 0, (size_t)h->ntiles * 32 * 8, s));
+    HIP_TRY(hipMalloc((void**)&h->loop_dbg, (size_t)h->ntiles * 64 * 8));
+    HIP_TRY(hipMemsetAsync(h->loop_dbg, 0, (size_t)h->ntiles * 64 * 8, s));
     h->loop_dbg_phase = phase;
     const int rc = run_loop(h, 0, x, noise, k_step, 0, s);
     hipError_t e = hipStreamSynchronize(s);
-    if (e == hipSuccess) e = hipMemcpy(out, h->loop_dbg, (size_t)h->ntiles * 32 * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out, h->loop_dbg, (size_t)h->ntiles * 64 * 8, hipMemcpyDeviceToHost);
     (void)hipFree(h->loop_dbg);
     h->loop_dbg = nullptr;
     if (rc != DSD_OK) return rc;

@@ -86,7 +86,9 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NMB][NB], const float4 (
 // All workgroups of an XCD walk the same weight stream in lock-step, so every chunk is a first touch of that L2:
 // the latency to hide is the Infinity-Cache / HBM one (~1-2 us), not an L2 hit - hence 5 chunks (>= 5k cycles) of
 // distance for the 16-MFMA chunks of the 32-frame kernels.
-template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff>
+// MBS: distance (in 32-row blocks of the packed stream) between the NMB row blocks a wave multiplies - 1: consecutive blocks; 2: a gate
+// block and its filter block / a residual block and its skip block (the row-split kernels of dsd_lat.hpp).
+template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff, int MBS = 1>
 struct GemmPipe {
     static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
     __amdgpu_buffer_rsrc_t rsrc;   // buffer descriptor over this wave's A stream (wave-uniform base = chunk 0 / row block 0)
@@ -108,7 +110,7 @@ struct GemmPipe {
         const int soff = kc * (ASTRIDE * 16);
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff + mb * 1024, soff, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff + mb * (MBS * 1024), soff, 0);
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const f32x4 f = __builtin_bit_cast(f32x4, v);      // whole-vector cast (element-wise bit_cast of v.x miscompiles)
             dst[mb] = make_float4(f.x, f.y, f.z, f.w);

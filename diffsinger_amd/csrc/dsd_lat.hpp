@@ -1,0 +1,258 @@
+// dsd_lat.hpp - LATENCY MODE of the residual layer (gfx950): one ResidualBlock (usr/diff/net.py:66-78) as TWO row-split kernels.
+//
+// Why.  k_layer / k_loop give one workgroup (= one CU) a whole 32-frame tile: 8192 MFMAs per layer per tile.  The reference's own
+// inference shape is ONE utterance per device (configs/tts/fs2.yaml:70 max_eval_sentences: 1): T = 512 frames are 16 tiles = 16 of 256
+// CUs, and the K = 100 loop takes the same ~130 ms as a chip-filling batch.  Frames cannot be split finer than the MFMA's N = 32, so the
+// OUTPUT ROWS of the two contractions are split over G workgroups per tile instead (G = 2, 4 or 8 -> up to 8 x more CUs per utterance):
+//
+//   k_lat_conv<G>   every workgroup stages the whole y = x + step tile (256 channels x (32 + 2 x 8) frames, zero outside [0, T):
+//                   net.py:69-71) and computes 512 / G rows of the dilated K = 768 contraction - a gate block together with its filter
+//                   block - adds the hoisted conditioner projection, applies sigmoid * tanh (net.py:73-74) and writes its 256 / G rows of
+//                   the gate tile to HBM/L2.
+//   k_lat_out<G>    every workgroup stages the whole gate tile (256 x 32) and computes 512 / G rows of the output projection (K = 256):
+//                   residual rows -> x' = (x + res + b) / sqrt(2), skip rows -> running skip sum (net.py:76-78), same buffers and layouts
+//                   as k_layer (tile-major x, fragment-order skip), so k_inproj / k_head / the sampler epilogues are shared.
+//
+// The all-gather a persistent formulation would need twice per layer (gate rows, then x' rows) is the kernel boundary here: both kernels
+// are nodes of the K-step hipGraph (2 x 20 + 1 nodes per evaluation), ~1.5-2 us each - of the same order as a flag hop through L2.
+//
+// Row ownership follows the packed weight streams (dsd.hip pack_a): stream "wave" w4 in [0,4) holds gate / residual rows [64 w4, 64 w4 +
+// 64) as row blocks 0, 1 and the matching filter / skip rows as row blocks 2, 3.
+//   G = 2: workgroup g <- streams {2g, 2g+1}; wave = (stream, pair p): row blocks {p, p + 2}, the whole K            (NMB = 2)
+//   G = 4: workgroup g <- stream g;           wave = row block; conv: the filter waves hand tanh(.) to the gate waves through LDS
+//   G = 8: workgroup g <- stream g / 2, pair g % 2; conv: wave = (gate | filter, K half) - the two K halves are summed through LDS
+//          (the ONLY place where the summation order differs from k_layer: (first half) + (second half) instead of one k-ordered chain);
+//          out-proj: two waves (residual block, skip block), the whole K.
+// G = 2 and G = 4 are bit-identical to k_layer; G = 8 agrees to reduction-order noise (tests/test_gpu_latency.py).
+#pragma once
+#include "dsd_kernels.hpp"
+
+namespace dsd {
+
+struct LatParams {
+    const float* x_in;      // [tiles][C][32] tile-major
+    float* x_out;           // [tiles][C][32]
+    float* gbuf;            // [tiles][C][32] gate tile (k_lat_conv -> k_lat_out)
+    const float4* w1p;      // this layer's dilated conv, packed [w4][kc96 = 3 * k8 + tap][mb4][lane64]
+    const float4* w2p;      // this layer's output projection, packed [w4][kc32][mb4][lane64]
+    const float* b2;        // output projection bias [2C] (residual half)
+    const float4* cp;       // this layer's hoisted conditioner projection (+ biases) [tile][w4][mb4][q4][lane64]
+    float4* skip;           // running skip sum [tile][w4][mb2][q4][lane64]
+    const float* ds;        // this layer's step-projection table: ds[t * ds_tstride + c]
+    const int* t_dev;       // per-utterance step index, or nullptr -> t_uniform
+    int t_uniform, ds_tstride;
+    int T, ntile32, ntiles, dil, first, last;
+};
+
+constexpr int kLatConvLdsBytes = (kC * (32 + 2 * kHalo) + 3 * 32 * 32) * (int)sizeof(float);     // y tile + K-half partials [2] + filter [1..2]
+constexpr int kLatOutLdsBytes = kC * 32 * (int)sizeof(float);
+
+// workgroup -> (tile, g): the G workgroups of a tile read the same x / gate tile, so they are placed behind the same L2 (workgroups
+// are dealt round-robin to the 8 XCDs by linear id): XCD x takes tiles x, x + 8, ...   grid = ceil(ntiles / 8) * 8 * G
+template <int G>
+__device__ __forceinline__ bool lat_map(int ntiles, int& tile, int& g) {
+    const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
+    tile = (k / G) * 8 + xcd;
+    g = k % G;
+    return tile < ntiles;
+}
+__host__ __device__ inline int lat_grid(int ntiles, int G) { return (ntiles + 7) / 8 * 8 * G; }
+
+template <int G>
+__global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
+    static_assert(G == 2 || G == 4 || G == 8, "row split");
+    constexpr int LD = 32 + 2 * kHalo, TILE = kC * 32;
+    constexpr int NMB = (G == 2) ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ytile = smem;                    // [256][48]
+    float* red = smem + kC * LD;            // [3][32][32]: G = 8: K-half partials of the gate / filter block, then tanh(filter); G = 4: tanh(filter) x 2
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile, g;
+    if (!lat_map<G>(p.ntiles, tile, g)) return;
+    const int b = tile / p.ntile32, tn = tile - b * p.ntile32, t0 = tn * 32;
+    const bool has_left = tn > 0, has_right = tn + 1 < p.ntile32;
+    const int T = p.T, dil = p.dil;
+
+    // role of this wave
+    int w4, mb0, kbeg;                      // packed stream, first row block, first chunk
+    constexpr int NCH = (G == 8) ? 48 : 96; // chunks per wave
+    if (G == 2) { w4 = 2 * g + (wv >> 1); mb0 = wv & 1; kbeg = 0; }
+    else if (G == 4) { w4 = g; mb0 = wv; kbeg = 0; }
+    else { w4 = g >> 1; mb0 = (g & 1) + 2 * (wv & 1); kbeg = 48 * (wv >> 1); }
+
+    // the weight stream does not depend on x: its first chunks are requested before the tile is staged
+    const float* yl = ytile + (kbeg / 3) * (8 * LD) + 4 * h * LD + kHalo + j;
+    const float* ytap[3] = {yl - dil, yl, yl + dil};
+    auto bof = [&](int it, int u) { return ytap[u % 3] + it * (16 * LD) + (u / 3) * (8 * LD); };
+    GemmPipe<NMB, 1, LD, 256, 6, decltype(bof), 2> pipe(p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, bof);
+    pipe.start_a();
+
+    // stage y = x + step_proj (zero at frames outside [0, T): the conv's zero padding applies to y, net.py:69-71)
+    const int tstep = p.t_dev ? p.t_dev[b] : p.t_uniform;
+    const float* __restrict__ dsl = p.ds + (size_t)tstep * p.ds_tstride;
+    const float* __restrict__ xt = p.x_in + (size_t)tile * TILE;
+    {
+        float4 xv[8], hv[4];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) xv[it] = reinterpret_cast<const float4*>(xt)[it * kThreads + tid];
+        // halo: thread = channel row; my left halo = the left tile's columns 24..31, my right halo = the right tile's columns 0..7
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            hv[q] = has_left ? *reinterpret_cast<const float4*>(xt - TILE + tid * 32 + 24 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            hv[2 + q] = has_right ? *reinterpret_cast<const float4*>(xt + TILE + tid * 32 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 32 + (tid >> 3), c4 = tid & 7, t = t0 + 4 * c4;
+            const float d = dsl[row];
+            float4 v = xv[it];
+            v.x = (t + 0 < T) ? v.x + d : 0.f;
+            v.y = (t + 1 < T) ? v.y + d : 0.f;
+            v.z = (t + 2 < T) ? v.z + d : 0.f;
+            v.w = (t + 3 < T) ? v.w + d : 0.f;
+            *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 4 * c4) = v;
+        }
+        const float d = dsl[tid];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool right = q >= 2, have = right ? has_right : has_left;
+            const int t = right ? t0 + 32 + 4 * (q - 2) : t0 - kHalo + 4 * q;
+            float4 v = hv[q];
+            v.x = (have && t + 0 < T) ? v.x + d : 0.f;
+            v.y = (have && t + 1 < T) ? v.y + d : 0.f;
+            v.z = (have && t + 2 < T) ? v.z + d : 0.f;
+            v.w = (have && t + 3 < T) ? v.w + d : 0.f;
+            *reinterpret_cast<float4*>(ytile + tid * LD + (right ? kHalo + 32 + 4 * (q - 2) : 4 * q)) = v;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NMB][1];
+#pragma unroll
+    for (int m = 0; m < NMB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
+    pipe.start_b();
+    pipe.run(acc, 0, NCH);
+
+    // hoisted conditioner projection (+ conv bias + cond bias) of this wave's row block(s), accumulator-fragment order
+    const float4* cpl = p.cp + ((size_t)tile * 4 + w4) * (4 * 4 * 64) + lane;
+    float* gout = p.gbuf + (size_t)tile * TILE;
+    if (G == 2) {
+        // a gate block and its filter block in the same wave: the gate never leaves registers (like k_layer)
+        float4 cg[4], cf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { cg[q] = cpl[(mb0 * 4 + q) * 64]; cf[q] = cpl[((mb0 + 2) * 4 + q) * 64]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float gv = sigmoid_f(acc[0][0][r] + f4at(cg[r >> 2], r & 3)) * tanh_f(acc[NMB - 1][0][r] + f4at(cf[r >> 2], r & 3));
+            gout[(64 * w4 + 32 * mb0 + frag_row(r, h)) * 32 + j] = gv;
+        }
+        return;
+    }
+    float4 cv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cv[q] = cpl[(mb0 * 4 + q) * 64];
+    if (G == 8) {
+        // sum the two K halves: the second-half waves hand their partial block to the first-half wave of the same role
+        float* part = red + (wv & 1) * 1024;
+        if (wv >= 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[frag_row(r, h) * 32 + j] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (wv < 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][0][r] + part[frag_row(r, h) * 32 + j];
+        }
+    }
+    // filter waves -> tanh(filter pre-activation) through LDS -> gate waves: sigmoid(gate pre-activation) * tanh(.)   (net.py:73-74)
+    const bool is_filter = (G == 4) ? (wv >= 2) : (wv == 1);
+    const bool is_gate = (G == 4) ? (wv < 2) : (wv == 0);
+    float* fx = (G == 4) ? red + (wv & 1) * 1024 : red + 2048;        // G = 4: two filter blocks (no K-half partials there); G = 8: one, behind them
+    if (is_filter) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fx[frag_row(r, h) * 32 + j] = tanh_f(acc[0][0][r] + f4at(cv[r >> 2], r & 3));
+    }
+    __syncthreads();
+    if (is_gate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float gv = sigmoid_f(acc[0][0][r] + f4at(cv[r >> 2], r & 3)) * fx[frag_row(r, h) * 32 + j];
+            gout[(64 * w4 + 32 * mb0 + frag_row(r, h)) * 32 + j] = gv;
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
+    static_assert(G == 2 || G == 4 || G == 8, "row split");
+    constexpr int TILE = kC * 32;
+    constexpr int NMB = (G == 2) ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* gtile = smem;                    // [256][32]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile, g;
+    if (!lat_map<G>(p.ntiles, tile, g)) return;
+
+    int w4, mb0;
+    bool active = true;
+    if (G == 2) { w4 = 2 * g + (wv >> 1); mb0 = wv & 1; }
+    else if (G == 4) { w4 = g; mb0 = wv; }
+    else { w4 = g >> 1; mb0 = (g & 1) + 2 * wv; active = wv < 2; if (!active) mb0 = (g & 1); }
+    // the last layer's residual half is dead (net.py:126 reads the skips only)
+    const bool do_res = !p.last && ((G == 2) || mb0 < 2);
+    const bool do_skip = (G == 2) || mb0 >= 2;
+    if (G != 2 && p.last && mb0 < 2) active = false;
+
+    const float* gl = gtile + 4 * h * 32 + j;
+    GemmPipe<NMB, 1, 32, 256, 6, TileB, 2> pipe(p.w2p + (size_t)w4 * (32 * 256) + mb0 * 64, lane, 32, TileB{gl, 8 * 32, 32});
+    if (active) pipe.start_a();
+
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.gbuf + (size_t)tile * TILE);
+        float4 v[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) v[it] = src[it * kThreads + tid];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) reinterpret_cast<float4*>(gtile)[it * kThreads + tid] = v[it];
+    }
+    __syncthreads();
+    if (!active) return;
+
+    f32x16 acc[NMB][1];
+#pragma unroll
+    for (int m = 0; m < NMB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
+    pipe.start_b();
+    pipe.run(acc, 0, 32);
+
+    if (do_res) {
+        // x' = (x + (res + b)) / sqrt(2)   (net.py:78; same operation order as k_layer)
+        const float* __restrict__ xi = p.x_in + (size_t)tile * TILE;
+        float* __restrict__ xo = p.x_out + (size_t)tile * TILE;
+        constexpr float kInvSqrt2 = 1.0f / 1.41421354f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 64 * w4 + 32 * (mb0 & 1) + frag_row(r, h);
+            const float bv = p.b2[row];
+            xo[row * 32 + j] = (xi[row * 32 + j] + (acc[0][0][r] + bv)) * kInvSqrt2;
+        }
+    }
+    if (do_skip) {
+        float4* sl = p.skip + (((size_t)tile * 4 + w4) * 2 + (mb0 & 1)) * (4 * 64) + lane;
+        const bool keep = !p.first;         // layer 0 starts the sum (select, not multiply: the buffer may hold anything)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = get4(acc[NMB - 1][0], q);
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (keep) s = sl[q * 64];
+            sl[q * 64] = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
+        }
+    }
+}
+
+}  // namespace dsd

@@ -44,7 +44,7 @@ struct LoopParams {
     float* halo;                // [2][ntiles_total][2 sides][256][8]
     unsigned* tmo;              // sticky timeout word, zero at launch
     int tile_base, n_tiles;     // this launch covers tiles [tile_base, tile_base + n_tiles)
-    unsigned long long* dbg;    // optional s_memtime stamps of phase dbg_phase: [workgroup][wave][8]
+    unsigned long long* dbg;    // optional s_memtime stamps: [workgroup][wave][16] - 0..7 the layer phase dbg_phase, 8..15 the head of its evaluation
     int dbg_phase;
 };
 
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
     };
     // debug stamps go straight to memory (held in registers they would cost 20 VGPRs for the whole kernel)
     const bool stamp = p.dbg != nullptr;
-#define LOOP_STAMP(i) do { if (stamp && ph == (unsigned)p.dbg_phase && lane == 0) p.dbg[((size_t)tl * 4 + w) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LOOP_STAMP(i) do { if (stamp && ph == (unsigned)p.dbg_phase && lane == 0) p.dbg[((size_t)tl * 4 + w) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define HEAD_STAMP(i) do { if (stamp && e == p.dbg_phase / p.L && lane == 0) p.dbg[((size_t)tl * 4 + w) * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
     unsigned ph = 0;
     publish(0);
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
         float* stile = ytile;               // [256][32]
         float* htile = gtile;               // [256][32]
         float* ptile = xt;                  // [96][32]
+        HEAD_STAMP(0);
         __syncthreads();                    // all waves are out of the last layer's out-proj (gate tile reads)
         // weight streams of the head GEMMs are requested ahead of the barriers that gate their B tiles
         const float* sl = stile + 4 * h * 32 + j;
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     stile[(64 * w + 32 * ms + frag_row(4 * q + ee, h)) * 32 + j] = __fdiv_rn(v[ee], p.head.sqrt_L);
             }
         __syncthreads();
+        HEAD_STAMP(1);
         {
             f32x16 acc[2][1];
 #pragma unroll
@@ -358,16 +361,19 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 for (int r = 0; r < 16; ++r)
                     htile[(64 * w + 32 * mb + frag_row(r, h)) * 32 + j] = fmaxf(acc[mb][0][r], 0.f);
         }
+        HEAD_STAMP(2);
         const float* hl = htile + 4 * h * 32 + j;
         GemmPipe<1, 1, 32, 192, 6, TileB> pipe_o(p.head.woutp + (size_t)min(w, 2) * 64, lane, 32, TileB{hl, 8 * 32, 32});
         if (w < 3) pipe_o.start_a();
         __syncthreads();
+        HEAD_STAMP(3);
         if (w < 3) {
             f32x16 acc[1][1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) set4(acc[0][0], q, p.head.boutp[(w * 2 + h) * 4 + q]);
             pipe_o.start_b();
             pipe_o.run(acc, 0, 32);
+            HEAD_STAMP(4);
             const int t = t0 + j;
             // sampler arithmetic (p_sample :134-166 / p_sample_plms :168-204).  All global reads of the 16 elements are issued
             // first (one workgroup per CU: nothing else would hide their latency), then the element-wise math, then the stores.
@@ -430,10 +436,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 ptile[m * 32 + j] = ok ? xn : 0.f;
             }
         }
+        HEAD_STAMP(5);
         __syncthreads();
+        HEAD_STAMP(6);
         if (fuse) { inproj_to_xreg(); publish(ph); }
+        HEAD_STAMP(7);
     }
 #undef LOOP_STAMP
+#undef HEAD_STAMP
     // a wait that hit its spin bound leaves garbage: make it LOUD - poison this tile of the result with NaN
     if (timed_out()) {
         float* xo = const_cast<float*>(p.spec0);

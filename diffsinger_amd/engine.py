@@ -100,8 +100,17 @@ class DenoiserEngine:
     def set_use_graph(self, enable: bool):
         _lib.check(self.lib.dsd_set_use_graph(self._h, int(bool(enable))))
 
+    def set_lat_split(self, g: int):
+        """Row split of the latency kernels (csrc/dsd_lat.hpp): -1 by batch size (default), 0 never, 2 / 4 / 8 forced."""
+        _lib.check(self.lib.dsd_set_lat_split(self._h, int(g)), 'dsd_set_lat_split')
+
+    def lat_split(self) -> int:
+        """G of the latency kernels the prepared batch runs with, 0 = not on that path."""
+        return self.lib.dsd_get_lat_split(self._h)
+
     def set_loop_mode(self, mode: int):
-        """1 (default): the whole K-step loop as one persistent kernel when the batch allows it; 0: per-layer kernels."""
+        """2 (default): automatic - latency kernels for small batches, else the persistent loop / per-layer kernels by chip occupancy;
+        1: the whole K-step loop as one persistent kernel when the batch allows it; 0: per-layer kernels; 3: latency kernels."""
         _lib.check(self.lib.dsd_set_loop_mode(self._h, int(mode)), 'dsd_set_loop_mode')
 
     def loop_mode(self) -> int:
@@ -306,19 +315,20 @@ class DenoiserEngine:
         return float(ms.value)
 
     def loop_timeline(self, x: torch.Tensor, noise: torch.Tensor, k_step: int, phase: int):
-        """Debug: per-wave shader-clock stamps [workgroups, 4 waves, 8] of one phase of the persistent DDPM loop."""
+        """Debug: per-wave shader-clock stamps [workgroups, 4 waves, 16] of the persistent DDPM loop: 0..7 the layer phase `phase`,
+        8..15 the head of its evaluation (include/dsd.h)."""
         import numpy as np
         xs = self._spec(x)
         if noise.dim() == 5:
             noise = noise[:, :, 0]
         max_wg = 1 << 12
-        out = np.zeros(max_wg * 32, dtype=np.uint64)
+        out = np.zeros(max_wg * 64, dtype=np.uint64)
         n = C.c_int32(0)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dsd_debug_loop_timeline(self._h, xs.data_ptr(), noise.data_ptr(), int(k_step), int(phase),
                                                         out.ctypes.data_as(C.POINTER(C.c_uint64)), max_wg, C.byref(n), _stream_ptr(self.device)),
                        'dsd_debug_loop_timeline')
-        return out[:n.value * 32].reshape(n.value, 4, 8)
+        return out[:n.value * 64].reshape(n.value, 4, 16)
 
     def layer_timeline(self, layer: int, t: int):
         """Debug: per-wave shader-clock stamps [blocks, 4 waves, 8] of one launch of the layer kernel."""

@@ -146,11 +146,21 @@ int dsd_denorm_spec(dsd_handle* h, const float* x, const float* mask, float* mel
 
 /* Options: 0 = eager launches (default 1 = replay the K-step loop as a cached hipGraph). */
 int dsd_set_use_graph(dsd_handle* h, int32_t enable);
-/* How the K-step loops run.  mode 1 (default): ONE persistent kernel for the whole loop whenever the prepared batch allows it
- * (32-frame tiles, hipGraph mode on, one utterance's tiles <= the CU count) - every workgroup keeps its x tile and skip sum in
- * registers across layers and steps and exchanges only the conv halo with its neighbours; larger batches run as chunks of
- * whole utterances.  mode 0: one kernel per residual layer + head (a cached hipGraph, or eager launches, see above).  Both
- * give bit-identical results.  dsd_get_loop_mode: 1 if the prepared batch would take the persistent path.
+/* How the K-step loops run (dsd_set_loop_mode):
+ *   2 (default) automatic.  A batch that fills less than half of the chip (32-frame tiles x 2 <= CU count; the reference's own inference
+ *     shape, one utterance per device: configs/tts/fs2.yaml:70) takes the LATENCY kernels: every residual layer as two kernels whose
+ *     workgroups split the output rows of a tile G = 8 / 4 / 2 ways (the largest G that still gives each workgroup its own CU), nodes of
+ *     the cached hipGraph - up to 8 x more CUs per utterance.  Larger batches take the PERSISTENT loop (below) unless its chunking in
+ *     whole utterances would idle more of the chip than the per-layer kernels' grid quantisation (e.g. T = 5000: 157 of 256 CUs).
+ *   1 the persistent loop whenever the prepared batch allows it (32-frame tiles, hipGraph mode on, one utterance's tiles <= the CU
+ *     count): ONE kernel for the whole loop - every workgroup keeps its x tile and skip sum in registers across layers and steps and
+ *     exchanges only the conv halo with its neighbours; larger batches run as chunks of whole utterances.
+ *   0 one kernel per residual layer + head (a cached hipGraph, or eager launches, see above).
+ *   3 the latency kernels regardless of the batch size (tests).
+ * Modes 0 and 1 and the G = 2 / 4 latency kernels give bit-identical results; G = 8 sums the two K halves of the dilated conv separately
+ * (reduction-order noise, ~1e-6).  dsd_set_lat_split: G = -1 by batch size (default), 0 never, 2 / 4 / 8 forced where the latency path
+ * applies; dsd_get_lat_split: the G the prepared batch runs with (0 = not on that path).  dsd_get_loop_mode: 1 if the prepared batch
+ * would take the persistent path.
  * dsd_loop_timeouts: synchronises the stream and returns the sticky timeout word of the persistent loop (0 = every
  * inter-workgroup wait was satisfied; nonzero = a wait hit its spin bound; the affected tiles of x are then NaN).
  * The persistent kernel needs all its workgroups resident at once (<= one per CU), so only ONE such loop may run on a device at
@@ -161,6 +171,8 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
  * dsd_loop_launches: k_loop launches per sampling call for the prepared batch (chunks of whole utterances; 0 = not on that path). */
 int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
 int dsd_loop_launches(dsd_handle* h);
+int dsd_set_lat_split(dsd_handle* h, int32_t g);
+int dsd_get_lat_split(dsd_handle* h);
 
 /* EXPERIMENT (csrc/dsd_split.hpp; default off, env DSD_SPLIT=1 turns it on at creation): the residual layers on
  * the bf16 matrix pipe with fp32-class accuracy - every fp32 operand is the exact sum of three bf16 planes, the six plane products
@@ -193,8 +205,10 @@ int dsd_debug_layer_timeline(dsd_handle* h, int32_t layer, int32_t t, uint64_t* 
                              void* stream);
 
 /* Debug hook of the persistent loop: runs the DDPM loop (arguments as dsd_sample_ddpm) with per-wave shader-clock stamps taken in
- * phase `phase` (= evaluation * L + layer, a non-last layer): HOST out[n_wg*4*8] u64 = {phase start, neighbours' flags seen,
- * y tile staged, conv done, gate done, x' ready, halo published, phase end}.  Single-launch batches only.  Synchronises. */
+ * phase `phase` (= evaluation * L + layer, a non-last layer of an evaluation that is not the last): HOST out[n_wg*4*16] u64 =
+ * [0..7] {phase start, neighbours' flags seen, y tile staged, conv done, gate done, x' ready, halo published, phase end},
+ * [8..15] the head of that evaluation {last layer done, skip tile staged, skip projection done, ReLU tile visible, final projection
+ * done, sampler update stored, barrier, next input projection + halo published}.  Single-launch batches only.  Synchronises. */
 int dsd_debug_loop_timeline(dsd_handle* h, float* x, const float* noise, int32_t k_step, int32_t phase, uint64_t* out,
                             int32_t max_wg, int32_t* n_wg, void* stream);
 

@@ -11,6 +11,7 @@ cond = torch.randn(B, T, 256, device=dev, generator=g).transpose(1, 2)
 x = torch.randn(B, 80, T, device=dev, generator=g)
 noise = torch.randn(K, B, 80, T, device=dev, generator=g)
 eng = gd._engine(cond)
+eng.set_loop_mode(1)
 for phase in (43, 44, 63):
     ts = eng.loop_timeline(x.clone(), noise, K, phase).astype(np.int64)
     d = np.diff(ts[:, :, :8], axis=2)
@@ -20,4 +21,15 @@ for phase in (43, 44, 63):
     for i, n in enumerate(names):
         print('  %-42s: mean %8.0f  min %8.0f  max %8.0f' % (n, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max()))
     print('  phase total: mean %.0f ; start skew across workgroups %.0f' % ((ts[:, :, 7] - ts[:, :, 0]).mean(), ts[:, :, 0].max() - ts[:, :, 0].min()))
+    hd = ts[:, :, 8:16]
+    hn = ['barrier behind the last layer + skip tile (bias, / sqrt(L), stage)', 'skip projection K=256 (2 row blocks / wave) + ReLU tile',
+          'final-projection weight prefetch + barrier', 'final projection K=256 (waves 0-2)', 'sampler update: global reads, math, stores (waves 0-2)',
+          'barrier', 'next input projection + halo publish']
+    print('  head of evaluation %d:' % (phase // 20))
+    for i, n in enumerate(hn):
+        sel = slice(0, 3) if i in (3, 4) else slice(0, 4)        # wave 3 has no final-projection rows
+        a0 = hd[:, sel, i] if i != 5 else hd[:, :3, i]
+        dd = hd[:, sel, i + 1] - a0 if i != 5 else hd[:, :3, i + 1] - a0
+        print('    %-66s: mean %8.0f  min %8.0f  max %8.0f' % (n, dd.mean(), dd.min(), dd.max()))
+    print('    head total (last layer done -> next evaluation\'s x published): mean %.0f' % (hd[:, :, 7] - hd[:, :, 0]).mean())
 print('timeouts', eng.loop_timeouts())

@@ -26,7 +26,7 @@ SHAPES = [(1, 512), (1, 1550), (4, 777), (8, 1000), (8, 1024), (5, 1550), (3, 50
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     shapes = SHAPES
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and not sys.argv[2].startswith('--'):
         shapes = [tuple(int(v) for v in s.split('x')) for s in sys.argv[2].split(',')]
     pre = presets()['lj_ds_beta6']
     hparams.clear()
@@ -39,6 +39,7 @@ def main():
     dev = torch.device('cuda', 0)
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     g = torch.Generator(device=dev).manual_seed(7)
+    modes = [2] if '--default-only' in sys.argv else [2, 1, 0]       # automatic (the product), then forced persistent loop / per-layer kernels
     for B, T in shapes:
         conds = [torch.randn(B, T, 256, device=dev, generator=g).transpose(1, 2) for _ in range(2)]
         x_T = torch.randn(B, 1, 80, T, device=dev, generator=g)
@@ -48,21 +49,28 @@ def main():
             k[0] += 1
             return gd.inference(conds[k[0] & 1], x_T=x_T, K_step=100, pndm_speedup=0, noise_seed=5)
 
-        out = one()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        row = {'B': B, 'T': T, 'K': 100, 'tiles32': B * ((T + 31) // 32), 'tiles_per_utt': (T + 31) // 32, 'n_cu': n_cu}
+        for mode in modes:
+            eng = gd.denoise_fn.engine()
+            eng.set_loop_mode(mode)
             out = one()
-        torch.cuda.synchronize()
-        sec = (time.perf_counter() - t0) / reps
-        eng = gd.denoise_fn.engine()
-        assert bool(torch.isfinite(out).all()) and eng.loop_timeouts() == 0
-        tiles = B * ((T + 31) // 32)
-        tf = B * T * 100 * F_EXEC / sec / 1e12
-        print(json.dumps({'B': B, 'T': T, 'K': 100, 'tiles32': tiles, 'tiles_per_utt': (T + 31) // 32, 'n_cu': n_cu,
-                          'persistent_loop': eng.loop_mode(), 'ms_per_pass': round(sec * 1e3, 3),
-                          'mel_frames_per_s': round(B * T / sec, 1), 'tflops_executed': round(tf, 2),
-                          'frac_fp32_mfma_peak': round(tf / PEAK_TF, 4)}), flush=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out = one()
+            torch.cuda.synchronize()
+            sec = (time.perf_counter() - t0) / reps
+            assert bool(torch.isfinite(out).all()) and eng.loop_timeouts() == 0
+            tf = B * T * 100 * F_EXEC / sec / 1e12
+            path = f'latency G={eng.lat_split()}' if eng.lat_split() else ('persistent' if eng.loop_mode() == 1 else f'per-layer tile {eng.layer_tile()}')
+            if mode == 2:
+                row.update({'path': path, 'ms_per_pass': round(sec * 1e3, 3), 'mel_frames_per_s': round(B * T / sec, 1),
+                            'tflops_executed': round(tf, 2), 'frac_fp32_mfma_peak': round(tf / PEAK_TF, 4)})
+            else:
+                row['forced_' + ('persistent' if mode == 1 else 'per_layer')] = {'path': path, 'ms_per_pass': round(sec * 1e3, 3),
+                                                                                'frac_fp32_mfma_peak': round(tf / PEAK_TF, 4)}
+        gd.denoise_fn.engine().set_loop_mode(2)
+        print(json.dumps(row), flush=True)
         del conds, x_T
 
 
