@@ -301,7 +301,7 @@ extern "C" int dsd_get_layer_tile(dsd_handle* h) { return h ? 32 * layer_nb(h) :
 // ------------------------------------------------------------------------------------------------------------
 static int pack_a(hipStream_t s, const float* src, float4* dst, int nw, int ntap, int nkc, int nmb, int split, int hi_base,
                   int rows_valid, int cols_valid, int row_stride, int col_stride) {
-    PackParams p{src, (float*)dst, nw, nkc, nmb, ntap, split, hi_base, rows_valid, cols_valid, row_stride, col_stride};
+    PackParams p{src, (float*)dst, nw, nkc, nmb, ntap, split, hi_base, rows_valid, cols_valid, row_stride, col_stride, /*centre_first*/ 1};
     const size_t n = (size_t)nw * ntap * nkc * nmb * 256;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(k_pack_a, dim3(blocks), dim3(256), 0, s, p);

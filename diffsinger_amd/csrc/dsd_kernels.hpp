@@ -197,6 +197,29 @@ __device__ __forceinline__ void gemm_k(f32x16 (&acc)[NMB][NB], const float4* __r
     pipe.run(acc, 0, n);
 }
 
+// K order of the dilated conv (K = 3 taps x 256 channels = 96 chunks of 8 channels x 1 tap): CENTRE TAP FIRST.
+//   chunk kc <  32: tap 1 (column offset 0) of channel group k8 = kc
+//   chunk kc >= 32: channel group k8 = (kc - 32) / 2, tap 0 (offset -dil) for even kc - 32, tap 2 (offset +dil) for odd
+// The centre tap reads no halo column, so the first 32 chunks (a third of the contraction, ~33 k MFMA cycles) need nothing from the
+// neighbour tiles: the persistent loop fetches its neighbours' columns UNDER them instead of in front of the conv (dsd_loop.hpp), and
+// within the centre region channels are consumed in ascending order (k_layer's progressive staging).  Every fp32 kernel and the weight
+// packers share this order, so they stay bit-identical to each other.
+constexpr int kConvCentre = 32;
+__host__ __device__ __forceinline__ int conv_chunk(int k8, int tap) { return (tap == 1) ? k8 : kConvCentre + 2 * k8 + (tap >> 1); }
+
+// B functor of the dilated conv over a y tile [channel][LD] whose column kHalo is frame 0 of the tile: yc = this lane's pointer to
+// (row 4 h, column kHalo + j); kbase = first chunk of this wave's K range (a multiple of 6).
+template <int LD>
+struct ConvB {
+    const float* yc; int dil, kbase;
+    __device__ __forceinline__ const float* operator()(int it, int u) const {
+        const int kc = kbase + 6 * it + u;
+        if (kc < kConvCentre) return yc + kc * (8 * LD);
+        const int idx = kc - kConvCentre;
+        return yc + (idx >> 1) * (8 * LD) + ((idx & 1) ? dil : -dil);
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // residual layer
 // ------------------------------------------------------------------------------------------------------------
@@ -315,14 +338,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     load_h(0);
     DSD_SB();
 
-    // conv operand pipeline.  K order of the dilated conv: chunk kc = 3 * k8 + tap (the three taps of one 8-channel group
-    // are consecutive), so inside a 6-chunk rotation the B address is {tap base} + it * 16 rows + a compile-time constant.
-    // Its weight stream does not depend on x: the first chunks are requested right behind the first quarter.
+    // conv operand pipeline.  K order of the dilated conv: centre tap first (ConvB above): chunk kc < 32 = centre tap of channel
+    // group kc, then the two outer taps of every group.  Its weight stream does not depend on x: the first chunks are requested
+    // right behind the first quarter.
     const int dil = p.dil;
-    const float* yl = ytile + 4 * h * LD + kHalo + j;
-    const float* ytap[3] = {yl - dil, yl, yl + dil};
-    auto bof1 = [&](int it, int u) { return ytap[u % 3] + it * (16 * LD) + (u / 3) * (8 * LD); };
-    GemmPipe<4, NB, LD, 256, (NB == 1 ? 6 : 3), decltype(bof1)> pipe1(p.w1p + (size_t)w * (96 * 256), lane, 96, bof1);
+    const ConvB<LD> bof1{ytile + 4 * h * LD + kHalo + j, dil, 0};
+    GemmPipe<4, NB, LD, 256, (NB == 1 ? 6 : 3), ConvB<LD>> pipe1(p.w1p + (size_t)w * (96 * 256), lane, 96, bof1);
     constexpr int ST1 = (NB == 1 ? 6 : 3);
     pipe1.template start_a<0, 2>();
     if (p.dbg) tsa = __builtin_amdgcn_s_memtime();
@@ -361,10 +382,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     __syncthreads();
     if (p.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
-    // 2. dilated conv: K = 3 taps x 256 channels = 96 chunks of 8; tap k reads column offset (k-1)*dil.  Channel quarter q
-    //    is chunks [24 q, 24 q + 24); it is written 6 chunks early (the B prefetch runs one chunk ahead).  The hoisted
-    //    conditioner projection (+ conv bias + cond bias) is fetched halfway through the loop, when the memory system is
-    //    idle, and added once the loop is done.
+    // 2. dilated conv: K = 3 taps x 256 channels = 96 chunks of 8; tap k reads column offset (k-1)*dil.  The centre-tap region
+    //    (chunks 0..31) consumes channel quarter q in chunks [8 q, 8 q + 8): quarter q + 1 is written at the 6-chunk boundary in
+    //    front of its first chunk (the B prefetch runs one chunk ahead) and requested one segment earlier; the outer taps and the
+    //    halo columns (chunks >= 32) find the whole tile in place.  The hoisted conditioner projection (+ conv bias + cond bias)
+    //    is fetched halfway through the loop, when the memory system is idle, and added once the loop is done.
     f32x16 acc[4][NB];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -381,15 +403,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
         pipe.template start_a<2, ST1 - 1>();
         load_quarter(1);
         pipe.start_b();
-        pipe.run(acc, 0, 18);
+        pipe.run(acc, 0, 6);
         write_quarter(1);
         __syncthreads();
         load_quarter(2);
-        pipe.run(acc, 18, 42);
+        pipe.run(acc, 6, 12);
         write_quarter(2);
         __syncthreads();
         load_quarter(3);
-        pipe.run(acc, 42, 48);
+        pipe.run(acc, 12, 18);
+        write_quarter(3);
+        __syncthreads();
+        pipe.run(acc, 18, 48);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const float4* cpl = p.cp + ((size_t)(tile0 + ((nb < ntv) ? nb : 0)) * 4 + w) * (4 * 4 * 64) + lane;
@@ -399,10 +424,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
                 for (int q = 0; q < 4; ++q) cpv[mb][nb][q] = cpl[(mb * 4 + q) * 64];   // tiles past the end: unused columns
         }
         DSD_SB();
-        pipe.run(acc, 48, 66);
-        write_quarter(3);
-        __syncthreads();
-        pipe.run(acc, 66, 96);
+        pipe.run(acc, 48, 96);
     }
     if (p.dbg) ts2 = __builtin_amdgcn_s_memtime();
 
@@ -775,6 +797,7 @@ struct PackParams {
     int split, hi_base;          // gate/filter or residual/skip split (hi rows start at hi_base)
     int rows_valid, cols_valid;  // zero outside (padding)
     int row_stride, col_stride;  // in floats: src[(row * row_stride) + col * col_stride + tap]
+    int centre_first;            // ntap == 3: chunk order of the dilated conv (conv_chunk above) instead of "taps of one group consecutive"
 };
 
 __global__ void k_pack_a(const PackParams p) {
@@ -785,7 +808,11 @@ __global__ void k_pack_a(const PackParams p) {
         const int mb = r % p.nmb; r /= p.nmb;
         const int kct = r % (p.ntap * p.nkc); r /= (p.ntap * p.nkc);
         const int w = (int)r;
-        const int tap = kct % p.ntap, kc = kct / p.ntap;      // taps of one 8-deep k group are consecutive chunks
+        int tap = kct % p.ntap, kc = kct / p.ntap;            // taps of one 8-deep k group are consecutive chunks ...
+        if (p.centre_first && p.ntap == 3) {                  // ... or the dilated conv's order: all centre taps, then the outer pairs
+            if (kct < p.nkc) { tap = 1; kc = kct; }
+            else { const int idx = kct - p.nkc; kc = idx >> 1; tap = (idx & 1) * 2; }
+        }
         const int i = lane & 31, h = lane >> 5;
         int row;
         if (p.split) {

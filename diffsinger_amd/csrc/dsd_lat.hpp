@@ -22,7 +22,7 @@
 //   G = 4: workgroup g <- stream g;           wave = row block; conv: the filter waves hand tanh(.) to the gate waves through LDS
 //   G = 8: workgroup g <- stream g / 2, pair g % 2; conv: wave = (gate | filter, K half) - the two K halves are summed through LDS
 //          (the ONLY place where the summation order differs from k_layer: (first half) + (second half) instead of one k-ordered chain);
-//          out-proj: two waves (residual block, skip block), the whole K.
+//          out-proj: wave = (residual | skip block, K half), summed the same way.
 // G = 2 and G = 4 are bit-identical to k_layer; G = 8 agrees to reduction-order noise (tests/test_gpu_latency.py).
 #pragma once
 #include "dsd_kernels.hpp"
@@ -33,7 +33,7 @@ struct LatParams {
     const float* x_in;      // [tiles][C][32] tile-major
     float* x_out;           // [tiles][C][32]
     float* gbuf;            // [tiles][C][32] gate tile (k_lat_conv -> k_lat_out)
-    const float4* w1p;      // this layer's dilated conv, packed [w4][kc96 = 3 * k8 + tap][mb4][lane64]
+    const float4* w1p;      // this layer's dilated conv, packed [w4][kc96: centre tap first, conv_chunk()][mb4][lane64]
     const float4* w2p;      // this layer's output projection, packed [w4][kc32][mb4][lane64]
     const float* b2;        // output projection bias [2C] (residual half)
     const float4* cp;       // this layer's hoisted conditioner projection (+ biases) [tile][w4][mb4][q4][lane64]
@@ -45,7 +45,7 @@ struct LatParams {
 };
 
 constexpr int kLatConvLdsBytes = (kC * (32 + 2 * kHalo) + 3 * 32 * 32) * (int)sizeof(float);     // y tile + K-half partials [2] + filter [1..2]
-constexpr int kLatOutLdsBytes = kC * 32 * (int)sizeof(float);
+constexpr int kLatOutLdsBytes = (kC * 32 + 2 * 32 * 32) * (int)sizeof(float);                     // gate tile + K-half partials [2] (G = 8)
 
 // workgroup -> (tile, g): the G workgroups of a tile read the same x / gate tile, so they are placed behind the same L2 (workgroups
 // are dealt round-robin to the 8 XCDs by linear id): XCD x takes tiles x, x + 8, ...   grid = ceil(ntiles / 8) * 8 * G
@@ -82,10 +82,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
     else { w4 = g >> 1; mb0 = (g & 1) + 2 * (wv & 1); kbeg = 48 * (wv >> 1); }
 
     // the weight stream does not depend on x: its first chunks are requested before the tile is staged
-    const float* yl = ytile + (kbeg / 3) * (8 * LD) + 4 * h * LD + kHalo + j;
-    const float* ytap[3] = {yl - dil, yl, yl + dil};
-    auto bof = [&](int it, int u) { return ytap[u % 3] + it * (16 * LD) + (u / 3) * (8 * LD); };
-    GemmPipe<NMB, 1, LD, 256, 6, decltype(bof), 2> pipe(p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, bof);
+    const ConvB<LD> bof{ytile + 4 * h * LD + kHalo + j, dil, kbeg};
+    GemmPipe<NMB, 1, LD, 256, 6, ConvB<LD>, 2> pipe(p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, bof);
     pipe.start_a();
 
     // stage y = x + step_proj (zero at frames outside [0, T): the conv's zero padding applies to y, net.py:69-71)
@@ -190,25 +188,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
     static_assert(G == 2 || G == 4 || G == 8, "row split");
     constexpr int TILE = kC * 32;
     constexpr int NMB = (G == 2) ? 2 : 1;
+    constexpr int NCH = (G == 8) ? 16 : 32;     // chunks per wave: G = 8 splits K = 256 over two waves per row block
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* gtile = smem;                    // [256][32]
+    float* red = smem + kC * 32;            // G = 8: [2][32][32] K-half partials of the residual / skip block
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile, g;
     if (!lat_map<G>(p.ntiles, tile, g)) return;
 
-    int w4, mb0;
-    bool active = true;
+    int w4, mb0, kbeg = 0;
     if (G == 2) { w4 = 2 * g + (wv >> 1); mb0 = wv & 1; }
     else if (G == 4) { w4 = g; mb0 = wv; }
-    else { w4 = g >> 1; mb0 = (g & 1) + 2 * wv; active = wv < 2; if (!active) mb0 = (g & 1); }
+    else { w4 = g >> 1; mb0 = (g & 1) + 2 * (wv & 1); kbeg = 16 * (wv >> 1); }
     // the last layer's residual half is dead (net.py:126 reads the skips only)
     const bool do_res = !p.last && ((G == 2) || mb0 < 2);
     const bool do_skip = (G == 2) || mb0 >= 2;
-    if (G != 2 && p.last && mb0 < 2) active = false;
+    const bool active = (G == 2) || !(p.last && mb0 < 2);
 
-    const float* gl = gtile + 4 * h * 32 + j;
-    GemmPipe<NMB, 1, 32, 256, 6, TileB, 2> pipe(p.w2p + (size_t)w4 * (32 * 256) + mb0 * 64, lane, 32, TileB{gl, 8 * 32, 32});
+    const float* gl = gtile + kbeg * (8 * 32) + 4 * h * 32 + j;
+    GemmPipe<NMB, 1, 32, 256, 6, TileB, 2> pipe(p.w2p + (size_t)w4 * (32 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, TileB{gl, 8 * 32, NCH});
     if (active) pipe.start_a();
 
     {
@@ -220,15 +219,31 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
         for (int it = 0; it < 8; ++it) reinterpret_cast<float4*>(gtile)[it * kThreads + tid] = v[it];
     }
     __syncthreads();
-    if (!active) return;
 
     f32x16 acc[NMB][1];
 #pragma unroll
     for (int m = 0; m < NMB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
-    pipe.start_b();
-    pipe.run(acc, 0, 32);
+    if (active) {
+        pipe.start_b();
+        pipe.run(acc, 0, NCH);
+    }
+    if (G == 8) {
+        // sum the two K halves (first half + second half; the only difference from k_layer's single k-ordered chain)
+        float* part = red + (wv & 1) * 1024;
+        if (active && wv >= 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[frag_row(r, h) * 32 + j] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (wv >= 2) return;
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][0][r] + part[frag_row(r, h) * 32 + j];
+        }
+    }
+    if (!active) return;
 
     if (do_res) {
         // x' = (x + (res + b)) / sqrt(2)   (net.py:78; same operation order as k_layer)

@@ -27,7 +27,7 @@ constexpr int kLoopMaxLayers = 64;
 constexpr int kLoopSpinLimit = 1 << 21;     // ~2-4 s of polling: far beyond any legitimate skew, still bounded
 
 struct LoopParams {
-    const float4* w1p;          // [L][w4][kc96][mb4][lane64]
+    const float4* w1p;          // [L][w4][kc96: centre tap first, conv_chunk()][mb4][lane64]
     const float4* w2p;          // [L][w4][kc32][mb4][lane64]
     const float* b2raw;         // [L][2C]
     const float4* cp;           // [L][tile][w4][mb4][q4][lane64]
@@ -141,14 +141,41 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             LOOP_STAMP(0);
 
             // (c) the weight stream does not depend on anything computed here: request its first chunks now
-            const float* yl = ytile + 4 * h * LD + kHalo + j;
-            const float* ytap[3] = {yl - dil, yl, yl + dil};
-            auto bof1 = [&](int it, int u) { return ytap[u % 3] + it * (16 * LD) + (u / 3) * (8 * LD); };
-            GemmPipe<4, 1, LD, 256, 6, decltype(bof1)> pipe1(p.w1p + ((size_t)l * 4 + w) * (96 * 256), lane, 96, bof1);
+            const ConvB<LD> bof1{ytile + 4 * h * LD + kHalo + j, dil, 0};
+            GemmPipe<4, 1, LD, 256, 6, ConvB<LD>> pipe1(p.w1p + ((size_t)l * 4 + w) * (96 * 256), lane, 96, bof1);
             pipe1.template start_a<0, 5>();
 
-            // (d) both neighbours have published phase ph?  (they did so at the end of their previous phase: the wait is the skew
-            //     between neighbouring workgroups, ~2 k cycles measured)
+            // (b) own columns of y = x + step_proj (zero at frames >= T: the conv's zero padding applies to y, net.py:69-71).  They
+            //     need nothing from the neighbours, and neither does the first third of the contraction: the K order of the dilated
+            //     conv starts with the CENTRE tap of every channel group (ConvB, chunks 0..31), which reads no halo column.
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = xrow0 + 8 * it, t = t0 + 4 * xc4;
+                const float d = dsl[row];
+                float4 v = xreg[it];
+                v.x = (t + 0 < T) ? v.x + d : 0.f;
+                v.y = (t + 1 < T) ? v.y + d : 0.f;
+                v.z = (t + 2 < T) ? v.z + d : 0.f;
+                v.w = (t + 3 < T) ? v.w + d : 0.f;
+                *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 4 * xc4) = v;
+            }
+            __syncthreads();
+            LOOP_STAMP(1);
+
+            // (g) dilated conv, K = 768 (one contraction, taps are column offsets).  The exchange with the neighbour tiles runs UNDER
+            //     the centre-tap chunks: flags polled behind chunk 12 (the neighbours published at the end of their previous phase:
+            //     normally long satisfied), their columns requested and in flight during chunks 12..29, written to the y tile in front
+            //     of chunk 30; the outer taps (chunks >= 32) are the first to read them.  The hoisted conditioner projection is
+            //     fetched half way.
+            f32x16 acc[4][1];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][0][r] = 0.f;
+            float4 cpv[4][4];
+            pipe1.start_b();
+            pipe1.run(acc, 0, 12);
+            // (d) both neighbours have published phase ph?
             if (w == 0 && lane < 2) {
                 const bool have = lane ? has_right : has_left;
                 if (have) {
@@ -162,7 +189,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 }
             }
             __syncthreads();
-            LOOP_STAMP(1);
             // (e1) request the neighbours' columns (thread = channel row; sc1 loads: the producer stored write-through)
             float4 hv[2][2];
             {
@@ -179,18 +205,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     }
                 }
             }
-            // (b) own columns of y = x + step_proj (zero at frames >= T: the conv's zero padding applies to y, net.py:69-71)
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = xrow0 + 8 * it, t = t0 + 4 * xc4;
-                const float d = dsl[row];
-                float4 v = xreg[it];
-                v.x = (t + 0 < T) ? v.x + d : 0.f;
-                v.y = (t + 1 < T) ? v.y + d : 0.f;
-                v.z = (t + 2 < T) ? v.z + d : 0.f;
-                v.w = (t + 3 < T) ? v.w + d : 0.f;
-                *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 4 * xc4) = v;
-            }
+            DSD_SB();
+            pipe1.run(acc, 12, 30);
             // (e2) halo columns of the y tile
             {
                 const float d = dsl[tid];
@@ -211,16 +227,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             }
             __syncthreads();
             LOOP_STAMP(2);
-
-            // (g) dilated conv, K = 768 (one contraction, taps are column offsets), cond projection fetched half way
-            f32x16 acc[4][1];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mb][0][r] = 0.f;
-            float4 cpv[4][4];
-            pipe1.start_b();
-            pipe1.run(acc, 0, 48);
+            pipe1.run(acc, 30, 48);
             {
                 const float4* cpl = p.cp + (size_t)l * p.cp_lstride + ((size_t)tile * 4 + w) * (4 * 4 * 64) + lane;
 #pragma unroll

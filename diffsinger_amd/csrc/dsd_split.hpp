@@ -37,7 +37,8 @@ __device__ __forceinline__ void sp_split3(float x, su16& a, su16& b, su16& c) {
     a = __builtin_bit_cast(su16, p0); b = __builtin_bit_cast(su16, p1); c = __builtin_bit_cast(su16, p2);
 }
 
-// fp32 fragment-order weights (k_pack_a, 32x32x2: [w][chunk8 = ntap * k8 + tap][mb 4][lane][4], lane (i, h), s -> channel 8 k8 + 4 h + s)
+// fp32 fragment-order weights (k_pack_a, 32x32x2: [w][chunk8][mb 4][lane][4], chunk8 = conv_chunk(k8, tap) for the dilated conv, = k8 for
+// the projections; lane (i, h), s -> channel 8 k8 + 4 h + s)
 // -> bf16 planes in 32x32x16 fragment order [w][chunk16 = ntap * g + tap][mb 4][plane 3][lane (i, h')][e 8], channel 16 g + 8 h' + e.
 __global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ dst, int nw, int ng, int ntap) {
     const size_t n = (size_t)nw * ng * ntap * 4 * 64 * 8;              // (w, chunk16, mb, lane, e)
@@ -49,7 +50,7 @@ __global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ d
         const int w = (int)r;
         const int g = c16 / ntap, tap = c16 - g * ntap;
         const int i = lane & 31, hp = lane >> 5;
-        const int k8 = 2 * g + hp, c8 = ntap * k8 + tap;               // source chunk
+        const int k8 = 2 * g + hp, c8 = (ntap == 3) ? conv_chunk(k8, tap) : ntap * k8 + tap;    // source chunk (the fp32 stream's order)
         const int lane_src = i + 32 * (e >> 2), s = e & 3;
         const float v = src[((((size_t)w * (2 * ng * ntap) + c8) * 4 + mb) * 64 + lane_src) * 4 + s];
         su16 p0, p1, p2;

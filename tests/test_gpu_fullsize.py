@@ -48,12 +48,24 @@ def test_config2_ddpm_k100_rows_vs_oracle_and_row_independence():
     for b in (0, 5):
         with torch.no_grad():
             want = O.infer_mel(p, cfg, sch, cond[b:b + 1], smin, smax, k_step=K, noises=list(noise[:, b:b + 1]), x_T=x_T[b:b + 1])
+            alone_default = gd.inference(_dev_cond(cond[b:b + 1]), x_T=x_T[b:b + 1].cuda(), noise=noise[:, b:b + 1].contiguous().cuda(),
+                                         K_step=K, pndm_speedup=0).cpu()
+            eng = gd.denoise_fn.engine()
+            assert eng.lat_split() == 8                                  # one utterance of 32 tiles: the latency kernels, 8-way row split
+            eng.set_loop_mode(1)                                         # ... and the same utterance on the kernel the batch of 8 ran on
             alone = gd.inference(_dev_cond(cond[b:b + 1]), x_T=x_T[b:b + 1].cuda(), noise=noise[:, b:b + 1].contiguous().cuda(),
                                  K_step=K, pndm_speedup=0).cpu()
+            eng.set_loop_mode(2)
         err = float((full[b:b + 1] - want).abs().max())
         print(f'config 2 row {b}: max-abs mel err vs oracle {err:.3e}')
         assert err <= 1e-4
-        assert torch.equal(alone, full[b:b + 1])                         # batch rows never interact
+        assert torch.equal(alone, full[b:b + 1])                         # batch rows never interact: bit-identical on the same kernels
+        # the automatic choice runs a lone utterance on the G = 8 latency kernels, which sum the two K halves of the dilated conv
+        # separately: the same mel to reduction-order noise (the reference's own B = 1 vs B = 2 results differ by 9.5e-7)
+        d = float((alone_default - full[b:b + 1]).abs().max())
+        print(f'config 2 row {b}: alone on the latency kernels vs row of the batch: max-abs mel difference {d:.3e}; vs oracle '
+              f'{float((alone_default - want).abs().max()):.3e}')
+        assert d <= 2e-5 and float((alone_default - want).abs().max()) <= 1e-4
 
 
 def test_config3_shallow_k60_row_vs_oracle():

@@ -125,10 +125,11 @@ def test_offline_gaussian_diffusion_forward_train_matches_oracle_loss():
     loss = ret['diff_loss']
     loss.backward()
     assert gd.denoise_fn.input_projection.weight.grad is not None
-    # the draws forward() made: t = randint(0, K_step, (B,)), then noise = randn_like(x) inside p_losses
+    # the draws forward() made: t = randint(0, K_step, (B,)), then noise = randn_like(x) inside p_losses - x is the TRANSPOSED VIEW
+    # norm_spec(mel).transpose(1, 2)[:, None] (:302-304) and randn_like fills a tensor of those strides
     torch.manual_seed(5)
     t = torch.randint(0, K, (B,), device=DEV).long()
-    noise = torch.randn(B, 1, 80, T, device=DEV)
+    noise = torch.randn_like(gd.norm_spec(target.to(DEV)).transpose(1, 2)[:, None, :, :])
     sch = O.make_schedule(H.betas_for(pre))
     x0 = O.norm_spec(target, smin, smax).transpose(1, 2)[:, None]
     with torch.no_grad():
@@ -169,7 +170,7 @@ def test_legacy_gaussian_diffusion_forward_both_branches():
     loss = gd(inp['txt_tokens'].to(DEV), ref_mels=target.to(DEV), infer=False, **kw)['diff_loss']
     torch.manual_seed(6)
     t = torch.randint(0, K, (B,), device=DEV).long().cpu()
-    noise = torch.randn(B, 1, 80, T, device=DEV).cpu()
+    noise = torch.randn_like(gd.norm_spec(target.to(DEV)).transpose(1, 2)[:, None, :, :]).cpu()     # strides of the view forward() builds
     x0 = O.norm_spec(target, smin, smax).transpose(1, 2)[:, None]
     with torch.no_grad():
         rec = O.diffnet_forward(p, cfg, O.q_sample(sch, x0, t, noise), t, cond)

@@ -30,8 +30,15 @@ def split3(x):
     return a, b, bf16_round((r1 - b).astype(np.float32))
 
 
+def conv_chunk(k8, tap, ntap):
+    """csrc/dsd_kernels.hpp conv_chunk: the dilated conv's chunk order is centre tap first; the projections have one tap."""
+    if ntap != 3:
+        return ntap * k8 + tap
+    return k8 if tap == 1 else 32 + 2 * k8 + (tap >> 1)
+
+
 def pack_a_split_rows(W, ntap):
-    """k_pack_a(nw=4, ntap, nkc=32, nmb=4, split=1, hi_base=256): fp32 [w][chunk8 = ntap*k8 + tap][mb][lane][4]."""
+    """k_pack_a(nw=4, ntap, nkc=32, nmb=4, split=1, hi_base=256, centre_first): fp32 [w][chunk8 = conv_chunk(k8, tap)][mb][lane][4]."""
     nk8 = 32
     out = np.zeros((4, ntap * nk8, 4, 64, 4), np.float32)
     for w in range(4):
@@ -40,7 +47,7 @@ def pack_a_split_rows(W, ntap):
             for k8 in range(nk8):
                 for tap in range(ntap):
                     for h in range(2):
-                        out[w, ntap * k8 + tap, mb, 32 * h:32 * h + 32, :] = W[rows][:, 8 * k8 + 4 * h:8 * k8 + 4 * h + 4, tap]
+                        out[w, conv_chunk(k8, tap, ntap), mb, 32 * h:32 * h + 32, :] = W[rows][:, 8 * k8 + 4 * h:8 * k8 + 4 * h + 4, tap]
     return out
 
 
@@ -57,7 +64,7 @@ def pack_split(src, ng, ntap):
                     i, hp = lane & 31, lane >> 5
                     for e in range(8):
                         k8 = 2 * g + hp
-                        c8 = ntap * k8 + tap
+                        c8 = conv_chunk(k8, tap, ntap)
                         lane_src, s = i + 32 * (e >> 2), e & 3
                         v = flat[((((w * (2 * ng * ntap) + c8) * 4 + mb) * 64 + lane_src) * 4) + s]
                         p0, p1, p2 = split3(np.array([v], np.float32))

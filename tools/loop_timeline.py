@@ -15,11 +15,12 @@ eng.set_loop_mode(1)
 for phase in (43, 44, 63):
     ts = eng.loop_timeline(x.clone(), noise, K, phase).astype(np.int64)
     d = np.diff(ts[:, :, :8], axis=2)
-    names = ['wait for neighbours (+prefetch issue)', 'stage y (halo loads, own cols, barrier)', 'conv K=768', 'gate + barrier',
+    names = ['weight prefetch issue, own columns of y, barrier', 'conv chunks 0-29 (centre taps) + flag poll, halo loads / writes, 2 barriers',
+             'conv chunks 30-95', 'gate + barrier',
              'out-proj K=256', 'residual transpose, x\'', 'publish (drain, barrier, flag) + skip sum']
     print(f'phase {phase} (layer {phase % 20}): {ts.shape[0]} workgroups, shader-clock ticks')
     for i, n in enumerate(names):
-        print('  %-42s: mean %8.0f  min %8.0f  max %8.0f' % (n, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max()))
+        print('  %-76s: mean %8.0f  min %8.0f  max %8.0f' % (n, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max()))
     print('  phase total: mean %.0f ; start skew across workgroups %.0f' % ((ts[:, :, 7] - ts[:, :, 0]).mean(), ts[:, :, 0].max() - ts[:, :, 0].min()))
     hd = ts[:, :, 8:16]
     hn = ['barrier behind the last layer + skip tile (bias, / sqrt(L), stage)', 'skip projection K=256 (2 row blocks / wave) + ReLU tile',
