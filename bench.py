@@ -253,6 +253,12 @@ def main_vocoder(args):
     mel = torch.randn(B, 80, T, device=device, generator=torch.Generator(device=device).manual_seed(1234 + rank))
     el, wav = _row_time(lambda: m(mel), args, world, device, dist)
     assert wav.shape == (B, 1, T * 256) and bool(torch.isfinite(wav).all()), 'bad waveform'
+    # the same forward replayed as ONE hipGraph (diffsinger_amd/graphs.py): the ~80 launches of a forward without their Python / ctypes issue cost
+    from diffsinger_amd.graphs import GraphedForward
+    gm = GraphedForward(m)
+    wav_g = gm(mel)
+    assert torch.equal(wav_g, wav), 'graph replay differs from the eager forward'
+    el_g, _ = _row_time(lambda: gm(mel), args, world, device, dist)
     if rank == 0:
         # dominant kernel: the resblock convolutions of the 8-channel stage (18 of the 76 launches, the longest time axis).  One launch
         # of k_voc_conv_fold<4> (kernel 11, dilation 1, leaky_relu in front, residual behind) timed with events on the launch stream.
@@ -296,7 +302,10 @@ def main_vocoder(args):
                                       f'frames per GPU -> {B} x {T * 256} samples', 'narrow_layers': 'folded (k_voc_conv_fold)' if F > 1 else 'unfolded',
                           'sharding': 'replicas (no exchange step in this row)'},
                'roofline': roof, 'model_tflops': world * B * T * fpf * args.steps / el / 1e12, 'flop_per_mel_frame': fpf,
-               'x_realtime_24k': value * 256 / 24000}
+               'x_realtime_24k': value * 256 / 24000,
+               'hipgraph_replay': {'ms_per_step': el_g / args.steps * 1e3, 'value': world * B * T * args.steps / el_g,
+                                   'note': 'the same forward captured once and replayed as one hipGraph (diffsinger_amd.graphs.GraphedForward); '
+                                           'bit-identical output; `value` above is the eager figure'}}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline_vocoder()
             res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
@@ -466,6 +475,19 @@ def main_fs2(args):
 
     el, r = _row_time(step, args, world, device, dist)
     assert r['mel_out'].shape == (B, T, 80) and bool(torch.isfinite(r['mel_out']).all()), 'bad mel'
+    # the same teacher-forced forward replayed as ONE hipGraph (diffsinger_amd/graphs.py)
+    from diffsinger_amd.graphs import GraphedForward
+    gm = GraphedForward(lambda tok_, mel2ph, f0, uv: m(tok_, infer=True, mel2ph=mel2ph, f0=f0, uv=uv))
+    hip_graph = None
+    try:
+        rg = gm(tok, kw['mel2ph'], kw['f0'], kw['uv'])
+        same = torch.equal(rg['mel_out'], r['mel_out'])
+        el_g, _ = _row_time(lambda: gm(tok, kw['mel2ph'], kw['f0'], kw['uv']), args, world, device, dist)
+        hip_graph = {'ms_per_step': el_g / args.steps * 1e3, 'value': world * B * T * args.steps / el_g, 'bit_identical_to_eager': bool(same),
+                     'note': 'the same forward captured once and replayed as one hipGraph (diffsinger_amd.graphs.GraphedForward); `value` above is '
+                             'the eager figure'}
+    except Exception as e:                                    # report, do not hide
+        hip_graph = {'error': repr(e)[:300]}
     if rank == 0:
         # dominant kernel: k_fs_conv<2> as the k = 9 conv of the feed-forward block (256 -> 1024), one launch timed with events on the launch stream
         from diffsinger_amd.fs2 import conv1d_cm, PackedWeight, padded_frames
@@ -495,7 +517,7 @@ def main_fs2(args):
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': f'SURVEY 8 row f1: FastSpeech2 of {PRESET} (4 + 4 FFT blocks, hidden 256), batch={B} x {T // 8} phones x 8 frames = '
                                       f'{T} mel frames per GPU, mel2ph / f0 / uv supplied', 'preset': PRESET, 'sharding': 'replicas (no exchange step in this row)'},
-               'roofline': roof}
+               'roofline': roof, 'hipgraph_replay': hip_graph}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline_fs2()
             res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']

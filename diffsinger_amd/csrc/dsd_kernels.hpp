@@ -402,15 +402,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
         auto& pipe = pipe1;
         pipe.template start_a<2, ST1 - 1>();
         load_quarter(1);
-        pipe.start_b();
+        if (NB == 1) { load_quarter(2); load_quarter(3); }      // 32-frame tiles: a 6-chunk segment (6 k cycles) is too short to hide a
+        pipe.start_b();                                         // quarter's latency at launch start - request all of them behind the first
         pipe.run(acc, 0, 6);
         write_quarter(1);
         __syncthreads();
-        load_quarter(2);
+        if (NB != 1) load_quarter(2);
         pipe.run(acc, 6, 12);
         write_quarter(2);
         __syncthreads();
-        load_quarter(3);
+        if (NB != 1) load_quarter(3);
         pipe.run(acc, 12, 18);
         write_quarter(3);
         __syncthreads();

@@ -48,7 +48,7 @@ struct LoopParams {
     int dbg_phase;
 };
 
-constexpr int kLoopLdsBytes = (kC * (32 + 2 * kHalo) + 2 * kC * 32) * (int)sizeof(float);      // y tile + gate tile + scratch
+constexpr int kLoopLdsBytes = (kC * (32 + 2 * kHalo) + 2 * kC * 32 + 2 * kC) * (int)sizeof(float);      // y tile + gate tile + scratch + step rows [2]
 
 __device__ __forceinline__ float4 ld16_sc1(const float* base_uniform, int byte_off) {
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
@@ -66,6 +66,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
     float* ytile = smem;                    // [256][48]  conv input y = x + step_proj (+ halo); head: scaled skip sum [256][32]
     float* gtile = smem + kC * LD;          // [256][32]  gate tile; head: relu(skip_projection)
     float* xt = gtile + kC * 32;            // [256][32]  scratch: residual transpose, spec tile of the in-projection
+    float* dsbuf = xt + kC * 32;            // [2][256]   step projection of phase ph in dsbuf[ph & 1]: fetched from the table one phase ahead,
+                                            //            so that staging y = x + step never waits for a global load
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
         const int m = idx >> 5, t = t0 + (idx & 31);
         xt[idx] = (m < M && t < T) ? p.spec0[((size_t)b * M + m) * T + t] : 0.f;
     }
+    dsbuf[tid] = p.ds_table[(size_t)p.eval_t[0] * p.L * kC + tid];       // phase 0 = (evaluation 0, layer 0)
     __syncthreads();
     inproj_to_xreg();
 
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
         const int t_e = p.eval_t[e];
         for (int l = 0; l < p.L; ++l, ++ph) {
             const bool last = (l == p.L - 1);
-            const float* __restrict__ dsl = p.ds_table + ((size_t)t_e * p.L + l) * kC;
+            const float* dsl = dsbuf + (ph & 1) * kC;
             const int dil = p.dil[l];
             LOOP_STAMP(0);
 
@@ -237,6 +240,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             }
             DSD_SB();
             pipe1.run(acc, 48, 96);
+            // step projection of the NEXT phase (next layer, or layer 0 of the next evaluation): requested now, parked in LDS behind the
+            // output projection, read by the next phase's staging
+            float ds_next = 0.f;
+            {
+                const bool more = !last || (e + 1 < p.n_evals);
+                const int tn_ = last ? p.eval_t[min(e + 1, p.n_evals - 1)] : t_e, ln_ = last ? 0 : l + 1;
+                if (more) ds_next = p.ds_table[((size_t)tn_ * p.L + ln_) * kC + tid];
+            }
 
             const float* gl = gtile + 4 * h * GLD + j;
             const TileB bof2{gl, 8 * GLD, 32};
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     xreg[it] = o;
                 }
                 LOOP_STAMP(6);
+                dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barrier inside publish()
                 publish(ph + 1u);
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
@@ -318,6 +330,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     for (int r = 0; r < 16; ++r) acc2[m][0][r] = 0.f;
                 pipe2.start_b();
                 pipe2.run(acc2, 0, 32);
+                dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barriers of the head
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -378,12 +391,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             f32x16 acc[1][1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) set4(acc[0][0], q, p.head.boutp[(w * 2 + h) * 4 + q]);
-            pipe_o.start_b();
-            pipe_o.run(acc, 0, 32);
-            HEAD_STAMP(4);
             const int t = t0 + j;
             // sampler arithmetic (p_sample :134-166 / p_sample_plms :168-204).  All global reads of the 16 elements are issued
-            // first (one workgroup per CU: nothing else would hide their latency), then the element-wise math, then the stores.
+            // first, in front of the final projection (one workgroup per CU: nothing else would hide their latency), then the GEMM,
+            // then the element-wise math, then the stores.
             size_t idxs[16];
             bool oks[16];
             float xv[16], av[16], bv[16], cv[16];
@@ -408,6 +419,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     if (hp.order >= PLMS_AB4) cv[r] = hp.e3[idxs[r]];
                 }
             }
+            pipe_o.start_b();
+            pipe_o.run(acc, 0, 32);
+            HEAD_STAMP(4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 32 * w + frag_row(r, h);
