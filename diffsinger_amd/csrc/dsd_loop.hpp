@@ -404,24 +404,30 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 nz = *hp.noise_cell;
                 if (nz) nz += hp.noise_off; else seed = *hp.seed_cell;
             }
+            auto load_inputs = [&]() {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = 32 * w + frag_row(r, h);
-                oks[r] = (m < M) && (t < T);
-                idxs[r] = oks[r] ? ((size_t)b * M + m) * T + t : 0;
-                xv[r] = hp.x_base[idxs[r]];
-                av[r] = bv[r] = cv[r] = 0.f;
-                if (MODE == HEAD_DDPM) {
-                    av[r] = nz ? nz[idxs[r]] : philox_normal(seed, hp.step_id, idxs[r]);
-                } else {
-                    if (hp.order >= PLMS_HEUN) av[r] = hp.e1[idxs[r]];
-                    if (hp.order >= PLMS_AB3) bv[r] = hp.e2[idxs[r]];
-                    if (hp.order >= PLMS_AB4) cv[r] = hp.e3[idxs[r]];
+                for (int r = 0; r < 16; ++r) {
+                    const int m = 32 * w + frag_row(r, h);
+                    oks[r] = (m < M) && (t < T);
+                    idxs[r] = oks[r] ? ((size_t)b * M + m) * T + t : 0;
+                    xv[r] = hp.x_base[idxs[r]];
+                    av[r] = bv[r] = cv[r] = 0.f;
+                    if (MODE == HEAD_DDPM) {
+                        av[r] = nz ? nz[idxs[r]] : philox_normal(seed, hp.step_id, idxs[r]);
+                    } else {
+                        if (hp.order >= PLMS_HEUN) av[r] = hp.e1[idxs[r]];
+                        if (hp.order >= PLMS_AB3) bv[r] = hp.e2[idxs[r]];
+                        if (hp.order >= PLMS_AB4) cv[r] = hp.e3[idxs[r]];
+                    }
                 }
-            }
+            };
+            // DDPM: the reads go in front of the final projection.  PLMS keeps them behind it (r02d: the hoisted PLMS epilogue differed from
+            // the per-layer path on the hardware; PLMS loops are 5-26 evaluations long, the reads' latency is irrelevant there)
+            if (MODE == HEAD_DDPM) load_inputs();
             pipe_o.start_b();
             pipe_o.run(acc, 0, 32);
             HEAD_STAMP(4);
+            if (MODE != HEAD_DDPM) load_inputs();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 32 * w + frag_row(r, h);

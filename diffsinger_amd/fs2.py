@@ -481,9 +481,11 @@ def norm_f0(f0, uv, hp):
 
 def f0_to_coarse(f0):
     f0_mel = 1127 * (1 + f0 / 700).log()                                    # utils/pitch_utils.py:21-30
-    f0_mel[f0_mel > 0] = (f0_mel[f0_mel > 0] - f0_mel_min) * (f0_bin - 2) / (f0_mel_max - f0_mel_min) + 1
-    f0_mel[f0_mel <= 1] = 1
-    f0_mel[f0_mel > f0_bin - 1] = f0_bin - 1
+    # the reference's boolean-mask gather / scatter (`f0_mel[f0_mel > 0] = ...`) sizes a temporary from the mask - a device -> host
+    # synchronisation; torch.where evaluates the same expression element-wise (bit-identical) without one, so the forward is capturable
+    f0_mel = torch.where(f0_mel > 0, (f0_mel - f0_mel_min) * (f0_bin - 2) / (f0_mel_max - f0_mel_min) + 1, f0_mel)
+    f0_mel = torch.where(f0_mel <= 1, torch.ones_like(f0_mel), f0_mel)
+    f0_mel = torch.where(f0_mel > f0_bin - 1, torch.full_like(f0_mel, f0_bin - 1), f0_mel)
     return (f0_mel + 0.5).long()
 
 
