@@ -378,18 +378,6 @@ def main_train(args):
 
     el, loss = _row_time(step, args, world, device, dist)
     assert bool(torch.isfinite(loss)), 'non-finite loss'
-    # the same step (plus the re-pack of every weight a real training loop pays after each optimiser step) replayed as ONE hipGraph
-    from diffsinger_amd.train import GraphedTrainStep
-    hip_graph = None
-    try:
-        gstep = GraphedTrainStep(gd)
-        lg = gstep(x0, t, cond, noise)
-        el_g, lg = _row_time(lambda: gstep(x0, t, cond, noise), args, world, device, dist)
-        hip_graph = {'ms_per_step': el_g / args.steps * 1e3, 'value': world * B * T * args.steps / el_g, 'loss_equals_eager': float(lg) == float(loss),
-                     'note': 'zero_grad + p_losses + backward captured once and replayed as one hipGraph (diffsinger_amd.train.GraphedTrainStep), '
-                             'weight re-packs included; `value` above is the eager figure (packs cached: the weights do not change in this bench)'}
-    except Exception as e:                                    # report, do not hide
-        hip_graph = {'error': repr(e)[:300]}
     if rank == 0:
         # dominant kernel: k_fs_conv<2> as the dilated convolution (256 -> 512, k = 3), forward; one launch timed with events on the launch stream
         from diffsinger_amd.fs2 import PackedWeight, padded_frames
@@ -423,7 +411,7 @@ def main_train(args):
                'config': {'workload': f'SURVEY 8 row f3: GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:213-231) of the DiffSpeech denoiser, '
                                       f'batch={B} x T={T} per GPU, forward + backward on the HIP training operators', 'preset': PRESET,
                           'optimizer': 'not included (diffsinger_amd/train_dist.py)', 'sharding': 'replicas (no gradient exchange in this bench)'},
-               'roofline': roof, 'model_tflops_gemm': world * B * T * 3 * F_TRAIN_FWD * args.steps / el / 1e12, 'hipgraph_replay': hip_graph}
+               'roofline': roof, 'model_tflops_gemm': world * B * T * 3 * F_TRAIN_FWD * args.steps / el / 1e12}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline_train()
             res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']

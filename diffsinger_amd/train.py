@@ -247,64 +247,3 @@ def p_losses(gd, x_start: torch.Tensor, t: torch.Tensor, cond: torch.Tensor, noi
         return F.mse_loss(noise, x_recon)
     raise NotImplementedError(gd.loss_type)
 
-
-class GraphedTrainStep:
-    """zero_grad + `p_losses` forward + backward of the denoiser replayed as ONE hipGraph (torch.cuda.CUDAGraph).
-
-    The step is ~300 operator launches issued from Python (every Conv1d / Linear forward, data gradient, weight gradient, the fused
-    element-wise kernels, the weight re-packs a changed parameter needs): captured once per input signature, replayed without the
-    Python / ctypes issue cost.  What is captured is exactly what one eager step of a TRAINING LOOP enqueues - including the re-pack of
-    every weight into MFMA-fragment order (the packs are forced into the capture; parameters change between steps, the graph re-reads
-    them) - so optimiser steps may run between replays (eager: their bias corrections are host scalars).  Gradients land in static
-    `.grad` tensors: either the views an optimiser owns (ShardedAdamW's flat buffer: pass its `zero_grad`) or tensors allocated from the
-    graph's pool at capture.  Inputs are copied into static buffers; the returned loss is a static 0-d tensor."""
-
-    def __init__(self, gd, zero_grad=None, warmup: int = 2):
-        self.gd, self.zero_grad, self.warmup = gd, zero_grad, warmup
-        self._cache = {}
-
-    def _step(self, x0, t, cond, noise, nonpadding):
-        if self.zero_grad is not None:
-            self.zero_grad()
-        loss = self.gd.p_losses(x0, t, cond, noise=noise, nonpadding=nonpadding)
-        loss.backward()
-        return loss
-
-    def __call__(self, x_start, t, cond, noise, nonpadding=None):
-        from . import train_dist
-        args = (x_start, t, cond, noise, nonpadding)
-        key = tuple((tuple(a.shape), a.dtype, a.stride()) if a is not None else None for a in args)
-        ent = self._cache.get(key)
-        if ent is None:
-            dev = x_start.device
-            if dev.type != 'cuda':
-                raise RuntimeError('GraphedTrainStep: the HIP training path has no CPU path')
-            static = [a.clone(memory_format=torch.preserve_format) if a is not None else None for a in args]
-            if static[2] is not None and not cond.is_contiguous():       # keep the reference's transposed-view strides of cond
-                static[2] = torch.empty_strided(cond.shape, cond.stride(), device=dev, dtype=cond.dtype).copy_(cond)
-            params = [p for p in self.gd.denoise_fn.parameters() if p.requires_grad]
-            cur = torch.cuda.current_stream(dev)
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                for _ in range(self.warmup):
-                    if self.zero_grad is None:
-                        for p in params:
-                            p.grad = None
-                    self._step(*static)
-            cur.wait_stream(side)
-            torch.cuda.synchronize(dev)
-            if self.zero_grad is None:
-                for p in params:
-                    p.grad = None                                        # the capture allocates the static .grad tensors
-            train_dist._GENERATION += 1                                  # every packed-weight cache is stale: the packs become graph nodes
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                loss = self._step(*static)
-            ent = self._cache[key] = (g, static, loss)
-        g, static, loss = ent
-        for s_, a in zip(static, args):
-            if s_ is not None:
-                s_.copy_(a)
-        g.replay()
-        return loss

@@ -21,7 +21,6 @@ rm -rf $O/prof_lat
 cd $R
 timeout 200 python bench.py --row vocoder --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_vocoder_row.json 2> $O/bench_vocoder_row.err
 timeout 200 python bench.py --row fs2 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_fs2_row.json 2> $O/bench_fs2_row.err
-timeout 300 python bench.py --row train --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_train_row.json 2> $O/bench_train_row.err
 if [ "$2" != "quick" ]; then
 timeout 300 python bench.py --config 5 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg5_n1.json 2> $O/bench_cfg5_n1.err
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_torchrun_n1.json 2> $O/bench_torchrun_n1.err
@@ -39,4 +38,4 @@ fi
 cd $R
 du -sh $O
 tail -60 $O/pytest_gpu.txt | cut -c1-220; cut -c1-1800 $O/bench_n1.json; tail -3 $O/bench_n1.err; cat $O/loop_timeline.txt; cat $O/plms_diag.txt; cat $O/shape_sweep.jsonl; tail -3 $O/shape_sweep.err
-head -12 $O/latency_kernel_stats.txt | cut -c1-150; python -c "import json,sys; [print(f, json.load(open('$O/'+f)).get('hipgraph_replay'), json.load(open('$O/'+f))['ms_per_step']) for f in ('bench_vocoder_row.json','bench_fs2_row.json','bench_train_row.json')]"; tail -2 $O/bench_vocoder_row.err $O/bench_fs2_row.err; cut -c1-900 $O/bench_cfg5_n1.json; tail -3 $O/bench_cfg5_n1.err; cut -c1-400 $O/bench_torchrun_n1.json; tail -3 $O/bench_torchrun_n1.err; head -12 $O/bench_n1_kernel_stats.txt | cut -c1-160; cat $O/loop_pmc.txt | tail -12
+head -12 $O/latency_kernel_stats.txt | cut -c1-150; python -c "import json,sys; [print(f, json.load(open('$O/'+f)).get('hipgraph_replay'), json.load(open('$O/'+f))['ms_per_step']) for f in ('bench_vocoder_row.json','bench_fs2_row.json')]"; tail -2 $O/bench_vocoder_row.err $O/bench_fs2_row.err; cut -c1-900 $O/bench_cfg5_n1.json; tail -3 $O/bench_cfg5_n1.err; cut -c1-400 $O/bench_torchrun_n1.json; tail -3 $O/bench_torchrun_n1.err; head -12 $O/bench_n1_kernel_stats.txt | cut -c1-160; cat $O/loop_pmc.txt | tail -12
