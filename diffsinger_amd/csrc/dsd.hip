@@ -112,9 +112,6 @@ struct dsd_handle {
     int loop_mode = 2;
     int lat_req = -1;           // row split of the latency kernels: -1 by batch size, 0 never, 2 / 4 / 8 forced (env DSD_LAT_G)
     float* gbuf = nullptr;      // [ntiles][C][32] gate tiles between k_lat_conv and k_lat_out
-    bool lat_stack = true;      // latency path: the layer stack of an evaluation as ONE kernel (k_lat_stack); env DSD_LAT_STACK=0: two kernels per layer
-    unsigned* lat_cnt = nullptr;   // [2][ntiles] exchange counters of k_lat_stack + its sticky timeout word behind them
-    unsigned lat_epoch = 0;     // k_lat_stack launches enqueued since the counters were zeroed
     int n_cu = 0;               // workgroups that are certainly co-resident at 1 per CU
     struct LoopPlan { HeadParams* evals = nullptr; int* eval_t = nullptr; int n_evals = 0; };
     std::map<GraphKey, LoopPlan> plans;
@@ -184,7 +181,7 @@ static void drop_graphs(dsd_handle* h) {
 static void free_workspace(dsd_handle* h) {
     drop_graphs(h);
     dev_free(h->xa_base); dev_free(h->xb_base); dev_free(h->condT); dev_free(h->cp); dev_free(h->skip);
-    dev_free(h->xs); dev_free(h->xtmp); dev_free(h->gbuf); dev_free(h->lat_cnt);
+    dev_free(h->xs); dev_free(h->xtmp); dev_free(h->gbuf);
     for (auto& e : h->ering) dev_free(e);
     dev_free(h->t_dev); dev_free(h->coef_dev); dev_free(h->eps_tmp);
     dev_free(h->loop_flags); dev_free(h->loop_halo);
@@ -217,7 +214,6 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     h->nk_in = (cfg->mel_bins + 7) / 8;
     if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);                // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_LAT_G")) h->lat_req = std::atoi(ev);                 // developer switch (A/B timing)
-    if (const char* ev = std::getenv("DSD_LAT_STACK")) h->lat_stack = (std::atoi(ev) != 0);    // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_WT_STORES")) h->wt_stores = (std::atoi(ev) != 0);  // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
@@ -235,9 +231,6 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_layer<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>());
         (void)hipFuncSetAttribute((const void*)k_layer<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
-        (void)hipFuncSetAttribute((const void*)k_lat_stack<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatStackLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_lat_stack<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatStackLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_lat_stack<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatStackLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -502,8 +495,6 @@ extern "C" int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* con
         DSD_TRY(dev_alloc(h, &h->cp, (size_t)h->L * ntiles * 4096, true));
         DSD_TRY(dev_alloc(h, &h->skip, (size_t)ntiles * 2048, true));
         DSD_TRY(dev_alloc(h, &h->gbuf, (size_t)ntiles * kC * 32, true));
-        DSD_TRY(dev_alloc(h, &h->lat_cnt, (size_t)2 * ntiles + 64, true));
-        HIP_TRY(hipMemsetAsync(h->lat_cnt, 0, ((size_t)2 * ntiles + 64) * sizeof(unsigned), s));
         DSD_TRY(dev_alloc(h, &h->xs, (size_t)spec, true));
         DSD_TRY(dev_alloc(h, &h->xtmp, (size_t)spec, true));
         for (auto& e : h->ering) DSD_TRY(dev_alloc(h, &e, (size_t)spec, true));
@@ -606,43 +597,9 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
     return DSD_OK;
 }
 
-// Latency path, one kernel per evaluation: possible when every workgroup of the row-split grid gets a CU of its own (they wait for each other)
-static bool lat_stack_ok(const dsd_handle* h) {
-    const int G = lat_g(h);
-    return G > 0 && h->lat_stack && h->lat_cnt && (long long)h->ntiles * G <= h->n_cu && h->L <= 64;
-}
-
-// Start of a sampling call / single evaluation on the latency path: the exchange counters restart from zero
-static int lat_begin(dsd_handle* h, hipStream_t s) {
-    if (!lat_stack_ok(h)) return DSD_OK;
-    HIP_TRY(hipMemsetAsync(h->lat_cnt, 0, ((size_t)2 * h->ntiles + 64) * sizeof(unsigned), s));
-    h->lat_epoch = 0;
-    return DSD_OK;
-}
-
-template <int G>
-static void launch_lat_stack(const LatStackParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((k_lat_stack<G>), dim3((unsigned)lat_grid(p.ntiles, G)), dim3(kThreads), kLatStackLdsBytes, s, p);
-}
-
 // The L residual layers of one denoiser evaluation at step t (per-utterance steps: t_dev)
 static int launch_stack(dsd_handle* h, int t_uniform, const int* t_dev, hipStream_t s) {
-    if (!lat_stack_ok(h)) {
-        for (int l = 0; l < h->L; ++l) DSD_TRY(launch_layer(h, l, t_uniform, t_dev, s));
-        return DSD_OK;
-    }
-    LatStackParams q{};
-    q.xa = h->xa; q.xb = h->xb; q.gbuf = h->gbuf;
-    q.w1p = h->w1p; q.w2p = h->w2p; q.b2raw = h->b2raw;
-    q.cp = h->cp; q.cp_lstride = (size_t)h->ntiles * 4096;
-    q.skip = h->skip; q.ds_table = h->ds_table; q.t_dev = t_dev; q.t_uniform = t_uniform;
-    q.L = h->L; q.T = h->T; q.ntile32 = h->ntile32; q.ntiles = h->ntiles;
-    for (int l = 0; l < h->L; ++l) q.dil[l] = (unsigned char)h->dil[l];
-    q.xcnt = h->lat_cnt; q.gcnt = h->lat_cnt + h->ntiles; q.tmo = h->lat_cnt + 2 * h->ntiles;
-    q.epoch = h->lat_epoch++;
-    const int G = lat_g(h);
-    if (G == 8) launch_lat_stack<8>(q, s); else if (G == 4) launch_lat_stack<4>(q, s); else launch_lat_stack<2>(q, s);
-    HIP_TRY(hipGetLastError());
+    for (int l = 0; l < h->L; ++l) DSD_TRY(launch_layer(h, l, t_uniform, t_dev, s));
     return DSD_OK;
 }
 
@@ -699,7 +656,6 @@ extern "C" int dsd_denoise(dsd_handle* h, const float* x, const int32_t* t, floa
         DSD_TRY(pin_release(h, slot, s));
         t_dev = h->t_dev;
     }
-    DSD_TRY(lat_begin(h, s));
     DSD_TRY(launch_inproj(h, x, s));
     DSD_TRY(launch_stack(h, t[0], t_dev, s));
     HeadParams p = head_base(h);
@@ -748,7 +704,6 @@ extern "C" int dsd_denorm_spec(dsd_handle* h, const float* x, const float* mask,
 // Enqueue the whole DDPM loop on stream s, operating on the internal spec buffer h->xs.
 static int enqueue_ddpm(dsd_handle* h, int k_step, hipStream_t s) {
     const size_t bmt = (size_t)h->B * h->M * h->T;
-    DSD_TRY(lat_begin(h, s));
     DSD_TRY(launch_inproj(h, h->xs, s));
     for (int j = 0; j < k_step; ++j) {
         const int t = k_step - 1 - j;
@@ -775,7 +730,6 @@ static void plms_coef(const dsd_handle* h, int t, int interval, float* dA, float
 }
 
 static int enqueue_plms(dsd_handle* h, int k_step, int interval, hipStream_t s) {
-    DSD_TRY(lat_begin(h, s));
     DSD_TRY(launch_inproj(h, h->xs, s));
     int hist = 0;           // len(noise_list), capped at 3 for the formula choice
     int head_slot = 0;      // ring slot receiving the next stored eps
@@ -956,7 +910,7 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
     } else if (!h->use_graph) {
         DSD_TRY(kind == 0 ? enqueue_ddpm(h, k_step, s) : enqueue_plms(h, k_step, interval, s));
     } else {
-        const GraphKey key{kind, h->B, h->T, k_step, interval, layer_nb(h) + 100 * lat_g(h) + (lat_stack_ok(h) ? 10000 : 0)};
+        const GraphKey key{kind, h->B, h->T, k_step, interval, layer_nb(h) + 100 * lat_g(h)};
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -1085,12 +1039,12 @@ extern "C" int dsd_loop_launches(dsd_handle* h) {
 
 extern "C" int dsd_loop_timeouts(dsd_handle* h, void* stream) {
     if (!h) return fail(DSD_ERR_INVALID, "dsd_loop_timeouts: null handle");
-    unsigned v = 0, u = 0;
+    if (!h->loop_flags) return 0;
+    unsigned v = 0;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (h->loop_flags) HIP_TRY(hipMemcpy(&v, h->loop_flags + h->ntiles, sizeof v, hipMemcpyDeviceToHost));
-    if (h->lat_cnt && h->prepared) HIP_TRY(hipMemcpy(&u, h->lat_cnt + 2 * h->ntiles, sizeof u, hipMemcpyDeviceToHost));      // k_lat_stack's word
-    return (int)(v + u);
+    HIP_TRY(hipMemcpy(&v, h->loop_flags + h->ntiles, sizeof v, hipMemcpyDeviceToHost));
+    return (int)v;
 }
 
 // Debug hook: run the persistent DDPM loop once on the prepared batch (x, noise as for dsd_sample_ddpm) with per-wave shader-clock
@@ -1141,7 +1095,6 @@ extern "C" int dsd_p_sample(dsd_handle* h, float* x, const float* noise, int32_t
     hipLaunchKernelGGL(k_set_cell, dim3(1), dim3(1), 0, s, h->noise_cell, noise);
     if (!noise) hipLaunchKernelGGL(k_set_seed, dim3(1), dim3(1), 0, s, h->seed_cell, h->noise_seed);
     HIP_TRY(hipGetLastError());
-    DSD_TRY(lat_begin(h, s));
     DSD_TRY(launch_inproj(h, x, s));
     DSD_TRY(launch_stack(h, t, nullptr, s));
     HeadParams p = head_base(h);

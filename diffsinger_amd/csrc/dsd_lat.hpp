@@ -270,296 +270,4 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// k_lat_stack<G>: the 20 residual layers of ONE denoiser evaluation as one kernel (same row split, no kernel boundaries)
-// ------------------------------------------------------------------------------------------------------------
-// The two-kernel form above pays a launch ramp (~1.5-2 us: dispatch, cold L2 behind the boundary's write-back / invalidate, first-touch
-// of the weight stream) 40 times per evaluation for ~8 us of MFMA work per layer.  Here the G workgroups of a tile stay resident for the
-// whole layer stack and replace the boundary by the exchange protocol of the persistent loop (dsd_loop.hpp; MI355X_MICROARCH.md
-// "Inter-workgroup visibility"): producers store write-through (sc1), every storing wave drains, one barrier, ONE relaxed agent-scope
-// atomic add on the tile's counter; consumers poll the counters they depend on and read with sc1 loads.
-//   conv phase of layer l   needs x(l) of the own and the two neighbour tiles: xcnt[tile +- 1, tile] >= G * l increments (+ epoch base)
-//   out  phase of layer l   needs the G gate slices of the own tile:          gcnt[tile] >= G * (l + 1)
-// x ping-pongs between the two tile-major buffers exactly like the per-layer path (layer l reads xa for even l); the gate buffer is
-// single: a workgroup writes gate(l) only after xcnt[tile] says every workgroup of the tile finished reading gate(l - 1).  A workgroup
-// keeps what only it needs in registers across the layers: its x rows (the residual term) and its rows of the running skip sum, which
-// reach HBM once, at the end, in the fragment order k_head reads.  The weight stream of the NEXT phase is requested before the wait.
-// The counters are monotonic over the launches of one sampling call (`epoch` = index of the launch; the host zeroes them once per
-// call); all workgroups must be co-resident (ntiles * G <= CU count - the host falls back to the two-kernel form otherwise); every
-// spin is bounded and a timeout is sticky (p.tmo), as in k_loop.
-struct LatStackParams {
-    float* xa; float* xb;       // [tiles][C][32] tile-major, layer l reads (l & 1 ? xb : xa) and writes the other
-    float* gbuf;                // [tiles][C][32] gate tile
-    const float4* w1p;          // [L][w4][kc96][mb4][lane64]
-    const float4* w2p;          // [L][w4][kc32][mb4][lane64]
-    const float* b2raw;         // [L][2C]
-    const float4* cp;           // [L][tile][w4][mb4][q4][lane64]
-    size_t cp_lstride;          // float4 between layers
-    float4* skip;               // [tile][w4][mb2][q4][lane64] (out)
-    const float* ds_table;      // [t][L][C]
-    const int* t_dev;           // per-utterance step index, or nullptr -> t_uniform
-    int t_uniform;
-    int L, T, ntile32, ntiles;
-    unsigned char dil[64];
-    unsigned* xcnt;             // [ntiles]
-    unsigned* gcnt;             // [ntiles]
-    unsigned* tmo;              // sticky timeout word
-    unsigned epoch;             // launches of this sampling call before this one
-};
-
-constexpr int kLatStackLdsBytes = (kC * (32 + 2 * kHalo) + kC * 32 + 3 * 32 * 32) * (int)sizeof(float);   // y tile + gate tile + exchange blocks
-constexpr int kLatSpinLimit = 1 << 21;
-
-__device__ __forceinline__ void st16_sc1(float* base_uniform, int byte_off, const float4& v) {
-    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    const f32x4_ f = {v.x, v.y, v.z, v.w};
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7ffffff0, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, f), r, byte_off, 0, 16);       // aux 16 = sc1
-}
-__device__ __forceinline__ void st4_sc1(float* base_uniform, int byte_off, float v) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7ffffff0, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 16);
-}
-__device__ __forceinline__ float4 ld16_sc1g(const float* base_uniform, int byte_off) {
-    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base_uniform), 0, 0x7ffffff0, 0x00020000);
-    const f32x4_ f = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
-    return make_float4(f.x, f.y, f.z, f.w);
-}
-__device__ __forceinline__ float ld4_sc1g(const float* base_uniform, int byte_off) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base_uniform), 0, 0x7ffffff0, 0x00020000);
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));
-}
-
-template <int G>
-__global__ __launch_bounds__(kThreads, 1) void k_lat_stack(const LatStackParams p) {
-    static_assert(G == 2 || G == 4 || G == 8, "row split");
-    typedef __attribute__((address_space(1))) unsigned gu32_;
-    constexpr int LD = 32 + 2 * kHalo, TILE = kC * 32;
-    constexpr int NMB = (G == 2) ? 2 : 1;
-    constexpr int NCH1 = (G == 8) ? 48 : 96, NCH2 = (G == 8) ? 16 : 32;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ytile = smem;                    // [256][48]
-    float* gtile = smem + kC * LD;          // [256][32]
-    float* red = gtile + kC * 32;           // [3][32][32]
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile, g;
-    if (!lat_map<G>(p.ntiles, tile, g)) return;
-    const int b = tile / p.ntile32, tn = tile - b * p.ntile32, t0 = tn * 32;
-    const bool has_left = tn > 0, has_right = tn + 1 < p.ntile32;
-    const int T = p.T;
-    const int tstep = p.t_dev ? p.t_dev[b] : p.t_uniform;
-    const unsigned base = p.epoch * (unsigned)(G * p.L);
-
-    // roles (as in k_lat_conv / k_lat_out)
-    int w4, mb1, kbeg1, mb2, kbeg2;
-    if (G == 2) { w4 = 2 * g + (wv >> 1); mb1 = mb2 = wv & 1; kbeg1 = kbeg2 = 0; }
-    else if (G == 4) { w4 = g; mb1 = mb2 = wv; kbeg1 = kbeg2 = 0; }
-    else { w4 = g >> 1; mb1 = mb2 = (g & 1) + 2 * (wv & 1); kbeg1 = 48 * (wv >> 1); kbeg2 = 16 * (wv >> 1); }
-    const bool conv_filter = (G == 4) ? (wv >= 2) : (G == 8 ? wv == 1 : false);
-    const bool conv_gate = (G == 4) ? (wv < 2) : (G == 8 ? wv == 0 : true);
-    const bool out_res = (G == 2) ? true : (G == 4 ? wv < 2 : wv == 0);          // this wave finishes a residual block
-    const bool out_skip = (G == 2) ? true : (G == 4 ? wv >= 2 : wv == 1);        // ... a skip block
-
-    auto timed_out = [&]() -> bool { return __hip_atomic_load((gu32_*)p.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; };
-    // wait until counter[tile + k - 1] >= target for the valid k in {0, 1, 2} (lanes 0..2 of wave 0 poll), then a barrier
-    auto wait_tiles = [&](const unsigned* cnt, unsigned target, bool neighbours) {
-        if (wv == 0 && lane < 3) {
-            const bool have = (lane == 1) || (neighbours && (lane == 0 ? has_left : has_right));
-            if (have) {
-                const gu32_* f = (const gu32_*)(cnt + tile + (lane - 1));
-                for (int spins = 0;; ++spins) {
-                    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-                    if ((spins & 255) == 255 && timed_out()) break;
-                    if (spins >= kLatSpinLimit) { __hip_atomic_store((gu32_*)p.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-        }
-        __syncthreads();
-    };
-    // every store of this phase has left the CU (write-through + drained), then one relaxed agent-scope increment of the tile's counter
-    auto signal = [&](unsigned* cnt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add((gu32_*)(cnt + tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-
-    // state kept in registers across the layers: this wave's x rows (residual term) and its skip rows, accumulator-fragment order
-    float xres[16];
-    float4 skp[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) skp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-        const float* x0 = p.xa + (size_t)tile * TILE;           // layer 0's input: written by the previous kernel (k_inproj / k_head)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xres[r] = out_res ? x0[(64 * w4 + 32 * (mb2 & 1) + frag_row(r, h)) * 32 + j] : 0.f;
-    }
-    constexpr float kInvSqrt2 = 1.0f / 1.41421354f;
-
-    for (int l = 0; l < p.L; ++l) {
-        const bool last = (l == p.L - 1);
-        const int dil = p.dil[l];
-        const float* xin = (l & 1) ? p.xb : p.xa;
-        float* xout = (l & 1) ? p.xa : p.xb;
-        const float* __restrict__ dsl = p.ds_table + ((size_t)tstep * p.L + l) * kC;
-
-        // ---------------- conv phase ----------------
-        const ConvB<LD> bof1{ytile + 4 * h * LD + kHalo + j, dil, kbeg1};
-        GemmPipe<NMB, 1, LD, 256, 6, ConvB<LD>, 2> pipe1(p.w1p + ((size_t)l * 4 + w4) * (96 * 256) + (size_t)kbeg1 * 256 + mb1 * 64, lane, NCH1, bof1);
-        pipe1.start_a();
-        if (l > 0) wait_tiles(p.xcnt, base + (unsigned)(G * l), true);
-        {
-            const float* xt = xin + (size_t)tile * TILE;
-            float4 xv[8], hv[4];
-#pragma unroll
-            for (int it = 0; it < 8; ++it) xv[it] = ld16_sc1g(xt, (it * kThreads + tid) * 16);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                hv[q] = has_left ? ld16_sc1g(xt - TILE, (tid * 32 + 24 + 4 * q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                hv[2 + q] = has_right ? ld16_sc1g(xt + TILE, (tid * 32 + 4 * q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 32 + (tid >> 3), c4 = tid & 7, t = t0 + 4 * c4;
-                const float d = dsl[row];
-                float4 v = xv[it];
-                v.x = (t + 0 < T) ? v.x + d : 0.f;
-                v.y = (t + 1 < T) ? v.y + d : 0.f;
-                v.z = (t + 2 < T) ? v.z + d : 0.f;
-                v.w = (t + 3 < T) ? v.w + d : 0.f;
-                *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 4 * c4) = v;
-            }
-            const float d = dsl[tid];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool right = q >= 2, have = right ? has_right : has_left;
-                const int t = right ? t0 + 32 + 4 * (q - 2) : t0 - kHalo + 4 * q;
-                float4 v = hv[q];
-                v.x = (have && t + 0 < T) ? v.x + d : 0.f;
-                v.y = (have && t + 1 < T) ? v.y + d : 0.f;
-                v.z = (have && t + 2 < T) ? v.z + d : 0.f;
-                v.w = (have && t + 3 < T) ? v.w + d : 0.f;
-                *reinterpret_cast<float4*>(ytile + tid * LD + (right ? kHalo + 32 + 4 * (q - 2) : 4 * q)) = v;
-            }
-        }
-        __syncthreads();
-        f32x16 acc[NMB][1];
-#pragma unroll
-        for (int m = 0; m < NMB; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
-        pipe1.start_b();
-        pipe1.run(acc, 0, NCH1);
-
-        // the output projection's weight stream: requested before the gate arithmetic and the exchange
-        const float* gl = gtile + kbeg2 * (8 * 32) + 4 * h * 32 + j;
-        GemmPipe<NMB, 1, 32, 256, 6, TileB, 2> pipe2(p.w2p + ((size_t)l * 4 + w4) * (32 * 256) + (size_t)kbeg2 * 256 + mb2 * 64, lane, NCH2,
-                                                     TileB{gl, 8 * 32, NCH2});
-        const bool out_active = (G == 2) || !(last && mb2 < 2);
-        if (out_active) pipe2.start_a();
-
-        const float4* cpl = p.cp + (size_t)l * p.cp_lstride + ((size_t)tile * 4 + w4) * (4 * 4 * 64) + lane;
-        float* gout = p.gbuf + (size_t)tile * TILE;
-        if (G == 2) {
-            float4 cg[4], cf[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { cg[q] = cpl[(mb1 * 4 + q) * 64]; cf[q] = cpl[((mb1 + 2) * 4 + q) * 64]; }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float gv = sigmoid_f(acc[0][0][r] + f4at(cg[r >> 2], r & 3)) * tanh_f(acc[NMB - 1][0][r] + f4at(cf[r >> 2], r & 3));
-                st4_sc1(gout, ((64 * w4 + 32 * mb1 + frag_row(r, h)) * 32 + j) * 4, gv);
-            }
-        } else {
-            float4 cv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cv[q] = cpl[(mb1 * 4 + q) * 64];
-            if (G == 8) {
-                float* part = red + (wv & 1) * 1024;
-                if (wv >= 2) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) part[frag_row(r, h) * 32 + j] = acc[0][0][r];
-                }
-                __syncthreads();
-                if (wv < 2) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][0][r] + part[frag_row(r, h) * 32 + j];
-                }
-            }
-            float* fx = (G == 4) ? red + (wv & 1) * 1024 : red + 2048;
-            if (conv_filter) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) fx[frag_row(r, h) * 32 + j] = tanh_f(acc[0][0][r] + f4at(cv[r >> 2], r & 3));
-            }
-            __syncthreads();
-            if (conv_gate) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float gv = sigmoid_f(acc[0][0][r] + f4at(cv[r >> 2], r & 3)) * fx[frag_row(r, h) * 32 + j];
-                    st4_sc1(gout, ((64 * w4 + 32 * mb1 + frag_row(r, h)) * 32 + j) * 4, gv);
-                }
-            }
-        }
-        signal(p.gcnt);
-
-        // ---------------- output-projection phase ----------------
-        wait_tiles(p.gcnt, base + (unsigned)(G * (l + 1)), false);
-        {
-            float4 v[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it) v[it] = ld16_sc1g(gout, (it * kThreads + tid) * 16);
-#pragma unroll
-            for (int it = 0; it < 8; ++it) reinterpret_cast<float4*>(gtile)[it * kThreads + tid] = v[it];
-        }
-        __syncthreads();
-        f32x16 acc2[NMB][1];
-#pragma unroll
-        for (int m = 0; m < NMB; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[m][0][r] = 0.f;
-        if (out_active) {
-            pipe2.start_b();
-            pipe2.run(acc2, 0, NCH2);
-        }
-        if (G == 8) {
-            float* part = red + (wv & 1) * 1024;
-            if (out_active && wv >= 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) part[frag_row(r, h) * 32 + j] = acc2[0][0][r];
-            }
-            __syncthreads();
-            if (out_active && wv < 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[0][0][r] = acc2[0][0][r] + part[frag_row(r, h) * 32 + j];
-            }
-        }
-        if (out_res && !last) {
-            // x' = (x + (res + b)) / sqrt(2): kept in registers for the next layer's residual term, published for everybody's conv
-            float* xo = xout + (size_t)tile * TILE;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 64 * w4 + 32 * (mb2 & 1) + frag_row(r, h);
-                const float bv = p.b2raw[(size_t)l * 2 * kC + row];
-                xres[r] = (xres[r] + (acc2[0][0][r] + bv)) * kInvSqrt2;
-                st4_sc1(xo, (row * 32 + j) * 4, xres[r]);
-            }
-        }
-        if (out_skip) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 a = get4(acc2[NMB - 1][0], q), sk = skp[q];
-                skp[q] = (l == 0) ? a : make_float4(a.x + sk.x, a.y + sk.y, a.z + sk.z, a.w + sk.w);
-            }
-        }
-        signal(p.xcnt);
-    }
-    if (out_skip) {
-        float4* sl = p.skip + (((size_t)tile * 4 + w4) * 2 + (mb2 & 1)) * (4 * 64) + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sl[q * 64] = skp[q];
-    }
-}
-
 }  // namespace dsd
