@@ -58,31 +58,6 @@ __device__ __forceinline__ bool lat_map(int ntiles, int& tile, int& g) {
 }
 __host__ __device__ inline int lat_grid(int ntiles, int G) { return (ntiles + 7) / 8 * 8 * G; }
 
-// L2 warm-up of a wave's weight slice: `nchunk` fragments of `nline` 128-byte lines each (chunk stride 4 KiB), one dword per line, issued
-// at kernel start and consumed (lat_touch_done) behind the staging barrier.  With one row block per wave a chunk is only 4 MFMAs (256
-// cycles), so the 5-chunk register prefetch of GemmPipe covers ~1.3 k cycles - enough for an L2 hit, not for the first touch of a
-// line (Infinity Cache / HBM, every layer's weights are new to the L2 in every evaluation).  The touches cost nchunk * nline / 64
-// load instructions per lane and no issue slot inside the MFMA loop.
-template <int NT>
-struct LatTouch {
-    unsigned v[NT];
-    __device__ __forceinline__ void issue(const float4* base_uniform, int lane, int nchunk, int nline) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(base_uniform), 0, 0x7ffffff0, 0x00020000);
-        const int per = 64 / nline;             // chunks covered by one instruction
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int kc = lane / nline + per * i;
-            v[i] = 0u;
-            if (kc < nchunk) v[i] = __builtin_amdgcn_raw_buffer_load_b32(r, kc * 4096 + (lane % nline) * 128, 0, 0);
-        }
-        DSD_SB();
-    }
-    __device__ __forceinline__ void done() {
-#pragma unroll
-        for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(v[i]));
-    }
-};
-
 template <int G>
 __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
     static_assert(G == 2 || G == 4 || G == 8, "row split");
@@ -108,13 +83,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
 
     // the weight stream does not depend on x: its first chunks are requested before the tile is staged
     const ConvB<LD> bof{ytile + 4 * h * LD + kHalo + j, dil, kbeg};
-    const float4* abase = p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64;
-    GemmPipe<NMB, 1, LD, 256, 6, ConvB<LD>, 2> pipe(abase, lane, NCH, bof);
+    GemmPipe<NMB, 1, LD, 256, 6, ConvB<LD>, 2> pipe(p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, bof);
     pipe.start_a();
-    // warm the L2 with the rest of this wave's weight slice (NMB = 2: the second row block sits 2 KiB behind the first)
-    LatTouch<NCH / 8> touch, touch2;
-    touch.issue(abase, lane, NCH, 8);
-    if (NMB == 2) touch2.issue(abase + 128, lane, NCH, 8);
 
     // stage y = x + step_proj (zero at frames outside [0, T): the conv's zero padding applies to y, net.py:69-71)
     const int tstep = p.t_dev ? p.t_dev[b] : p.t_uniform;
@@ -155,8 +125,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
         }
     }
     __syncthreads();
-    touch.done();
-    if (NMB == 2) touch2.done();
 
     f32x16 acc[NMB][1];
 #pragma unroll
@@ -239,14 +207,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
     const bool active = (G == 2) || !(p.last && mb0 < 2);
 
     const float* gl = gtile + kbeg * (8 * 32) + 4 * h * 32 + j;
-    const float4* abase = p.w2p + (size_t)w4 * (32 * 256) + (size_t)kbeg * 256 + mb0 * 64;
-    GemmPipe<NMB, 1, 32, 256, 6, TileB, 2> pipe(abase, lane, NCH, TileB{gl, 8 * 32, NCH});
-    LatTouch<NCH / 8> touch, touch2;
-    if (active) {
-        pipe.start_a();
-        touch.issue(abase, lane, NCH, 8);
-        if (NMB == 2) touch2.issue(abase + 128, lane, NCH, 8);
-    }
+    GemmPipe<NMB, 1, 32, 256, 6, TileB, 2> pipe(p.w2p + (size_t)w4 * (32 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, TileB{gl, 8 * 32, NCH});
+    if (active) pipe.start_a();
 
     {
         const float4* src = reinterpret_cast<const float4*>(p.gbuf + (size_t)tile * TILE);
@@ -257,10 +219,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
         for (int it = 0; it < 8; ++it) reinterpret_cast<float4*>(gtile)[it * kThreads + tid] = v[it];
     }
     __syncthreads();
-    if (active) {
-        touch.done();
-        if (NMB == 2) touch2.done();
-    }
 
     f32x16 acc[NMB][1];
 #pragma unroll
