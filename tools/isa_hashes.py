@@ -44,7 +44,7 @@ def kernel_hashes():
 if __name__ == '__main__':
     h = kernel_hashes()
     if '--update' in sys.argv:
-        keep = [k for k in sorted(h) if not re.search(os.environ.get('DSD_ISA_UNVERIFIED', r'k_lat_'), k)]     # kernels not yet run on hardware
+        keep = [k for k in sorted(h) if not re.search(os.environ.get('DSD_ISA_UNVERIFIED', r'^$'), k)]     # kernels not yet run on hardware
         json.dump({'note': 'sha1 of the normalised gfx950 assembly of every kernel that has run (and passed its parity tests) on the MI355X; '
                            'tools/isa_hashes.py --update after a GPU run', 'kernels': {k: h[k] for k in keep}}, open(GOLDEN, 'w'), indent=1)
         print(f'{len(keep)} kernels written to {GOLDEN} ({len(h) - len(keep)} not-yet-run kernels left out)')
