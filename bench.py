@@ -714,6 +714,17 @@ def main_path(args):
                          'peak / 6 in fp32-equivalent FLOPs')
             ref_acc = frames * F_LAYER_REF / (ms * 1e-3) / 1e12
             frames_k = frames
+        if persistent:
+            # where a launch spends its time: in-kernel s_memtime stamps of one layer phase and one head (tools/loop_timeline.py, same shape)
+            try:
+                tl = json.load(open(os.path.join(ROOT, 'profiles', 'loop_timeline.json')))
+                ph, hd = tl['phase_cycles_mean'], tl['head_cycles_mean']
+                share = L_LAYERS * ph / (L_LAYERS * ph + hd)
+                note += (f'; per evaluation {L_LAYERS} layer phases of {ph:.0f} cycles ({tl["mfma_issue_ideal_per_phase"]} of MFMA issue) + a head of {hd:.0f} '
+                         f'cycles -> layers_ms {ms * share:.2f}, head_ms {ms * (1 - share):.2f} of this launch (profiles/loop_timeline.json, '
+                         f'round {tl.get("round", "?")})')
+            except Exception:
+                pass
         traffic, traffic_src = pmc_traffic(kname, frames_k)
         peak = 2500.0 / 6 if args.split else PEAK_FP32_MFMA_TFLOPS
         roof = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': peak,

@@ -393,8 +393,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             for (int q = 0; q < 4; ++q) set4(acc[0][0], q, p.head.boutp[(w * 2 + h) * 4 + q]);
             const int t = t0 + j;
             // sampler arithmetic (p_sample :134-166 / p_sample_plms :168-204).  All global reads of the 16 elements are issued
-            // first, in front of the final projection (one workgroup per CU: nothing else would hide their latency), then the GEMM,
-            // then the element-wise math, then the stores.
+            // first (one workgroup per CU: nothing else would hide their latency), then the element-wise math, then the stores.
             size_t idxs[16];
             bool oks[16];
             float xv[16], av[16], bv[16], cv[16];
@@ -421,13 +420,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     }
                 }
             };
-            // DDPM: the reads go in front of the final projection.  PLMS keeps them behind it (r02d: the hoisted PLMS epilogue differed from
-            // the per-layer path on the hardware; PLMS loops are 5-26 evaluations long, the reads' latency is irrelevant there)
-            if (MODE == HEAD_DDPM) load_inputs();
+            // (Issuing these reads in FRONT of the final projection was tried in round 2: vmcnt counts in order, so the GEMM's own
+            // operand waits then cover the 32 cold reads as well - the projection went from 9.3 k to 17.3 k cycles for 4 k saved here,
+            // profiles/r02e_loop_timeline.txt - and the PLMS variant stopped matching the per-layer path.  They stay behind it.)
             pipe_o.start_b();
             pipe_o.run(acc, 0, 32);
             HEAD_STAMP(4);
-            if (MODE != HEAD_DDPM) load_inputs();
+            load_inputs();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 32 * w + frag_row(r, h);

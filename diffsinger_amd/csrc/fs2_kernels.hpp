@@ -76,6 +76,13 @@ __global__ __launch_bounds__(kThreads, NMB == 4 ? 1 : 2) void k_fs_conv(const Fs
     const float* inb = p.in + (size_t)b * p.Ci * p.TS;
     for (int c0 = 0; c0 < p.Ci; c0 += kFsSlab) {
         const int nc = min(kFsSlab, p.Ci - c0);
+        // the weight stream does not depend on the slab: its first chunks are requested BEFORE the slab is staged, so that their first-touch
+        // latency (every workgroup of a launch walks the stream in lock-step: each chunk is new to the L2) overlaps the staging loads
+        const int nch = (nc / 8) * p.KT;
+        const float4* ap = p.wp + (((size_t)mt * 4 + w) * nchunk_total + (size_t)(c0 / 8) * p.KT) * (NMB * 64);
+        const FsTapB bof{smem + 4 * h * kFsLD + kFsHalo + j - p.pad, p.KT, p.dil, nch};
+        GemmPipe<NMB, 1, kFsLD, NMB * 64, 6, FsTapB> pipe(ap, lane, nch, bof);
+        pipe.start_a();
         // stage channels [c0, c0 + nc) x frames [t0 - 8, t0 + 40): 12 float4 per row, zero outside [0, TS)
         for (int idx = tid; idx < nc * (kFsLD / 4); idx += kThreads) {
             const int row = idx / (kFsLD / 4), g = idx - row * (kFsLD / 4);
@@ -85,10 +92,8 @@ __global__ __launch_bounds__(kThreads, NMB == 4 ? 1 : 2) void k_fs_conv(const Fs
             *reinterpret_cast<float4*>(smem + row * kFsLD + 4 * g) = v;
         }
         __syncthreads();
-        const int nch = (nc / 8) * p.KT;
-        const float4* ap = p.wp + (((size_t)mt * 4 + w) * nchunk_total + (size_t)(c0 / 8) * p.KT) * (NMB * 64);
-        const FsTapB bof{smem + 4 * h * kFsLD + kFsHalo + j - p.pad, p.KT, p.dil, nch};
-        gemm_k<NMB, 1, kFsLD, NMB * 64>(acc, ap, lane, nch, bof);
+        pipe.start_b();
+        pipe.run(acc, 0, nch);
         __syncthreads();
     }
     const int t = t0 + j;

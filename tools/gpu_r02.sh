@@ -11,7 +11,7 @@ cd $R
 HEAD=$(cat gpurun_head.txt 2>/dev/null || echo unknown)
 timeout 1500 python -m pytest tests -m gpu -q -rf 2>&1 | tail -150 > $O/pytest_gpu.txt
 timeout 600 python bench.py --steps 5 --warmup 2 > $O/bench_n1.json 2> $O/bench_n1.err
-timeout 200 python tools/loop_timeline.py > $O/loop_timeline.txt 2>&1
+timeout 200 python tools/loop_timeline.py $O/loop_timeline.json > $O/loop_timeline.txt 2>&1
 timeout 100 python tools/plms_diag.py > $O/plms_diag.txt 2>&1
 timeout 400 python tools/shape_sweep.py 2 > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
 cd /tmp

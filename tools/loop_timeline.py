@@ -12,6 +12,7 @@ x = torch.randn(B, 80, T, device=dev, generator=g)
 noise = torch.randn(K, B, 80, T, device=dev, generator=g)
 eng = gd._engine(cond)
 eng.set_loop_mode(1)
+summary = {'phase_cycles': [], 'head_cycles': [], 'mfma_issue_ideal_per_phase': 2048 * 64}
 for phase in (43, 44, 63):
     ts = eng.loop_timeline(x.clone(), noise, K, phase).astype(np.int64)
     d = np.diff(ts[:, :, :8], axis=2)
@@ -22,6 +23,7 @@ for phase in (43, 44, 63):
     for i, n in enumerate(names):
         print('  %-76s: mean %8.0f  min %8.0f  max %8.0f' % (n, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max()))
     print('  phase total: mean %.0f ; start skew across workgroups %.0f' % ((ts[:, :, 7] - ts[:, :, 0]).mean(), ts[:, :, 0].max() - ts[:, :, 0].min()))
+    summary['phase_cycles'].append(float((ts[:, :, 7] - ts[:, :, 0]).mean()))
     hd = ts[:, :, 8:16]
     hn = ['barrier behind the last layer + skip tile (bias, / sqrt(L), stage)', 'skip projection K=256 (2 row blocks / wave) + ReLU tile',
           'final-projection weight prefetch + barrier', 'final projection K=256 (waves 0-2)', 'sampler update: global reads, math, stores (waves 0-2)',
@@ -33,4 +35,11 @@ for phase in (43, 44, 63):
         dd = hd[:, sel, i + 1] - a0 if i != 5 else hd[:, :3, i + 1] - a0
         print('    %-66s: mean %8.0f  min %8.0f  max %8.0f' % (n, dd.mean(), dd.min(), dd.max()))
     print('    head total (last layer done -> next evaluation\'s x published): mean %.0f' % (hd[:, :, 7] - hd[:, :, 0]).mean())
+    summary['head_cycles'].append(float((hd[:, :, 7] - hd[:, :, 0]).mean()))
 print('timeouts', eng.loop_timeouts())
+if len(sys.argv) > 1:
+    import json
+    summary['phase_cycles_mean'] = sum(summary['phase_cycles']) / len(summary['phase_cycles'])
+    summary['head_cycles_mean'] = sum(summary['head_cycles']) / len(summary['head_cycles'])
+    summary['shape'] = {'B': B, 'T': T, 'layers': 20}
+    json.dump(summary, open(sys.argv[1], 'w'), indent=1)
