@@ -100,13 +100,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
     for (int c0 = 0; c0 < p.Ci; c0 += SLAB) {
         const int nc = min(SLAB, p.Ci - c0);
         const int nc8 = (nc + 7) / 8 * 8;                            // rows [nc, nc8) are staged as zeros (their weights are zero too)
-        // the weight stream does not depend on the slab: its first chunks are requested before the slab is staged (first-touch latency
-        // under the staging loads; a launch is ONE wave of workgroups walking the stream in lock-step)
-        const int nch = (nc8 / 8) * p.KT;
-        const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
-        const VocTapB<LD> bof{smem + 4 * h * LD + kVocHalo + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch};
-        GemmPipe<1, NB, LD, 64, 6, VocTapB<LD>> pipe(ap, lane, nch, bof);
-        pipe.start_a();
         // stage channels [c0, c0 + nc) x samples [t0 - halo, t0 + SPAN + halo), zero outside [0, LSi), leaky_relu applied here
         for (int idx = tid; idx < nc8 * NCOL4; idx += kThreads) {
             const int row = idx / NCOL4, g = idx - row * NCOL4;
@@ -119,8 +112,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
             *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
         }
         __syncthreads();
-        pipe.start_b();
-        pipe.run(acc, 0, nch);
+        const int nch = (nc8 / 8) * p.KT;
+        const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
+        const VocTapB<LD> bof{smem + 4 * h * LD + kVocHalo + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch};
+        gemm_k<1, NB, LD, 64>(acc, ap, lane, nch, bof);
         __syncthreads();
     }
     if (rb >= nrb) return;
