@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
     // wave drained, barrier, ONE relaxed agent-scope flag store.  Called as soon as x is known (behind the residual transpose of a
     // layer / behind the input projection); the skip-sum update, the next phase's weight prefetch and own-column staging
     // overlap the hop.
-    auto publish = [&](unsigned phase) {
+    auto publish_issue = [&](unsigned phase) {
         float* hb = p.halo + ((size_t)(phase & 1) * p.ntiles_total + tile) * (2 * kC * 8);
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
         typedef float f32x4_ __attribute__((ext_vector_type(4)));
@@ -124,10 +124,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, f), r, ((side * kC + xrow0 + 8 * it) * 8 + 4 * c) * 4, 0, 16);
             }
         }
+    };
+    auto publish_finish = [&](unsigned phase) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store((gu32*)(p.flags + tile), phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    auto publish = [&](unsigned phase) { publish_issue(phase); publish_finish(phase); };
     // debug stamps go straight to memory (held in registers they would cost 20 VGPRs for the whole kernel)
     const bool stamp = p.dbg != nullptr;
 #define LOOP_STAMP(i) do { if (stamp && ph == (unsigned)p.dbg_phase && lane == 0) p.dbg[((size_t)tl * 4 + w) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -164,10 +167,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             }
             __syncthreads();
             LOOP_STAMP(1);
+            // (d1) EVERY wave reads the two neighbour flags now (lanes 0 / 1), without waiting: the value returns under the first chunks
+            //      and is tested behind chunk 12.  The neighbours published at the end of their previous phase, so it is normally current
+            //      already - no poll round trip with the matrix pipe idle, and, every wave having seen the flags itself, no barrier
+            //      between the test and the halo loads.
+            unsigned fv = 0xffffffffu;
+            if (lane < 2) {
+                const bool have = lane ? has_right : has_left;
+                if (have) fv = __hip_atomic_load((const gu32*)(p.flags + tile + (lane ? 1 : -1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            DSD_SB();
 
             // (g) dilated conv, K = 768 (one contraction, taps are column offsets).  The exchange with the neighbour tiles runs UNDER
-            //     the centre-tap chunks: flags polled behind chunk 12 (the neighbours published at the end of their previous phase:
-            //     normally long satisfied), their columns requested and in flight during chunks 12..29, written to the y tile in front
+            //     the centre-tap chunks: flags read at chunk 0 and tested behind chunk 12 (the neighbours published at the end of their
+            //     previous phase), their columns requested and in flight during chunks 12..29, written to the y tile in front
             //     of chunk 30; the outer taps (chunks >= 32) are the first to read them.  The hoisted conditioner projection is
             //     fetched half way.
             f32x16 acc[4][1];
@@ -178,20 +191,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             float4 cpv[4][4];
             pipe1.start_b();
             pipe1.run(acc, 0, 12);
-            // (d) both neighbours have published phase ph?
-            if (w == 0 && lane < 2) {
-                const bool have = lane ? has_right : has_left;
-                if (have) {
-                    const gu32* f = (const gu32*)(p.flags + tile + (lane ? 1 : -1));
-                    for (int spins = 0;; ++spins) {
-                        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ph + 1u) break;
-                        if ((spins & 255) == 255 && timed_out()) break;
-                        if (spins >= kLoopSpinLimit) { __hip_atomic_store((gu32*)p.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
+            // (d2) both neighbours have published phase ph?  Lanes whose early read was too early poll (bounded, sticky timeout)
+            if (fv < ph + 1u) {
+                const gu32* f = (const gu32*)(p.flags + tile + (lane ? 1 : -1));
+                for (int spins = 0;; ++spins) {
+                    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ph + 1u) break;
+                    if ((spins & 255) == 255 && timed_out()) break;
+                    if (spins >= kLoopSpinLimit) { __hip_atomic_store((gu32*)p.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
             }
-            __syncthreads();
             // (e1) request the neighbours' columns (thread = channel row; sc1 loads: the producer stored write-through)
             float4 hv[2][2];
             {
@@ -307,8 +316,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     xreg[it] = o;
                 }
                 LOOP_STAMP(6);
-                dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barrier inside publish()
-                publish(ph + 1u);
+                dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barrier inside publish_finish()
+                publish_issue(ph + 1u);                             // the halo stores drain while the skip sum is updated
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -316,6 +325,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                         const float4 a = get4(acc2[2 + ms][0], q), s = skp[ms][q];
                         skp[ms][q] = (l == 0) ? a : make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
                     }
+                publish_finish(ph + 1u);
                 LOOP_STAMP(7);
             } else {
                 // last layer: only the skip half (net.py:126 reads the skips; the residual is dead)
@@ -391,9 +401,15 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             f32x16 acc[1][1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) set4(acc[0][0], q, p.head.boutp[(w * 2 + h) * 4 + q]);
+            pipe_o.start_b();
+            pipe_o.run(acc, 0, 32);
+            HEAD_STAMP(4);
             const int t = t0 + j;
             // sampler arithmetic (p_sample :134-166 / p_sample_plms :168-204).  All global reads of the 16 elements are issued
             // first (one workgroup per CU: nothing else would hide their latency), then the element-wise math, then the stores.
+            // (Issuing the reads in FRONT of the final projection was tried in round 2: vmcnt counts in order, so the GEMM's operand
+            // waits then cover the 32 cold reads too - the projection went from 9.3 k to 17.3 k cycles for 4 k saved here,
+            // profiles/r02e_loop_timeline.txt.)
             size_t idxs[16];
             bool oks[16];
             float xv[16], av[16], bv[16], cv[16];
@@ -403,30 +419,21 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 nz = *hp.noise_cell;
                 if (nz) nz += hp.noise_off; else seed = *hp.seed_cell;
             }
-            auto load_inputs = [&]() {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = 32 * w + frag_row(r, h);
-                    oks[r] = (m < M) && (t < T);
-                    idxs[r] = oks[r] ? ((size_t)b * M + m) * T + t : 0;
-                    xv[r] = hp.x_base[idxs[r]];
-                    av[r] = bv[r] = cv[r] = 0.f;
-                    if (MODE == HEAD_DDPM) {
-                        av[r] = nz ? nz[idxs[r]] : philox_normal(seed, hp.step_id, idxs[r]);
-                    } else {
-                        if (hp.order >= PLMS_HEUN) av[r] = hp.e1[idxs[r]];
-                        if (hp.order >= PLMS_AB3) bv[r] = hp.e2[idxs[r]];
-                        if (hp.order >= PLMS_AB4) cv[r] = hp.e3[idxs[r]];
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * w + frag_row(r, h);
+                oks[r] = (m < M) && (t < T);
+                idxs[r] = oks[r] ? ((size_t)b * M + m) * T + t : 0;
+                xv[r] = hp.x_base[idxs[r]];
+                av[r] = bv[r] = cv[r] = 0.f;
+                if (MODE == HEAD_DDPM) {
+                    av[r] = nz ? nz[idxs[r]] : philox_normal(seed, hp.step_id, idxs[r]);
+                } else {
+                    if (hp.order >= PLMS_HEUN) av[r] = hp.e1[idxs[r]];
+                    if (hp.order >= PLMS_AB3) bv[r] = hp.e2[idxs[r]];
+                    if (hp.order >= PLMS_AB4) cv[r] = hp.e3[idxs[r]];
                 }
-            };
-            // (Issuing these reads in FRONT of the final projection was tried in round 2: vmcnt counts in order, so the GEMM's own
-            // operand waits then cover the 32 cold reads as well - the projection went from 9.3 k to 17.3 k cycles for 4 k saved here,
-            // profiles/r02e_loop_timeline.txt - and the PLMS variant stopped matching the per-layer path.  They stay behind it.)
-            pipe_o.start_b();
-            pipe_o.run(acc, 0, 32);
-            HEAD_STAMP(4);
-            load_inputs();
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 32 * w + frag_row(r, h);
