@@ -1229,4 +1229,5 @@ extern "C" int dsd_debug_layer_timeline(dsd_handle* h, int32_t layer, int32_t t,
 }
 
 #include "fs2_abi.hpp"
+#include "train_abi.hpp"
 #include "voc_abi.hpp"

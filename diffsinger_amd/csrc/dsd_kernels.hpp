@@ -265,8 +265,15 @@ __device__ __forceinline__ void store16(float4* base_uniform, int idx, const flo
 
 __device__ __forceinline__ float f4at(const float4& v, int e) { return (e == 0) ? v.x : (e == 1) ? v.y : (e == 2) ? v.z : v.w; }
 
-template <int NB, bool LAST>
-__global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
+// What the TRAINING forward (csrc/train_kernels.hpp) keeps of a layer for its backward pass; the
+// inference kernels instantiate the body with TRAIN = false and none of this exists in their code.
+struct LayerSave {
+    float* y_cm;            // y = x + step projection, channel-major [B][C][TS], zero for t >= T (B operand of the conv weight gradient)
+    float4* a_frag;         // pre-activation of the gate (conv + conditioner projection + biases) in accumulator-fragment order, the layout of `cp`
+};
+
+template <int NB, bool LAST, bool TRAIN>
+__device__ __forceinline__ void layer_body(const LayerParams& p, const LayerSave& sv) {
     constexpr int LD = 32 * NB + 2 * kHalo;   // y tile row stride (floats), 16-byte multiple
     constexpr int GLD = 32 * NB;              // gate tile row stride
     constexpr int TILE = kC * 32;             // floats per 32-frame x tile
@@ -363,6 +370,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
                 v.z = (ok && t + 2 < p.T) ? v.z + d : 0.f;
                 v.w = (ok && t + 3 < p.T) ? v.w + d : 0.f;
                 *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 32 * nbi + 4 * c4) = v;
+                if (TRAIN && ok) *reinterpret_cast<float4*>(sv.y_cm + ((size_t)b * kC + row) * p.TS + t) = v;
             }
         {
             const int row = 64 * q + (tid >> 2);
@@ -437,6 +445,21 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
     GemmPipe<NMB2, NB, GLD, 256, (NB == 1 ? 6 : 3), TileB> pipe2(p.w2p + (size_t)w * (32 * 256) + MB0 * 64, lane, 32, bof2);
     pipe2.start_a();
 
+    if (TRAIN) {
+        // the backward pass differentiates the gate from the pre-activation a = conv + cp: saved in fragment order (1 KiB per instruction)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (nb >= ntv) continue;
+            float4* al = sv.a_frag + ((size_t)(tile0 + nb) * 4 + w) * (4 * 4 * 64) + lane;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 c = cpv[mb][nb][q], a = get4(acc[mb][nb], q);
+                    al[(mb * 4 + q) * 64] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+                }
+        }
+    }
     // 3. gate in registers: rows [64w,64w+64) are gates, their partners (row blocks 2,3) the filters (net.py:73-74)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr)
@@ -541,6 +564,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
         unsigned long long* d = p.dbg + (((size_t)b * p.tiles_per_utt + tn) * 4 + w) * 8;
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = __builtin_amdgcn_s_memtime(); d[6] = tsa; d[7] = tsb;
     }
+}
+
+template <int NB, bool LAST>
+__global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
+    layer_body<NB, LAST, false>(p, LayerSave{nullptr, nullptr});
+}
+// the same layer in a training forward: additionally writes y and the gate pre-activation (LayerSave)
+template <bool LAST>
+__global__ __launch_bounds__(kThreads, 1) void k_tr_layer(const LayerParams p, const LayerSave sv) {
+    layer_body<1, LAST, true>(p, sv);
 }
 
 // ------------------------------------------------------------------------------------------------------------

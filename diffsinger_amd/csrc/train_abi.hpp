@@ -1,0 +1,316 @@
+// train_abi.hpp - host side of the fused training stack (C ABI in include/dsf.h, "Training, the FUSED residual stack"); included at the
+// end of dsd.hip behind fs2_abi.hpp (one translation unit: shares fail(), HIP_TRY, fs_ts and the packing kernels).
+#include "train_kernels.hpp"
+
+namespace {
+
+constexpr size_t kTrW3 = (size_t)4 * 96 * 256 * 4;       // floats of one packed [512][256][3] (or its transpose) weight
+constexpr size_t kTrW1 = (size_t)4 * 32 * 256 * 4;       // floats of one packed [512][256] weight
+constexpr size_t kTrSlack = (size_t)kWeightSlack * 4;    // floats of A-prefetch slack behind a packed region
+constexpr int kTrMaxSplit = 16;
+
+static inline size_t tr_al(size_t n) { return (n + 1023) / 1024 * 1024; }      // keeps every sub-buffer 4 KiB aligned
+
+struct TrSave {             // offsets in floats into save_ws
+    size_t w1p, wcp, w2p, b1p, cp, X, Y, A, skip, bsum, iota, total;
+    size_t cp_l, X_l, Y_l, A_l;      // per-layer strides
+};
+static TrSave tr_save_layout(int B, int TS, int L) {
+    const size_t ntiles = (size_t)B * TS / 32;
+    TrSave s{};
+    size_t o = 0;
+    s.w1p = o; o += L * kTrW3;
+    s.wcp = o; o += L * kTrW1;
+    s.w2p = o; o += L * kTrW1 + kTrSlack;
+    s.b1p = o; o += tr_al((size_t)L * 512);
+    s.cp_l = ntiles * 16384; s.cp = o; o += L * s.cp_l;
+    s.X_l = ntiles * 8192; s.X = o; o += L * s.X_l;
+    s.Y_l = (size_t)B * kC * TS; s.Y = o; o += L * s.Y_l;
+    s.A_l = ntiles * 16384; s.A = o; o += L * s.A_l;
+    s.skip = o; o += ntiles * 8192;
+    s.bsum = o; o += 1024;
+    s.iota = o; o += tr_al((size_t)B);
+    s.total = o;
+    return s;
+}
+
+struct TrBwd {              // offsets in floats into bwd_ws
+    size_t wotp, wdtp, da, g, dxp0, dxp1, dds_part, part, part_b, total;
+};
+static TrBwd tr_bwd_layout(int B, int TS, int L) {
+    const size_t ntiles = (size_t)B * TS / 32, act = (size_t)B * kC * TS;
+    TrBwd s{};
+    size_t o = 0;
+    s.wotp = o; o += L * kTrW1;
+    s.wdtp = o; o += L * kTrW3 + kTrSlack;
+    s.da = o; o += 2 * act;
+    s.g = o; o += act;
+    s.dxp0 = o; o += act;
+    s.dxp1 = o; o += act;
+    s.dds_part = o; o += tr_al((size_t)L * ntiles * kC);
+    s.part = o; o += (size_t)kTrWgMaxTiles * kTrMaxSplit * 128 * 256;
+    s.part_b = o; o += tr_al((size_t)kTrWgMaxTiles * kTrMaxSplit * 128);
+    s.total = o;
+    return s;
+}
+
+static int tr_check(const char* who, int B, int T, int L) {
+    if (B < 1 || T < 1 || L < 1 || L > kTrMaxLayers) return fail(DSD_ERR_INVALID, "%s: bad shape (B=%d T=%d L=%d; L <= %d)", who, B, T, L, kTrMaxLayers);
+    return DSD_OK;
+}
+
+static TrPtrs tr_ptrs(const float* const* tbl, int L) {
+    TrPtrs t{};
+    for (int l = 0; l < L; ++l) t.p[l] = tbl[l];
+    return t;
+}
+
+static int tr_pack_multi(hipStream_t s, const float* const* src, int L, float* dst, size_t layer_floats, int ntap, int nkc, int nmb, int split,
+                         int hi_base, int rows_valid, int cols_valid, int row_stride, int col_stride, int tap_rev) {
+    PackMultiParams m{};
+    m.pp.dst = dst; m.pp.nw = 4; m.pp.nkc = nkc; m.pp.nmb = nmb; m.pp.ntap = ntap; m.pp.split = split; m.pp.hi_base = hi_base;
+    m.pp.rows_valid = rows_valid; m.pp.cols_valid = cols_valid; m.pp.row_stride = row_stride; m.pp.col_stride = col_stride; m.pp.centre_first = 1;
+    m.src = tr_ptrs(src, L);
+    m.dst_layer_floats = layer_floats;
+    m.tap_rev = tap_rev;
+    const size_t n = (size_t)4 * ntap * nkc * nmb * 256;
+    hipLaunchKernelGGL(k_pack_a_multi, dim3((unsigned)((n + 255) / 256), (unsigned)L), dim3(256), 0, s, m);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+static int tr_attrs() {
+    static bool done = false;
+    if (done) return DSD_OK;
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
+    done = true;
+    return DSD_OK;
+}
+
+// split-K factor of a weight-gradient launch of `ndesc` output tiles: fill the chip once (one workgroup per CU), never more splits than frame tiles
+static int tr_nsplit(int ndesc, int ntile) {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+    }
+    int ns = ncu / std::max(ndesc, 1);
+    ns = std::max(1, std::min(ns, kTrMaxSplit));
+    return std::min(ns, ntile);
+}
+
+static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int T, int TS) {
+    wp.B = B; wp.T = T; wp.TS = TS;
+    wp.nsplit = tr_nsplit(ndesc, B * TS / 32);
+    hipLaunchKernelGGL(k_tr_wgrad, dim3((unsigned)ndesc, (unsigned)wp.nsplit), dim3(kThreads), kTrWgLdsBytes, s, wp);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_tr_wgrad_reduce, dim3((unsigned)ndesc, 128), dim3(256), 0, s, wp);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t dsf_stack_workspace_floats(int32_t B, int32_t T, int32_t L, int32_t which) {
+    if (B < 1 || T < 1 || L < 1 || L > kTrMaxLayers || which < 0 || which > 1) return -1;
+    const int TS = fs_ts(T);
+    return (int64_t)(which == 0 ? tr_save_layout(B, TS, L).total : tr_bwd_layout(B, TS, L).total);
+}
+
+extern "C" int dsf_stack_offsets(int32_t B, int32_t T, int32_t L, int32_t which, int64_t* out, int32_t n) {
+    if (!out || tr_check("dsf_stack_offsets", B, T, L) != DSD_OK) return DSD_ERR_INVALID;
+    const int TS = fs_ts(T);
+    int64_t v[16] = {0};
+    if (which == 0) {
+        const TrSave s = tr_save_layout(B, TS, L);
+        const int64_t t[] = {(int64_t)s.w1p, (int64_t)s.wcp, (int64_t)s.w2p, (int64_t)s.b1p, (int64_t)s.cp, (int64_t)s.X, (int64_t)s.Y, (int64_t)s.A,
+                             (int64_t)s.skip, (int64_t)s.bsum, (int64_t)s.cp_l, (int64_t)s.X_l, (int64_t)s.Y_l, (int64_t)s.A_l, (int64_t)s.total, 0};
+        memcpy(v, t, sizeof(v));
+    } else {
+        const TrBwd s = tr_bwd_layout(B, TS, L);
+        const int64_t t[] = {(int64_t)s.wotp, (int64_t)s.wdtp, (int64_t)s.da, (int64_t)s.g, (int64_t)s.dxp0, (int64_t)s.dxp1, (int64_t)s.dds_part,
+                             (int64_t)s.part, (int64_t)s.part_b, (int64_t)s.total, 0, 0, 0, 0, 0, 0};
+        memcpy(v, t, sizeof(v));
+    }
+    for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
+    return DSD_OK;
+}
+
+extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float* step, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L,
+                                 float* ws, float* skip_out, void* stream) {
+    if (!x0 || !cond || !step || !w || !ws || !skip_out) return fail(DSD_ERR_INVALID, "dsf_stack_forward: null argument");
+    DSD_TRY(tr_check("dsf_stack_forward", B, T, L));
+    for (int l = 0; l < L; ++l)
+        if (w->dilations[l] < 1 || w->dilations[l] > kHalo) return fail(DSD_ERR_INVALID, "dsf_stack_forward: dilation %d of layer %d (1..%d)", w->dilations[l], l, kHalo);
+    DSD_TRY(tr_attrs());
+    hipStream_t s = (hipStream_t)stream;
+    const int TS = fs_ts(T), ntile32 = TS / 32, ntiles = B * ntile32;
+    const TrSave lay = tr_save_layout(B, TS, L);
+    // weights -> fragment order, all layers per launch (they change every optimiser step)
+    DSD_TRY(tr_pack_multi(s, w->dilated_conv_w, L, ws + lay.w1p, kTrW3, 3, 32, 4, 1, kC, 2 * kC, kC, 3 * kC, 3, 0));
+    DSD_TRY(tr_pack_multi(s, w->cond_w, L, ws + lay.wcp, kTrW1, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1, 0));
+    DSD_TRY(tr_pack_multi(s, w->out_w, L, ws + lay.w2p, kTrW1, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1, 0));
+    {
+        PackBiasMultiParams m{};
+        m.pp.dst = ws + lay.b1p; m.pp.nw = 4; m.pp.nmb = 4; m.pp.split = 1; m.pp.hi_base = kC; m.pp.rows_valid = 2 * kC;
+        m.a = tr_ptrs(w->dilated_conv_b, L); m.b = tr_ptrs(w->cond_b, L); m.has_b = 1; m.dst_layer_floats = 512;
+        hipLaunchKernelGGL(k_pack_bias_multi, dim3(2, (unsigned)L), dim3(256), 0, s, m);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_tr_bsum, dim3(1), dim3(256), 0, s, tr_ptrs(w->out_b, L), ws + lay.bsum, L);
+    int* iota = reinterpret_cast<int*>(ws + lay.iota);
+    hipLaunchKernelGGL(k_tr_iota, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, iota, B);
+    const size_t n4 = (size_t)B * kC * TS / 4;
+    hipLaunchKernelGGL(k_tr_cm_to_tm, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 16384)), dim3(256), 0, s, (const float4*)x0, (float4*)(ws + lay.X), TS, n4);
+    HIP_TRY(hipGetLastError());
+    {
+        CondProjParams p{};
+        p.condT = cond; p.wcp = (const float4*)(ws + lay.wcp); p.b1p = (const float4*)(ws + lay.b1p); p.cp = (float4*)(ws + lay.cp);
+        p.TS = TS; p.ntile32 = ntile32; p.ntiles_total = ntiles;
+        hipLaunchKernelGGL(k_condproj, dim3((unsigned)ntiles, (unsigned)L), dim3(kThreads), kC * 32 * 4, s, p);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int l = 0; l < L; ++l) {
+        const bool last = (l == L - 1);
+        LayerParams p{};
+        p.x_in = ws + lay.X + (size_t)l * lay.X_l;
+        p.x_out = last ? nullptr : ws + lay.X + (size_t)(l + 1) * lay.X_l;
+        p.w1p = (const float4*)(ws + lay.w1p + (size_t)l * kTrW3);
+        p.w2p = (const float4*)(ws + lay.w2p + (size_t)l * kTrW1);
+        p.b2 = w->out_b[l];
+        p.cp = (const float4*)(ws + lay.cp + (size_t)l * lay.cp_l);
+        p.skip = (float4*)(ws + lay.skip);
+        p.ds = step + (size_t)l * kC;
+        p.t_dev = iota; p.t_uniform = 0; p.ds_tstride = L * kC;
+        p.T = T; p.TS = TS; p.ntile32 = ntile32; p.tiles_per_utt = ntile32; p.dil = w->dilations[l]; p.first = (l == 0);
+        p.wt_stores = 1;
+        p.xcd_q = ntiles / 8; p.xcd_r = ntiles % 8;
+        p.dbg = nullptr;
+        const LayerSave sv{ws + lay.Y + (size_t)l * lay.Y_l, (float4*)(ws + lay.A + (size_t)l * lay.A_l)};
+        if (last) hipLaunchKernelGGL(k_tr_layer<true>, dim3((unsigned)ntiles), dim3(kThreads), layer_lds_bytes<1>(), s, p, sv);
+        else hipLaunchKernelGGL(k_tr_layer<false>, dim3((unsigned)ntiles), dim3(kThreads), layer_lds_bytes<1>(), s, p, sv);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_tr_skip_to_cm, dim3((unsigned)ntiles), dim3(kThreads), 0, s, (const float4*)(ws + lay.skip), ws + lay.bsum, skip_out, T, TS, ntile32);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L, const float* sws,
+                                  float* bws, const dsf_stack_grads* g, float* da_all, void* stream) {
+    if (!dskip || !cond || !w || !sws || !bws || !g || !g->dx0 || !g->dstep) return fail(DSD_ERR_INVALID, "dsf_stack_backward: null argument");
+    DSD_TRY(tr_check("dsf_stack_backward", B, T, L));
+    DSD_TRY(tr_attrs());
+    hipStream_t s = (hipStream_t)stream;
+    const int TS = fs_ts(T), ntile32 = TS / 32, ntiles = B * ntile32;
+    const TrSave lay = tr_save_layout(B, TS, L);
+    const TrBwd bl = tr_bwd_layout(B, TS, L);
+    const size_t act = (size_t)B * kC * TS;
+    (void)act;
+    // transposed weights in fragment order: Wo^T [256 gate channels][512 output rows]; Wd^T flipped [256 input channels][3 x 512]
+    DSD_TRY(tr_pack_multi(s, w->out_w, L, bws + bl.wotp, kTrW1, 1, 64, 2, 0, 0, kC, 2 * kC, 1, kC, 0));
+    DSD_TRY(tr_pack_multi(s, w->dilated_conv_w, L, bws + bl.wdtp, kTrW3, 3, 64, 2, 0, 0, kC, 2 * kC, 3, 3 * kC, 1));
+    float* dxp[2] = {bws + bl.dxp0, bws + bl.dxp1};
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = (l == L - 1);
+        const float* dxp_in = last ? nullptr : dxp[(l + 1) & 1];
+        float* dx_out = (l == 0) ? g->dx0 : dxp[l & 1];
+        float* da = da_all ? da_all + (size_t)l * 2 * kC * TS : bws + bl.da;
+        const long long da_bs = da_all ? (long long)L * 2 * kC * TS : (long long)2 * kC * TS;
+        {
+            TrbGateParams p{};
+            p.dxp = dxp_in; p.dsk = dskip; p.a_frag = (const float4*)(sws + lay.A + (size_t)l * lay.A_l);
+            p.wotp = (const float4*)(bws + bl.wotp + (size_t)l * kTrW1);
+            p.da = da; p.g = bws + bl.g; p.da_bstride = da_bs; p.T = T; p.TS = TS; p.ntile32 = ntile32;
+            if (last) hipLaunchKernelGGL(k_trb_gate<true>, dim3((unsigned)ntiles), dim3(kThreads), kTrbGateLdsBytes, s, p);
+            else hipLaunchKernelGGL(k_trb_gate<false>, dim3((unsigned)ntiles), dim3(kThreads), kTrbGateLdsBytes, s, p);
+            HIP_TRY(hipGetLastError());
+        }
+        {
+            TrbConvParams p{};
+            p.da = da; p.wdtp = (const float4*)(bws + bl.wdtp + (size_t)l * kTrW3); p.dxp = dxp_in; p.dx_out = dx_out;
+            p.dds_part = bws + bl.dds_part + (size_t)l * ntiles * kC; p.da_bstride = da_bs;
+            p.T = T; p.TS = TS; p.ntile32 = ntile32; p.dil = w->dilations[l];
+            if (last) hipLaunchKernelGGL(k_trb_conv<true>, dim3((unsigned)ntiles), dim3(kThreads), kTrbConvLdsBytes, s, p);
+            else hipLaunchKernelGGL(k_trb_conv<false>, dim3((unsigned)ntiles), dim3(kThreads), kTrbConvLdsBytes, s, p);
+            HIP_TRY(hipGetLastError());
+        }
+        // the layer's weight gradients: 12 (dilated conv: 4 row tiles x 3 taps) + 4 (conditioner projection) + 4 or 2 (output projection) tiles
+        TrWgParams wp{};
+        int nd = 0;
+        const float* y = sws + lay.Y + (size_t)l * lay.Y_l;
+        const int dil = w->dilations[l];
+        for (int mt = 0; mt < 4; ++mt)
+            for (int tap = 0; tap < 3; ++tap) {
+                TrWgTile& d = wp.tile[nd++];
+                d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = y; d.b_bstride = (long long)kC * TS; d.shift = (tap - 1) * dil;
+                d.out = g->dilated_conv_w[l] + (size_t)mt * 128 * 3 * kC + tap; d.out_rs = 3 * kC; d.out_cs = 3;
+                d.out_bias = (tap == 0) ? g->dilated_conv_b[l] + mt * 128 : nullptr; d.a_scale = 1.f;
+            }
+        for (int mt = 0; mt < 4; ++mt) {
+            TrWgTile& d = wp.tile[nd++];
+            d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = cond; d.b_bstride = (long long)kC * TS; d.shift = 0;
+            d.out = g->cond_w[l] + (size_t)mt * 128 * kC; d.out_rs = kC; d.out_cs = 1; d.out_bias = g->cond_b[l] + mt * 128; d.a_scale = 1.f;
+        }
+        for (int mt = last ? 2 : 0; mt < 4; ++mt) {
+            TrWgTile& d = wp.tile[nd++];
+            if (mt < 2) { d.a = dxp_in + (size_t)mt * 128 * TS; d.a_scale = kTrInvSqrt2; }
+            else { d.a = dskip + (size_t)(mt - 2) * 128 * TS; d.a_scale = 1.f; }
+            d.a_bstride = (long long)kC * TS; d.bsrc = bws + bl.g; d.b_bstride = (long long)kC * TS; d.shift = 0;
+            d.out = g->out_w[l] + (size_t)mt * 128 * kC; d.out_rs = kC; d.out_cs = 1; d.out_bias = g->out_b[l] + mt * 128;
+        }
+        if (last) {          // the residual half of the last layer's output projection is dead (net.py:126 reads the skips only): zero gradient
+            HIP_TRY(hipMemsetAsync(g->out_w[l], 0, (size_t)kC * kC * sizeof(float), s));
+            HIP_TRY(hipMemsetAsync(g->out_b[l], 0, (size_t)kC * sizeof(float), s));
+        }
+        wp.part = bws + bl.part; wp.part_b = bws + bl.part_b;
+        DSD_TRY(tr_wgrad_launch(s, wp, nd, B, T, TS));
+    }
+    hipLaunchKernelGGL(k_tr_dds_reduce, dim3((unsigned)B, (unsigned)L), dim3(kC), 0, s, bws + bl.dds_part, g->dstep, L, ntile32, ntiles);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int64_t dsf_wgrad2_workspace_floats(int32_t Co, int32_t Ci, int32_t KT) {
+    if (Co < 128 || (Co % 128) || Ci < 256 || (Ci % 256) || (KT != 1 && KT != 3)) return -1;
+    const int nd = (Co / 128) * (Ci / 256) * KT;
+    return (int64_t)nd * kTrMaxSplit * (128 * 256 + 128);
+}
+
+extern "C" int dsf_conv1d_wgrad2(const float* dy, const float* x, float* dw, float* db, float* workspace, int32_t B, int32_t Ci, int32_t Co, int32_t KT,
+                                 int32_t dil, int32_t T, void* stream) {
+    if (!dy || !x || !dw || !workspace) return fail(DSD_ERR_INVALID, "dsf_conv1d_wgrad2: null argument");
+    if (B < 1 || T < 1 || Co < 128 || (Co % 128) || Ci < 256 || (Ci % 256) || (KT != 1 && KT != 3) || dil < 1 || dil > kHalo)
+        return fail(DSD_ERR_INVALID, "dsf_conv1d_wgrad2: bad shape (B=%d T=%d Ci=%d Co=%d K=%d dil=%d): Co %% 128 == 0, Ci %% 256 == 0, K in {1, 3}", B, T, Ci, Co, KT, dil);
+    DSD_TRY(tr_attrs());
+    hipStream_t s = (hipStream_t)stream;
+    const int TS = fs_ts(T);
+    const int per = kTrWgMaxTiles, ndtot = (Co / 128) * (Ci / 256) * KT;
+    // descriptors in launches of at most kTrWgMaxTiles tiles
+    int done = 0;
+    while (done < ndtot) {
+        TrWgParams wp{};
+        int nd = 0;
+        for (; nd < per && done + nd < ndtot; ++nd) {
+            const int id = done + nd;
+            const int tap = id % KT, nt = (id / KT) % (Ci / 256), mt = id / (KT * (Ci / 256));
+            TrWgTile& d = wp.tile[nd];
+            d.a = dy + (size_t)mt * 128 * TS; d.a_bstride = (long long)Co * TS;
+            d.bsrc = x + (size_t)nt * 256 * TS; d.b_bstride = (long long)Ci * TS;
+            d.shift = (tap - (KT - 1) / 2) * dil;
+            d.out = dw + ((size_t)mt * 128 * Ci + (size_t)nt * 256) * KT + tap; d.out_rs = Ci * KT; d.out_cs = KT;
+            d.out_bias = (db && tap == 0 && nt == 0) ? db + mt * 128 : nullptr; d.a_scale = 1.f;
+        }
+        wp.part = workspace + (size_t)done * kTrMaxSplit * (128 * 256);
+        wp.part_b = workspace + (size_t)ndtot * kTrMaxSplit * (128 * 256) + (size_t)done * kTrMaxSplit * 128;
+        DSD_TRY(tr_wgrad_launch(s, wp, nd, B, T, TS));
+        done += nd;
+    }
+    return DSD_OK;
+}

@@ -212,14 +212,24 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
     d = step_embedding(diffusion_step, net.residual_channels)       # :119
     h = F.linear(d, net.mlp[0].weight, net.mlp[0].bias)
     d = F.linear(h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)      # :120 (Mish)
-    skip = None
-    for l, layer in enumerate(net.residual_layers):                 # ResidualBlock.forward :66-78
-        ds = F.linear(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)
-        y = _AddStep.apply(x, ds, T)
-        a = conv(f'l{l}.dc', y, layer.dilated_conv, layer.dilation) + conv(f'l{l}.cp', cm, layer.conditioner_projection)
-        g = _Gate.apply(a, T)
-        y = conv(f'l{l}.op', g, layer.output_projection)
-        x, skip = _ResSkip.apply(x, y, skip, T)
+    from . import train_fused
+    if train_fused.enabled() and train_fused.supported(net):
+        # the whole residual stack as ONE autograd node on the fused kernels (csrc/train_kernels.hpp); the step projections of all layers
+        # (net.py:67) are one batched linear
+        layers = list(net.residual_layers)
+        wd = torch.cat([l.diffusion_projection.weight for l in layers], 0)
+        bd = torch.cat([l.diffusion_projection.bias for l in layers], 0)
+        step_all = F.linear(d, wd, bd).view(B, len(layers), net.residual_channels)
+        skip = train_fused.residual_stack(net, x, cm, step_all, T)
+    else:
+        skip = None
+        for l, layer in enumerate(net.residual_layers):             # ResidualBlock.forward :66-78
+            ds = F.linear(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)
+            y = _AddStep.apply(x, ds, T)
+            a = conv(f'l{l}.dc', y, layer.dilated_conv, layer.dilation) + conv(f'l{l}.cp', cm, layer.conditioner_projection)
+            g = _Gate.apply(a, T)
+            y = conv(f'l{l}.op', g, layer.output_projection)
+            x, skip = _ResSkip.apply(x, y, skip, T)
     x = skip / math.sqrt(len(net.residual_layers))                  # :126
     x = F.relu(conv('sp', x, net.skip_projection))                  # :127-128
     x = conv('out', x, net.output_projection)                       # :129

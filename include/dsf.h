@@ -102,6 +102,47 @@ int dsf_denorm_spec(const float* x, const float* mask, float* mel, const float* 
 int dsf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step, const float* grad_scale, void* stream);
 
+/* Training, the FUSED residual stack: the 20 ResidualBlocks of DiffNet.forward (usr/diff/net.py:66-78, :121-126)
+ * forward and backward as what torch autograd would run for them, for residual_channels = encoder_hidden = 256 and L <= 32 layers.
+ *   forward   x0 [B][256][TS] (relu(input_projection), net.py:116-118), cond [B][256][TS], step [B][L][256] (diffusion_projection_l of the
+ *             step embedding, :67) -> skip [B][256][TS] = sum_l skip_l (the tensor :126 divides by sqrt(L)).  One conditioner-projection
+ *             launch for all layers + the inference layer kernel per layer, which additionally saves y = x + step and the gate
+ *             pre-activation into `save_ws` for the backward pass.
+ *   backward  dskip [B][256][TS] -> dx0, dstep [B][L][256], every weight / bias gradient of the stack (torch layouts, OVERWRITTEN),
+ *             per layer: output-projection data gradient + gate derivative, transposed dilated conv + residual path, and ONE launch for
+ *             the layer's three weight gradients (contraction over frames, split-K partials reduced in a fixed order: deterministic).
+ *             da_all: NULL, or [B][L*512][TS] to keep every layer's gradient wrt the gate pre-activation (rows [512 l, 512 l + 512) of an
+ *             utterance) - the operand of the conditioner gradient dcond = sum_l Wc_l^T da_l, one dsf_conv1d over 512 L input channels.
+ * The weight tables are HOST arrays of L device pointers in torch layouts: dilated_conv [512][256][3], conditioner / output projection
+ * [512][256][1], biases [512].  Workspaces are caller-owned: dsf_stack_workspace_floats(B, T, L, 0) floats for save_ws (written by forward,
+ * read by backward), (.., 1) for the backward scratch; contents are private to the library (dsf_stack_offsets: test access). */
+typedef struct dsf_stack_weights {
+    const float* const* dilated_conv_w; const float* const* dilated_conv_b;
+    const float* const* cond_w;         const float* const* cond_b;
+    const float* const* out_w;          const float* const* out_b;
+    const int32_t* dilations;           /* [L], each in {1, 2, 4, 8} */
+} dsf_stack_weights;
+typedef struct dsf_stack_grads {
+    float* const* dilated_conv_w; float* const* dilated_conv_b;
+    float* const* cond_w;         float* const* cond_b;
+    float* const* out_w;          float* const* out_b;
+    float* dx0;                   /* [B][256][TS] */
+    float* dstep;                 /* [B][L][256] */
+} dsf_stack_grads;
+int64_t dsf_stack_workspace_floats(int32_t B, int32_t T, int32_t L, int32_t which);
+int dsf_stack_offsets(int32_t B, int32_t T, int32_t L, int32_t which, int64_t* out, int32_t n);
+int dsf_stack_forward(const float* x0, const float* cond, const float* step, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L,
+                      float* save_ws, float* skip_out, void* stream);
+int dsf_stack_backward(const float* dskip, const float* cond, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L, const float* save_ws,
+                       float* bwd_ws, const dsf_stack_grads* grads, float* da_all, void* stream);
+
+/* The weight-gradient kernel of the fused stack as a stand-alone operator with dsf_conv1d_wgrad's contract (K = 1 or 3, Co a multiple of
+ * 128, Ci a multiple of 256): dw[co][ci][k] = sum dy[b][co][t] x[b][ci][t + (k - (K-1)/2) dil], db[co] = sum dy.  workspace:
+ * dsf_wgrad2_workspace_floats(Co, Ci, K) floats. */
+int64_t dsf_wgrad2_workspace_floats(int32_t Co, int32_t Ci, int32_t K);
+int dsf_conv1d_wgrad2(const float* dy, const float* x, float* dw, float* db, float* workspace, int32_t B, int32_t Ci, int32_t Co, int32_t K,
+                      int32_t dil, int32_t T, void* stream);
+
 /* PitchExtractor (modules/fastspeech/pe.py:119-148; SURVEY section 8 row f2: mel -> f0 for the NSF vocoder) beyond the operators above:
  *   channel_affine  y = (x * a[c] + b[c]) * keep[b][t]: nn.BatchNorm1d in eval mode folded to a = gamma / sqrt(var + eps),
  *                   b = beta - mean * a, and Prenet's `* nonpadding_mask` (pe.py:12-17, :33-35); keep may be NULL

@@ -1,0 +1,188 @@
+"""GPU: the FUSED training stack (diffsinger_amd/train_fused.py, csrc/train_kernels.hpp) against torch autograd
+in float64 on the CPU of the reference's ResidualBlock arithmetic (usr/diff/net.py:66-78, :121-126): the stand-alone weight-gradient
+operator, the forward (skip sum and the tensors it saves), and every gradient of the backward pass - dx0, dcond, dstep and the six
+parameter tensors of every layer.  Errors are judged relative to the max-abs of the reference tensor (gradients are sums over B * T frames)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+@pytest.mark.parametrize('B,T,Ci,Co,K,dil', [(2, 50, 256, 512, 3, 1), (3, 77, 256, 512, 3, 8), (2, 96, 256, 512, 3, 2), (2, 64, 256, 512, 1, 1),
+                                           (1, 33, 512, 256, 3, 4), (8, 1024, 256, 512, 3, 1), (48, 512, 256, 512, 1, 1)])
+def test_wgrad2_operator(B, T, Ci, Co, K, dil):
+    from diffsinger_amd import fs2, train_fused
+    g = torch.Generator().manual_seed(T + Co + K)
+    TS = fs2.padded_frames(T)
+    x = torch.randn(B, Ci, T, generator=g)
+    dy = torch.randn(B, Co, T, generator=g)
+    big = B * T > 4096
+    dev = torch.device('cuda', 0)
+    if big:         # reference on the GPU (float64 autograd of conv1d)
+        xr, dyr = x.to(dev).double(), dy.to(dev).double()
+    else:
+        xr, dyr = x.double(), dy.double()
+    w = torch.zeros(Co, Ci, K, dtype=torch.float64, device=xr.device, requires_grad=True)
+    bias = torch.zeros(Co, dtype=torch.float64, device=xr.device, requires_grad=True)
+    F.conv1d(xr, w, bias, padding=dil * (K - 1) // 2, dilation=dil).backward(dyr)
+    xd = F.pad(x, (0, TS - T)).to(dev).contiguous()
+    dyd = F.pad(dy, (0, TS - T)).to(dev).contiguous()
+    dyd[:, :, T:] = 7.0                                  # garbage in the tail of dy must not leak
+    dw, db = train_fused.conv1d_wgrad2(dyd, xd, K, dil, T)
+    dw2, _ = train_fused.conv1d_wgrad2(dyd, xd, K, dil, T)
+    e_w, e_b = _rel(dw, w.grad.cpu()), _rel(db, bias.grad.cpu())
+    print(f'wgrad2 B={B} T={T} Ci={Ci} Co={Co} K={K} dil={dil}: dw {e_w:.2e} db {e_b:.2e}')
+    assert torch.equal(dw, dw2)                          # deterministic
+    assert e_w <= 2e-5 and e_b <= 2e-5
+
+
+def _make_stack(L, cycle, seed):
+    g = torch.Generator().manual_seed(seed)
+    ws = {}
+    ws['dc_w'] = [torch.randn(512, 256, 3, generator=g) * (256 * 3) ** -0.5 for _ in range(L)]
+    ws['dc_b'] = [torch.randn(512, generator=g) * 0.1 for _ in range(L)]
+    ws['cp_w'] = [torch.randn(512, 256, 1, generator=g) * 256 ** -0.5 for _ in range(L)]
+    ws['cp_b'] = [torch.randn(512, generator=g) * 0.1 for _ in range(L)]
+    ws['op_w'] = [torch.randn(512, 256, 1, generator=g) * 256 ** -0.5 for _ in range(L)]
+    ws['op_b'] = [torch.randn(512, generator=g) * 0.1 for _ in range(L)]
+    dils = [2 ** (l % cycle) for l in range(L)]
+    return ws, dils
+
+
+def _ref_stack(x0, cond, step, ws, dils, keep=None):
+    """float64 reference of the residual stack on [B][256][T] tensors (no padding); keep: dict that receives y / a of every layer."""
+    x, skip = x0, 0
+    L = len(dils)
+    for l in range(L):
+        y = x + step[:, l, :, None]
+        a = F.conv1d(y, ws['dc_w'][l], ws['dc_b'][l], padding=dils[l], dilation=dils[l]) + F.conv1d(cond, ws['cp_w'][l], ws['cp_b'][l])
+        if keep is not None:
+            keep.setdefault('y', []).append(y.detach())
+            keep.setdefault('a', []).append(a.detach())
+        g = torch.sigmoid(a[:, :256]) * torch.tanh(a[:, 256:])
+        o = F.conv1d(g, ws['op_w'][l], ws['op_b'][l])
+        x = (x + o[:, :256]) / math.sqrt(2.0)
+        skip = skip + o[:, 256:]
+    return skip
+
+
+def _frag_to_rows(frag, ntiles):
+    """[ntiles][w4][mb4][q4][lane64][e4] (the layout of the saved pre-activation) -> [ntiles][512 rows][32 frames]"""
+    f = frag.reshape(ntiles, 4, 4, 4, 2, 32, 4)                 # tile, w, mb, q, h, j, e
+    out = torch.zeros(ntiles, 512, 32)
+    for w in range(4):
+        for mb in range(4):
+            base = (64 * w + 32 * mb) if mb < 2 else (256 + 64 * w + 32 * (mb - 2))
+            for q in range(4):
+                for h in range(2):
+                    for e in range(4):
+                        out[:, base + 8 * q + 4 * h + e, :] = f[:, w, mb, q, h, :, e]
+    return out
+
+
+@pytest.mark.parametrize('B,T,L,cycle', [(2, 50, 3, 4), (3, 96, 5, 1), (2, 70, 20, 4)])
+def test_stack_forward_and_backward(B, T, L, cycle):
+    from diffsinger_amd import _lib, fs2, train_fused
+    lib = _lib.load()
+    train_fused._bind(lib)
+    ws, dils = _make_stack(L, cycle, seed=L + T)
+    g = torch.Generator().manual_seed(5 + T)
+    x0 = torch.relu(torch.randn(B, 256, T, generator=g))
+    cond = torch.randn(B, 256, T, generator=g)
+    step = torch.randn(B, L, 256, generator=g) * 0.5
+    dskip = torch.randn(B, 256, T, generator=g)
+    # float64 reference with autograd
+    r = {k: [t.double().requires_grad_(True) for t in v] for k, v in ws.items()}
+    x0r, condr, stepr = x0.double().requires_grad_(True), cond.double().requires_grad_(True), step.double().requires_grad_(True)
+    keep = {}
+    skip_ref = _ref_stack(x0r, condr, stepr, r, dils, keep)
+    skip_ref.backward(dskip.double())
+
+    dev = torch.device('cuda', 0)
+    TS = fs2.padded_frames(T)
+    ntiles = B * TS // 32
+    pad = lambda t: F.pad(t, (0, TS - T)).to(dev).contiguous()
+    x0d, condd = pad(x0).requires_grad_(True), pad(cond).requires_grad_(True)
+    stepd = step.to(dev).requires_grad_(True)
+    order = ['dc_w', 'dc_b', 'cp_w', 'cp_b', 'op_w', 'op_b']
+    wd = [t.to(dev).requires_grad_(True) for k in order for t in ws[k]]
+    skip = train_fused._ResidualStack.apply(x0d, condd, stepd, T, dils, fs2.PackedWeight(), *wd)
+    e_skip = _rel(skip[:, :, :T], skip_ref.detach())
+    assert float(skip[:, :, T:].abs().max() if TS > T else 0) == 0
+    # the tensors the forward saved for the backward pass
+    save = skip.grad_fn.saved_tensors[1]
+    off = (C.c_int64 * 16)()
+    _lib.check(lib.dsf_stack_offsets(B, T, L, 0, off, 16))
+    oY, oA, Yl, Al = off[6], off[7], off[12], off[13]
+    e_y = e_a = 0.0
+    for l in range(L):
+        y = save[oY + l * Yl: oY + (l + 1) * Yl].reshape(B, 256, TS).cpu()
+        e_y = max(e_y, _rel(y[:, :, :T], keep['y'][l]))
+        assert float(y[:, :, T:].abs().max() if TS > T else 0) == 0
+        a = _frag_to_rows(save[oA + l * Al: oA + (l + 1) * Al].cpu(), ntiles).reshape(B, TS // 32, 512, 32).permute(0, 2, 1, 3).reshape(B, 512, TS)
+        e_a = max(e_a, _rel(a[:, :, :T], keep['a'][l]))
+    print(f'stack B={B} T={T} L={L}: skip {e_skip:.2e}, saved y {e_y:.2e}, saved a {e_a:.2e}')
+    assert e_skip <= 2e-5 and e_y <= 1e-5 and e_a <= 2e-5
+
+    dsk = pad(dskip)
+    dsk[:, :, T:] = 3.0                                   # garbage in the tail of the incoming gradient must not leak
+    skip.backward(dsk)
+    errs = {'dx0': _rel(x0d.grad[:, :, :T], x0r.grad), 'dcond': _rel(condd.grad[:, :, :T], condr.grad), 'dstep': _rel(stepd.grad, stepr.grad)}
+    assert float(x0d.grad[:, :, T:].abs().max() if TS > T else 0) == 0
+    per_layer = []
+    for ki, k in enumerate(order):
+        worst = 0.0
+        for l in range(L):
+            e = _rel(wd[ki * L + l].grad, r[k][l].grad)
+            per_layer.append((k, l, e))
+            worst = max(worst, e)
+        errs[k] = worst
+    print('  backward: ' + ', '.join(f'{k} {v:.2e}' for k, v in errs.items()))
+    bad = [(k, l, e) for k, l, e in per_layer if e > 2e-5]
+    if bad:
+        print('  layers over tolerance: ' + ', '.join(f'{k}[{l}] {e:.1e}' for k, l, e in bad[:40]))
+    assert all(v <= 2e-5 for v in errs.values()), errs
+
+
+def test_p_losses_gradients_fused_equals_operator_path(monkeypatch):
+    """The fused stack and the operator-by-operator path of train.py give the same loss and gradients on a real DiffNet."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from tests import helpers as H
+    pre = H.presets()['opencpop_ds60_rel']
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('DSD_TRAIN_FUSED', mode)
+        hparams.clear()
+        diffsinger_amd.use_preset('opencpop_ds60_rel')
+        torch.manual_seed(7)
+        net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+        torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+        gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=pre['timesteps'], K_step=pre['K_step'], loss_type='l1',
+                                              spec_min=pre['spec_min'], spec_max=pre['spec_max']).cuda().train()
+        g = torch.Generator().manual_seed(3)
+        x0 = torch.clamp(torch.randn(3, 1, 80, 83, generator=g) * 0.5, -1, 1).cuda()
+        noise = torch.randn(3, 1, 80, 83, generator=g).cuda()
+        cond = torch.randn(3, 83, 256, generator=g).transpose(1, 2).cuda().requires_grad_(True)
+        t = torch.tensor([5, 40, 17]).cuda()
+        loss = gd.p_losses(x0, t, cond, noise=noise)
+        loss.backward()
+        res[mode] = (float(loss), {k: p.grad.detach().cpu() for k, p in net.named_parameters()}, cond.grad.detach().cpu())
+    assert abs(res['1'][0] - res['0'][0]) <= 2e-6 * abs(res['0'][0])
+    worst = ('', 0.0)
+    for k, gref in res['0'][1].items():
+        e = float((res['1'][1][k] - gref).abs().max() / max(float(gref.abs().max()), 1e-30))
+        if e > worst[1]:
+            worst = (k, e)
+    e_c = float((res['1'][2] - res['0'][2]).abs().max() / float(res['0'][2].abs().max()))
+    print(f'fused vs operator path: loss {res["1"][0]:.6f} / {res["0"][0]:.6f}, worst parameter gradient {worst[1]:.2e} at {worst[0]}, dcond {e_c:.2e}')
+    assert worst[1] <= 5e-5 and e_c <= 5e-5

@@ -94,6 +94,10 @@ def run(B, T, reps, torch_conv=False, reference_style=False):
 
 if __name__ == '__main__':
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    if '--hip-only' in sys.argv:                    # for rocprofv3 runs: only the HIP variant, one shape
+        B, T = (int(v) for v in sys.argv[sys.argv.index('--hip-only') + 1].split('x'))
+        run(B, T, reps)
+        sys.exit(0)
     for B, T in ((8, 1024), (48, 512)):
         run(B, T, reps)
         run(B, T, reps, torch_conv=True)
