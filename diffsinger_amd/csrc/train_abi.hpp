@@ -65,15 +65,15 @@ static TrPtrs tr_ptrs(const float* const* tbl, int L) {
     return t;
 }
 
-static int tr_pack_multi(hipStream_t s, const float* const* src, int L, float* dst, size_t layer_floats, int ntap, int nkc, int nmb, int split,
+static int tr_pack_multi(hipStream_t s, const float* const* src, int L, float* dst, size_t layer_floats, int nw, int ntap, int nkc, int nmb, int split,
                          int hi_base, int rows_valid, int cols_valid, int row_stride, int col_stride, int tap_rev) {
     PackMultiParams m{};
-    m.pp.dst = dst; m.pp.nw = 4; m.pp.nkc = nkc; m.pp.nmb = nmb; m.pp.ntap = ntap; m.pp.split = split; m.pp.hi_base = hi_base;
+    m.pp.dst = dst; m.pp.nw = nw; m.pp.nkc = nkc; m.pp.nmb = nmb; m.pp.ntap = ntap; m.pp.split = split; m.pp.hi_base = hi_base;
     m.pp.rows_valid = rows_valid; m.pp.cols_valid = cols_valid; m.pp.row_stride = row_stride; m.pp.col_stride = col_stride; m.pp.centre_first = 1;
     m.src = tr_ptrs(src, L);
     m.dst_layer_floats = layer_floats;
     m.tap_rev = tap_rev;
-    const size_t n = (size_t)4 * ntap * nkc * nmb * 256;
+    const size_t n = (size_t)nw * ntap * nkc * nmb * 256;
     hipLaunchKernelGGL(k_pack_a_multi, dim3((unsigned)((n + 255) / 256), (unsigned)L), dim3(256), 0, s, m);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
@@ -153,9 +153,9 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
     const int TS = fs_ts(T), ntile32 = TS / 32, ntiles = B * ntile32;
     const TrSave lay = tr_save_layout(B, TS, L);
     // weights -> fragment order, all layers per launch (they change every optimiser step)
-    DSD_TRY(tr_pack_multi(s, w->dilated_conv_w, L, ws + lay.w1p, kTrW3, 3, 32, 4, 1, kC, 2 * kC, kC, 3 * kC, 3, 0));
-    DSD_TRY(tr_pack_multi(s, w->cond_w, L, ws + lay.wcp, kTrW1, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1, 0));
-    DSD_TRY(tr_pack_multi(s, w->out_w, L, ws + lay.w2p, kTrW1, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1, 0));
+    DSD_TRY(tr_pack_multi(s, w->dilated_conv_w, L, ws + lay.w1p, kTrW3, 4, 3, 32, 4, 1, kC, 2 * kC, kC, 3 * kC, 3, 0));
+    DSD_TRY(tr_pack_multi(s, w->cond_w, L, ws + lay.wcp, kTrW1, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1, 0));
+    DSD_TRY(tr_pack_multi(s, w->out_w, L, ws + lay.w2p, kTrW1, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1, 0));
     {
         PackBiasMultiParams m{};
         m.pp.dst = ws + lay.b1p; m.pp.nw = 4; m.pp.nmb = 4; m.pp.split = 1; m.pp.hi_base = kC; m.pp.rows_valid = 2 * kC;
@@ -213,9 +213,14 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
     const TrBwd bl = tr_bwd_layout(B, TS, L);
     const size_t act = (size_t)B * kC * TS;
     (void)act;
-    // transposed weights in fragment order: Wo^T [256 gate channels][512 output rows]; Wd^T flipped [256 input channels][3 x 512]
-    DSD_TRY(tr_pack_multi(s, w->out_w, L, bws + bl.wotp, kTrW1, 1, 64, 2, 0, 0, kC, 2 * kC, 1, kC, 0));
-    DSD_TRY(tr_pack_multi(s, w->dilated_conv_w, L, bws + bl.wdtp, kTrW3, 3, 64, 2, 0, 0, kC, 2 * kC, 3, 3 * kC, 1));
+    // transposed weights in fragment order, two 128-row groups of four row blocks: Wo^T [256 gate channels][512 output rows]; Wd^T flipped
+    // [256 input channels][3 x 512]
+    DSD_TRY(tr_pack_multi(s, w->out_w, L, bws + bl.wotp, kTrW1, 2, 1, 64, 4, 0, 0, kC, 2 * kC, 1, kC, 0));
+    {   // each K half (gate rows / filter rows of da) of every layer as its own [256 input channels] x [3 x 256] matrix, centre taps first
+        const float* halves[2 * kTrMaxLayers];
+        for (int l = 0; l < L; ++l) { halves[2 * l] = w->dilated_conv_w[l]; halves[2 * l + 1] = w->dilated_conv_w[l] + (size_t)kC * 3 * kC; }
+        DSD_TRY(tr_pack_multi(s, halves, 2 * L, bws + bl.wdtp, kTrW3 / 2, 2, 3, 32, 4, 0, 0, kC, kC, 3, 3 * kC, 1));
+    }
     float* dxp[2] = {bws + bl.dxp0, bws + bl.dxp1};
     for (int l = L - 1; l >= 0; --l) {
         const bool last = (l == L - 1);

@@ -21,7 +21,7 @@ namespace dsd {
 constexpr float kTrInvSqrt2 = 1.0f / 1.41421354f;      // the constant layer_body multiplies (x + residual) with
 constexpr int kTrMaxLayers = 32;
 
-struct TrPtrs { const float* p[kTrMaxLayers]; };        // per-layer device pointers, passed by value
+struct TrPtrs { const float* p[2 * kTrMaxLayers]; };           // per-layer device pointers, passed by value
 
 // ------------------------------------------------------------------------------------------------------------
 // layout converters around the fused stack
@@ -156,61 +156,128 @@ __global__ void k_pack_bias_multi(const PackBiasMultiParams m) {
 // ------------------------------------------------------------------------------------------------------------
 // backward, part 1: output projection (data gradient) + gate derivative
 // ------------------------------------------------------------------------------------------------------------
+// Wave roles of both backward contractions (M = 256 output rows): wave (wr = w & 1, wk = w >> 1) multiplies the 128 rows [128 wr, +128) -
+// four row blocks, 16 MFMAs per 4 weight loads + 4 LDS reads, the operand ratio of the layer kernel - over HALF of the K range; the two
+// K halves are then summed through LDS (a fixed order: deterministic) and wave (wr, wk) finishes the row blocks 2 wk, 2 wk + 1 of its
+// row half, i.e. rows [128 wr + 64 wk, +64) = [64 w', +64) with w' = 2 wr + wk - the rows wave w' of the forward kernel owned.
+// xl: this wave's exchange slice in LDS (2 blocks x 16 registers x 64 lanes), xp: the partner's.
+__device__ __forceinline__ void trb_exchange(f32x16 (&acc)[4][1], f32x16 (&fin)[2], float* xbuf, int wr, int wk, int lane) {
+    float* mine = xbuf + ((wr * 2 + wk) * 32) * 64 + lane;              // what the partner finishes: blocks 2 (1 - wk) + {0, 1}
+    const float* theirs = xbuf + ((wr * 2 + (1 - wk)) * 32) * 64 + lane;
+#pragma unroll
+    for (int mbb = 0; mbb < 2; ++mbb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = wk ? acc[mbb][0][r] : acc[2 + mbb][0][r];
+            mine[(mbb * 16 + r) * 64] = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int mbb = 0; mbb < 2; ++mbb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float own = wk ? acc[2 + mbb][0][r] : acc[mbb][0][r];
+            const float oth = theirs[(mbb * 16 + r) * 64];
+            fin[mbb][r] = wk ? oth + own : own + oth;                   // always (K half 0) + (K half 1)
+        }
+}
+
 struct TrbGateParams {
     const float* dxp;           // gradient wrt this layer's x_out, channel-major [B][256][TS] (not read when LAST: x_out of the last layer is dead)
     const float* dsk;           // gradient wrt the skip sum [B][256][TS] (the same tensor for every layer)
     const float4* a_frag;       // saved gate pre-activation [ntiles][w4][mb4][q4][lane64]
-    const float4* wotp;         // output_projection.weight transposed, packed [w4][kc64][mb2][lane64]: row = gate channel, k = output row
+    const float4* wotp;         // output_projection.weight transposed, packed [wr2][kc64][mb4][lane64]: row = gate channel, k = output row
     float* da;                  // gradient wrt a: da[b * da_bstride + row * TS + t], rows [0,256) gate, [256,512) filter
     float* g;                   // gate output sigmoid(a_gate) * tanh(a_filter) [B][256][TS]
     long long da_bstride;
     int T, TS, ntile32;
 };
-constexpr int kTrbGateLdsBytes = 2 * kC * 32 * (int)sizeof(float);
+constexpr int kTrbGateLdsBytes = (2 * kC * 32 + 4 * 32 * 64) * (int)sizeof(float);
 
 template <bool LAST>
 __global__ __launch_bounds__(kThreads, 1) void k_trb_gate(const TrbGateParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // dy2 tile [512][32]: rows [0,256) dx' / sqrt(2), [256,512) dskip
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // dy2 tile [512][32]: rows [0,256) dx' / sqrt(2), [256,512) dskip; exchange
+    float* xbuf = smem + 2 * kC * 32;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w & 1, wk = w >> 1;
     const int tile = blockIdx.x, b = tile / p.ntile32, t0 = (tile - b * p.ntile32) * 32;
-    // saved pre-activation of this wave's gate rows (blocks 0,1) and their filter rows (blocks 2,3): requested first, used last
+    // K = 64 chunks (output rows 8 kc ..): K half 0 = the residual rows, K half 1 = the skip rows; the last layer has no residual half
+    // (its x_out is dead) and splits the skip rows
+    constexpr int NCH = LAST ? 16 : 32;
+    const int ch0 = (LAST ? 32 : 0) + NCH * wk;
+    const TileB bof{smem + ch0 * 8 * 32 + 4 * h * 32 + j, 8 * 32, NCH};
+    GemmPipe<4, 1, 32, 256, 6, TileB> pipe(p.wotp + ((size_t)wr * 64 + ch0) * 256, lane, NCH, bof);
+    const int sg = tid & 7, st = t0 + 4 * sg;
+    const bool m0 = st + 0 < p.T, m1 = st + 1 < p.T, m2 = st + 2 < p.T, m3 = st + 3 < p.T;
+    // the tile is requested in four quarters - 64 rows of each K half, the rows chunks [8 q, 8 q + 8) of either half read - all up front;
+    // quarter q + 1 is written (one barrier) at the 6-chunk boundary in front of its first chunk, so only the first quarter's latency sits
+    // in front of the first MFMA (the progressive staging of the forward layer kernel)
+    float4 vx[4][2], vs[4][2];
+    auto request = [&](int q) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const size_t off = ((size_t)b * kC + 64 * q + 32 * it + (tid >> 3)) * p.TS + st;
+            if (!LAST) vx[q][it] = *reinterpret_cast<const float4*>(p.dxp + off);
+            vs[q][it] = *reinterpret_cast<const float4*>(p.dsk + off);
+        }
+        DSD_SB();
+    };
+    auto write = [&](int q) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = 64 * q + 32 * it + (tid >> 3);
+            if (!LAST) {
+                const float4 v = vx[q][it];
+                *reinterpret_cast<float4*>(smem + row * 32 + 4 * sg) =
+                    make_float4(m0 ? v.x * kTrInvSqrt2 : 0.f, m1 ? v.y * kTrInvSqrt2 : 0.f, m2 ? v.z * kTrInvSqrt2 : 0.f, m3 ? v.w * kTrInvSqrt2 : 0.f);
+            }
+            const float4 s = vs[q][it];
+            *reinterpret_cast<float4*>(smem + (kC + row) * 32 + 4 * sg) = make_float4(m0 ? s.x : 0.f, m1 ? s.y : 0.f, m2 ? s.z : 0.f, m3 ? s.w : 0.f);
+        }
+    };
+    request(0);
+    pipe.template start_a<0, 2>();
+    request(1); request(2); request(3);
+    pipe.template start_a<2, 5>();
+    // saved pre-activation of the rows this wave finishes (forward wave w' = 2 wr + wk: gate blocks 0,1, filter blocks 2,3): behind the
+    // tile in the memory queue, in flight during the contraction
     float4 av[4][4];
     {
-        const float4* al = p.a_frag + ((size_t)tile * 4 + w) * (4 * 4 * 64) + lane;
+        const float4* al = p.a_frag + ((size_t)tile * 4 + 2 * wr + wk) * (4 * 4 * 64) + lane;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) av[mb][q] = al[(mb * 4 + q) * 64];
     }
-    constexpr int NCH = LAST ? 32 : 64, CH0 = LAST ? 32 : 0;
-    const TileB bof{smem + CH0 * 8 * 32 + 4 * h * 32 + j, 8 * 32, NCH};
-    GemmPipe<2, 1, 32, 128, 6, TileB> pipe(p.wotp + ((size_t)w * 64 + CH0) * 128, lane, NCH, bof);
-    pipe.start_a();
-    {
-        const int g = tid & 7, t = t0 + 4 * g;
-        const bool m0 = t + 0 < p.T, m1 = t + 1 < p.T, m2 = t + 2 < p.T, m3 = t + 3 < p.T;
+    DSD_SB();
+    f32x16 acc[4][1];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 32 + (tid >> 3);
-            const size_t off = ((size_t)b * kC + row) * p.TS + t;
-            if (!LAST) {
-                const float4 v = *reinterpret_cast<const float4*>(p.dxp + off);
-                *reinterpret_cast<float4*>(smem + row * 32 + 4 * g) =
-                    make_float4(m0 ? v.x * kTrInvSqrt2 : 0.f, m1 ? v.y * kTrInvSqrt2 : 0.f, m2 ? v.z * kTrInvSqrt2 : 0.f, m3 ? v.w * kTrInvSqrt2 : 0.f);
-            }
-            const float4 s = *reinterpret_cast<const float4*>(p.dsk + off);
-            *reinterpret_cast<float4*>(smem + (kC + row) * 32 + 4 * g) = make_float4(m0 ? s.x : 0.f, m1 ? s.y : 0.f, m2 ? s.z : 0.f, m3 ? s.w : 0.f);
-        }
-    }
-    __syncthreads();
-    f32x16 acc[2][1];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][0][r] = 0.f;
-    pipe.start_b();
-    pipe.run(acc, 0, NCH);
+    if (LAST) {
+        write(0); write(1); write(2); write(3);
+        __syncthreads();
+        pipe.start_b();
+        pipe.run(acc, 0, NCH);
+    } else {
+        write(0);
+        __syncthreads();
+        pipe.start_b();
+        pipe.run(acc, 0, 6);
+        write(1);
+        __syncthreads();
+        pipe.run(acc, 6, 12);
+        write(2);
+        __syncthreads();
+        pipe.run(acc, 12, 18);
+        write(3);
+        __syncthreads();
+        pipe.run(acc, 18, NCH);
+    }
+    f32x16 fin[2];
+    trb_exchange(acc, fin, xbuf, wr, wk, lane);
     // gate derivative (net.py:73-74): g = s * th, da_gate = dg * th * s (1 - s), da_filter = dg * s * (1 - th^2)
     const int t = t0 + j;
     const bool ok = t < p.T;
@@ -221,35 +288,24 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_gate(const TrbGateParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float ag = f4at(av[mb][r >> 2], r & 3), af = f4at(av[mb + 2][r >> 2], r & 3);
-            const float sg = 1.f / (1.f + expf(-ag)), th = tanhf(af);
-            const float dg = acc[mb][0][r];
-            const int row = 64 * w + 32 * mb + frag_row(r, h);
-            dab[(size_t)row * p.TS] = ok ? dg * th * (sg * (1.f - sg)) : 0.f;
-            dab[(size_t)(kC + row) * p.TS] = ok ? dg * sg * (1.f - th * th) : 0.f;
-            gb[(size_t)row * p.TS] = ok ? sg * th : 0.f;
+            const float sg_ = 1.f / (1.f + expf(-ag)), th = tanhf(af);
+            const float dg = fin[mb][r];
+            const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
+            dab[(size_t)row * p.TS] = ok ? dg * th * (sg_ * (1.f - sg_)) : 0.f;
+            dab[(size_t)(kC + row) * p.TS] = ok ? dg * sg_ * (1.f - th * th) : 0.f;
+            gb[(size_t)row * p.TS] = ok ? sg_ * th : 0.f;
         }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // backward, part 2: data gradient of the dilated convolution + residual path + step-projection gradient
 // ------------------------------------------------------------------------------------------------------------
-// B functor of the transposed conv over a da tile [512][LD] (column kHalo = frame 0 of the tile): chunks [0, 64) = centre tap of channel
-// group kc, then (tap 0 -> column offset -dil, tap 2 -> +dil) pairs - k_pack_a's centre-first order with 64 groups.
-template <int LD>
-struct ConvTB {
-    const float* yc; int dil;
-    __device__ __forceinline__ const float* operator()(int it, int u) const {
-        int kc = 6 * it + u;
-        kc = (kc < 192) ? kc : 191;
-        if (kc < 64) return yc + kc * (8 * LD);
-        const int idx = kc - 64;
-        return yc + (idx >> 1) * (8 * LD) + ((idx & 1) ? dil : -dil);
-    }
-};
-
+// K order of the transposed conv: K half hk = the 256 da rows [256 hk, +256) (hk = 0 gate rows, 1 filter rows) as 96 chunks in the order of
+// the forward conv (ConvB: 32 centre-tap chunks of 8 rows, then the (offset -dil, +dil) pairs) - each half is packed as its own matrix
+// [hk][wr2][kc96][mb4][lane64], so a wave walks ITS rows in ascending order and the tile can be staged progressively.
 struct TrbConvParams {
     const float* da;            // da[b * da_bstride + row * TS + t], 512 rows, zero for t >= T
-    const float4* wdtp;         // dilated_conv.weight flipped + transposed, packed [w4][kc192][mb2][lane64]: row = input channel, k = (output row, tap)
+    const float4* wdtp;         // dilated_conv.weight flipped + transposed, packed [hk2][wr2][kc96][mb4][lane64]: row = input channel, k = (da row, tap)
     const float* dxp;           // gradient wrt this layer's x_out [B][256][TS] (residual path; not read when LAST)
     float* dx_out;              // gradient wrt this layer's x_in [B][256][TS]
     float* dds_part;            // [ntiles][256] per-tile row sums of dy
@@ -257,30 +313,47 @@ struct TrbConvParams {
     int T, TS, ntile32, dil;
 };
 constexpr int kTrbConvLD = 32 + 2 * kHalo;
-constexpr int kTrbConvLdsBytes = 2 * kC * kTrbConvLD * (int)sizeof(float);
+constexpr int kTrbConvLdsBytes = (2 * kC * kTrbConvLD + 4 * 32 * 64) * (int)sizeof(float);
 
 template <bool LAST>
 __global__ __launch_bounds__(kThreads, 1) void k_trb_conv(const TrbConvParams p) {
     constexpr int LD = kTrbConvLD;
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // da tile [512][48]
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // da tile [512][48]; exchange
+    float* xbuf = smem + 2 * kC * LD;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w & 1, wk = w >> 1;
     const int tile = blockIdx.x, b = tile / p.ntile32, t0 = (tile - b * p.ntile32) * 32;
-    const ConvTB<LD> bof{smem + 4 * h * LD + kHalo + j, p.dil};
-    GemmPipe<2, 1, LD, 128, 6, ConvTB<LD>> pipe(p.wdtp + (size_t)w * (192 * 128), lane, 192, bof);
-    pipe.start_a();
-    {
-        const float* src = p.da + (size_t)b * p.da_bstride;
-#pragma unroll 4
-        for (int it = 0; it < 24; ++it) {
-            const int idx = it * kThreads + tid, row = idx / 12, g = idx - row * 12;
+    const ConvB<LD> bof{smem + (wk * kC + 4 * h) * LD + kHalo + j, p.dil, 0};
+    GemmPipe<4, 1, LD, 256, 6, ConvB<LD>> pipe(p.wdtp + ((size_t)(wk * 2 + wr) * 96) * 256, lane, 96, bof);
+    // progressive staging (see k_trb_gate): quarter q = rows [64 q, +64) of either K half with their halo columns, 6 float4 per thread
+    const float* src = p.da + (size_t)b * p.da_bstride;
+    float4 sv[4][6];
+    auto request = [&](int q) {
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int idx = it * kThreads + tid, rq = idx / 12, g = idx - rq * 12;
+            const int row = (rq < 64) ? 64 * q + rq : kC + 64 * q + (rq - 64);
             const int t = t0 - kHalo + 4 * g;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(src + (size_t)row * p.TS + t);
-            *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
+            const bool in = (t >= 0) && (t < p.TS);
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)row * p.TS + (in ? t : t0));
+            sv[q][it] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    }
-    // residual-path gradient at this lane's fragment positions: requested before the contraction
+        DSD_SB();
+    };
+    auto write = [&](int q) {
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int idx = it * kThreads + tid, rq = idx / 12, g = idx - rq * 12;
+            const int row = (rq < 64) ? 64 * q + rq : kC + 64 * q + (rq - 64);
+            *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = sv[q][it];
+        }
+    };
+    request(0);
+    pipe.template start_a<0, 2>();
+    request(1); request(2); request(3);
+    pipe.template start_a<2, 5>();
+    // residual-path gradient at the fragment positions this wave finishes: behind the tile in the memory queue
     const int t = t0 + j;
     const bool ok = t < p.T;
     float rv[2][16];
@@ -288,24 +361,37 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_conv(const TrbConvParams p)
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = 64 * w + 32 * mb + frag_row(r, h);
+            const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
             rv[mb][r] = LAST ? 0.f : p.dxp[((size_t)b * kC + row) * p.TS + t];
         }
-    __syncthreads();
-    f32x16 acc[2][1];
+    DSD_SB();
+    f32x16 acc[4][1];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][0][r] = 0.f;
+    write(0);
+    __syncthreads();
     pipe.start_b();
-    pipe.run(acc, 0, 192);
+    pipe.run(acc, 0, 6);
+    write(1);
+    __syncthreads();
+    pipe.run(acc, 6, 12);
+    write(2);
+    __syncthreads();
+    pipe.run(acc, 12, 18);
+    write(3);
+    __syncthreads();
+    pipe.run(acc, 18, 96);
+    f32x16 fin[2];
+    trb_exchange(acc, fin, xbuf, wr, wk, lane);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = 64 * w + 32 * mb + frag_row(r, h);
+            const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
             // frames >= T are zero padding of y in the forward pass (net.py:69-71 pads the conv input): no gradient flows into them
-            const float dy = ok ? acc[mb][0][r] : 0.f;
+            const float dy = ok ? fin[mb][r] : 0.f;
             p.dx_out[((size_t)b * kC + row) * p.TS + t] = ok ? rv[mb][r] * kTrInvSqrt2 + dy : 0.f;
             float s = dy;
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
@@ -367,7 +453,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
     const int srow = tid >> 3, sg = tid & 7;
     float4 av[4], bv[8];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    int a_valid = 0;
+    int a_valid = 0, b_shift = 0;
     const float a_scale = d.a_scale;
     const int shift = d.shift;
     auto fetch = [&](int tile) {
@@ -377,23 +463,17 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const float4*>(ap + (size_t)(32 * q) * p.TS);
         a_valid = p.T - t;                                  // frames >= T carry no gradient: masked when the tile is written to LDS
+        // B: frames t + shift .. + 3 of 256 rows.  One dword-aligned 16-byte load per row from an address clamped into the row, branch-free
+        // (the loads of a step are in flight during the previous step's MFMAs); where the window leaves [0, TS) - first / last tile of an
+        // utterance under a tap shift - the elements are shifted into place and the outside ones zeroed when the tile is written to LDS
         const int tb = t + shift;
-        const float* bp = d.bsrc + (size_t)b * d.b_bstride + (size_t)srow * p.TS + tb;
-        if (tb >= 0 && tb + 3 < p.TS) {
+        const int tbc = min(max(tb, 0), p.TS - 4);
+        b_shift = tb - tbc;
+        const float* bp = d.bsrc + (size_t)b * d.b_bstride + (size_t)srow * p.TS + tbc;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const tr_f4u v = *reinterpret_cast<const tr_f4u*>(bp + (size_t)(32 * q) * p.TS);
-                bv[q] = make_float4(v.x, v.y, v.z, v.w);
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float* r = bp + (size_t)(32 * q) * p.TS;
-                float4 v;
-                v.x = (tb + 0 >= 0 && tb + 0 < p.TS) ? r[0] : 0.f; v.y = (tb + 1 >= 0 && tb + 1 < p.TS) ? r[1] : 0.f;
-                v.z = (tb + 2 >= 0 && tb + 2 < p.TS) ? r[2] : 0.f; v.w = (tb + 3 >= 0 && tb + 3 < p.TS) ? r[3] : 0.f;
-                bv[q] = v;
-            }
+        for (int q = 0; q < 8; ++q) {
+            const tr_f4u v = *reinterpret_cast<const tr_f4u*>(bp + (size_t)(32 * q) * p.TS);
+            bv[q] = make_float4(v.x, v.y, v.z, v.w);
         }
         DSD_SB();
     };
@@ -407,6 +487,19 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
             v.z = (a_valid > 2) ? v.z * a_scale : 0.f; v.w = (a_valid > 3) ? v.w * a_scale : 0.f;
             *reinterpret_cast<float4*>(As + (srow + 32 * q) * LD + 4 * sg) = v;
             bsum[q] += (v.x + v.y) + (v.z + v.w);
+        }
+        if (b_shift != 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = bv[q];
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int idx = e + b_shift;            // element of the loaded window that holds frame t + shift + e, if any
+                    o[e] = (idx == 0) ? v.x : (idx == 1) ? v.y : (idx == 2) ? v.z : (idx == 3) ? v.w : 0.f;
+                }
+                bv[q] = make_float4(o[0], o[1], o[2], o[3]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(Bs + (srow + 32 * q) * LD + 4 * sg) = bv[q];
