@@ -379,17 +379,15 @@ def main_train(args):
     el, loss = _row_time(step, args, world, device, dist)
     assert bool(torch.isfinite(loss)), 'non-finite loss'
     if rank == 0:
-        # dominant kernel: k_fs_conv<2> as the dilated convolution (256 -> 512, k = 3), forward; one launch timed with events on the launch stream
-        from diffsinger_amd.fs2 import PackedWeight, padded_frames
-        from diffsinger_amd import _lib
-        lib = _lib.load()
-        w = torch.randn(512, 256, 3, device=device) * (256 * 3) ** -0.5
-        x = torch.randn(B, 256, padded_frames(T), device=device)
-        out = torch.empty(B, 512, padded_frames(T), device=device)
-        wp = PackedWeight().get(w)
-        sptr = torch.cuda.current_stream(device).cuda_stream
-        launch = lambda: _lib.check(lib.dsf_conv1d_dilated(x.data_ptr(), wp.data_ptr(), None, out.data_ptr(), B, 256, 512, 3, 1, T, sptr), 'dsf_conv1d_dilated')
-        launch()
+        # dominant kernel of the fused stack: k_tr_wgrad - here as the weight gradient of the dilated convolution (512 x 256 x 3) through
+        # dsf_conv1d_wgrad2, launches timed with events on the launch stream; the split-K reduction kernel behind it is part of the figure
+        from diffsinger_amd import train_fused
+        from diffsinger_amd.fs2 import padded_frames
+        dyw = torch.randn(B, 512, padded_frames(T), device=device)
+        xw = torch.randn(B, 256, padded_frames(T), device=device)
+        launch = lambda: train_fused.conv1d_wgrad2(dyw, xw, 3, 1, T)
+        for _ in range(3):
+            launch()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(20):
@@ -399,17 +397,20 @@ def main_train(args):
         ms = ev0.elapsed_time(ev1) / 20
         flop = 2 * 512 * 768 * B * T
         achieved = flop / (ms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': 'k_fs_conv<2>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+        fused = train_fused.enabled() and train_fused.supported(net)
+        roof = {'bound': 'mfma', 'kernel': 'k_tr_wgrad (+ k_tr_wgrad_reduce)', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_launch_ms': ms, 'flop_per_launch': flop,
                 'algorithmic_bytes_per_launch': 4 * B * T * (256 + 512) + 4 * 512 * 768,
-                'note': 'the dilated convolution of one residual block, forward (its data gradient is the same kernel with the flipped, transposed weight); '
-                        'eager launch incl. the ctypes call.  No PMC pass of this kernel is committed yet'}
+                'note': 'the weight gradient of the dilated convolution of one residual block as a stand-alone launch (12 output tiles x 16 frame '
+                        'splits = 192 workgroups on 256 CUs; inside the training step the layer\'s three weight gradients are ONE launch of 20 tiles '
+                        'x 12 splits: profiles/r02o_train_kernel_stats_8x1024.txt, 10.7 GFLOP in 113 us = 0.60 of peak); eager launches incl. the '
+                        'ctypes calls and the reduction kernel.  No PMC pass of this kernel is committed yet'}
         value = world * B * T * args.steps / el
         res = {'metric': 'frames/sec (whole node) through one denoiser training step: q_sample + DiffNet forward + L1 + backward, T=1024', 'value': value,
                'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': f'SURVEY 8 row f3: GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:213-231) of the DiffSpeech denoiser, '
-                                      f'batch={B} x T={T} per GPU, forward + backward on the HIP training operators', 'preset': PRESET,
+                                      f'batch={B} x T={T} per GPU, forward + backward on the ' + ('fused residual-stack kernels (csrc/train_kernels.hpp)' if fused else 'HIP training operators'), 'preset': PRESET,
                           'optimizer': 'not included (diffsinger_amd/train_dist.py)', 'sharding': 'replicas (no gradient exchange in this bench)'},
                'roofline': roof, 'model_tflops_gemm': world * B * T * 3 * F_TRAIN_FWD * args.steps / el / 1e12}
         if world == 1 and not args.no_cpu_baseline:

@@ -88,7 +88,8 @@ static int tr_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
     done = true;
     return DSD_OK;
 }
@@ -108,7 +109,11 @@ static int tr_nsplit(int ndesc, int ntile) {
 static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int T, int TS) {
     wp.B = B; wp.T = T; wp.TS = TS;
     wp.nsplit = tr_nsplit(ndesc, B * TS / 32);
-    hipLaunchKernelGGL(k_tr_wgrad, dim3((unsigned)ndesc, (unsigned)wp.nsplit), dim3(kThreads), kTrWgLdsBytes, s, wp);
+    const int total = ndesc * wp.nsplit;
+    wp.ndesc = ndesc; wp.xcd_q = total / 8; wp.xcd_r = total % 8;
+    static const bool pipe = []() { const char* e = getenv("DSD_WGRAD_PIPE"); return !(e && e[0] == '0'); }();      // developer switch (A/B on one box)
+    if (pipe) hipLaunchKernelGGL(k_tr_wgrad<true>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
+    else hipLaunchKernelGGL(k_tr_wgrad<false>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_tr_wgrad_reduce, dim3((unsigned)ndesc, 128), dim3(256), 0, s, wp);
     HIP_TRY(hipGetLastError());
@@ -232,7 +237,7 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
             TrbGateParams p{};
             p.dxp = dxp_in; p.dsk = dskip; p.a_frag = (const float4*)(sws + lay.A + (size_t)l * lay.A_l);
             p.wotp = (const float4*)(bws + bl.wotp + (size_t)l * kTrW1);
-            p.da = da; p.g = bws + bl.g; p.da_bstride = da_bs; p.T = T; p.TS = TS; p.ntile32 = ntile32;
+            p.da = da; p.g = bws + bl.g; p.da_bstride = da_bs; p.T = T; p.TS = TS; p.ntile32 = ntile32; p.xcd_q = ntiles / 8; p.xcd_r = ntiles % 8;
             if (last) hipLaunchKernelGGL(k_trb_gate<true>, dim3((unsigned)ntiles), dim3(kThreads), kTrbGateLdsBytes, s, p);
             else hipLaunchKernelGGL(k_trb_gate<false>, dim3((unsigned)ntiles), dim3(kThreads), kTrbGateLdsBytes, s, p);
             HIP_TRY(hipGetLastError());
@@ -241,7 +246,7 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
             TrbConvParams p{};
             p.da = da; p.wdtp = (const float4*)(bws + bl.wdtp + (size_t)l * kTrW3); p.dxp = dxp_in; p.dx_out = dx_out;
             p.dds_part = bws + bl.dds_part + (size_t)l * ntiles * kC; p.da_bstride = da_bs;
-            p.T = T; p.TS = TS; p.ntile32 = ntile32; p.dil = w->dilations[l];
+            p.T = T; p.TS = TS; p.ntile32 = ntile32; p.dil = w->dilations[l]; p.xcd_q = ntiles / 8; p.xcd_r = ntiles % 8;
             if (last) hipLaunchKernelGGL(k_trb_conv<true>, dim3((unsigned)ntiles), dim3(kThreads), kTrbConvLdsBytes, s, p);
             else hipLaunchKernelGGL(k_trb_conv<false>, dim3((unsigned)ntiles), dim3(kThreads), kTrbConvLdsBytes, s, p);
             HIP_TRY(hipGetLastError());

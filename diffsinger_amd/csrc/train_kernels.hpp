@@ -21,6 +21,13 @@ namespace dsd {
 constexpr float kTrInvSqrt2 = 1.0f / 1.41421354f;      // the constant layer_body multiplies (x + residual) with
 constexpr int kTrMaxLayers = 32;
 
+// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2: XCD x takes the CONTIGUOUS range
+// [x q + min(x, r), ...) of a 1-D index space of 8 q + r items, so that neighbours in that space share an L2 (the map of layer_body).
+__device__ __forceinline__ int xcd_item(int lin, int q, int r) {
+    const int xcd = lin & 7;
+    return xcd * q + min(xcd, r) + (lin >> 3);
+}
+
 struct TrPtrs { const float* p[2 * kTrMaxLayers]; };           // per-layer device pointers, passed by value
 
 // ------------------------------------------------------------------------------------------------------------
@@ -191,6 +198,7 @@ struct TrbGateParams {
     float* g;                   // gate output sigmoid(a_gate) * tanh(a_filter) [B][256][TS]
     long long da_bstride;
     int T, TS, ntile32;
+    int xcd_q, xcd_r;           // XCD-aware workgroup -> tile map (ntiles = 8 xcd_q + xcd_r)
 };
 constexpr int kTrbGateLdsBytes = (2 * kC * 32 + 4 * 32 * 64) * (int)sizeof(float);
 
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_gate(const TrbGateParams p)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w & 1, wk = w >> 1;
-    const int tile = blockIdx.x, b = tile / p.ntile32, t0 = (tile - b * p.ntile32) * 32;
+    const int tile = xcd_item(blockIdx.x, p.xcd_q, p.xcd_r), b = tile / p.ntile32, t0 = (tile - b * p.ntile32) * 32;
     // K = 64 chunks (output rows 8 kc ..): K half 0 = the residual rows, K half 1 = the skip rows; the last layer has no residual half
     // (its x_out is dead) and splits the skip rows
     constexpr int NCH = LAST ? 16 : 32;
@@ -311,6 +319,7 @@ struct TrbConvParams {
     float* dds_part;            // [ntiles][256] per-tile row sums of dy
     long long da_bstride;
     int T, TS, ntile32, dil;
+    int xcd_q, xcd_r;           // XCD-aware workgroup -> tile map: a tile's halo columns come from tiles behind the same L2
 };
 constexpr int kTrbConvLD = 32 + 2 * kHalo;
 constexpr int kTrbConvLdsBytes = (2 * kC * kTrbConvLD + 4 * 32 * 64) * (int)sizeof(float);
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_conv(const TrbConvParams p)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w & 1, wk = w >> 1;
-    const int tile = blockIdx.x, b = tile / p.ntile32, t0 = (tile - b * p.ntile32) * 32;
+    const int tile = xcd_item(blockIdx.x, p.xcd_q, p.xcd_r), b = tile / p.ntile32, t0 = (tile - b * p.ntile32) * 32;
     const ConvB<LD> bof{smem + (wk * kC + 4 * h) * LD + kHalo + j, p.dil, 0};
     GemmPipe<4, 1, LD, 256, 6, ConvB<LD>> pipe(p.wdtp + ((size_t)(wk * 2 + wr) * 96) * 256, lane, 96, bof);
     // progressive staging (see k_trb_gate): quarter q = rows [64 q, +64) of either K half with their halo columns, 6 float4 per thread
@@ -424,6 +433,8 @@ struct TrWgParams {
     float* part;                // [ntile_desc][nsplit][128][256]
     float* part_b;              // [ntile_desc][nsplit][128]
     int nsplit, B, T, TS;
+    int ndesc, xcd_q, xcd_r;    // 1-D grid of ndesc * nsplit workgroups, XCD x takes a contiguous range of (split, tile) pairs: the workgroups
+                                // behind one L2 contract (nearly) the same frames, so every operand line is fetched from the fabric by ~1.3 L2s, not 8
 };
 constexpr int kTrWgLD = 36;
 constexpr int kTrWgStage = (128 + 256) * kTrWgLD;
@@ -431,14 +442,16 @@ constexpr int kTrWgLdsBytes = 2 * kTrWgStage * (int)sizeof(float);
 
 struct __attribute__((aligned(4))) tr_f4u { float x, y, z, w; };       // a 16-byte load that is only dword-aligned
 
+template <bool PIPE>
 __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
     constexpr int LD = kTrWgLD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const TrWgTile& d = p.tile[blockIdx.x];
+    const int item = xcd_item(blockIdx.x, p.xcd_q, p.xcd_r);
+    const int split = item / p.ndesc, desc = item - split * p.ndesc;
+    const TrWgTile& d = p.tile[desc];
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w & 1, wn = w >> 1;
-    const int split = blockIdx.y;
     const int tiles_per_utt = p.TS / 32, ntile = p.B * tiles_per_utt;
     const int per = (ntile + p.nsplit - 1) / p.nsplit;
     const int tile_lo = split * per, tile_hi = min(ntile, tile_lo + per);
@@ -504,35 +517,82 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(Bs + (srow + 32 * q) * LD + 4 * sg) = bv[q];
     };
-    if (tile_lo < tile_hi) {
+    // Software pipeline over the 32-frame steps (one wave per SIMD: nothing else hides a bubble).  At the top of step k LDS buffer k & 1
+    // holds tile k, the staging registers hold tile k + 1 (requested a whole step ago) and the fragments of chunk 0 are already in
+    // registers.  Step k: chunk 1's fragments are requested, tile k + 1 goes to the other buffer (free since the barrier of step k - 1),
+    // tile k + 2 is requested, then the MFMAs of chunks 0..2 run with the next chunk's fragments always in flight; behind chunk 3's reads
+    // comes the ONE barrier of the step (every wave is done reading this buffer, every wave's writes of the other one have landed), the
+    // fragments of the next step's chunk 0 are requested, and only then chunk 3's 32 MFMAs are issued - they cover barrier skew and LDS latency.
+    const int nstep = tile_hi - tile_lo;
+    float4 fa[2][2], fb[2][4];
+    auto frags = [&](int set, int buf, int c) {
+        const float* ap = smem + buf * kTrWgStage + (64 * wm + i) * LD + 4 * h + 8 * c;
+        const float* bp = smem + buf * kTrWgStage + 128 * LD + (128 * wn + i) * LD + 4 * h + 8 * c;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) fa[set][mb] = *reinterpret_cast<const float4*>(ap + 32 * mb * LD);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) fb[set][nb] = *reinterpret_cast<const float4*>(bp + 32 * nb * LD);
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma32(f4at(fa[set][mb], s), f4at(fb[set][nb], s), acc[mb][nb]);
+    };
+  if (PIPE) {
+    if (nstep > 0) {
+        fetch(tile_lo);
+        stash(0);
+        if (nstep > 1) fetch(tile_lo + 1);
+    }
+    __syncthreads();
+    if (nstep > 0) frags(0, 0, 0);
+    for (int k = 0; k < nstep; ++k) {
+        const int cur = k & 1;
+        frags(1, cur, 1);
+        if (k + 1 < nstep) stash(cur ^ 1);
+        if (k + 2 < nstep) fetch(tile_lo + k + 2);
+        DSD_SB();
+        mma(0);
+        DSD_SB();
+        frags(0, cur, 2);
+        DSD_SB();
+        mma(1);
+        DSD_SB();
+        frags(1, cur, 3);
+        DSD_SB();
+        mma(0);
+        DSD_SB();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k + 1 < nstep) frags(0, cur ^ 1, 0);
+        DSD_SB();
+        mma(1);
+        DSD_SB();
+    }
+  } else {
+    // the plain form (kept for A/B runs on one box): fragments read right in front of their MFMAs, the next tile written behind the step
+    if (nstep > 0) {
         fetch(tile_lo);
         stash(0);
     }
     __syncthreads();
-    for (int tile = tile_lo; tile < tile_hi; ++tile) {
-        const int cur = (tile - tile_lo) & 1;
-        const bool more = tile + 1 < tile_hi;
-        if (more) fetch(tile + 1);
-        const float* ap = smem + cur * kTrWgStage + (64 * wm + i) * LD + 4 * h;
-        const float* bp = smem + cur * kTrWgStage + 128 * LD + (128 * wn + i) * LD + 4 * h;
+    for (int k = 0; k < nstep; ++k) {
+        const int cur = k & 1;
+        const bool more = k + 1 < nstep;
+        if (more) fetch(tile_lo + k + 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float4 af[2], bf[4];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) af[mb] = *reinterpret_cast<const float4*>(ap + 32 * mb * LD + 8 * c);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) bf[nb] = *reinterpret_cast<const float4*>(bp + 32 * nb * LD + 8 * c);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma32(f4at(af[mb], s), f4at(bf[nb], s), acc[mb][nb]);
+            frags(0, cur, c);
+            mma(0);
         }
         if (more) stash(cur ^ 1);
         __syncthreads();
     }
-    float* out = p.part + ((size_t)blockIdx.x * p.nsplit + split) * (128 * 256);
+  }
+    float* out = p.part + ((size_t)desc * p.nsplit + split) * (128 * 256);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -544,7 +604,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
         for (int q = 0; q < 4; ++q) {
             float sb = bsum[q];
             sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64); sb += __shfl_xor(sb, 4, 64);
-            if (sg == 0) p.part_b[((size_t)blockIdx.x * p.nsplit + split) * 128 + srow + 32 * q] = sb;
+            if (sg == 0) p.part_b[((size_t)desc * p.nsplit + split) * 128 + srow + 32 * q] = sb;
         }
     }
 }

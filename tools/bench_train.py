@@ -40,7 +40,8 @@ def reference_style_forward(net, spec, t, cond):
     return F.conv1d(x, net.output_projection.weight, net.output_projection.bias)[:, None]
 
 
-def run(B, T, reps, torch_conv=False, reference_style=False):
+def run(B, T, reps, torch_conv=False, reference_style=False, fused=True):
+    os.environ['DSD_TRAIN_FUSED'] = '1' if (fused and not torch_conv and not reference_style) else '0'
     pre = presets()['lj_ds_beta6']
     hparams.clear()
     diffsinger_amd.use_preset('lj_ds_beta6')
@@ -84,7 +85,8 @@ def run(B, T, reps, torch_conv=False, reference_style=False):
         train.ConvCache.__call__ = orig
     frames = B * T
     impl = ('reference-style PyTorch-ROCm eager graph (MIOpen convolutions, ATen element-wise ops)' if reference_style else
-            'torch conv1d (MIOpen) inside the HIP graph (fused glue kept)' if torch_conv else 'HIP operators (dsf_conv1d_dilated / dsf_conv1d_wgrad / dsf_train_*)')
+            'torch conv1d (MIOpen) inside the HIP graph (fused glue kept)' if torch_conv else
+            'fused residual stack (dsf_stack_forward / dsf_stack_backward)' if fused else 'HIP operators (dsf_conv1d_dilated / dsf_conv1d_wgrad / dsf_train_*)')
     print(json.dumps({'impl': impl,
                       'B': B, 'T': T, 'ms_per_step_fwd_bwd': sec * 1e3, 'frames_per_s': frames / sec,
                       'tflops_gemm': 3 * F_FWD * frames / sec / 1e12, 'loss': float(loss)}), flush=True)
@@ -100,5 +102,6 @@ if __name__ == '__main__':
         sys.exit(0)
     for B, T in ((8, 1024), (48, 512)):
         run(B, T, reps)
+        run(B, T, reps, fused=False)
         run(B, T, reps, torch_conv=True)
         run(B, T, reps, reference_style=True)
