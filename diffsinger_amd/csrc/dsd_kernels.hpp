@@ -263,13 +263,22 @@ __device__ __forceinline__ void store16(float4* base_uniform, int idx, const flo
     }
 }
 
+// 4-byte WRITE-THROUGH store (sc1) at float index idx behind a wave-uniform base: outputs of the training kernels that the NEXT kernel reads
+// leave the L2 as they are written instead of in the release at the kernel boundary
+__device__ __forceinline__ void store4_wt(float* base_uniform, int idx, float v) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7ffffff0, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, idx * 4, 0, 16);      // aux 16 = sc1
+}
+
 __device__ __forceinline__ float f4at(const float4& v, int e) { return (e == 0) ? v.x : (e == 1) ? v.y : (e == 2) ? v.z : v.w; }
 
 // What the TRAINING forward (csrc/train_kernels.hpp) keeps of a layer for its backward pass; the
 // inference kernels instantiate the body with TRAIN = false and none of this exists in their code.
 struct LayerSave {
-    float* y_cm;            // y = x + step projection, channel-major [B][C][TS], zero for t >= T (B operand of the conv weight gradient)
+    float* y_cm;            // y = x + step projection, channel-major rows of y_rs floats: y_cm[(b * C + row) * y_rs + t], zero for t >= T (B operand
+                            // of the conv weight gradient; the rows carry zero pads on both sides so that a tap shift never leaves a row)
     float4* a_frag;         // pre-activation of the gate (conv + conditioner projection + biases) in accumulator-fragment order, the layout of `cp`
+    int y_rs;
 };
 
 template <int NB, bool LAST, bool TRAIN>
@@ -370,7 +379,7 @@ __device__ __forceinline__ void layer_body(const LayerParams& p, const LayerSave
                 v.z = (ok && t + 2 < p.T) ? v.z + d : 0.f;
                 v.w = (ok && t + 3 < p.T) ? v.w + d : 0.f;
                 *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 32 * nbi + 4 * c4) = v;
-                if (TRAIN && ok) *reinterpret_cast<float4*>(sv.y_cm + ((size_t)b * kC + row) * p.TS + t) = v;
+                if (TRAIN && ok) store16<true>(reinterpret_cast<float4*>(sv.y_cm + (size_t)b * kC * sv.y_rs), (row * sv.y_rs + t) >> 2, v);
             }
         {
             const int row = 64 * q + (tid >> 2);
@@ -450,13 +459,13 @@ __device__ __forceinline__ void layer_body(const LayerParams& p, const LayerSave
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             if (nb >= ntv) continue;
-            float4* al = sv.a_frag + ((size_t)(tile0 + nb) * 4 + w) * (4 * 4 * 64) + lane;
+            float4* al = sv.a_frag + ((size_t)(tile0 + nb) * 4 + w) * (4 * 4 * 64);      // wave-uniform; write-through like x_out / skip
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 c = cpv[mb][nb][q], a = get4(acc[mb][nb], q);
-                    al[(mb * 4 + q) * 64] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+                    store16<true>(al, (mb * 4 + q) * 64 + lane, make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w));
                 }
         }
     }
@@ -568,7 +577,7 @@ __device__ __forceinline__ void layer_body(const LayerParams& p, const LayerSave
 
 template <int NB, bool LAST>
 __global__ __launch_bounds__(kThreads, 1) void k_layer(const LayerParams p) {
-    layer_body<NB, LAST, false>(p, LayerSave{nullptr, nullptr});
+    layer_body<NB, LAST, false>(p, LayerSave{nullptr, nullptr, 0});
 }
 // the same layer in a training forward: additionally writes y and the gate pre-activation (LayerSave)
 template <bool LAST>

@@ -25,7 +25,7 @@ static TrSave tr_save_layout(int B, int TS, int L) {
     s.b1p = o; o += tr_al((size_t)L * 512);
     s.cp_l = ntiles * 16384; s.cp = o; o += L * s.cp_l;
     s.X_l = ntiles * 8192; s.X = o; o += L * s.X_l;
-    s.Y_l = (size_t)B * kC * TS; s.Y = o; o += L * s.Y_l;
+    s.Y_l = (size_t)B * kC * (TS + 2 * kTrYPad); s.Y = o; o += tr_al(L * s.Y_l);      // rows padded: kTrYPad zero floats on both sides
     s.A_l = ntiles * 16384; s.A = o; o += L * s.A_l;
     s.skip = o; o += ntiles * 8192;
     s.bsum = o; o += 1024;
@@ -106,13 +106,13 @@ static int tr_nsplit(int ndesc, int ntile) {
     return std::min(ns, ntile);
 }
 
-static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int T, int TS) {
+// fix: some B operand is not padded against its tap shift (k_tr_wgrad<true>)
+static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int T, int TS, bool fix) {
     wp.B = B; wp.T = T; wp.TS = TS;
     wp.nsplit = tr_nsplit(ndesc, B * TS / 32);
     const int total = ndesc * wp.nsplit;
     wp.ndesc = ndesc; wp.xcd_q = total / 8; wp.xcd_r = total % 8;
-    static const bool pipe = []() { const char* e = getenv("DSD_WGRAD_PIPE"); return !(e && e[0] == '0'); }();      // developer switch (A/B on one box)
-    if (pipe) hipLaunchKernelGGL(k_tr_wgrad<true>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
+    if (fix) hipLaunchKernelGGL(k_tr_wgrad<true>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
     else hipLaunchKernelGGL(k_tr_wgrad<false>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_tr_wgrad_reduce, dim3((unsigned)ndesc, 128), dim3(256), 0, s, wp);
@@ -181,6 +181,11 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
         hipLaunchKernelGGL(k_condproj, dim3((unsigned)ntiles, (unsigned)L), dim3(kThreads), kC * 32 * 4, s, p);
         HIP_TRY(hipGetLastError());
     }
+    {
+        const size_t rows = (size_t)L * B * kC;
+        hipLaunchKernelGGL(k_tr_zero_pads, dim3((unsigned)std::min<size_t>((rows * 2 * kTrYPad + 255) / 256, 8192)), dim3(256), 0, s, ws + lay.Y, rows, TS + 2 * kTrYPad);
+        HIP_TRY(hipGetLastError());
+    }
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
         LayerParams p{};
@@ -197,7 +202,7 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
         p.wt_stores = 1;
         p.xcd_q = ntiles / 8; p.xcd_r = ntiles % 8;
         p.dbg = nullptr;
-        const LayerSave sv{ws + lay.Y + (size_t)l * lay.Y_l, (float4*)(ws + lay.A + (size_t)l * lay.A_l)};
+        const LayerSave sv{ws + lay.Y + (size_t)l * lay.Y_l + kTrYPad, (float4*)(ws + lay.A + (size_t)l * lay.A_l), TS + 2 * kTrYPad};
         if (last) hipLaunchKernelGGL(k_tr_layer<true>, dim3((unsigned)ntiles), dim3(kThreads), layer_lds_bytes<1>(), s, p, sv);
         else hipLaunchKernelGGL(k_tr_layer<false>, dim3((unsigned)ntiles), dim3(kThreads), layer_lds_bytes<1>(), s, p, sv);
         HIP_TRY(hipGetLastError());
@@ -254,25 +259,26 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         // the layer's weight gradients: 12 (dilated conv: 4 row tiles x 3 taps) + 4 (conditioner projection) + 4 or 2 (output projection) tiles
         TrWgParams wp{};
         int nd = 0;
-        const float* y = sws + lay.Y + (size_t)l * lay.Y_l;
+        const float* y = sws + lay.Y + (size_t)l * lay.Y_l + kTrYPad;
+        const int yrs = TS + 2 * kTrYPad;
         const int dil = w->dilations[l];
         for (int mt = 0; mt < 4; ++mt)
             for (int tap = 0; tap < 3; ++tap) {
                 TrWgTile& d = wp.tile[nd++];
-                d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = y; d.b_bstride = (long long)kC * TS; d.shift = (tap - 1) * dil;
+                d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = y; d.b_bstride = (long long)kC * yrs; d.b_rs = yrs; d.shift = (tap - 1) * dil;
                 d.out = g->dilated_conv_w[l] + (size_t)mt * 128 * 3 * kC + tap; d.out_rs = 3 * kC; d.out_cs = 3;
                 d.out_bias = (tap == 0) ? g->dilated_conv_b[l] + mt * 128 : nullptr; d.a_scale = 1.f;
             }
         for (int mt = 0; mt < 4; ++mt) {
             TrWgTile& d = wp.tile[nd++];
-            d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = cond; d.b_bstride = (long long)kC * TS; d.shift = 0;
+            d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = cond; d.b_bstride = (long long)kC * TS; d.b_rs = TS; d.shift = 0;
             d.out = g->cond_w[l] + (size_t)mt * 128 * kC; d.out_rs = kC; d.out_cs = 1; d.out_bias = g->cond_b[l] + mt * 128; d.a_scale = 1.f;
         }
         for (int mt = last ? 2 : 0; mt < 4; ++mt) {
             TrWgTile& d = wp.tile[nd++];
             if (mt < 2) { d.a = dxp_in + (size_t)mt * 128 * TS; d.a_scale = kTrInvSqrt2; }
             else { d.a = dskip + (size_t)(mt - 2) * 128 * TS; d.a_scale = 1.f; }
-            d.a_bstride = (long long)kC * TS; d.bsrc = bws + bl.g; d.b_bstride = (long long)kC * TS; d.shift = 0;
+            d.a_bstride = (long long)kC * TS; d.bsrc = bws + bl.g; d.b_bstride = (long long)kC * TS; d.b_rs = TS; d.shift = 0;
             d.out = g->out_w[l] + (size_t)mt * 128 * kC; d.out_rs = kC; d.out_cs = 1; d.out_bias = g->out_b[l] + mt * 128;
         }
         if (last) {          // the residual half of the last layer's output projection is dead (net.py:126 reads the skips only): zero gradient
@@ -280,7 +286,7 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
             HIP_TRY(hipMemsetAsync(g->out_b[l], 0, (size_t)kC * sizeof(float), s));
         }
         wp.part = bws + bl.part; wp.part_b = bws + bl.part_b;
-        DSD_TRY(tr_wgrad_launch(s, wp, nd, B, T, TS));
+        DSD_TRY(tr_wgrad_launch(s, wp, nd, B, T, TS, false));
     }
     hipLaunchKernelGGL(k_tr_dds_reduce, dim3((unsigned)B, (unsigned)L), dim3(kC), 0, s, bws + bl.dds_part, g->dstep, L, ntile32, ntiles);
     HIP_TRY(hipGetLastError());
@@ -312,14 +318,14 @@ extern "C" int dsf_conv1d_wgrad2(const float* dy, const float* x, float* dw, flo
             const int tap = id % KT, nt = (id / KT) % (Ci / 256), mt = id / (KT * (Ci / 256));
             TrWgTile& d = wp.tile[nd];
             d.a = dy + (size_t)mt * 128 * TS; d.a_bstride = (long long)Co * TS;
-            d.bsrc = x + (size_t)nt * 256 * TS; d.b_bstride = (long long)Ci * TS;
+            d.bsrc = x + (size_t)nt * 256 * TS; d.b_bstride = (long long)Ci * TS; d.b_rs = TS;
             d.shift = (tap - (KT - 1) / 2) * dil;
             d.out = dw + ((size_t)mt * 128 * Ci + (size_t)nt * 256) * KT + tap; d.out_rs = Ci * KT; d.out_cs = KT;
             d.out_bias = (db && tap == 0 && nt == 0) ? db + mt * 128 : nullptr; d.a_scale = 1.f;
         }
         wp.part = workspace + (size_t)done * kTrMaxSplit * (128 * 256);
         wp.part_b = workspace + (size_t)ndtot * kTrMaxSplit * (128 * 256) + (size_t)done * kTrMaxSplit * 128;
-        DSD_TRY(tr_wgrad_launch(s, wp, nd, B, T, TS));
+        DSD_TRY(tr_wgrad_launch(s, wp, nd, B, T, TS, true));
         done += nd;
     }
     return DSD_OK;

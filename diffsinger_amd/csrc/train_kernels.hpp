@@ -289,8 +289,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_gate(const TrbGateParams p)
     // gate derivative (net.py:73-74): g = s * th, da_gate = dg * th * s (1 - s), da_filter = dg * s * (1 - th^2)
     const int t = t0 + j;
     const bool ok = t < p.T;
-    float* dab = p.da + (size_t)b * p.da_bstride + t;
-    float* gb = p.g + (size_t)b * kC * p.TS + t;
+    float* dab = p.da + (size_t)b * p.da_bstride;            // wave-uniform bases of the write-through stores
+    float* gb = p.g + (size_t)b * kC * p.TS;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -299,9 +299,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_gate(const TrbGateParams p)
             const float sg_ = 1.f / (1.f + expf(-ag)), th = tanhf(af);
             const float dg = fin[mb][r];
             const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
-            dab[(size_t)row * p.TS] = ok ? dg * th * (sg_ * (1.f - sg_)) : 0.f;
-            dab[(size_t)(kC + row) * p.TS] = ok ? dg * sg_ * (1.f - th * th) : 0.f;
-            gb[(size_t)row * p.TS] = ok ? sg_ * th : 0.f;
+            store4_wt(dab, row * p.TS + t, ok ? dg * th * (sg_ * (1.f - sg_)) : 0.f);
+            store4_wt(dab, (kC + row) * p.TS + t, ok ? dg * sg_ * (1.f - th * th) : 0.f);
+            store4_wt(gb, row * p.TS + t, ok ? sg_ * th : 0.f);
         }
 }
 
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_conv(const TrbConvParams p)
             const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
             // frames >= T are zero padding of y in the forward pass (net.py:69-71 pads the conv input): no gradient flows into them
             const float dy = ok ? fin[mb][r] : 0.f;
-            p.dx_out[((size_t)b * kC + row) * p.TS + t] = ok ? rv[mb][r] * kTrInvSqrt2 + dy : 0.f;
+            store4_wt(p.dx_out + (size_t)b * kC * p.TS, row * p.TS + t, ok ? rv[mb][r] * kTrInvSqrt2 + dy : 0.f);
             float s = dy;
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
             if (j == 0) p.dds_part[(size_t)tile * kC + row] = s;
@@ -420,11 +420,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_conv(const TrbConvParams p)
 // step k, one barrier per step.
 struct TrWgTile {
     const float* a;             // A rows of this tile: a + b * a_bstride + m * TS + t, m in [0,128)
-    const float* bsrc;          // B rows: bsrc + b * b_bstride + n * TS + t, n in [0,256)
+    const float* bsrc;          // B rows: bsrc + b * b_bstride + n * b_rs + t, n in [0,256)
     float* out;                 // gradient: out[m * out_rs + n * out_cs] (written by k_tr_wgrad_reduce)
     float* out_bias;            // row sums of A -> out_bias[m], or nullptr
     long long a_bstride, b_bstride;
-    int shift, out_rs, out_cs;
+    int shift, out_rs, out_cs, b_rs;
     float a_scale;
 };
 constexpr int kTrWgMaxTiles = 24;
@@ -439,10 +439,28 @@ struct TrWgParams {
 constexpr int kTrWgLD = 36;
 constexpr int kTrWgStage = (128 + 256) * kTrWgLD;
 constexpr int kTrWgLdsBytes = 2 * kTrWgStage * (int)sizeof(float);
+constexpr int kTrYPad = 8;      // zero floats on both sides of every row of the saved y (>= the largest tap shift): a shifted 16-byte load stays in its row
 
 struct __attribute__((aligned(4))) tr_f4u { float x, y, z, w; };       // a 16-byte load that is only dword-aligned
 
-template <bool PIPE>
+// {1 MFMA, then up to NV VALU, 1 LDS write, 1 global load, 1 LDS read} x n: the non-MFMA work of a step is issued in the shadow of the MFMAs
+// (one wave per SIMD: nothing else would fill the pipe while this wave computes addresses or writes the next tile)
+template <int NV, bool DSW, bool VMEM, bool DSR>
+__device__ __forceinline__ void tr_interleave(int) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (DSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        if (DSW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+}
+
+// FIX: the B rows are NOT padded (the stand-alone operator on a caller's tensor): the shifted load is clamped into the row and the first /
+// last tile of an utterance patches the elements when it writes the tile (a branch in the step).  The fused stack pads its y rows (kTrYPad)
+// and runs the branch-free form.
+template <bool FIX>
 __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
     constexpr int LD = kTrWgLD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     int a_valid = 0, b_shift = 0;
     const float a_scale = d.a_scale;
-    const int shift = d.shift;
+    const int shift = d.shift, b_rs = d.b_rs;
     auto fetch = [&](int tile) {
         const int b = tile / tiles_per_utt, t0 = (tile - b * tiles_per_utt) * 32;
         const int t = t0 + 4 * sg;
@@ -476,21 +494,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const float4*>(ap + (size_t)(32 * q) * p.TS);
         a_valid = p.T - t;                                  // frames >= T carry no gradient: masked when the tile is written to LDS
-        // B: frames t + shift .. + 3 of 256 rows.  One dword-aligned 16-byte load per row from an address clamped into the row, branch-free
-        // (the loads of a step are in flight during the previous step's MFMAs); where the window leaves [0, TS) - first / last tile of an
-        // utterance under a tap shift - the elements are shifted into place and the outside ones zeroed when the tile is written to LDS
+        // B: frames t + shift .. + 3 of 256 rows, one dword-aligned 16-byte load per row
         const int tb = t + shift;
-        const int tbc = min(max(tb, 0), p.TS - 4);
+        const int tbc = FIX ? min(max(tb, 0), p.TS - 4) : tb;
         b_shift = tb - tbc;
-        const float* bp = d.bsrc + (size_t)b * d.b_bstride + (size_t)srow * p.TS + tbc;
+        const float* bp = d.bsrc + (size_t)b * d.b_bstride + (size_t)srow * b_rs + tbc;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const tr_f4u v = *reinterpret_cast<const tr_f4u*>(bp + (size_t)(32 * q) * p.TS);
+            const tr_f4u v = *reinterpret_cast<const tr_f4u*>(bp + (size_t)(32 * q) * b_rs);
             bv[q] = make_float4(v.x, v.y, v.z, v.w);
         }
-        DSD_SB();
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, float live) {
         float* As = smem + buf * kTrWgStage;
         float* Bs = As + 128 * LD;
 #pragma unroll
@@ -499,9 +514,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
             v.x = (a_valid > 0) ? v.x * a_scale : 0.f; v.y = (a_valid > 1) ? v.y * a_scale : 0.f;
             v.z = (a_valid > 2) ? v.z * a_scale : 0.f; v.w = (a_valid > 3) ? v.w * a_scale : 0.f;
             *reinterpret_cast<float4*>(As + (srow + 32 * q) * LD + 4 * sg) = v;
-            bsum[q] += (v.x + v.y) + (v.z + v.w);
+            bsum[q] += live * ((v.x + v.y) + (v.z + v.w));
         }
-        if (b_shift != 0) {
+        if (FIX && b_shift != 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float4 v = bv[q];
@@ -519,10 +534,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
     };
     // Software pipeline over the 32-frame steps (one wave per SIMD: nothing else hides a bubble).  At the top of step k LDS buffer k & 1
     // holds tile k, the staging registers hold tile k + 1 (requested a whole step ago) and the fragments of chunk 0 are already in
-    // registers.  Step k: chunk 1's fragments are requested, tile k + 1 goes to the other buffer (free since the barrier of step k - 1),
-    // tile k + 2 is requested, then the MFMAs of chunks 0..2 run with the next chunk's fragments always in flight; behind chunk 3's reads
-    // comes the ONE barrier of the step (every wave is done reading this buffer, every wave's writes of the other one have landed), the
-    // fragments of the next step's chunk 0 are requested, and only then chunk 3's 32 MFMAs are issued - they cover barrier skew and LDS latency.
+    // registers.  Step k: chunk 1's fragments are requested, tile k + 1 goes to the other buffer (free since the barrier of step k - 1) and
+    // tile k + 2 is requested - all of it issued BETWEEN the MFMAs of chunk 0 (tr_interleave); chunks 1, 2 run with the next chunk's
+    // fragments in flight; behind chunk 3's reads comes the ONE barrier of the step (every wave is done reading this buffer, every wave's
+    // writes of the other one have landed), the fragments of the next step's chunk 0 are requested, and only then chunk 3's 32 MFMAs are
+    // issued - they cover barrier skew and LDS latency.  The step is branch-free: behind the last tile the staging registers repeat it
+    // (`live` = 0 keeps it out of the bias sums; the buffer it lands in is never multiplied).
     const int nstep = tile_hi - tile_lo;
     float4 fa[2][2], fb[2][4];
     auto frags = [&](int set, int buf, int c) {
@@ -541,64 +558,44 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma32(f4at(fa[set][mb], s), f4at(fb[set][nb], s), acc[mb][nb]);
     };
-  if (PIPE) {
     if (nstep > 0) {
         fetch(tile_lo);
-        stash(0);
-        if (nstep > 1) fetch(tile_lo + 1);
-    }
-    __syncthreads();
-    if (nstep > 0) frags(0, 0, 0);
-    for (int k = 0; k < nstep; ++k) {
-        const int cur = k & 1;
-        frags(1, cur, 1);
-        if (k + 1 < nstep) stash(cur ^ 1);
-        if (k + 2 < nstep) fetch(tile_lo + k + 2);
-        DSD_SB();
-        mma(0);
-        DSD_SB();
-        frags(0, cur, 2);
-        DSD_SB();
-        mma(1);
-        DSD_SB();
-        frags(1, cur, 3);
-        DSD_SB();
-        mma(0);
-        DSD_SB();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stash(0, 1.f);
+        fetch(min(tile_lo + 1, tile_hi - 1));
         __syncthreads();
-        if (k + 1 < nstep) frags(0, cur ^ 1, 0);
-        DSD_SB();
-        mma(1);
-        DSD_SB();
-    }
-  } else {
-    // the plain form (kept for A/B runs on one box): fragments read right in front of their MFMAs, the next tile written behind the step
-    if (nstep > 0) {
-        fetch(tile_lo);
-        stash(0);
-    }
-    __syncthreads();
-    for (int k = 0; k < nstep; ++k) {
-        const int cur = k & 1;
-        const bool more = k + 1 < nstep;
-        if (more) fetch(tile_lo + k + 1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            frags(0, cur, c);
+        frags(0, 0, 0);
+        for (int k = 0; k < nstep; ++k) {
+            const int cur = k & 1;
+            const float live = (k + 1 < nstep) ? 1.f : 0.f;
+            frags(1, cur, 1);
+            stash(cur ^ 1, live);
+            fetch(min(tile_lo + k + 2, tile_hi - 1));
             mma(0);
+            if (!FIX) tr_interleave<4, true, true, true>(0);
+            DSD_SB();
+            frags(0, cur, 2);
+            mma(1);
+            tr_interleave<0, false, false, true>(0);
+            DSD_SB();
+            frags(1, cur, 3);
+            mma(0);
+            tr_interleave<0, false, false, true>(0);
+            DSD_SB();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            frags(0, cur ^ 1, 0);
+            mma(1);
+            tr_interleave<0, false, false, true>(0);
+            DSD_SB();
         }
-        if (more) stash(cur ^ 1);
-        __syncthreads();
     }
-  }
-    float* out = p.part + ((size_t)desc * p.nsplit + split) * (128 * 256);
+    float* out = p.part + ((size_t)desc * p.nsplit + split) * (128 * 256);       // wave-uniform; write-through: the reduction kernel reads it next
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[(64 * wm + 32 * mb + frag_row(r, h)) * 256 + 128 * wn + 32 * nb + i] = acc[mb][nb][r];
+            for (int r = 0; r < 16; ++r) store4_wt(out, (64 * wm + 32 * mb + frag_row(r, h)) * 256 + 128 * wn + 32 * nb + i, acc[mb][nb][r]);
     if (d.out_bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -606,6 +603,15 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
             sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64); sb += __shfl_xor(sb, 4, 64);
             if (sg == 0) p.part_b[((size_t)desc * p.nsplit + split) * 128 + srow + 32 * q] = sb;
         }
+    }
+}
+
+// rows of the saved y carry kTrYPad zero floats on both sides: written once per forward
+__global__ void k_tr_zero_pads(float* __restrict__ y, size_t rows, int rs) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < rows * (2 * kTrYPad); i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / (2 * kTrYPad);
+        const int e = (int)(i - row * (2 * kTrYPad));
+        y[row * rs + (e < kTrYPad ? e : rs - 2 * kTrYPad + e)] = 0.f;
     }
 }
 

@@ -125,9 +125,10 @@ def test_stack_forward_and_backward(B, T, L, cycle):
     oY, oA, Yl, Al = off[6], off[7], off[12], off[13]
     e_y = e_a = 0.0
     for l in range(L):
-        y = save[oY + l * Yl: oY + (l + 1) * Yl].reshape(B, 256, TS).cpu()
+        yp = save[oY + l * Yl: oY + (l + 1) * Yl].reshape(B, 256, TS + 16).cpu()     # rows carry 8 zero floats on both sides (kTrYPad)
+        y = yp[:, :, 8:8 + TS]
         e_y = max(e_y, _rel(y[:, :, :T], keep['y'][l]))
-        assert float(y[:, :, T:].abs().max() if TS > T else 0) == 0
+        assert float(y[:, :, T:].abs().max() if TS > T else 0) == 0 and float(yp[:, :, :8].abs().max()) == 0 and float(yp[:, :, 8 + TS:].abs().max()) == 0
         a = _frag_to_rows(save[oA + l * Al: oA + (l + 1) * Al].cpu(), ntiles).reshape(B, TS // 32, 512, 32).permute(0, 2, 1, 3).reshape(B, 512, TS)
         e_a = max(e_a, _rel(a[:, :, :T], keep['a'][l]))
     print(f'stack B={B} T={T} L={L}: skip {e_skip:.2e}, saved y {e_y:.2e}, saved a {e_a:.2e}')
