@@ -40,7 +40,7 @@ def reference_style_forward(net, spec, t, cond):
     return F.conv1d(x, net.output_projection.weight, net.output_projection.bias)[:, None]
 
 
-def run(B, T, reps, torch_conv=False, reference_style=False, fused=True):
+def run(B, T, reps, torch_conv=False, reference_style=False, fused=True, graph=False):
     os.environ['DSD_TRAIN_FUSED'] = '1' if (fused and not torch_conv and not reference_style) else '0'
     pre = presets()['lj_ds_beta6']
     hparams.clear()
@@ -76,9 +76,24 @@ def run(B, T, reps, torch_conv=False, reference_style=False, fused=True):
             return loss
         step(); step()
         torch.cuda.synchronize()
+        if graph:                                   # experiment: the whole step captured once and replayed as ONE hipGraph
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                loss = step()
+            run_step = cg.replay
+        else:
+            run_step = step
+        run_step()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            loss = step()
+            r = run_step()
+            loss = r if r is not None else loss
         torch.cuda.synchronize()
         sec = (time.perf_counter() - t0) / reps
     finally:
@@ -87,7 +102,7 @@ def run(B, T, reps, torch_conv=False, reference_style=False, fused=True):
     impl = ('reference-style PyTorch-ROCm eager graph (MIOpen convolutions, ATen element-wise ops)' if reference_style else
             'torch conv1d (MIOpen) inside the HIP graph (fused glue kept)' if torch_conv else
             'fused residual stack (dsf_stack_forward / dsf_stack_backward)' if fused else 'HIP operators (dsf_conv1d_dilated / dsf_conv1d_wgrad / dsf_train_*)')
-    print(json.dumps({'impl': impl,
+    print(json.dumps({'impl': impl + (' replayed as one hipGraph' if graph else ''),
                       'B': B, 'T': T, 'ms_per_step_fwd_bwd': sec * 1e3, 'frames_per_s': frames / sec,
                       'tflops_gemm': 3 * F_FWD * frames / sec / 1e12, 'loss': float(loss)}), flush=True)
     del gd, net
@@ -98,7 +113,7 @@ if __name__ == '__main__':
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     if '--hip-only' in sys.argv:                    # for rocprofv3 runs: only the HIP variant, one shape
         B, T = (int(v) for v in sys.argv[sys.argv.index('--hip-only') + 1].split('x'))
-        run(B, T, reps)
+        run(B, T, reps, graph='--graph' in sys.argv)
         sys.exit(0)
     for B, T in ((8, 1024), (48, 512)):
         run(B, T, reps)
