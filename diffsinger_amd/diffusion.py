@@ -98,8 +98,13 @@ class GaussianDiffusion(nn.Module):
         self._sched_tag = None
 
     # -- engine plumbing ---------------------------------------------------------------------------------------
+    def _fused(self) -> bool:
+        """True: the denoiser is the DiffNet the fused engine is built for; False: any other denoise_fn (the `FFT` candidate, a DiffNet of
+        another width) - one denoiser forward per step on the HIP operators + element-wise sampler arithmetic."""
+        return isinstance(self.denoise_fn, DiffNet) and self.denoise_fn.fused()
+
     def _engine(self, cond):
-        if not isinstance(self.denoise_fn, DiffNet):
+        if not self._fused():
             raise TypeError("the HIP sampler needs the HIP denoiser: diff_decoder_type 'wavenet' from "
                             "diffsinger_amd.DIFF_DECODERS (got %s)" % type(self.denoise_fn).__name__)
         eng = self.denoise_fn.bind_cond(cond)
@@ -117,6 +122,8 @@ class GaussianDiffusion(nn.Module):
         if noise is None:
             noise = torch.randn_like(x_start)
         tt = int(t.reshape(-1)[0]) if isinstance(t, torch.Tensor) else int(t)
+        if not self._fused():
+            return self.sqrt_alphas_cumprod[tt] * x_start + self.sqrt_one_minus_alphas_cumprod[tt] * noise
         eng = self.denoise_fn.engine()
         if eng.n_sched != self.num_timesteps:
             eng.set_schedule(self._betas64)
@@ -129,12 +136,22 @@ class GaussianDiffusion(nn.Module):
         """:159-166.  One ancestral step; returns a new tensor like the reference.  t: [B] long tensor - one step index per utterance,
         equal or not (the sampling loop passes torch.full((B,), i)); clip_denoised / repeat_noise as in the reference (noise_like
         :38-41: with repeat_noise ONE [1,1,M,T] draw serves the whole batch).  `noise` makes the draw explicit."""
-        eng = self._engine(cond)
         tt = t.reshape(-1).tolist()
         if len(tt) == 1:
             tt = tt * x.shape[0]
         if noise is None:                                       # noise_like(:38-41), drawn at every step, t = 0 included
             noise = torch.randn((1, *x.shape[1:]) if repeat_noise else x.shape, device=x.device)
+        if not self._fused():                                   # :134-166 with [B,1,1,1] table gathers, the denoiser on the HIP operators
+            tl = torch.tensor(tt, device=x.device, dtype=torch.long)
+            ex = lambda a: a.gather(-1, tl).reshape(-1, 1, 1, 1)
+            eps = self.denoise_fn(x, tl, cond=cond)
+            x0 = ex(self.sqrt_recip_alphas_cumprod) * x - ex(self.sqrt_recipm1_alphas_cumprod) * eps
+            if clip_denoised:
+                x0 = x0.clamp(-1., 1.)
+            mean = ex(self.posterior_mean_coef1) * x0 + ex(self.posterior_mean_coef2) * x
+            nonzero = (1 - (tl == 0).float()).reshape(-1, 1, 1, 1)
+            return mean + nonzero * (0.5 * ex(self.posterior_log_variance_clipped)).exp() * noise
+        eng = self._engine(cond)
         out = x.clone().contiguous()
         if clip_denoised and not repeat_noise and all(v == tt[0] for v in tt):
             eng.p_sample(out, noise, int(tt[0]))                # the configuration of the sampling loop: fused into the head kernel
@@ -146,8 +163,12 @@ class GaussianDiffusion(nn.Module):
     def p_sample_plms(self, x, t, interval, cond, clip_denoised=True, repeat_noise=False):
         """:168-204, stateful through `self.noise_list` exactly like the reference.  Convenience API composed of
         HIP denoiser evaluations + element-wise torch ops; the production path is `inference()` (fused loop)."""
-        eng = self._engine(cond)
         tt = int(t.reshape(-1)[0])
+        if self._fused():
+            eng = self._engine(cond)
+            eps_at = lambda xx, ti: eng.denoise(xx, ti)[:, None]
+        else:
+            eps_at = lambda xx, ti: self.denoise_fn(xx, torch.full((xx.shape[0],), ti, device=xx.device, dtype=torch.long), cond=cond)
 
         def get_x_pred(xx, noise_t, ti):
             a_t = self.alphas_cumprod[ti]
@@ -158,10 +179,10 @@ class GaussianDiffusion(nn.Module):
             return xx + x_delta
 
         noise_list = self.noise_list
-        noise_pred = eng.denoise(x, tt)[:, None]
+        noise_pred = eps_at(x, tt)
         if len(noise_list) == 0:
             x_pred = get_x_pred(x, noise_pred, tt)
-            noise_pred_prev = eng.denoise(x_pred, max(tt - interval, 0))[:, None]
+            noise_pred_prev = eps_at(x_pred, max(tt - interval, 0))
             noise_pred_prime = (noise_pred + noise_pred_prev) / 2
         elif len(noise_list) == 1:
             noise_pred_prime = (3 * noise_pred - noise_list[-1]) / 2
@@ -186,7 +207,7 @@ class GaussianDiffusion(nn.Module):
                   inside the kernel (Philox, seed = noise_seed or a value taken from torch's CPU generator) - nothing of
                   size K*B*M*T is ever materialised
         Returns de-normalised mel [B,T,M] (times mel_mask [B,T] if given); with return_x also x_0 [B,1,M,T]."""
-        if not isinstance(self.denoise_fn, DiffNet):
+        if not self._fused():
             return self._inference_generic(cond, fs2_mels=fs2_mels, x_T=x_T, noise=noise, q_noise=q_noise, K_step=K_step,
                                            pndm_speedup=pndm_speedup, gaussian_start=gaussian_start, mel_mask=mel_mask, return_x=return_x)
         eng = self._engine(cond)
@@ -231,8 +252,6 @@ class GaussianDiffusion(nn.Module):
             raise RuntimeError('the HIP sampler has no CPU path')
         if pndm_speedup is None:
             pndm_speedup = hparams.get('pndm_speedup')
-        if pndm_speedup:
-            raise NotImplementedError('PLMS with a non-DiffNet denoiser')
         B, _, T = cond.shape
         M, dev = self.mel_bins, cond.device
         t = self.K_step if K_step is None else K_step
@@ -251,6 +270,11 @@ class GaussianDiffusion(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         tab = [getattr(self, k).detach().cpu().numpy() for k in ('sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod',
                                                                  'posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped')]
+        if pndm_speedup:                                        # :261-267: the PLMS loop over p_sample_plms (batched: rows are independent)
+            self.noise_list = deque(maxlen=4)
+            for i in reversed(range(0, t, int(pndm_speedup))):
+                x = self.p_sample_plms(x, torch.full((B,), i, device=dev, dtype=torch.long), int(pndm_speedup), cond)
+            t = 0
         for j in range(t):
             i = t - 1 - j
             eps = self.denoise_fn(x, torch.full((B,), i, device=dev, dtype=torch.long), cond=cond).contiguous()

@@ -109,8 +109,22 @@ class DiffNet(nn.Module):
             self._cond_ref = cond
         return eng
 
+    def fused(self) -> bool:
+        """The fused engine (persistent loop, per-layer / latency kernels, include/dsd.h) is built for the width every shipped DiffSpeech /
+        DiffSinger config uses: residual_channels == hidden_size == 256, at most 96 mel bins, dilations up to 8.  The reference reads the
+        widths from hparams (usr/diff/net.py:85-90): any other width - multiples of 8 - runs on the generic HIP operators instead
+        (`train.diffnet_forward_train` without autograd: one launch per Conv1d / element-wise piece) under the generic sampler of
+        `GaussianDiffusion`: the same results and API, operator-path speed."""
+        return (self.residual_channels == 256 and self.encoder_hidden == 256 and self.in_dims <= 96 and self.dilation_cycle_length <= 4)
+
     def forward(self, spec, diffusion_step, cond):
         """:param spec: [B, 1, M, T]  :param diffusion_step: [B]  :param cond: [B, H, T]  :return: [B, 1, M, T]"""
+        if not self.fused():
+            from .train import diffnet_forward_train
+            if self.residual_channels % 8 or self.encoder_hidden % 8 or self.in_dims % 8:
+                raise NotImplementedError('DiffNet on the HIP operators needs channel counts that are multiples of 8 '
+                                          f'(residual_channels={self.residual_channels}, hidden_size={self.encoder_hidden}, mel bins={self.in_dims})')
+            return diffnet_forward_train(self, spec, diffusion_step.reshape(-1), cond)
         if torch.is_grad_enabled() and (cond.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training (p_losses, usr/diff/shallow_diffusion_tts.py:213-231): the autograd path on the HIP conv / wgrad operators
             from .train import diffnet_forward_train

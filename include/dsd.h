@@ -43,8 +43,8 @@ typedef enum dsd_status {
 /* The hparams DiffNet reads at construction (usr/diff/net.py:85-90) + audio_num_mel_bins (:82). */
 typedef struct dsd_config {
     int32_t mel_bins;               /* M, <= 96                                  */
-    int32_t residual_channels;      /* C, must be 256 on this build              */
-    int32_t encoder_hidden;         /* H (cond width), must be 256 on this build */
+    int32_t residual_channels;      /* C, must be 256 for this (fused) engine; other widths run on the generic operators of dsf.h */
+    int32_t encoder_hidden;         /* H (cond width), must be 256 for this engine (diffsinger_amd/net.py DiffNet.fused())        */
     int32_t residual_layers;        /* L, 1..64                                  */
     int32_t dilation_cycle_length;  /* dilation of layer l = 2^(l % cycle), must stay <= 8 */
 } dsd_config;
