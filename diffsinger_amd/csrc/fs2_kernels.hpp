@@ -74,24 +74,40 @@ __global__ __launch_bounds__(kThreads, NMB == 4 ? 1 : 2) void k_fs_conv(const Fs
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][0][r] = 0.f;
     const float* inb = p.in + (size_t)b * p.Ci * p.TS;
+    // Staging: channels [c0, c0 + nc) x frames [t0 - 8, t0 + 40) of a slab, 12 float4 per row, zero outside [0, TS).  All the loads of a slab
+    // are requested at once (12 per thread for 256 channels) and the NEXT slab's loads are in flight during this slab's contraction: a
+    // load -> write -> load chain exposes the memory latency once per float4 (12 times per slab - more than the 7 us of MFMA work a K = 256
+    // convolution has per workgroup; A/B inside one GPU call: FastSpeech2 forward 3.94 -> 3.82 ms, profiles/r02x_fs_conv_staging_ab.jsonl)
+    constexpr int NIT = kFsSlab * (kFsLD / 4) / kThreads;
+    float4 sv[NIT];
+    auto request = [&](int c0, int nc) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * kThreads + tid, row = idx / (kFsLD / 4), g = idx - row * (kFsLD / 4);
+            const int t = t0 - kFsHalo + 4 * g;
+            const bool ok = (row < nc) && (t >= 0) && (t < p.TS);
+            const float4 v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + (ok ? row : 0)) * p.TS + (ok ? t : t0));
+            sv[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        DSD_SB();
+    };
+    request(0, min(kFsSlab, p.Ci));
     for (int c0 = 0; c0 < p.Ci; c0 += kFsSlab) {
         const int nc = min(kFsSlab, p.Ci - c0);
-        // the weight stream does not depend on the slab: its first chunks are requested BEFORE the slab is staged, so that their first-touch
-        // latency (every workgroup of a launch walks the stream in lock-step: each chunk is new to the L2) overlaps the staging loads
+        // the weight stream does not depend on the slab: its first chunks are requested BEFORE the slab is written, so that their first-touch
+        // latency (every workgroup of a launch walks the stream in lock-step: each chunk is new to the L2) overlaps the staging
         const int nch = (nc / 8) * p.KT;
         const float4* ap = p.wp + (((size_t)mt * 4 + w) * nchunk_total + (size_t)(c0 / 8) * p.KT) * (NMB * 64);
         const FsTapB bof{smem + 4 * h * kFsLD + kFsHalo + j - p.pad, p.KT, p.dil, nch};
         GemmPipe<NMB, 1, kFsLD, NMB * 64, 6, FsTapB> pipe(ap, lane, nch, bof);
         pipe.start_a();
-        // stage channels [c0, c0 + nc) x frames [t0 - 8, t0 + 40): 12 float4 per row, zero outside [0, TS)
-        for (int idx = tid; idx < nc * (kFsLD / 4); idx += kThreads) {
-            const int row = idx / (kFsLD / 4), g = idx - row * (kFsLD / 4);
-            const int t = t0 - kFsHalo + 4 * g;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < p.TS) v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + row) * p.TS + t);
-            *reinterpret_cast<float4*>(smem + row * kFsLD + 4 * g) = v;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * kThreads + tid, row = idx / (kFsLD / 4), g = idx - row * (kFsLD / 4);
+            if (row < nc) *reinterpret_cast<float4*>(smem + row * kFsLD + 4 * g) = sv[it];
         }
         __syncthreads();
+        if (c0 + kFsSlab < p.Ci) request(c0 + kFsSlab, min(kFsSlab, p.Ci - c0 - kFsSlab));
         pipe.start_b();
         pipe.run(acc, 0, nch);
         __syncthreads();
