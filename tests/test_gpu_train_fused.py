@@ -89,7 +89,7 @@ def _frag_to_rows(frag, ntiles):
     return out
 
 
-@pytest.mark.parametrize('B,T,L,cycle', [(2, 50, 3, 4), (3, 96, 5, 1), (2, 70, 20, 4)])
+@pytest.mark.parametrize('B,T,L,cycle', [(2, 50, 3, 4), (3, 96, 5, 1), (2, 70, 20, 4), (1, 5, 1, 1), (1, 32, 2, 4), (4, 33, 2, 2), (9, 129, 4, 3)])
 def test_stack_forward_and_backward(B, T, L, cycle):
     from diffsinger_amd import _lib, fs2, train_fused
     lib = _lib.load()
