@@ -131,17 +131,27 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
     for (int m = 0; m < NMB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
+    // hoisted conditioner projection (+ conv bias + cond bias) of this wave's row block(s), accumulator-fragment order: requested in
+    // front of the contraction (behind it the load latency would sit between the last MFMA and the gate, once per kernel node)
+    const float4* cpl = p.cp + ((size_t)tile * 4 + w4) * (4 * 4 * 64) + lane;
+    float4 cv[4], cf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cv[q] = cf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.T > 0) {          // always true; a load in its own block cannot be sunk into the (conditional) blocks of its uses behind the MFMAs
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cv[q] = cpl[(mb0 * 4 + q) * 64];
+            if (G == 2) cf[q] = cpl[((mb0 + 2) * 4 + q) * 64];
+        }
+    }
+    DSD_SB();
     pipe.start_b();
     pipe.run(acc, 0, NCH);
 
-    // hoisted conditioner projection (+ conv bias + cond bias) of this wave's row block(s), accumulator-fragment order
-    const float4* cpl = p.cp + ((size_t)tile * 4 + w4) * (4 * 4 * 64) + lane;
     float* gout = p.gbuf + (size_t)tile * TILE;
     if (G == 2) {
         // a gate block and its filter block in the same wave: the gate never leaves registers (like k_layer)
-        float4 cg[4], cf[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { cg[q] = cpl[(mb0 * 4 + q) * 64]; cf[q] = cpl[((mb0 + 2) * 4 + q) * 64]; }
+        float4 (&cg)[4] = cv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float gv = sigmoid_f(acc[0][0][r] + f4at(cg[r >> 2], r & 3)) * tanh_f(acc[NMB - 1][0][r] + f4at(cf[r >> 2], r & 3));
@@ -149,9 +159,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
         }
         return;
     }
-    float4 cv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cv[q] = cpl[(mb0 * 4 + q) * 64];
     if (G == 8) {
         // sum the two K halves: the second-half waves hand their partial block to the first-half wave of the same role
         float* part = red + (wv & 1) * 1024;
@@ -225,6 +232,30 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
     for (int m = 0; m < NMB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
+    // what the epilogue reads - x and the bias at this lane's residual rows, the running skip sum - is requested in front of the contraction
+    // (the waves that only contribute a K half, G = 8, finish nothing)
+    const bool fin = active && (G != 8 || wv < 2);
+    const float* __restrict__ xi = p.x_in + (size_t)tile * TILE;
+    float4* sl = p.skip + (((size_t)tile * 4 + w4) * 2 + (mb0 & 1)) * (4 * 64) + lane;
+    const bool keep = !p.first;             // layer 0 starts the sum (select, not multiply: the buffer may hold anything)
+    float xv[16], bvv[16];
+    float4 sk[4];
+    if (fin && do_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 64 * w4 + 32 * (mb0 & 1) + frag_row(r, h);
+            xv[r] = xi[row * 32 + j];
+            bvv[r] = p.b2[row];
+        }
+    }
+    if (fin && do_skip) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sk[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (keep) sk[q] = sl[q * 64];
+        }
+    }
+    DSD_SB();
     if (active) {
         pipe.start_b();
         pipe.run(acc, 0, NCH);
@@ -247,24 +278,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
 
     if (do_res) {
         // x' = (x + (res + b)) / sqrt(2)   (net.py:78; same operation order as k_layer)
-        const float* __restrict__ xi = p.x_in + (size_t)tile * TILE;
         float* __restrict__ xo = p.x_out + (size_t)tile * TILE;
         constexpr float kInvSqrt2 = 1.0f / 1.41421354f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 64 * w4 + 32 * (mb0 & 1) + frag_row(r, h);
-            const float bv = p.b2[row];
-            xo[row * 32 + j] = (xi[row * 32 + j] + (acc[0][0][r] + bv)) * kInvSqrt2;
+            xo[row * 32 + j] = (xv[r] + (acc[0][0][r] + bvv[r])) * kInvSqrt2;
         }
     }
     if (do_skip) {
-        float4* sl = p.skip + (((size_t)tile * 4 + w4) * 2 + (mb0 & 1)) * (4 * 64) + lane;
-        const bool keep = !p.first;         // layer 0 starts the sum (select, not multiply: the buffer may hold anything)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 a = get4(acc[NMB - 1][0], q);
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (keep) s = sl[q * 64];
+            const float4 a = get4(acc[NMB - 1][0], q), s = sk[q];
             sl[q * 64] = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
         }
     }
