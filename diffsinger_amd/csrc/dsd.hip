@@ -112,6 +112,7 @@ struct dsd_handle {
     int loop_mode = 2;
     int lat_req = -1;           // row split of the latency kernels: -1 by batch size, 0 never, 2 / 4 / 8 forced (env DSD_LAT_G)
     float* gbuf = nullptr;      // [ntiles][C][32] gate tiles between k_lat_conv and k_lat_out
+    bool lat_head_split = true; // G = 8 latency path: the head as three row-split kernels (env DSD_LAT_HEAD=0: k_head on one workgroup per tile)
     int n_cu = 0;               // workgroups that are certainly co-resident at 1 per CU
     struct LoopPlan { HeadParams* evals = nullptr; int* eval_t = nullptr; int n_evals = 0; };
     std::map<GraphKey, LoopPlan> plans;
@@ -216,6 +217,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     if (const char* ev = std::getenv("DSD_LAT_G")) h->lat_req = std::atoi(ev);                 // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_WT_STORES")) h->wt_stores = (std::atoi(ev) != 0);  // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
+    if (const char* ev = std::getenv("DSD_LAT_HEAD")) h->lat_head_split = (std::atoi(ev) != 0);  // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
@@ -615,6 +617,18 @@ static HeadParams head_base(dsd_handle* h) {
 
 template <int MODE>
 static int launch_head(dsd_handle* h, const HeadParams& p, bool fuse, hipStream_t s) {
+    if (MODE != HEAD_EPS && lat_g(h) == 8 && h->lat_head_split) {
+        // G = 8 latency path: the head row-split like the layers (dsd_lat.hpp): skip projection on 8 workgroups per tile -> final projection +
+        // sampler update on 3 -> next input projection on 8.  hbuf = the gate buffer (free behind the last layer), pbuf = the x buffer
+        // the last layer read (the other one receives the next x)
+        LatHeadParams q{};
+        q.hp = p; q.hbuf = h->gbuf; q.pbuf = h->xb; q.ntiles = h->ntiles;
+        hipLaunchKernelGGL(k_lat_head_a, dim3((unsigned)lat_grid(h->ntiles, 8)), dim3(kThreads), kLatHeadALdsBytes, s, q);
+        hipLaunchKernelGGL((k_lat_head_b<MODE>), dim3((unsigned)lat_grid(h->ntiles, 4)), dim3(kThreads), kLatHeadBLdsBytes, s, q);
+        if (fuse) hipLaunchKernelGGL(k_lat_head_c, dim3((unsigned)lat_grid(h->ntiles, 8)), dim3(kThreads), kLatHeadCLdsBytes, s, q);
+        HIP_TRY(hipGetLastError());
+        return DSD_OK;
+    }
     if (fuse) hipLaunchKernelGGL((k_head<MODE, true>), dim3(h->ntiles), dim3(kThreads), kHeadLdsBytes, s, p);
     else hipLaunchKernelGGL((k_head<MODE, false>), dim3(h->ntiles), dim3(kThreads), kHeadLdsBytes, s, p);
     HIP_TRY(hipGetLastError());

@@ -722,6 +722,63 @@ struct HeadParams {
     int order;
 };
 
+// The sampler arithmetic behind the final projection for ONE element (idx = (b * M + m) * T + t), shared by k_head and the row-split head
+// of the latency path (dsd_lat.hpp): head_prefetch reads what the update needs besides eps - so that a kernel can issue it in front of a
+// contraction - and head_apply does the arithmetic and the stores.  No FMA contraction: the reference rounds every product.
+struct HeadPre { float x, z, e1, e2, e3; };
+
+template <int MODE>
+__device__ __forceinline__ void head_prefetch(const HeadParams& p, size_t idx, HeadPre& pre) {
+    pre.x = pre.z = pre.e1 = pre.e2 = pre.e3 = 0.f;
+    if (MODE == HEAD_DDPM) {
+        pre.x = p.x_base[idx];
+        const float* nzb = *p.noise_cell;
+        pre.z = nzb ? nzb[p.noise_off + idx] : philox_normal(*p.seed_cell, p.step_id, idx);
+    } else if (MODE == HEAD_PLMS) {
+        if (p.order != PLMS_RAW) pre.e1 = p.e1[idx];
+        if (p.order == PLMS_AB3 || p.order == PLMS_AB4) pre.e2 = p.e2[idx];
+        if (p.order == PLMS_AB4) pre.e3 = p.e3[idx];
+        pre.x = p.x_base[idx];
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ float head_apply(const HeadParams& p, float eps, size_t idx, const HeadPre& pre) {
+    float xn = 0.f;
+    if (MODE == HEAD_EPS) {
+        p.eps_out[idx] = eps;
+    } else if (MODE == HEAD_DDPM) {
+        // p_mean_variance + p_sample (shallow_diffusion_tts.py:134-166)
+        const float x = pre.x, z = pre.z;
+        float x0 = __fsub_rn(__fmul_rn(p.sa, x), __fmul_rn(p.sb, eps));
+        x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        const float mean = __fadd_rn(__fmul_rn(p.c1, x0), __fmul_rn(p.c2, x));
+        xn = __fadd_rn(mean, __fmul_rn(p.sigma, z));
+        p.x_out[idx] = xn;
+    } else {
+        // p_sample_plms (shallow_diffusion_tts.py:168-204)
+        float ep;
+        if (p.order == PLMS_RAW) {
+            ep = eps;
+        } else if (p.order == PLMS_HEUN) {
+            ep = __fmul_rn(__fadd_rn(pre.e1, eps), 0.5f);                 // (first + prev) / 2
+        } else if (p.order == PLMS_AB2) {
+            ep = __fmul_rn(__fsub_rn(__fmul_rn(3.f, eps), pre.e1), 0.5f);
+        } else if (p.order == PLMS_AB3) {
+            ep = __fdiv_rn(__fadd_rn(__fsub_rn(__fmul_rn(23.f, eps), __fmul_rn(16.f, pre.e1)), __fmul_rn(5.f, pre.e2)), 12.f);
+        } else {
+            ep = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(55.f, eps), __fmul_rn(59.f, pre.e1)), __fmul_rn(37.f, pre.e2)),
+                                     __fmul_rn(9.f, pre.e3)), 24.f);
+        }
+        if (p.eps_out) p.eps_out[idx] = eps;
+        const float x = pre.x;
+        const float delta = __fmul_rn(p.dA, __fsub_rn(__fmul_rn(p.cx, x), __fmul_rn(p.ce, ep)));
+        xn = __fadd_rn(x, delta);
+        p.x_out[idx] = xn;
+    }
+    return xn;
+}
+
 template <int MODE, bool FUSE_INPROJ>
 __global__ __launch_bounds__(kThreads, 2) void k_head(const HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -781,41 +838,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_head(const HeadParams p) {
             const float eps = acc[0][0][r];
             float xn = 0.f;
             if (ok) {
-                if (MODE == HEAD_EPS) {
-                    p.eps_out[idx] = eps;
-                } else if (MODE == HEAD_DDPM) {
-                    // p_mean_variance + p_sample (shallow_diffusion_tts.py:134-166); no FMA contraction, the
-                    // reference rounds every product
-                    const float x = p.x_base[idx];
-                    const float* nzb = *p.noise_cell;
-                    const float z = nzb ? nzb[p.noise_off + idx] : philox_normal(*p.seed_cell, p.step_id, idx);
-                    float x0 = __fsub_rn(__fmul_rn(p.sa, x), __fmul_rn(p.sb, eps));
-                    x0 = fminf(fmaxf(x0, -1.f), 1.f);
-                    const float mean = __fadd_rn(__fmul_rn(p.c1, x0), __fmul_rn(p.c2, x));
-                    xn = __fadd_rn(mean, __fmul_rn(p.sigma, z));
-                    p.x_out[idx] = xn;
-                } else {
-                    // p_sample_plms (shallow_diffusion_tts.py:168-204)
-                    float ep;
-                    if (p.order == PLMS_RAW) {
-                        ep = eps;
-                    } else if (p.order == PLMS_HEUN) {
-                        ep = __fmul_rn(__fadd_rn(p.e1[idx], eps), 0.5f);                 // (first + prev) / 2
-                    } else if (p.order == PLMS_AB2) {
-                        ep = __fmul_rn(__fsub_rn(__fmul_rn(3.f, eps), p.e1[idx]), 0.5f);
-                    } else if (p.order == PLMS_AB3) {
-                        ep = __fdiv_rn(__fadd_rn(__fsub_rn(__fmul_rn(23.f, eps), __fmul_rn(16.f, p.e1[idx])),
-                                                 __fmul_rn(5.f, p.e2[idx])), 12.f);
-                    } else {
-                        ep = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(55.f, eps), __fmul_rn(59.f, p.e1[idx])),
-                                                           __fmul_rn(37.f, p.e2[idx])), __fmul_rn(9.f, p.e3[idx])), 24.f);
-                    }
-                    if (p.eps_out) p.eps_out[idx] = eps;
-                    const float x = p.x_base[idx];
-                    const float delta = __fmul_rn(p.dA, __fsub_rn(__fmul_rn(p.cx, x), __fmul_rn(p.ce, ep)));
-                    xn = __fadd_rn(x, delta);
-                    p.x_out[idx] = xn;
-                }
+                HeadPre pre;
+                head_prefetch<MODE>(p, idx, pre);
+                xn = head_apply<MODE>(p, eps, idx, pre);
             }
             if (FUSE_INPROJ) ptile[m * 32 + j] = ok ? xn : 0.f;
         }

@@ -295,4 +295,171 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The head of an evaluation (net.py:126-129 + the sampler update + the next evaluation's input projection) for the G = 8 latency path
+// ------------------------------------------------------------------------------------------------------------
+// k_head gives a tile to one workgroup: with 16 tiles (one utterance of 512 frames) the head runs on 16 CUs for ~31 us per evaluation - as
+// long as one and a half row-split layers.  Here its three contractions are split over the rows like the layers, three kernel nodes with the
+// all-gathers at the boundaries:
+//   k_lat_head_a   8 workgroups per tile: workgroup g = rows [32 g, +32) of relu(skip_projection(sum(skip) / sqrt(L))) -> hbuf
+//   k_lat_head_b   3 workgroups per tile (of a G = 4 map): workgroup g = mel rows [32 g, +32) of the final projection + the sampler update
+//                  (head_prefetch / head_apply of k_head) -> x, and the next x as a padded [96][32] tile -> pbuf
+//   k_lat_head_c   8 workgroups per tile: rows [32 g, +32) of relu(input_projection(next x)) -> the x tile of the next evaluation
+// In a and b the four waves of a workgroup split K = 256 four ways (8 chunks each, partial blocks summed through LDS in wave order: the
+// summation order differs from k_head's single chain - like the G = 8 layer kernels, which this path accompanies); c is one short chain
+// (K = 8 nk <= 96) on wave 0.
+struct LatHeadParams {
+    HeadParams hp;
+    float* hbuf;            // [tiles][256][32] relu(skip projection)
+    float* pbuf;            // [tiles][96][32] next x (mel rows padded with zeros)
+    int ntiles;
+};
+constexpr int kLatHeadALdsBytes = (kC * 32 + 3 * 32 * 32) * (int)sizeof(float);
+constexpr int kLatHeadBLdsBytes = (kC * 32 + 3 * 32 * 32) * (int)sizeof(float);
+constexpr int kLatHeadCLdsBytes = kMPad * 32 * (int)sizeof(float);
+
+// partial blocks of waves 1..3 -> wave 0: ((own + p1) + p2) + p3
+__device__ __forceinline__ void lat_ksum4(f32x16& acc, float* red, int wv, int j, int h) {
+    if (wv > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wv - 1) * 1024 + frag_row(r, h) * 32 + j] = acc[r];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] + red[q * 1024 + frag_row(r, h) * 32 + j];
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void k_lat_head_a(const LatHeadParams q) {
+    const HeadParams& p = q.hp;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* stile = smem;                    // [256][32] scaled skip sum
+    float* red = smem + kC * 32;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile, g;
+    if (!lat_map<8>(q.ntiles, tile, g)) return;
+    const int w4 = g >> 1, mb = g & 1;      // rows [32 g, +32) = packed stream w4, row block mb
+    GemmPipe<1, 1, 32, 128, 6, TileB> pipe(p.wsp + (size_t)w4 * (32 * 128) + (size_t)(8 * wv) * 128 + mb * 64, lane, 8,
+                                           TileB{stile + (8 * wv) * (8 * 32) + 4 * h * 32 + j, 8 * 32, 8});
+    pipe.start_a();
+    // x = sum(skip) / sqrt(L)   (net.py:126): wave wv stages the rows of packed stream wv, as k_head does
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const float4* sl = p.skip + (((size_t)tile * 4 + wv) * 2 + ms) * (4 * 64) + lane;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const float4 s = sl[qq * 64], bs = p.bskp[((wv * 2 + ms) * 2 + h) * 4 + qq];
+            const float v[4] = {s.x + bs.x, s.y + bs.y, s.z + bs.z, s.w + bs.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stile[(64 * wv + 32 * ms + frag_row(4 * qq + e, h)) * 32 + j] = __fdiv_rn(v[e], p.sqrt_L);
+        }
+    }
+    __syncthreads();
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const float4 bz = (wv == 0) ? p.bsp[((w4 * 2 + mb) * 2 + h) * 4 + qq] : make_float4(0.f, 0.f, 0.f, 0.f);
+        set4(acc[0][0], qq, bz);
+    }
+    pipe.start_b();
+    pipe.run(acc, 0, 8);
+    lat_ksum4(acc[0][0], red, wv, j, h);
+    if (wv == 0) {
+        float* out = q.hbuf + (size_t)tile * (kC * 32);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(32 * g + frag_row(r, h)) * 32 + j] = fmaxf(acc[0][0][r], 0.f);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 2) void k_lat_head_b(const LatHeadParams q) {
+    const HeadParams& p = q.hp;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* htile = smem;                    // [256][32] relu(skip projection)
+    float* red = smem + kC * 32;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile, g;
+    if (!lat_map<4>(q.ntiles, tile, g)) return;
+    if (g >= 3) return;                     // 96 padded mel rows = three row blocks
+    const int b = tile / p.ntile32, t0 = (tile - b * p.ntile32) * 32;
+    GemmPipe<1, 1, 32, 192, 6, TileB> pipe(p.woutp + (size_t)(8 * wv) * 192 + g * 64, lane, 8,
+                                           TileB{htile + (8 * wv) * (8 * 32) + 4 * h * 32 + j, 8 * 32, 8});
+    pipe.start_a();
+    {
+        const float4* src = reinterpret_cast<const float4*>(q.hbuf + (size_t)tile * (kC * 32));
+        float4 v[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) v[it] = src[it * kThreads + tid];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) reinterpret_cast<float4*>(htile)[it * kThreads + tid] = v[it];
+    }
+    __syncthreads();
+    // what the sampler update reads besides eps, at the positions wave 0 finishes: requested in front of the contraction
+    const int t = t0 + j;
+    HeadPre pre[16];
+    if (wv == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * g + frag_row(r, h);
+            const bool ok = (m < p.M) && (t < p.T);
+            const size_t idx = ((size_t)b * p.M + (ok ? m : 0)) * p.T + (ok ? t : 0);
+            head_prefetch<MODE>(p, idx, pre[r]);
+        }
+    }
+    DSD_SB();
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const float4 bz = (wv == 0) ? p.boutp[(g * 2 + h) * 4 + qq] : make_float4(0.f, 0.f, 0.f, 0.f);
+        set4(acc[0][0], qq, bz);
+    }
+    pipe.start_b();
+    pipe.run(acc, 0, 8);
+    lat_ksum4(acc[0][0], red, wv, j, h);
+    if (wv == 0) {
+        float* pt = q.pbuf + (size_t)tile * (kMPad * 32);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * g + frag_row(r, h);
+            const bool ok = (m < p.M) && (t < p.T);
+            const size_t idx = ((size_t)b * p.M + m) * p.T + t;
+            float xn = 0.f;
+            if (ok) xn = head_apply<MODE>(p, acc[0][0][r], idx, pre[r]);
+            pt[m * 32 + j] = ok ? xn : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void k_lat_head_c(const LatHeadParams q) {
+    const HeadParams& p = q.hp;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [96][32] next x
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile, g;
+    if (!lat_map<8>(q.ntiles, tile, g)) return;
+    const int w4 = g >> 1, mb = g & 1;
+    GemmPipe<1, 1, 32, 128, 6, TileB> pipe(p.winp + (size_t)w4 * p.nk_in * 128 + mb * 64, lane, p.nk_in, TileB{smem + 4 * h * 32 + j, 8 * 32, p.nk_in});
+    if (wv == 0) pipe.start_a();
+    {
+        const float4* src = reinterpret_cast<const float4*>(q.pbuf + (size_t)tile * (kMPad * 32));
+#pragma unroll
+        for (int it = 0; it < 3; ++it) reinterpret_cast<float4*>(smem)[it * kThreads + tid] = src[it * kThreads + tid];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) set4(acc[0][0], qq, p.binp[((w4 * 2 + mb) * 2 + h) * 4 + qq]);
+    pipe.start_b();
+    pipe.run(acc, 0, p.nk_in);
+    float* out = p.x_next + (size_t)tile * (kC * 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(32 * g + frag_row(r, h)) * 32 + j] = fmaxf(acc[0][0][r], 0.f);
+}
+
 }  // namespace dsd
