@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -297,6 +298,17 @@ static int layer_nb(const dsd_handle* h) {
     return (h->ntiles > 1024) ? 2 : 1;
 }
 extern "C" int dsd_get_layer_tile(dsd_handle* h) { return h ? 32 * layer_nb(h) : 0; }
+
+// Function attributes (dynamic LDS above 64 KiB) belong to a DEVICE's code object: true the first time call site `site` is reached on the
+// current device - a process that drives several GPUs (the reference's DP threads, utils/pl_utils.py:146-154) sets them on each.
+static bool first_on_device(int site) {
+    static std::mutex mu;
+    static std::set<std::pair<int, int>> seen;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    return seen.emplace(dev, site).second;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // weights
@@ -962,11 +974,9 @@ extern "C" int dsd_philox_normal(dsd_handle* h, uint64_t seed, int32_t step, flo
 }
 
 static void split_kernel_attrs() {
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (first_on_device(1)) {
         (void)hipFuncSetAttribute((const void*)k_layer_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLayerLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_layer_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLayerLdsBytes);
-        attr_done = true;
     }
 }
 

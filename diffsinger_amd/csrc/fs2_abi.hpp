@@ -57,11 +57,9 @@ static int fs_conv_launch(const float* in, const float* wpacked, const float* bi
     if (B < 1 || T < 1 || Co < 1 || Ci < 8 || (Ci % 8) || KT < 1 || KT > 2 * kFsHalo + 1 || !(KT & 1) || act < 0 || act > 3 || dil < 1 ||
         dil * (KT - 1) / 2 > kFsHalo)
         return fail(DSD_ERR_INVALID, "dsf_conv1d: bad shape (B=%d T=%d Ci=%d Co=%d K=%d dil=%d act=%d)", B, T, Ci, Co, KT, dil, act);
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (first_on_device(10)) {
         (void)hipFuncSetAttribute((const void*)k_fs_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_fs_conv<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
-        attr_done = true;
     }
     FsConvParams p{};
     p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.keep = keep;
@@ -95,10 +93,8 @@ extern "C" int dsf_attention(const float* qkv, const uint8_t* key_pad, float* ou
     FsAttnParams p{};
     p.qkv = qkv; p.key_pad = key_pad; p.out = out; p.C = C; p.T = T; p.TS = fs_ts(T);
     p.scale = (float)std::sqrt(1.0 / 128.0);
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (first_on_device(11)) {
         (void)hipFuncSetAttribute((const void*)k_fs_attn<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fs_attn_lds_bytes<128>());
-        attr_done = true;
     }
     hipLaunchKernelGGL((k_fs_attn<128>), dim3((unsigned)(p.TS / 32), (unsigned)heads, (unsigned)B), dim3(kThreads), fs_attn_lds_bytes<128>(),
                        (hipStream_t)stream, p);

@@ -80,8 +80,7 @@ static int tr_pack_multi(hipStream_t s, const float* const* src, int L, float* d
 }
 
 static int tr_attrs() {
-    static bool done = false;
-    if (done) return DSD_OK;
+    if (!first_on_device(30)) return DSD_OK;
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
@@ -90,7 +89,6 @@ static int tr_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
-    done = true;
     return DSD_OK;
 }
 

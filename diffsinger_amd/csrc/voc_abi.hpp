@@ -40,10 +40,8 @@ extern "C" int dsv_pad_rows(const float* in, float* out, int64_t R, int32_t L, v
 
 template <int NB, int WT>
 static void voc_conv_launch(const VocConvParams& p, int B, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (first_on_device(100 + 10 * NB + WT)) {
         (void)hipFuncSetAttribute((const void*)k_voc_conv<NB, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, voc_lds_bytes<NB, WT>());
-        attr_done = true;
     }
     constexpr int WR = 4 / WT, SPAN = voc_span<NB, WT>();
     const size_t lds = (size_t)voc_lds_bytes<NB, WT>();
@@ -93,11 +91,9 @@ extern "C" int32_t dsv_fold_factor(int32_t Co, int32_t Ci, int32_t K, int32_t di
 
 template <int F>
 static void voc_fold_launch(const VocFoldParams& p, int B, hipStream_t s) {
-    static bool attr_done = false;
     const size_t lds = (size_t)fold_lds_bytes<F>();
-    if (!attr_done) {
+    if (first_on_device(200 + F)) {
         (void)hipFuncSetAttribute((const void*)k_voc_conv_fold<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     const int fd = F * p.dil;
     const int groups = (p.LS + fd - 1) / fd;
