@@ -9,11 +9,11 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INST
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/pmc/fetch -o fetch -- python $R/tools/bench_train.py 3 --hip-only 8x1024 > $O/fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc/write -o write -- python $R/tools/bench_train.py 3 --hip-only 8x1024 > $O/write.log 2>&1
 cd $R
-for k in k_tr_wgradILb1 k_trb_convILb0 k_trb_gateILb0 k_tr_layerILb0; do
+for k in SKIP; do continue
   python tools/pmc_summary.py $O/pmc $k $O/pmc_$k.txt $O/pmc_$k.json round=$TAG shape=8x1024 > /dev/null 2>> $O/pmc_err.txt
 done
-for k in "k_tr_wgrad<true>" "k_trb_conv<false>" "k_trb_gate<false>" "k_tr_layer<false>"; do
+for k in "k_tr_wgrad<false>" "k_trb_conv<false>" "k_trb_gate<false>" "k_tr_layer<false>"; do
   python tools/pmc_summary.py $O/pmc "$k" "$O/pmc_$(echo $k | tr -d '<>').txt" "$O/pmc_$(echo $k | tr -d '<>').json" round=$TAG shape=8x1024 > /dev/null 2>> $O/pmc_err.txt
 done
 rm -rf $O/pmc
-ls $O; cat $O/pmc_k_tr_wgradtrue.txt; tail -3 $O/pmc_err.txt
+ls $O; cat $O/pmc_k_tr_wgradfalse.txt; tail -3 $O/pmc_err.txt
