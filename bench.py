@@ -404,7 +404,15 @@ def main_train(args):
                 'note': 'the weight gradient of the dilated convolution of one residual block as a stand-alone launch (12 output tiles x 16 frame '
                         'splits = 192 workgroups on 256 CUs; inside the training step the layer\'s three weight gradients are ONE launch of 20 tiles '
                         'x 12 splits: profiles/r02o_train_kernel_stats_8x1024.txt, 10.7 GFLOP in 113 us = 0.60 of peak); eager launches incl. the '
-                        'ctypes calls and the reduction kernel.  No PMC pass of this kernel is committed yet'}
+                        'ctypes calls and the reduction kernel'}
+        try:        # fabric-side bytes of the kernel as it runs inside the step (20 tiles x 12 splits), from the round's separate --pmc passes
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'train_wgrad_pmc.json')))
+            roof['traffic'] = pm['hbm_bytes_per_launch']['total']
+            roof['traffic_unit'] = 'bytes/launch'
+            roof['traffic_source'] = (f"profiles/train_wgrad_pmc.json ({pm.get('round', '?')}): FETCH_SIZE x 2 + WRITE_SIZE of k_tr_wgrad inside the training step "
+                                      f"(one layer's three weight gradients: 10.7 GFLOP, 59 MB of operands + 31.5 MB of split-K partials per launch)")
+        except (OSError, KeyError, ValueError):
+            pass
         value = world * B * T * args.steps / el
         res = {'metric': 'frames/sec (whole node) through one denoiser training step: q_sample + DiffNet forward + L1 + backward, T=1024', 'value': value,
                'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
