@@ -38,34 +38,41 @@ extern "C" int dsv_pad_rows(const float* in, float* out, int64_t R, int32_t L, v
     return DSD_OK;
 }
 
-template <int NB, int WT>
+template <int NB, int WT, int HALO>
 static void voc_conv_launch(const VocConvParams& p, int B, hipStream_t s) {
-    if (first_on_device(100 + 10 * NB + WT)) {
-        (void)hipFuncSetAttribute((const void*)k_voc_conv<NB, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, voc_lds_bytes<NB, WT>());
+    if (first_on_device(100 + 10 * NB + WT + 1000 * (HALO != kVocHalo))) {
+        (void)hipFuncSetAttribute((const void*)k_voc_conv<NB, WT, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, voc_lds_bytes<NB, WT, HALO>());
     }
     constexpr int WR = 4 / WT, SPAN = voc_span<NB, WT>();
-    const size_t lds = (size_t)voc_lds_bytes<NB, WT>();
+    const size_t lds = (size_t)voc_lds_bytes<NB, WT, HALO>();
     const dim3 grid((unsigned)((p.LSi + SPAN - 1) / SPAN), (unsigned)B, (unsigned)((p.rows + 32 * WR - 1) / (32 * WR)));
-    hipLaunchKernelGGL((k_voc_conv<NB, WT>), grid, dim3(kThreads), lds, s, p);
+    hipLaunchKernelGGL((k_voc_conv<NB, WT, HALO>), grid, dim3(kThreads), lds, s, p);
 }
 
 extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t rows, int32_t KT,
                           int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in,
                           float divide, int32_t act, void* stream) {
     if (!in || !wpacked || !out) return fail(DSD_ERR_INVALID, "dsv_conv1d: null argument");
-    if (B < 1 || B > 65535 || Ci < 1 || rows < 1 || KT < 1 || dil < 1 || L_in < 1 || up < 1 || (rows % up) || pad < 0 || pad > kVocHalo ||
-        (KT - 1) * dil - pad > kVocHalo || (KT - 1) * dil - pad < 0 || act < 0 || act > 1 || divide == 0.f || (int64_t)L_in * up > (1 << 30))
+    if (B < 1 || B > 65535 || Ci < 1 || rows < 1 || KT < 1 || dil < 1 || L_in < 1 || up < 1 || (rows % up) || pad < 0 || pad > kVocHaloWide ||
+        (KT - 1) * dil - pad > kVocHaloWide || (KT - 1) * dil - pad < 0 || act < 0 || act > 1 || divide == 0.f || (int64_t)L_in * up > (1 << 30))
         return fail(DSD_ERR_INVALID, "dsv_conv1d: bad shape (B=%d Ci=%d rows=%d K=%d pad=%d dil=%d L=%d up=%d act=%d); taps must stay within +-%d samples",
-                    B, Ci, rows, KT, pad, dil, L_in, up, act, kVocHalo);
+                    B, Ci, rows, KT, pad, dil, L_in, up, act, kVocHaloWide);
     VocConvParams p{};
     p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.sum_in = sum_in;
     p.Ci = Ci; p.rows = rows; p.KT = KT; p.pad = pad; p.dil = dil;
     p.Li = L_in; p.LSi = voc_ls(L_in); p.U = up; p.Lo = L_in * up; p.LSo = voc_ls(p.Lo);
     p.pre_slope = pre_slope; p.divide = divide; p.act = act;
     // narrow layers: one row block, the four waves split 512 samples; 64 rows: 2 x 2; wide (low-rate) layers: four row blocks x 32 samples
-    if (rows <= 32) voc_conv_launch<4, 4>(p, B, (hipStream_t)stream);
-    else if (rows <= 64) voc_conv_launch<2, 2>(p, B, (hipStream_t)stream);
-    else voc_conv_launch<1, 1>(p, B, (hipStream_t)stream);
+    const bool wide = pad > kVocHalo || (KT - 1) * dil - pad > kVocHalo;        // taps beyond the +-28 samples of the standard staging window
+    if (wide) {
+        if (rows <= 32) voc_conv_launch<4, 4, kVocHaloWide>(p, B, (hipStream_t)stream);
+        else if (rows <= 64) voc_conv_launch<2, 2, kVocHaloWide>(p, B, (hipStream_t)stream);
+        else voc_conv_launch<1, 1, kVocHaloWide>(p, B, (hipStream_t)stream);
+    } else {
+        if (rows <= 32) voc_conv_launch<4, 4, kVocHalo>(p, B, (hipStream_t)stream);
+        else if (rows <= 64) voc_conv_launch<2, 2, kVocHalo>(p, B, (hipStream_t)stream);
+        else voc_conv_launch<1, 1, kVocHalo>(p, B, (hipStream_t)stream);
+    }
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

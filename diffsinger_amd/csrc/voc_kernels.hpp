@@ -28,16 +28,18 @@
 
 namespace dsd {
 
-constexpr int kVocHalo = 28;               // taps reach +-25 samples (kernel 11, dilation 5); multiple of 4 for the float4 staging
+constexpr int kVocHalo = 28;               // taps reach +-25 samples (kernel 11, dilation 5) on the shipped generators; multiple of 4 (float4 staging)
+constexpr int kVocHaloWide = 48;           // second instantiation of k_voc_conv: taps up to +-48 samples (the official v3 generator: kernel 7 at
+                                           // dilation 12 = 36), hifigan.py:104-179 accepts any config
 constexpr int kVocLdsBudget = 72 * 1024;   // two workgroups per CU
 
 template <int NB, int WT> constexpr int voc_span() { return 32 * NB * WT; }                    // samples per workgroup
-template <int NB, int WT> constexpr int voc_ld() { return voc_span<NB, WT>() + 2 * kVocHalo; }  // LDS row stride
-template <int NB, int WT> constexpr int voc_slab() {                                          // input channels staged per pass
-    const int s = kVocLdsBudget / (voc_ld<NB, WT>() * 4) / 8 * 8;
+template <int NB, int WT, int HALO = kVocHalo> constexpr int voc_ld() { return voc_span<NB, WT>() + 2 * HALO; }  // LDS row stride
+template <int NB, int WT, int HALO = kVocHalo> constexpr int voc_slab() {                     // input channels staged per pass
+    const int s = kVocLdsBudget / (voc_ld<NB, WT, HALO>() * 4) / 8 * 8;
     return s > 256 ? 256 : s;
 }
-template <int NB, int WT> constexpr int voc_lds_bytes() { return voc_slab<NB, WT>() * voc_ld<NB, WT>() * 4; }
+template <int NB, int WT, int HALO = kVocHalo> constexpr int voc_lds_bytes() { return voc_slab<NB, WT, HALO>() * voc_ld<NB, WT, HALO>() * 4; }
 
 enum VocAct { VOC_ACT_NONE = 0, VOC_ACT_TANH = 1 };
 
@@ -76,9 +78,9 @@ struct VocTapB {            // B-operand functor of GemmPipe: chunk kc = ci8 * K
 __device__ __forceinline__ float voc_lrelu(float v, float slope) { return (v > 0.f) ? v : v * slope; }
 
 // Workgroup = WR = 4 / WT row blocks of 32 x (WT * NB * 32) samples of one utterance.  Wave w: row block (w % WR), time part (w / WR).
-template <int NB, int WT>
+template <int NB, int WT, int HALO = kVocHalo>
 __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p) {
-    constexpr int LD = voc_ld<NB, WT>(), SPAN = voc_span<NB, WT>(), SLAB = voc_slab<NB, WT>(), WR = 4 / WT;
+    constexpr int LD = voc_ld<NB, WT, HALO>(), SPAN = voc_span<NB, WT>(), SLAB = voc_slab<NB, WT, HALO>(), WR = 4 / WT;
     constexpr int NCOL4 = LD / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [SLAB][LD]
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
         // stage channels [c0, c0 + nc) x samples [t0 - halo, t0 + SPAN + halo), zero outside [0, LSi), leaky_relu applied here
         for (int idx = tid; idx < nc8 * NCOL4; idx += kThreads) {
             const int row = idx / NCOL4, g = idx - row * NCOL4;
-            const int t = t0 - kVocHalo + 4 * g;
+            const int t = t0 - HALO + 4 * g;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < nc && t >= 0 && t < p.LSi) {
                 v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + row) * p.LSi + t);
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
         __syncthreads();
         const int nch = (nc8 / 8) * p.KT;
         const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
-        const VocTapB<LD> bof{smem + 4 * h * LD + kVocHalo + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch};
+        const VocTapB<LD> bof{smem + 4 * h * LD + HALO + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch};
         gemm_k<1, NB, LD, 64>(acc, ap, lane, nch, bof);
         __syncthreads();
     }

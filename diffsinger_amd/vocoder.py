@@ -25,7 +25,7 @@ from torch import nn
 from . import _lib
 
 LRELU_SLOPE = 0.1
-MAX_REACH = 28        # kVocHalo of csrc/voc_kernels.hpp: taps may reach +-28 samples
+MAX_REACH = 48        # kVocHaloWide of csrc/voc_kernels.hpp: taps may reach +-48 samples (beyond +-28 a second instantiation of the conv kernel runs)
 
 
 def padded_samples(L: int) -> int:
@@ -290,7 +290,7 @@ class HifiGanGenerator(nn.Module):
         co, ci, k = conv.wshape()
         if get_padding(k, dil) > MAX_REACH:
             raise NotImplementedError(f'Conv1d kernel {k} at dilation {dil} reaches {get_padding(k, dil)} samples; the vocoder kernels stage +-{MAX_REACH} '
-                                      f'(kernel 11 at dilation 5 = 25, the shipped generators)')
+                                      f'(kernel 11 at dilation 5 = 25 on the shipped generators, kernel 7 at dilation 12 = 36 on the official v3)')
         F = self._ops.fold_factor(co, ci, k, dil)
         e = self._prep(key, conv, fold=F)
         if F > 1:

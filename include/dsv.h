@@ -41,8 +41,9 @@ int dsv_pad_rows(const float* in, float* out, int64_t R, int32_t L, void* stream
  *     co = row / up, phase = row % up, n = q * up + phase                                              (up = 1: plain Conv1d)
  *     v = y + bias[co] ; v += residual[co][n] ; v = sum_in[co][n] + v ; v = v / divide ; v = act(v)  -> out[co][n]
  * in [B][Ci][LS(L_in)]; out / residual / sum_in [B][rows / up][LS(L_in * up)]; bias [rows / up]; residual, sum_in, bias may be
- * NULL; pre_slope 1 = no activation in front, divide 1 = none.  Taps must stay within +-28 samples (pad <= 28 and
- * (K-1) * dil - pad <= 28: kernel 11 at dilation 5 reaches 25).
+ * NULL; pre_slope 1 = no activation in front, divide 1 = none.  Taps must stay within +-48 samples (pad <= 48 and
+ * (K-1) * dil - pad <= 48: kernel 11 at dilation 5 reaches 25 on the shipped generators, the official v3's kernel 7 at dilation 12
+ * reaches 36; beyond +-28 a second instantiation of the kernel with a wider staged window runs).
  * Covers: `leaky_relu -> convs1[i]`, `leaky_relu -> convs2[i] -> + x` (residual), the last conv of resblock j adding into
  * the running `xs` (sum_in) and the last one also doing `/ num_kernels` (divide), `leaky_relu -> ups[i] (+ x_source)`
  * (up = stride, residual = the noise_convs output), conv_pre, and `leaky_relu(0.01) -> conv_post -> tanh`. */

@@ -40,6 +40,9 @@ CONV_CASES = [
     dict(ci=512, co=256, k=3, dil=1, L=50),                                                  # more than one channel slab, two row tiles
     dict(ci=8, co=1, k=7, dil=1, L=2000, slope=0.01, act=1),                                 # conv_post -> tanh
     dict(ci=12, co=20, k=5, dil=2, L=77, slope=0.1),                                         # nothing a multiple of 8 / 32
+    dict(ci=32, co=32, k=7, dil=12, L=900, slope=0.1, res=True),                            # reach 36 > 28: the wide-window instantiation (official v3)
+    dict(ci=64, co=64, k=9, dil=12, L=300, slope=0.1),                                      # reach 48, <2,2> tiling
+    dict(ci=128, co=128, k=7, dil=12, L=100, slope=0.1, res=True, acc=True),               # reach 36, <1,1> tiling
 ]
 
 

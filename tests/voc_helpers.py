@@ -23,7 +23,7 @@ class HeaderFormulaOps:
 
     def conv(self, x, L_in, wp, bias, rows, ci, k, pad, dil, up=1, pre_slope=1.0, residual=None, sum_in=None, divide=1.0, act=0):
         assert x.shape[2] == padded_samples(L_in) and float(x[:, :, L_in:].abs().sum()) == 0.0, 'input tail must be zero'
-        assert pad <= 28 and (k - 1) * dil - pad <= 28
+        assert pad <= 48 and (k - 1) * dil - pad <= 48
         xin = x[:, :, :L_in]
         if pre_slope != 1.0:
             xin = torch.where(xin > 0, xin, xin * pre_slope)
