@@ -43,8 +43,8 @@ static TrBwd tr_bwd_layout(int B, int TS, int L) {
     size_t o = 0;
     s.wotp = o; o += L * kTrW1;
     s.wdtp = o; o += L * kTrW3 + kTrSlack;
-    s.da = o; o += 2 * act;
-    s.g = o; o += act;
+    s.da = o; o += 2 * (2 * act);           // two slots each of da / g: the fused kernel of layer l reads da(l) and writes da(l - 1), g(l - 1)
+    s.g = o; o += 2 * act;
     s.dxp0 = o; o += act;
     s.dxp1 = o; o += act;
     s.dds_part = o; o += tr_al((size_t)L * ntiles * kC);
@@ -87,6 +87,8 @@ static int tr_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
     return DSD_OK;
@@ -220,7 +222,6 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
     const TrSave lay = tr_save_layout(B, TS, L);
     const TrBwd bl = tr_bwd_layout(B, TS, L);
     const size_t act = (size_t)B * kC * TS;
-    (void)act;
     // transposed weights in fragment order, two 128-row groups of four row blocks: Wo^T [256 gate channels][512 output rows]; Wd^T flipped
     // [256 input channels][3 x 512]
     DSD_TRY(tr_pack_multi(s, w->out_w, L, bws + bl.wotp, kTrW1, 2, 1, 64, 4, 0, 0, kC, 2 * kC, 1, kC, 0));
@@ -229,32 +230,30 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         for (int l = 0; l < L; ++l) { halves[2 * l] = w->dilated_conv_w[l]; halves[2 * l + 1] = w->dilated_conv_w[l] + (size_t)kC * 3 * kC; }
         DSD_TRY(tr_pack_multi(s, halves, 2 * L, bws + bl.wdtp, kTrW3 / 2, 2, 3, 32, 4, 0, 0, kC, kC, 3, 3 * kC, 1));
     }
-    float* dxp[2] = {bws + bl.dxp0, bws + bl.dxp1};
-    for (int l = L - 1; l >= 0; --l) {
+    float* dxp[2] = {bws + bl.dxp0, bws + bl.dxp1};           // dxp[k & 1]: gradient wrt the output x of layer k
+    const long long da_bs = da_all ? (long long)L * 2 * kC * TS : (long long)2 * kC * TS;
+    auto da_of = [&](int l) { return da_all ? da_all + (size_t)l * 2 * kC * TS : bws + bl.da + (size_t)(l & 1) * 2 * act; };
+    auto g_of = [&](int l) { return bws + bl.g + (size_t)(l & 1) * act; };
+    auto gate_params = [&](int l) {
+        TrbGateParams p{};
+        p.dxp = (l == L - 1) ? nullptr : dxp[l & 1]; p.dsk = dskip; p.a_frag = (const float4*)(sws + lay.A + (size_t)l * lay.A_l);
+        p.wotp = (const float4*)(bws + bl.wotp + (size_t)l * kTrW1);
+        p.da = da_of(l); p.g = g_of(l); p.da_bstride = da_bs; p.T = T; p.TS = TS; p.ntile32 = ntile32; p.xcd_q = ntiles / 8; p.xcd_r = ntiles % 8;
+        return p;
+    };
+    auto conv_params = [&](int l) {
+        TrbConvParams p{};
+        p.da = da_of(l); p.wdtp = (const float4*)(bws + bl.wdtp + (size_t)l * kTrW3); p.dxp = (l == L - 1) ? nullptr : dxp[l & 1];
+        p.dx_out = (l == 0) ? g->dx0 : dxp[(l - 1) & 1];
+        p.dds_part = bws + bl.dds_part + (size_t)l * ntiles * kC; p.da_bstride = da_bs;
+        p.T = T; p.TS = TS; p.ntile32 = ntile32; p.dil = w->dilations[l]; p.xcd_q = ntiles / 8; p.xcd_r = ntiles % 8;
+        return p;
+    };
+    // the layer's weight gradients: 12 (dilated conv: 4 row tiles x 3 taps) + 4 (conditioner projection) + 4 or 2 (output projection) tiles
+    auto wgrad = [&](int l) -> int {
         const bool last = (l == L - 1);
-        const float* dxp_in = last ? nullptr : dxp[(l + 1) & 1];
-        float* dx_out = (l == 0) ? g->dx0 : dxp[l & 1];
-        float* da = da_all ? da_all + (size_t)l * 2 * kC * TS : bws + bl.da;
-        const long long da_bs = da_all ? (long long)L * 2 * kC * TS : (long long)2 * kC * TS;
-        {
-            TrbGateParams p{};
-            p.dxp = dxp_in; p.dsk = dskip; p.a_frag = (const float4*)(sws + lay.A + (size_t)l * lay.A_l);
-            p.wotp = (const float4*)(bws + bl.wotp + (size_t)l * kTrW1);
-            p.da = da; p.g = bws + bl.g; p.da_bstride = da_bs; p.T = T; p.TS = TS; p.ntile32 = ntile32; p.xcd_q = ntiles / 8; p.xcd_r = ntiles % 8;
-            if (last) hipLaunchKernelGGL(k_trb_gate<true>, dim3((unsigned)ntiles), dim3(kThreads), kTrbGateLdsBytes, s, p);
-            else hipLaunchKernelGGL(k_trb_gate<false>, dim3((unsigned)ntiles), dim3(kThreads), kTrbGateLdsBytes, s, p);
-            HIP_TRY(hipGetLastError());
-        }
-        {
-            TrbConvParams p{};
-            p.da = da; p.wdtp = (const float4*)(bws + bl.wdtp + (size_t)l * kTrW3); p.dxp = dxp_in; p.dx_out = dx_out;
-            p.dds_part = bws + bl.dds_part + (size_t)l * ntiles * kC; p.da_bstride = da_bs;
-            p.T = T; p.TS = TS; p.ntile32 = ntile32; p.dil = w->dilations[l]; p.xcd_q = ntiles / 8; p.xcd_r = ntiles % 8;
-            if (last) hipLaunchKernelGGL(k_trb_conv<true>, dim3((unsigned)ntiles), dim3(kThreads), kTrbConvLdsBytes, s, p);
-            else hipLaunchKernelGGL(k_trb_conv<false>, dim3((unsigned)ntiles), dim3(kThreads), kTrbConvLdsBytes, s, p);
-            HIP_TRY(hipGetLastError());
-        }
-        // the layer's weight gradients: 12 (dilated conv: 4 row tiles x 3 taps) + 4 (conditioner projection) + 4 or 2 (output projection) tiles
+        const float* da = da_of(l);
+        const float* dxp_in = last ? nullptr : dxp[l & 1];
         TrWgParams wp{};
         int nd = 0;
         const float* y = sws + lay.Y + (size_t)l * lay.Y_l + kTrYPad;
@@ -276,7 +275,7 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
             TrWgTile& d = wp.tile[nd++];
             if (mt < 2) { d.a = dxp_in + (size_t)mt * 128 * TS; d.a_scale = kTrInvSqrt2; }
             else { d.a = dskip + (size_t)(mt - 2) * 128 * TS; d.a_scale = 1.f; }
-            d.a_bstride = (long long)kC * TS; d.bsrc = bws + bl.g; d.b_bstride = (long long)kC * TS; d.b_rs = TS; d.shift = 0;
+            d.a_bstride = (long long)kC * TS; d.bsrc = g_of(l); d.b_bstride = (long long)kC * TS; d.b_rs = TS; d.shift = 0;
             d.out = g->out_w[l] + (size_t)mt * 128 * kC; d.out_rs = kC; d.out_cs = 1; d.out_bias = g->out_b[l] + mt * 128;
         }
         if (last) {          // the residual half of the last layer's output projection is dead (net.py:126 reads the skips only): zero gradient
@@ -284,7 +283,36 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
             HIP_TRY(hipMemsetAsync(g->out_b[l], 0, (size_t)kC * sizeof(float), s));
         }
         wp.part = bws + bl.part; wp.part_b = bws + bl.part_b;
-        DSD_TRY(tr_wgrad_launch(s, wp, nd, B, T, TS, false));
+        return tr_wgrad_launch(s, wp, nd, B, T, TS, false);
+    };
+    static const bool fuse = []() { const char* e = getenv("DSD_TRAIN_FUSE_BWD"); return !(e && e[0] == '0'); }();     // developer switch (A/B on one box)
+    const dim3 grid((unsigned)ntiles), blk(kThreads);
+    {   // gate derivative of the last layer (its x_out is dead: K = 256)
+        const TrbGateParams p = gate_params(L - 1);
+        hipLaunchKernelGGL(k_trb_gate<true>, grid, blk, kTrbGateLdsBytes, s, p);
+        HIP_TRY(hipGetLastError());
+        DSD_TRY(wgrad(L - 1));
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = (l == L - 1);
+        if (l > 0 && fuse) {
+            // transposed conv of layer l + gate derivative of layer l - 1 in one kernel (the dx tile stays in the workgroup)
+            TrbFusedParams q{conv_params(l), gate_params(l - 1)};
+            if (last) hipLaunchKernelGGL(k_trb_fused<true>, grid, blk, kTrbFusedLdsBytes, s, q);
+            else hipLaunchKernelGGL(k_trb_fused<false>, grid, blk, kTrbFusedLdsBytes, s, q);
+            HIP_TRY(hipGetLastError());
+        } else {
+            const TrbConvParams p = conv_params(l);
+            if (last) hipLaunchKernelGGL(k_trb_conv<true>, grid, blk, kTrbConvLdsBytes, s, p);
+            else hipLaunchKernelGGL(k_trb_conv<false>, grid, blk, kTrbConvLdsBytes, s, p);
+            HIP_TRY(hipGetLastError());
+            if (l > 0) {
+                const TrbGateParams pg = gate_params(l - 1);
+                hipLaunchKernelGGL(k_trb_gate<false>, grid, blk, kTrbGateLdsBytes, s, pg);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        if (l > 0) DSD_TRY(wgrad(l - 1));
     }
     hipLaunchKernelGGL(k_tr_dds_reduce, dim3((unsigned)B, (unsigned)L), dim3(kC), 0, s, bws + bl.dds_part, g->dstep, L, ntile32, ntiles);
     HIP_TRY(hipGetLastError());

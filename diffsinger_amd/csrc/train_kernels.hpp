@@ -409,6 +409,162 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_conv(const TrbConvParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// backward, parts 2 + 1 fused: k_trb_conv of layer l, then k_trb_gate of layer l - 1 on the same tile
+// ------------------------------------------------------------------------------------------------------------
+// The gate kernel of layer l - 1 reads exactly the dx tile the conv kernel of layer l just produced (the output projection is a 1 x 1
+// convolution: no halo) - so it runs behind it in the SAME workgroup: dx goes from the accumulators into the dy2 tile in LDS (and to global
+// memory for the weight gradient and the next residual path), one kernel node and one round trip through memory less per layer.  The
+// kernel boundary stays where a tile needs its neighbours: in front of the transposed conv (halo columns of da).  Arithmetic and summation
+// orders are those of the two kernels: results are bit-identical to them.
+struct TrbFusedParams {
+    TrbConvParams c;            // layer l
+    TrbGateParams g;            // layer l - 1 (g.dxp is not read: the gradient comes from this workgroup's accumulators)
+};
+constexpr int kTrbFusedLdsBytes = kTrbConvLdsBytes;
+
+template <bool LAST>            // LAST: layer l is the last layer (no residual path into its conv gradient)
+__global__ __launch_bounds__(kThreads, 1) void k_trb_fused(const TrbFusedParams q) {
+    constexpr int LD = kTrbConvLD;
+    const TrbConvParams& p = q.c;
+    const TrbGateParams& pg = q.g;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // da tile [512][48], then dy2 tile [512][32]; exchange
+    float* xbuf = smem + 2 * kC * LD;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w & 1, wk = w >> 1;
+    const int tile = xcd_item(blockIdx.x, p.xcd_q, p.xcd_r), b = tile / p.ntile32, t0 = (tile - b * p.ntile32) * 32;
+    const ConvB<LD> bof{smem + (wk * kC + 4 * h) * LD + kHalo + j, p.dil, 0};
+    GemmPipe<4, 1, LD, 256, 6, ConvB<LD>> pipe(p.wdtp + ((size_t)(wk * 2 + wr) * 96) * 256, lane, 96, bof);
+    const float* src = p.da + (size_t)b * p.da_bstride;
+    float4 sv[4][6];
+    auto request = [&](int qq) {
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int idx = it * kThreads + tid, rq = idx / 12, g = idx - rq * 12;
+            const int row = (rq < 64) ? 64 * qq + rq : kC + 64 * qq + (rq - 64);
+            const int t = t0 - kHalo + 4 * g;
+            const bool in = (t >= 0) && (t < p.TS);
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)row * p.TS + (in ? t : t0));
+            sv[qq][it] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        DSD_SB();
+    };
+    auto write = [&](int qq) {
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int idx = it * kThreads + tid, rq = idx / 12, g = idx - rq * 12;
+            const int row = (rq < 64) ? 64 * qq + rq : kC + 64 * qq + (rq - 64);
+            *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = sv[qq][it];
+        }
+    };
+    request(0);
+    pipe.template start_a<0, 2>();
+    request(1); request(2); request(3);
+    pipe.template start_a<2, 5>();
+    const int t = t0 + j;
+    const bool ok = t < p.T;
+    float rv[2][16];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
+            rv[mb][r] = LAST ? 0.f : p.dxp[((size_t)b * kC + row) * p.TS + t];
+        }
+    DSD_SB();
+    f32x16 acc[4][1];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][0][r] = 0.f;
+    write(0);
+    __syncthreads();
+    pipe.start_b();
+    pipe.run(acc, 0, 6);
+    write(1);
+    __syncthreads();
+    pipe.run(acc, 6, 12);
+    write(2);
+    __syncthreads();
+    pipe.run(acc, 12, 18);
+    write(3);
+    __syncthreads();
+    // the skip rows of the next contraction's B tile and its first weight chunks are requested half way through this one
+    pipe.run(acc, 18, 48);
+    constexpr int NCH = 32;
+    const int ch0 = NCH * wk;
+    const TileB bofg{smem + ch0 * 8 * 32 + 4 * h * 32 + j, 8 * 32, NCH};
+    GemmPipe<4, 1, 32, 256, 6, TileB> pipeg(pg.wotp + ((size_t)wr * 64 + ch0) * 256, lane, NCH, bofg);
+    const int sg = tid & 7, st = t0 + 4 * sg;
+    float4 vs[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) vs[it] = *reinterpret_cast<const float4*>(pg.dsk + ((size_t)b * kC + it * 32 + (tid >> 3)) * p.TS + st);
+    DSD_SB();
+    pipe.run(acc, 48, 96);
+    f32x16 fin[2];
+    trb_exchange(acc, fin, xbuf, wr, wk, lane);          // its barrier: every wave is done reading the da tile
+    pipeg.start_a();
+    // saved pre-activation of layer l - 1 at the rows this wave finishes there
+    float4 av[4][4];
+    {
+        const float4* al = pg.a_frag + ((size_t)tile * 4 + 2 * wr + wk) * (4 * 4 * 64) + lane;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) av[mb][qq] = al[(mb * 4 + qq) * 64];
+    }
+    DSD_SB();
+    // conv gradient epilogue (k_trb_conv) + the residual rows of the dy2 tile
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
+            const float dy = ok ? fin[mb][r] : 0.f;
+            const float dx = ok ? rv[mb][r] * kTrInvSqrt2 + dy : 0.f;
+            store4_wt(p.dx_out + (size_t)b * kC * p.TS, row * p.TS + t, dx);
+            smem[row * 32 + j] = dx * kTrInvSqrt2;
+            float s = dy;
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+            if (j == 0) p.dds_part[(size_t)tile * kC + row] = s;
+        }
+    {
+        const bool m0 = st + 0 < p.T, m1 = st + 1 < p.T, m2 = st + 2 < p.T, m3 = st + 3 < p.T;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 32 + (tid >> 3);
+            const float4 s4 = vs[it];
+            *reinterpret_cast<float4*>(smem + (kC + row) * 32 + 4 * sg) = make_float4(m0 ? s4.x : 0.f, m1 ? s4.y : 0.f, m2 ? s4.z : 0.f, m3 ? s4.w : 0.f);
+        }
+    }
+    __syncthreads();
+    // output-projection data gradient + gate derivative of layer l - 1 (k_trb_gate<false>)
+    f32x16 accg[4][1];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accg[mb][0][r] = 0.f;
+    pipeg.start_b();
+    pipeg.run(accg, 0, NCH);
+    f32x16 fing[2];
+    trb_exchange(accg, fing, xbuf, wr, wk, lane);
+    float* dab = pg.da + (size_t)b * pg.da_bstride;
+    float* gb = pg.g + (size_t)b * kC * p.TS;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ag = f4at(av[mb][r >> 2], r & 3), af = f4at(av[mb + 2][r >> 2], r & 3);
+            const float sg_ = 1.f / (1.f + expf(-ag)), th = tanhf(af);
+            const float dg = fing[mb][r];
+            const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
+            store4_wt(dab, row * p.TS + t, ok ? dg * th * (sg_ * (1.f - sg_)) : 0.f);
+            store4_wt(dab, (kC + row) * p.TS + t, ok ? dg * sg_ * (1.f - th * th) : 0.f);
+            store4_wt(gb, row * p.TS + t, ok ? sg_ * th : 0.f);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // weight gradients: dW[m][n] = sum_b sum_t A[m][t] * B[n][t + shift], 128 x 256 output tiles, contraction over frames
 // ------------------------------------------------------------------------------------------------------------
 // MFMA roles: D[i = m][j = n] += A[i][k] B[k][j] with k = frame.  Both operands are activations with the frame axis contiguous: a
