@@ -249,13 +249,11 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         p.T = T; p.TS = TS; p.ntile32 = ntile32; p.dil = w->dilations[l]; p.xcd_q = ntiles / 8; p.xcd_r = ntiles % 8;
         return p;
     };
-    // the layer's weight gradients: 12 (dilated conv: 4 row tiles x 3 taps) + 4 (conditioner projection) + 4 or 2 (output projection) tiles
-    auto wgrad = [&](int l) -> int {
+    // a layer's weight gradients: 12 (dilated conv: 4 row tiles x 3 taps) + 4 (conditioner projection) + 4 or 2 (output projection) tiles
+    auto wgrad_tiles = [&](int l, TrWgParams& wp, int& nd) -> int {
         const bool last = (l == L - 1);
         const float* da = da_of(l);
         const float* dxp_in = last ? nullptr : dxp[l & 1];
-        TrWgParams wp{};
-        int nd = 0;
         const float* y = sws + lay.Y + (size_t)l * lay.Y_l + kTrYPad;
         const int yrs = TS + 2 * kTrYPad;
         const int dil = w->dilations[l];
@@ -282,8 +280,26 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
             HIP_TRY(hipMemsetAsync(g->out_w[l], 0, (size_t)kC * kC * sizeof(float), s));
             HIP_TRY(hipMemsetAsync(g->out_b[l], 0, (size_t)kC * sizeof(float), s));
         }
+        return DSD_OK;
+    };
+    // Layers whose operands are complete (da, g written by their gate kernel; the gradient wrt their output x by the conv kernel of the layer
+    // above) wait here: two layers share ONE weight-gradient launch - 40 tiles x 6 frame splits instead of 2 x (20 x 12): the same 240
+    // workgroups work twice as long, half the split-K partials per layer are written and reduced, half the launches.  The slots of da / g /
+    // dx alternate by layer parity: a pair is launched before the next kernel overwrites the older one's slot.
+    static const bool pair = []() { const char* e = getenv("DSD_TRAIN_WGRAD_PAIR"); return !(e && e[0] == '0'); }();     // developer switch (A/B on one box)
+    int pending[2], npend = 0;
+    auto wgrad_flush = [&]() -> int {
+        if (!npend) return DSD_OK;
+        TrWgParams wp{};
+        int nd = 0;
+        for (int i = 0; i < npend; ++i) DSD_TRY(wgrad_tiles(pending[i], wp, nd));
+        npend = 0;
         wp.part = bws + bl.part; wp.part_b = bws + bl.part_b;
         return tr_wgrad_launch(s, wp, nd, B, T, TS, false);
+    };
+    auto wgrad = [&](int l) -> int {
+        pending[npend++] = l;
+        return (npend == 2 || !pair) ? wgrad_flush() : DSD_OK;
     };
     static const bool fuse = []() { const char* e = getenv("DSD_TRAIN_FUSE_BWD"); return !(e && e[0] == '0'); }();     // developer switch (A/B on one box)
     const dim3 grid((unsigned)ntiles), blk(kThreads);
@@ -314,6 +330,7 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         }
         if (l > 0) DSD_TRY(wgrad(l - 1));
     }
+    DSD_TRY(wgrad_flush());
     hipLaunchKernelGGL(k_tr_dds_reduce, dim3((unsigned)B, (unsigned)L), dim3(kC), 0, s, bws + bl.dds_part, g->dstep, L, ntile32, ntiles);
     HIP_TRY(hipGetLastError());
     return DSD_OK;

@@ -583,7 +583,7 @@ struct TrWgTile {
     int shift, out_rs, out_cs, b_rs;
     float a_scale;
 };
-constexpr int kTrWgMaxTiles = 24;
+constexpr int kTrWgMaxTiles = 40;        // the weight gradients of TWO layers per launch (2 x 20 tiles x 6 frame splits = 240 workgroups)
 struct TrWgParams {
     TrWgTile tile[kTrWgMaxTiles];
     float* part;                // [ntile_desc][nsplit][128][256]
