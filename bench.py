@@ -379,38 +379,37 @@ def main_train(args):
     el, loss = _row_time(step, args, world, device, dist)
     assert bool(torch.isfinite(loss)), 'non-finite loss'
     if rank == 0:
-        # dominant kernel of the fused stack: k_tr_wgrad - here as the weight gradient of the dilated convolution (512 x 256 x 3) through
-        # dsf_conv1d_wgrad2, launches timed with events on the launch stream; the split-K reduction kernel behind it is part of the figure
+        # dominant kernel of the fused stack: k_tr_wgrad, timed live AS IT RUNS INSIDE THE STEP - the library brackets every weight-gradient
+        # launch with events on its stream (dsf_wgrad_probe); one launch = the weight gradients of two layers (40 tiles x 6 frame splits)
         from diffsinger_amd import train_fused
-        from diffsinger_amd.fs2 import padded_frames
-        dyw = torch.randn(B, 512, padded_frames(T), device=device)
-        xw = torch.randn(B, 256, padded_frames(T), device=device)
-        launch = lambda: train_fused.conv1d_wgrad2(dyw, xw, 3, 1, T)
-        for _ in range(3):
-            launch()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(20):
-            launch()
-        ev1.record()
-        ev1.synchronize()
-        ms = ev0.elapsed_time(ev1) / 20
-        flop = 2 * 512 * 768 * B * T
-        achieved = flop / (ms * 1e-3) / 1e12
         fused = train_fused.enabled() and train_fused.supported(net)
-        roof = {'bound': 'mfma', 'kernel': 'k_tr_wgrad (+ k_tr_wgrad_reduce)', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_launch_ms': ms, 'flop_per_launch': flop,
-                'algorithmic_bytes_per_launch': 4 * B * T * (256 + 512) + 4 * 512 * 768,
-                'note': 'the weight gradient of the dilated convolution of one residual block as a stand-alone launch (12 output tiles x 16 frame '
-                        'splits = 192 workgroups on 256 CUs; inside the training step the layer\'s three weight gradients are ONE launch of 20 tiles '
-                        'x 12 splits: profiles/r02o_train_kernel_stats_8x1024.txt, 10.7 GFLOP in 113 us = 0.60 of peak); eager launches incl. the '
-                        'ctypes calls and the reduction kernel'}
-        try:        # fabric-side bytes of the kernel as it runs inside the step (20 tiles x 12 splits), from the round's separate --pmc passes
+        roof = None
+        if fused:
+            train_fused.wgrad_probe(True)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize(device)
+            ms_tot, n_launch, fl = train_fused.wgrad_probe_read()
+            train_fused.wgrad_probe(False)
+            ms = ms_tot / max(n_launch, 1)
+            flop = fl / max(n_launch, 1)
+            achieved = flop / (ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'k_tr_wgrad<false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_launch_ms': ms, 'flop_per_launch': flop, 'launches_timed': n_launch,
+                    'note': 'every weight gradient of two residual layers per launch (dilated conv 3 taps, conditioner projection, output projection: '
+                            '2 x 20 output tiles of 128 x 256, contracted over the frames in 6 splits = 240 workgroups); average over the launches of '
+                            '3 steps, events on the launch stream around each launch (they include the gap to the previous kernel); the split-K '
+                            'reduction kernel behind it is not part of the figure.  Kernel times of the whole step: profiles/r03m_train_kernel_stats.txt'}
+        else:
+            roof = {'bound': 'mfma', 'kernel': 'k_fs_conv<2> (operator path)', 'achieved': None, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
+                    'traffic': None, 'note': 'the fused stack is switched off (DSD_TRAIN_FUSED=0) or does not cover this DiffNet'}
+        try:        # fabric-side bytes of the same launch (two layers), from the round's separate --pmc passes over the training step
             pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'train_wgrad_pmc.json')))
-            roof['traffic'] = pm['hbm_bytes_per_launch']['total']
-            roof['traffic_unit'] = 'bytes/launch'
-            roof['traffic_source'] = (f"profiles/train_wgrad_pmc.json ({pm.get('round', '?')}): FETCH_SIZE x 2 + WRITE_SIZE of k_tr_wgrad inside the training step "
-                                      f"(one layer's three weight gradients: 10.7 GFLOP, 59 MB of operands + 31.5 MB of split-K partials per launch)")
+            if fused:
+                roof['traffic'] = pm['hbm_bytes_per_launch']['total']
+                roof['traffic_unit'] = 'bytes/launch'
+                roof['traffic_source'] = (f"profiles/train_wgrad_pmc.json ({pm.get('round', '?')}): FETCH_SIZE x 2 + WRITE_SIZE of k_tr_wgrad inside the training step; "
+                                          f"algorithmic: 118 MB of operands (da, y, cond, g, dx', dskip of two layers) + 31.5 MB of split-K partials per launch")
         except (OSError, KeyError, ValueError):
             pass
         value = world * B * T * args.steps / el

@@ -106,15 +106,36 @@ static int tr_nsplit(int ndesc, int ntile) {
     return std::min(ns, ntile);
 }
 
+// Measurement hook (bench.py --row train): with the probe on, every k_tr_wgrad launch of the fused stack is bracketed by two events on its own
+// stream; dsf_wgrad_probe_read sums the elapsed times (the roofline figure of the dominant kernel as it runs INSIDE the step).
+struct TrProbe { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0.0; };
+static TrProbe& tr_probe() { static TrProbe p; return p; }
+
 // fix: some B operand is not padded against its tap shift (k_tr_wgrad<true>)
 static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int T, int TS, bool fix) {
     wp.B = B; wp.T = T; wp.TS = TS;
     wp.nsplit = tr_nsplit(ndesc, B * TS / 32);
     const int total = ndesc * wp.nsplit;
     wp.ndesc = ndesc; wp.xcd_q = total / 8; wp.xcd_r = total % 8;
+    TrProbe& pr = tr_probe();
+    const bool probe = pr.on && !fix;
+    if (probe) {
+        if (pr.used == pr.ev.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            pr.ev.emplace_back(a, b);
+        }
+        HIP_TRY(hipEventRecord(pr.ev[pr.used].first, s));
+    }
     if (fix) hipLaunchKernelGGL(k_tr_wgrad<true>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
     else hipLaunchKernelGGL(k_tr_wgrad<false>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
     HIP_TRY(hipGetLastError());
+    if (probe) {
+        HIP_TRY(hipEventRecord(pr.ev[pr.used].second, s));
+        ++pr.used;
+        pr.flops += 2.0 * 128 * 256 * (double)ndesc * (double)B * (double)T;
+    }
     hipLaunchKernelGGL(k_tr_wgrad_reduce, dim3((unsigned)ndesc, 128), dim3(256), 0, s, wp);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
@@ -371,5 +392,29 @@ extern "C" int dsf_conv1d_wgrad2(const float* dy, const float* x, float* dw, flo
         DSD_TRY(tr_wgrad_launch(s, wp, nd, B, T, TS, true));
         done += nd;
     }
+    return DSD_OK;
+}
+
+extern "C" int dsf_wgrad_probe(int32_t on) {
+    TrProbe& pr = tr_probe();
+    pr.on = on != 0;
+    pr.used = 0;
+    pr.flops = 0.0;
+    return DSD_OK;
+}
+
+extern "C" int dsf_wgrad_probe_read(double* total_ms, int64_t* launches, double* flops) {
+    if (!total_ms || !launches || !flops) return fail(DSD_ERR_INVALID, "dsf_wgrad_probe_read: null argument");
+    TrProbe& pr = tr_probe();
+    double ms = 0.0;
+    for (size_t i = 0; i < pr.used; ++i) {
+        HIP_TRY(hipEventSynchronize(pr.ev[i].second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, pr.ev[i].first, pr.ev[i].second));
+        ms += t;
+    }
+    *total_ms = ms; *launches = (int64_t)pr.used; *flops = pr.flops;
+    pr.used = 0;
+    pr.flops = 0.0;
     return DSD_OK;
 }

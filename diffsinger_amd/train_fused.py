@@ -69,6 +69,8 @@ def _bind(lib):
     lib.dsf_wgrad2_workspace_floats.argtypes = [i32, i32, i32]
     lib.dsf_wgrad2_workspace_floats.restype = i64
     lib.dsf_conv1d_wgrad2.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.dsf_wgrad_probe.argtypes = [i32]
+    lib.dsf_wgrad_probe_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib._stack_bound = True
 
 
@@ -161,3 +163,19 @@ def conv1d_wgrad2(dy: torch.Tensor, x: torch.Tensor, K: int, dil: int, T: int, w
         _lib.check(lib.dsf_conv1d_wgrad2(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if want_bias else None, ws.data_ptr(), B, Ci, Co, K, dil,
                                          T, _stream(dy.device)), 'dsf_conv1d_wgrad2')
     return dw, db
+
+
+def wgrad_probe(on: bool):
+    """Bracket every weight-gradient launch of the fused stack with events (bench.py --row train)."""
+    lib = _lib.load()
+    _bind(lib)
+    _lib.check(lib.dsf_wgrad_probe(1 if on else 0), 'dsf_wgrad_probe')
+
+
+def wgrad_probe_read():
+    """-> (summed kernel time in ms, launches, algorithmic FLOP) of the launches since the probe was switched on / last read."""
+    lib = _lib.load()
+    _bind(lib)
+    ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+    _lib.check(lib.dsf_wgrad_probe_read(C.byref(ms), C.byref(n), C.byref(fl)), 'dsf_wgrad_probe_read')
+    return ms.value, n.value, fl.value

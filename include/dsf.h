@@ -136,6 +136,12 @@ int dsf_stack_forward(const float* x0, const float* cond, const float* step, con
 int dsf_stack_backward(const float* dskip, const float* cond, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L, const float* save_ws,
                        float* bwd_ws, const dsf_stack_grads* grads, float* da_all, void* stream);
 
+/* Measurement hook of the fused stack's dominant kernel: with the probe on, every weight-gradient launch of dsf_stack_backward is bracketed by
+ * two events on its stream; ..._read waits for them and returns the summed kernel time, the number of launches and their algorithmic FLOP
+ * (2 x 128 x 256 x tiles x B x T), then resets.  bench.py --row train reports its roofline from this. */
+int dsf_wgrad_probe(int32_t on);
+int dsf_wgrad_probe_read(double* total_ms, int64_t* launches, double* flops);
+
 /* The weight-gradient kernel of the fused stack as a stand-alone operator with dsf_conv1d_wgrad's contract (K = 1 or 3, Co a multiple of
  * 128, Ci a multiple of 256): dw[co][ci][k] = sum dy[b][co][t] x[b][ci][t + (k - (K-1)/2) dil], db[co] = sum dy.  workspace:
  * dsf_wgrad2_workspace_floats(Co, Ci, K) floats. */
