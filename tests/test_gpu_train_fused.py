@@ -187,3 +187,45 @@ def test_p_losses_gradients_fused_equals_operator_path(monkeypatch):
     e_c = float((res['1'][2] - res['0'][2]).abs().max() / float(res['0'][2].abs().max()))
     print(f'fused vs operator path: loss {res["1"][0]:.6f} / {res["0"][0]:.6f}, worst parameter gradient {worst[1]:.2e} at {worst[0]}, dcond {e_c:.2e}')
     assert worst[1] <= 5e-5 and e_c <= 5e-5
+
+
+@pytest.mark.parametrize('loss_type,masked', [('l1', True), ('l2', False)])
+def test_p_losses_variants_on_the_fused_path(loss_type, masked):
+    """The masked L1 loss (shallow_diffusion_tts.py:222-226: `* nonpadding.unsqueeze(1)`) and the L2 loss (:228) through the fused stack: loss and every
+    parameter gradient against torch autograd on the CPU oracle; padded frames of a shorter utterance carry no loss."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from oracle import diffnet_oracle as O
+    from tests import helpers as H
+    pre = H.presets()['lj_ds_beta6']
+    cfg = H.net_config(pre)
+    params = {k: v.clone().requires_grad_(True) for k, v in H.oracle_params(cfg).items()}
+    B, T = 3, 77
+    g = torch.Generator().manual_seed(23)
+    x0 = torch.clamp(torch.randn(B, 1, 80, T, generator=g) * 0.5, -1, 1)
+    noise = torch.randn(B, 1, 80, T, generator=g)
+    cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
+    t = torch.tensor([3, 99, 41])
+    keep = torch.ones(B, 1, T)                                          # [B,1,T]: nonpadding.unsqueeze(1) multiplies [B,1,M,T] like the reference's broadcast
+    keep[1, :, 50:] = 0
+    keep[2, :, 10:] = 0
+    sch = O.make_schedule(H.betas_for(pre))
+    eps_ref = O.diffnet_forward(params, cfg, O.q_sample(sch, x0, t, noise), t, cond)
+    if loss_type == 'l1':
+        loss_ref = ((noise - eps_ref).abs() * keep.unsqueeze(1)).mean() if masked else (noise - eps_ref).abs().mean()
+    else:
+        loss_ref = F.mse_loss(noise, eps_ref)
+    loss_ref.backward()
+    hparams.clear()
+    diffsinger_amd.use_preset('lj_ds_beta6')
+    net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+    net.load_state_dict({k: v.detach() for k, v in params.items()}, strict=True)
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=pre['timesteps'], K_step=pre['K_step'], loss_type=loss_type,
+                                          spec_min=pre['spec_min'], spec_max=pre['spec_max']).cuda().train()
+    loss = gd.p_losses(x0.cuda(), t.cuda(), cond.cuda(), noise=noise.cuda(), nonpadding=keep.cuda() if masked else None)
+    loss.backward()
+    worst = 0.0
+    for k, p in net.named_parameters():
+        worst = max(worst, float((p.grad.cpu() - params[k].grad).abs().max() / max(float(params[k].grad.abs().max()), 1e-30)))
+    print(f'{loss_type} masked={masked}: loss {float(loss.detach()):.6f} (ref {float(loss_ref.detach()):.6f}), worst gradient rel err {worst:.2e}')
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 2e-6 * abs(float(loss_ref.detach())) and worst <= 2e-4
