@@ -1,6 +1,7 @@
 // train_abi.hpp - host side of the fused training stack (C ABI in include/dsf.h, "Training, the FUSED residual stack"); included at the
 // end of dsd.hip behind fs2_abi.hpp (one translation unit: shares fail(), HIP_TRY, fs_ts and the packing kernels).
 #include "train_kernels.hpp"
+#include "train_loop.hpp"
 
 namespace {
 
@@ -12,7 +13,7 @@ constexpr int kTrMaxSplit = 16;
 static inline size_t tr_al(size_t n) { return (n + 1023) / 1024 * 1024; }      // keeps every sub-buffer 4 KiB aligned
 
 struct TrSave {             // offsets in floats into save_ws
-    size_t w1p, wcp, w2p, b1p, cp, X, Y, A, skip, bsum, iota, total;
+    size_t w1p, wcp, w2p, b1p, cp, X, Y, A, skip, bsum, iota, flags, total;
     size_t cp_l, X_l, Y_l, A_l;      // per-layer strides
 };
 static TrSave tr_save_layout(int B, int TS, int L) {
@@ -30,6 +31,7 @@ static TrSave tr_save_layout(int B, int TS, int L) {
     s.skip = o; o += ntiles * 8192;
     s.bsum = o; o += 1024;
     s.iota = o; o += tr_al((size_t)B);
+    s.flags = o; o += tr_al(ntiles + 64);       // phase flags + timeout word of the persistent forward (its halo buffers alias X)
     s.total = o;
     return s;
 }
@@ -83,6 +85,7 @@ static int tr_attrs() {
     if (!first_on_device(30)) return DSD_OK;
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_stack_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
@@ -95,12 +98,16 @@ static int tr_attrs() {
 }
 
 // split-K factor of a weight-gradient launch of `ndesc` output tiles: fill the chip once (one workgroup per CU), never more splits than frame tiles
-static int tr_nsplit(int ndesc, int ntile) {
+static int tr_ncu() {
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
     }
+    return ncu;
+}
+static int tr_nsplit(int ndesc, int ntile) {
+    const int ncu = tr_ncu();
     int ns = ncu / std::max(ndesc, 1);
     ns = std::max(1, std::min(ns, kTrMaxSplit));
     return std::min(ns, ntile);
@@ -168,6 +175,65 @@ extern "C" int dsf_stack_offsets(int32_t B, int32_t T, int32_t L, int32_t which,
     return DSD_OK;
 }
 
+// The forward as ONE persistent launch per chunk of whole utterances (train_loop.hpp) instead of a launch per layer: on when an utterance fits
+// the co-resident grid (one workgroup per CU) and the chunks fill the chip at least as well as the per-layer grid does (the rule of
+// loop_applicable(), dsd.hip).  DSD_TRAIN_PERSIST=0 keeps the per-layer launches (the A/B switch of tools/bench_train.py).
+static bool tr_persist_applies(int B, int ntile32) {
+    const char* e = getenv("DSD_TRAIN_PERSIST");
+    if (e && atoi(e) == 0) return false;
+    const int ncu = tr_ncu();
+    if (ncu < 8 || ntile32 > ncu) return false;
+    if (e && atoi(e) == 2) return true;            // forced (tests of the chunked form on any shape)
+    const int ntiles = B * ntile32, upc = std::max(1, ncu / ntile32), chunks = (B + upc - 1) / upc;
+    const double u_p = (double)ntiles / ((double)chunks * ncu);
+    const double u_l = 0.9 * (double)ntiles / ((double)((ntiles + ncu - 1) / ncu) * ncu);
+    return u_p >= u_l;
+}
+
+static int tr_forward_persistent(const float* x0, const float* step, const dsf_stack_weights* w, int B, int T, int L, float* ws, const TrSave& lay,
+                                 float* skip_out, hipStream_t s) {
+    const int TS = fs_ts(T), ntile32 = TS / 32, ntiles = B * ntile32;
+    unsigned* flags = reinterpret_cast<unsigned*>(ws + lay.flags);
+    HIP_TRY(hipMemsetAsync(flags, 0, ((size_t)ntiles + 64) * sizeof(unsigned), s));
+    TrLoopParams p{};
+    p.w1p = (const float4*)(ws + lay.w1p); p.w2p = (const float4*)(ws + lay.w2p); p.b2 = tr_ptrs(w->out_b, L);
+    p.cp = (const float4*)(ws + lay.cp); p.cp_lstride = lay.cp_l / 4;
+    p.step = step; p.x0 = x0;
+    p.y_cm = ws + lay.Y + kTrYPad; p.y_lstride = lay.Y_l; p.y_rs = TS + 2 * kTrYPad;
+    p.a_frag = (float4*)(ws + lay.A); p.a_lstride = lay.A_l / 4;
+    p.bsum = ws + lay.bsum; p.skip_out = skip_out;
+    p.L = L; p.T = T; p.TS = TS; p.ntile32 = ntile32; p.ntiles_total = ntiles;
+    for (int l = 0; l < L; ++l) p.dil[l] = (unsigned char)w->dilations[l];
+    p.flags = flags; p.tmo = flags + ntiles;
+    p.halo = ws + lay.X;                            // 2 x ntiles x 16 KiB = one layer of the (here unused) tile-major x buffers
+    // chunks of whole utterances, at most one workgroup per CU (all workgroups of a launch wait for each other); launches of persistent
+    // kernels on one device are serialised across streams (two co-resident grids could starve each other), as in run_persistent()
+    const int upc = std::max(1, tr_ncu() / ntile32);
+    int dv = 0;
+    (void)hipGetDevice(&dv);
+    if (dv < 0 || dv >= kMaxDevices) dv = 0;
+    std::lock_guard<std::mutex> guard(g_loop_mu[dv]);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool guarded = (cap == hipStreamCaptureStatusNone);
+    if (guarded) {
+        if (!g_loop_ev[dv]) HIP_TRY(hipEventCreateWithFlags(&g_loop_ev[dv], hipEventDisableTiming));
+        if (g_loop_has[dv] && g_loop_stream[dv] != s) HIP_TRY(hipStreamWaitEvent(s, g_loop_ev[dv], 0));
+    }
+    for (int b0 = 0; b0 < B; b0 += upc) {
+        const int nb = std::min(upc, B - b0);
+        p.tile_base = b0 * ntile32; p.n_tiles = nb * ntile32;
+        hipLaunchKernelGGL(k_tr_stack_fwd, dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
+        HIP_TRY(hipGetLastError());
+    }
+    if (guarded) {
+        HIP_TRY(hipEventRecord(g_loop_ev[dv], s));
+        g_loop_stream[dv] = s;
+        g_loop_has[dv] = true;
+    }
+    return DSD_OK;
+}
+
 extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float* step, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L,
                                  float* ws, float* skip_out, void* stream) {
     if (!x0 || !cond || !step || !w || !ws || !skip_out) return fail(DSD_ERR_INVALID, "dsf_stack_forward: null argument");
@@ -190,11 +256,14 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_tr_bsum, dim3(1), dim3(256), 0, s, tr_ptrs(w->out_b, L), ws + lay.bsum, L);
+    const bool persist = tr_persist_applies(B, ntile32);
     int* iota = reinterpret_cast<int*>(ws + lay.iota);
-    hipLaunchKernelGGL(k_tr_iota, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, iota, B);
-    const size_t n4 = (size_t)B * kC * TS / 4;
-    hipLaunchKernelGGL(k_tr_cm_to_tm, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 16384)), dim3(256), 0, s, (const float4*)x0, (float4*)(ws + lay.X), TS, n4);
-    HIP_TRY(hipGetLastError());
+    if (!persist) {
+        hipLaunchKernelGGL(k_tr_iota, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, iota, B);
+        const size_t n4 = (size_t)B * kC * TS / 4;
+        hipLaunchKernelGGL(k_tr_cm_to_tm, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 16384)), dim3(256), 0, s, (const float4*)x0, (float4*)(ws + lay.X), TS, n4);
+        HIP_TRY(hipGetLastError());
+    }
     {
         CondProjParams p{};
         p.condT = cond; p.wcp = (const float4*)(ws + lay.wcp); p.b1p = (const float4*)(ws + lay.b1p); p.cp = (float4*)(ws + lay.cp);
@@ -207,6 +276,7 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
         hipLaunchKernelGGL(k_tr_zero_pads, dim3((unsigned)std::min<size_t>((rows * 2 * kTrYPad + 255) / 256, 8192)), dim3(256), 0, s, ws + lay.Y, rows, TS + 2 * kTrYPad);
         HIP_TRY(hipGetLastError());
     }
+    if (persist) return tr_forward_persistent(x0, step, w, B, T, L, ws, lay, skip_out, s);
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
         LayerParams p{};

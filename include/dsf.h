@@ -106,8 +106,11 @@ int dsf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, doub
  * forward and backward as what torch autograd would run for them, for residual_channels = encoder_hidden = 256 and L <= 32 layers.
  *   forward   x0 [B][256][TS] (relu(input_projection), net.py:116-118), cond [B][256][TS], step [B][L][256] (diffusion_projection_l of the
  *             step embedding, :67) -> skip [B][256][TS] = sum_l skip_l (the tensor :126 divides by sqrt(L)).  One conditioner-projection
- *             launch for all layers + the inference layer kernel per layer, which additionally saves y = x + step and the gate
- *             pre-activation into `save_ws` for the backward pass.
+ *             launch for all layers + the layers as ONE persistent launch per chunk of whole utterances (the tile ownership and
+ *             neighbour exchange of the inference loop, csrc/train_loop.hpp) when an utterance fits one workgroup per CU and the chunks
+ *             fill the chip, else the inference layer kernel per layer (DSD_TRAIN_PERSIST=0 forces that form; the two are bit-identical);
+ *             either saves y = x + step and the gate pre-activation of every layer into `save_ws` for the backward pass.  A neighbour
+ *             wait that hits its (seconds-long) bound poisons `skip` with NaN instead of hanging.
  *   backward  dskip [B][256][TS] -> dx0, dstep [B][L][256], every weight / bias gradient of the stack (torch layouts, OVERWRITTEN),
  *             per layer: output-projection data gradient + gate derivative, transposed dilated conv + residual path, and ONE launch for
  *             the layer's three weight gradients (contraction over frames, split-K partials reduced in a fixed order: deterministic).

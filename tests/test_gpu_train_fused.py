@@ -154,6 +154,36 @@ def test_stack_forward_and_backward(B, T, L, cycle):
     assert all(v <= 2e-5 for v in errs.values()), errs
 
 
+@pytest.mark.parametrize('B,T,L,cycle', [(9, 1000, 3, 4), (2, 50, 3, 4), (3, 96, 20, 4), (1, 5, 1, 1), (17, 500, 2, 2)])
+def test_persistent_forward_equals_per_layer_launches(B, T, L, cycle, monkeypatch):
+    """csrc/train_loop.hpp (ONE launch per chunk of whole utterances, neighbour exchange through flags) against the k_tr_layer launches: the
+    skip sum and everything saved for the backward are the same BITS; (9, 1000) and (17, 500) take two chunks on a 256-CU part."""
+    from diffsinger_amd import _lib, fs2, train_fused
+    lib = _lib.load()
+    train_fused._bind(lib)
+    ws, dils = _make_stack(L, cycle, seed=3 * L + T)
+    g = torch.Generator().manual_seed(T)
+    dev = torch.device('cuda', 0)
+    TS = fs2.padded_frames(T)
+    pad = lambda t: F.pad(t, (0, TS - T)).to(dev).contiguous()
+    x0, cond = pad(torch.randn(B, 256, T, generator=g)), pad(torch.randn(B, 256, T, generator=g))
+    step = (torch.randn(B, L, 256, generator=g) * 0.5).to(dev)
+    wd = [t.to(dev) for k in ['dc_w', 'dc_b', 'cp_w', 'cp_b', 'op_w', 'op_b'] for t in ws[k]]
+    off = (C.c_int64 * 16)()
+    _lib.check(lib.dsf_stack_offsets(B, T, L, 0, off, 16))
+    oY, oA, Yl, Al = off[6], off[7], off[12], off[13]
+    got = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('DSD_TRAIN_PERSIST', mode)
+        skip = train_fused._ResidualStack.apply(x0.clone().requires_grad_(True), cond, step, T, dils, fs2.PackedWeight(), *wd)
+        save = skip.grad_fn.saved_tensors[1]
+        got[mode] = (skip.detach().clone(), save[oY: oY + L * Yl].clone(), save[oA: oA + L * Al].clone())
+        torch.cuda.synchronize()
+    assert bool(torch.isfinite(got['2'][0]).all())
+    for a, b in zip(got['0'], got['2']):
+        assert torch.equal(a, b)
+
+
 def test_p_losses_gradients_fused_equals_operator_path(monkeypatch):
     """The fused stack and the operator-by-operator path of train.py give the same loss and gradients on a real DiffNet."""
     import diffsinger_amd
