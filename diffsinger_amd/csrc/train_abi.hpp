@@ -12,6 +12,36 @@ constexpr int kTrMaxSplit = 16;
 
 static inline size_t tr_al(size_t n) { return (n + 1023) / 1024 * 1024; }      // keeps every sub-buffer 4 KiB aligned
 
+static int tr_ncu() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+    }
+    return ncu;
+}
+// The forward as ONE persistent launch per chunk of whole utterances (train_loop.hpp) instead of a launch per layer: on when an utterance fits
+// the co-resident grid (one workgroup per CU) and the chunks fill the chip at least as well as the per-layer grid does (the rule of
+// loop_applicable(), dsd.hip).  DSD_TRAIN_PERSIST=0 keeps the per-layer launches (the A/B switch of tools/bench_train.py).  The data-gradient
+// chain of the backward pass has the same two forms (k_trb_loop; DSD_TRAIN_PERSIST_BWD=0 keeps its per-layer launches).
+static bool tr_persist_applies(int B, int ntile32) {
+    const char* e = getenv("DSD_TRAIN_PERSIST");
+    if (e && atoi(e) == 0) return false;
+    const int ncu = tr_ncu();
+    if (ncu < 8 || ntile32 > ncu) return false;
+    if (e && atoi(e) == 2) return true;            // forced (tests of the chunked form on any shape)
+    const int ntiles = B * ntile32, upc = std::max(1, ncu / ntile32), chunks = (B + upc - 1) / upc;
+    const double u_p = (double)ntiles / ((double)chunks * ncu);
+    const double u_l = 0.9 * (double)ntiles / ((double)((ntiles + ncu - 1) / ncu) * ncu);
+    return u_p >= u_l;
+}
+
+static bool tr_persist_bwd_applies(int B, int ntile32) {
+    const char* e = getenv("DSD_TRAIN_PERSIST_BWD");
+    if (e && atoi(e) == 0) return false;
+    return tr_persist_applies(B, ntile32);
+}
+
 struct TrSave {             // offsets in floats into save_ws
     size_t w1p, wcp, w2p, b1p, cp, X, Y, A, skip, bsum, iota, flags, total;
     size_t cp_l, X_l, Y_l, A_l;      // per-layer strides
@@ -37,7 +67,8 @@ static TrSave tr_save_layout(int B, int TS, int L) {
 }
 
 struct TrBwd {              // offsets in floats into bwd_ws
-    size_t wotp, wdtp, da, g, dxp0, dxp1, dds_part, part, part_b, total;
+    size_t wotp, wdtp, da, g, dxp0, dxp1, dds_part, part, part_b, pda, pg, pdx, pflags, phalo, total;
+    bool persist;           // the persistent form (k_trb_loop): da / g / dx of EVERY layer are kept (the weight gradients run behind the kernel)
 };
 static TrBwd tr_bwd_layout(int B, int TS, int L) {
     const size_t ntiles = (size_t)B * TS / 32, act = (size_t)B * kC * TS;
@@ -52,6 +83,14 @@ static TrBwd tr_bwd_layout(int B, int TS, int L) {
     s.dds_part = o; o += tr_al((size_t)L * ntiles * kC);
     s.part = o; o += (size_t)kTrWgMaxTiles * kTrMaxSplit * 128 * 256;
     s.part_b = o; o += tr_al((size_t)kTrWgMaxTiles * kTrMaxSplit * 128);
+    s.persist = tr_persist_bwd_applies(B, TS / 32);
+    if (s.persist) {
+        s.pda = o; o += (size_t)L * 2 * act;        // [L][B][512][TS] (unused when the caller keeps da_all)
+        s.pg = o; o += (size_t)L * act;
+        s.pdx = o; o += (size_t)std::max(L - 1, 1) * act;
+        s.pflags = o; o += tr_al(ntiles + 64);
+        s.phalo = o; o += ntiles * 16384;           // [2 parities][ntiles][2 sides][512][8]
+    }
     s.total = o;
     return s;
 }
@@ -86,6 +125,7 @@ static int tr_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_stack_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_loop, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
@@ -98,14 +138,6 @@ static int tr_attrs() {
 }
 
 // split-K factor of a weight-gradient launch of `ndesc` output tiles: fill the chip once (one workgroup per CU), never more splits than frame tiles
-static int tr_ncu() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
-    }
-    return ncu;
-}
 static int tr_nsplit(int ndesc, int ntile) {
     const int ncu = tr_ncu();
     int ns = ncu / std::max(ndesc, 1);
@@ -175,19 +207,33 @@ extern "C" int dsf_stack_offsets(int32_t B, int32_t T, int32_t L, int32_t which,
     return DSD_OK;
 }
 
-// The forward as ONE persistent launch per chunk of whole utterances (train_loop.hpp) instead of a launch per layer: on when an utterance fits
-// the co-resident grid (one workgroup per CU) and the chunks fill the chip at least as well as the per-layer grid does (the rule of
-// loop_applicable(), dsd.hip).  DSD_TRAIN_PERSIST=0 keeps the per-layer launches (the A/B switch of tools/bench_train.py).
-static bool tr_persist_applies(int B, int ntile32) {
-    const char* e = getenv("DSD_TRAIN_PERSIST");
-    if (e && atoi(e) == 0) return false;
-    const int ncu = tr_ncu();
-    if (ncu < 8 || ntile32 > ncu) return false;
-    if (e && atoi(e) == 2) return true;            // forced (tests of the chunked form on any shape)
-    const int ntiles = B * ntile32, upc = std::max(1, ncu / ntile32), chunks = (B + upc - 1) / upc;
-    const double u_p = (double)ntiles / ((double)chunks * ncu);
-    const double u_l = 0.9 * (double)ntiles / ((double)((ntiles + ncu - 1) / ncu) * ncu);
-    return u_p >= u_l;
+// Launches of a persistent kernel: chunks of whole utterances, at most one workgroup per CU (all workgroups of a launch wait for each other);
+// persistent launches on one device are serialised across streams (two co-resident grids could starve each other), as in run_persistent()
+template <typename F>
+static int tr_persistent_chunks(hipStream_t s, int B, int ntile32, F launch) {
+    const int upc = std::max(1, tr_ncu() / ntile32);
+    int dv = 0;
+    (void)hipGetDevice(&dv);
+    if (dv < 0 || dv >= kMaxDevices) dv = 0;
+    std::lock_guard<std::mutex> guard(g_loop_mu[dv]);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool guarded = (cap == hipStreamCaptureStatusNone);
+    if (guarded) {
+        if (!g_loop_ev[dv]) HIP_TRY(hipEventCreateWithFlags(&g_loop_ev[dv], hipEventDisableTiming));
+        if (g_loop_has[dv] && g_loop_stream[dv] != s) HIP_TRY(hipStreamWaitEvent(s, g_loop_ev[dv], 0));
+    }
+    for (int b0 = 0; b0 < B; b0 += upc) {
+        const int nb = std::min(upc, B - b0);
+        launch(b0 * ntile32, nb * ntile32);
+        HIP_TRY(hipGetLastError());
+    }
+    if (guarded) {
+        HIP_TRY(hipEventRecord(g_loop_ev[dv], s));
+        g_loop_stream[dv] = s;
+        g_loop_has[dv] = true;
+    }
+    return DSD_OK;
 }
 
 static int tr_forward_persistent(const float* x0, const float* step, const dsf_stack_weights* w, int B, int T, int L, float* ws, const TrSave& lay,
@@ -206,32 +252,10 @@ static int tr_forward_persistent(const float* x0, const float* step, const dsf_s
     for (int l = 0; l < L; ++l) p.dil[l] = (unsigned char)w->dilations[l];
     p.flags = flags; p.tmo = flags + ntiles;
     p.halo = ws + lay.X;                            // 2 x ntiles x 16 KiB = one layer of the (here unused) tile-major x buffers
-    // chunks of whole utterances, at most one workgroup per CU (all workgroups of a launch wait for each other); launches of persistent
-    // kernels on one device are serialised across streams (two co-resident grids could starve each other), as in run_persistent()
-    const int upc = std::max(1, tr_ncu() / ntile32);
-    int dv = 0;
-    (void)hipGetDevice(&dv);
-    if (dv < 0 || dv >= kMaxDevices) dv = 0;
-    std::lock_guard<std::mutex> guard(g_loop_mu[dv]);
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cap);
-    const bool guarded = (cap == hipStreamCaptureStatusNone);
-    if (guarded) {
-        if (!g_loop_ev[dv]) HIP_TRY(hipEventCreateWithFlags(&g_loop_ev[dv], hipEventDisableTiming));
-        if (g_loop_has[dv] && g_loop_stream[dv] != s) HIP_TRY(hipStreamWaitEvent(s, g_loop_ev[dv], 0));
-    }
-    for (int b0 = 0; b0 < B; b0 += upc) {
-        const int nb = std::min(upc, B - b0);
-        p.tile_base = b0 * ntile32; p.n_tiles = nb * ntile32;
-        hipLaunchKernelGGL(k_tr_stack_fwd, dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
-        HIP_TRY(hipGetLastError());
-    }
-    if (guarded) {
-        HIP_TRY(hipEventRecord(g_loop_ev[dv], s));
-        g_loop_stream[dv] = s;
-        g_loop_has[dv] = true;
-    }
-    return DSD_OK;
+    return tr_persistent_chunks(s, B, ntile32, [&](int tile_base, int n_tiles) {
+        p.tile_base = tile_base; p.n_tiles = n_tiles;
+        hipLaunchKernelGGL(k_tr_stack_fwd, dim3((unsigned)n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
+    });
 }
 
 extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float* step, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L,
@@ -322,9 +346,13 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         DSD_TRY(tr_pack_multi(s, halves, 2 * L, bws + bl.wdtp, kTrW3 / 2, 2, 3, 32, 4, 0, 0, kC, kC, 3, 3 * kC, 1));
     }
     float* dxp[2] = {bws + bl.dxp0, bws + bl.dxp1};           // dxp[k & 1]: gradient wrt the output x of layer k
+    const bool persist = bl.persist;                          // every layer keeps its own da / g / dx slab (k_trb_loop)
     const long long da_bs = da_all ? (long long)L * 2 * kC * TS : (long long)2 * kC * TS;
-    auto da_of = [&](int l) { return da_all ? da_all + (size_t)l * 2 * kC * TS : bws + bl.da + (size_t)(l & 1) * 2 * act; };
-    auto g_of = [&](int l) { return bws + bl.g + (size_t)(l & 1) * act; };
+    auto da_of = [&](int l) {
+        return da_all ? da_all + (size_t)l * 2 * kC * TS : persist ? bws + bl.pda + (size_t)l * 2 * act : bws + bl.da + (size_t)(l & 1) * 2 * act;
+    };
+    auto g_of = [&](int l) { return persist ? bws + bl.pg + (size_t)l * act : bws + bl.g + (size_t)(l & 1) * act; };
+    auto dx_of = [&](int l) { return persist ? bws + bl.pdx + (size_t)l * act : dxp[l & 1]; };      // gradient wrt the output x of layer l < L - 1
     auto gate_params = [&](int l) {
         TrbGateParams p{};
         p.dxp = (l == L - 1) ? nullptr : dxp[l & 1]; p.dsk = dskip; p.a_frag = (const float4*)(sws + lay.A + (size_t)l * lay.A_l);
@@ -344,7 +372,7 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
     auto wgrad_tiles = [&](int l, TrWgParams& wp, int& nd) -> int {
         const bool last = (l == L - 1);
         const float* da = da_of(l);
-        const float* dxp_in = last ? nullptr : dxp[l & 1];
+        const float* dxp_in = last ? nullptr : dx_of(l);
         const float* y = sws + lay.Y + (size_t)l * lay.Y_l + kTrYPad;
         const int yrs = TS + 2 * kTrYPad;
         const int dil = w->dilations[l];
@@ -394,6 +422,28 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
     };
     static const bool fuse = []() { const char* e = getenv("DSD_TRAIN_FUSE_BWD"); return !(e && e[0] == '0'); }();     // developer switch (A/B on one box)
     const dim3 grid((unsigned)ntiles), blk(kThreads);
+    if (persist) {
+        // the whole data-gradient chain as ONE launch per chunk of whole utterances (k_trb_loop), every layer's weight gradients behind it
+        unsigned* flags = reinterpret_cast<unsigned*>(bws + bl.pflags);
+        HIP_TRY(hipMemsetAsync(flags, 0, ((size_t)ntiles + 64) * sizeof(unsigned), s));
+        TrbLoopParams p{};
+        p.dsk = dskip; p.a_frag = (const float4*)(sws + lay.A); p.a_lstride = lay.A_l / 4;
+        p.wotp = (const float4*)(bws + bl.wotp); p.wdtp = (const float4*)(bws + bl.wdtp);
+        p.da = da_of(0); p.da_bstride = da_bs; p.da_lstride = da_all ? (size_t)2 * kC * TS : 2 * act;
+        p.g = g_of(0); p.dx = dx_of(0); p.act = act; p.dx0 = g->dx0; p.dds_part = bws + bl.dds_part;
+        p.L = L; p.T = T; p.TS = TS; p.ntile32 = ntile32; p.ntiles_total = ntiles;
+        for (int l = 0; l < L; ++l) p.dil[l] = (unsigned char)w->dilations[l];
+        p.flags = flags; p.tmo = flags + ntiles; p.halo = bws + bl.phalo;
+        DSD_TRY(tr_persistent_chunks(s, B, ntile32, [&](int tile_base, int n_tiles) {
+            p.tile_base = tile_base; p.n_tiles = n_tiles;
+            hipLaunchKernelGGL(k_trb_loop, dim3((unsigned)n_tiles), blk, kTrbFusedLdsBytes, s, p);
+        }));
+        for (int l = L - 1; l >= 0; --l) DSD_TRY(wgrad(l));
+        DSD_TRY(wgrad_flush());
+        hipLaunchKernelGGL(k_tr_dds_reduce, dim3((unsigned)B, (unsigned)L), dim3(kC), 0, s, bws + bl.dds_part, g->dstep, L, ntile32, ntiles);
+        HIP_TRY(hipGetLastError());
+        return DSD_OK;
+    }
     {   // gate derivative of the last layer (its x_out is dead: K = 256)
         const TrbGateParams p = gate_params(L - 1);
         hipLaunchKernelGGL(k_trb_gate<true>, grid, blk, kTrbGateLdsBytes, s, p);

@@ -154,10 +154,12 @@ def test_stack_forward_and_backward(B, T, L, cycle):
     assert all(v <= 2e-5 for v in errs.values()), errs
 
 
-@pytest.mark.parametrize('B,T,L,cycle', [(9, 1000, 3, 4), (2, 50, 3, 4), (3, 96, 20, 4), (1, 5, 1, 1), (17, 500, 2, 2)])
-def test_persistent_forward_equals_per_layer_launches(B, T, L, cycle, monkeypatch):
-    """csrc/train_loop.hpp (ONE launch per chunk of whole utterances, neighbour exchange through flags) against the k_tr_layer launches: the
-    skip sum and everything saved for the backward are the same BITS; (9, 1000) and (17, 500) take two chunks on a 256-CU part."""
+@pytest.mark.parametrize('B,T,L,cycle,dcond', [(9, 1000, 3, 4, False), (2, 50, 3, 4, True), (3, 96, 20, 4, False), (1, 5, 1, 1, True), (17, 500, 2, 2, True),
+                                               (1, 200, 4, 1, False)])
+def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond, monkeypatch):
+    """csrc/train_loop.hpp (forward and data-gradient chain as ONE launch each per chunk of whole utterances, neighbour exchange through flags)
+    against the per-layer launches: the skip sum, everything saved for the backward and every gradient are the same BITS; (9, 1000) and
+    (17, 500) take two chunks on a 256-CU part; dcond selects the caller-kept da_all layout of the backward."""
     from diffsinger_amd import _lib, fs2, train_fused
     lib = _lib.load()
     train_fused._bind(lib)
@@ -168,20 +170,29 @@ def test_persistent_forward_equals_per_layer_launches(B, T, L, cycle, monkeypatc
     pad = lambda t: F.pad(t, (0, TS - T)).to(dev).contiguous()
     x0, cond = pad(torch.randn(B, 256, T, generator=g)), pad(torch.randn(B, 256, T, generator=g))
     step = (torch.randn(B, L, 256, generator=g) * 0.5).to(dev)
-    wd = [t.to(dev) for k in ['dc_w', 'dc_b', 'cp_w', 'cp_b', 'op_w', 'op_b'] for t in ws[k]]
+    dskip = pad(torch.randn(B, 256, T, generator=g))
+    dskip[:, :, T:] = -2.0
+    wsrc = [t.to(dev) for k in ['dc_w', 'dc_b', 'cp_w', 'cp_b', 'op_w', 'op_b'] for t in ws[k]]
     off = (C.c_int64 * 16)()
     _lib.check(lib.dsf_stack_offsets(B, T, L, 0, off, 16))
     oY, oA, Yl, Al = off[6], off[7], off[12], off[13]
     got = {}
     for mode in ('0', '2'):
         monkeypatch.setenv('DSD_TRAIN_PERSIST', mode)
-        skip = train_fused._ResidualStack.apply(x0.clone().requires_grad_(True), cond, step, T, dils, fs2.PackedWeight(), *wd)
+        xin, cin, sin = x0.clone().requires_grad_(True), cond.clone().requires_grad_(dcond), step.clone().requires_grad_(True)
+        wd = [t.clone().requires_grad_(True) for t in wsrc]
+        skip = train_fused._ResidualStack.apply(xin, cin, sin, T, dils, fs2.PackedWeight(), *wd)
         save = skip.grad_fn.saved_tensors[1]
-        got[mode] = (skip.detach().clone(), save[oY: oY + L * Yl].clone(), save[oA: oA + L * Al].clone())
+        res = [skip.detach().clone(), save[oY: oY + L * Yl].clone(), save[oA: oA + L * Al].clone()]
+        skip.backward(dskip)
+        res += [xin.grad.clone(), sin.grad.clone()] + [t.grad.clone() for t in wd]
+        if dcond:
+            res.append(cin.grad.clone())
+        got[mode] = res
         torch.cuda.synchronize()
-    assert bool(torch.isfinite(got['2'][0]).all())
-    for a, b in zip(got['0'], got['2']):
-        assert torch.equal(a, b)
+    assert all(bool(torch.isfinite(t).all()) for t in got['2'])
+    for i, (a, b) in enumerate(zip(got['0'], got['2'])):
+        assert torch.equal(a, b), f'tensor {i} differs: {float((a - b).abs().max())}'
 
 
 def test_p_losses_gradients_fused_equals_operator_path(monkeypatch):
