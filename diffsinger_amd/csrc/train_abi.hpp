@@ -23,7 +23,7 @@ static int tr_ncu() {
 // The forward as ONE persistent launch per chunk of whole utterances (train_loop.hpp) instead of a launch per layer: on when an utterance fits
 // the co-resident grid (one workgroup per CU) and the chunks fill the chip at least as well as the per-layer grid does (the rule of
 // loop_applicable(), dsd.hip).  DSD_TRAIN_PERSIST=0 keeps the per-layer launches (the A/B switch of tools/bench_train.py).  The data-gradient
-// chain of the backward pass has the same two forms (k_trb_loop; DSD_TRAIN_PERSIST_BWD=0 keeps its per-layer launches).
+// chain of the backward pass has the same two forms; its persistent form (k_trb_loop) is opt-in (DSD_TRAIN_PERSIST_BWD=1).
 static bool tr_persist_applies(int B, int ntile32) {
     const char* e = getenv("DSD_TRAIN_PERSIST");
     if (e && atoi(e) == 0) return false;
@@ -38,7 +38,7 @@ static bool tr_persist_applies(int B, int ntile32) {
 
 static bool tr_persist_bwd_applies(int B, int ntile32) {
     const char* e = getenv("DSD_TRAIN_PERSIST_BWD");
-    if (e && atoi(e) == 0) return false;
+    if (!e || atoi(e) == 0) return false;          // opt-in: measured equal to the per-layer launches (profiles/r03z), for 30 % more workspace
     return tr_persist_applies(B, ntile32);
 }
 

@@ -114,6 +114,8 @@ int dsf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, doub
  *   backward  dskip [B][256][TS] -> dx0, dstep [B][L][256], every weight / bias gradient of the stack (torch layouts, OVERWRITTEN),
  *             per layer: output-projection data gradient + gate derivative, transposed dilated conv + residual path, and ONE launch for
  *             the layer's three weight gradients (contraction over frames, split-K partials reduced in a fixed order: deterministic).
+ *             DSD_TRAIN_PERSIST_BWD=1 runs the data-gradient chain as one persistent launch per chunk of whole utterances instead
+ *             (bit-identical, measured equal, more workspace: dsf_stack_workspace_floats reads the same switch).
  *             da_all: NULL, or [B][L*512][TS] to keep every layer's gradient wrt the gate pre-activation (rows [512 l, 512 l + 512) of an
  *             utterance) - the operand of the conditioner gradient dcond = sum_l Wc_l^T da_l, one dsf_conv1d over 512 L input channels.
  * The weight tables are HOST arrays of L device pointers in torch layouts: dilated_conv [512][256][3], conditioner / output projection

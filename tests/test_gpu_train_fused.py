@@ -179,6 +179,7 @@ def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond, monk
     got = {}
     for mode in ('0', '2'):
         monkeypatch.setenv('DSD_TRAIN_PERSIST', mode)
+        monkeypatch.setenv('DSD_TRAIN_PERSIST_BWD', '1' if mode == '2' else '0')
         xin, cin, sin = x0.clone().requires_grad_(True), cond.clone().requires_grad_(dcond), step.clone().requires_grad_(True)
         wd = [t.clone().requires_grad_(True) for t in wsrc]
         skip = train_fused._ResidualStack.apply(xin, cin, sin, T, dils, fs2.PackedWeight(), *wd)
