@@ -29,6 +29,7 @@ static bool tr_persist_applies(int B, int ntile32) {
     if (e && atoi(e) == 0) return false;
     const int ncu = tr_ncu();
     if (ncu < 8 || ntile32 > ncu) return false;
+    if ((long long)B * ntile32 > 32768) return false;         // 32-bit byte offsets into the halo buffers (32 KiB per tile in k_trb_loop)
     if (e && atoi(e) == 2) return true;            // forced (tests of the chunked form on any shape)
     const int ntiles = B * ntile32, upc = std::max(1, ncu / ntile32), chunks = (B + upc - 1) / upc;
     const double u_p = (double)ntiles / ((double)chunks * ncu);
