@@ -2,6 +2,7 @@
 // sequencing of the K-step reverse loop (eager or as a cached hipGraph).  C ABI in include/dsd.h.
 #include "dsd_kernels.hpp"
 #include "dsd_loop.hpp"
+#include "dsd_loop_fm.hpp"
 #include "dsd_lat.hpp"
 #include "dsd_split.hpp"
 
@@ -115,6 +116,7 @@ struct dsd_handle {
     float* gbuf = nullptr;      // [ntiles][C][32] gate tiles between k_lat_conv and k_lat_out
     bool lat_head_split = true; // G = 8 latency path: the head as three row-split kernels (env DSD_LAT_HEAD=0: k_head on one workgroup per tile)
     int n_cu = 0;               // workgroups that are certainly co-resident at 1 per CU
+    bool loop_fm = false;       // opt-in (env DSD_LOOP_FM=1): the persistent loop on frame-major tiles (dsd_loop_fm.hpp), bit-identical, +1 %
     struct LoopPlan { HeadParams* evals = nullptr; int* eval_t = nullptr; int n_evals = 0; };
     std::map<GraphKey, LoopPlan> plans;
     unsigned* loop_flags = nullptr;   // [ntiles] + timeout word behind it
@@ -220,6 +222,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_LAT_HEAD")) h->lat_head_split = (std::atoi(ev) != 0);  // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
+    if (const char* ev = std::getenv("DSD_LOOP_FM")) h->loop_fm = (std::atoi(ev) != 0);      // opt-in: frame-major persistent loop
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
         if (e > 3) { delete h; return fail(DSD_ERR_INVALID, "dsd_create: dilation 2^%d exceeds the supported maximum %d", e, kHalo); }
@@ -236,6 +239,8 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_fm<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopFmLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_fm<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopFmLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -911,7 +916,10 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
     for (int b0 = 0; b0 < h->B; b0 += utt_per_chunk) {
         const int nb = std::min(utt_per_chunk, h->B - b0);
         p.tile_base = b0 * h->ntile32; p.n_tiles = nb * h->ntile32;
-        if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
+        if (h->loop_fm) {
+            if (kind == 0) hipLaunchKernelGGL((k_loop_fm<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopFmLdsBytes, s, p);
+            else hipLaunchKernelGGL((k_loop_fm<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopFmLdsBytes, s, p);
+        } else if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         else hipLaunchKernelGGL((k_loop<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         HIP_TRY(hipGetLastError());
     }

@@ -88,9 +88,12 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NMB][NB], const float4 (
 // distance for the 16-MFMA chunks of the 32-frame kernels.
 // MBS: distance (in 32-row blocks of the packed stream) between the NMB row blocks a wave multiplies - 1: consecutive blocks; 2: a gate
 // block and its filter block / a residual block and its skip block (the row-split kernels of dsd_lat.hpp).
-template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff, int MBS = 1>
+// BV: the B tile is FRAME-MAJOR ([frame][k], k contiguous; dsd_loop_fm.hpp): the four k values of a chunk a lane needs (k = 4h + s) are
+// ONE aligned ds_read_b128 instead of four ds_read_b32 at a stride of LD.
+template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff, int MBS = 1, bool BV = false>
 struct GemmPipe {
     static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
+    static_assert(!BV || NB == 1, "frame-major B tiles are one 32-frame block wide");
     __amdgpu_buffer_rsrc_t rsrc;   // buffer descriptor over this wave's A stream (wave-uniform base = chunk 0 / row block 0)
     unsigned aoff;                 // this lane's byte offset inside a 1 KiB fragment row (lane * 16)
     int n;
@@ -120,10 +123,15 @@ struct GemmPipe {
     // part of the address that depends on u into the ds_read immediate)
     __device__ __forceinline__ void ldb(float (&dst)[4][NB], int it, int u) {
         const float* bp = bof(it, u);
+        if constexpr (BV) {
+            const float4 v = *reinterpret_cast<const float4*>(bp);
+            dst[0][0] = v.x; dst[1][0] = v.y; dst[2][0] = v.z; dst[3][0] = v.w;
+        } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) dst[s][nb] = bp[s * LD + nb * 32];
+                for (int nb = 0; nb < NB; ++nb) dst[s][nb] = bp[s * LD + nb * 32];
+        }
     }
     // interleave: {1 MFMA, 1 global load} x NMB, {1 MFMA, 1 LDS read} x 2NB, then the remaining MFMAs
     __device__ __forceinline__ void pattern() {
@@ -132,12 +140,13 @@ struct GemmPipe {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
+        constexpr int NDS = BV ? 1 : 2 * NB;      // LDS reads of a chunk
 #pragma unroll
-        for (int i = 0; i < 2 * NB; ++i) {
+        for (int i = 0; i < NDS; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NMB * NB - NMB - 2 * NB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NMB * NB - NMB - NDS, 0);
     }
     // The A prefetch depends on nothing the kernel computes: start_a() may be issued long before the B tile is
     // ready (before staging / before the gate), so the first-touch latency of the weight stream is off the critical path.

@@ -168,7 +168,9 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
  * the previous persistent launch of any handle on the same GPU that went to a different stream - two handles / two streams sampling
  * "concurrently" are serialised (each loop fills the chip anyway), never starved into the timeout.  Two PROCESSES sharing one GPU
  * cannot see each other: use mode 0 there (one process per device, as the reference's DDP runner does, is always safe).
- * dsd_loop_launches: k_loop launches per sampling call for the prepared batch (chunks of whole utterances; 0 = not on that path). */
+ * dsd_loop_launches: k_loop launches per sampling call for the prepared batch (chunks of whole utterances; 0 = not on that path).
+ * Env DSD_LOOP_FM=1 at dsd_create selects the frame-major form of the persistent kernel (csrc/dsd_loop_fm.hpp: same results bit for
+ * bit, ~1 % faster; opt-in until the whole GPU suite has run with it). */
 int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
 int dsd_loop_launches(dsd_handle* h);
 int dsd_set_lat_split(dsd_handle* h, int32_t g);
