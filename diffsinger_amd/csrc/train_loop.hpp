@@ -1,5 +1,8 @@
-// train_loop.hpp - the FORWARD of the fused training stack as ONE persistent kernel (gfx950).
+// train_loop.hpp - the fused training stack as PERSISTENT kernels (gfx950): k_tr_stack_fwd, the forward (default where
+// an utterance fits the co-resident grid), and - further down - k_trb_loop, the data-gradient chain of the backward pass (opt-in: measured equal
+// to the per-layer launches).
 //
+// k_tr_stack_fwd:
 // The 20 ResidualBlock.forward calls of DiffNet.forward (usr/diff/net.py:119-124; block :66-78) under GaussianDiffusion.p_losses
 // (usr/diff/shallow_diffusion_tts.py:213-231), on the tile ownership and the neighbour exchange of the inference loop (dsd_loop.hpp:
 // one workgroup owns a 32-frame tile, x and the running skip sum stay in registers from layer to layer, the 8 halo columns of a layer
