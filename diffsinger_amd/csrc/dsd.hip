@@ -114,6 +114,7 @@ struct dsd_handle {
     int loop_mode = 2;
     int lat_req = -1;           // row split of the latency kernels: -1 by batch size, 0 never, 2 / 4 / 8 forced (env DSD_LAT_G)
     float* gbuf = nullptr;      // [ntiles][C][32] gate tiles between k_lat_conv and k_lat_out
+    bool lat_bf = false;        // opt-in (env DSD_LAT_BF=1): k_lat_conv<8> with the branch-free chunk map (ConvB<LD, true>; not yet run on hardware)
     bool lat_head_split = true; // G = 8 latency path: the head as three row-split kernels (env DSD_LAT_HEAD=0: k_head on one workgroup per tile)
     int n_cu = 0;               // workgroups that are certainly co-resident at 1 per CU
     bool loop_fm = false;       // opt-in (env DSD_LOOP_FM=1): the persistent loop on frame-major tiles (dsd_loop_fm.hpp), bit-identical, +1 %
@@ -222,6 +223,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_LAT_HEAD")) h->lat_head_split = (std::atoi(ev) != 0);  // developer switch (A/B timing)
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
+    if (const char* ev = std::getenv("DSD_LAT_BF")) h->lat_bf = (std::atoi(ev) != 0);         // opt-in: branch-free K-half conv of the latency path
     if (const char* ev = std::getenv("DSD_LOOP_FM")) h->loop_fm = (std::atoi(ev) != 0);      // opt-in: frame-major persistent loop
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
@@ -547,9 +549,10 @@ static int launch_inproj(dsd_handle* h, const float* spec, hipStream_t s) {
 }
 
 template <int G>
-static void launch_lat(const LatParams& p, hipStream_t s) {
+static void launch_lat(const LatParams& p, hipStream_t s, bool bf) {
     const dim3 grid((unsigned)lat_grid(p.ntiles, G));
-    hipLaunchKernelGGL((k_lat_conv<G>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
+    if (G == 8 && bf) hipLaunchKernelGGL((k_lat_conv<kLatG8BF>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
+    else hipLaunchKernelGGL((k_lat_conv<G>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
     hipLaunchKernelGGL((k_lat_out<G>), grid, dim3(kThreads), kLatOutLdsBytes, s, p);
 }
 
@@ -569,7 +572,7 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
         q.t_dev = t_dev; q.t_uniform = t_uniform; q.ds_tstride = h->L * kC;
         q.T = h->T; q.ntile32 = h->ntile32; q.ntiles = h->ntiles; q.dil = h->dil[l];
         q.first = (l == 0); q.last = (l == h->L - 1);
-        if (G == 8) launch_lat<8>(q, s); else if (G == 4) launch_lat<4>(q, s); else launch_lat<2>(q, s);
+        if (G == 8) launch_lat<8>(q, s, h->lat_bf); else if (G == 4) launch_lat<4>(q, s, false); else launch_lat<2>(q, s, false);
         HIP_TRY(hipGetLastError());
         return DSD_OK;
     }

@@ -218,14 +218,23 @@ __host__ __device__ __forceinline__ int conv_chunk(int k8, int tap) { return (ta
 
 // B functor of the dilated conv over a y tile [channel][LD] whose column kHalo is frame 0 of the tile: yc = this lane's pointer to
 // (row 4 h, column kHalo + j); kbase = first chunk of this wave's K range (a multiple of 6).
-template <int LD>
+// BF (branch-free): with a kbase known only at run time (the K-half waves of k_lat_conv<8>) the two returns become a BRANCH per chunk; the
+// prefetch loads of the GemmPipe steps are then sunk across the block boundaries to their first use and the A stream runs one chunk ahead
+// instead of five (s_waitcnt vmcnt(0) in front of every chunk, found in the ISA at the end of round 2).  The select form keeps a chunk one block.
+template <int LD, bool BF = false>
 struct ConvB {
     const float* yc; int dil, kbase;
     __device__ __forceinline__ const float* operator()(int it, int u) const {
         const int kc = kbase + 6 * it + u;
-        if (kc < kConvCentre) return yc + kc * (8 * LD);
-        const int idx = kc - kConvCentre;
-        return yc + (idx >> 1) * (8 * LD) + ((idx & 1) ? dil : -dil);
+        if constexpr (BF) {
+            const int idx = kc - kConvCentre;
+            const int oc = kc * (8 * LD), oo = (idx >> 1) * (8 * LD) + ((idx & 1) ? dil : -dil);
+            return yc + ((kc < kConvCentre) ? oc : oo);
+        } else {
+            if (kc < kConvCentre) return yc + kc * (8 * LD);
+            const int idx = kc - kConvCentre;
+            return yc + (idx >> 1) * (8 * LD) + ((idx & 1) ? dil : -dil);
+        }
     }
 };
 

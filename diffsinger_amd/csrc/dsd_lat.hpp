@@ -58,8 +58,13 @@ __device__ __forceinline__ bool lat_map(int ntiles, int& tile, int& g) {
 }
 __host__ __device__ inline int lat_grid(int ntiles, int G) { return (ntiles + 7) / 8 * 8 * G; }
 
-template <int G>
+// GX = the row split G, or kLatG8BF: G = 8 with the branch-free chunk -> pointer map (ConvB<LD, true>), opt-in DSD_LAT_BF=1 until it has run
+// on the hardware (an extra template parameter would rename the verified instantiations)
+constexpr int kLatG8BF = 9;
+template <int GX>
 __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
+    constexpr int G = (GX == kLatG8BF) ? 8 : GX;
+    constexpr bool BF = (GX == kLatG8BF);
     static_assert(G == 2 || G == 4 || G == 8, "row split");
     constexpr int LD = 32 + 2 * kHalo, TILE = kC * 32;
     constexpr int NMB = (G == 2) ? 2 : 1;
@@ -82,8 +87,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
     else { w4 = g >> 1; mb0 = (g & 1) + 2 * (wv & 1); kbeg = 48 * (wv >> 1); }
 
     // the weight stream does not depend on x: its first chunks are requested before the tile is staged
-    const ConvB<LD> bof{ytile + 4 * h * LD + kHalo + j, dil, kbeg};
-    GemmPipe<NMB, 1, LD, 256, 6, ConvB<LD>, 2> pipe(p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, bof);
+    const ConvB<LD, BF> bof{ytile + 4 * h * LD + kHalo + j, dil, kbeg};
+    GemmPipe<NMB, 1, LD, 256, 6, ConvB<LD, BF>, 2> pipe(p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, bof);
     pipe.start_a();
 
     // stage y = x + step_proj (zero at frames outside [0, T): the conv's zero padding applies to y, net.py:69-71)

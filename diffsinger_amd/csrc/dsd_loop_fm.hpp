@@ -2,7 +2,7 @@
 //
 // OPT-IN (DSD_LOOP_FM=1): written at the very end of round 2; bit-identical to k_loop on its first hardware run (tests/test_gpu_loop_fm.py,
 // profiles/r04c) and +1.0-1.4 % on the headline workload inside one call (63.6-64.1 k vs 63.1 k frames/s, 0.860 vs 0.850 of peak,
-// profiles/r04e_loop_fm_ab.jsonl); it becomes the default once the whole GPU suite has run with it (tools/gpu_next_loop_fm.sh).
+// profiles/r04e_loop_fm_ab.jsonl); it becomes the default once the whole GPU suite has run with it (tools/gpu_next_promote.sh).
 // Same arithmetic in the same order as k_loop (dsd_loop.hpp: the reverse loop usr/diff/shallow_diffusion_tts.py:261-270 over
 // DiffNet.forward usr/diff/net.py:107-130) - what changes is how a tile's activations are laid out between the matrix operations of a layer:
 //   * k_loop keeps the conv input y and the gate tile as [channel][frame] (frames contiguous).  A lane of the 32x32x2 MFMA supplies
