@@ -187,6 +187,27 @@ struct GemmPipe {
             step<5>(acc, it);
         }
     }
+    // The same walk for a RUN-TIME chunk count with the whole groups of six as ONE basic block (one branch per six chunks) and the tail
+    // behind it.  With `end` unknown at compile time every `break` above ends a block; hipcc then sinks the prefetch loads of the steps
+    // across the blocks (seen in the disassembly: the six A loads of an iteration issued together behind its fifth chunk, s_waitcnt
+    // vmcnt(0) in front of chunks) and the fences inside a step no longer order anything.
+    __device__ __forceinline__ void run_blocks(f32x16 (&acc)[NMB][NB], int end) {
+        int it = 0;
+        for (; 6 * it + 6 <= end; ++it) {
+            step<0>(acc, it); step<1>(acc, it); step<2>(acc, it); step<3>(acc, it); step<4>(acc, it); step<5>(acc, it);
+        }
+        const int kc = 6 * it;
+        if (kc >= end) return;
+        step<0>(acc, it);
+        if (kc + 1 >= end) return;
+        step<1>(acc, it);
+        if (kc + 2 >= end) return;
+        step<2>(acc, it);
+        if (kc + 3 >= end) return;
+        step<3>(acc, it);
+        if (kc + 4 >= end) return;
+        step<4>(acc, it);
+    }
 };
 
 // B functor of a plain [k][frame] LDS tile: chunk kc at base + kc * 8 rows (clamped: the prefetch of the chunk behind
@@ -204,6 +225,12 @@ __device__ __forceinline__ void gemm_k(f32x16 (&acc)[NMB][NB], const float4* __r
     GemmPipe<NMB, NB, LD, ASTRIDE, 6, BOff> pipe(abase_uniform, lane, n, bof);
     pipe.start();
     pipe.run(acc, 0, n);
+}
+template <int NMB, int NB, int LD, int ASTRIDE, typename BOff>
+__device__ __forceinline__ void gemm_k_blocks(f32x16 (&acc)[NMB][NB], const float4* __restrict__ abase_uniform, int lane, int n, BOff bof) {
+    GemmPipe<NMB, NB, LD, ASTRIDE, 6, BOff> pipe(abase_uniform, lane, n, bof);
+    pipe.start();
+    pipe.run_blocks(acc, n);
 }
 
 // K order of the dilated conv (K = 3 taps x 256 channels = 96 chunks of 8 channels x 1 tap): CENTRE TAP FIRST.

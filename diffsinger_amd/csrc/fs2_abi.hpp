@@ -67,7 +67,16 @@ static int fs_conv_launch(const float* in, const float* wpacked, const float* bi
     p.scale = scale; p.act = act;
     const int nmb = fs_nmb(Co);
     const dim3 grid((unsigned)(p.TS / 32), (unsigned)B, (unsigned)((Co + 128 * nmb - 1) / (128 * nmb)));
-    if (nmb == 4) hipLaunchKernelGGL((k_fs_conv<4>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
+    // opt-in (env DSF_CONV_INC=1, not yet run on hardware): running chunk pointer + six chunks per basic block (FsTapBInc, fs2_kernels.hpp)
+    const char* inc = std::getenv("DSF_CONV_INC");
+    if (inc && std::atoi(inc) != 0) {
+        if (first_on_device(11)) {
+            (void)hipFuncSetAttribute((const void*)k_fs_conv_inc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
+            (void)hipFuncSetAttribute((const void*)k_fs_conv_inc<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
+        }
+        if (nmb == 4) hipLaunchKernelGGL((k_fs_conv_inc<4>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((k_fs_conv_inc<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
+    } else if (nmb == 4) hipLaunchKernelGGL((k_fs_conv<4>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_fs_conv<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return DSD_OK;

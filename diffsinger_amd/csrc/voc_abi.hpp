@@ -46,6 +46,14 @@ static void voc_conv_launch(const VocConvParams& p, int B, hipStream_t s) {
     constexpr int WR = 4 / WT, SPAN = voc_span<NB, WT>();
     const size_t lds = (size_t)voc_lds_bytes<NB, WT, HALO>();
     const dim3 grid((unsigned)((p.LSi + SPAN - 1) / SPAN), (unsigned)B, (unsigned)((p.rows + 32 * WR - 1) / (32 * WR)));
+    // opt-in (env DSV_CONV_INC=1, not yet run on hardware): the chunk -> pointer map as a running pointer (VocTapBInc, voc_kernels.hpp)
+    const char* e = std::getenv("DSV_CONV_INC");
+    if (e && std::atoi(e) != 0) {
+        if (first_on_device(2100 + 10 * NB + WT + 1000 * (HALO != kVocHalo)))
+            (void)hipFuncSetAttribute((const void*)k_voc_conv_inc<NB, WT, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, voc_lds_bytes<NB, WT, HALO>());
+        hipLaunchKernelGGL((k_voc_conv_inc<NB, WT, HALO>), grid, dim3(kThreads), lds, s, p);
+        return;
+    }
     hipLaunchKernelGGL((k_voc_conv<NB, WT, HALO>), grid, dim3(kThreads), lds, s, p);
 }
 
