@@ -121,6 +121,11 @@ struct dsd_handle {
     struct LoopPlan { HeadParams* evals = nullptr; int* eval_t = nullptr; int n_evals = 0; };
     std::map<GraphKey, LoopPlan> plans;
     unsigned* loop_flags = nullptr;   // [ntiles] + timeout word behind it
+    // the timeout word of every finished persistent loop is latched (k_latch_tmo, enqueued behind the loop) into a word of PINNED host
+    // memory: the next call into the handle - or dsd_check - reads it without synchronising anything and fails loudly
+    unsigned* sticky_host = nullptr;
+    unsigned* sticky_dev = nullptr;
+    bool persist_off = false;         // set when a timeout was reported: the handle stays on the hipGraph path until dsd_set_loop_mode
     float* loop_halo = nullptr;       // [2][ntiles][2][256][8]
     int loop_cap_tiles = 0;
     unsigned long long* loop_dbg = nullptr;   // debug: stamps of one phase (dsd_debug_loop_timeline)
@@ -156,13 +161,17 @@ static int pin_acquire(dsd_handle* h, size_t bytes, char** out, int* slot) {
     if (bytes > r.slot) {
         for (int i = 0; i < kPinSlots; ++i)
             if (r.used[i]) { HIP_TRY(hipEventSynchronize(r.ev[i])); r.used[i] = false; }
+        // allocate first, commit base / slot only on success: a failed growth leaves the old (smaller) ring usable
+        const size_t slot = (bytes + 4095) / 4096 * 4096;
+        char* base = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&base, slot * kPinSlots, hipHostMallocDefault));
         if (r.base) (void)hipHostFree(r.base);
-        r.base = nullptr;
-        r.slot = (bytes + 4095) / 4096 * 4096;
-        HIP_TRY(hipHostMalloc((void**)&r.base, r.slot * kPinSlots, hipHostMallocDefault));
+        r.base = base;
+        r.slot = slot;
         for (int i = 0; i < kPinSlots; ++i)
             if (!r.ev[i]) HIP_TRY(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
     }
+    if (!r.base) return fail(DSD_ERR_NOMEM, "pinned staging ring is not allocated");
     const int i = r.next;
     r.next = (r.next + 1) % kPinSlots;
     if (r.used[i]) { HIP_TRY(hipEventSynchronize(r.ev[i])); r.used[i] = false; }
@@ -267,6 +276,7 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     dev_free(h->noise_cell); dev_free(h->seed_cell);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->pin.base) (void)hipHostFree(h->pin.base);
+    if (h->sticky_host) (void)hipHostFree(h->sticky_host);
     for (auto& e : h->pin.ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -315,6 +325,47 @@ static bool first_on_device(int site) {
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     return seen.emplace(dev, site).second;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// loud persistent-loop failures
+// ------------------------------------------------------------------------------------------------------------
+// One thread, enqueued behind every persistent loop: copies a raised timeout word into the handle's pinned host word (system scope).
+__global__ void k_latch_tmo(const unsigned* tmo, unsigned* sticky) {
+    if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Debug / test hook kernel: holds a CU (all of its LDS) for `ticks` of the 100 MHz wall clock.
+__global__ void k_hold_cu(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ unsigned hold_lds[];
+    hold_lds[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink && hold_lds[threadIdx.x] == 0xffffffffu) *sink = 1u;
+}
+
+static int sticky_alloc(dsd_handle* h) {
+    if (h->sticky_host) return DSD_OK;
+    HIP_TRY(hipHostMalloc((void**)&h->sticky_host, 64, hipHostMallocMapped));
+    std::memset(h->sticky_host, 0, 64);
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->sticky_dev, h->sticky_host, 0));
+    return DSD_OK;
+}
+
+// Non-synchronising: has a persistent loop that FINISHED since the last report hit its spin bound?  Consumes the report, parks the
+// handle on the hipGraph path (a retry of the same call then runs the per-layer kernels) and fails with DSD_ERR_TIMEOUT.
+static int check_sticky(dsd_handle* h, const char* who) {
+    if (!h->sticky_host) return DSD_OK;
+    const unsigned v = __atomic_load_n(h->sticky_host, __ATOMIC_ACQUIRE);
+    if (v == 0u) return DSD_OK;
+    __atomic_store_n(h->sticky_host, 0u, __ATOMIC_RELEASE);
+    h->persist_off = true;
+    return fail(DSD_ERR_TIMEOUT,
+                "%s: %u persistent K-step loop launch(es) of an EARLIER call on this handle hit the inter-workgroup spin bound (a foreign kernel held "
+                "compute units the loop needs: another process on this GPU, a collective or another model on a side stream) - the mel / x tiles "
+                "those calls returned are NaN.  The handle now runs the hipGraph path (per-layer kernels) until dsd_set_loop_mode is called: "
+                "repeat the call", who, v);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -500,6 +551,7 @@ extern "C" int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* con
     if (!h || !cond) return fail(DSD_ERR_INVALID, "dsd_prepare: null argument");
     if (!h->has_weights) return fail(DSD_ERR_STATE, "dsd_prepare: call dsd_load_weights first");
     if (B < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsd_prepare: B and T must be positive (got %d, %d)", B, T);
+    DSD_TRY(check_sticky(h, "dsd_prepare"));
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int TS = (T + 31) / 32 * 32, ntile32 = TS / 32;
@@ -660,7 +712,7 @@ static int check_ready(dsd_handle* h, const char* who, bool need_sched) {
     if (!h->has_weights) return fail(DSD_ERR_STATE, "%s: weights not loaded", who);
     if (!h->prepared) return fail(DSD_ERR_STATE, "%s: no batch prepared (dsd_prepare)", who);
     if (need_sched && !h->has_schedule) return fail(DSD_ERR_STATE, "%s: schedule not set (dsd_set_schedule)", who);
-    return DSD_OK;
+    return check_sticky(h, who);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -859,7 +911,7 @@ static bool g_loop_has[kMaxDevices];
 
 // true when the prepared batch can run as the persistent loop: 32-frame tiles, a whole utterance fits the co-resident grid
 static bool loop_applicable(const dsd_handle* h) {
-    if (!((h->loop_mode == 1 || h->loop_mode == 2) && !h->split_mode && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 &&
+    if (!((h->loop_mode == 1 || h->loop_mode == 2) && !h->persist_off && !h->split_mode && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 &&
           h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers)) return false;
     if (h->loop_mode == 2) {
         if (lat_g(h)) return false;
@@ -926,6 +978,9 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
         else hipLaunchKernelGGL((k_loop<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         HIP_TRY(hipGetLastError());
     }
+    DSD_TRY(sticky_alloc(h));
+    hipLaunchKernelGGL(k_latch_tmo, dim3(1), dim3(1), 0, s, (const unsigned*)p.tmo, h->sticky_dev);
+    HIP_TRY(hipGetLastError());
     if (guarded) {
         HIP_TRY(hipEventRecord(g_loop_ev[dv], s));
         g_loop_stream[dv] = s;
@@ -1053,6 +1108,7 @@ extern "C" int dsd_set_loop_mode(dsd_handle* h, int32_t mode) {
     if (!h || mode < 0 || mode > 3)
         return fail(DSD_ERR_INVALID, "dsd_set_loop_mode: mode must be 0 (per-layer kernels), 1 (persistent loop), 2 (automatic) or 3 (latency kernels)");
     h->loop_mode = mode;
+    h->persist_off = false;           // an explicit choice re-arms the persistent path after a reported timeout
     return DSD_OK;
 }
 
@@ -1080,6 +1136,23 @@ extern "C" int dsd_loop_timeouts(dsd_handle* h, void* stream) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(&v, h->loop_flags + h->ntiles, sizeof v, hipMemcpyDeviceToHost));
     return (int)v;
+}
+
+extern "C" int dsd_check(dsd_handle* h) {
+    if (!h) return fail(DSD_ERR_INVALID, "dsd_check: null handle");
+    return check_sticky(h, "dsd_check");
+}
+
+extern "C" int dsd_debug_hold_cus(int32_t device, int32_t n_workgroups, int32_t milliseconds, void* stream) {
+    if (n_workgroups < 1 || n_workgroups > 4096 || milliseconds < 1 || milliseconds > 20000)
+        return fail(DSD_ERR_INVALID, "dsd_debug_hold_cus: 1..4096 workgroups, 1..20000 ms");
+    HIP_TRY(hipSetDevice(device));
+    const int lds = 160 * 1024;                                    // the whole LDS of a CU: one holder per CU, nothing else fits beside it
+    if (first_on_device(2)) HIP_TRY(hipFuncSetAttribute((const void*)k_hold_cu, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(k_hold_cu, dim3((unsigned)n_workgroups), dim3(64), lds, (hipStream_t)stream, (unsigned long long)milliseconds * 100000ull,
+                       (unsigned*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
 }
 
 // Debug hook: run the persistent DDPM loop once on the prepared batch (x, noise as for dsd_sample_ddpm) with per-wave shader-clock

@@ -70,7 +70,7 @@ static int fs_conv_launch(const float* in, const float* wpacked, const float* bi
     // opt-in (env DSF_CONV_INC=1, not yet run on hardware): running chunk pointer + six chunks per basic block (FsTapBInc, fs2_kernels.hpp)
     const char* inc = std::getenv("DSF_CONV_INC");
     if (inc && std::atoi(inc) != 0) {
-        if (first_on_device(11)) {
+        if (first_on_device(12)) {
             (void)hipFuncSetAttribute((const void*)k_fs_conv_inc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
             (void)hipFuncSetAttribute((const void*)k_fs_conv_inc<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
         }

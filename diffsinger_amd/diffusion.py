@@ -115,6 +115,13 @@ class GaussianDiffusion(nn.Module):
             self._sched_tag = tag
         return eng
 
+    def check_loops(self, synchronize: bool = True):
+        """Raise RuntimeError if a persistent K-step loop of an earlier `inference()` call was starved into its spin bound (NaN mels);
+        with synchronize (default) the current stream is drained first, so every call made so far is covered.  No-op for denoisers that do
+        not run on the fused engine."""
+        if self._fused() and self.denoise_fn._engine is not None:
+            self.denoise_fn._engine.check(synchronize=synchronize)
+
     # -- reference API: single steps ---------------------------------------------------------------------------
     @torch.no_grad()
     def q_sample(self, x_start, t, noise=None):
@@ -197,7 +204,7 @@ class GaussianDiffusion(nn.Module):
     # -- the hot loop -------------------------------------------------------------------------------------------
     @torch.no_grad()
     def inference(self, cond, *, fs2_mels=None, x_T=None, noise=None, q_noise=None, K_step=None, pndm_speedup=None,
-                  gaussian_start=None, mel_mask=None, return_x=False, noise_seed=None):
+                  gaussian_start=None, mel_mask=None, return_x=False, noise_seed=None, check=False):
         """The inference branch of `forward` (:248-276) from `cond` on.
 
         cond      [B,H,T] fp32 on the device (any strides; the reference passes decoder_inp.transpose(1,2))
@@ -206,6 +213,9 @@ class GaussianDiffusion(nn.Module):
         noise     [K,B,1,M,T] explicit per-step N(0,1) draws for DDPM (slice j <-> t = K-1-j).  None: the draws are made
                   inside the kernel (Philox, seed = noise_seed or a value taken from torch's CPU generator) - nothing of
                   size K*B*M*T is ever materialised
+        check     True: wait for the loop and raise RuntimeError if the persistent kernel hit its inter-workgroup spin bound (a foreign
+                  kernel held compute units: the mel would be NaN) - `forward(infer=True)` does.  False: nothing waits; such a failure
+                  raises at the NEXT call into the engine (include/dsd.h dsd_check).  After the report the engine runs the hipGraph path.
         Returns de-normalised mel [B,T,M] (times mel_mask [B,T] if given); with return_x also x_0 [B,1,M,T]."""
         if not self._fused():
             return self._inference_generic(cond, fs2_mels=fs2_mels, x_T=x_T, noise=noise, q_noise=q_noise, K_step=K_step,
@@ -240,6 +250,8 @@ class GaussianDiffusion(nn.Module):
             else:
                 eng.sample_ddpm(x, noise.reshape(t, B, M, T) if noise.dim() == 5 else noise, t)
         mel = eng.denorm_spec(x, mel_mask)                                    # :271-275
+        if check:
+            eng.check(synchronize=True)
         return (mel, x[:, None]) if return_x else mel
 
     @torch.no_grad()
@@ -304,7 +316,8 @@ class GaussianDiffusion(nn.Module):
         cond = ret['decoder_inp'].transpose(1, 2)
         ret['fs2_mel'] = ret['mel_out']
         mask = (mel2ph > 0).float() if mel2ph is not None else None           # :272-273
-        ret['mel_out'] = self.inference(cond, fs2_mels=ret['mel_out'], mel_mask=mask)
+        # the caller reads the mel next (tasks/tts/fs2.py:394-431 moves it to the host): waiting here costs nothing and a starved loop is loud
+        ret['mel_out'] = self.inference(cond, fs2_mels=ret['mel_out'], mel_mask=mask, check=True)
         return ret
 
     def p_losses(self, x_start, t, cond, noise=None, nonpadding=None):
@@ -366,5 +379,5 @@ class OfflineGaussianDiffusion(GaussianDiffusion):
             x = self.norm_spec(target).transpose(1, 2)[:, None, :, :]
             ret['diff_loss'] = self.p_losses(x, t, cond)
         else:
-            ret['mel_out'] = self.inference(cond, fs2_mels=fs2_mels, pndm_speedup=0)
+            ret['mel_out'] = self.inference(cond, fs2_mels=fs2_mels, pndm_speedup=0, check=True)
         return ret

@@ -65,12 +65,28 @@ def sharded_inference(model, conds: Sequence[torch.Tensor], *, micro_batch: int 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = shard_indices(len(conds), rank, world)
-    outs = []
-    for s in range(0, len(mine), micro_batch):
-        idx = mine[s:s + micro_batch]
-        cond = torch.stack([conds[i] for i in idx])
-        kw = {k: (v(idx) if callable(v) else v) for k, v in infer_kw.items()}
-        outs.append(model.inference(cond, **kw))
+
+    def run_shard():
+        outs = []
+        for s in range(0, len(mine), micro_batch):
+            idx = mine[s:s + micro_batch]
+            cond = torch.stack([conds[i] for i in idx])
+            kw = {k: (v(idx) if callable(v) else v) for k, v in infer_kw.items()}
+            outs.append(model.inference(cond, **kw))
+        if hasattr(model, 'check_loops'):
+            model.check_loops()             # ONE wait per shard: a persistent loop starved by a foreign kernel must not reach the gather as NaN
+        return outs
+
+    try:
+        outs = run_shard()
+    except RuntimeError as e:
+        if 'spin bound' not in str(e):
+            raise
+        # every rank must still arrive at the collective: repeat this rank's shard - the engine is parked on the hipGraph path (per-layer
+        # kernels, no co-residency requirement) since the report - and only raise if that fails as well
+        import warnings
+        warnings.warn(f'rank {rank}: {e}  -- repeating the shard on the hipGraph path')
+        outs = run_shard()
     some = next(c for c in conds if c is not None)          # a rank only needs ITS utterances' conditioners; the others may be None
     T = some.shape[-1]
     local = torch.cat(outs) if outs else torch.zeros(0, T, model.mel_bins, device=some.device)

@@ -152,6 +152,21 @@ class DenoiserEngine:
             _lib.check(rc, 'dsd_loop_timeouts')
         return rc
 
+    def check(self, synchronize: bool = False):
+        """Raise RuntimeError if a persistent K-step loop that has FINISHED since the last report hit its spin bound (its mel / x tiles are
+        NaN).  Reads a pinned host word: no synchronisation unless asked for - then the caller's current stream is drained first, so the
+        verdict covers everything enqueued so far.  After the report the handle runs the hipGraph path (repeat the call; set_loop_mode
+        re-arms the persistent loop).  Every other engine call makes the same check on entry."""
+        if synchronize:
+            torch.cuda.current_stream(self.device).synchronize()
+        _lib.check(self.lib.dsd_check(self._h), 'persistent loop')
+
+    def hold_cus(self, n_workgroups: int, milliseconds: int, stream: Optional[torch.cuda.Stream] = None):
+        """Test hook: a foreign kernel that occupies `n_workgroups` compute units for `milliseconds` on `stream` (default: the current one)."""
+        s = stream.cuda_stream if stream is not None else _stream_ptr(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dsd_debug_hold_cus(self.device.index or 0, int(n_workgroups), int(milliseconds), s), 'dsd_debug_hold_cus')
+
     def set_layer_tile(self, frames: int):
         _lib.check(self.lib.dsd_set_layer_tile(self._h, int(frames)))
 

@@ -129,8 +129,17 @@ class _ResidualStack(torch.autograd.Function):
             dcond = None
             if want_dcond:
                 # dcond = sum_l Wc_l^T da_l: ONE 1x1 convolution over the 512 L stacked channels (usr/diff/net.py:68 backward, all layers)
-                wcat = torch.cat([w.reshape(512, 256) for w in ws[2 * L:3 * L]], 0).t().contiguous()        # [256][512 L]
-                wp = ctx.cond_pack.get(wcat)
+                # the packed Wc^T is keyed on the SOURCE parameters (address + version of every conditioner weight + the raw-pointer
+                # optimiser's generation), never on the temporary: a fresh cat() has version 0 and usually the same address every step
+                from .train_dist import param_generation
+                cw = ws[2 * L:3 * L]
+                tag = (tuple((w.data_ptr(), w._version) for w in cw), param_generation())
+                pack = ctx.cond_pack
+                if pack.get('tag') != tag:
+                    pack['wcat'] = torch.cat([w.reshape(512, 256) for w in cw], 0).t().contiguous()          # [256][512 L], kept alive
+                    pack['packed'] = PackedWeight()
+                    pack['tag'] = tag
+                wp = pack['packed'].get(pack['wcat'])
                 dcond = torch.empty(B, 256, TS, device=dev, dtype=torch.float32)
                 _lib.check(lib.dsf_conv1d(da_all.data_ptr(), wp.data_ptr(), None, dcond.data_ptr(), B, L * 512, 256, 1, T, 1.0, 0, None, None,
                                           _stream(dev)), 'dsf_conv1d (dcond)')
@@ -143,7 +152,7 @@ def residual_stack(net, x0: torch.Tensor, cond_cm: torch.Tensor, step_all: torch
     ws = ([l.dilated_conv.weight for l in layers] + [l.dilated_conv.bias for l in layers] +
           [l.conditioner_projection.weight for l in layers] + [l.conditioner_projection.bias for l in layers] +
           [l.output_projection.weight for l in layers] + [l.output_projection.bias for l in layers])
-    pack = net.__dict__.setdefault('_train_cond_pack', PackedWeight())
+    pack = net.__dict__.setdefault('_train_cond_pack', {})
     return _ResidualStack.apply(x0, cond_cm, step_all, T, [int(l.dilation) for l in layers], pack, *ws)
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DSD_ABI_VERSION 2
+#define DSD_ABI_VERSION 3
 
 typedef struct dsd_handle dsd_handle;
 
@@ -37,7 +37,8 @@ typedef enum dsd_status {
     DSD_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
     DSD_ERR_HIP = -2,          /* a HIP runtime call failed */
     DSD_ERR_STATE = -3,        /* call order violated (weights / schedule / prepare missing) */
-    DSD_ERR_NOMEM = -4
+    DSD_ERR_NOMEM = -4,
+    DSD_ERR_TIMEOUT = -5       /* a persistent K-step loop of an EARLIER call hit its inter-workgroup spin bound (see dsd_check) */
 } dsd_status;
 
 /* The hparams DiffNet reads at construction (usr/diff/net.py:85-90) + audio_num_mel_bins (:82). */
@@ -191,6 +192,20 @@ int dsd_get_split_mode(dsd_handle* h);
 int dsd_debug_layer(dsd_handle* h, int32_t layer, int32_t t, const float* x_in, float* x_out, float* skip_out, void* stream);
 int dsd_get_loop_mode(dsd_handle* h);
 int dsd_loop_timeouts(dsd_handle* h, void* stream);
+
+/* Loud failures of the persistent loop (the reference's loop, usr/diff/shallow_diffusion_tts.py:261-270, cannot fail this way - ours must
+ * not fail silently).  A one-thread kernel enqueued behind every persistent loop latches a raised timeout word into PINNED host memory.
+ * dsd_check reads that word WITHOUT synchronising anything: DSD_OK, or DSD_ERR_TIMEOUT when a persistent loop that has finished since the
+ * last report hit its spin bound (its result tiles are NaN).  Every data-path entry point (dsd_prepare, dsd_denoise, dsd_sample_*,
+ * dsd_denorm_spec, ...) makes the same check first, so a timeout of call n surfaces at call n + 1 at the latest; a caller that wants it
+ * at call n synchronises its stream (it does anyway before reading the mel) and calls dsd_check.  Reporting consumes the flag and parks
+ * the handle on the hipGraph path (per-layer kernels, no co-residency requirement) so that the retry succeeds; dsd_set_loop_mode re-arms
+ * the persistent path. */
+int dsd_check(dsd_handle* h);
+
+/* Test hook: occupy `n_workgroups` compute units (one 64-thread workgroup with the whole 160 KiB of LDS each, so nothing else fits
+ * beside it) for `milliseconds` of wall-clock time on `stream` - the "foreign kernel" the persistent loop's timeout exists for. */
+int dsd_debug_hold_cus(int32_t device, int32_t n_workgroups, int32_t milliseconds, void* stream);
 
 /* Frames per workgroup of the residual-layer kernel: 0 = choose from the batch size, 32 or 64. */
 int dsd_set_layer_tile(dsd_handle* h, int32_t frames);

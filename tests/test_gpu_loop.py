@@ -109,3 +109,62 @@ def test_persistent_loop_under_concurrent_load():
         assert eng.loop_timeouts() == 0, 'an inter-workgroup wait timed out under load'
         np.testing.assert_array_equal(out, ref, err_msg=f'repetition {rep}')
     torch.cuda.synchronize()
+
+
+def test_starved_persistent_loop_is_loud_and_the_retry_succeeds():
+    """a foreign kernel that holds compute units the persistent loop needs (here: 64 CUs for 10 s on a side stream,
+    dsd_debug_hold_cus) drives the loop's inter-workgroup waits into their spin bound - the mel tiles are NaN.  That must RAISE:
+    with check=True at the call itself (what forward(infer=True) does), without it at the NEXT call into the engine, never rc = 0 with
+    NaNs handed on.  After the report the engine is parked on the hipGraph path: the retry succeeds while the foreign kernel is still
+    resident and equals the clean result bit for bit."""
+    import time
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from diffsinger_amd.synth import presets
+    pre = presets()['lj_ds_beta6']
+    hparams.clear()
+    diffsinger_amd.use_preset('lj_ds_beta6')
+    torch.manual_seed(5)
+    net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+    torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+    B, T, K = 8, 1024, 3                                        # 256 tiles: the loop needs every CU of the chip
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=100, K_step=K, loss_type='l1', spec_min=pre['spec_min'],
+                                          spec_max=pre['spec_max']).cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(8)
+    cond = torch.randn(B, T, 256, device='cuda', generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, device='cuda', generator=g)
+    noise = torch.randn(K, B, 1, 80, T, device='cuda', generator=g)
+    eng = gd._engine(cond)
+    eng.set_loop_mode(1)
+    run = lambda **kw: gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0, **kw)
+    ref = run(check=True).cpu().numpy()
+    assert eng.loop_mode() == 1 and np.isfinite(ref).all()
+    side = torch.cuda.Stream()
+
+    # (a) check=True: the call itself raises
+    eng.hold_cus(64, 10000, side)
+    time.sleep(0.5)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='spin bound'):
+        run(check=True)
+    print(f'starved loop reported after {time.time() - t0:.1f} s')
+    assert eng.loop_mode() == 0                                 # parked on the hipGraph path
+    out = run(check=True).cpu().numpy()                         # the retry, the holder may still be resident
+    np.testing.assert_array_equal(out, ref)
+    side.synchronize()
+
+    # (b) without check: nothing waits, the NaNs come back - and the next call into the engine raises
+    eng.set_loop_mode(1)
+    assert eng.loop_mode() == 1
+    eng.hold_cus(64, 10000, side)
+    time.sleep(0.5)
+    mel = run()
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(mel).all()), 'the starved loop should have poisoned its tiles'
+    with pytest.raises(RuntimeError, match='spin bound'):
+        run()
+    out = run(check=True).cpu().numpy()
+    np.testing.assert_array_equal(out, ref)
+    eng.set_loop_mode(1)                                        # re-armed: the persistent loop works again once the chip is free
+    np.testing.assert_array_equal(run(check=True).cpu().numpy(), ref)
+    assert eng.loop_mode() == 1 and eng.loop_timeouts() == 0

@@ -115,7 +115,7 @@ def test_stack_forward_and_backward(B, T, L, cycle):
     stepd = step.to(dev).requires_grad_(True)
     order = ['dc_w', 'dc_b', 'cp_w', 'cp_b', 'op_w', 'op_b']
     wd = [t.to(dev).requires_grad_(True) for k in order for t in ws[k]]
-    skip = train_fused._ResidualStack.apply(x0d, condd, stepd, T, dils, fs2.PackedWeight(), *wd)
+    skip = train_fused._ResidualStack.apply(x0d, condd, stepd, T, dils, {}, *wd)
     e_skip = _rel(skip[:, :, :T], skip_ref.detach())
     assert float(skip[:, :, T:].abs().max() if TS > T else 0) == 0
     # the tensors the forward saved for the backward pass
@@ -182,7 +182,7 @@ def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond, monk
         monkeypatch.setenv('DSD_TRAIN_PERSIST_BWD', '1' if mode == '2' else '0')
         xin, cin, sin = x0.clone().requires_grad_(True), cond.clone().requires_grad_(dcond), step.clone().requires_grad_(True)
         wd = [t.clone().requires_grad_(True) for t in wsrc]
-        skip = train_fused._ResidualStack.apply(xin, cin, sin, T, dils, fs2.PackedWeight(), *wd)
+        skip = train_fused._ResidualStack.apply(xin, cin, sin, T, dils, {}, *wd)
         save = skip.grad_fn.saved_tensors[1]
         res = [skip.detach().clone(), save[oY: oY + L * Yl].clone(), save[oA: oA + L * Al].clone()]
         skip.backward(dskip)
@@ -229,6 +229,49 @@ def test_p_losses_gradients_fused_equals_operator_path(monkeypatch):
     e_c = float((res['1'][2] - res['0'][2]).abs().max() / float(res['0'][2].abs().max()))
     print(f'fused vs operator path: loss {res["1"][0]:.6f} / {res["0"][0]:.6f}, worst parameter gradient {worst[1]:.2e} at {worst[0]}, dcond {e_c:.2e}')
     assert worst[1] <= 5e-5 and e_c <= 5e-5
+
+
+def test_dcond_follows_the_weights_over_optimizer_steps(monkeypatch):
+    """the packed Wc^T of the dcond convolution must be rebuilt when a STOCK torch optimiser changes the conditioner weights
+    (joint FastSpeech2 training, usr/diffsinger_task.py:60-64): three AdamW steps with cond.requires_grad on the fused path and on the
+    operator-by-operator path (DSD_TRAIN_FUSED=0) - dcond of every step must agree, and must differ from step to step."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from tests import helpers as H
+    pre = H.presets()['opencpop_ds60_rel']
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('DSD_TRAIN_FUSED', mode)
+        hparams.clear()
+        diffsinger_amd.use_preset('opencpop_ds60_rel')
+        torch.manual_seed(11)
+        net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+        torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+        gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=pre['timesteps'], K_step=pre['K_step'], loss_type='l1',
+                                              spec_min=pre['spec_min'], spec_max=pre['spec_max']).cuda().train()
+        opt = torch.optim.AdamW(net.parameters(), lr=2e-3, weight_decay=0.0)        # every weight moves by ~2e-3 (3 % of its scale) per step: a stale
+        # Wc^T would show as ~1e-2, while the two paths still agree to rounding (lr 5e-2 blows the net up: 1e-3 of honest reassociation noise)
+        g = torch.Generator().manual_seed(4)
+        x0 = torch.clamp(torch.randn(2, 1, 80, 70, generator=g) * 0.5, -1, 1).cuda()
+        noise = torch.randn(2, 1, 80, 70, generator=g).cuda()
+        cond0 = torch.randn(2, 70, 256, generator=g).transpose(1, 2).cuda()
+        t = torch.tensor([9, 33]).cuda()
+        dconds = []
+        for it in range(3):
+            cond = cond0.clone().requires_grad_(True)
+            opt.zero_grad(set_to_none=True)
+            loss = gd.p_losses(x0, t, cond, noise=noise)
+            loss.backward()
+            dconds.append(cond.grad.detach().cpu().clone())
+            opt.step()
+        res[mode] = dconds
+    for it in range(3):
+        ref = res['0'][it]
+        e = float((res['1'][it] - ref).abs().max() / float(ref.abs().max()))
+        print(f'step {it}: dcond fused vs operator path {e:.2e}')
+        assert e <= 1e-4, (it, e)
+    moved = float((res['0'][2] - res['0'][0]).abs().max() / float(res['0'][0].abs().max()))
+    assert moved > 3e-3, moved                      # the test is only meaningful when the weights changed dcond
 
 
 @pytest.mark.parametrize('loss_type,masked', [('l1', True), ('l2', False)])
