@@ -2,7 +2,6 @@
 // sequencing of the K-step reverse loop (eager or as a cached hipGraph).  C ABI in include/dsd.h.
 #include "dsd_kernels.hpp"
 #include "dsd_loop.hpp"
-#include "dsd_loop_fm.hpp"
 #include "dsd_lat.hpp"
 #include "dsd_split.hpp"
 
@@ -67,8 +66,6 @@ struct dsd_handle {
     bool has_weights = false, has_schedule = false, has_spec = false, prepared = false;
     bool use_graph = true;
     int layer_tile_req = 0;     // 0 auto, 32, 64
-    bool wt_stores = true;      // write-through epilogue stores in k_layer (env DSD_WT_STORES=0: plain stores)
-    bool xcd_map = true;        // XCD-aware workgroup->tile map of k_layer (env DSD_XCD_MAP=0 restores the plain 2-D grid)
     int64_t bytes = 0;       // device bytes owned: packed weights + tables (persistent)
     int64_t bytes_ws = 0;    // ... + workspace of the prepared batch
 
@@ -112,12 +109,9 @@ struct dsd_handle {
     // it; 2 (default) automatic - row-split latency kernels (dsd_lat.hpp) for batches that fill less than half the chip, else the
     // persistent loop unless its whole-utterance chunking wastes more of the chip than the per-layer kernels would; 3 latency kernels
     int loop_mode = 2;
-    int lat_req = -1;           // row split of the latency kernels: -1 by batch size, 0 never, 2 / 4 / 8 forced (env DSD_LAT_G)
+    int lat_req = -1;           // row split of the latency kernels: -1 by batch size, 0 never, 2 / 4 / 8 forced (dsd_set_lat_split)
     float* gbuf = nullptr;      // [ntiles][C][32] gate tiles between k_lat_conv and k_lat_out
-    bool lat_bf = false;        // opt-in (env DSD_LAT_BF=1): k_lat_conv<8> with the branch-free chunk map (ConvB<LD, true>; not yet run on hardware)
-    bool lat_head_split = true; // G = 8 latency path: the head as three row-split kernels (env DSD_LAT_HEAD=0: k_head on one workgroup per tile)
     int n_cu = 0;               // workgroups that are certainly co-resident at 1 per CU
-    bool loop_fm = false;       // opt-in (env DSD_LOOP_FM=1): the persistent loop on frame-major tiles (dsd_loop_fm.hpp), bit-identical, +1 %
     struct LoopPlan { HeadParams* evals = nullptr; int* eval_t = nullptr; int n_evals = 0; };
     std::map<GraphKey, LoopPlan> plans;
     unsigned* loop_flags = nullptr;   // [ntiles] + timeout word behind it
@@ -226,14 +220,8 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     h->L = cfg->residual_layers;
     h->M = cfg->mel_bins;
     h->nk_in = (cfg->mel_bins + 7) / 8;
-    if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);                // developer switch (A/B timing)
-    if (const char* ev = std::getenv("DSD_LAT_G")) h->lat_req = std::atoi(ev);                 // developer switch (A/B timing)
-    if (const char* ev = std::getenv("DSD_WT_STORES")) h->wt_stores = (std::atoi(ev) != 0);  // developer switch (A/B timing)
-    if (const char* ev = std::getenv("DSD_XCD_MAP")) h->xcd_map = (std::atoi(ev) != 0);      // developer switch (A/B timing)
-    if (const char* ev = std::getenv("DSD_LAT_HEAD")) h->lat_head_split = (std::atoi(ev) != 0);  // developer switch (A/B timing)
+    if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);     // the same choice as dsd_set_loop_mode, for an unmodified host
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
-    if (const char* ev = std::getenv("DSD_LAT_BF")) h->lat_bf = (std::atoi(ev) != 0);         // opt-in: branch-free K-half conv of the latency path
-    if (const char* ev = std::getenv("DSD_LOOP_FM")) h->loop_fm = (std::atoi(ev) != 0);      // opt-in: frame-major persistent loop
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
         if (e > 3) { delete h; return fail(DSD_ERR_INVALID, "dsd_create: dilation 2^%d exceeds the supported maximum %d", e, kHalo); }
@@ -250,8 +238,6 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_fm<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopFmLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_fm<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopFmLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -601,10 +587,9 @@ static int launch_inproj(dsd_handle* h, const float* spec, hipStream_t s) {
 }
 
 template <int G>
-static void launch_lat(const LatParams& p, hipStream_t s, bool bf) {
+static void launch_lat(const LatParams& p, hipStream_t s) {
     const dim3 grid((unsigned)lat_grid(p.ntiles, G));
-    if (G == 8 && bf) hipLaunchKernelGGL((k_lat_conv<kLatG8BF>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
-    else hipLaunchKernelGGL((k_lat_conv<G>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
+    hipLaunchKernelGGL((k_lat_conv<G>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
     hipLaunchKernelGGL((k_lat_out<G>), grid, dim3(kThreads), kLatOutLdsBytes, s, p);
 }
 
@@ -624,7 +609,7 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
         q.t_dev = t_dev; q.t_uniform = t_uniform; q.ds_tstride = h->L * kC;
         q.T = h->T; q.ntile32 = h->ntile32; q.ntiles = h->ntiles; q.dil = h->dil[l];
         q.first = (l == 0); q.last = (l == h->L - 1);
-        if (G == 8) launch_lat<8>(q, s, h->lat_bf); else if (G == 4) launch_lat<4>(q, s, false); else launch_lat<2>(q, s, false);
+        if (G == 8) launch_lat<8>(q, s); else if (G == 4) launch_lat<4>(q, s); else launch_lat<2>(q, s);
         HIP_TRY(hipGetLastError());
         return DSD_OK;
     }
@@ -648,9 +633,8 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
     p.dbg = dbg;
     const int total = p.tiles_per_utt * h->B;
     dim3 grid((unsigned)p.tiles_per_utt, (unsigned)h->B);
-    p.wt_stores = h->wt_stores ? 1 : 0;
-    p.xcd_q = -1; p.xcd_r = 0;
-    if (h->xcd_map) { p.xcd_q = total / 8; p.xcd_r = total % 8; grid = dim3((unsigned)total); }
+    p.wt_stores = 1;                                      // write-through epilogue stores (plain stores lost the A/B of round 1, profiles/r01c)
+    p.xcd_q = total / 8; p.xcd_r = total % 8; grid = dim3((unsigned)total);      // XCD-aware workgroup -> tile map (profiles/r01b)
     const bool last = (l == h->L - 1);
     if (h->split_mode) {
         p.w1p = reinterpret_cast<const float4*>(h->w1s + (size_t)l * 4 * 48 * 12 * 64);
@@ -689,7 +673,7 @@ static HeadParams head_base(dsd_handle* h) {
 
 template <int MODE>
 static int launch_head(dsd_handle* h, const HeadParams& p, bool fuse, hipStream_t s) {
-    if (MODE != HEAD_EPS && lat_g(h) == 8 && h->lat_head_split) {
+    if (MODE != HEAD_EPS && lat_g(h) == 8) {
         // G = 8 latency path: the head row-split like the layers (dsd_lat.hpp): skip projection on 8 workgroups per tile -> final projection +
         // sampler update on 3 -> next input projection on 8.  hbuf = the gate buffer (free behind the last layer), pbuf = the x buffer
         // the last layer read (the other one receives the next x)
@@ -971,10 +955,7 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
     for (int b0 = 0; b0 < h->B; b0 += utt_per_chunk) {
         const int nb = std::min(utt_per_chunk, h->B - b0);
         p.tile_base = b0 * h->ntile32; p.n_tiles = nb * h->ntile32;
-        if (h->loop_fm) {
-            if (kind == 0) hipLaunchKernelGGL((k_loop_fm<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopFmLdsBytes, s, p);
-            else hipLaunchKernelGGL((k_loop_fm<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopFmLdsBytes, s, p);
-        } else if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
+        if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         else hipLaunchKernelGGL((k_loop<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         HIP_TRY(hipGetLastError());
     }

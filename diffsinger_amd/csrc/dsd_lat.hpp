@@ -58,13 +58,12 @@ __device__ __forceinline__ bool lat_map(int ntiles, int& tile, int& g) {
 }
 __host__ __device__ inline int lat_grid(int ntiles, int G) { return (ntiles + 7) / 8 * 8 * G; }
 
-// GX = the row split G, or kLatG8BF: G = 8 with the branch-free chunk -> pointer map (ConvB<LD, true>), opt-in DSD_LAT_BF=1 until it has run
-// on the hardware (an extra template parameter would rename the verified instantiations)
-constexpr int kLatG8BF = 9;
-template <int GX>
+// G = 8 splits the K range between wave pairs: the first chunk of a wave is a run-time value, so its chunk -> pointer map is the
+// branch-free form (ConvB<LD, true>; the branching one let hipcc sink the weight prefetch to its use: 39.4 -> 32.9 ms per 1 x 512 K = 100
+// call, bit-identical, profiles/r05_fm_lat_bf_probe_1x512.json)
+template <int G>
 __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
-    constexpr int G = (GX == kLatG8BF) ? 8 : GX;
-    constexpr bool BF = (GX == kLatG8BF);
+    constexpr bool BF = (G == 8);
     static_assert(G == 2 || G == 4 || G == 8, "row split");
     constexpr int LD = 32 + 2 * kHalo, TILE = kC * 32;
     constexpr int NMB = (G == 2) ? 2 : 1;

@@ -1,21 +1,30 @@
-// dsd_loop.hpp - the WHOLE K-step reverse loop as ONE persistent kernel (gfx950).
+// dsd_loop.hpp - the WHOLE K-step reverse loop as ONE persistent kernel (gfx950), frame-major LDS tiles, x resident in accumulator-fragment order.
 //
 // Replaces, for batches that fit the chip (<= one workgroup per CU), the hipGraph of 21 kernels per step
 // (usr/diff/shallow_diffusion_tts.py:261-270 loop; per step DiffNet.forward usr/diff/net.py:107-130 + p_sample :159-166 /
-// p_sample_plms :168-204).  Same arithmetic, same order, bit-identical results (tests/test_gpu_loop.py) - what changes is where
-// the data lives between layers:
+// p_sample_plms :168-204).  Same arithmetic, same order, bit-identical results to the per-layer kernels (tests/test_gpu_loop.py) -
+// what changes is where the data lives between layers:
 //   * a workgroup OWNS one 32-frame tile for the whole loop.  Its x tile (256 channels x 32 frames) and its running skip sum
 //     stay in REGISTERS from layer to layer and from step to step; per layer only the hoisted conditioner projection (2 KiB /
 //     frame) and the weight stream are read, nothing but the halo is written (the per-layer kernels move 6 KiB / frame and
 //     pay a kernel boundary - 1.45 us + the write-back of 16.8 MB of dirty L2 lines - 21 times per step).
 //   * the 3-tap dilated conv needs 8 frames of the two NEIGHBOUR tiles' x: each workgroup publishes its first / last 8
-//     columns per layer (2 x 8 KiB, write-through sc1 stores), raises a per-tile phase flag, and reads its neighbours'
-//     columns with sc1 loads once their flag has reached the phase (MI355X_MICROARCH.md "Inter-workgroup visibility": sc1
+//     frames per layer (2 x 8 KiB, write-through sc1 stores), raises a per-tile phase flag, and reads its neighbours'
+//     frames with sc1 loads once their flag has reached the phase (MI355X_MICROARCH.md "Inter-workgroup visibility": sc1
 //     stores + every storing wave drained + relaxed agent-scope flag; sc1 loads on the consumer).  Halo buffers are double
 //     buffered by phase parity: a neighbour can be at most one phase ahead.  No grid-wide barrier anywhere.
-//   * all workgroups must be co-resident (they wait for each other): the host launches at most one workgroup per CU (112 KiB
-//     of LDS each) and splits larger batches into chunks of whole utterances; every spin is bounded and a timeout is sticky
-//     (the loop then finishes instead of hanging, poisons the result with NaN and the host can read the timeout word).
+//   * all workgroups must be co-resident (they wait for each other): the host launches at most one workgroup per CU and splits
+//     larger batches into chunks of whole utterances; every spin is bounded and a timeout is sticky (the loop then finishes instead
+//     of hanging, poisons the result with NaN, and the host latches the timeout word into pinned memory: dsd_check, include/dsd.h).
+// Tile layout (the row-major form of rounds 1-2 was retired in round 3 after the whole GPU suite ran on this one, profiles/r05_*:
+// bit-identical, 0.862 vs 0.850 of the fp32 MFMA peak inside one call):
+//   * the conv input y and the gate tile are [frame][channel] with a row stride of 260 floats (conflict-free for the lane groups of
+//     ds_read_b128 / ds_write_b128, MI355X_MICROARCH.md section LDS).  A lane of the 32x32x2 MFMA supplies B[k = 4h + s][frame j] for the
+//     four steps s of an 8-deep chunk: ONE ds_read_b128 (a [channel][frame] tile needs four ds_read_b32 at a stride of one row).
+//   * x lives in fragment order all the time - xq[mb][q] = channels 64 w + 32 mb + 8 q + 4 h + {0..3} of frame j, exactly what the
+//     output projection's accumulators hold - so the residual update is register arithmetic, y = x + step is written to the
+//     frame-major tile with 8 ds_write_b128, the gate tile likewise, and the frame mask is ONE predicate per lane.
+//   * the halo buffers are [side][8 frames][256 channels]; a tile's first / last 8 frames are held by the lanes j < 8 / j >= 24.
 #pragma once
 #include "dsd_kernels.hpp"
 
@@ -48,8 +57,6 @@ struct LoopParams {
     int dbg_phase;
 };
 
-constexpr int kLoopLdsBytes = (kC * (32 + 2 * kHalo) + 2 * kC * 32 + 2 * kC) * (int)sizeof(float);      // y tile + gate tile + scratch + step rows [2]
-
 __device__ __forceinline__ float4 ld16_sc1(const float* base_uniform, int byte_off) {
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
@@ -58,20 +65,46 @@ __device__ __forceinline__ float4 ld16_sc1(const float* base_uniform, int byte_o
     return make_float4(f.x, f.y, f.z, f.w);
 }
 
+constexpr int kFmLDK = kC + 4;              // row stride of the frame-major tiles: 65 x 16 bytes, an odd number of 16-byte slots
+constexpr int kFmY = (32 + 2 * kHalo) * kFmLDK, kFmG = 32 * kFmLDK;
+constexpr int kLoopLdsBytes = (kFmY + kFmG + kC * 32 + 2 * kC) * (int)sizeof(float);
+static_assert(kFmY >= kC * 32 && kFmG >= kC * 32, "the head reuses the two tiles as [256][32]");
+
+// B functor of the dilated conv over the frame-major y tile: yc = this lane's pointer to (frame row kHalo + j, channel 4 h); a tap is a ROW offset
+struct ConvBT {
+    const float* yc; int dilrow;            // dil * kFmLDK
+    __device__ __forceinline__ const float* operator()(int it, int u) const {
+        const int kc = 6 * it + u;
+        if (kc < kConvCentre) return yc + kc * 8;
+        const int idx = kc - kConvCentre;
+        return yc + (idx >> 1) * 8 + ((idx & 1) ? dilrow : -dilrow);
+    }
+};
+// B functor of a frame-major [frame][k] tile: chunk kc at + 8 kc (clamped: the prefetch behind the last chunk stays inside the row)
+struct TileBT {
+    const float* base; int n;
+    __device__ __forceinline__ const float* operator()(int it, int u) const {
+        const int kc = 6 * it + u;
+        return base + ((kc < n) ? kc : n - 1) * 8;
+    }
+};
+
+__device__ __forceinline__ float4 fm_add_masked(const float4& x, const float4& d, bool ok) {
+    return make_float4(ok ? x.x + d.x : 0.f, ok ? x.y + d.y : 0.f, ok ? x.z + d.z : 0.f, ok ? x.w + d.w : 0.f);
+}
+
 // MODE: HEAD_DDPM or HEAD_PLMS (the sampler arithmetic of the head epilogue)
 template <int MODE>
 __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
-    constexpr int LD = 32 + 2 * kHalo, GLD = 32;
+    constexpr int LDK = kFmLDK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ytile = smem;                    // [256][48]  conv input y = x + step_proj (+ halo); head: scaled skip sum [256][32]
-    float* gtile = smem + kC * LD;          // [256][32]  gate tile; head: relu(skip_projection)
-    float* xt = gtile + kC * 32;            // [256][32]  scratch: residual transpose, spec tile of the in-projection
-    float* dsbuf = xt + kC * 32;            // [2][256]   step projection of phase ph in dsbuf[ph & 1]: fetched from the table one phase ahead,
-                                            //            so that staging y = x + step never waits for a global load
+    float* ytile = smem;                    // [48][260] conv input y = x + step_proj (+ halo rows), frame-major; head: scaled skip sum [256][32]
+    float* gtile = smem + kFmY;             // [32][260] gate tile, frame-major; head: relu(skip_projection) [256][32]
+    float* xt = gtile + kFmG;               // [256][32] scratch: spec tile of the in-projection
+    float* dsbuf = xt + kC * 32;            // [2][256]  step projection of phase ph in dsbuf[ph & 1], fetched one phase ahead
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware map (speed only): XCD x owns a contiguous range of this launch's tiles
     int tl;
     {
         const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
@@ -82,20 +115,26 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
     const int b = tile / p.ntile32, tn = tile - b * p.ntile32, t0 = tn * 32;
     const bool has_left = tn > 0, has_right = tn + 1 < p.ntile32;
     const int M = p.head.M, T = p.T;
+    const bool in_t = t0 + j < T;           // this lane's frame is a frame of the utterance
 
-    float4 xreg[8];         // x tile, row layout: wave w owns rows [64w, 64w+64); xreg[it] = row 64w + 8 it + lane/8, cols 4 (lane%8)..+3
-    float4 skp[2][4];       // running skip sum of this wave's skip rows, accumulator-fragment order
-    const int xrow0 = 64 * w + (lane >> 3), xc4 = lane & 7;
+    float4 xq[2][4];        // x tile in fragment order: xq[mb][q] = channels 64 w + 32 mb + 8 q + 4 h + {0,1,2,3} of frame j
+    float4 skp[2][4];       // running skip sum of this wave's skip rows, the same order
+    const int ch0 = 64 * w + 4 * h;         // channel of xq[0][0].x
 
     auto timed_out = [&]() -> bool { return __hip_atomic_load((gu32*)p.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; };
 
-    // in-projection of the tile in xt (as [kMPad][32]) -> xreg, through the (free) y tile region as [256][32]
-    auto inproj_to_xreg = [&]() {
+    // in-projection of the tile in xt (as [kMPad][32]) -> xq, through the (free) y tile region as [256][32]
+    auto inproj_to_xq = [&]() {
         inproj_tile(xt, p.head.winp, p.head.binp, p.head.nk_in, ytile, w, lane);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int it = 0; it < 8; ++it) xreg[it] = reinterpret_cast<const float4*>(ytile + 64 * w * 32)[it * 64 + lane];
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* src = ytile + (ch0 + 32 * mb + 8 * q) * 32 + j;
+                xq[mb][q] = make_float4(src[0], src[32], src[64], src[96]);
+            }
         __syncthreads();    // every wave has its rows before the region becomes the y tile again
     };
 
@@ -105,24 +144,24 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
     }
     dsbuf[tid] = p.ds_table[(size_t)p.eval_t[0] * p.L * kC + tid];       // phase 0 = (evaluation 0, layer 0)
     __syncthreads();
-    inproj_to_xreg();
+    inproj_to_xq();
 
-    // publish this tile's first / last 8 columns of x (xreg) as the halo of phase `phase`: write-through stores, EVERY storing
-    // wave drained, barrier, ONE relaxed agent-scope flag store.  Called as soon as x is known (behind the residual transpose of a
-    // layer / behind the input projection); the skip-sum update, the next phase's weight prefetch and own-column staging
-    // overlap the hop.
+    // publish this tile's first / last 8 frames of x as the halo of phase `phase`, [side][frame][channel]: the lanes that hold those frames
+    // store their 8 float4 (write-through), every storing wave drains, barrier, ONE relaxed agent-scope flag store (the protocol of k_loop)
     auto publish_issue = [&](unsigned phase) {
         float* hb = p.halo + ((size_t)(phase & 1) * p.ntiles_total + tile) * (2 * kC * 8);
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
         typedef float f32x4_ __attribute__((ext_vector_type(4)));
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(hb, 0, 0x7ffffff0, 0x00020000);
-        if (xc4 < 2 || xc4 >= 6) {
-            const int side = (xc4 >= 6) ? 1 : 0, c = xc4 & 1;
+        if (j < 8 || j >= 24) {
+            const int side = (j >= 24) ? 1 : 0, f = j & 7;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const f32x4_ f = {xreg[it].x, xreg[it].y, xreg[it].z, xreg[it].w};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, f), r, ((side * kC + xrow0 + 8 * it) * 8 + 4 * c) * 4, 0, 16);
-            }
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4_ v = {xq[mb][q].x, xq[mb][q].y, xq[mb][q].z, xq[mb][q].w};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, ((side * 8 + f) * kC + ch0 + 32 * mb + 8 * q) * 4, 0, 16);
+                }
         }
     };
     auto publish_finish = [&](unsigned phase) {
@@ -131,7 +170,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
         if (tid == 0) __hip_atomic_store((gu32*)(p.flags + tile), phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto publish = [&](unsigned phase) { publish_issue(phase); publish_finish(phase); };
-    // debug stamps go straight to memory (held in registers they would cost 20 VGPRs for the whole kernel)
     const bool stamp = p.dbg != nullptr;
 #define LOOP_STAMP(i) do { if (stamp && ph == (unsigned)p.dbg_phase && lane == 0) p.dbg[((size_t)tl * 4 + w) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define HEAD_STAMP(i) do { if (stamp && e == p.dbg_phase / p.L && lane == 0) p.dbg[((size_t)tl * 4 + w) * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -143,34 +181,26 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
         for (int l = 0; l < p.L; ++l, ++ph) {
             const bool last = (l == p.L - 1);
             const float* dsl = dsbuf + (ph & 1) * kC;
-            const int dil = p.dil[l];
             LOOP_STAMP(0);
 
             // (c) the weight stream does not depend on anything computed here: request its first chunks now
-            const ConvB<LD> bof1{ytile + 4 * h * LD + kHalo + j, dil, 0};
-            GemmPipe<4, 1, LD, 256, 6, ConvB<LD>> pipe1(p.w1p + ((size_t)l * 4 + w) * (96 * 256), lane, 96, bof1);
+            const ConvBT bof1{ytile + (kHalo + j) * LDK + 4 * h, (int)p.dil[l] * LDK};
+            GemmPipe<4, 1, LDK, 256, 6, ConvBT, 1, true> pipe1(p.w1p + ((size_t)l * 4 + w) * (96 * 256), lane, 96, bof1);
             pipe1.template start_a<0, 5>();
 
-            // (b) own columns of y = x + step_proj (zero at frames >= T: the conv's zero padding applies to y, net.py:69-71).  They
-            //     need nothing from the neighbours, and neither does the first third of the contraction: the K order of the dilated
-            //     conv starts with the CENTRE tap of every channel group (ConvB, chunks 0..31), which reads no halo column.
+            // (b) own frames of y = x + step_proj (zero at frames >= T: the conv's zero padding applies to y, net.py:69-71): the lane's 32
+            //     channels of frame j as 8 ds_write_b128 into row kHalo + j
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = xrow0 + 8 * it, t = t0 + 4 * xc4;
-                const float d = dsl[row];
-                float4 v = xreg[it];
-                v.x = (t + 0 < T) ? v.x + d : 0.f;
-                v.y = (t + 1 < T) ? v.y + d : 0.f;
-                v.z = (t + 2 < T) ? v.z + d : 0.f;
-                v.w = (t + 3 < T) ? v.w + d : 0.f;
-                *reinterpret_cast<float4*>(ytile + row * LD + kHalo + 4 * xc4) = v;
-            }
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = ch0 + 32 * mb + 8 * q;
+                    const float4 d = *reinterpret_cast<const float4*>(dsl + c);
+                    *reinterpret_cast<float4*>(ytile + (kHalo + j) * LDK + c) = fm_add_masked(xq[mb][q], d, in_t);
+                }
             __syncthreads();
             LOOP_STAMP(1);
-            // (d1) EVERY wave reads the two neighbour flags now (lanes 0 / 1), without waiting: the value returns under the first chunks
-            //      and is tested behind chunk 12.  The neighbours published at the end of their previous phase, so it is normally current
-            //      already - no poll round trip with the matrix pipe idle, and, every wave having seen the flags itself, no barrier
-            //      between the test and the halo loads.
+            // (d1) every wave reads the two neighbour flags now (lanes 0 / 1), tested behind chunk 12
             unsigned fv = 0xffffffffu;
             if (lane < 2) {
                 const bool have = lane ? has_right : has_left;
@@ -178,11 +208,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             }
             DSD_SB();
 
-            // (g) dilated conv, K = 768 (one contraction, taps are column offsets).  The exchange with the neighbour tiles runs UNDER
-            //     the centre-tap chunks: flags read at chunk 0 and tested behind chunk 12 (the neighbours published at the end of their
-            //     previous phase), their columns requested and in flight during chunks 12..29, written to the y tile in front
-            //     of chunk 30; the outer taps (chunks >= 32) are the first to read them.  The hoisted conditioner projection is
-            //     fetched half way.
+            // (g) dilated conv, K = 768, centre taps first: the exchange with the neighbour tiles runs under them
             f32x16 acc[4][1];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
@@ -201,39 +227,36 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            // (e1) request the neighbours' columns (thread = channel row; sc1 loads: the producer stored write-through)
+            // (e1) request the neighbours' frames: 8 frames x 256 channels per side = 512 float4, two per thread (sc1 loads)
             float4 hv[2][2];
             {
                 const float* hbase = p.halo + (size_t)(ph & 1) * p.ntiles_total * (2 * kC * 8);
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
                     const bool have = side ? has_right : has_left;
-                    // my left halo = left neighbour's LAST 8 columns (its side 1); my right halo = right neighbour's first 8 (side 0)
-                    const int off = (((tile + (side ? 1 : -1)) * 2 + (side ? 0 : 1)) * kC + tid) * 8 * 4;
+                    // my left halo = left neighbour's LAST 8 frames (its side 1); my right halo = right neighbour's first 8 (side 0)
+                    const int off = (((tile + (side ? 1 : -1)) * 2 + (side ? 0 : 1)) * (8 * kC) + 4 * tid) * 4;
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         hv[side][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (have) hv[side][g] = ld16_sc1(hbase, off + 16 * g);
+                        if (have) hv[side][g] = ld16_sc1(hbase, off + g * (4 * kC * 4));       // float4 index tid + 256 g: frame 4 g + tid / 64
                     }
                 }
             }
             DSD_SB();
             pipe1.run(acc, 12, 30);
-            // (e2) halo columns of the y tile
+            // (e2) halo rows of the y tile: float4 index tid + 256 g = (frame f = 4 g + tid / 64, channels 4 (tid % 64) ..)
             {
-                const float d = dsl[tid];
+                const int c = 4 * (tid & 63);
+                const float4 d = *reinterpret_cast<const float4*>(dsl + c);
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
                     const bool have = side ? has_right : has_left;
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        float4 v = hv[side][g];
-                        const int t = side ? t0 + 32 + 4 * g : t0 - kHalo + 4 * g;
-                        v.x = (have && t + 0 < T) ? v.x + d : 0.f;
-                        v.y = (have && t + 1 < T) ? v.y + d : 0.f;
-                        v.z = (have && t + 2 < T) ? v.z + d : 0.f;
-                        v.w = (have && t + 3 < T) ? v.w + d : 0.f;
-                        *reinterpret_cast<float4*>(ytile + tid * LD + (side ? kHalo + 32 : 0) + 4 * g) = v;
+                        const int f = 4 * g + (tid >> 6);
+                        const int t = side ? t0 + 32 + f : t0 - kHalo + f;
+                        *reinterpret_cast<float4*>(ytile + ((side ? kHalo + 32 : 0) + f) * LDK + c) = fm_add_masked(hv[side][g], d, have && t < T);
                     }
                 }
             }
@@ -249,8 +272,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
             }
             DSD_SB();
             pipe1.run(acc, 48, 96);
-            // step projection of the NEXT phase (next layer, or layer 0 of the next evaluation): requested now, parked in LDS behind the
-            // output projection, read by the next phase's staging
+            // step projection of the NEXT phase (next layer, or layer 0 of the next evaluation)
             float ds_next = 0.f;
             {
                 const bool more = !last || (e + 1 < p.n_evals);
@@ -258,26 +280,27 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 if (more) ds_next = p.ds_table[((size_t)tn_ * p.L + ln_) * kC + tid];
             }
 
-            const float* gl = gtile + 4 * h * GLD + j;
-            const TileB bof2{gl, 8 * GLD, 32};
-            // gate (net.py:73-74) in registers -> gate tile (called behind the out-proj weight prefetch)
+            const TileBT bof2{gtile + j * LDK + 4 * h, 32};
+            // gate (net.py:73-74) in registers -> frame-major gate tile, 8 ds_write_b128 (called behind the out-proj weight prefetch)
             auto do_gate = [&]() {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float vg = f4at(cpv[pr][r >> 2], r & 3), vf = f4at(cpv[pr + 2][r >> 2], r & 3);
-                        const float g = sigmoid_f(acc[pr][0][r] + vg) * tanh_f(acc[pr + 2][0][r] + vf);
-                        gtile[(64 * w + 32 * pr + frag_row(r, h)) * GLD + j] = g;
+                    for (int q = 0; q < 4; ++q) {
+                        float g4[4];
+#pragma unroll
+                        for (int ee = 0; ee < 4; ++ee) {
+                            const int r = 4 * q + ee;
+                            const float vg = f4at(cpv[pr][q], ee), vf = f4at(cpv[pr + 2][q], ee);
+                            g4[ee] = sigmoid_f(acc[pr][0][r] + vg) * tanh_f(acc[pr + 2][0][r] + vf);
+                        }
+                        *reinterpret_cast<float4*>(gtile + j * LDK + ch0 + 32 * pr + 8 * q) = make_float4(g4[0], g4[1], g4[2], g4[3]);
                     }
             };
-            float* tw = xt + w * (64 * 32);
             LOOP_STAMP(3);
             if (!last) {
-                // output projection, all four row blocks (0,1 residual, 2,3 skip) in one pass.  (Splitting it - residual rows
-                // first, halo published, skip rows behind - hides the hop but costs more in pipeline restart + second B pass
-                // than the hop itself: measured 135.3 vs 133.0 ms per 100-step loop, profiles/r01h.)
-                GemmPipe<4, 1, GLD, 256, 6, TileB> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
+                // output projection, all four row blocks (0,1 residual, 2,3 skip) in one pass
+                GemmPipe<4, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
@@ -287,34 +310,26 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[m][0][r] = 0.f;
-                float brow[8];
+                float4 bq[2][4];            // residual-half bias of this lane's channels
                 pipe2.start_b();
                 pipe2.run(acc2, 0, 6);
 #pragma unroll
-                for (int it = 0; it < 8; ++it) brow[it] = p.b2raw[(size_t)l * 2 * kC + 64 * w + it * 8 + (lane >> 3)];
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[mb][q] = *reinterpret_cast<const float4*>(p.b2raw + (size_t)l * 2 * kC + ch0 + 32 * mb + 8 * q);
                 DSD_SB();
                 pipe2.run(acc2, 6, 32);
                 LOOP_STAMP(5);
-                // residual: accumulator fragments -> row layout through this wave's slice of the scratch; x' = (x + res + b) / sqrt(2)
+                // residual in place: x' = (x + res + b) / sqrt(2) - the accumulators hold exactly the elements of xq
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) tw[(32 * mb + frag_row(r, h)) * 32 + j] = acc2[mb][0][r];
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const float4 v = reinterpret_cast<const float4*>(tw)[it * 64 + lane];
-                    const float4 x = xreg[it];
-                    const float bv = brow[it];
-                    constexpr float kInvSqrt2 = 1.0f / 1.41421354f;
-                    float4 o;
-                    o.x = (x.x + (v.x + bv)) * kInvSqrt2;
-                    o.y = (x.y + (v.y + bv)) * kInvSqrt2;
-                    o.z = (x.z + (v.z + bv)) * kInvSqrt2;
-                    o.w = (x.w + (v.w + bv)) * kInvSqrt2;
-                    xreg[it] = o;
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = get4(acc2[mb][0], q), x = xq[mb][q], bv = bq[mb][q];
+                        constexpr float kInvSqrt2 = 1.0f / 1.41421354f;
+                        xq[mb][q] = make_float4((x.x + (v.x + bv.x)) * kInvSqrt2, (x.y + (v.y + bv.y)) * kInvSqrt2,
+                                                (x.z + (v.z + bv.z)) * kInvSqrt2, (x.w + (v.w + bv.w)) * kInvSqrt2);
+                    }
                 LOOP_STAMP(6);
                 dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barrier inside publish_finish()
                 publish_issue(ph + 1u);                             // the halo stores drain while the skip sum is updated
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                 LOOP_STAMP(7);
             } else {
                 // last layer: only the skip half (net.py:126 reads the skips; the residual is dead)
-                GemmPipe<2, 1, GLD, 256, 6, TileB> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256) + 2 * 64, lane, 32, bof2);
+                GemmPipe<2, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256) + 2 * 64, lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
@@ -349,8 +364,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
                         skp[ms][q] = (l == 0) ? a : make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
                     }
             }
-            // the y tile is rewritten at the top of the next phase: every wave passed the barrier behind the gate, i.e. is
-            // done reading it; the gate tile is rewritten only behind the next phase's barriers
         }
 
         // ---- head (net.py:126-129) + sampler epilogue for this tile, then the next evaluation's input projection -----------
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop(const LoopParams p) {
         HEAD_STAMP(5);
         __syncthreads();
         HEAD_STAMP(6);
-        if (fuse) { inproj_to_xreg(); publish(ph); }
+        if (fuse) { inproj_to_xq(); publish(ph); }
         HEAD_STAMP(7);
     }
 #undef LOOP_STAMP

@@ -5,9 +5,8 @@
 #include "../../include/dsf.h"
 
 static inline int fs_ts(int T) { return (T + 31) / 32 * 32; }
-// Row blocks per wave of k_fs_conv (fixes the packed weight layout).  4 (512 rows per workgroup, one workgroup per CU) was measured
-// SLOWER than 2 on the wide layers - FastSpeech2 forward 5.9 vs 5.2 ms, training step 16.8 vs 16.3 ms (profiles/r01s_*): with
-// unpipelined staging the second co-resident workgroup is what hides the slab loads.
+// Row blocks per wave of k_fs_conv (fixes the packed weight layout): 2 = 256 rows per workgroup, two workgroups per CU.  (4 - 512 rows, one
+// workgroup per CU - was measured slower on the wide layers in round 1, profiles/r01s_*, and its instantiation was dropped in round 3.)
 static inline int fs_nmb(int Co) { (void)Co; return 2; }
 
 extern "C" int dsf_padded_frames(int32_t T) { return fs_ts(T); }
@@ -59,7 +58,6 @@ static int fs_conv_launch(const float* in, const float* wpacked, const float* bi
         return fail(DSD_ERR_INVALID, "dsf_conv1d: bad shape (B=%d T=%d Ci=%d Co=%d K=%d dil=%d act=%d)", B, T, Ci, Co, KT, dil, act);
     if (first_on_device(10)) {
         (void)hipFuncSetAttribute((const void*)k_fs_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_fs_conv<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
     }
     FsConvParams p{};
     p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.keep = keep;
@@ -67,17 +65,7 @@ static int fs_conv_launch(const float* in, const float* wpacked, const float* bi
     p.scale = scale; p.act = act;
     const int nmb = fs_nmb(Co);
     const dim3 grid((unsigned)(p.TS / 32), (unsigned)B, (unsigned)((Co + 128 * nmb - 1) / (128 * nmb)));
-    // opt-in (env DSF_CONV_INC=1, not yet run on hardware): running chunk pointer + six chunks per basic block (FsTapBInc, fs2_kernels.hpp)
-    const char* inc = std::getenv("DSF_CONV_INC");
-    if (inc && std::atoi(inc) != 0) {
-        if (first_on_device(12)) {
-            (void)hipFuncSetAttribute((const void*)k_fs_conv_inc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
-            (void)hipFuncSetAttribute((const void*)k_fs_conv_inc<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
-        }
-        if (nmb == 4) hipLaunchKernelGGL((k_fs_conv_inc<4>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((k_fs_conv_inc<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
-    } else if (nmb == 4) hipLaunchKernelGGL((k_fs_conv<4>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((k_fs_conv<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((k_fs_conv<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

@@ -39,32 +39,14 @@ struct FsConvParams {
     int act;
 };
 
-struct FsTapB {             // B-operand functor of GemmPipe: chunk kc = ci8 * KT + tap of the staged slab
-    const float* base;      // slab + 4 h LD + halo + j - pad
-    int KT, dil, n;
-    __device__ __forceinline__ const float* operator()(int it, int u) const {
-        int kc = 6 * it + u;
-        kc = (kc < n) ? kc : n - 1;
-        // chunk -> (8-channel group, tap): constant divisors for the kernel sizes the models use (a uniform branch instead of a
-        // software integer division in front of every 8 MFMAs)
-        int g;
-        if (KT == 1) g = kc;
-        else if (KT == 3) g = kc / 3;
-        else if (KT == 9) g = kc / 9;
-        else if (KT == 5) g = kc / 5;
-        else g = kc / KT;
-        const int tap = kc - g * KT;
-        return base + g * (8 * kFsLD) + tap * dil;
-    }
-};
-
-// The chunk -> pointer map as a RUNNING pointer (opt-in DSF_CONV_INC=1, k_fs_conv_inc; not yet run on hardware): see VocTapBInc (voc_kernels.hpp) -
-// FsTapB costs a chain of uniform branches and a constant-divisor division in front of every 4 NMB MFMAs, and the run-time chunk count makes
-// every step of GemmPipe::run a basic block of its own; k_fs_conv_inc walks whole groups of six chunks as one block (GemmPipe::run_blocks).
-struct FsTapBInc {
-    const float* cur;       // the chunk handed out next
+// B-operand functor of GemmPipe: chunk kc = ci8 * KT + tap of the staged slab as a RUNNING pointer (see VocTapB, voc_kernels.hpp): GemmPipe asks
+// for the chunks strictly in order, so the map is tap + 1 / wrap to the next 8-channel group / freeze on the last chunk - a handful of selects
+// instead of a branch chain + constant-divisor division in front of every 4 NMB MFMAs; the K loop walks whole groups of six chunks as one
+// basic block (GemmPipe::run_blocks).  -5 % on the FastSpeech2 forward (profiles/r05_fm_conv_inc_ab.jsonl).
+struct FsTapB {
+    const float* cur;       // the chunk handed out next (base = slab + 4 h LD + halo + j - pad)
     int KT, dil, left, tap;
-    __device__ __forceinline__ FsTapBInc(const float* base, int KT_, int dil_, int n) : cur(base), KT(KT_), dil(dil_), left(n - 1), tap(0) {}
+    __device__ __forceinline__ FsTapB(const float* base, int KT_, int dil_, int n) : cur(base), KT(KT_), dil(dil_), left(n - 1), tap(0) {}
     __device__ __forceinline__ const float* operator()(int, int) {
         const float* r = cur;
         const bool adv = left > 0, wrap = (tap + 1 == KT);
@@ -81,19 +63,83 @@ struct FsTapBInc {
 // 512 output rows; NMB = 2 keeps two workgroups per CU for the narrow ones.
 template <int NMB>
 __global__ __launch_bounds__(kThreads, NMB == 4 ? 1 : 2) void k_fs_conv(const FsConvParams p) {
-#define FS_TAPB FsTapB
-#define FS_RUN(pipe, acc, n) pipe.run(acc, 0, n)
-#include "fs_conv_body.inc"
-#undef FS_RUN
-#undef FS_TAPB
-}
-template <int NMB>
-__global__ __launch_bounds__(kThreads, NMB == 4 ? 1 : 2) void k_fs_conv_inc(const FsConvParams p) {
-#define FS_TAPB FsTapBInc
-#define FS_RUN(pipe, acc, n) pipe.run_blocks(acc, n)
-#include "fs_conv_body.inc"
-#undef FS_RUN
-#undef FS_TAPB
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [kFsSlab][kFsLD]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * 32, b = blockIdx.y, mt = blockIdx.z;
+    const int nchunk_total = (p.Ci / 8) * p.KT;
+    f32x16 acc[NMB][1];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][0][r] = 0.f;
+    const float* inb = p.in + (size_t)b * p.Ci * p.TS;
+    // Staging: channels [c0, c0 + nc) x frames [t0 - 8, t0 + 40) of a slab, 12 float4 per row, zero outside [0, TS).  All the loads of a slab
+    // are requested at once (12 per thread for 256 channels) and the NEXT slab's loads are in flight during this slab's contraction: a
+    // load -> write -> load chain exposes the memory latency once per float4 (12 times per slab - more than the 7 us of MFMA work a K = 256
+    // convolution has per workgroup; A/B inside one GPU call: FastSpeech2 forward 3.94 -> 3.82 ms, profiles/r02x_fs_conv_staging_ab.jsonl)
+    constexpr int NIT = kFsSlab * (kFsLD / 4) / kThreads;
+    float4 sv[NIT];
+    auto request = [&](int c0, int nc) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * kThreads + tid, row = idx / (kFsLD / 4), g = idx - row * (kFsLD / 4);
+            const int t = t0 - kFsHalo + 4 * g;
+            const bool ok = (row < nc) && (t >= 0) && (t < p.TS);
+            const float4 v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + (ok ? row : 0)) * p.TS + (ok ? t : t0));
+            sv[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        DSD_SB();
+    };
+    request(0, min(kFsSlab, p.Ci));
+    for (int c0 = 0; c0 < p.Ci; c0 += kFsSlab) {
+        const int nc = min(kFsSlab, p.Ci - c0);
+        // the weight stream does not depend on the slab: its first chunks are requested BEFORE the slab is written, so that their first-touch
+        // latency (every workgroup of a launch walks the stream in lock-step: each chunk is new to the L2) overlaps the staging
+        const int nch = (nc / 8) * p.KT;
+        const float4* ap = p.wp + (((size_t)mt * 4 + w) * nchunk_total + (size_t)(c0 / 8) * p.KT) * (NMB * 64);
+        FsTapB bof(smem + 4 * h * kFsLD + kFsHalo + j - p.pad, p.KT, p.dil, nch);
+        GemmPipe<NMB, 1, kFsLD, NMB * 64, 6, FsTapB> pipe(ap, lane, nch, bof);
+        pipe.start_a();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * kThreads + tid, row = idx / (kFsLD / 4), g = idx - row * (kFsLD / 4);
+            if (row < nc) *reinterpret_cast<float4*>(smem + row * kFsLD + 4 * g) = sv[it];
+        }
+        __syncthreads();
+        if (c0 + kFsSlab < p.Ci) request(c0 + kFsSlab, min(kFsSlab, p.Ci - c0 - kFsSlab));
+        pipe.start_b();
+        pipe.run_blocks(acc, nch);
+        __syncthreads();
+    }
+    const int t = t0 + j;
+    const bool tv = t < p.T;
+    float kp = 1.f;
+    if (p.keep && tv) kp = p.keep[(size_t)b * p.T + t];
+    // epilogue: all the bias / residual reads are issued first (clamped row index, no branches between them), then the
+    // arithmetic, then the stores - two workgroups per CU are not enough to hide 32 dependent load -> store round trips
+    float bv[NMB][16], rv[NMB][16];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (mt * 4 + w) * (32 * NMB) + 32 * mb + frag_row(r, h);
+            const int rc = (row < p.Co) ? row : 0;
+            bv[mb][r] = p.bias ? p.bias[rc] : 0.f;
+            rv[mb][r] = p.res ? p.res[((size_t)b * p.Co + rc) * p.TS + t] : 0.f;
+        }
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (mt * 4 + w) * (32 * NMB) + 32 * mb + frag_row(r, h);
+            float v = (acc[mb][0][r] + bv[mb][r]) * p.scale;
+            if (p.act == FS_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == FS_ACT_GELU) v = v * 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+            else if (p.act == FS_ACT_MISH) v = v * tanhf((v > 20.f) ? v : log1pf(expf(v)));        // x * tanh(softplus(x)), usr/diff/diffusion.py:68-70
+            v = (v + rv[mb][r]) * kp;
+            if (row < p.Co) p.out[((size_t)b * p.Co + row) * p.TS + t] = tv ? v : 0.f;
+        }
 }
 constexpr int kFsConvLdsBytes = kFsSlab * kFsLD * (int)sizeof(float);
 

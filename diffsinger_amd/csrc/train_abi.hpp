@@ -22,25 +22,27 @@ static int tr_ncu() {
 }
 // The forward as ONE persistent launch per chunk of whole utterances (train_loop.hpp) instead of a launch per layer: on when an utterance fits
 // the co-resident grid (one workgroup per CU) and the chunks fill the chip at least as well as the per-layer grid does (the rule of
-// loop_applicable(), dsd.hip).  DSD_TRAIN_PERSIST=0 keeps the per-layer launches (the A/B switch of tools/bench_train.py).  The data-gradient
-// chain of the backward pass has the same two forms; its persistent form (k_trb_loop) is opt-in (DSD_TRAIN_PERSIST_BWD=1).
+// loop_applicable(), dsd.hip).  dsf_set_stack_mode: 1 automatic (default), 0 per-layer launches always (the A/B switch of tools/bench_train.py),
+// 2 persistent wherever an utterance fits the grid (tests of the chunked form on any shape).  A process-wide setting, read once per call:
+// the workspace layouts do not depend on it.  (The data-gradient chain of the backward pass had a persistent form too - k_trb_loop, round 2:
+// measured equal to the per-layer launches for 30 % more workspace, profiles/r03z - deleted in round 3.)
+static int g_tr_stack_mode = 1;
+extern "C" int dsf_set_stack_mode(int32_t mode) {
+    if (mode < 0 || mode > 2) return fail(DSD_ERR_INVALID, "dsf_set_stack_mode: 0 (per-layer launches), 1 (automatic) or 2 (persistent wherever it fits)");
+    g_tr_stack_mode = mode;
+    return DSD_OK;
+}
 static bool tr_persist_applies(int B, int ntile32) {
-    const char* e = getenv("DSD_TRAIN_PERSIST");
-    if (e && atoi(e) == 0) return false;
+    const int mode = g_tr_stack_mode;
+    if (mode == 0) return false;
     const int ncu = tr_ncu();
     if (ncu < 8 || ntile32 > ncu) return false;
-    if ((long long)B * ntile32 > 32768) return false;         // 32-bit byte offsets into the halo buffers (32 KiB per tile in k_trb_loop)
-    if (e && atoi(e) == 2) return true;            // forced (tests of the chunked form on any shape)
+    if ((long long)B * ntile32 > 32768) return false;
+    if (mode == 2) return true;
     const int ntiles = B * ntile32, upc = std::max(1, ncu / ntile32), chunks = (B + upc - 1) / upc;
     const double u_p = (double)ntiles / ((double)chunks * ncu);
     const double u_l = 0.9 * (double)ntiles / ((double)((ntiles + ncu - 1) / ncu) * ncu);
     return u_p >= u_l;
-}
-
-static bool tr_persist_bwd_applies(int B, int ntile32) {
-    const char* e = getenv("DSD_TRAIN_PERSIST_BWD");
-    if (!e || atoi(e) == 0) return false;          // opt-in: measured equal to the per-layer launches (profiles/r03z), for 30 % more workspace
-    return tr_persist_applies(B, ntile32);
 }
 
 struct TrSave {             // offsets in floats into save_ws
@@ -68,8 +70,7 @@ static TrSave tr_save_layout(int B, int TS, int L) {
 }
 
 struct TrBwd {              // offsets in floats into bwd_ws
-    size_t wotp, wdtp, da, g, dxp0, dxp1, dds_part, part, part_b, pda, pg, pdx, pflags, phalo, total;
-    bool persist;           // the persistent form (k_trb_loop): da / g / dx of EVERY layer are kept (the weight gradients run behind the kernel)
+    size_t wotp, wdtp, da, g, dxp0, dxp1, dds_part, part, part_b, total;
 };
 static TrBwd tr_bwd_layout(int B, int TS, int L) {
     const size_t ntiles = (size_t)B * TS / 32, act = (size_t)B * kC * TS;
@@ -84,14 +85,6 @@ static TrBwd tr_bwd_layout(int B, int TS, int L) {
     s.dds_part = o; o += tr_al((size_t)L * ntiles * kC);
     s.part = o; o += (size_t)kTrWgMaxTiles * kTrMaxSplit * 128 * 256;
     s.part_b = o; o += tr_al((size_t)kTrWgMaxTiles * kTrMaxSplit * 128);
-    s.persist = tr_persist_bwd_applies(B, TS / 32);
-    if (s.persist) {
-        s.pda = o; o += (size_t)L * 2 * act;        // [L][B][512][TS] (unused when the caller keeps da_all)
-        s.pg = o; o += (size_t)L * act;
-        s.pdx = o; o += (size_t)std::max(L - 1, 1) * act;
-        s.pflags = o; o += tr_al(ntiles + 64);
-        s.phalo = o; o += ntiles * 16384;           // [2 parities][ntiles][2 sides][512][8]
-    }
     s.total = o;
     return s;
 }
@@ -125,9 +118,7 @@ static int tr_attrs() {
     if (!first_on_device(30)) return DSD_OK;
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_stack_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_loop, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedLdsBytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_stack_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, kTrStackLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
@@ -255,7 +246,7 @@ static int tr_forward_persistent(const float* x0, const float* step, const dsf_s
     p.halo = ws + lay.X;                            // 2 x ntiles x 16 KiB = one layer of the (here unused) tile-major x buffers
     return tr_persistent_chunks(s, B, ntile32, [&](int tile_base, int n_tiles) {
         p.tile_base = tile_base; p.n_tiles = n_tiles;
-        hipLaunchKernelGGL(k_tr_stack_fwd, dim3((unsigned)n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
+        hipLaunchKernelGGL(k_tr_stack_fwd, dim3((unsigned)n_tiles), dim3(kThreads), kTrStackLdsBytes, s, p);
     });
 }
 
@@ -347,13 +338,10 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         DSD_TRY(tr_pack_multi(s, halves, 2 * L, bws + bl.wdtp, kTrW3 / 2, 2, 3, 32, 4, 0, 0, kC, kC, 3, 3 * kC, 1));
     }
     float* dxp[2] = {bws + bl.dxp0, bws + bl.dxp1};           // dxp[k & 1]: gradient wrt the output x of layer k
-    const bool persist = bl.persist;                          // every layer keeps its own da / g / dx slab (k_trb_loop)
     const long long da_bs = da_all ? (long long)L * 2 * kC * TS : (long long)2 * kC * TS;
-    auto da_of = [&](int l) {
-        return da_all ? da_all + (size_t)l * 2 * kC * TS : persist ? bws + bl.pda + (size_t)l * 2 * act : bws + bl.da + (size_t)(l & 1) * 2 * act;
-    };
-    auto g_of = [&](int l) { return persist ? bws + bl.pg + (size_t)l * act : bws + bl.g + (size_t)(l & 1) * act; };
-    auto dx_of = [&](int l) { return persist ? bws + bl.pdx + (size_t)l * act : dxp[l & 1]; };      // gradient wrt the output x of layer l < L - 1
+    auto da_of = [&](int l) { return da_all ? da_all + (size_t)l * 2 * kC * TS : bws + bl.da + (size_t)(l & 1) * 2 * act; };
+    auto g_of = [&](int l) { return bws + bl.g + (size_t)(l & 1) * act; };
+    auto dx_of = [&](int l) { return dxp[l & 1]; };           // gradient wrt the output x of layer l < L - 1
     auto gate_params = [&](int l) {
         TrbGateParams p{};
         p.dxp = (l == L - 1) ? nullptr : dxp[l & 1]; p.dsk = dskip; p.a_frag = (const float4*)(sws + lay.A + (size_t)l * lay.A_l);
@@ -406,7 +394,6 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
     // above) wait here: two layers share ONE weight-gradient launch - 40 tiles x 6 frame splits instead of 2 x (20 x 12): the same 240
     // workgroups work twice as long, half the split-K partials per layer are written and reduced, half the launches.  The slots of da / g /
     // dx alternate by layer parity: a pair is launched before the next kernel overwrites the older one's slot.
-    static const bool pair = []() { const char* e = getenv("DSD_TRAIN_WGRAD_PAIR"); return !(e && e[0] == '0'); }();     // developer switch (A/B on one box)
     int pending[2], npend = 0;
     auto wgrad_flush = [&]() -> int {
         if (!npend) return DSD_OK;
@@ -419,32 +406,9 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
     };
     auto wgrad = [&](int l) -> int {
         pending[npend++] = l;
-        return (npend == 2 || !pair) ? wgrad_flush() : DSD_OK;
+        return (npend == 2) ? wgrad_flush() : DSD_OK;
     };
-    static const bool fuse = []() { const char* e = getenv("DSD_TRAIN_FUSE_BWD"); return !(e && e[0] == '0'); }();     // developer switch (A/B on one box)
     const dim3 grid((unsigned)ntiles), blk(kThreads);
-    if (persist) {
-        // the whole data-gradient chain as ONE launch per chunk of whole utterances (k_trb_loop), every layer's weight gradients behind it
-        unsigned* flags = reinterpret_cast<unsigned*>(bws + bl.pflags);
-        HIP_TRY(hipMemsetAsync(flags, 0, ((size_t)ntiles + 64) * sizeof(unsigned), s));
-        TrbLoopParams p{};
-        p.dsk = dskip; p.a_frag = (const float4*)(sws + lay.A); p.a_lstride = lay.A_l / 4;
-        p.wotp = (const float4*)(bws + bl.wotp); p.wdtp = (const float4*)(bws + bl.wdtp);
-        p.da = da_of(0); p.da_bstride = da_bs; p.da_lstride = da_all ? (size_t)2 * kC * TS : 2 * act;
-        p.g = g_of(0); p.dx = dx_of(0); p.act = act; p.dx0 = g->dx0; p.dds_part = bws + bl.dds_part;
-        p.L = L; p.T = T; p.TS = TS; p.ntile32 = ntile32; p.ntiles_total = ntiles;
-        for (int l = 0; l < L; ++l) p.dil[l] = (unsigned char)w->dilations[l];
-        p.flags = flags; p.tmo = flags + ntiles; p.halo = bws + bl.phalo;
-        DSD_TRY(tr_persistent_chunks(s, B, ntile32, [&](int tile_base, int n_tiles) {
-            p.tile_base = tile_base; p.n_tiles = n_tiles;
-            hipLaunchKernelGGL(k_trb_loop, dim3((unsigned)n_tiles), blk, kTrbFusedLdsBytes, s, p);
-        }));
-        for (int l = L - 1; l >= 0; --l) DSD_TRY(wgrad(l));
-        DSD_TRY(wgrad_flush());
-        hipLaunchKernelGGL(k_tr_dds_reduce, dim3((unsigned)B, (unsigned)L), dim3(kC), 0, s, bws + bl.dds_part, g->dstep, L, ntile32, ntiles);
-        HIP_TRY(hipGetLastError());
-        return DSD_OK;
-    }
     {   // gate derivative of the last layer (its x_out is dead: K = 256)
         const TrbGateParams p = gate_params(L - 1);
         hipLaunchKernelGGL(k_trb_gate<true>, grid, blk, kTrbGateLdsBytes, s, p);
@@ -453,23 +417,17 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
     }
     for (int l = L - 1; l >= 0; --l) {
         const bool last = (l == L - 1);
-        if (l > 0 && fuse) {
+        if (l > 0) {
             // transposed conv of layer l + gate derivative of layer l - 1 in one kernel (the dx tile stays in the workgroup)
             TrbFusedParams q{conv_params(l), gate_params(l - 1)};
             if (last) hipLaunchKernelGGL(k_trb_fused<true>, grid, blk, kTrbFusedLdsBytes, s, q);
             else hipLaunchKernelGGL(k_trb_fused<false>, grid, blk, kTrbFusedLdsBytes, s, q);
-            HIP_TRY(hipGetLastError());
         } else {
             const TrbConvParams p = conv_params(l);
             if (last) hipLaunchKernelGGL(k_trb_conv<true>, grid, blk, kTrbConvLdsBytes, s, p);
             else hipLaunchKernelGGL(k_trb_conv<false>, grid, blk, kTrbConvLdsBytes, s, p);
-            HIP_TRY(hipGetLastError());
-            if (l > 0) {
-                const TrbGateParams pg = gate_params(l - 1);
-                hipLaunchKernelGGL(k_trb_gate<false>, grid, blk, kTrbGateLdsBytes, s, pg);
-                HIP_TRY(hipGetLastError());
-            }
         }
+        HIP_TRY(hipGetLastError());
         if (l > 0) DSD_TRY(wgrad(l - 1));
     }
     DSD_TRY(wgrad_flush());

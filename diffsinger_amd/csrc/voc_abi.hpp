@@ -46,14 +46,6 @@ static void voc_conv_launch(const VocConvParams& p, int B, hipStream_t s) {
     constexpr int WR = 4 / WT, SPAN = voc_span<NB, WT>();
     const size_t lds = (size_t)voc_lds_bytes<NB, WT, HALO>();
     const dim3 grid((unsigned)((p.LSi + SPAN - 1) / SPAN), (unsigned)B, (unsigned)((p.rows + 32 * WR - 1) / (32 * WR)));
-    // opt-in (env DSV_CONV_INC=1, not yet run on hardware): the chunk -> pointer map as a running pointer (VocTapBInc, voc_kernels.hpp)
-    const char* e = std::getenv("DSV_CONV_INC");
-    if (e && std::atoi(e) != 0) {
-        if (first_on_device(2100 + 10 * NB + WT + 1000 * (HALO != kVocHalo)))
-            (void)hipFuncSetAttribute((const void*)k_voc_conv_inc<NB, WT, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, voc_lds_bytes<NB, WT, HALO>());
-        hipLaunchKernelGGL((k_voc_conv_inc<NB, WT, HALO>), grid, dim3(kThreads), lds, s, p);
-        return;
-    }
     hipLaunchKernelGGL((k_voc_conv<NB, WT, HALO>), grid, dim3(kThreads), lds, s, p);
 }
 
@@ -85,15 +77,11 @@ extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bi
     return DSD_OK;
 }
 
-static int g_voc_fold = -1;      // -1: read DSV_FOLD from the environment on first use (default on)
+static int g_voc_fold = 1;       // dsv_set_fold: the A/B switch of the measurement (narrow layers on the unfolded kernel)
 
 extern "C" int dsv_set_fold(int32_t on) { g_voc_fold = on ? 1 : 0; return DSD_OK; }
 
 extern "C" int32_t dsv_fold_factor(int32_t Co, int32_t Ci, int32_t K, int32_t dil) {
-    if (g_voc_fold < 0) {
-        const char* e = getenv("DSV_FOLD");
-        g_voc_fold = (e && e[0] == '0') ? 0 : 1;
-    }
     if (!g_voc_fold || Co < 1 || Ci < 1 || Ci > kFoldMaxCi || K < 1 || !(K & 1) || dil < 1) return 1;
     const int F = (Co <= 8) ? 4 : (Co <= 16) ? 2 : 1;
     if (F == 1) return 1;

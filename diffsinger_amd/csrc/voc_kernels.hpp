@@ -57,34 +57,16 @@ struct VocConvParams {
     int act;
 };
 
+// B-operand functor of GemmPipe: chunk kc = ci8 * KT + tap of the staged slab, as a RUNNING pointer.  GemmPipe asks for the chunks strictly in
+// order, one call per chunk (start_b, then every step): tap + 1, wrap to the next 8-channel group, freeze on the last chunk (the prefetch
+// behind it must stay inside the slab) - a handful of selects.  (Rounds 1-2 recomputed the map per chunk: a chain of uniform branches, one per
+// supported kernel size, and a constant-divisor division in front of EVERY chunk - ~85 scalar / vector instructions between two groups of
+// 4 NB MFMAs with the matrix pipe idle; -4.5 % on the whole generator forward, profiles/r05_fm_conv_inc_ab.jsonl.)
 template <int LD>
-struct VocTapB {            // B-operand functor of GemmPipe: chunk kc = ci8 * KT + tap of the staged slab
-    const float* base;      // slab + 4 h LD + halo + this wave's first sample + j - pad
-    int KT, dil, n;
-    __device__ __forceinline__ const float* operator()(int it, int u) const {
-        int kc = 6 * it + u;
-        kc = (kc < n) ? kc : n - 1;
-        int g;                                  // constant divisors for the kernel sizes of the shipped configs
-        if (KT == 1) g = kc;
-        else if (KT == 3) g = kc / 3;
-        else if (KT == 7) g = kc / 7;
-        else if (KT == 11) g = kc / 11;
-        else g = kc / KT;
-        const int tap = kc - g * KT;
-        return base + g * (8 * LD) + tap * dil;
-    }
-};
-
-// The same map as a RUNNING pointer (opt-in DSV_CONV_INC=1, k_voc_conv_inc; not yet run on hardware).  GemmPipe asks for the chunks strictly in
-// order, one call per chunk (start_b, then every step).  VocTapB pays a chain of uniform branches (one per supported kernel size) and a
-// constant-divisor division in front of EVERY chunk: ~85 scalar / vector instructions between two groups of 4 NB MFMAs in the disassembly of
-// round 2, with the matrix pipe idle behind the last MFMA of the chunk (only 256-1024 cycles of work per chunk here).  The running form is a
-// handful of selects: tap + 1, wrap to the next 8-channel group, freeze on the last chunk (the prefetch behind it must stay inside the slab).
-template <int LD>
-struct VocTapBInc {
-    const float* cur;       // the chunk handed out next
+struct VocTapB {
+    const float* cur;       // the chunk handed out next (base = slab + 4 h LD + halo + this wave's first sample + j - pad)
     int KT, dil, left, tap; // left: chunks that may still be advanced past
-    __device__ __forceinline__ VocTapBInc(const float* base, int KT_, int dil_, int n) : cur(base), KT(KT_), dil(dil_), left(n - 1), tap(0) {}
+    __device__ __forceinline__ VocTapB(const float* base, int KT_, int dil_, int n) : cur(base), KT(KT_), dil(dil_), left(n - 1), tap(0) {}
     __device__ __forceinline__ const float* operator()(int, int) {
         const float* r = cur;
         const bool adv = left > 0, wrap = (tap + 1 == KT);
@@ -101,19 +83,112 @@ __device__ __forceinline__ float voc_lrelu(float v, float slope) { return (v > 0
 // Workgroup = WR = 4 / WT row blocks of 32 x (WT * NB * 32) samples of one utterance.  Wave w: row block (w % WR), time part (w / WR).
 template <int NB, int WT, int HALO = kVocHalo>
 __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p) {
-#define VOC_TAPB VocTapB
-#define VOC_GEMM gemm_k
-#include "voc_conv_body.inc"
-#undef VOC_GEMM
-#undef VOC_TAPB
-}
-template <int NB, int WT, int HALO = kVocHalo>
-__global__ __launch_bounds__(kThreads, 2) void k_voc_conv_inc(const VocConvParams p) {
-#define VOC_TAPB VocTapBInc
-#define VOC_GEMM gemm_k_blocks
-#include "voc_conv_body.inc"
-#undef VOC_GEMM
-#undef VOC_TAPB
+    constexpr int LD = voc_ld<NB, WT, HALO>(), SPAN = voc_span<NB, WT>(), SLAB = voc_slab<NB, WT, HALO>(), WR = 4 / WT;
+    constexpr int NCOL4 = LD / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [SLAB][LD]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w % WR, wt = w / WR;
+    const int t0 = blockIdx.x * SPAN, b = blockIdx.y;
+    const int rb = blockIdx.z * WR + wr;                             // this wave's 32-row block
+    const int nrb = (p.rows + 31) / 32;
+    const int rbc = (rb < nrb) ? rb : nrb - 1;                       // waves past the last block walk valid memory and store nothing
+    const int ci8 = (p.Ci + 7) / 8;
+    const int nchunk_total = ci8 * p.KT;
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+    const float* inb = p.in + (size_t)b * p.Ci * p.LSi;
+    const float slope = p.pre_slope;
+    for (int c0 = 0; c0 < p.Ci; c0 += SLAB) {
+        const int nc = min(SLAB, p.Ci - c0);
+        const int nc8 = (nc + 7) / 8 * 8;                            // rows [nc, nc8) are staged as zeros (their weights are zero too)
+        // stage channels [c0, c0 + nc) x samples [t0 - halo, t0 + SPAN + halo), zero outside [0, LSi), leaky_relu applied here
+        for (int idx = tid; idx < nc8 * NCOL4; idx += kThreads) {
+            const int row = idx / NCOL4, g = idx - row * NCOL4;
+            const int t = t0 - HALO + 4 * g;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nc && t >= 0 && t < p.LSi) {
+                v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + row) * p.LSi + t);
+                v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+            }
+            *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
+        }
+        __syncthreads();
+        const int nch = (nc8 / 8) * p.KT;
+        const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
+        VocTapB<LD> bof(smem + 4 * h * LD + HALO + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch);
+        gemm_k_blocks<1, NB, LD, 64>(acc, ap, lane, nch, bof);
+        __syncthreads();
+    }
+    if (rb >= nrb) return;
+    const int U = p.U, Co = p.rows / U;
+    const int q0 = t0 + wt * (32 * NB) + j;                          // input-rate sample index of frame block 0
+    if ((U & 3) == 0) {
+        // rows 8 rg + 4 h + (0..3) of this lane are 4 consecutive phases of ONE output channel: 16-byte accesses
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int q = q0 + 32 * nb;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = rb * 32 + 8 * rg + 4 * h;
+                const int co = row / U, ph = row - co * U;
+                const int n = q * U + ph;
+                if (row >= p.rows || n >= p.LSo) continue;
+                const size_t o = ((size_t)b * Co + co) * p.LSo + n;
+                const float bv = p.bias ? p.bias[co] : 0.f;
+                float4 v = get4(acc[0][nb], rg);
+                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                if (p.res) { const float4 r4 = *reinterpret_cast<const float4*>(p.res + o); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+                if (p.sum_in) { const float4 s4 = *reinterpret_cast<const float4*>(p.sum_in + o); v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w; }
+                if (p.divide != 1.f) { v.x = v.x / p.divide; v.y = v.y / p.divide; v.z = v.z / p.divide; v.w = v.w / p.divide; }
+                if (p.act == VOC_ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+                if (n + 0 >= p.Lo) v.x = 0.f;
+                if (n + 1 >= p.Lo) v.y = 0.f;
+                if (n + 2 >= p.Lo) v.z = 0.f;
+                if (n + 3 >= p.Lo) v.w = 0.f;
+                *reinterpret_cast<float4*>(p.out + o) = v;
+            }
+        }
+        return;
+    }
+    // general phase count (1: plain convolution, lanes j write consecutive samples; 2: two channels x two phases per register quad)
+    float bv[16];
+    int cov[16], phv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rb * 32 + frag_row(r, h);
+        const int rc = (row < p.rows) ? row : 0;
+        cov[r] = rc / U;
+        phv[r] = rc - cov[r] * U;
+        bv[r] = p.bias ? p.bias[cov[r]] : 0.f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int q = q0 + 32 * nb;
+        float rv[16], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                               // all the reads first
+            const int n = q * U + phv[r];
+            const bool ok = (rb * 32 + frag_row(r, h) < p.rows) && n < p.LSo;
+            const size_t o = ((size_t)b * Co + cov[r]) * p.LSo + (ok ? n : 0);
+            rv[r] = (p.res && ok) ? p.res[o] : 0.f;
+            sv[r] = (p.sum_in && ok) ? p.sum_in[o] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = q * U + phv[r];
+            const bool ok = (rb * 32 + frag_row(r, h) < p.rows) && n < p.LSo;
+            float v = acc[0][nb][r] + bv[r];
+            if (p.res) v += rv[r];
+            if (p.sum_in) v = sv[r] + v;
+            if (p.divide != 1.f) v = v / p.divide;
+            if (p.act == VOC_ACT_TANH) v = tanhf(v);
+            if (ok) p.out[((size_t)b * Co + cov[r]) * p.LSo + n] = (n < p.Lo) ? v : 0.f;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -63,6 +63,7 @@ def _bind(lib):
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.dsf_stack_workspace_floats.argtypes = [i32, i32, i32, i32]
     lib.dsf_stack_workspace_floats.restype = i64
+    lib.dsf_set_stack_mode.argtypes = [i32]
     lib.dsf_stack_offsets.argtypes = [i32, i32, i32, i32, C.POINTER(i64), i32]
     lib.dsf_stack_forward.argtypes = [vp, vp, vp, C.POINTER(DsfStackWeights), i32, i32, i32, vp, vp, vp]
     lib.dsf_stack_backward.argtypes = [vp, vp, C.POINTER(DsfStackWeights), i32, i32, i32, vp, vp, C.POINTER(DsfStackGrads), vp, vp]
@@ -72,6 +73,14 @@ def _bind(lib):
     lib.dsf_wgrad_probe.argtypes = [i32]
     lib.dsf_wgrad_probe_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib._stack_bound = True
+
+
+def set_stack_mode(mode: int):
+    """How the forward of the fused stack is launched (include/dsf.h dsf_set_stack_mode): 1 automatic, 0 one launch per layer, 2 the persistent
+    kernel wherever an utterance fits the grid."""
+    lib = _lib.load()
+    _bind(lib)
+    _lib.check(lib.dsf_set_stack_mode(int(mode)), 'dsf_set_stack_mode')
 
 
 def _weights_struct(ws: List[torch.Tensor], L: int, dils: List[int]):

@@ -170,9 +170,8 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
  * "concurrently" are serialised (each loop fills the chip anyway), never starved into the timeout.  Two PROCESSES sharing one GPU
  * cannot see each other: use mode 0 there (one process per device, as the reference's DDP runner does, is always safe).
  * dsd_loop_launches: k_loop launches per sampling call for the prepared batch (chunks of whole utterances; 0 = not on that path).
- * Env DSD_LOOP_FM=1 at dsd_create selects the frame-major form of the persistent kernel (csrc/dsd_loop_fm.hpp: same results bit for
- * bit, ~1 % faster; opt-in until the whole GPU suite has run with it); DSD_LAT_BF=1 the branch-free K-half convolution of the G = 8
- * latency kernels (same results bit for bit, 39.4 -> 32.3 ms per 1 x 512 K = 100 call; opt-in for the same reason). */
+ * Environment: DSD_LOOP=<mode> at dsd_create is the same choice as dsd_set_loop_mode for a host that cannot be changed; DSD_SPLIT=1 turns the
+ * split-precision experiment on (below).  There are no other switches: one kernel per job. */
 int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
 int dsd_loop_launches(dsd_handle* h);
 int dsd_set_lat_split(dsd_handle* h, int32_t g);

@@ -108,14 +108,12 @@ int dsf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, doub
  *             step embedding, :67) -> skip [B][256][TS] = sum_l skip_l (the tensor :126 divides by sqrt(L)).  One conditioner-projection
  *             launch for all layers + the layers as ONE persistent launch per chunk of whole utterances (the tile ownership and
  *             neighbour exchange of the inference loop, csrc/train_loop.hpp) when an utterance fits one workgroup per CU and the chunks
- *             fill the chip, else the inference layer kernel per layer (DSD_TRAIN_PERSIST=0 forces that form; the two are bit-identical);
+ *             fill the chip, else the inference layer kernel per layer (dsf_set_stack_mode picks; the two are bit-identical);
  *             either saves y = x + step and the gate pre-activation of every layer into `save_ws` for the backward pass.  A neighbour
  *             wait that hits its (seconds-long) bound poisons `skip` with NaN instead of hanging.
  *   backward  dskip [B][256][TS] -> dx0, dstep [B][L][256], every weight / bias gradient of the stack (torch layouts, OVERWRITTEN),
  *             per layer: output-projection data gradient + gate derivative, transposed dilated conv + residual path, and ONE launch for
  *             the layer's three weight gradients (contraction over frames, split-K partials reduced in a fixed order: deterministic).
- *             DSD_TRAIN_PERSIST_BWD=1 runs the data-gradient chain as one persistent launch per chunk of whole utterances instead
- *             (bit-identical, measured equal, more workspace: dsf_stack_workspace_floats reads the same switch).
  *             da_all: NULL, or [B][L*512][TS] to keep every layer's gradient wrt the gate pre-activation (rows [512 l, 512 l + 512) of an
  *             utterance) - the operand of the conditioner gradient dcond = sum_l Wc_l^T da_l, one dsf_conv1d over 512 L input channels.
  * The weight tables are HOST arrays of L device pointers in torch layouts: dilated_conv [512][256][3], conditioner / output projection
@@ -135,6 +133,10 @@ typedef struct dsf_stack_grads {
     float* dstep;                 /* [B][L][256] */
 } dsf_stack_grads;
 int64_t dsf_stack_workspace_floats(int32_t B, int32_t T, int32_t L, int32_t which);
+/* How dsf_stack_forward launches the layers (process-wide): 1 automatic (default: one persistent launch per chunk of whole utterances where
+ * that fills the chip, else one launch per layer), 0 per-layer launches always (the A/B switch of the measurement), 2 persistent wherever an
+ * utterance fits the co-resident grid (tests of the chunked form).  The workspace sizes do not depend on it. */
+int dsf_set_stack_mode(int32_t mode);
 int dsf_stack_offsets(int32_t B, int32_t T, int32_t L, int32_t which, int64_t* out, int32_t n);
 int dsf_stack_forward(const float* x0, const float* cond, const float* step, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L,
                       float* save_ws, float* skip_out, void* stream);

@@ -54,7 +54,7 @@ int dsv_conv1d(const float* in, const float* wpacked, const float* bias, float* 
 /* The same convolution (up = 1, 'same' padding pad = (K-1) * dil / 2, K odd) for the NARROW layers, Co <= 16 - the 16- and 8-channel
  * resblocks and conv_post of the shipped generator: F output samples are folded into the 32 MFMA rows so that no row multiplies
  * zeros.  dsv_fold_factor returns the F the library wants for such a layer (4: Co <= 8, 2: Co <= 16, 1: use dsv_conv1d; also 1
- * after dsv_set_fold(0) or with DSV_FOLD=0 in the environment - the A/B switch of the measurement).  The caller packs, with
+ * after dsv_set_fold(0) - the A/B switch of the measurement).  The caller packs, with
  * dsv_pack_weight(rows = Co * F, Ci, K + F - 1), the F shifted copies of the filter
  *     W'[co * F + e][ci][s] = w[co][ci][s - e]   (0 <= s - e < K, else 0)
  * and the kernel evaluates, with pos(c) = (c / dil) * F * dil + c % dil,

@@ -63,11 +63,9 @@ def test_one_layer_against_the_oracle_layer_every_split(preset, layer):
 @pytest.mark.parametrize('G', [2, 4, 8])
 @pytest.mark.parametrize('name,tol', [('denoise_lj', 1e-5), ('denoise_opencpop', 1e-5), ('ddpm_lj_k100', 1e-4), ('shallow_opencpop_k60', 1e-4),
                                       ('plms_opencpop_i40', 1e-4)])
-def test_golden_cases_with_every_split(name, tol, G, monkeypatch):
-    monkeypatch.setenv('DSD_LOOP', '3')
-    monkeypatch.setenv('DSD_LAT_G', str(G))
+def test_golden_cases_with_every_split(name, tol, G):
     g = H.load_golden(name)
-    out = run_hip_case(name)
+    out = run_hip_case(name, loop_mode=3, lat_split=G)
     scale = float(np.abs(g['out']).max()) if name.startswith('plms') else 1.0        # PLMS: no clamp, graded relative
     err = float(np.abs(out - g['out']).max()) / scale
     print(f'{name} G={G}: max-abs error vs the reference fixture {err:.3e} (/ {scale:.3g})')

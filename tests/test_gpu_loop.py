@@ -42,9 +42,10 @@ def test_persistent_loop_equals_per_layer_kernels(name):
     assert float(np.abs(a - g).max()) / scale <= 1e-4
 
 
-@pytest.mark.parametrize('B,T,K', [(8, 1024, 12), (5, 2048, 6), (3, 1000, 8)])
+@pytest.mark.parametrize('B,T,K', [(8, 1024, 12), (5, 2048, 6), (3, 1000, 8), (2, 33, 5), (1, 5, 3)])
 def test_persistent_loop_full_width(B, T, K):
-    """Bench-size batches: 256 workgroups at once (8 x 1024), chunks of whole utterances (5 x 2048 -> 4 + 1), ragged T."""
+    """Bench-size batches: 256 workgroups at once (8 x 1024), chunks of whole utterances (5 x 2048 -> 4 + 1), ragged T, a two-tile utterance
+    with a one-frame tail, a one-tile utterance."""
     import diffsinger_amd
     from diffsinger_amd import hparams
     from diffsinger_amd.synth import presets

@@ -156,8 +156,8 @@ def test_stack_forward_and_backward(B, T, L, cycle):
 
 @pytest.mark.parametrize('B,T,L,cycle,dcond', [(9, 1000, 3, 4, False), (2, 50, 3, 4, True), (3, 96, 20, 4, False), (1, 5, 1, 1, True), (17, 500, 2, 2, True),
                                                (1, 200, 4, 1, False)])
-def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond, monkeypatch):
-    """csrc/train_loop.hpp (forward and data-gradient chain as ONE launch each per chunk of whole utterances, neighbour exchange through flags)
+def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond):
+    """csrc/train_loop.hpp (the forward as ONE launch per chunk of whole utterances, neighbour exchange through flags)
     against the per-layer launches: the skip sum, everything saved for the backward and every gradient are the same BITS; (9, 1000) and
     (17, 500) take two chunks on a 256-CU part; dcond selects the caller-kept da_all layout of the backward."""
     from diffsinger_amd import _lib, fs2, train_fused
@@ -178,8 +178,7 @@ def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond, monk
     oY, oA, Yl, Al = off[6], off[7], off[12], off[13]
     got = {}
     for mode in ('0', '2'):
-        monkeypatch.setenv('DSD_TRAIN_PERSIST', mode)
-        monkeypatch.setenv('DSD_TRAIN_PERSIST_BWD', '1' if mode == '2' else '0')
+        train_fused.set_stack_mode(int(mode))
         xin, cin, sin = x0.clone().requires_grad_(True), cond.clone().requires_grad_(dcond), step.clone().requires_grad_(True)
         wd = [t.clone().requires_grad_(True) for t in wsrc]
         skip = train_fused._ResidualStack.apply(xin, cin, sin, T, dils, {}, *wd)
@@ -191,6 +190,7 @@ def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond, monk
             res.append(cin.grad.clone())
         got[mode] = res
         torch.cuda.synchronize()
+    train_fused.set_stack_mode(1)
     assert all(bool(torch.isfinite(t).all()) for t in got['2'])
     for i, (a, b) in enumerate(zip(got['0'], got['2'])):
         assert torch.equal(a, b), f'tensor {i} differs: {float((a - b).abs().max())}'

@@ -58,31 +58,20 @@ def test_workspace_layout_and_argument_checks():
     assert lib.dsf_conv1d_wgrad2(None, None, None, None, None, 1, 256, 512, 3, 1, 8, None) != 0
 
 
-def test_persistent_backward_workspace_follows_its_switch(monkeypatch):
-    """DSD_TRAIN_PERSIST_BWD=1 (csrc/train_loop.hpp k_trb_loop) keeps da / g / dx of EVERY layer + flags + a halo buffer: the workspace query reads
-    the same switch as the backward entry point; shapes the persistent form does not take (an utterance longer than the co-resident grid) and
-    DSD_TRAIN_PERSIST=0 leave the size alone."""
+def test_stack_mode_switch_and_workspace_sizes():
+    """dsf_set_stack_mode (include/dsf.h) replaces the environment switches of round 2: it validates its argument, and the workspace sizes do
+    not depend on it (a size query and the backward call could disagree when the environment changed in between)."""
     lib = _lib.load()
     train_fused._bind(lib)
     B, T, L = 8, 1024, 20
-    act = B * 256 * 1024
-    monkeypatch.delenv('DSD_TRAIN_PERSIST', raising=False)
-    monkeypatch.delenv('DSD_TRAIN_PERSIST_BWD', raising=False)
-    base = lib.dsf_stack_workspace_floats(B, T, L, 1)
-    monkeypatch.setenv('DSD_TRAIN_PERSIST_BWD', '1')
-    big = lib.dsf_stack_workspace_floats(B, T, L, 1)
-    ntiles = B * 1024 // 32
-    extra = L * 2 * act + L * act + (L - 1) * act + ntiles * 16384
-    assert extra <= big - base <= extra + 4096
-    assert lib.dsf_stack_workspace_floats(B, T, L, 0) == lib.dsf_stack_workspace_floats(B, T, L, 0)      # the forward's save buffer does not depend on it
-    monkeypatch.setenv('DSD_TRAIN_PERSIST', '0')
-    assert lib.dsf_stack_workspace_floats(B, T, L, 1) == base
-    monkeypatch.delenv('DSD_TRAIN_PERSIST')
-    assert lib.dsf_stack_workspace_floats(1, 9000, L, 1) == lib.dsf_stack_workspace_floats(1, 9000, L, 1)
-    monkeypatch.delenv('DSD_TRAIN_PERSIST_BWD')
-    long_base = lib.dsf_stack_workspace_floats(1, 9000, L, 1)
-    monkeypatch.setenv('DSD_TRAIN_PERSIST_BWD', '1')
-    assert lib.dsf_stack_workspace_floats(1, 9000, L, 1) == long_base                                      # 282 tiles > one workgroup per CU
+    sizes = []
+    for mode in (1, 0, 2, 1):
+        train_fused.set_stack_mode(mode)
+        sizes.append((lib.dsf_stack_workspace_floats(B, T, L, 0), lib.dsf_stack_workspace_floats(B, T, L, 1)))
+    assert len(set(sizes)) == 1 and sizes[0][0] > 0 and sizes[0][1] > 0
+    with pytest.raises(RuntimeError):
+        train_fused.set_stack_mode(3)
+    train_fused.set_stack_mode(1)
 
 
 def test_fused_path_refuses_cpu_tensors():
