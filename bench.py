@@ -584,6 +584,45 @@ def self_launch(args):
 
 
 CFG5_UTTS, CFG5_T, CFG5_MICRO = 512, 2048, 16         # BASELINE configs[4]: 512 synthetic utterances x T=2048, K=100
+BASELINE_METRIC = 'mel-frames/sec (whole node) at K=100 DDPM, 80-bin, T=1024'      # BASELINE.json `metric`; the workload of a line is config.workload
+
+
+def cfg5_workload(gd, rank, world, device, *, n_utts=CFG5_UTTS, T=CFG5_T, micro=CFG5_MICRO, K=K_STEPS, M=80, H=256, group=None):
+    """BASELINE configs[4] exactly as the N-GPU run executes it: the SAME n_utts utterances x T at every N (strong scaling); rank r takes
+    utterances r::W (tasks/tts/tts.py:85-88), samples them in micro-batches with zero communication, ONE gather collates the mels on rank 0
+    (the reference collates through the filesystem, tasks/tts/fs2.py:414-431).  Returns (step, local_only, mine, first_cond, x_T, noise):
+    step() = the timed unit (shard -> micro-batches -> gather -> [n_utts, T, M] on rank 0, None elsewhere); local_only() = this rank's shard
+    without the gather (the same-workload N = 1 rate per GPU).  `gd` needs only `.inference(cond, **kw)` and `.mel_bins`
+    (tests/test_bench_cfg5_gloo.py drives this function at world 2 over gloo with a stand-in sampler)."""
+    from diffsinger_amd.dist import sharded_inference, shard_indices
+    mine = shard_indices(n_utts, rank, world)
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    gens = {i: torch.Generator(device=device).manual_seed(50_000 + i) for i in mine}
+    utt_conds = [None] * n_utts
+    for i in mine:                                       # utterance i's conditioner depends on i only, not on the sharding
+        utt_conds[i] = torch.randn(T, H, device=device, generator=gens[i]).t()
+    x_T = torch.randn(micro, 1, M, T, device=device, generator=g)
+    noise = torch.randn(K, micro, 1, M, T, device=device, generator=g)          # 1.05 GB at the full size, shared by the micro-batches
+    kw = dict(x_T=lambda idx: x_T[:len(idx)], noise=lambda idx: noise[:, :len(idx)].contiguous() if len(idx) < micro else noise,
+              K_step=K, pndm_speedup=0)
+
+    def step():
+        out = sharded_inference(gd, utt_conds, micro_batch=micro, dst=0, group=group, **kw)
+        if rank == 0:
+            assert out is not None and tuple(out.shape) == (n_utts, T, M), None if out is None else tuple(out.shape)
+        else:
+            assert out is None or world == 1
+        return out
+
+    def local_only():
+        outs = []
+        for s0 in range(0, len(mine), micro):
+            idx = mine[s0:s0 + micro]
+            outs.append(gd.inference(torch.stack([utt_conds[i] for i in idx]), **{k: (v(idx) if callable(v) else v) for k, v in kw.items()}))
+        return outs
+
+    first_cond = torch.stack([utt_conds[i] for i in mine[:micro]]) if mine else None
+    return step, local_only, mine, first_cond, x_T, noise
 
 
 def _time_steps(step, args, world, device, dist):
@@ -629,7 +668,6 @@ def main_path(args):
     cfg = args.config or (5 if world > 1 else 2)
 
     gd, pre = build_model(device)
-    from diffsinger_amd.dist import sharded_inference, shard_indices
     K, M = K_STEPS, 80
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     if cfg == 2:
@@ -648,23 +686,9 @@ def main_path(args):
             return gd.inference(conds[count[0] & 1], x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
         cond = conds[0]
     else:
-        # BASELINE configs[4]: the SAME 512 utterances x T=2048 at every N (strong scaling): rank r takes utterances r::W
-        # (tasks/tts/tts.py:85-88), runs them in micro-batches of 16 with zero communication, ONE RCCL gather collates the mels on rank 0
-        # (the reference collates through the filesystem, tasks/tts/fs2.py:414-431)
         B, T = CFG5_MICRO, CFG5_T
-        mine = shard_indices(CFG5_UTTS, rank, world)
-        gens = {i: torch.Generator(device=device).manual_seed(50_000 + i) for i in mine}
-        utt_conds = [None] * CFG5_UTTS
-        for i in mine:                                   # utterance i's conditioner depends on i only, not on the sharding
-            utt_conds[i] = torch.randn(T, 256, device=device, generator=gens[i]).t()
-        x_T = torch.randn(B, 1, M, T, device=device, generator=g)
-        noise = torch.randn(K, B, 1, M, T, device=device, generator=g)          # 1.05 GB, shared by the micro-batches
+        step, local_only, mine, cond, x_T, noise = cfg5_workload(gd, rank, world, device)
         frames_per_step = CFG5_UTTS * T
-
-        def step():
-            return sharded_inference(gd, utt_conds, micro_batch=B, dst=0, x_T=lambda idx: x_T[:len(idx)],
-                                     noise=lambda idx: noise[:, :len(idx)].contiguous() if len(idx) < B else noise, K_step=K, pndm_speedup=0)
-        cond = torch.stack([utt_conds[i] for i in mine[:B]])
     eng = gd._engine(cond)
     eng.set_layer_tile(args.tile)
     if args.split:
@@ -674,6 +698,20 @@ def main_path(args):
     if rank == 0:
         assert out is not None and bool(torch.isfinite(out).all()), 'non-finite mel'
         assert out.shape == ((CFG5_UTTS, T, M) if cfg == 5 else (B, T, M)), out.shape
+    scale_ref = None
+    if cfg == 5 and world > 1:
+        # the same-workload N = 1 reference for whoever divides the N > 1 value: rank 0 samples ITS shard once more, alone and without the
+        # gather, while the other ranks wait - the per-GPU rate of configs[4]; N x this is the ideal of the line above it
+        if rank == 0:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            local_only()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            scale_ref = {'value': len(mine) * T / dt, 'unit': 'mel-frames/s', 'n_gpus': 1,
+                         'what': f"rank 0's shard ({len(mine)} of {CFG5_UTTS} utterances x T={T}, micro-batches of {B}) sampled alone after the timed "
+                                 f'region, no gather: the per-GPU rate of BASELINE configs[4]; ideal at N={world} = {world} x this'}
+        dist.barrier()
 
     # roofline of the dominant kernel, measured live with HIP events on the launch stream (torch's current stream IS the
     # stream every dsd_* call is enqueued on).  Persistent path: the kernel is k_loop, ONE launch = the whole 100-step loop
@@ -696,19 +734,23 @@ def main_path(args):
             ev1.synchronize()
             assert eng.loop_timeouts() == 0, 'persistent loop: an inter-workgroup wait timed out'
             launches = eng.loop_launches()
-            ms = ev0.elapsed_time(ev1) / reps / launches
-            frames_l = frames // launches
-            flop = frames_l * K * F_EVAL_EXEC
-            achieved = flop / (ms * 1e-3) / 1e12
+            ms_call = ev0.elapsed_time(ev1) / reps                           # the whole call: every k_loop launch of the batch
+            ms = ms_call / launches
+            # whole-call FLOPs over whole-call time (chunks of whole utterances: the last launch of a batch may cover fewer frames than the
+            # others - a per-launch figure from frames // launches would mislabel an average); per-launch numbers are AVERAGES
+            flop = frames * K * F_EVAL_EXEC / launches
+            achieved = frames * K * F_EVAL_EXEC / (ms_call * 1e-3) / 1e12
+            frames_l = frames / launches
             kname = 'k_loop<1>'
-            alg_bytes = K * (frames_l * (20 * 2048 + 2 * 320 + 320) + L_LAYERS * 2 * 1024 * 1024 + frames_l // 32 * L_LAYERS * 2 * 16384)
+            alg_bytes = int(K * (frames * (20 * 2048 + 2 * 320 + 320) + launches * L_LAYERS * 2 * 1024 * 1024 + frames // 32 * L_LAYERS * 2 * 16384) / launches)
             note = (f'one launch = the whole K=100 reverse loop (100 x (20 residual layers + head + sampler update + next input '
-                    f'projection)) for {frames_l} frames ({launches} launch(es) per batch of {B} x {T}); achieved counts executed fp32 FLOPs '
-                    '(21 053 440 / frame / evaluation: conditioner projection hoisted, dead residual half of the last layer dropped); the figure '
-                    'includes two device copies of the spec tensor and a flag memset around the launch; *_ref_accounting credits the reference '
-                    '26 427 392 FLOP / frame / evaluation')
-            ref_acc = frames_l * K * F_EVAL_REF / (ms * 1e-3) / 1e12
-            frames_k = frames_l
+                    f'projection)) for a chunk of whole utterances; this batch of {B} x {T} = {launches} launch(es) of on average {frames_l:.0f} frames; '
+                    'achieved = executed fp32 FLOPs of the WHOLE call / its duration (HIP events on the launch stream), per-launch fields are '
+                    'averages; executed = 21 053 440 FLOP / frame / evaluation (conditioner projection hoisted, dead residual half of the last layer '
+                    'dropped); the duration includes two device copies of the spec tensor, a flag memset and the one-thread timeout latch around '
+                    'the launches; *_ref_accounting credits the reference 26 427 392 FLOP / frame / evaluation')
+            ref_acc = frames * K * F_EVAL_REF / (ms_call * 1e-3) / 1e12
+            frames_k = int(frames_l)
         else:
             ms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
             flop = frames * F_LAYER_EXEC
@@ -765,13 +807,15 @@ def main_path(args):
                      'sharding': f'utterances r::W, RCCL gather of mels to rank 0 (backend {dist.get_backend()}, world {dist.get_world_size()})'
                                  if world > 1 else 'single GPU'})
         res = {
-            'metric': f'mel-frames/sec (whole node) at K=100 DDPM, 80-bin, T={T}', 'value': value, 'unit': 'mel-frames/s',
+            'metric': BASELINE_METRIC, 'value': value, 'unit': 'mel-frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak' if cfg == 2 else 'strong', 'vs_baseline': None,
             'dtype': 'f32 as 3 exact bf16 planes, 6 plane products per product, f32 accumulate (EXPERIMENT --split)' if args.split else 'f32',
             'data': 'synthetic', 'config': conf, 'roofline': roof,
             'model_tflops_ref_accounting': frames_per_step * K * F_EVAL_REF * args.steps / el / 1e12,
         }
+        if scale_ref is not None:
+            res['scale_ref_n1'] = scale_ref
         try:
             res['parity'] = parity_check(device)
         except Exception as e:          # fixtures missing etc. - report, do not hide
