@@ -1,0 +1,36 @@
+# GPU box: the evidence round of the CURRENT binary - whole GPU suite + smoke, headline bench (+ CPU baseline), k_loop timeline, rocprofv3 kernel
+# stats of the bench command, the three PMC passes over k_loop (separate --pmc runs, kernel-trace only) -> loop_pmc.json, machine ceilings
+# (bare fp32 MFMA stream, HBM read / copy), small-batch shape sweep, row benches (vocoder / fs2 / train), all-config throughput.
+#   usage: bash tools/gpu_evidence.sh <tag> [nopytest]
+set -x
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; TAG=${1:-r06}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+git_rev=$(cat .git_rev 2>/dev/null || echo unknown)
+if [ "$2" != "nopytest" ]; then
+( time timeout 1500 python -m pytest tests -m gpu -q -rf 2>&1 | tail -40 ) > $O/pytest_gpu.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
+fi
+timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 200 python tools/loop_timeline.py $O/loop_timeline.json > $O/loop_timeline.txt 2>&1
+[ -x tools/mfma_probe4.bin ] && timeout 120 tools/mfma_probe4.bin > $O/mfma_probe4.txt 2>&1
+[ -x tools/hbm_probe.bin ] && timeout 120 tools/hbm_probe.bin > $O/hbm_probe.txt 2>&1
+timeout 300 python tools/shape_sweep.py 3 1x512,1x1550,4x777,8x1024,16x2048 > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
+for row in vocoder fs2 train; do
+timeout 300 python bench.py --row $row --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_row_$row.json 2> $O/bench_row_$row.err
+done
+timeout 400 python tools/bench_configs.py 3 > $O/configs_throughput.jsonl 2> $O/configs_throughput.err
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $O/prof/*.db $O/prof/*/*.db 2>/dev/null | head -1) > $O/bench_n1_kernel_stats.txt 2>> $O/prof.log
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/pmc/fetch -o fetch -- python $R/tools/profile_loop.py 3 > $O/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc/write -o write -- python $R/tools/profile_loop.py 3 > $O/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $O/pmc/sq -o sq -- python $R/tools/profile_loop.py 3 > $O/pmc_sq.log 2>&1
+python $R/tools/pmc_summary.py $O/pmc 'k_loop<1>' $O/loop_pmc.txt $O/loop_pmc.json frames=8192 'kernel_tag=k_loop<1>' round=$TAG commit=$git_rev > $O/pmc_summary.log 2>&1
+rm -rf $O/prof
+find $O/pmc -name '*.db' -delete
+du -sh $O
+tail -15 $O/pytest_gpu.txt | cut -c1-220; tail -3 $O/smoke.txt; cut -c1-600 $O/bench_n1.json; cat $O/shape_sweep.jsonl | cut -c1-260; for row in vocoder fs2 train; do cut -c1-330 $O/bench_row_$row.json; echo; done
+cat $O/mfma_probe4.txt | tail -8; cat $O/hbm_probe.txt | tail -4; tail -5 $O/loop_pmc.txt
