@@ -239,7 +239,8 @@ def cpu_baseline_vocoder(budget_s: float = 20.0):
 def main_vocoder(args):
     """Row f2: `steps` forwards of the HIP HiFi-GAN generator over 8 x 1024 mel frames per GPU (replicas: the row has no exchange step)."""
     world, rank, device, dist = _row_setup()
-    from diffsinger_amd.vocoder import HifiGanGenerator, _HipOps, fold_weight, padded_samples
+    from diffsinger_amd.vocoder import HifiGanGenerator, _HipOps, fold_weight, padded_samples, set_chain_mode
+    set_chain_mode(None if args.chain == 'default' else args.chain)
     h = VOC_CONFIG
     m = HifiGanGenerator(h)
     m.remove_weight_norm()
@@ -548,6 +549,8 @@ def main():
     ap.add_argument('--config', type=int, choices=[2, 5], default=0,
                     help='BASELINE configuration of the headline run: 2 = configs[1] (8 x T=1024 per GPU; the default at --gpus 1), 5 = configs[4] '
                          '(512 utterances x T=2048 sharded across the GPUs, strong scaling; the default at --gpus > 1)')
+    ap.add_argument('--chain', choices=['default', 'off', 'stage', 'resblock', 'pair'], default='default',
+                    help='--row vocoder: how the ResBlock1 chains are launched (diffsinger_amd.vocoder.set_chain_mode); default = by channel count')
     ap.add_argument('--split', action='store_true', help='EXPERIMENT: residual layers as six bf16 plane products per fp32 product (fp32-class accuracy) '
                                                           'on the bf16 matrix pipe; per-layer kernel path; the JSON line says so in dtype / config')
     args = ap.parse_args()

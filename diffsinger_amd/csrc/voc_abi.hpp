@@ -1,6 +1,7 @@
 // voc_abi.hpp - host side of the HiFi-GAN / NSF-HiFi-GAN generator ops (C ABI in include/dsv.h); included at the end of dsd.hip so
 // the library stays one translation unit (shares the error string, the HIP_TRY macros and the operand-packing kernel).
 #include "voc_kernels.hpp"
+#include "voc_chain.hpp"
 
 #include "../../include/dsv.h"
 
@@ -124,6 +125,78 @@ extern "C" int dsv_conv1d_folded(const float* in, const float* wpacked, const fl
     else voc_fold_launch<2>(p, B, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fused ResBlock1 chains (voc_chain.hpp)
+// ------------------------------------------------------------------------------------------------------------
+template <int C, int F, int NB>
+static int voc_chain_geometry(const dsv_chain_conv* convs, int nres, int npairs, int* N_out, int* Hh_out) {
+    // halo = the receptive field of the longest chain; every convolution must cover N + 2 Hh samples
+    constexpr int NCOL = 128 * NB;
+    int hh = 0, cover = NCOL * F;
+    for (int r = 0; r < nres; ++r) {
+        int h = 0;
+        for (int i = 0; i < 2 * npairs; ++i) {
+            const dsv_chain_conv& c = convs[r * 2 * npairs + i];
+            const int pad = (c.K - 1) * c.dil / 2;
+            if (c.K < 1 || !(c.K & 1) || c.dil < 1 || pad > kVocHalo || F * c.dil > kChainSlack || ((i & 1) && c.dil != 1)) return -1;
+            h += pad;
+            cover = std::min(cover, (NCOL / c.dil) * F * c.dil);
+        }
+        hh = std::max(hh, h);
+    }
+    hh = (hh + 3) / 4 * 4;
+    const int n = (cover - 2 * hh) / 32 * 32;
+    if (n < 64) return -1;
+    *N_out = n; *Hh_out = hh;
+    return 0;
+}
+
+template <int C, int F, int NB>
+static int voc_chain_launch(VocChainParams& p, const dsv_chain_conv* convs, int B, hipStream_t s) {
+    if (voc_chain_geometry<C, F, NB>(convs, p.nres, p.npairs, &p.N, &p.Hh) != 0)
+        return fail(DSD_ERR_INVALID, "dsv_resblock_chain: the chain does not fit the staged tile (ask dsv_chain_supported first)");
+    constexpr int lds = chain_lds_bytes<C, F, NB>();
+    if (first_on_device(300 + C)) HIP_TRY(hipFuncSetAttribute((const void*)k_voc_chain<C, F, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const dim3 grid((unsigned)((p.LS + p.N - 1) / p.N), (unsigned)B);
+    hipLaunchKernelGGL((k_voc_chain<C, F, NB>), grid, dim3(kThreads), lds, s, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int32_t dsv_chain_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs) {
+    if (!convs || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs) return 0;
+    int n = 0, hh = 0, rc = -1;
+    if (C == 8) rc = voc_chain_geometry<8, 4, 2>(convs, nres, npairs, &n, &hh);
+    else if (C == 16) rc = voc_chain_geometry<16, 2, 3>(convs, nres, npairs, &n, &hh);
+    else if (C == 32) rc = voc_chain_geometry<32, 1, 4>(convs, nres, npairs, &n, &hh);
+    return rc == 0 ? n : 0;
+}
+
+extern "C" int32_t dsv_chain_fold(int32_t C) { return C == 8 ? 4 : C == 16 ? 2 : C == 32 ? 1 : 0; }
+
+extern "C" int dsv_resblock_chain(const float* in, const float* wpacked, const float* bias, float* out, const float* sum_in, int32_t B, int32_t C,
+                                  int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream) {
+    if (!in || !wpacked || !bias || !out || !convs) return fail(DSD_ERR_INVALID, "dsv_resblock_chain: null argument");
+    if (in == out) return fail(DSD_ERR_INVALID, "dsv_resblock_chain: in and out must be different buffers (workgroups read their neighbours' samples)");
+    if (B < 1 || B > 65535 || L < 1 || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs || divide == 0.f || !dsv_chain_fold(C))
+        return fail(DSD_ERR_INVALID, "dsv_resblock_chain: bad shape (B=%d C=%d L=%d nres=%d npairs=%d): 8, 16 or 32 channels, at most %d convolutions", B, C,
+                    L, nres, npairs, kChainMaxConvs);
+    VocChainParams p{};
+    p.in = in; p.out = out; p.sum_in = sum_in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias;
+    p.L = L; p.LS = voc_ls(L); p.nres = nres; p.npairs = npairs; p.slope = pre_slope; p.divide = divide;
+    const int F = dsv_chain_fold(C);
+    for (int i = 0; i < nres * npairs * 2; ++i) {
+        const dsv_chain_conv& c = convs[i];
+        if (c.w_offset < 0 || (c.w_offset % 256) || c.bias_offset < 0)
+            return fail(DSD_ERR_INVALID, "dsv_resblock_chain: convolution %d: weight offsets are multiples of 256 floats (whole chunks)", i);
+        p.conv[i].woff = (int)(c.w_offset / 4); p.conv[i].boff = c.bias_offset; p.conv[i].KT = c.K + F - 1; p.conv[i].dil = c.dil;
+        p.conv[i].pad = (c.K - 1) * c.dil / 2;
+    }
+    if (C == 8) return voc_chain_launch<8, 4, 2>(p, convs, B, (hipStream_t)stream);
+    if (C == 16) return voc_chain_launch<16, 2, 3>(p, convs, B, (hipStream_t)stream);
+    return voc_chain_launch<32, 1, 4>(p, convs, B, (hipStream_t)stream);
 }
 
 extern "C" int dsv_noise_conv(const float* har, const float* w, const float* bias, float* out, int32_t B, int32_t C, int32_t K, int32_t stride,

@@ -1,0 +1,285 @@
+// voc_chain.hpp - gfx950: whole ResBlock1 chains of the HiFi-GAN generator in ONE kernel, activations resident in LDS.
+//
+// What is computed, and where the reference computes it (paths relative to the reference root): for nres parallel resblocks r and npairs conv
+// pairs q per resblock (modules/hifigan/hifigan.py:54-61 inside :161-166),
+//     y = x
+//     for q:  xt = convs1[q](leaky_relu(y)) ; xt = convs2[q](leaky_relu(xt)) ; y = xt + y              ResBlock1.forward
+//     xs = y_0 ; xs = xs + y_1 ; ... ; out = (sum_in + xs) / divide                                   `xs += resblock(x)`, `x = xs / num_kernels`
+// k_voc_conv / k_voc_conv_fold run every convolution as its own launch: a stage of the shipped generator reads and writes its activation
+// ~40 times (round 2: 0.36 of the HBM roof on the narrow stages).  Here a workgroup owns N output samples of all C channels of one utterance
+// plus a halo of Hh samples per side (the receptive field of the chain), stages leaky_relu(x) once, and runs the convolutions back to back:
+//   * two LDS tiles [C][LD]: A = leaky_relu(y) (input of convs1), T = leaky_relu(xt) (input of convs2); the raw y lives in REGISTERS in the
+//     accumulator-fragment order of convs2 (always dilation 1), so the residual add is register arithmetic; the running sum over the parallel
+//     resblocks likewise.  Per stage the activation is read nres times and written once.
+//   * C * F == 32: the F-fold of k_voc_conv_fold for the narrow stages (row = co * F + e computes output sample pos(c) + e * dil of channel co,
+//     pos(c) = (c / dil) * F * dil + c % dil for column c; the A operand holds the F shifted copies of the filter, K + F - 1 taps) - F = 4 for
+//     8 channels, 2 for 16, 1 (no fold) for 32.  All 32 MFMA rows carry work.
+//   * values outside [0, L) are written to the tiles as ZERO (the convolutions' zero padding applies to every intermediate activation);
+//     columns whose samples fall outside the range a later convolution needs compute garbage that is never read for a needed sample: the
+//     host picks N so that N + 2 Hh <= the samples EVERY convolution of the chain covers (min over dilations of floor(NCOL / dil) * F * dil).
+// Arithmetic and summation order are those of the one-convolution kernels (chunk order ci8 * KT + tap, bias, + residual, sum_in + v, / divide):
+// results are BIT-IDENTICAL to the unfused path (tests/test_gpu_vocoder.py).
+#pragma once
+#include "voc_kernels.hpp"
+
+namespace dsd {
+
+constexpr int kChainMaxConvs = 18;         // 3 resblocks x 3 pairs x 2
+constexpr int kChainSlack = 32;            // zero / scratch columns on both sides of a tile row (>= the largest pad, kVocHalo, rounded to 32)
+
+struct VocChainConv {
+    int woff;               // float4 index of this convolution's packed weight [chunk = ci8 * KT + s][lane64] inside wp
+    int boff;               // float index of its bias [C] inside bias
+    int KT;                 // folded taps K + F - 1
+    int dil, pad;           // pad = (K - 1) * dil / 2
+};
+
+struct VocChainParams {
+    const float* in;        // [B][C][LS]
+    float* out;             // [B][C][LS]
+    const float* sum_in;    // [B][C][LS] or nullptr
+    const float4* wp;
+    const float* bias;
+    int L, LS;
+    int N, Hh;              // output samples per workgroup (multiple of 32), halo per side (multiple of 4)
+    int nres, npairs;
+    float slope, divide;
+    VocChainConv conv[kChainMaxConvs];      // [res][pair][2]
+};
+
+template <int F, int NB> constexpr int chain_wpos() { return 128 * NB * F; }                     // samples a dilation-1 convolution covers
+template <int F, int NB> constexpr int chain_ld() { return chain_wpos<F, NB>() + 2 * kChainSlack; }
+template <int C, int F, int NB> constexpr int chain_lds_bytes() { return (2 * C * chain_ld<F, NB>() + 256) * (int)sizeof(float); }
+
+// K loop of one convolution: A fragments stream from global / L2 (6 register stages), B from the LDS tile with a lane-specific offset per
+// column block (pos(c) is not linear in the column once dil > 1) and a RUNNING chunk pointer (tap + 1, wrap to the next 8-channel group).
+template <int NB, int LD>
+struct ChainPipe {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned aoff;
+    const float* cur;
+    int KT, dil, left, tap;
+    int boff[NB];
+    float4 a[6][1];
+    float b[2][4][NB];
+
+    __device__ __forceinline__ ChainPipe(const float4* abase_uniform, int lane, int n, const float* bbase, int KT_, int dil_, const int (&boff_)[NB])
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(abase_uniform), 0, 0x7ffffff0, 0x00020000)),
+          aoff((unsigned)lane * 16u), cur(bbase), KT(KT_), dil(dil_), left(n - 1), tap(0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) boff[nb] = boff_[nb];
+    }
+    __device__ __forceinline__ void lda(float4 (&dst)[1], int kc) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kc * (64 * 16), 0);
+        const f32x4 f = __builtin_bit_cast(f32x4, v);
+        dst[0] = make_float4(f.x, f.y, f.z, f.w);
+    }
+    __device__ __forceinline__ void ldb(float (&dst)[4][NB]) {
+        const float* bp = cur;
+        const bool adv = left > 0, wrap = (tap + 1 == KT);
+        const int step = wrap ? 8 * LD - (KT - 1) * dil : dil;
+        cur += adv ? step : 0;
+        tap = adv ? (wrap ? 0 : tap + 1) : tap;
+        left -= adv ? 1 : 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) dst[s][nb] = bp[s * LD + boff[nb]];
+    }
+    __device__ __forceinline__ void pattern() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - 1 - 2 * NB, 0);
+    }
+    __device__ __forceinline__ void start_a() {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) lda(a[i], i);
+        DSD_SB();
+    }
+    __device__ __forceinline__ void start_b() {
+        ldb(b[0]);
+        DSD_SB();
+    }
+    template <int I>
+    __device__ __forceinline__ void step(f32x16 (&acc)[1][NB], int it) {
+        lda(a[(I + 5) % 6], 6 * it + I + 5);
+        ldb(b[(I + 1) & 1]);
+        mma_chunk<1, NB>(acc, a[I % 6], b[I & 1]);
+        pattern();
+        DSD_SB();
+    }
+    // whole groups of six chunks as ONE basic block, the tail behind it (GemmPipe::run_blocks)
+    __device__ __forceinline__ void run_blocks(f32x16 (&acc)[1][NB], int end) {
+        int it = 0;
+        for (; 6 * it + 6 <= end; ++it) {
+            step<0>(acc, it); step<1>(acc, it); step<2>(acc, it); step<3>(acc, it); step<4>(acc, it); step<5>(acc, it);
+        }
+        const int kc = 6 * it;
+        if (kc >= end) return;
+        step<0>(acc, it);
+        if (kc + 1 >= end) return;
+        step<1>(acc, it);
+        if (kc + 2 >= end) return;
+        step<2>(acc, it);
+        if (kc + 3 >= end) return;
+        step<3>(acc, it);
+        if (kc + 4 >= end) return;
+        step<4>(acc, it);
+    }
+};
+
+// grid (ceil(LS / N), B); 4 waves, wave w owns the columns [32 NB w, 32 NB (w + 1)) of every convolution
+template <int C, int F, int NB>
+__global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024) ? 2 : 1) void k_voc_chain(const VocChainParams p) {
+    static_assert(C * F == 32 && (C % 8) == 0, "one 32-row MFMA block: 8 channels x 4, 16 x 2 or 32 x 1");
+    constexpr int LD = chain_ld<F, NB>(), SLK = kChainSlack, NCOL4 = LD / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* bufA = smem;                     // [C][LD] leaky_relu(y): input of convs1
+    float* bufT = smem + C * LD;            // [C][LD] leaky_relu(xt): input of convs2
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * p.N, b = blockIdx.y;
+    const int ws = t0 - p.Hh;               // sample of tile column SLK
+    const int cw = w * (32 * NB);
+    const int L = p.L, LS = p.LS;
+    const float slope = p.slope;
+    const float* inb = p.in + (size_t)b * C * LS;
+
+    // the scratch columns of T are read (for samples nobody needs) before anything wrote them: make them finite once
+    for (int idx = tid; idx < (C * LD + 256) / 4; idx += kThreads) *reinterpret_cast<float4*>(bufT + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    f32x16 y[NB], sum[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[nb][r] = 0.f;
+
+#pragma unroll 1
+    for (int res = 0; res < p.nres; ++res) {
+        __syncthreads();                    // the previous resblock's last readers of A are done
+        // stage A = leaky_relu(x) for the samples [ws - SLK, ws - SLK + LD), zero outside [0, LS) (x is zero in [L, LS) already)
+        for (int idx = tid; idx < C * NCOL4; idx += kThreads) {
+            const int row = idx / NCOL4, g = idx - row * NCOL4;
+            const int t = ws - SLK + 4 * g;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < LS) {
+                v = *reinterpret_cast<const float4*>(inb + (size_t)row * LS + t);
+                v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+            }
+            *reinterpret_cast<float4*>(bufA + row * LD + 4 * g) = v;
+        }
+        // y = x in the fragment order of a dilation-1 convolution: register r of column c holds channel row / F, sample ws + c F + row % F
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int c = cw + 32 * nb + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = frag_row(r, h), co = row / F, e = row % F;
+                const int t = ws + c * F + e;
+                y[nb][r] = (t >= 0 && t < LS) ? inb[(size_t)co * LS + t] : 0.f;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int q = 0; q < p.npairs; ++q) {
+#pragma unroll 1
+            for (int ci = 0; ci < 2; ++ci) {
+                const VocChainConv cv = p.conv[(res * p.npairs + q) * 2 + ci];
+                const float* src = ci ? bufT : bufA;
+                float* dst = ci ? bufA : bufT;
+                const int dil = cv.dil;
+                // column -> first sample (relative to ws) of its F-step group
+                int rel[NB], boff[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int c = cw + 32 * nb + j;
+                    const int g = c / dil;
+                    rel[nb] = g * (F * dil) + (c - g * dil);
+                    boff[nb] = rel[nb] - rel[0];
+                }
+                float bv[16 / F];
+#pragma unroll
+                for (int i = 0; i < 16 / F; ++i) bv[i] = p.bias[cv.boff + frag_row(i * F, h) / F];
+                f32x16 acc[1][NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+                const int nch = (C / 8) * cv.KT;
+                ChainPipe<NB, LD> pipe(p.wp + cv.woff, lane, nch, src + 4 * h * LD + SLK + rel[0] - cv.pad, cv.KT, dil, boff);
+                pipe.start_a();
+                pipe.start_b();
+                pipe.run_blocks(acc, nch);
+                const bool feed = !(ci == 1 && q == p.npairs - 1);       // the last convolution of a resblock feeds no further one
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = frag_row(r, h), co = row / F, e = row % F;
+                        const int ro = rel[nb] + e * dil;
+                        float v = acc[0][nb][r] + bv[r / F];
+                        if (ci) { v += y[nb][r]; y[nb][r] = v; }
+                        const int t = ws + ro;
+                        if (feed) dst[co * LD + SLK + ro] = (t >= 0 && t < L) ? voc_lrelu(v, slope) : 0.f;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum[nb][r] = (res == 0) ? y[nb][r] : sum[nb][r] + y[nb][r];
+    }
+
+    // out = (sum_in + sum) / divide for the samples [t0, t0 + N) of this workgroup, zero in [L, LS)
+    float* outb = p.out + (size_t)b * C * LS;
+    const float* sinb = p.sum_in ? p.sum_in + (size_t)b * C * LS : nullptr;
+    const int tend = min(t0 + p.N, LS);
+    if constexpr (F == 4) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int t = ws + (cw + 32 * nb + j) * 4;
+            if (t < t0 || t >= tend) continue;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int co = 2 * rg + h;
+                const size_t o = (size_t)co * LS + t;
+                float4 v = get4(sum[nb], rg);
+                if (sinb) { const float4 s4 = *reinterpret_cast<const float4*>(sinb + o); v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w; }
+                if (p.divide != 1.f) { v.x = v.x / p.divide; v.y = v.y / p.divide; v.z = v.z / p.divide; v.w = v.w / p.divide; }
+                if (t + 0 >= L) v.x = 0.f;
+                if (t + 1 >= L) v.y = 0.f;
+                if (t + 2 >= L) v.z = 0.f;
+                if (t + 3 >= L) v.w = 0.f;
+                *reinterpret_cast<float4*>(outb + o) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int c = cw + 32 * nb + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = frag_row(r, h), co = row / F, e = row % F;
+                const int t = ws + c * F + e;
+                if (t < t0 || t >= tend) continue;
+                const size_t o = (size_t)co * LS + t;
+                float v = sum[nb][r];
+                if (sinb) v = sinb[o] + v;
+                if (p.divide != 1.f) v = v / p.divide;
+                outb[o] = (t < L) ? v : 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace dsd

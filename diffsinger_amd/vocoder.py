@@ -72,6 +72,28 @@ def fold_weight(w: torch.Tensor, F: int) -> torch.Tensor:
     return wf.reshape(co * F, ci, k + F - 1).contiguous()
 
 
+import ctypes as _C
+
+
+class DsvChainConv(_C.Structure):
+    """include/dsv.h dsv_chain_conv"""
+    _fields_ = [('w_offset', _C.c_int64), ('bias_offset', _C.c_int32), ('K', _C.c_int32), ('dil', _C.c_int32), ('reserved', _C.c_int32)]
+
+
+# How the ResBlock1 chains of a stage are launched (csrc/voc_chain.hpp): None = by channel count (8 / 16 channels: the whole stage - three
+# parallel resblocks of three conv pairs each - as ONE launch; 32 channels: one launch per conv pair; wider stages: one launch per convolution);
+# 'stage' / 'resblock' / 'pair' force that grouping wherever the library supports it; 'off' = one launch per convolution everywhere (the A/B
+# switch of the measurement and of the bit-identity tests).
+_CHAIN_MODE = None
+
+
+def set_chain_mode(mode):
+    global _CHAIN_MODE
+    if mode not in (None, 'stage', 'resblock', 'pair', 'off'):
+        raise ValueError(mode)
+    _CHAIN_MODE = mode
+
+
 class _HipOps:
     """The C ABI of include/dsv.h on torch device tensors (buffers in, buffers out).  There is no other implementation in the
     package: tests swap in a torch restatement of the header's formulas to check the orchestration on CPU."""
@@ -125,6 +147,29 @@ class _HipOps:
             _lib.check(self.lib.dsv_conv1d_folded(x.data_ptr(), wp.data_ptr(), self._p(bias), out.data_ptr(), B, ci, co, k, F, dil, L,
                                                   float(pre_slope), self._p(residual), self._p(sum_in), float(divide), int(act),
                                                   self._s(x.device)), 'dsv_conv1d_folded')
+        return out
+
+    def chain_fold(self, C: int) -> int:
+        return int(self.lib.dsv_chain_fold(C))
+
+    def chain_supported(self, C, nres, npairs, descs) -> int:
+        return int(self.lib.dsv_chain_supported(C, nres, npairs, descs))
+
+    def pack_into(self, w: torch.Tensor, buf: torch.Tensor, offset: int):
+        """dsv_pack_weight of w [rows][Ci][K] into buf at float offset `offset` (the call also zeroes the slack behind the piece)."""
+        rows, ci, k = w.shape
+        w = w.contiguous()
+        with torch.cuda.device(w.device):
+            _lib.check(self.lib.dsv_pack_weight(w.data_ptr(), rows, ci, k, buf.data_ptr() + 4 * offset, self._s(w.device)), 'dsv_pack_weight')
+        w.record_stream(torch.cuda.current_stream(w.device))
+
+    def resblock_chain(self, x, L, wp, bias, C, nres, npairs, descs, sum_in=None, divide=1.0, pre_slope=LRELU_SLOPE):
+        B = x.shape[0]
+        assert x.shape[1] == C and x.shape[2] == padded_samples(L) and x.is_contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.dsv_resblock_chain(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr(), self._p(sum_in), B, C, L, nres, npairs,
+                                                   descs, float(pre_slope), float(divide), self._s(x.device)), 'dsv_resblock_chain')
         return out
 
     def noise_conv(self, har, L_har, w, bias, stride, pad, L_out):
@@ -297,6 +342,75 @@ class HifiGanGenerator(nn.Module):
             return self._ops.conv_folded(x, L, e['wp'], e['bias'], co, ci, k, F, dil, **kw)
         return self._ops.conv(x, L, e['wp'], e['bias'], e['rows'], e['ci'], e['k'], get_padding(e['k'], dil), dil, **kw)
 
+    def _chain_prep(self, i: int):
+        """Stage i's ResBlock1 convolutions as the chain kernel wants them: ONE packed weight buffer (per convolution the F shifted copies of
+        the filter, dsv_pack_weight(rows = 32, C, K + F - 1)), one bias buffer, and a descriptor per convolution.  None: not a ResBlock1 stage
+        of 8 / 16 / 32 channels.  Cached per parameter version."""
+        rbs = [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)]
+        if any(rb.kind != '1' for rb in rbs) or len({len(rb.dils) for rb in rbs}) != 1:
+            return None
+        C = rbs[0].convs1[0].wshape()[0]
+        F = self._ops.chain_fold(C)
+        if not F:
+            return None
+        convs = [(c, d if which == 0 else 1) for rb in rbs for q, d in enumerate(rb.dils) for which, c in ((0, rb.convs1[q]), (1, rb.convs2[q]))]
+        tag = tuple(c.tag() for c, _ in convs)
+        hit = self._packed.get(f'chain{i}')
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        sizes = [(C // 8) * (c.wshape()[2] + F - 1) * 256 for c, _ in convs]
+        dev = convs[0][0].bias.device
+        slack = self._ops.lib.dsv_packed_floats(32, C, 1) - (C // 8) * 256          # the A prefetch overruns the last piece by up to five chunks
+        wp = torch.zeros(sum(sizes) + slack, device=dev, dtype=torch.float32)
+        bias = torch.empty(len(convs), C, device=dev, dtype=torch.float32)
+        descs = (DsvChainConv * len(convs))()
+        off = 0
+        for n, ((c, d), sz) in enumerate(zip(convs, sizes)):
+            w = c.plain_weight().to(torch.float32)
+            self._ops.pack_into(fold_weight(w, F) if F > 1 else w.contiguous(), wp, off)
+            bias[n] = c.bias.detach().to(torch.float32)
+            descs[n] = DsvChainConv(off, n * C, int(w.shape[2]), int(d), 0)
+            off += sz
+        entry = dict(wp=wp, bias=bias, descs=descs, C=C, npairs=len(rbs[0].dils), nres=len(rbs))
+        self._packed[f'chain{i}'] = (tag, entry)
+        return entry
+
+    def _stage_resblocks(self, i: int, x, L):
+        """x = (sum_j resblock_{i, j}(x)) / num_kernels (hifigan.py:161-166): fused chains where the library offers them, else one launch per
+        convolution.  Every grouping gives the same bits."""
+        mode = _CHAIN_MODE
+        e = self._chain_prep(i) if mode != 'off' else None
+        if e is not None:
+            C, nres, npairs = e['C'], e['nres'], e['npairs']
+            if mode is None:
+                mode = 'stage' if C <= 16 else 'pair'
+            sub = lambda r0, q0, nr, nq: (DsvChainConv * (nr * nq * 2))(*[e['descs'][(r * npairs + q) * 2 + k] for r in range(r0, r0 + nr)
+                                                                       for q in range(q0, q0 + nq) for k in range(2)])
+            ops, nk = self._ops, float(self.num_kernels)
+            if mode == 'stage' and ops.chain_supported(C, nres, npairs, e['descs']):
+                return ops.resblock_chain(x, L, e['wp'], e['bias'], C, nres, npairs, e['descs'], divide=nk)
+            if mode in ('stage', 'resblock') and all(ops.chain_supported(C, 1, npairs, sub(r, 0, 1, npairs)) for r in range(nres)):
+                acc = None
+                for r in range(nres):
+                    acc = ops.resblock_chain(x, L, e['wp'], e['bias'], C, 1, npairs, sub(r, 0, 1, npairs), sum_in=acc,
+                                             divide=nk if r == nres - 1 else 1.0)
+                return acc
+            if all(ops.chain_supported(C, 1, 1, sub(r, q, 1, 1)) for r in range(nres) for q in range(npairs)):
+                acc = None
+                for r in range(nres):
+                    y = x
+                    for q in range(npairs):
+                        last = q == npairs - 1
+                        y = ops.resblock_chain(y, L, e['wp'], e['bias'], C, 1, 1, sub(r, q, 1, 1), sum_in=acc if last else None,
+                                               divide=nk if (last and r == nres - 1) else 1.0)
+                    acc = y
+                return acc
+        acc = None
+        for j in range(self.num_kernels):                            # xs = rb0(x); xs += rb1(x); ...; x = xs / num_kernels
+            last = j == self.num_kernels - 1
+            acc = self._resblock(i * self.num_kernels + j, x, L, acc, float(self.num_kernels) if last else 1.0)
+        return acc
+
     def _resblock(self, idx: int, x, L, sum_in, divide):
         """One ResBlock on x; its last convolution also adds the block output into `sum_in` (xs += ...) and divides."""
         rb = self.resblocks[idx]
@@ -360,11 +474,7 @@ class HifiGanGenerator(nn.Module):
             e = self._prep(f'ups{i}', self.ups[i], transposed_stride=u, transposed_pad=(k - u) // 2)
             x = ops.conv(x, L, e['wp'], e['bias'], e['rows'], e['ci'], e['k'], e['pad'], 1, up=u, pre_slope=LRELU_SLOPE, residual=xs)
             L = L * u
-            acc = None
-            for j in range(self.num_kernels):                        # xs = rb0(x); xs += rb1(x); ...; x = xs / num_kernels
-                last = j == self.num_kernels - 1
-                acc = self._resblock(i * self.num_kernels + j, x, L, acc, float(self.num_kernels) if last else 1.0)
-            x = acc
+            x = self._stage_resblocks(i, x, L)
         x = self._conv('post', self.conv_post, x, L, pre_slope=0.01, act=1)                                  # F.leaky_relu default slope, tanh
         return x[:, :, :L].contiguous()
 

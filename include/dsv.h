@@ -66,6 +66,30 @@ int dsv_conv1d_folded(const float* in, const float* wpacked, const float* bias, 
                       int32_t F, int32_t dil, int32_t L, float pre_slope, const float* residual, const float* sum_in, float divide,
                       int32_t act, void* stream);
 
+/* Whole ResBlock1 chains in ONE launch, activations resident in LDS (csrc/voc_chain.hpp) - `xs = sum_r resblock_r(x)` of
+ * HifiGanGenerator.forward (hifigan.py:161-166) with ResBlock1.forward (:54-61) inside:
+ *     for r < nres:  y = x ; for q < npairs:  xt = conv[r][q][0](leaky_relu(y)) ; xt = conv[r][q][1](leaky_relu(xt)) ; y = xt + y
+ *     out = (sum_in + y_0 + y_1 + ...) / divide            (sum_in may be NULL: the running `xs` of resblocks that ran before this call)
+ * for C = 8, 16 or 32 channels (C * F == 32 with the fold F = dsv_chain_fold(C) = 4, 2, 1 of dsv_conv1d_folded).  in, out, sum_in:
+ * [B][C][LS(L)], in != out.  convs: HOST array [nres][npairs][2] - the first convolution of a pair at dilation `dil`, the second at 1
+ * ('same' padding, K odd); w_offset = float offset of its packed weight inside `wpacked` (each piece = dsv_pack_weight(rows = 32,
+ * Ci = C, K + F - 1) of the F shifted copies W'[co * F + e][ci][s] = w[co][ci][s - e], pieces at multiples of 256 floats, the buffer
+ * ending with the slack dsv_packed_floats includes), bias_offset = float offset of its bias [C] inside `bias`.  A workgroup owns N output
+ * samples plus a halo of the chain's receptive field; dsv_chain_supported returns that N (0: the chain does not fit the staged tile -
+ * kernel / dilation too wide, too many convolutions - run it convolution by convolution with dsv_conv1d / dsv_conv1d_folded).  The
+ * summation order of every output sample is the one of those operators: the results are bit-identical to theirs. */
+typedef struct dsv_chain_conv {
+    int64_t w_offset;
+    int32_t bias_offset;
+    int32_t K;
+    int32_t dil;
+    int32_t reserved;
+} dsv_chain_conv;
+int32_t dsv_chain_fold(int32_t C);
+int32_t dsv_chain_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs);
+int dsv_resblock_chain(const float* in, const float* wpacked, const float* bias, float* out, const float* sum_in, int32_t B, int32_t C,
+                       int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream);
+
 /* noise_convs[i] (hifigan.py:124-130, :158-160): the strided Conv1d(1 -> C, kernel K, stride, padding) over the harmonic
  * source.  har [B][LS(L_har)], w [C][K] (the torch weight [C][1][K]), bias [C] or NULL, out [B][C][LS(L_out)];
  * L_out must equal (L_har + 2 * pad - K) / stride + 1. */

@@ -251,3 +251,65 @@ def test_spec2wav_wrapper_and_own_draws():
     assert wav.shape == (case['T'] * 256,) and wav.dtype == np.float32 and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0
     plain = HifiGAN(m, DEV, use_nsf=False).spec2wav(mel[0].t().numpy(), f0=f0[0].numpy())          # use_nsf off: f0 ignored (vocoders/hifigan.py:62)
     assert plain.shape == wav.shape and not np.array_equal(plain, wav)
+
+
+# ---- fused ResBlock1 chains (csrc/voc_chain.hpp, dsv_resblock_chain) ----------------------------------------------------------------
+
+@pytest.fixture
+def chain_default():
+    from diffsinger_amd import vocoder
+    vocoder.set_chain_mode(None)
+    yield vocoder
+    vocoder.set_chain_mode(None)
+
+
+@pytest.mark.parametrize('stage,L', [(3, 5000), (3, 896), (3, 33), (2, 3001), (2, 640), (1, 1500), (1, 449), (0, 300)])
+@pytest.mark.parametrize('mode', ['stage', 'resblock', 'pair'])
+def test_resblock_chain_is_bit_identical_to_the_single_convolutions(stage, L, mode, chain_default):
+    """One stage's `(sum_j resblock_j(x)) / 3` (hifigan.py:161-166, :54-61) with the ResBlock1 chains fused in LDS - the whole stage, one
+    resblock, or one conv pair per launch - against one launch per convolution: same chunk order, same epilogue arithmetic -> the same BITS.
+    Ragged lengths: several tiles with a partial last one, exactly one tile, a tile shorter than the halo; stage 0 (64 channels) has no chain
+    kernel and must fall through unchanged."""
+    case = dict(nsf=False, B=2, T=8, seed=41 + stage)
+    h, p, m = _generator(case)
+    m(torch.zeros(1, 80, 4, device=DEV))                              # creates the op table
+    C = 128 >> (stage + 1)
+    g = torch.Generator().manual_seed(100 * stage + L)
+    x = _cm(torch.randn(3, C, L, generator=g), L).to(DEV)
+    chain_default.set_chain_mode('off')
+    want = m._stage_resblocks(stage, x, L)
+    chain_default.set_chain_mode(mode)
+    got = m._stage_resblocks(stage, x, L)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and float(got[:, :, L:].abs().max() if got.shape[2] > L else 0) == 0
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize('mode', [None, 'stage', 'resblock', 'pair'])
+def test_generator_with_fused_chains_equals_the_unfused_generator(mode, chain_default):
+    case = dict(nsf=True, B=3, T=150, seed=77)
+    h, p, m = _generator(case)
+    g = torch.Generator().manual_seed(5)
+    mel = torch.randn(case['B'], 80, case['T'], generator=g).to(DEV)
+    f0 = (torch.rand(case['B'], case['T'], generator=g) * 400 + 70).to(DEV)
+    ri, nz = draws_like_reference(9, case['B'], case['T'] * 256)
+    chain_default.set_chain_mode('off')
+    want = m(mel, f0, rand_ini=ri.to(DEV), noise=nz.to(DEV))
+    chain_default.set_chain_mode(mode)
+    got = m(mel, f0, rand_ini=ri.to(DEV), noise=nz.to(DEV))
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+def test_chain_entry_point_refuses_what_it_cannot_tile():
+    from diffsinger_amd.vocoder import DsvChainConv
+    lib = _lib.load()
+    ok = (DsvChainConv * 2)(DsvChainConv(0, 0, 11, 5, 0), DsvChainConv(3584, 8, 11, 1, 0))
+    assert lib.dsv_chain_supported(8, 1, 1, ok) > 0 and lib.dsv_chain_fold(8) == 4 and lib.dsv_chain_fold(64) == 0
+    wide = (DsvChainConv * 2)(DsvChainConv(0, 0, 7, 12, 0), DsvChainConv(2560, 8, 7, 1, 0))           # the official v3 generator: 36 samples of reach
+    assert lib.dsv_chain_supported(8, 1, 1, wide) == 0
+    second_dilated = (DsvChainConv * 2)(DsvChainConv(0, 0, 3, 1, 0), DsvChainConv(1536, 8, 3, 3, 0))
+    assert lib.dsv_chain_supported(8, 1, 1, second_dilated) == 0
+    assert lib.dsv_chain_supported(64, 1, 1, ok) == 0 and lib.dsv_chain_supported(8, 4, 3, ok) == 0
+    x = torch.zeros(1, 8, 64, device=DEV)
+    assert lib.dsv_resblock_chain(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 1, 8, 64, 1, 1, ok, 0.1, 1.0, None) != 0
+    assert b'different buffers' in lib.dsd_last_error()

@@ -46,6 +46,9 @@ class HeaderFormulaOps:
         out[:, :, :Lo] = v
         return out
 
+    def chain_fold(self, C):
+        return 0                                                      # the fused ResBlock1 chains (dsv_resblock_chain) exist on the device only
+
     fold = True                                                       # mirrors dsv_fold_factor / dsv_set_fold
 
     def fold_factor(self, co, ci, k, dil):
