@@ -323,12 +323,13 @@ __global__ void k_latch_tmo(const unsigned* tmo, unsigned* sticky) {
 }
 
 // Debug / test hook kernel: holds a CU (all of its LDS) for `ticks` of the 100 MHz wall clock.
-__global__ void k_hold_cu(unsigned long long ticks, unsigned* sink) {
+__global__ void k_hold_cu(unsigned long long ticks, unsigned* started) {
     extern __shared__ unsigned hold_lds[];
     hold_lds[threadIdx.x] = threadIdx.x;
+    if (started && threadIdx.x == 0) atomicAdd(started, 1u);            // the caller can wait until the holders are resident
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-    if (sink && hold_lds[threadIdx.x] == 0xffffffffu) *sink = 1u;
+    if (started && hold_lds[threadIdx.x] == 0xffffffffu) *started = 0u;   // keeps the LDS allocation alive
 }
 
 static int sticky_alloc(dsd_handle* h) {
@@ -1124,14 +1125,14 @@ extern "C" int dsd_check(dsd_handle* h) {
     return check_sticky(h, "dsd_check");
 }
 
-extern "C" int dsd_debug_hold_cus(int32_t device, int32_t n_workgroups, int32_t milliseconds, void* stream) {
+extern "C" int dsd_debug_hold_cus(int32_t device, int32_t n_workgroups, int32_t milliseconds, uint32_t* started, void* stream) {
     if (n_workgroups < 1 || n_workgroups > 4096 || milliseconds < 1 || milliseconds > 20000)
         return fail(DSD_ERR_INVALID, "dsd_debug_hold_cus: 1..4096 workgroups, 1..20000 ms");
     HIP_TRY(hipSetDevice(device));
     const int lds = 160 * 1024;                                    // the whole LDS of a CU: one holder per CU, nothing else fits beside it
     if (first_on_device(2)) HIP_TRY(hipFuncSetAttribute((const void*)k_hold_cu, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(k_hold_cu, dim3((unsigned)n_workgroups), dim3(64), lds, (hipStream_t)stream, (unsigned long long)milliseconds * 100000ull,
-                       (unsigned*)nullptr);
+                       (unsigned*)started);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

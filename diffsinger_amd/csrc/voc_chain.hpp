@@ -63,9 +63,17 @@ struct ChainPipe {
     float4 a[6][1];
     float b[2][4][NB];
 
-    __device__ __forceinline__ ChainPipe(const float4* abase_uniform, int lane, int n, const float* bbase, int KT_, int dil_, const int (&boff_)[NB])
+    __device__ __forceinline__ ChainPipe(const float4* abase_uniform, int lane)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(abase_uniform), 0, 0x7ffffff0, 0x00020000)),
-          aoff((unsigned)lane * 16u), cur(bbase), KT(KT_), dil(dil_), left(n - 1), tap(0) {
+          aoff((unsigned)lane * 16u), cur(nullptr), KT(1), dil(1), left(0), tap(0) {}
+    // The weight stream of a convolution depends on nothing the kernel computes: it is re-targeted and its first five chunks are requested
+    // BEHIND the previous convolution's last MFMA - in front of that convolution's epilogue and the barrier - so that the L2 round trip of a
+    // stream's first touch is not paid at the head of every (short: 6 - 56 chunks) contraction.
+    __device__ __forceinline__ void set_a(const float4* abase_uniform) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(abase_uniform), 0, 0x7ffffff0, 0x00020000);
+    }
+    __device__ __forceinline__ void set_b(int n, const float* bbase, int KT_, int dil_, const int (&boff_)[NB]) {
+        cur = bbase; KT = KT_; dil = dil_; left = n - 1; tap = 0;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) boff[nb] = boff_[nb];
     }
@@ -161,83 +169,125 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum[nb][r] = 0.f;
 
+    const int total = p.nres * p.npairs * 2;
+    ChainPipe<NB, LD> pipe(p.wp + p.conv[0].woff, lane);
+    pipe.start_a();
+    int q = 0;                              // pair of the convolution n inside its resblock
 #pragma unroll 1
-    for (int res = 0; res < p.nres; ++res) {
-        __syncthreads();                    // the previous resblock's last readers of A are done
-        // stage A = leaky_relu(x) for the samples [ws - SLK, ws - SLK + LD), zero outside [0, LS) (x is zero in [L, LS) already)
-        for (int idx = tid; idx < C * NCOL4; idx += kThreads) {
-            const int row = idx / NCOL4, g = idx - row * NCOL4;
-            const int t = ws - SLK + 4 * g;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < LS) {
-                v = *reinterpret_cast<const float4*>(inb + (size_t)row * LS + t);
-                v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
-            }
-            *reinterpret_cast<float4*>(bufA + row * LD + 4 * g) = v;
-        }
-        // y = x in the fragment order of a dilation-1 convolution: register r of column c holds channel row / F, sample ws + c F + row % F
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int c = cw + 32 * nb + j;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = frag_row(r, h), co = row / F, e = row % F;
-                const int t = ws + c * F + e;
-                y[nb][r] = (t >= 0 && t < LS) ? inb[(size_t)co * LS + t] : 0.f;
-            }
-        }
-        __syncthreads();
-
-#pragma unroll 1
-        for (int q = 0; q < p.npairs; ++q) {
-#pragma unroll 1
-            for (int ci = 0; ci < 2; ++ci) {
-                const VocChainConv cv = p.conv[(res * p.npairs + q) * 2 + ci];
-                const float* src = ci ? bufT : bufA;
-                float* dst = ci ? bufA : bufT;
-                const int dil = cv.dil;
-                // column -> first sample (relative to ws) of its F-step group
-                int rel[NB], boff[NB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int c = cw + 32 * nb + j;
-                    const int g = c / dil;
-                    rel[nb] = g * (F * dil) + (c - g * dil);
-                    boff[nb] = rel[nb] - rel[0];
+    for (int n = 0; n < total; ++n) {
+        const int ci = n & 1;
+        if (ci == 0 && q == 0) {
+            __syncthreads();                // the previous resblock's last readers of A are done
+            // stage A = leaky_relu(x) for the samples [ws - SLK, ws - SLK + LD), zero outside [0, LS) (x is zero in [L, LS) already)
+            for (int idx = tid; idx < C * NCOL4; idx += kThreads) {
+                const int row = idx / NCOL4, g = idx - row * NCOL4;
+                const int t = ws - SLK + 4 * g;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t >= 0 && t < LS) {
+                    v = *reinterpret_cast<const float4*>(inb + (size_t)row * LS + t);
+                    v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
                 }
-                float bv[16 / F];
+                *reinterpret_cast<float4*>(bufA + row * LD + 4 * g) = v;
+            }
+            // y = x in the fragment order of a dilation-1 convolution: register r of column c holds channel row / F, sample ws + c F + row % F
 #pragma unroll
-                for (int i = 0; i < 16 / F; ++i) bv[i] = p.bias[cv.boff + frag_row(i * F, h) / F];
-                f32x16 acc[1][NB];
+            for (int nb = 0; nb < NB; ++nb) {
+                const int t = ws + (cw + 32 * nb + j) * F;
+                if constexpr (F == 4) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
-                const int nch = (C / 8) * cv.KT;
-                ChainPipe<NB, LD> pipe(p.wp + cv.woff, lane, nch, src + 4 * h * LD + SLK + rel[0] - cv.pad, cv.KT, dil, boff);
-                pipe.start_a();
-                pipe.start_b();
-                pipe.run_blocks(acc, nch);
-                const bool feed = !(ci == 1 && q == p.npairs - 1);       // the last convolution of a resblock feeds no further one
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
+                    for (int rg = 0; rg < 4; ++rg) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (t >= 0 && t < LS) v = *reinterpret_cast<const float4*>(inb + (size_t)(2 * rg + h) * LS + t);
+                        set4(y[nb], rg, v);
+                    }
+                } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = frag_row(r, h), co = row / F, e = row % F;
-                        const int ro = rel[nb] + e * dil;
-                        float v = acc[0][nb][r] + bv[r / F];
-                        if (ci) { v += y[nb][r]; y[nb][r] = v; }
-                        const int t = ws + ro;
-                        if (feed) dst[co * LD + SLK + ro] = (t >= 0 && t < L) ? voc_lrelu(v, slope) : 0.f;
+                        y[nb][r] = (t + e >= 0 && t + e < LS) ? inb[(size_t)co * LS + t + e] : 0.f;
                     }
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
+        const VocChainConv cv = p.conv[n];
+        const float* src = ci ? bufT : bufA;
+        float* dst = ci ? bufA : bufT;
+        const int dil = cv.dil;
+        // column -> first sample (relative to ws) of its F-step group
+        int rel[NB], boff[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int c = cw + 32 * nb + j;
+            const int g = c / dil;
+            rel[nb] = g * (F * dil) + (c - g * dil);
+            boff[nb] = rel[nb] - rel[0];
+        }
+        float bv[16 / F];
+#pragma unroll
+        for (int i = 0; i < 16 / F; ++i) bv[i] = p.bias[cv.boff + frag_row(i * F, h) / F];
+        f32x16 acc[1][NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum[nb][r] = (res == 0) ? y[nb][r] : sum[nb][r] + y[nb][r];
+            for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+        const int nch = (C / 8) * cv.KT;
+        pipe.set_b(nch, src + 4 * h * LD + SLK + rel[0] - cv.pad, cv.KT, dil, boff);
+        pipe.start_b();
+        pipe.run_blocks(acc, nch);
+        if (n + 1 < total) {                // the next convolution's weights: requested now, used behind the epilogue and the barrier
+            pipe.set_a(p.wp + p.conv[n + 1].woff);
+            pipe.start_a();
+        }
+        const bool last_of_res = (ci == 1 && q == p.npairs - 1);        // the last convolution of a resblock feeds no further one
+        if (ci == 1 && F == 4) {
+            // dilation 1: rows 8 rg + 4 h + (0..3) of a column are four consecutive samples of channel 2 rg + h: 16-byte tile writes
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int ro = rel[nb], t = ws + ro;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    float4 v = get4(acc[0][nb], rg), yv = get4(y[nb], rg);
+                    const float b0 = bv[rg];
+                    v.x = (v.x + b0) + yv.x; v.y = (v.y + b0) + yv.y; v.z = (v.z + b0) + yv.z; v.w = (v.w + b0) + yv.w;
+                    set4(y[nb], rg, v);
+                    if (!last_of_res) {
+                        float4 o;
+                        o.x = (t + 0 >= 0 && t + 0 < L) ? voc_lrelu(v.x, slope) : 0.f;
+                        o.y = (t + 1 >= 0 && t + 1 < L) ? voc_lrelu(v.y, slope) : 0.f;
+                        o.z = (t + 2 >= 0 && t + 2 < L) ? voc_lrelu(v.z, slope) : 0.f;
+                        o.w = (t + 3 >= 0 && t + 3 < L) ? voc_lrelu(v.w, slope) : 0.f;
+                        *reinterpret_cast<float4*>(dst + (2 * rg + h) * LD + SLK + ro) = o;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = frag_row(r, h), co = row / F, e = row % F;
+                    const int ro = rel[nb] + e * dil;
+                    float v = acc[0][nb][r] + bv[r / F];
+                    if (ci) { v += y[nb][r]; y[nb][r] = v; }
+                    const int t = ws + ro;
+                    if (!last_of_res) dst[co * LD + SLK + ro] = (t >= 0 && t < L) ? voc_lrelu(v, slope) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (ci == 1) {
+            if (last_of_res) {
+                const bool first = (n == 2 * p.npairs - 1);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum[nb][r] = first ? y[nb][r] : sum[nb][r] + y[nb][r];
+                q = 0;
+            } else {
+                ++q;
+            }
+        }
     }
 
     // out = (sum_in + sum) / divide for the samples [t0, t0 + N) of this workgroup, zero in [L, LS)

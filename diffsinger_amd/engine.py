@@ -161,11 +161,22 @@ class DenoiserEngine:
             torch.cuda.current_stream(self.device).synchronize()
         _lib.check(self.lib.dsd_check(self._h), 'persistent loop')
 
-    def hold_cus(self, n_workgroups: int, milliseconds: int, stream: Optional[torch.cuda.Stream] = None):
-        """Test hook: a foreign kernel that occupies `n_workgroups` compute units for `milliseconds` on `stream` (default: the current one)."""
+    def hold_cus(self, n_workgroups: int, milliseconds: int, stream: Optional[torch.cuda.Stream] = None, wait: bool = True):
+        """Test hook: a foreign kernel that occupies `n_workgroups` compute units for `milliseconds` on `stream` (default: the current one).
+        wait: return only when every holder is resident (polls a device counter through the current stream, which must be idle)."""
         s = stream.cuda_stream if stream is not None else _stream_ptr(self.device)
+        started = torch.zeros(1, dtype=torch.int32, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.dsd_debug_hold_cus(self.device.index or 0, int(n_workgroups), int(milliseconds), s), 'dsd_debug_hold_cus')
+            _lib.check(self.lib.dsd_debug_hold_cus(self.device.index or 0, int(n_workgroups), int(milliseconds), started.data_ptr(), s), 'dsd_debug_hold_cus')
+        if wait and stream is not None:
+            import time
+            t0 = time.time()
+            while int(started.item()) < n_workgroups:
+                if time.time() - t0 > 5.0:
+                    raise RuntimeError(f'hold_cus: only {int(started.item())} of {n_workgroups} holders became resident within 5 s')
+                time.sleep(0.005)
+        self._hold_keep = started
 
     def set_layer_tile(self, frames: int):
         _lib.check(self.lib.dsd_set_layer_tile(self._h, int(frames)))

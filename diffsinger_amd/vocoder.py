@@ -80,10 +80,10 @@ class DsvChainConv(_C.Structure):
     _fields_ = [('w_offset', _C.c_int64), ('bias_offset', _C.c_int32), ('K', _C.c_int32), ('dil', _C.c_int32), ('reserved', _C.c_int32)]
 
 
-# How the ResBlock1 chains of a stage are launched (csrc/voc_chain.hpp): None = by channel count (8 / 16 channels: the whole stage - three
-# parallel resblocks of three conv pairs each - as ONE launch; 32 channels: one launch per conv pair; wider stages: one launch per convolution);
-# 'stage' / 'resblock' / 'pair' force that grouping wherever the library supports it; 'off' = one launch per convolution everywhere (the A/B
-# switch of the measurement and of the bit-identity tests).
+# How the ResBlock1 chains of a stage are launched (csrc/voc_chain.hpp): None = the whole stage - three parallel resblocks of three conv pairs
+# each - as ONE launch wherever the library supports it (8 / 16 / 32 channels; wider stages: one launch per convolution) - the fastest grouping
+# measured (profiles/r07_voc_chain_ab.jsonl); 'stage' / 'resblock' / 'pair' force that grouping; 'off' = one launch per convolution everywhere
+# (the A/B switch of the measurement and of the bit-identity tests).
 _CHAIN_MODE = None
 
 
@@ -383,7 +383,7 @@ class HifiGanGenerator(nn.Module):
         if e is not None:
             C, nres, npairs = e['C'], e['nres'], e['npairs']
             if mode is None:
-                mode = 'stage' if C <= 16 else 'pair'
+                mode = 'stage'
             sub = lambda r0, q0, nr, nq: (DsvChainConv * (nr * nq * 2))(*[e['descs'][(r * npairs + q) * 2 + k] for r in range(r0, r0 + nr)
                                                                        for q in range(q0, q0 + nq) for k in range(2)])
             ops, nk = self._ops, float(self.num_kernels)

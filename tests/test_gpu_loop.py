@@ -143,8 +143,7 @@ def test_starved_persistent_loop_is_loud_and_the_retry_succeeds():
     side = torch.cuda.Stream()
 
     # (a) check=True: the call itself raises
-    eng.hold_cus(64, 10000, side)
-    time.sleep(0.5)
+    eng.hold_cus(64, 10000, side)                              # returns when all 64 holders are resident
     t0 = time.time()
     with pytest.raises(RuntimeError, match='spin bound'):
         run(check=True)
@@ -157,8 +156,7 @@ def test_starved_persistent_loop_is_loud_and_the_retry_succeeds():
     # (b) without check: nothing waits, the NaNs come back - and the next call into the engine raises
     eng.set_loop_mode(1)
     assert eng.loop_mode() == 1
-    eng.hold_cus(64, 10000, side)
-    time.sleep(0.5)
+    eng.hold_cus(64, 10000, side)                              # returns when all 64 holders are resident
     mel = run()
     torch.cuda.synchronize()
     assert not bool(torch.isfinite(mel).all()), 'the starved loop should have poisoned its tiles'

@@ -233,7 +233,7 @@ def test_p_losses_gradients_fused_equals_operator_path(monkeypatch):
 
 def test_dcond_follows_the_weights_over_optimizer_steps(monkeypatch):
     """the packed Wc^T of the dcond convolution must be rebuilt when a STOCK torch optimiser changes the conditioner weights
-    (joint FastSpeech2 training, usr/diffsinger_task.py:60-64): three AdamW steps with cond.requires_grad on the fused path and on the
+    (joint FastSpeech2 training, usr/diffsinger_task.py:60-64): three optimiser steps with cond.requires_grad on the fused path and on the
     operator-by-operator path (DSD_TRAIN_FUSED=0) - dcond of every step must agree, and must differ from step to step."""
     import diffsinger_amd
     from diffsinger_amd import hparams
@@ -249,8 +249,9 @@ def test_dcond_follows_the_weights_over_optimizer_steps(monkeypatch):
         torch.nn.init.normal_(net.output_projection.weight, std=0.02)
         gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=pre['timesteps'], K_step=pre['K_step'], loss_type='l1',
                                               spec_min=pre['spec_min'], spec_max=pre['spec_max']).cuda().train()
-        opt = torch.optim.AdamW(net.parameters(), lr=2e-3, weight_decay=0.0)        # every weight moves by ~2e-3 (3 % of its scale) per step: a stale
-        # Wc^T would show as ~1e-2, while the two paths still agree to rounding (lr 5e-2 blows the net up: 1e-3 of honest reassociation noise)
+        # a stock torch optimiser that updates the parameters in place.  SGD: smooth in the gradient (Adam divides by |g|: the 1e-6 differences
+        # between the two paths flip the sign of near-zero gradients and the NETS part within two steps - measured, profiles/r07_diag_dcond_*.txt)
+        opt = torch.optim.SGD(net.parameters(), lr=10.0)
         g = torch.Generator().manual_seed(4)
         x0 = torch.clamp(torch.randn(2, 1, 80, 70, generator=g) * 0.5, -1, 1).cuda()
         noise = torch.randn(2, 1, 80, 70, generator=g).cuda()
