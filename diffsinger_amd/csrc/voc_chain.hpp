@@ -178,21 +178,41 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
         const int ci = n & 1;
         if (ci == 0 && q == 0) {
             __syncthreads();                // the previous resblock's last readers of A are done
-            // stage A = leaky_relu(x) for the samples [ws - SLK, ws - SLK + LD), zero outside [0, LS) (x is zero in [L, LS) already)
-            for (int idx = tid; idx < C * NCOL4; idx += kThreads) {
-                const int row = idx / NCOL4, g = idx - row * NCOL4;
-                const int t = ws - SLK + 4 * g;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t >= 0 && t < LS) {
-                    v = *reinterpret_cast<const float4*>(inb + (size_t)row * LS + t);
-                    v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+            // stage A = leaky_relu(x) for the samples [ws - SLK, ws - SLK + LD), zero outside [0, LS) (x is zero in [L, LS) already).  ALL the
+            // loads of the tile are requested before the first one is used: a load -> write -> load chain pays the memory latency once per
+            // float4 (18 times per thread at 32 channels - a third of the workgroup's time in the first version, profiles/r08_*)
+            // (the addresses below do not depend on the convolution index: hipcc hoists all of them - 18 + 64 pointers at 32 channels - out of the
+            // loop and keeps them in registers across every contraction; an opaque zero defined HERE keeps the index arithmetic in this block)
+            int oz = 0;
+            asm volatile("" : "+v"(oz));
+            constexpr int NST = (C * NCOL4 + kThreads - 1) / kThreads, SB = (NST > 9) ? 6 : NST;                 // batches of at most six loads per thread beyond nine
+#pragma unroll
+            for (int it0 = 0; it0 < NST; it0 += SB) {
+                float4 sv[SB];
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int idx = (it0 + i) * kThreads + tid + oz;
+                    const int row = idx / NCOL4, g = idx - row * NCOL4;
+                    const int t = ws - SLK + 4 * g;
+                    const bool ok = (idx < C * NCOL4) && t >= 0 && t < LS;
+                    const float4 v = *reinterpret_cast<const float4*>(inb + (size_t)(ok ? row : 0) * LS + (ok ? t : 0));
+                    sv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                *reinterpret_cast<float4*>(bufA + row * LD + 4 * g) = v;
+                DSD_SB();
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int idx = (it0 + i) * kThreads + tid + oz;
+                    const int row = idx / NCOL4, g = idx - row * NCOL4;
+                    float4 v = sv[i];
+                    v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+                    if (idx < C * NCOL4) *reinterpret_cast<float4*>(bufA + row * LD + 4 * g) = v;
+                }
+                DSD_SB();
             }
             // y = x in the fragment order of a dilation-1 convolution: register r of column c holds channel row / F, sample ws + c F + row % F
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int t = ws + (cw + 32 * nb + j) * F;
+                const int t = ws + (cw + 32 * nb + j + oz) * F;
                 if constexpr (F == 4) {
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
