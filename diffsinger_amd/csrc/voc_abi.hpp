@@ -165,6 +165,9 @@ static int voc_chain_launch(VocChainParams& p, const dsv_chain_conv* convs, int 
     return DSD_OK;
 }
 
+static unsigned long long* g_chain_dbg = nullptr;
+extern "C" int dsv_debug_chain_timeline(uint64_t* device_stamps) { g_chain_dbg = (unsigned long long*)device_stamps; return DSD_OK; }
+
 extern "C" int32_t dsv_chain_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs) {
     if (!convs || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs) return 0;
     int n = 0, hh = 0, rc = -1;
@@ -185,7 +188,7 @@ extern "C" int dsv_resblock_chain(const float* in, const float* wpacked, const f
                     L, nres, npairs, kChainMaxConvs);
     VocChainParams p{};
     p.in = in; p.out = out; p.sum_in = sum_in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias;
-    p.L = L; p.LS = voc_ls(L); p.nres = nres; p.npairs = npairs; p.slope = pre_slope; p.divide = divide;
+    p.L = L; p.LS = voc_ls(L); p.nres = nres; p.npairs = npairs; p.slope = pre_slope; p.divide = divide; p.dbg = g_chain_dbg;
     const int F = dsv_chain_fold(C);
     for (int i = 0; i < nres * npairs * 2; ++i) {
         const dsv_chain_conv& c = convs[i];

@@ -44,6 +44,7 @@ struct VocChainParams {
     int N, Hh;              // output samples per workgroup (multiple of 32), halo per side (multiple of 4)
     int nres, npairs;
     float slope, divide;
+    unsigned long long* dbg;                // optional s_memtime stamps of ONE workgroup (dsv_debug_chain_timeline): [conv][wave 4][4]
     VocChainConv conv[kChainMaxConvs];      // [res][pair][2]
 };
 
@@ -170,6 +171,8 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
         for (int r = 0; r < 16; ++r) sum[nb][r] = 0.f;
 
     const int total = p.nres * p.npairs * 2;
+    const bool stamp = p.dbg != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0;
+    auto mark = [&](int n, int k) { if (stamp) p.dbg[(n * 4 + w) * 4 + k] = __builtin_amdgcn_s_memtime(); };
     ChainPipe<NB, LD> pipe(p.wp + p.conv[0].woff, lane);
     pipe.start_a();
     int q = 0;                              // pair of the convolution n inside its resblock
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
             }
             __syncthreads();
         }
+        mark(n, 0);
         const VocChainConv cv = p.conv[n];
         const float* src = ci ? bufT : bufA;
         float* dst = ci ? bufA : bufT;
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
         pipe.set_b(nch, src + 4 * h * LD + SLK + rel[0] - cv.pad, cv.KT, dil, boff);
         pipe.start_b();
         pipe.run_blocks(acc, nch);
+        mark(n, 1);
         if (n + 1 < total) {                // the next convolution's weights: requested now, used behind the epilogue and the barrier
             pipe.set_a(p.wp + p.conv[n + 1].woff);
             pipe.start_a();
@@ -295,7 +300,9 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
                 }
             }
         }
+        mark(n, 2);
         __syncthreads();
+        mark(n, 3);
         if (ci == 1) {
             if (last_of_res) {
                 const bool first = (n == 2 * p.npairs - 1);

@@ -89,6 +89,10 @@ int32_t dsv_chain_fold(int32_t C);
 int32_t dsv_chain_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs);
 int dsv_resblock_chain(const float* in, const float* wpacked, const float* bias, float* out, const float* sum_in, int32_t B, int32_t C,
                        int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream);
+/* Measurement hook: DEVICE buffer of 18 * 4 * 4 uint64 (or NULL to switch it off) - the following dsv_resblock_chain launches record the
+ * shader clock of ONE workgroup (the middle tile of utterance 0) per convolution n and wave w at [n][w][0..3] = {convolution start,
+ * contraction done, epilogue done, barrier passed}. */
+int dsv_debug_chain_timeline(uint64_t* device_stamps);
 
 /* noise_convs[i] (hifigan.py:124-130, :158-160): the strided Conv1d(1 -> C, kernel K, stride, padding) over the harmonic
  * source.  har [B][LS(L_har)], w [C][K] (the torch weight [C][1][K]), bias [C] or NULL, out [B][C][LS(L_out)];
