@@ -183,6 +183,7 @@ extern "C" int dsv_resblock_chain(const float* in, const float* wpacked, const f
                                   int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream) {
     if (!in || !wpacked || !bias || !out || !convs) return fail(DSD_ERR_INVALID, "dsv_resblock_chain: null argument");
     if (in == out) return fail(DSD_ERR_INVALID, "dsv_resblock_chain: in and out must be different buffers (workgroups read their neighbours' samples)");
+    if (!(pre_slope >= 0.f && pre_slope <= 1.f)) return fail(DSD_ERR_INVALID, "dsv_resblock_chain: pre_slope must be in [0, 1] (leaky_relu as max(v, slope v))");
     if (B < 1 || B > 65535 || L < 1 || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs || divide == 0.f || !dsv_chain_fold(C))
         return fail(DSD_ERR_INVALID, "dsv_resblock_chain: bad shape (B=%d C=%d L=%d nres=%d npairs=%d): 8, 16 or 32 channels, at most %d convolutions", B, C,
                     L, nres, npairs, kChainMaxConvs);

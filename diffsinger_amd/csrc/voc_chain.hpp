@@ -20,6 +20,8 @@
 // Arithmetic and summation order are those of the one-convolution kernels (chunk order ci8 * KT + tap, bias, + residual, sum_in + v, / divide):
 // results are BIT-IDENTICAL to the unfused path (tests/test_gpu_vocoder.py).
 #pragma once
+#include <type_traits>
+
 #include "voc_kernels.hpp"
 
 namespace dsd {
@@ -171,6 +173,8 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
         for (int r = 0; r < 16; ++r) sum[nb][r] = 0.f;
 
     const int total = p.nres * p.npairs * 2;
+    // every sample this workgroup can write to a tile (columns SLK .. SLK + WPOS + F * dil) lies inside [0, L): no range masks in the epilogues
+    const bool interior = (ws >= 0) && (ws + chain_wpos<F, NB>() + SLK <= L);
     const bool stamp = p.dbg != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0;
     auto mark = [&](int n, int k) { if (stamp) p.dbg[(n * 4 + w) * 4 + k] = __builtin_amdgcn_s_memtime(); };
     ChainPipe<NB, LD> pipe(p.wp + p.conv[0].woff, lane);
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
                     const int idx = (it0 + i) * kThreads + tid + oz;
                     const int row = idx / NCOL4, g = idx - row * NCOL4;
                     float4 v = sv[i];
-                    v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+                    v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope); v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
                     if (idx < C * NCOL4) *reinterpret_cast<float4*>(bufA + row * LD + 4 * g) = v;
                 }
                 DSD_SB();
@@ -265,41 +269,55 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
             pipe.start_a();
         }
         const bool last_of_res = (ci == 1 && q == p.npairs - 1);        // the last convolution of a resblock feeds no further one
-        if (ci == 1 && F == 4) {
-            // dilation 1: rows 8 rg + 4 h + (0..3) of a column are four consecutive samples of channel 2 rg + h: 16-byte tile writes
+        // Epilogue: v = acc + bias (+ y -> the new y), leaky_relu(v) -> the other tile.  The first version spent 6 650 cycles per convolution here
+        // (64 values x ~100 cycles of index / mask arithmetic, profiles/r10_voc_chain_timeline.txt): row and step of a register are compile-time
+        // constants up to the half-wave term, which moves into the lane's base pointer; tiles whose every writable sample lies inside [0, L) -
+        // all but the first and last of an utterance - skip the range masks, and leaky_relu is max(v, slope v) (the same value for 0 <= slope <= 1)
+        auto epilogue = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+            int ed[F];
+#pragma unroll
+            for (int e = 0; e < F; ++e) ed[e] = e * dil;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int ro = rel[nb], t = ws + ro;
+                float* dbase = dst + (h * (4 / F)) * LD + SLK + rel[nb];
+                const int tb = ws + rel[nb];
+                if (ci == 1 && F == 4) {
+                    // dilation 1: rows 8 rg + 4 h + (0..3) of a column are four consecutive samples of channel 2 rg + h: 16-byte tile writes
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    float4 v = get4(acc[0][nb], rg), yv = get4(y[nb], rg);
-                    const float b0 = bv[rg];
-                    v.x = (v.x + b0) + yv.x; v.y = (v.y + b0) + yv.y; v.z = (v.z + b0) + yv.z; v.w = (v.w + b0) + yv.w;
-                    set4(y[nb], rg, v);
-                    if (!last_of_res) {
-                        float4 o;
-                        o.x = (t + 0 >= 0 && t + 0 < L) ? voc_lrelu(v.x, slope) : 0.f;
-                        o.y = (t + 1 >= 0 && t + 1 < L) ? voc_lrelu(v.y, slope) : 0.f;
-                        o.z = (t + 2 >= 0 && t + 2 < L) ? voc_lrelu(v.z, slope) : 0.f;
-                        o.w = (t + 3 >= 0 && t + 3 < L) ? voc_lrelu(v.w, slope) : 0.f;
-                        *reinterpret_cast<float4*>(dst + (2 * rg + h) * LD + SLK + ro) = o;
+                    for (int rg = 0; rg < 4; ++rg) {
+                        float4 v = get4(acc[0][nb], rg), yv = get4(y[nb], rg);
+                        const float b0 = bv[rg];
+                        v.x = (v.x + b0) + yv.x; v.y = (v.y + b0) + yv.y; v.z = (v.z + b0) + yv.z; v.w = (v.w + b0) + yv.w;
+                        set4(y[nb], rg, v);
+                        if (!last_of_res) {
+                            float4 o = make_float4(fmaxf(v.x, v.x * slope), fmaxf(v.y, v.y * slope), fmaxf(v.z, v.z * slope), fmaxf(v.w, v.w * slope));
+                            if (!INTERIOR) {
+                                if (!(tb + 0 >= 0 && tb + 0 < L)) o.x = 0.f;
+                                if (!(tb + 1 >= 0 && tb + 1 < L)) o.y = 0.f;
+                                if (!(tb + 2 >= 0 && tb + 2 < L)) o.z = 0.f;
+                                if (!(tb + 3 >= 0 && tb + 3 < L)) o.w = 0.f;
+                            }
+                            *reinterpret_cast<float4*>(dbase + (2 * rg) * LD) = o;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row0 = (r & 3) + 8 * (r >> 2);            // frag_row without the half-wave term (4 h: a multiple of F)
+                        const int co0 = row0 / F, e = row0 % F;
+                        float v = acc[0][nb][r] + bv[r / F];
+                        if (ci) { v += y[nb][r]; y[nb][r] = v; }
+                        if (!last_of_res) {
+                            float o = fmaxf(v, v * slope);
+                            if (!INTERIOR) { const int t = tb + ed[e]; if (!(t >= 0 && t < L)) o = 0.f; }
+                            dbase[co0 * LD + ed[e]] = o;
+                        }
                     }
                 }
             }
-        } else {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = frag_row(r, h), co = row / F, e = row % F;
-                    const int ro = rel[nb] + e * dil;
-                    float v = acc[0][nb][r] + bv[r / F];
-                    if (ci) { v += y[nb][r]; y[nb][r] = v; }
-                    const int t = ws + ro;
-                    if (!last_of_res) dst[co * LD + SLK + ro] = (t >= 0 && t < L) ? voc_lrelu(v, slope) : 0.f;
-                }
-            }
-        }
+        };
+        if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
         mark(n, 2);
         __syncthreads();
         mark(n, 3);
