@@ -11,7 +11,7 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(PKG, 'csrc', 'dsd.hip')]
-DEPS = SRC + [os.path.join(PKG, 'csrc', f) for f in ('dsd_kernels.hpp', 'dsd_loop.hpp', 'dsd_lat.hpp', 'dsd_split.hpp', 'fs2_kernels.hpp', 'fs2_abi.hpp', 'train_kernels.hpp', 'train_loop.hpp', 'train_abi.hpp',
+DEPS = SRC + [os.path.join(PKG, 'csrc', f) for f in ('dsd_kernels.hpp', 'dsd_loop.hpp', 'dsd_lat.hpp', 'dsd_split.hpp', 'fs2_kernels.hpp', 'fs2_train.hpp', 'fs2_abi.hpp', 'train_kernels.hpp', 'train_loop.hpp', 'train_abi.hpp',
                                                    'voc_kernels.hpp', 'voc_chain.hpp', 'voc_abi.hpp')] + [
     os.path.join(os.path.dirname(PKG), 'include', f) for f in ('dsd.h', 'dsf.h', 'dsv.h')]
 LIB = os.path.join(PKG, 'libdsdenoise.so')

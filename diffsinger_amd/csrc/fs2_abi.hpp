@@ -1,6 +1,7 @@
 // fs2_abi.hpp - host side of the FastSpeech2 conditioner ops (C ABI in include/dsf.h); included at the end of dsd.hip so the
 // library stays one translation unit (shares the error string, the HIP_TRY macros and the operand-packing kernels).
 #include "fs2_kernels.hpp"
+#include "fs2_train.hpp"
 
 #include "../../include/dsf.h"
 
@@ -95,6 +96,74 @@ extern "C" int dsf_attention(const float* qkv, const uint8_t* key_pad, float* ou
     }
     hipLaunchKernelGGL((k_fs_attn<128>), dim3((unsigned)(p.TS / 32), (unsigned)heads, (unsigned)B), dim3(kThreads), fs_attn_lds_bytes<128>(),
                        (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward of LayerNorm and of the attention core (fs2_train.hpp)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int64_t dsf_ln_bwd_workspace_floats(int32_t B, int32_t T) {
+    if (B < 1 || T < 1) return -1;
+    return (int64_t)B * (fs_ts(T) / 32) * 512;
+}
+
+extern "C" int dsf_layer_norm_bwd(const float* x, const float* gamma, const float* dy, const float* keep, float* dx, float* dgamma, float* dbeta,
+                                  float* ws, int32_t B, int32_t C, int32_t T, float eps, int32_t relu_in, void* stream) {
+    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !ws) return fail(DSD_ERR_INVALID, "dsf_layer_norm_bwd: null argument");
+    if (C != kC) return fail(DSD_ERR_INVALID, "dsf_layer_norm_bwd: this build normalises over %d channels (got %d)", kC, C);
+    if (B < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_layer_norm_bwd: bad shape");
+    FsLnBwdParams p{};
+    p.x = x; p.dy = dy; p.gamma = gamma; p.keep = keep; p.dx = dx; p.part = ws; p.T = T; p.TS = fs_ts(T); p.eps = eps; p.relu_in = relu_in;
+    const int ntile = p.TS / 32;
+    hipLaunchKernelGGL(k_fs_ln_bwd, dim3((unsigned)ntile, (unsigned)B), dim3(kThreads), 0, (hipStream_t)stream, p);
+    // partials are [B * ntile][dgamma 256 | dbeta 256]
+    hipLaunchKernelGGL(k_fs_colsum, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dgamma, B * ntile, 256, 512);
+    hipLaunchKernelGGL(k_fs_colsum, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws + 256, dbeta, B * ntile, 256, 512);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int64_t dsf_attention_bwd_workspace_floats(int32_t B, int32_t heads, int32_t T) {
+    if (B < 1 || heads < 1 || T < 1) return -1;
+    return (int64_t)2 * B * heads * T * T;
+}
+
+static void fs_bmm(hipStream_t s, const float* A, const float* Bm, float* C, int M, int N, int K, long long am, long long ak, long long bk, long long bn,
+                   long long cm, long long cn, int outer, int inner, long long a_o, long long a_i, long long b_o, long long b_i, long long c_o, long long c_i,
+                   float alpha) {
+    FsBmmParams p{A, Bm, C, M, N, K, am, ak, bk, bn, cm, cn, inner, a_o, a_i, b_o, b_i, c_o, c_i, alpha};
+    hipLaunchKernelGGL(k_fs_bmm, dim3((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32), (unsigned)(outer * inner)), dim3(256), 0, s, p);
+}
+
+extern "C" int dsf_attention_bwd(const float* qkv, const uint8_t* key_pad, const float* dout, float* dqkv, float* ws, int32_t B, int32_t C,
+                                 int32_t heads, int32_t T, void* stream) {
+    if (!qkv || !dout || !dqkv || !ws) return fail(DSD_ERR_INVALID, "dsf_attention_bwd: null argument");
+    if (B < 1 || T < 1 || heads < 1 || C != heads * 128 || (int64_t)B * heads > 65535)
+        return fail(DSD_ERR_INVALID, "dsf_attention_bwd: this build supports head_dim 128 (C=%d, heads=%d)", C, heads);
+    hipStream_t s = (hipStream_t)stream;
+    const int TS = fs_ts(T), HD = 128, BH = B * heads;
+    const long long ts = TS, tt = T;
+    const float scale = (float)std::sqrt(1.0 / 128.0);
+    float* P = ws;                                       // [BH][T][T] probabilities
+    float* D = ws + (size_t)BH * T * T;                  // [BH][T][T] dP, then dS
+    const float *q = qkv, *k = qkv + (size_t)C * TS, *v = qkv + (size_t)2 * C * TS;
+    float *dq = dqkv, *dk = dqkv + (size_t)C * TS, *dv = dqkv + (size_t)2 * C * TS;
+    const long long qo = 3LL * C * TS, qi = (long long)HD * TS;          // batch strides of q / k / v and their gradients
+    const long long oo = (long long)C * TS, oi = (long long)HD * TS;     // ... of the attention output / its gradient
+    const long long po = (long long)heads * tt * tt, pi = tt * tt;
+    HIP_TRY(hipMemsetAsync(dqkv, 0, (size_t)B * 3 * C * TS * sizeof(float), s));                        // zero tails [T, TS)
+    // S[tq][tk] = scale * sum_d q[d][tq] k[d][tk]
+    fs_bmm(s, q, k, P, T, T, HD, 1, ts, ts, 1, tt, 1, B, heads, qo, qi, qo, qi, po, pi, scale);
+    hipLaunchKernelGGL(k_fs_softmax_rows, dim3((unsigned)T, (unsigned)BH), dim3(256), 0, s, P, (const unsigned char*)key_pad, T, heads);
+    // dP[tq][tk] = sum_d dO[d][tq] v[d][tk]
+    fs_bmm(s, dout, v, D, T, T, HD, 1, ts, ts, 1, tt, 1, B, heads, oo, oi, qo, qi, po, pi, 1.f);
+    // dv[d][tk] = sum_tq dO[d][tq] P[tq][tk]
+    fs_bmm(s, dout, P, dv, HD, T, T, ts, 1, tt, 1, ts, 1, B, heads, oo, oi, po, pi, qo, qi, 1.f);
+    hipLaunchKernelGGL(k_fs_softmax_bwd_rows, dim3((unsigned)T, (unsigned)BH), dim3(256), 0, s, (const float*)P, D, T);
+    // dq[d][tq] = scale * sum_tk k[d][tk] dS[tq][tk] ; dk[d][tk] = scale * sum_tq q[d][tq] dS[tq][tk]
+    fs_bmm(s, k, D, dq, HD, T, T, ts, 1, 1, tt, ts, 1, B, heads, qo, qi, po, pi, qo, qi, scale);
+    fs_bmm(s, q, D, dk, HD, T, T, ts, 1, tt, 1, ts, 1, B, heads, qo, qi, po, pi, qo, qi, scale);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

@@ -101,12 +101,12 @@ __global__ __launch_bounds__(kThreads) void k_fs_ln_bwd(const FsLnBwdParams p) {
     }
 }
 
-// out[c] = sum_r part[r][c] in row order (fixed summation order), c < ncol
-__global__ __launch_bounds__(256) void k_fs_colsum(const float* __restrict__ part, float* __restrict__ out, int nrows, int ncol) {
+// out[c] = sum_r part[r * stride + c] in row order (fixed summation order), c < ncol
+__global__ __launch_bounds__(256) void k_fs_colsum(const float* __restrict__ part, float* __restrict__ out, int nrows, int ncol, int stride) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= ncol) return;
     float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += part[(size_t)r * ncol + c];
+    for (int r = 0; r < nrows; ++r) s += part[(size_t)r * stride + c];
     out[c] = s;
 }
 

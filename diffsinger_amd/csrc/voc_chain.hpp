@@ -251,9 +251,17 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
             rel[nb] = g * (F * dil) + (c - g * dil);
             boff[nb] = rel[nb] - rel[0];
         }
+        // the bias of this lane's channels through SCALAR loads (constant address space: s_load, lgkmcnt): a vector load issued here and used in the
+        // epilogue made hipcc wait for the next convolution's weight prefetch (vmcnt counts in order) - an L2 round trip in front of every epilogue
+        typedef const __attribute__((address_space(4))) float cfloat;
+        cfloat* bias_c = (cfloat*)(p.bias + cv.boff);
         float bv[16 / F];
 #pragma unroll
-        for (int i = 0; i < 16 / F; ++i) bv[i] = p.bias[cv.boff + frag_row(i * F, h) / F];
+        for (int i = 0; i < 16 / F; ++i) {
+            const int c0 = (((i * F) & 3) + 8 * ((i * F) >> 2)) / F;            // frag_row(i F, 0) / F; the other half-wave: + 4 / F
+            const float b0 = bias_c[c0], b1 = bias_c[c0 + 4 / F];
+            bv[i] = h ? b1 : b0;
+        }
         f32x16 acc[1][NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -273,8 +281,8 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
         // (64 values x ~100 cycles of index / mask arithmetic, profiles/r10_voc_chain_timeline.txt): row and step of a register are compile-time
         // constants up to the half-wave term, which moves into the lane's base pointer; tiles whose every writable sample lies inside [0, L) -
         // all but the first and last of an utterance - skip the range masks, and leaky_relu is max(v, slope v) (the same value for 0 <= slope <= 1)
-        auto epilogue = [&](auto interior_tag) {
-            constexpr bool INTERIOR = decltype(interior_tag)::value;
+        auto epilogue = [&](auto ci_tag, auto last_tag, auto interior_tag) {
+            constexpr bool CI = decltype(ci_tag)::value, LAST = decltype(last_tag)::value, INTERIOR = decltype(interior_tag)::value;
             int ed[F];
 #pragma unroll
             for (int e = 0; e < F; ++e) ed[e] = e * dil;
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
             for (int nb = 0; nb < NB; ++nb) {
                 float* dbase = dst + (h * (4 / F)) * LD + SLK + rel[nb];
                 const int tb = ws + rel[nb];
-                if (ci == 1 && F == 4) {
+                if constexpr (CI && F == 4) {
                     // dilation 1: rows 8 rg + 4 h + (0..3) of a column are four consecutive samples of channel 2 rg + h: 16-byte tile writes
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
                         const float b0 = bv[rg];
                         v.x = (v.x + b0) + yv.x; v.y = (v.y + b0) + yv.y; v.z = (v.z + b0) + yv.z; v.w = (v.w + b0) + yv.w;
                         set4(y[nb], rg, v);
-                        if (!last_of_res) {
+                        if constexpr (!LAST) {
                             float4 o = make_float4(fmaxf(v.x, v.x * slope), fmaxf(v.y, v.y * slope), fmaxf(v.z, v.z * slope), fmaxf(v.w, v.w * slope));
                             if (!INTERIOR) {
                                 if (!(tb + 0 >= 0 && tb + 0 < L)) o.x = 0.f;
@@ -307,8 +315,8 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
                         const int row0 = (r & 3) + 8 * (r >> 2);            // frag_row without the half-wave term (4 h: a multiple of F)
                         const int co0 = row0 / F, e = row0 % F;
                         float v = acc[0][nb][r] + bv[r / F];
-                        if (ci) { v += y[nb][r]; y[nb][r] = v; }
-                        if (!last_of_res) {
+                        if constexpr (CI) { v += y[nb][r]; y[nb][r] = v; }
+                        if constexpr (!LAST) {
                             float o = fmaxf(v, v * slope);
                             if (!INTERIOR) { const int t = tb + ed[e]; if (!(t >= 0 && t < L)) o = 0.f; }
                             dbase[co0 * LD + ed[e]] = o;
@@ -317,7 +325,12 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
                 }
             }
         };
-        if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        {
+            using T_ = std::true_type; using F_ = std::false_type;
+            if (ci == 0) { if (interior) epilogue(F_{}, F_{}, T_{}); else epilogue(F_{}, F_{}, F_{}); }
+            else if (!last_of_res) { if (interior) epilogue(T_{}, F_{}, T_{}); else epilogue(T_{}, F_{}, F_{}); }
+            else epilogue(T_{}, T_{}, T_{});                  // the last convolution of a resblock writes no tile: nothing to mask
+        }
         mark(n, 2);
         __syncthreads();
         mark(n, 3);

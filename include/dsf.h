@@ -51,6 +51,20 @@ int dsf_layer_norm(const float* in, const float* gamma, const float* beta, float
  * [h*128, h*128+128) of each), key_pad [B][T] bytes (nonzero = padded key) or NULL, out [B][C][TS].  head_dim 128. */
 int dsf_attention(const float* qkv, const uint8_t* key_pad, float* out, int32_t B, int32_t C, int32_t heads, int32_t T, void* stream);
 
+/* BACKWARD of the two operators above - what torch autograd runs for nn.LayerNorm and F.multi_head_attention_forward when FastSpeech2 is trained
+ * (the Opencpop e2e configuration trains it jointly with the denoiser: usr/diffsinger_task.py:60-64, :273-300; csrc/fs2_train.hpp).
+ * dsf_layer_norm_bwd: x = the forward INPUT, dy = gradient wrt the forward output (times keep inside, like the forward) -> dx [B][C][TS]
+ * (zero tail), dgamma [C], dbeta [C] (overwritten; per-tile partial sums in ws, added in a fixed order: deterministic);
+ * ws: dsf_ln_bwd_workspace_floats(B, T) floats.
+ * dsf_attention_bwd: dout [B][C][TS] -> dqkv [B][3C][TS] (zero tail); the probabilities are recomputed ([B heads][T][T], twice, in ws:
+ * dsf_attention_bwd_workspace_floats(B, heads, T) floats) - the attention of the model that is trained runs at the phone rate. */
+int64_t dsf_ln_bwd_workspace_floats(int32_t B, int32_t T);
+int dsf_layer_norm_bwd(const float* x, const float* gamma, const float* dy, const float* keep, float* dx, float* dgamma, float* dbeta, float* ws,
+                       int32_t B, int32_t C, int32_t T, float eps, int32_t relu_in, void* stream);
+int64_t dsf_attention_bwd_workspace_floats(int32_t B, int32_t heads, int32_t T);
+int dsf_attention_bwd(const float* qkv, const uint8_t* key_pad, const float* dout, float* dqkv, float* ws, int32_t B, int32_t C, int32_t heads,
+                      int32_t T, void* stream);
+
 /* Layout changes at the boundary: the reference's [B,T,C] tensors (any element strides) <-> channel-major. */
 int dsf_to_channel_major(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_t, float* out, int32_t B, int32_t C,
                          int32_t T, void* stream);
