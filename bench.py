@@ -261,46 +261,49 @@ def main_vocoder(args):
     assert torch.equal(wav_g, wav), 'graph replay differs from the eager forward'
     el_g, _ = _row_time(lambda: gm(mel), args, world, device, dist)
     if rank == 0:
-        # dominant kernel: the resblock convolutions of the 8-channel stage (18 of the 76 launches, the longest time axis).  One launch
-        # of k_voc_conv_fold<4> (kernel 11, dilation 1, leaky_relu in front, residual behind) timed with events on the launch stream.
-        ops = _HipOps()
-        ch, L = 8, T * 256
+        # dominant kernel: the fused resblock stage of the 32-channel stage - ONE launch of k_voc_chain<32,1,4> = 3 resblocks x 3 conv pairs
+        # (18 convolutions, kernels 3 / 7 / 11, dilations 1 / 3 / 5) over 8 x 65 536 samples, 40 % of the forward - timed with events on the
+        # launch stream.  With the chains fused the row is bound by the fp32 matrix pipe, not by HBM any more (its traffic is the PMC figure).
+        chained = args.chain != 'off' and m._chain_prep(1) is not None
+        stage, ch = 1, 32
+        L = T * 64
         x = torch.randn(B, ch, padded_samples(L), device=device)
         x[:, :, L:] = 0
-        bias = torch.zeros(ch, device=device)
-        F = ops.fold_factor(ch, ch, 11, 1)
-        wraw = torch.randn(ch, ch, 11, device=device) / (ch * 11) ** 0.5
-        if F > 1:
-            wp = ops.pack(fold_weight(wraw, F))
-            launch = lambda: ops.conv_folded(x, L, wp, bias, ch, ch, 11, F, 1, pre_slope=0.1, residual=x)
-            kname = f'k_voc_conv_fold<{F}>'
-        else:
-            wp = ops.pack(wraw)
-            launch = lambda: ops.conv(x, L, wp, bias, ch, ch, 11, 5, 1, pre_slope=0.1, residual=x)
-            kname = 'k_voc_conv<4,4>'
+        launch = lambda: m._stage_resblocks(stage, x, L)
         launch()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
         ev0.record()
-        for _ in range(20):
+        for _ in range(reps):
             launch()
         ev1.record()
         ev1.synchronize()
-        ms = ev0.elapsed_time(ev1) / 20
-        alg_bytes = 3 * B * ch * L * 4                      # input + residual + output, once each
-        flop = 2 * B * L * ch * ch * 11
-        gbps = alg_bytes / (ms * 1e-3) / 1e9
-        roof = {'bound': 'hbm', 'kernel': kname, 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS, 'traffic': None,
-                'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms, 'flop_per_launch': flop, 'useful_tflops': flop / (ms * 1e-3) / 1e12,
-                'note': 'one resblock convolution of the 8-channel stage (kernel 11): 14.7 flop/B, so 8 TB/s of HBM bounds it at 117 TFLOP/s and the '
-                        'fp32 MFMA peak, after the (K+F-1)/K tap padding of the folded kernel, at 124 - the two roofs coincide; launch time incl. the '
-                        'torch.empty of the output and the ctypes call (eager).  No PMC pass of this kernel is committed yet'}
+        ms = ev0.elapsed_time(ev1) / reps
+        flop = sum(2 * B * L * ch * ch * k * 6 for k in h['resblock_kernel_sizes'])          # useful FLOPs: 6 convolutions per resblock
+        alg_bytes = 2 * B * ch * L * 4                                                          # the stage input read once, its output written once
+        traffic, traffic_src = None, 'no PMC pass of this kernel committed'
+        try:
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'voc_chain_32ch_pmc.json')))
+            traffic = pj['hbm_bytes_per_launch']['total']
+            traffic_src = (f"profiles/voc_chain_32ch_pmc.json (round {pj.get('round', '?')}, commit {pj.get('commit', '?')}): FETCH_SIZE KiB x 1024 x 2 "
+                           '(gfx950 wide-read correction) + WRITE_SIZE KiB x 1024 of one launch at this shape')
+        except Exception:
+            pass
+        kname = 'k_voc_chain<32,1,4>' if chained else 'k_voc_conv<4,4> x 18 (chains off)'
+        roof = {'bound': 'mfma', 'kernel': kname, 'achieved': flop / (ms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic if chained else None, 'traffic_unit': 'bytes/launch',
+                'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms, 'flop_per_launch': flop,
+                'note': 'achieved = USEFUL fp32 FLOPs of the 18 convolutions (2 x 32 x 32 x k per sample) / launch time incl. the torch.empty of the output and '
+                        'the ctypes call; the kernel executes 1.33 x that (a workgroup owns 384 samples + 2 x 60 of receptive field, 512 staged) on one 32-row '
+                        'MFMA block; 4 bytes / sample / channel in and out = 16 kFLOP/B: far above the ridge (20 FLOP/B), the matrix pipe is the roof. '
+                        'Round 2 ran the same stage as 18 launches of k_voc_conv<4,4> that moved 3.2 GB (0.36 of the HBM roof on the narrow stages)'}
         fpf = vocoder_flop_per_frame(h)
         value = world * B * T * args.steps / el
         res = {'metric': 'mel-frames/sec (whole node) through the HiFi-GAN generator, 80-bin mel -> 24 kHz waveform, hop 256, T=1024', 'value': value,
                'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': f'SURVEY 8 row f2: HifiGanGenerator of configs/tts/hifigan.yaml (128 -> 8 channels, x256), batch={B} x T={T} mel '
-                                      f'frames per GPU -> {B} x {T * 256} samples', 'narrow_layers': 'folded (k_voc_conv_fold)' if F > 1 else 'unfolded',
+                                      f'frames per GPU -> {B} x {T * 256} samples', 'resblock_chains': 'one launch per stage for the 32 / 16 / 8-channel stages (k_voc_chain)' if chained else 'off: one launch per convolution',
                           'sharding': 'replicas (no exchange step in this row)'},
                'roofline': roof, 'model_tflops': world * B * T * fpf * args.steps / el / 1e12, 'flop_per_mel_frame': fpf,
                'x_realtime_24k': value * 256 / 24000,

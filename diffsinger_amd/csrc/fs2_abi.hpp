@@ -209,26 +209,36 @@ extern "C" int dsf_denorm_spec(const float* x, const float* mask, float* mel, co
 static const int kWgSplits = 16;
 
 extern "C" int64_t dsf_wgrad_workspace_floats(int32_t Co, int32_t Ci, int32_t KT) {
-    if (Co < 1 || Ci < 1 || (KT != 1 && KT != 3)) return -1;
-    return (int64_t)kWgSplits * Co * Ci * KT + (int64_t)kWgSplits * Co;
+    if (Co < 1 || Ci < 1 || KT < 1 || !(KT & 1) || KT > 2 * kFsHalo + 1) return -1;
+    return (int64_t)kWgSplits * Co * Ci * std::min(KT, 3) + (int64_t)kWgSplits * Co;
 }
 
+// Kernels wider than 3 taps (FastSpeech2: the k = 9 conv-FFN, the k = 5 pitch predictor) run as groups of three taps: the kernel computes the taps
+// k = 0..2 at the frame shifts k * dil - pad', and pad' = pad - tap0 * dil selects the group; k_fs_wgrad_reduce_taps adds the frame splits in a
+// fixed order and writes the group's taps into dW [Co][Ci][KT].
 extern "C" int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, float* db, float* workspace, int32_t B, int32_t Ci, int32_t Co,
                                 int32_t KT, int32_t dil, int32_t T, int32_t accumulate, void* stream) {
     if (!dy || !x || !dw || !workspace) return fail(DSD_ERR_INVALID, "dsf_conv1d_wgrad: null argument");
-    if (B < 1 || T < 1 || Co < 1 || Ci < 1 || (KT != 1 && KT != 3) || dil < 1 || dil * (KT - 1) / 2 > kFsHalo)
-        return fail(DSD_ERR_INVALID, "dsf_conv1d_wgrad: bad shape (B=%d T=%d Ci=%d Co=%d K=%d dil=%d); kernels 1 and 3 are supported", B, T, Ci, Co, KT, dil);
-    FsWgradParams p{};
-    p.dy = dy; p.x = x; p.part = workspace; p.part_b = db ? workspace + (size_t)kWgSplits * Co * Ci * KT : nullptr; p.B = B; p.Ci = Ci; p.Co = Co; p.dil = dil; p.pad = dil * (KT - 1) / 2; p.T = T; p.TS = fs_ts(T);
-    p.nsplit = kWgSplits;
+    if (B < 1 || T < 1 || Co < 1 || Ci < 1 || KT < 1 || !(KT & 1) || dil < 1 || dil * (KT - 1) / 2 > kFsHalo)
+        return fail(DSD_ERR_INVALID, "dsf_conv1d_wgrad: bad shape (B=%d T=%d Ci=%d Co=%d K=%d dil=%d); odd kernels whose taps stay within +-%d frames", B, T, Ci, Co, KT,
+                    dil, kFsHalo);
+    const int pad = dil * (KT - 1) / 2;
+    const int gk = std::min(KT, 3);
+    float* part_b = workspace + (size_t)kWgSplits * Co * Ci * gk;
     const dim3 grid((unsigned)((Co + 127) / 128), (unsigned)((Ci + 63) / 64), (unsigned)kWgSplits);
-    if (KT == 1) hipLaunchKernelGGL((k_fs_wgrad<1>), grid, dim3(kThreads), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((k_fs_wgrad<3>), grid, dim3(kThreads), 0, (hipStream_t)stream, p);
-    HIP_TRY(hipGetLastError());
-    const size_t n = (size_t)Co * Ci * KT;
-    hipLaunchKernelGGL(k_fs_wgrad_reduce, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, workspace, dw, n,
-                       kWgSplits, accumulate);
-    if (db) hipLaunchKernelGGL(k_fs_wgrad_reduce, dim3((unsigned)((Co + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.part_b, db, (size_t)Co,
+    for (int tap0 = 0; tap0 < KT; tap0 += 3) {
+        const int ntap = std::min(3, KT - tap0);
+        FsWgradParams p{};
+        p.dy = dy; p.x = x; p.part = workspace; p.part_b = (db && tap0 == 0) ? part_b : nullptr;
+        p.B = B; p.Ci = Ci; p.Co = Co; p.dil = dil; p.pad = pad - tap0 * dil; p.T = T; p.TS = fs_ts(T); p.nsplit = kWgSplits;
+        if (KT == 1) hipLaunchKernelGGL((k_fs_wgrad<1>), grid, dim3(kThreads), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((k_fs_wgrad<3>), grid, dim3(kThreads), 0, (hipStream_t)stream, p);
+        HIP_TRY(hipGetLastError());
+        const size_t nrow = (size_t)Co * Ci;
+        hipLaunchKernelGGL(k_fs_wgrad_reduce_taps, dim3((unsigned)std::min<size_t>((nrow * ntap + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)workspace, dw, nrow, gk, ntap, KT, tap0, kWgSplits, accumulate);
+    }
+    if (db) hipLaunchKernelGGL(k_fs_wgrad_reduce, dim3((unsigned)((Co + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part_b, db, (size_t)Co,
                                kWgSplits, accumulate);
     HIP_TRY(hipGetLastError());
     return DSD_OK;

@@ -497,6 +497,20 @@ __global__ void k_fs_wgrad_reduce(const float* __restrict__ part, float* __restr
     }
 }
 
+// the same for a GROUP of taps: part [nsplit][nrow][gk] (gk taps computed, the first ntap of them valid) -> dw [nrow][KT] at taps tap0 .. tap0 + ntap
+__global__ void k_fs_wgrad_reduce_taps(const float* __restrict__ part, float* __restrict__ dw, size_t nrow, int gk, int ntap, int KT, int tap0, int nsplit,
+                                       int accumulate) {
+    const size_t n = nrow * ntap;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / ntap;
+        const int k = (int)(i - row * ntap);
+        float* d = dw + row * KT + tap0 + k;
+        float s = accumulate ? *d : 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)sp * nrow + row) * gk + k];
+        *d = s;
+    }
+}
+
 // db[c] = sum_b sum_t dy[b][c][t] (bias gradient): one wave per channel, fixed summation order
 __global__ void k_fs_bias_grad(const float* __restrict__ dy, float* __restrict__ db, int B, int C, int T, int TS, int accumulate) {
     const int c = blockIdx.x, lane = threadIdx.x;

@@ -86,6 +86,8 @@ def conv1d_cm(x: torch.Tensor, T: int, weight: torch.Tensor, packed: PackedWeigh
               scale: float = 1.0, act: str = 'none', residual: Optional[torch.Tensor] = None, keep: Optional[torch.Tensor] = None):
     """y = act(scale * (W * x + bias)) (+ residual) (* keep): nn.Conv1d 'SAME' / nn.Linear on a cm tensor."""
     _need_hip(x, 'conv1d')
+    if _needs_grad(x, weight, bias, residual):
+        return _conv1d_cm_train(x, T, weight, packed, bias, scale, act, residual, keep)
     lib = _lib.load()
     B, Ci, TS = x.shape
     Co = weight.shape[0]
@@ -103,6 +105,12 @@ def conv1d_cm(x: torch.Tensor, T: int, weight: torch.Tensor, packed: PackedWeigh
 def layer_norm_cm(x: torch.Tensor, T: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *, relu_in: bool = False,
                   keep: Optional[torch.Tensor] = None):
     _need_hip(x, 'layer_norm')
+    if _needs_grad(x, gamma, beta):
+        return _LayerNormCM.apply(x, gamma, beta, T, float(eps), bool(relu_in), keep)
+    return _layer_norm_raw(x, T, gamma, beta, eps, relu_in, keep)
+
+
+def _layer_norm_raw(x, T, gamma, beta, eps, relu_in, keep):
     lib = _lib.load()
     B, Cc, TS = x.shape
     out = torch.empty_like(x)
@@ -114,6 +122,12 @@ def layer_norm_cm(x: torch.Tensor, T: int, gamma: torch.Tensor, beta: torch.Tens
 
 def attention_cm(qkv: torch.Tensor, T: int, key_pad_u8: Optional[torch.Tensor], heads: int):
     _need_hip(qkv, 'attention')
+    if _needs_grad(qkv):
+        return _AttentionCM.apply(qkv, T, key_pad_u8, heads)
+    return _attention_raw(qkv, T, key_pad_u8, heads)
+
+
+def _attention_raw(qkv, T, key_pad_u8, heads):
     lib = _lib.load()
     B, C3, TS = qkv.shape
     out = torch.empty(B, C3 // 3, TS, device=qkv.device, dtype=torch.float32)
@@ -126,6 +140,12 @@ def attention_cm(qkv: torch.Tensor, T: int, key_pad_u8: Optional[torch.Tensor], 
 def to_cm(x_btc: torch.Tensor) -> torch.Tensor:
     """[B,T,C] (any strides) -> channel-major [B][C][TS], zero in [T,TS)."""
     _need_hip(x_btc, 'to_cm')
+    if _needs_grad(x_btc):
+        return _ToCM.apply(x_btc)
+    return _to_cm_raw(x_btc)
+
+
+def _to_cm_raw(x_btc: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x_btc = x_btc.to(torch.float32)
     B, T, Cc = x_btc.shape
@@ -138,12 +158,132 @@ def to_cm(x_btc: torch.Tensor) -> torch.Tensor:
 
 def from_cm(x_cm: torch.Tensor, T: int) -> torch.Tensor:
     _need_hip(x_cm, 'from_cm')
+    if _needs_grad(x_cm):
+        return _FromCM.apply(x_cm, T)
+    return _from_cm_raw(x_cm, T)
+
+
+def _from_cm_raw(x_cm: torch.Tensor, T: int) -> torch.Tensor:
     lib = _lib.load()
     B, Cc, TS = x_cm.shape
     out = torch.empty(B, T, Cc, device=x_cm.device, dtype=torch.float32)
     with torch.cuda.device(x_cm.device):
         _lib.check(lib.dsf_from_channel_major(x_cm.data_ptr(), out.data_ptr(), B, Cc, T, _stream(x_cm.device)), 'dsf_from_channel_major')
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the same operators under autograd (training of FastSpeech2 / FastSpeech2MIDI: the Opencpop e2e configuration trains it jointly with the
+# denoiser - usr/diffsinger_task.py:60-64, :273-300, usr/configs/midi/e2e/opencpop/ds1000.yaml:18).  Forward = the inference kernels;
+# backward = HIP kernels too: convolutions through train._Conv1dCM (data gradient = the conv kernel with the flipped, transposed weight; weight
+# and bias gradient = dsf_conv1d_wgrad), LayerNorm and the attention core through dsf_layer_norm_bwd / dsf_attention_bwd (csrc/fs2_train.hpp),
+# the layout changes are each other's adjoints.  The fused epilogues of the inference convolution (scale, activation, residual, padding mask)
+# are torch element-wise ops here - glue, not contractions.
+# --------------------------------------------------------------------------------------------------------------
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _keep_cm(keep: torch.Tensor, TS: int) -> torch.Tensor:
+    """[B,T] mask -> [B,1,TS] (zero tail) for broadcasting over a cm tensor."""
+    return F.pad(keep, (0, TS - keep.shape[1]))[:, None, :]
+
+
+def _conv1d_cm_train(x, T, weight, packed, bias, scale, act, residual, keep):
+    from .train import ConvCache
+    cache = packed.__dict__.get('train')
+    if cache is None:
+        cache = packed.__dict__['train'] = ConvCache()
+    y = cache(x.contiguous(), weight, bias, T)
+    if scale != 1.0:
+        y = y * scale
+    if act == 'relu':
+        y = F.relu(y)
+    elif act == 'gelu':
+        y = F.gelu(y)
+    elif act == 'mish':
+        y = y * torch.tanh(F.softplus(y))
+    if residual is not None:
+        y = y + residual
+    if keep is not None:
+        y = y * _keep_cm(keep, y.shape[2])
+    return y
+
+
+class _LayerNormCM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, T, eps, relu_in, keep):
+        x = x.contiguous()
+        out = _layer_norm_raw(x, T, gamma.detach(), beta.detach(), eps, relu_in, keep)
+        ctx.save_for_backward(x, gamma.detach())
+        ctx.keep, ctx.T, ctx.eps, ctx.relu_in = keep, T, eps, relu_in
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma = ctx.saved_tensors
+        B, Cc, TS = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(Cc, device=x.device, dtype=torch.float32)
+        db = torch.empty(Cc, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.dsf_ln_bwd_workspace_floats(B, ctx.T), device=x.device, dtype=torch.float32)
+        keep = ctx.keep
+        with torch.cuda.device(x.device):
+            _lib.check(lib.dsf_layer_norm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), keep.data_ptr() if keep is not None else None,
+                                              dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), B, Cc, ctx.T, float(ctx.eps), int(ctx.relu_in),
+                                              _stream(x.device)), 'dsf_layer_norm_bwd')
+        return dx, dg, db, None, None, None, None
+
+
+class _AttentionCM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, T, key_pad_u8, heads):
+        qkv = qkv.contiguous()
+        out = _attention_raw(qkv, T, key_pad_u8, heads)
+        ctx.save_for_backward(qkv)
+        ctx.key_pad, ctx.T, ctx.heads = key_pad_u8, T, heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        qkv, = ctx.saved_tensors
+        B, C3, TS = qkv.shape
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ws = torch.empty(lib.dsf_attention_bwd_workspace_floats(B, ctx.heads, ctx.T), device=qkv.device, dtype=torch.float32)
+        kp = ctx.key_pad
+        with torch.cuda.device(qkv.device):
+            _lib.check(lib.dsf_attention_bwd(qkv.data_ptr(), kp.data_ptr() if kp is not None else None, dout.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
+                                             B, C3 // 3, ctx.heads, ctx.T, _stream(qkv.device)), 'dsf_attention_bwd')
+        return dqkv, None, None, None
+
+
+class _ToCM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_btc):
+        ctx.T = x_btc.shape[1]
+        return _to_cm_raw(x_btc)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _from_cm_raw(g.contiguous(), ctx.T)
+
+
+class _FromCM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cm, T):
+        return _from_cm_raw(x_cm.contiguous(), T)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _to_cm_raw(g), None
+
+
+def _drop(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    return F.dropout(x, p, True) if (training and p > 0) else x
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -29,8 +29,18 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_G
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc/write -o write -- python $R/tools/profile_loop.py 3 > $O/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $O/pmc/sq -o sq -- python $R/tools/profile_loop.py 3 > $O/pmc_sq.log 2>&1
 python $R/tools/pmc_summary.py $O/pmc 'k_loop<1>' $O/loop_pmc.txt $O/loop_pmc.json frames=8192 'kernel_tag=k_loop<1>' round=$TAG commit=$git_rev > $O/pmc_summary.log 2>&1
-rm -rf $O/prof
-find $O/pmc -name '*.db' -delete
+# vocoder row: kernel stats + FETCH / WRITE / SQ passes over the fused resblock-stage kernels (bench.py --row vocoder reads voc_chain_32ch_pmc.json)
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_voc -o voc -- python $R/bench.py --row vocoder --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_voc.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $O/prof_voc/*.db $O/prof_voc/*/*.db 2>/dev/null | head -1) > $O/vocoder_kernel_stats.txt 2>> $O/prof_voc.log
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/pmc_voc/fetch -o fetch -- python $R/bench.py --row vocoder --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_voc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d $O/pmc_voc/write -o write -- python $R/bench.py --row vocoder --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_voc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $O/pmc_voc/sq -o sq -- python $R/bench.py --row vocoder --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_voc_sq.log 2>&1
+for k in 8 16 32; do
+python $R/tools/pmc_summary.py $O/pmc_voc "k_voc_chain<$k" $O/voc_chain_${k}ch_pmc.txt $O/voc_chain_${k}ch_pmc.json "kernel_tag=k_voc_chain<$k" round=$TAG commit=$git_rev >> $O/pmc_summary.log 2>&1
+done
+timeout 200 python tools/voc_chain_timeline.py > $O/voc_chain_timeline.txt 2>&1
+rm -rf $O/prof $O/prof_voc
+find $O/pmc $O/pmc_voc -name '*.db' -delete
 du -sh $O
 tail -15 $O/pytest_gpu.txt | cut -c1-220; tail -3 $O/smoke.txt; cut -c1-600 $O/bench_n1.json; cat $O/shape_sweep.jsonl | cut -c1-260; for row in vocoder fs2 train; do cut -c1-330 $O/bench_row_$row.json; echo; done
 cat $O/mfma_probe4.txt | tail -8; cat $O/hbm_probe.txt | tail -4; tail -5 $O/loop_pmc.txt
