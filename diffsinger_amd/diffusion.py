@@ -326,15 +326,11 @@ class GaussianDiffusion(nn.Module):
         return p_losses(self, x_start, t, cond, noise=noise, nonpadding=nonpadding)
 
     def _forward_train(self, txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, **kwargs):
-        """The training branch of forward (:233-247): fs2(skip_decoder=True) -> t ~ U[0, K_step) -> p_losses.  The reference's
-        FastSpeech2 (inside its tree) runs as it is, with its gradients; the HIP FastSpeech2 is inference-only and acts as a
-        frozen conditioner here."""
-        from .fs2 import FastSpeech2 as HipFS2
-        if isinstance(self.fs2, HipFS2):
-            with torch.no_grad():
-                ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=True, **kwargs)
-        else:
-            ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=False, **kwargs)
+        """The training branch of forward (:233-247): fs2(skip_decoder=True, infer=False) -> t ~ U[0, K_step) -> p_losses.  FastSpeech2 - the
+        reference's inside its tree, or the HIP one - runs under autograd: when its parameters require grad (the e2e configurations,
+        usr/diffsinger_task.py:60-64) the diffusion loss back-propagates through `cond` into it; a frozen FastSpeech2
+        (requires_grad False, the cascade configurations :62-64) costs no graph."""
+        ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=False, **kwargs)
         cond = ret['decoder_inp'].transpose(1, 2)
         b = txt_tokens.shape[0]
         t = torch.randint(0, self.K_step, (b,), device=txt_tokens.device).long()
@@ -365,12 +361,11 @@ class OfflineGaussianDiffusion(GaussianDiffusion):
                 **kwargs):
         if self.fs2 is None:
             raise RuntimeError('no FastSpeech2 attached (self.fs2)')
+        # :295-296 passes infer=True in BOTH branches; FastSpeech2.forward does not read the flag (fs2.py:93-149) - the HIP FastSpeech2 takes it as
+        # "no autograd graph", so the training branch hands it infer=False to keep the reference's gradient flow into a trainable FastSpeech2
         from .fs2 import FastSpeech2 as HipFS2
-        if isinstance(self.fs2, HipFS2) and not infer:          # the HIP FastSpeech2 has no autograd: a frozen conditioner in training
-            with torch.no_grad():
-                ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=True, **kwargs)
-        else:
-            ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=True, **kwargs)
+        ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True,
+                       infer=(infer if isinstance(self.fs2, HipFS2) else True), **kwargs)
         cond = ret['decoder_inp'].transpose(1, 2)
         fs2_mels, target = ref_mels[1], ref_mels[0]
         if not infer:

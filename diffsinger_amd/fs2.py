@@ -1,5 +1,5 @@
 """FastSpeech2 / FastSpeech2MIDI - the conditioner + aux decoder in front of the diffusion hot path (SURVEY.md section 8
-row f1) - as nn.Modules whose INFERENCE forward runs on the HIP kernels of libdsdenoise.so (include/dsf.h).
+row f1) - as nn.Modules whose forward (and, under autograd, backward) runs on the HIP kernels of libdsdenoise.so (include/dsf.h).
 
 Mirrors the reference module tree (paths relative to the reference root) name for name, so a reference checkpoint's
 `model.fs2.*` state_dict loads with strict=True and vice versa:
@@ -13,8 +13,9 @@ Mirrors the reference module tree (paths relative to the reference root) name fo
 What runs where: every contraction (attention projections, the k=9 conv-FFN, predictor convolutions, mel_out), every
 LayerNorm and the softmax-attention core are HIP kernels on a channel-major [B][C][T] layout (>99.9 % of the FLOPs).  The
 index plumbing between them - embedding lookups, the length-regulator gather, padding masks, f0 quantisation - is data
-movement on [B,T,C] tensors and uses torch indexing ops on the device.  Inference only (training = row f3); no CPU path:
-the ops raise when the tensors are not on the MI355X.
+movement on [B,T,C] tensors and uses torch indexing ops on the device.  forward(infer=False) under autograd builds a graph whose
+backward runs on HIP kernels as well (joint training of the e2e configurations); no CPU path: the ops raise when the tensors are
+not on the MI355X.
 
 Not covered (raise NotImplementedError): speaker embeddings (use_spk_id / use_spk_embed), energy embedding, pitch_ar,
 pitch_type 'ph', dur_loss other than 'mse', ffn_padding 'LEFT', norm 'bn' - none is used by a shipped DiffSpeech / DiffSinger
@@ -391,23 +392,32 @@ class TransformerFFNLayer(nn.Module):
 
 
 class EncSALayer(nn.Module):
-    def __init__(self, c, num_heads, kernel_size=9, padding='SAME', act='gelu'):
+    def __init__(self, c, num_heads, kernel_size=9, padding='SAME', act='gelu', dropout=None):
         super().__init__()
         self.c, self.num_heads = c, num_heads
+        self.dropout = hparams['dropout'] if dropout is None else dropout      # tts_modules.py:17-26: dropout = relu_dropout, attention_dropout 0
         self.layer_norm1 = nn.LayerNorm(c)
         self.self_attn = MultiheadAttention(c, num_heads)
         self.layer_norm2 = nn.LayerNorm(c)
         self.ffn = TransformerFFNLayer(c, 4 * c, kernel_size=kernel_size, padding=padding, act=act)
 
     def forward_cm(self, x, T, keep, pad_u8):
-        """EncSALayer.forward (common_layers.py:565-588), eval mode, on a cm tensor."""
+        """EncSALayer.forward (common_layers.py:565-588) on a cm tensor; with self.training and dropout > 0 the three dropouts of the reference
+        (:576, TransformerFFNLayer :520, :584) sit between the convolutions and their residual adds, so those run unfused."""
         a, f = self.self_attn, self.ffn
+        p = self.dropout if self.training else 0.0
         y = layer_norm_cm(x, T, self.layer_norm1.weight, self.layer_norm1.bias, 1e-5)
         qkv = conv1d_cm(y, T, a.in_proj_weight, a._pin)
         o = attention_cm(qkv, T, pad_u8, self.num_heads)
-        x = conv1d_cm(o, T, a.out_proj.weight, a._pout, residual=x, keep=keep)
+        if p > 0:
+            x = (x + F.dropout(conv1d_cm(o, T, a.out_proj.weight, a._pout), p, True)) * _keep_cm(keep, x.shape[2])
+        else:
+            x = conv1d_cm(o, T, a.out_proj.weight, a._pout, residual=x, keep=keep)
         y = layer_norm_cm(x, T, self.layer_norm2.weight, self.layer_norm2.bias, 1e-5)
         hdn = conv1d_cm(y, T, f.ffn_1.weight, f._p1, f.ffn_1.bias, scale=f.kernel_size ** -0.5, act=f.act)
+        if p > 0:
+            out = conv1d_cm(F.dropout(hdn, p, True), T, f.ffn_2.weight, f._p2, f.ffn_2.bias)
+            return (x + F.dropout(out, p, True)) * _keep_cm(keep, x.shape[2])
         return conv1d_cm(hdn, T, f.ffn_2.weight, f._p2, f.ffn_2.bias, residual=x, keep=keep)
 
 
@@ -437,6 +447,7 @@ class FFTBlocks(nn.Module):
         pad_u8 = padding_mask.to(torch.uint8).contiguous()
         if self.use_pos_embed:
             x = x + self.pos_embed_alpha * self.embed_positions(x[..., 0])
+            x = _drop(x, hparams['dropout'], self.training)                          # tts_modules.py:293
         xc = to_cm(x * keep[:, :, None])
         for layer in self.layers:
             xc = layer.op.forward_cm(xc, T, keep, pad_u8)
@@ -466,7 +477,7 @@ class FastspeechEncoder(FFTBlocks):
             if hparams.get('rel_pos'):
                 raise NotImplementedError('rel_pos without use_midi (the reference would scale the integer tokens)')
             x = x + self.embed_positions(txt_tokens)
-        return x
+        return _drop(x, hparams['dropout'], self.training)                           # tts_modules.py:346
 
     def forward(self, txt_tokens):
         return FFTBlocks.forward(self, self.forward_embedding(txt_tokens), txt_tokens.eq(self.padding_idx))
@@ -481,7 +492,7 @@ class FastspeechMIDIEncoder(FastspeechEncoder):
                 x = self.embed_positions(x)
             else:
                 x = x + self.embed_positions(txt_tokens)
-        return x
+        return _drop(x, hparams['dropout'], self.training)                           # diffsinger_midi/fs2.py:28
 
     def forward(self, txt_tokens, midi_embedding, midi_dur_embedding, slur_embedding):
         x = self.forward_embedding(txt_tokens, midi_embedding, midi_dur_embedding, slur_embedding)
@@ -518,6 +529,7 @@ def _run_pred_convs(convs, packs, xc, T, keep):
         conv, ln = seq[1], seq[3]
         y = conv1d_cm(xc, T, conv.weight, pk, conv.bias)            # ReLU is fused into the LayerNorm kernel's load
         xc = layer_norm_cm(y, T, ln.weight, ln.bias, 1e-12, relu_in=True, keep=keep)
+        xc = seq[4](xc)                                             # nn.Dropout(predictor_dropout): identity in eval mode (tts_modules.py:94, :216)
     return xc
 
 
@@ -678,11 +690,18 @@ class FastSpeech2(nn.Module):
     def _encode(self, txt_tokens, **kwargs):
         return self.encoder(txt_tokens)
 
-    @torch.no_grad()
     def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None, skip_decoder=False,
                 spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, **kwargs):
-        if not infer:
-            raise NotImplementedError('the HIP FastSpeech2 is inference-only (training = SURVEY section 8 row f3)')
+        """fs2.py:93-149.  infer=True (or torch.no_grad()): the inference kernels with their fused epilogues.  infer=False with autograd on:
+        the same forward as an autograd graph whose backward runs on HIP kernels too (the operator layer above) - what DiffSingerTask /
+        DiffSingerMIDITask train when `fs2_ckpt` is empty (usr/diffsinger_task.py:60-64, :273-300); the gradient scaling of the predictor
+        inputs (`predictor_grad`, fs2.py:153, :194) is part of the graph."""
+        if infer or not torch.is_grad_enabled():
+            with torch.no_grad():
+                return self._forward(txt_tokens, mel2ph, f0, uv, skip_decoder, infer, **kwargs)
+        return self._forward(txt_tokens, mel2ph, f0, uv, skip_decoder, infer, **kwargs)
+
+    def _forward(self, txt_tokens, mel2ph, f0, uv, skip_decoder, infer, **kwargs):
         ret = {}
         encoder_out = self._encode(txt_tokens, **kwargs)                                        # [B,T_txt,H]
         src_nonpadding = (txt_tokens > 0).float()[:, :, None]
@@ -700,8 +719,16 @@ class FastSpeech2(nn.Module):
         ret['mel_out'] = self.run_decoder(decoder_inp, tgt_nonpadding, ret, infer=infer, **kwargs)
         return ret
 
+    @staticmethod
+    def _scale_grad(x):
+        """x.detach() + predictor_grad * (x - x.detach()): the value of x, predictor_grad times its gradient (fs2.py:153, :194)."""
+        if not (torch.is_grad_enabled() and x.requires_grad):
+            return x
+        return x.detach() + hparams['predictor_grad'] * (x - x.detach())
+
     def add_dur(self, dur_input, mel2ph, txt_tokens, ret):
         src_padding = txt_tokens == 0
+        dur_input = self._scale_grad(dur_input)
         if mel2ph is None:
             dur, xs = self.dur_predictor.inference(dur_input, src_padding)
             ret['dur'], ret['dur_choice'] = xs, dur
@@ -712,7 +739,8 @@ class FastSpeech2(nn.Module):
         return mel2ph
 
     def add_pitch(self, decoder_inp, f0, uv, mel2ph, ret, encoder_out=None):
-        """fs2.py:183-231, inference."""
+        """fs2.py:183-231."""
+        decoder_inp = self._scale_grad(decoder_inp)
         pitch_padding = mel2ph == 0
         given = f0 is not None
         if hparams['pitch_type'] == 'cwt':

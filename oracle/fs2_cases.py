@@ -20,6 +20,8 @@ CASES = {
     'fs2_midi_cascade_teacher': dict(preset='opencpop_ds60_rel', mode='teacher', B=2, T_txt=23, seed=205),
     # FastSpeech2MIDI e2e (no pitch embedding), predicted durations
     'fs2_midi_e2e_free': dict(preset='opencpop_ds1000', mode='free', B=3, T_txt=18, seed=206),
+    # ... and teacher-forced: the forward of the e2e TRAINING step (BASELINE configs[3]; usr/diffsinger_task.py:273-300)
+    'fs2_midi_e2e_teacher': dict(preset='opencpop_ds1000', mode='teacher', B=2, T_txt=20, seed=207),
 }
 
 OUT_KEYS = ['encoder_out', 'mel2ph', 'dur', 'decoder_inp', 'mel_out', 'pitch_pred', 'cwt', 'f0_denorm']

@@ -257,10 +257,19 @@ def cwt2f0_norm(cwt_spec, mean, std, mel2ph, hp):
     return norm_f0(f0, None, hp)
 
 
+def scale_grad(x, g):
+    """fs2.py:153, :194: `x.detach() + predictor_grad * (x - x.detach())` - the value of x (bit for bit: x - x is 0), predictor_grad times its
+    gradient.  Only under autograd (the gradient pin of the training path, oracle/check_fs2_grad.py)."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    return x.detach() + g * (x - x.detach())
+
+
 def add_pitch(p, hp, decoder_inp, f0, uv, mel2ph, ret, encoder_out):
-    """FastSpeech2.add_pitch (fs2.py:183-231), inference."""
+    """FastSpeech2.add_pitch (fs2.py:183-231)."""
     if hp['pitch_type'] == 'ph' or hp.get('pitch_ar'):
         raise NotImplementedError('pitch_type ph / pitch_ar')
+    decoder_inp = scale_grad(decoder_inp, hp['predictor_grad'])
     pitch_padding = mel2ph == 0
     given_f0 = f0 is not None
     if hp['pitch_type'] == 'cwt':
@@ -315,7 +324,7 @@ def fs2_forward(p: Dict[str, torch.Tensor], hp: dict, txt_tokens, mel2ph=None, f
         encoder_out = encoder(p, hp, txt_tokens)
     ret['encoder_out'] = encoder_out
     src_nonpadding = (txt_tokens > 0).float()[:, :, None]
-    dur_inp = encoder_out * src_nonpadding
+    dur_inp = scale_grad(encoder_out * src_nonpadding, hp['predictor_grad'])
     if mel2ph is None:
         dur, xs = duration_predictor_inference(p, hp, dur_inp, txt_tokens == 0)
         ret['dur'], ret['dur_choice'] = xs, dur
