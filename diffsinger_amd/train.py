@@ -67,12 +67,17 @@ class _Conv1dCM(torch.autograd.Function):
                 wt = cache.get('bwd_w')
                 from .train_dist import param_generation
                 tag = (weight.data_ptr(), weight._version, param_generation())
-                if wt is None or cache.get('bwd_tag') != tag:
-                    wt = w3.detach().flip(2).transpose(0, 1).contiguous()
+                Cop = (Co + 7) // 8 * 8                         # the convolution kernel contracts over multiples of 8 channels: a narrow output
+                if wt is None or cache.get('bwd_tag') != tag:   # (the duration predictor's Linear(C, 1)) is padded with zero channels
+                    wt = w3.detach().flip(2).transpose(0, 1)
+                    if Cop != Co:
+                        wt = F.pad(wt, (0, 0, 0, Cop - Co))
+                    wt = wt.contiguous()
                     cache['bwd_w'], cache['bwd_tag'] = wt, tag
                 wtp = cache['bwd'].get(wt)
+                dyd = dy if Cop == Co else F.pad(dy, (0, 0, 0, Cop - Co))
                 dx = torch.empty(B, Ci, TS, device=dev, dtype=torch.float32)
-                _lib.check(lib.dsf_conv1d_dilated(dy.data_ptr(), wtp.data_ptr(), None, dx.data_ptr(), B, Co, Ci, K, dil, T, _stream(dev)),
+                _lib.check(lib.dsf_conv1d_dilated(dyd.data_ptr(), wtp.data_ptr(), None, dx.data_ptr(), B, Cop, Ci, K, dil, T, _stream(dev)),
                            'dsf_conv1d_dilated (dgrad)')
             want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
@@ -209,9 +214,20 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
     xm = F.pad(spec[:, 0], pad)                                     # [B][M][TS], zero tail
     cm = F.pad(cond, pad).contiguous()                              # [B][H][TS]
     x = F.relu(conv('in', xm, net.input_projection))                # :116-118 (every conv output has the zero tail; relu keeps it)
+    # the step-embedding MLP and the layers' step projections (net.py:94-98, :119-120, :67) on the HIP convolution operators too (round 2 left
+    # these [B, C] products to torch = rocBLAS: vendor BLAS on the path): the B utterances are the "frames" of one row
+    def linear_rows(name, v, weight, bias):
+        vc = v.t().contiguous()[None]                               # [1][Cin][B]
+        n = vc.shape[2]
+        vc = F.pad(vc, (0, padded_frames(n) - n))
+        c = caches.get(name)
+        if c is None:
+            c = caches[name] = ConvCache()
+        return c(vc, weight, bias, n)[0, :, :n].t()                 # [B][Cout]
+
     d = step_embedding(diffusion_step, net.residual_channels)       # :119
-    h = F.linear(d, net.mlp[0].weight, net.mlp[0].bias)
-    d = F.linear(h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)      # :120 (Mish)
+    h = linear_rows('mlp0', d, net.mlp[0].weight, net.mlp[0].bias)
+    d = linear_rows('mlp2', h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)      # :120 (Mish)
     from . import train_fused
     if train_fused.enabled() and train_fused.supported(net):
         # the whole residual stack as ONE autograd node on the fused kernels (csrc/train_kernels.hpp); the step projections of all layers
@@ -219,12 +235,12 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
         layers = list(net.residual_layers)
         wd = torch.cat([l.diffusion_projection.weight for l in layers], 0)
         bd = torch.cat([l.diffusion_projection.bias for l in layers], 0)
-        step_all = F.linear(d, wd, bd).view(B, len(layers), net.residual_channels)
+        step_all = linear_rows('dp_all', d, wd, bd).reshape(B, len(layers), net.residual_channels)
         skip = train_fused.residual_stack(net, x, cm, step_all, T)
     else:
         skip = None
         for l, layer in enumerate(net.residual_layers):             # ResidualBlock.forward :66-78
-            ds = F.linear(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)
+            ds = linear_rows(f'l{l}.dp', d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)
             y = _AddStep.apply(x, ds, T)
             a = conv(f'l{l}.dc', y, layer.dilated_conv, layer.dilation) + conv(f'l{l}.cp', cm, layer.conditioner_projection)
             g = _Gate.apply(a, T)

@@ -114,6 +114,7 @@ def test_offline_gaussian_diffusion_forward_train_matches_oracle_loss():
     K = 51
     case, gd, hp, params, inp, pre, cfg = _fs2_and_gd('fs2_popcs_teacher', OfflineGaussianDiffusion, timesteps=pre_timesteps('popcs_ds_beta6'), K_step=K)
     gd.train()
+    gd.fs2.eval()                                             # dropout off in the conditioner: the oracle it is compared with has none
     B, T = inp['mel2ph'].shape
     g = torch.Generator().manual_seed(78)
     smin = torch.tensor(pre['spec_min'])[None, None, :]
@@ -165,6 +166,7 @@ def test_legacy_gaussian_diffusion_forward_both_branches():
     assert err <= 1e-4
     # infer=False: t ~ U[0, num_timesteps), L1 with the (mel2ph != 0) factor broadcast exactly like the reference writes it (:284-286, :304-305)
     gd.train()
+    gd.fs2.eval()                                             # dropout off in the conditioner: the oracle it is compared with has none
     target = (torch.clamp(torch.randn(B, T, 80, generator=g) * 0.5, -1, 1) + 1) / 2 * (smax - smin) + smin
     torch.manual_seed(6)
     loss = gd(inp['txt_tokens'].to(DEV), ref_mels=target.to(DEV), infer=False, **kw)['diff_loss']
