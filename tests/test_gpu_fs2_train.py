@@ -131,7 +131,7 @@ def test_training_forward_and_every_parameter_gradient_match_the_oracle(name):
     print(f'{name}: loss {float(lh.detach()):.6f} (oracle {float(lo.detach()):.6f}), forward {e_fwd}, {n} parameter gradients, worst rel err {worst[1]:.2e} at {worst[0]}')
     assert abs(float(lh.detach()) - float(lo.detach())) <= 2e-5 * max(1.0, abs(float(lo.detach())))
     assert all(v <= 2e-5 for v in e_fwd.values())
-    assert n >= 60 and worst[1] <= 1e-5, worst
+    assert n >= 60 and worst[1] <= 5e-6, worst                  # every FastSpeech2 parameter gradient within 5e-6 (relative)
 
 
 def test_e2e_training_step_flows_from_the_diffusion_loss_into_fastspeech2():
@@ -186,7 +186,7 @@ def test_e2e_training_step_flows_from_the_diffusion_loss_into_fastspeech2():
             worst = (k, e)
     print(f'e2e step: diff_loss {float(loss.detach()):.6f} (oracle {float(loss_ref.detach()):.6f}); {n} FastSpeech2MIDI gradients through cond, worst rel err {worst[1]:.2e} at {worst[0]}')
     assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 5e-6 * abs(float(loss_ref.detach()))
-    assert n >= 40 and worst[1] <= 5e-5, worst
+    assert n >= 40 and worst[1] <= 1e-5, worst
     # and the module's forward(infer=False) returns the loss dict key the task reads
     out = gd(inp['txt_tokens'].to(DEV), ref_mels=mel.to(DEV), infer=False, **{k: v.clone().to(DEV) for k, v in inp.items() if k != 'txt_tokens'})
     assert out['diff_loss'].requires_grad and torch.isfinite(out['diff_loss'])
