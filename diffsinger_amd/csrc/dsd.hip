@@ -71,6 +71,7 @@ struct dsd_handle {
 
     // packed weights (device)
     float4 *w1p = nullptr, *w2p = nullptr, *wcp = nullptr, *b1p = nullptr, *bskp = nullptr;
+    float4* w1q = nullptr;      // dilated conv once more, 16 gate rows + their 16 filter rows per 32-row block (G = 16 latency kernels, dsd_lat.hpp)
     float *b2raw = nullptr, *bsum = nullptr;   // output_projection biases [L][2C]; sum over layers of their skip halves [C]
     float4 *winp = nullptr, *binp = nullptr, *wsp = nullptr, *bsp = nullptr, *woutp = nullptr, *boutp = nullptr;
     // raw copies for the step table
@@ -255,7 +256,7 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     dev_free(h->w1s); dev_free(h->w2s);
-    dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->bskp); dev_free(h->b2raw); dev_free(h->bsum);
+    dev_free(h->w1q); dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->bskp); dev_free(h->b2raw); dev_free(h->bsum);
     dev_free(h->winp); dev_free(h->binp); dev_free(h->wsp); dev_free(h->bsp); dev_free(h->woutp); dev_free(h->boutp);
     dev_free(h->mlp0_w); dev_free(h->mlp0_b); dev_free(h->mlp2_w); dev_free(h->mlp2_b); dev_free(h->dp_w); dev_free(h->dp_b);
     dev_free(h->ds_table); dev_free(h->spec_min_d); dev_free(h->spec_max_d);
@@ -282,13 +283,13 @@ extern "C" int dsd_set_layer_tile(dsd_handle* h, int32_t frames) {
 
 extern "C" int64_t dsd_device_bytes(dsd_handle* h) { return h ? h->bytes + h->bytes_ws : 0; }
 
-// Row split G of the latency kernels for the prepared batch, 0 = not on that path.  Automatic mode: the largest G in {8, 4, 2} that
+// Row split G of the latency kernels for the prepared batch, 0 = not on that path.  Automatic mode: the largest G in {16, 8, 4, 2} that
 // still gives every workgroup a CU of its own - i.e. only batches that leave at least half of the chip idle.
 static int lat_g(const dsd_handle* h) {
     if (h->split_mode || h->layer_tile_req || h->lat_req == 0 || h->loop_mode < 2) return 0;
-    int g = (8 * h->ntiles <= h->n_cu) ? 8 : (4 * h->ntiles <= h->n_cu) ? 4 : (2 * h->ntiles <= h->n_cu) ? 2 : 0;
+    int g = (16 * h->ntiles <= h->n_cu) ? 16 : (8 * h->ntiles <= h->n_cu) ? 8 : (4 * h->ntiles <= h->n_cu) ? 4 : (2 * h->ntiles <= h->n_cu) ? 2 : 0;
     if (h->loop_mode == 3 && g == 0) g = 2;
-    if (g && (h->lat_req == 2 || h->lat_req == 4 || h->lat_req == 8)) g = h->lat_req;
+    if (g && (h->lat_req == 2 || h->lat_req == 4 || h->lat_req == 8 || h->lat_req == 16)) g = h->lat_req;
     return g;
 }
 
@@ -413,6 +414,7 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
     const int L = h->L, M = h->M;
     if (!h->w1p) {
         DSD_TRY(dev_alloc(h, &h->w1p, (size_t)L * 4 * 96 * 256 + kWeightSlack));
+        DSD_TRY(dev_alloc(h, &h->w1q, (size_t)L * 16 * 96 * 64 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->w2p, (size_t)L * 4 * 32 * 256 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->wcp, (size_t)L * 4 * 32 * 256 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->b1p, (size_t)L * 4 * 4 * 8));
@@ -440,6 +442,7 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
             return fail(DSD_ERR_INVALID, "dsd_load_weights: null tensor in layer %d", l);
         // gate rows [0,C) / filter rows [C,2C) split across waves so each wave owns matching pairs
         DSD_TRY(pack_a(s, w->dilated_conv_w[l], h->w1p + (size_t)l * 4 * 96 * 256, 4, 3, 32, 4, 1, kC, 2 * kC, kC, 3 * kC, 3));
+        DSD_TRY(pack_a(s, w->dilated_conv_w[l], h->w1q + (size_t)l * 16 * 96 * 64, 16, 3, 32, 1, 2, kC, 2 * kC, kC, 3 * kC, 3));
         DSD_TRY(pack_a(s, w->conditioner_projection_w[l], h->wcp + (size_t)l * 4 * 32 * 256, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1));
         DSD_TRY(pack_a(s, w->output_projection_w[l], h->w2p + (size_t)l * 4 * 32 * 256, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1));
         DSD_TRY(pack_bias(s, w->dilated_conv_b[l], w->conditioner_projection_b[l], h->b1p + (size_t)l * 128, 4, 4, 1, kC, 2 * kC));
@@ -602,6 +605,7 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
         q.x_out = (l & 1) ? h->xa : h->xb;
         q.gbuf = h->gbuf;
         q.w1p = h->w1p + (size_t)l * 4 * 96 * 256;
+        q.w1q = h->w1q + (size_t)l * 16 * 96 * 64;
         q.w2p = h->w2p + (size_t)l * 4 * 32 * 256;
         q.b2 = h->b2raw + (size_t)l * 2 * kC;
         q.cp = h->cp + (size_t)l * h->ntiles * 4096;
@@ -610,7 +614,7 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
         q.t_dev = t_dev; q.t_uniform = t_uniform; q.ds_tstride = h->L * kC;
         q.T = h->T; q.ntile32 = h->ntile32; q.ntiles = h->ntiles; q.dil = h->dil[l];
         q.first = (l == 0); q.last = (l == h->L - 1);
-        if (G == 8) launch_lat<8>(q, s); else if (G == 4) launch_lat<4>(q, s); else launch_lat<2>(q, s);
+        if (G == 16) launch_lat<16>(q, s); else if (G == 8) launch_lat<8>(q, s); else if (G == 4) launch_lat<4>(q, s); else launch_lat<2>(q, s);
         HIP_TRY(hipGetLastError());
         return DSD_OK;
     }
@@ -674,7 +678,7 @@ static HeadParams head_base(dsd_handle* h) {
 
 template <int MODE>
 static int launch_head(dsd_handle* h, const HeadParams& p, bool fuse, hipStream_t s) {
-    if (MODE != HEAD_EPS && lat_g(h) == 8) {
+    if (MODE != HEAD_EPS && lat_g(h) >= 8) {
         // G = 8 latency path: the head row-split like the layers (dsd_lat.hpp): skip projection on 8 workgroups per tile -> final projection +
         // sampler update on 3 -> next input projection on 8.  hbuf = the gate buffer (free behind the last layer), pbuf = the x buffer
         // the last layer read (the other one receives the next x)
@@ -1095,7 +1099,8 @@ extern "C" int dsd_set_loop_mode(dsd_handle* h, int32_t mode) {
 }
 
 extern "C" int dsd_set_lat_split(dsd_handle* h, int32_t g) {
-    if (!h || !(g == -1 || g == 0 || g == 2 || g == 4 || g == 8)) return fail(DSD_ERR_INVALID, "dsd_set_lat_split: g must be -1 (by batch size), 0, 2, 4 or 8");
+    if (!h || !(g == -1 || g == 0 || g == 2 || g == 4 || g == 8 || g == 16))
+        return fail(DSD_ERR_INVALID, "dsd_set_lat_split: g must be -1 (by batch size), 0, 2, 4, 8 or 16");
     h->lat_req = g;
     return DSD_OK;
 }

@@ -903,6 +903,7 @@ constexpr int kHeadLdsBytes = (2 * kC * 32 + kMPad * 32) * (int)sizeof(float);
 // Generic A-operand pack: dst[(w, kc, mb, lane, s)] = src[row(w,mb,lane) * row_stride + col(kc,lane,s) * col_stride + tap]
 // rows: split == 1: mb < nmb/2 -> base_lo + (nmb/2*32)*w + 32*mb + i ; else base_hi + (nmb/2*32)*w + 32*(mb-nmb/2) + i
 //       split == 0: rows_per_wave*w + 32*mb + i
+//       split == 2: block b = w * nmb + mb holds rows 16 b + (0..15) and hi_base + 16 b + (0..15)
 struct PackParams {
     const float* src; float* dst;
     int nw, nkc, nmb;            // destination dims [nw][ntap*nkc][nmb][64][4]
@@ -928,7 +929,10 @@ __global__ void k_pack_a(const PackParams p) {
         }
         const int i = lane & 31, h = lane >> 5;
         int row;
-        if (p.split) {
+        if (p.split == 2) {
+            // one 32-row block = 16 low rows and THEIR 16 high rows (a gate half-block with its filter half-block: the G = 16 latency kernels)
+            row = (i < 16) ? 16 * (w * p.nmb + mb) + i : p.hi_base + 16 * (w * p.nmb + mb) + (i - 16);
+        } else if (p.split) {
             const int half = p.nmb / 2;
             row = (mb < half) ? (half * 32) * w + 32 * mb + i : p.hi_base + (half * 32) * w + 32 * (mb - half) + i;
         } else {

@@ -23,7 +23,12 @@
 //   G = 8: workgroup g <- stream g / 2, pair g % 2; conv: wave = (gate | filter, K half) - the two K halves are summed through LDS
 //          (the ONLY place where the summation order differs from k_layer: (first half) + (second half) instead of one k-ordered chain);
 //          out-proj: wave = (residual | skip block, K half), summed the same way.
-// G = 2 and G = 4 are bit-identical to k_layer; G = 8 agrees to reduction-order noise (tests/test_gpu_latency.py).
+//   G = 16 (round 3: one utterance of <= 512 frames = 16 tiles on ALL 256 CUs): conv: workgroup g <- ONE 32-row block of a second packing
+//          (w1q) that holds 16 gate rows and THEIR 16 filter rows - register r (gate) and r + 8 (filter) of a lane are a pair, the gate
+//          never leaves the lane; the four waves split K = 768 four ways (24 chunks = 96 MFMAs each, half the G = 8 kernel's matrix time),
+//          partial blocks summed through LDS in wave order (lat_ksum4).  out-proj: workgroup g <- row block (stream g / 4, block g % 4), the
+//          four waves split K = 256 four ways.
+// G = 2 and G = 4 are bit-identical to k_layer; G = 8 and G = 16 agree to reduction-order noise (tests/test_gpu_latency.py).
 #pragma once
 #include "dsd_kernels.hpp"
 
@@ -34,6 +39,7 @@ struct LatParams {
     float* x_out;           // [tiles][C][32]
     float* gbuf;            // [tiles][C][32] gate tile (k_lat_conv -> k_lat_out)
     const float4* w1p;      // this layer's dilated conv, packed [w4][kc96: centre tap first, conv_chunk()][mb4][lane64]
+    const float4* w1q;      // the same weights for G = 16: [b16][kc96][lane64], block b16 = gate rows [16 b16, +16) + their filter rows
     const float4* w2p;      // this layer's output projection, packed [w4][kc32][mb4][lane64]
     const float* b2;        // output projection bias [2C] (residual half)
     const float4* cp;       // this layer's hoisted conditioner projection (+ biases) [tile][w4][mb4][q4][lane64]
@@ -45,7 +51,7 @@ struct LatParams {
 };
 
 constexpr int kLatConvLdsBytes = (kC * (32 + 2 * kHalo) + 3 * 32 * 32) * (int)sizeof(float);     // y tile + K-half partials [2] + filter [1..2]
-constexpr int kLatOutLdsBytes = (kC * 32 + 2 * 32 * 32) * (int)sizeof(float);                     // gate tile + K-half partials [2] (G = 8)
+constexpr int kLatOutLdsBytes = (kC * 32 + 3 * 32 * 32) * (int)sizeof(float);                     // gate tile + K partials [2] (G = 8) / [3] (G = 16)
 
 // workgroup -> (tile, g): the G workgroups of a tile read the same x / gate tile, so they are placed behind the same L2 (workgroups
 // are dealt round-robin to the 8 XCDs by linear id): XCD x takes tiles x, x + 8, ...   grid = ceil(ntiles / 8) * 8 * G
@@ -61,10 +67,12 @@ __host__ __device__ inline int lat_grid(int ntiles, int G) { return (ntiles + 7)
 // G = 8 splits the K range between wave pairs: the first chunk of a wave is a run-time value, so its chunk -> pointer map is the
 // branch-free form (ConvB<LD, true>; the branching one let hipcc sink the weight prefetch to its use: 39.4 -> 32.9 ms per 1 x 512 K = 100
 // call, bit-identical, profiles/r05_fm_lat_bf_probe_1x512.json)
+__device__ __forceinline__ void lat_ksum4(f32x16& acc, float* red, int wv, int j, int h);
+
 template <int G>
 __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
-    constexpr bool BF = (G == 8);
-    static_assert(G == 2 || G == 4 || G == 8, "row split");
+    constexpr bool BF = (G >= 8);
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "row split");
     constexpr int LD = 32 + 2 * kHalo, TILE = kC * 32;
     constexpr int NMB = (G == 2) ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -80,14 +88,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
 
     // role of this wave
     int w4, mb0, kbeg;                      // packed stream, first row block, first chunk
-    constexpr int NCH = (G == 8) ? 48 : 96; // chunks per wave
+    constexpr int NCH = (G == 16) ? 24 : (G == 8) ? 48 : 96; // chunks per wave
     if (G == 2) { w4 = 2 * g + (wv >> 1); mb0 = wv & 1; kbeg = 0; }
     else if (G == 4) { w4 = g; mb0 = wv; kbeg = 0; }
-    else { w4 = g >> 1; mb0 = (g & 1) + 2 * (wv & 1); kbeg = 48 * (wv >> 1); }
+    else if (G == 8) { w4 = g >> 1; mb0 = (g & 1) + 2 * (wv & 1); kbeg = 48 * (wv >> 1); }
+    else { w4 = g >> 2; mb0 = (g & 3) >> 1; kbeg = 24 * wv; }       // G = 16: (w4, mb0) = the standard gate block the 16 gate rows of block g lie in
 
     // the weight stream does not depend on x: its first chunks are requested before the tile is staged
     const ConvB<LD, BF> bof{ytile + 4 * h * LD + kHalo + j, dil, kbeg};
-    GemmPipe<NMB, 1, LD, 256, 6, ConvB<LD, BF>, 2> pipe(p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, bof);
+    constexpr int ASTR = (G == 16) ? 64 : 256;                      // float4 between consecutive chunks of the packed stream
+    const float4* abase = (G == 16) ? p.w1q + ((size_t)g * 96 + kbeg) * 64 : p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64;
+    GemmPipe<NMB, 1, LD, ASTR, 6, ConvB<LD, BF>, 2> pipe(abase, lane, NCH, bof);
     pipe.start_a();
 
     // stage y = x + step_proj (zero at frames outside [0, T): the conv's zero padding applies to y, net.py:69-71)
@@ -142,10 +153,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) cv[q] = cf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.T > 0) {          // always true; a load in its own block cannot be sunk into the (conditional) blocks of its uses behind the MFMAs
+        if (G == 16) {
+            // gate row 16 g + i sits in the standard block (w4, mb0) at row 16 (g & 1) + i: register r of THIS lane there is r + 8 (g & 1) ->
+            // quads q' = q + 2 (g & 1), q = 0, 1; the filter rows are the same quads of block mb0 + 2.  Only wave 0 finishes the block.
+            if (wv == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            cv[q] = cpl[(mb0 * 4 + q) * 64];
-            if (G == 2) cf[q] = cpl[((mb0 + 2) * 4 + q) * 64];
+                for (int q = 0; q < 2; ++q) {
+                    cv[q] = cpl[(mb0 * 4 + q + 2 * (g & 1)) * 64];
+                    cf[q] = cpl[((mb0 + 2) * 4 + q + 2 * (g & 1)) * 64];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cv[q] = cpl[(mb0 * 4 + q) * 64];
+                if (G == 2) cf[q] = cpl[((mb0 + 2) * 4 + q) * 64];
+            }
         }
     }
     DSD_SB();
@@ -153,6 +176,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
     pipe.run(acc, 0, NCH);
 
     float* gout = p.gbuf + (size_t)tile * TILE;
+    if (G == 16) {
+        lat_ksum4(acc[0][0], red, wv, j, h);
+        if (wv == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float gv = sigmoid_f(acc[0][0][r] + f4at(cv[r >> 2], r & 3)) * tanh_f(acc[0][0][r + 8] + f4at(cf[r >> 2], r & 3));
+                gout[(16 * g + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = gv;
+            }
+        }
+        return;
+    }
     if (G == 2) {
         // a gate block and its filter block in the same wave: the gate never leaves registers (like k_layer)
         float4 (&cg)[4] = cv;
@@ -196,10 +230,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
 
 template <int G>
 __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
-    static_assert(G == 2 || G == 4 || G == 8, "row split");
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "row split");
     constexpr int TILE = kC * 32;
     constexpr int NMB = (G == 2) ? 2 : 1;
-    constexpr int NCH = (G == 8) ? 16 : 32;     // chunks per wave: G = 8 splits K = 256 over two waves per row block
+    constexpr int NCH = (G == 16) ? 8 : (G == 8) ? 16 : 32;     // chunks per wave: G = 8 / 16 split K = 256 over two / four waves per row block
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* gtile = smem;                    // [256][32]
     float* red = smem + kC * 32;            // G = 8: [2][32][32] K-half partials of the residual / skip block
@@ -211,7 +245,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
     int w4, mb0, kbeg = 0;
     if (G == 2) { w4 = 2 * g + (wv >> 1); mb0 = wv & 1; }
     else if (G == 4) { w4 = g; mb0 = wv; }
-    else { w4 = g >> 1; mb0 = (g & 1) + 2 * (wv & 1); kbeg = 16 * (wv >> 1); }
+    else if (G == 8) { w4 = g >> 1; mb0 = (g & 1) + 2 * (wv & 1); kbeg = 16 * (wv >> 1); }
+    else { w4 = g >> 2; mb0 = g & 3; kbeg = 8 * wv; }
     // the last layer's residual half is dead (net.py:126 reads the skips only)
     const bool do_res = !p.last && ((G == 2) || mb0 < 2);
     const bool do_skip = (G == 2) || mb0 >= 2;
@@ -238,7 +273,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
         for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
     // what the epilogue reads - x and the bias at this lane's residual rows, the running skip sum - is requested in front of the contraction
     // (the waves that only contribute a K half, G = 8, finish nothing)
-    const bool fin = active && (G != 8 || wv < 2);
+    const bool fin = active && ((G == 16) ? (wv == 0) : (G != 8 || wv < 2));
     const float* __restrict__ xi = p.x_in + (size_t)tile * TILE;
     float4* sl = p.skip + (((size_t)tile * 4 + w4) * 2 + (mb0 & 1)) * (4 * 64) + lane;
     const bool keep = !p.first;             // layer 0 starts the sum (select, not multiply: the buffer may hold anything)
@@ -263,6 +298,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
     if (active) {
         pipe.start_b();
         pipe.run(acc, 0, NCH);
+    }
+    if (G == 16) {
+        if (!active) return;                 // uniform per workgroup: the whole block is dead
+        lat_ksum4(acc[0][0], red, wv, j, h);
+        if (wv > 0) return;
     }
     if (G == 8) {
         // sum the two K halves (first half + second half; the only difference from k_layer's single k-ordered chain)

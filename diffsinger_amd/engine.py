@@ -101,7 +101,7 @@ class DenoiserEngine:
         _lib.check(self.lib.dsd_set_use_graph(self._h, int(bool(enable))))
 
     def set_lat_split(self, g: int):
-        """Row split of the latency kernels (csrc/dsd_lat.hpp): -1 by batch size (default), 0 never, 2 / 4 / 8 forced."""
+        """Row split of the latency kernels (csrc/dsd_lat.hpp): -1 by batch size (default), 0 never, 2 / 4 / 8 / 16 forced."""
         _lib.check(self.lib.dsd_set_lat_split(self._h, int(g)), 'dsd_set_lat_split')
 
     def lat_split(self) -> int:

@@ -150,7 +150,7 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
 /* How the K-step loops run (dsd_set_loop_mode):
  *   2 (default) automatic.  A batch that fills less than half of the chip (32-frame tiles x 2 <= CU count; the reference's own inference
  *     shape, one utterance per device: configs/tts/fs2.yaml:70) takes the LATENCY kernels: every residual layer as two kernels whose
- *     workgroups split the output rows of a tile G = 8 / 4 / 2 ways (the largest G that still gives each workgroup its own CU), nodes of
+ *     workgroups split the output rows of a tile G = 16 / 8 / 4 / 2 ways (the largest G that still gives each workgroup its own CU), nodes of
  *     the cached hipGraph - up to 8 x more CUs per utterance.  Larger batches take the PERSISTENT loop (below) unless its chunking in
  *     whole utterances would idle more of the chip than the per-layer kernels' grid quantisation (e.g. T = 5000: 157 of 256 CUs).
  *   1 the persistent loop whenever the prepared batch allows it (32-frame tiles, hipGraph mode on, one utterance's tiles <= the CU
@@ -158,8 +158,8 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
  *     exchanges only the conv halo with its neighbours; larger batches run as chunks of whole utterances.
  *   0 one kernel per residual layer + head (a cached hipGraph, or eager launches, see above).
  *   3 the latency kernels regardless of the batch size (tests).
- * Modes 0 and 1 and the G = 2 / 4 latency kernels give bit-identical results; G = 8 sums the two K halves of the dilated conv separately
- * (reduction-order noise, ~1e-6).  dsd_set_lat_split: G = -1 by batch size (default), 0 never, 2 / 4 / 8 forced where the latency path
+ * Modes 0 and 1 and the G = 2 / 4 latency kernels give bit-identical results; G = 8 / 16 sum the K halves / quarters of the contractions separately
+ * (reduction-order noise, ~1e-6).  dsd_set_lat_split: G = -1 by batch size (default), 0 never, 2 / 4 / 8 / 16 forced where the latency path
  * applies; dsd_get_lat_split: the G the prepared batch runs with (0 = not on that path).  dsd_get_loop_mode: 1 if the prepared batch
  * would take the persistent path.
  * dsd_loop_timeouts: synchronises the stream and returns the sticky timeout word of the persistent loop (0 = every

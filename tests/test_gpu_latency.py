@@ -42,7 +42,7 @@ def test_one_layer_against_the_oracle_layer_every_split(preset, layer):
     base_x, base_skip = eng.debug_layer(layer, t, x.to(DEV))
     eng.set_loop_mode(3)
     last = layer == cfg.residual_layers - 1
-    for G in (2, 4, 8):
+    for G in (2, 4, 8, 16):
         eng.set_lat_split(G)
         assert eng.lat_split() == G
         xo, sk = eng.debug_layer(layer, t, x.to(DEV))
@@ -60,7 +60,7 @@ def test_one_layer_against_the_oracle_layer_every_split(preset, layer):
     eng.set_lat_split(-1)
 
 
-@pytest.mark.parametrize('G', [2, 4, 8])
+@pytest.mark.parametrize('G', [2, 4, 8, 16])
 @pytest.mark.parametrize('name,tol', [('denoise_lj', 1e-5), ('denoise_opencpop', 1e-5), ('ddpm_lj_k100', 1e-4), ('shallow_opencpop_k60', 1e-4),
                                       ('plms_opencpop_i40', 1e-4)])
 def test_golden_cases_with_every_split(name, tol, G):
@@ -75,7 +75,7 @@ def test_golden_cases_with_every_split(name, tol, G):
 def test_default_mode_picks_the_latency_kernels_for_small_batches_only():
     gd, _, _ = build_hip('lj_ds_beta6', 100)
     eng = None
-    for (B, T), want in {(1, 512): 8, (1, 1550): 4, (4, 777): 2, (8, 1024): 0, (5, 1550): 0}.items():
+    for (B, T), want in {(1, 512): 16, (1, 1000): 8, (1, 1550): 4, (4, 777): 2, (8, 1024): 0, (5, 1550): 0}.items():
         cond = torch.randn(B, T, 256, device=DEV).transpose(1, 2)
         eng = gd._engine(cond)
         assert eng.lat_split() == want, ((B, T), eng.lat_split())
@@ -95,7 +95,7 @@ def test_loop_with_latency_kernels_is_bit_identical_to_the_per_layer_kernels_for
     cond, x_T, noise = inp['cond'].to(DEV), inp['x_T'].to(DEV), inp['noise'].to(DEV)
     eng = gd._engine(cond)
     outs = {}
-    for mode, G in ((0, -1), (3, 2), (3, 4), (3, 8), (1, -1)):
+    for mode, G in ((0, -1), (3, 2), (3, 4), (3, 8), (3, 16), (1, -1)):
         eng.set_loop_mode(mode)
         eng.set_lat_split(G)
         outs[(mode, G)] = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).clone()
@@ -105,14 +105,15 @@ def test_loop_with_latency_kernels_is_bit_identical_to_the_per_layer_kernels_for
     assert torch.equal(outs[(0, -1)], outs[(1, -1)])
     assert torch.equal(outs[(0, -1)], outs[(3, 2)]) and torch.equal(outs[(0, -1)], outs[(3, 4)])
     d8 = float((outs[(3, 8)] - outs[(0, -1)]).abs().max())
-    print(f'G=8 vs per-layer kernels after {K} steps: max-abs mel difference {d8:.3e}')
-    assert d8 <= 2e-5
+    d16 = float((outs[(3, 16)] - outs[(0, -1)]).abs().max())
+    print(f'G=8 / G=16 vs per-layer kernels after {K} steps: max-abs mel difference {d8:.3e} / {d16:.3e}')
+    assert d8 <= 2e-5 and d16 <= 2e-5
     # per-utterance step indices (dsd_denoise with t[B]) on the latency kernels
     t = torch.tensor([3, 55])
     want = O.diffnet_forward(H.oracle_params(H.net_config(H.presets()['opencpop_ds60_rel'])), H.net_config(H.presets()['opencpop_ds60_rel']),
                              inp['x_T'], t, inp['cond'])
     got = gd.denoise_fn(x_T, t.to(DEV), cond)
-    assert eng.lat_split() == 8
+    assert eng.lat_split() == 16                             # 2 x 90 frames = 6 tiles: 16 workgroups per tile still find a CU each
     assert float((got.cpu() - want).abs().max()) <= 1e-5
 
 
@@ -123,7 +124,7 @@ def test_one_utterance_latency_next_to_the_persistent_loop():
     cond, x_T, noise = inp['cond'].to(DEV), inp['x_T'].to(DEV), inp['noise'].to(DEV)
     eng = gd._engine(cond)
     res, outs = {}, {}
-    for label, mode, G in (('persistent k_loop', 1, -1), ('latency G=2', 3, 2), ('latency G=4', 3, 4), ('latency G=8', 3, 8), ('default', 2, -1)):
+    for label, mode, G in (('persistent k_loop', 1, -1), ('latency G=2', 3, 2), ('latency G=4', 3, 4), ('latency G=8', 3, 8), ('latency G=16', 3, 16), ('default', 2, -1)):
         eng.set_loop_mode(mode)
         eng.set_lat_split(G)
         outs[label] = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).clone()      # graph capture / plan upload
@@ -134,7 +135,7 @@ def test_one_utterance_latency_next_to_the_persistent_loop():
         torch.cuda.synchronize()
         res[label] = (time.perf_counter() - t0) / 3 * 1e3
     print('K=100 DDPM, 1 utterance x 512 frames, ms per sampling call: ' + ', '.join(f'{k} {v:.1f}' for k, v in res.items()))
-    assert eng.lat_split() == 8
+    assert eng.lat_split() == 16
     ref = outs['persistent k_loop']
     for k, v in outs.items():
         assert float((v - ref).abs().max()) <= 2e-5, k
