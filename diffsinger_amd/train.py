@@ -214,20 +214,13 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
     xm = F.pad(spec[:, 0], pad)                                     # [B][M][TS], zero tail
     cm = F.pad(cond, pad).contiguous()                              # [B][H][TS]
     x = F.relu(conv('in', xm, net.input_projection))                # :116-118 (every conv output has the zero tail; relu keeps it)
-    # the step-embedding MLP and the layers' step projections (net.py:94-98, :119-120, :67) on the HIP convolution operators too (round 2 left
-    # these [B, C] products to torch = rocBLAS: vendor BLAS on the path): the B utterances are the "frames" of one row
-    def linear_rows(name, v, weight, bias):
-        vc = v.t().contiguous()[None]                               # [1][Cin][B]
-        n = vc.shape[2]
-        vc = F.pad(vc, (0, padded_frames(n) - n))
-        c = caches.get(name)
-        if c is None:
-            c = caches[name] = ConvCache()
-        return c(vc, weight, bias, n)[0, :, :n].t()                 # [B][Cout]
-
+    # the step-embedding MLP and the layers' step projections (net.py:94-98, :119-120, :67) are [B, C] x [C, C'] products on B rows - torch
+    # linear ops (rocBLAS), 0.4 % of a step.  Round 3 routed them through the convolution operators (utterances as the frames of one row): every
+    # call then pays layout changes, a weight re-pack per optimiser step and a 16-way split-K reduction for three rows - +0.37 ms per 8 x 1024
+    # step (profiles/r15_bench_row_train.json: 6.40 vs 6.03 ms) - and was reverted
     d = step_embedding(diffusion_step, net.residual_channels)       # :119
-    h = linear_rows('mlp0', d, net.mlp[0].weight, net.mlp[0].bias)
-    d = linear_rows('mlp2', h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)      # :120 (Mish)
+    h = F.linear(d, net.mlp[0].weight, net.mlp[0].bias)
+    d = F.linear(h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)      # :120 (Mish)
     from . import train_fused
     if train_fused.enabled() and train_fused.supported(net):
         # the whole residual stack as ONE autograd node on the fused kernels (csrc/train_kernels.hpp); the step projections of all layers
@@ -235,12 +228,12 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
         layers = list(net.residual_layers)
         wd = torch.cat([l.diffusion_projection.weight for l in layers], 0)
         bd = torch.cat([l.diffusion_projection.bias for l in layers], 0)
-        step_all = linear_rows('dp_all', d, wd, bd).reshape(B, len(layers), net.residual_channels)
+        step_all = F.linear(d, wd, bd).view(B, len(layers), net.residual_channels)
         skip = train_fused.residual_stack(net, x, cm, step_all, T)
     else:
         skip = None
         for l, layer in enumerate(net.residual_layers):             # ResidualBlock.forward :66-78
-            ds = linear_rows(f'l{l}.dp', d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)
+            ds = F.linear(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)
             y = _AddStep.apply(x, ds, T)
             a = conv(f'l{l}.dc', y, layer.dilated_conv, layer.dilation) + conv(f'l{l}.cp', cm, layer.conditioner_projection)
             g = _Gate.apply(a, T)

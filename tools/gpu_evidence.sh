@@ -10,7 +10,7 @@ mkdir -p $O
 cd $R
 git_rev=$(cat .git_rev 2>/dev/null || echo unknown)
 if [ "$2" != "nopytest" ]; then
-( time timeout 1500 python -m pytest tests -m gpu -q -rf 2>&1 | tail -40 ) > $O/pytest_gpu.txt 2>&1
+( time timeout 1500 python -m pytest tests -m gpu -q -rf > $O/pytest_gpu_full.txt 2>&1 ) 2> $O/pytest_gpu_time.txt; tail -40 $O/pytest_gpu_full.txt > $O/pytest_gpu.txt; cat $O/pytest_gpu_time.txt >> $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 fi
 timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.err
