@@ -123,6 +123,7 @@ struct dsd_handle {
     bool persist_off = false;         // set when a timeout was reported: the handle stays on the hipGraph path until dsd_set_loop_mode
     float* loop_halo = nullptr;       // [2][ntiles][2][256][8]
     int loop_cap_tiles = 0;
+    int loop_tmo_at = -1;             // index of the timeout word of the LAST persistent run inside loop_flags (its ntiles), -1: none yet
     unsigned long long* loop_dbg = nullptr;   // debug: stamps of one phase (dsd_debug_loop_timeline)
     int loop_dbg_phase = 0;
 
@@ -195,6 +196,7 @@ static void free_workspace(dsd_handle* h) {
     dev_free(h->t_dev); dev_free(h->coef_dev); dev_free(h->eps_tmp);
     dev_free(h->loop_flags); dev_free(h->loop_halo);
     h->loop_cap_tiles = 0;
+    h->loop_tmo_at = -1;
     h->xa = h->xb = nullptr;
     h->cap_frames = 0; h->cap_B = 0; h->cap_spec = 0;
     h->bytes_ws = 0;
@@ -931,6 +933,7 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
     }
     if (h->loop_cap_tiles < h->ntiles) {
         dev_free(h->loop_flags); dev_free(h->loop_halo);
+        h->loop_tmo_at = -1;
         DSD_TRY(dev_alloc(h, &h->loop_flags, (size_t)h->ntiles + 64, true));
         DSD_TRY(dev_alloc(h, &h->loop_halo, (size_t)2 * h->ntiles * 2 * kC * 8, true));
         h->loop_cap_tiles = h->ntiles;
@@ -945,6 +948,7 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
     p.evals = it->second.evals; p.eval_t = it->second.eval_t; p.n_evals = it->second.n_evals;
     p.spec0 = h->xs;
     p.flags = h->loop_flags; p.halo = h->loop_halo; p.tmo = h->loop_flags + h->ntiles;
+    h->loop_tmo_at = h->ntiles;
     p.dbg = h->loop_dbg; p.dbg_phase = h->loop_dbg_phase;
     // chunks of whole utterances, at most one workgroup per CU (all workgroups of a launch wait for each other)
     const int utt_per_chunk = std::max(1, h->n_cu / h->ntile32);
@@ -1117,11 +1121,12 @@ extern "C" int dsd_loop_launches(dsd_handle* h) {
 
 extern "C" int dsd_loop_timeouts(dsd_handle* h, void* stream) {
     if (!h) return fail(DSD_ERR_INVALID, "dsd_loop_timeouts: null handle");
-    if (!h->loop_flags) return 0;
+    if (!h->loop_flags || h->loop_tmo_at < 0) return 0;
     unsigned v = 0;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    HIP_TRY(hipMemcpy(&v, h->loop_flags + h->ntiles, sizeof v, hipMemcpyDeviceToHost));
+    // the word of the last persistent run (a batch prepared SINCE then may have fewer tiles: flags[ntiles] would be one of that run's tile flags)
+    HIP_TRY(hipMemcpy(&v, h->loop_flags + h->loop_tmo_at, sizeof v, hipMemcpyDeviceToHost));
     return (int)v;
 }
 
