@@ -325,14 +325,18 @@ __global__ void k_latch_tmo(const unsigned* tmo, unsigned* sticky) {
         __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Debug / test hook kernel: holds a CU (all of its LDS) for `ticks` of the 100 MHz wall clock.
-__global__ void k_hold_cu(unsigned long long ticks, unsigned* started) {
+// Debug / test hook kernel: holds a CU (all of its LDS) for `ticks` of the 100 MHz wall clock, or until the caller sets the release word
+// ctl[1] (ctl[0] counts the holders that are resident).
+__global__ void k_hold_cu(unsigned long long ticks, unsigned* ctl) {
     extern __shared__ unsigned hold_lds[];
     hold_lds[threadIdx.x] = threadIdx.x;
-    if (started && threadIdx.x == 0) atomicAdd(started, 1u);            // the caller can wait until the holders are resident
+    if (ctl && threadIdx.x == 0) atomicAdd(ctl, 1u);                    // the caller can wait until the holders are resident
     const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-    if (started && hold_lds[threadIdx.x] == 0xffffffffu) *started = 0u;   // keeps the LDS allocation alive
+    while (wall_clock64() - t0 < ticks) {
+        if (ctl && __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+    if (ctl && hold_lds[threadIdx.x] == 0xffffffffu) *ctl = 0u;          // keeps the LDS allocation alive
 }
 
 static int sticky_alloc(dsd_handle* h) {
@@ -1136,8 +1140,8 @@ extern "C" int dsd_check(dsd_handle* h) {
 }
 
 extern "C" int dsd_debug_hold_cus(int32_t device, int32_t n_workgroups, int32_t milliseconds, uint32_t* started, void* stream) {
-    if (n_workgroups < 1 || n_workgroups > 4096 || milliseconds < 1 || milliseconds > 20000)
-        return fail(DSD_ERR_INVALID, "dsd_debug_hold_cus: 1..4096 workgroups, 1..20000 ms");
+    if (n_workgroups < 1 || n_workgroups > 4096 || milliseconds < 1 || milliseconds > 300000)
+        return fail(DSD_ERR_INVALID, "dsd_debug_hold_cus: 1..4096 workgroups, 1..300000 ms");
     HIP_TRY(hipSetDevice(device));
     const int lds = 160 * 1024;                                    // the whole LDS of a CU: one holder per CU, nothing else fits beside it
     if (first_on_device(2)) HIP_TRY(hipFuncSetAttribute((const void*)k_hold_cu, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -254,17 +254,31 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
 
     const float* gl = gtile + kbeg * (8 * 32) + 4 * h * 32 + j;
     GemmPipe<NMB, 1, 32, 256, 6, TileB, 2> pipe(p.w2p + (size_t)w4 * (32 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, TileB{gl, 8 * 32, NCH});
-    if (active) pipe.start_a();
-
-    {
+    // G = 16: a wave contracts over ONE quarter of the gate tile (8 chunks = 32 values per lane) and no other wave of the workgroup reads
+    // that quarter - the B fragments come straight from global memory into registers, all requested at once behind the 8 A fragments;
+    // there is no staging pass, no barrier in front of the contraction and nothing to wait for inside it
+    float4 aq[(G == 16) ? 8 : 1][NMB];
+    float bq[(G == 16) ? 8 : 1][4][1];
+    if constexpr (G == 16) {
+        if (active) {
+            const float* __restrict__ gs = p.gbuf + (size_t)tile * TILE + kbeg * (8 * 32) + 4 * h * 32 + j;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) pipe.lda(aq[c], c);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bq[c][s][0] = gs[(c * 8 + s) * 32];
+        }
+    } else {
+        if (active) pipe.start_a();
         const float4* src = reinterpret_cast<const float4*>(p.gbuf + (size_t)tile * TILE);
         float4 v[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) v[it] = src[it * kThreads + tid];
 #pragma unroll
         for (int it = 0; it < 8; ++it) reinterpret_cast<float4*>(gtile)[it * kThreads + tid] = v[it];
+        __syncthreads();
     }
-    __syncthreads();
 
     f32x16 acc[NMB][1];
 #pragma unroll
@@ -295,7 +309,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
         }
     }
     DSD_SB();
-    if (active) {
+    if constexpr (G == 16) {
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) mma_chunk<NMB, 1>(acc, aq[c], bq[c]);
+        }
+    } else if (active) {
         pipe.start_b();
         pipe.run(acc, 0, NCH);
     }

@@ -161,22 +161,48 @@ class DenoiserEngine:
             torch.cuda.current_stream(self.device).synchronize()
         _lib.check(self.lib.dsd_check(self._h), 'persistent loop')
 
-    def hold_cus(self, n_workgroups: int, milliseconds: int, stream: Optional[torch.cuda.Stream] = None, wait: bool = True):
-        """Test hook: a foreign kernel that occupies `n_workgroups` compute units for `milliseconds` on `stream` (default: the current one).
-        wait: return only when every holder is resident (polls a device counter through the current stream, which must be idle)."""
-        s = stream.cuda_stream if stream is not None else _stream_ptr(self.device)
-        started = torch.zeros(1, dtype=torch.int32, device=self.device)
-        torch.cuda.current_stream(self.device).synchronize()
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.dsd_debug_hold_cus(self.device.index or 0, int(n_workgroups), int(milliseconds), started.data_ptr(), s), 'dsd_debug_hold_cus')
-        if wait and stream is not None:
-            import time
+    def hold_cus(self, n_workgroups: int, milliseconds: int, stream: Optional[torch.cuda.Stream] = None):
+        """Test hook: a foreign kernel that occupies `n_workgroups` compute units for `milliseconds` or until release_cus(), whichever comes
+        first, on a side stream that really runs BESIDE the current stream; returns that stream once every holder is resident.
+        HIP multiplexes streams onto a few hardware queues: a side stream that shares its queue with the current stream would serialise the
+        caller's next kernel BEHIND the holders instead of starving it (seen after many streams had been created in the process).  So
+        each candidate stream is probed - an event recorded on the current stream must complete while the holders are resident - and given
+        up for the next one if it does not.  The control words live in pinned host memory: counting the resident holders and releasing
+        them never goes through a stream."""
+        import time
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        cur.synchronize()
+        for attempt in range(8):
+            side = stream if (stream is not None and attempt == 0) else torch.cuda.Stream(dev)
+            ctl = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._hold_ctl = ctl
+            with torch.cuda.device(dev):
+                _lib.check(self.lib.dsd_debug_hold_cus(dev.index or 0, int(n_workgroups), int(milliseconds), ctl.data_ptr(), side.cuda_stream),
+                           'dsd_debug_hold_cus')
             t0 = time.time()
-            while int(started.item()) < n_workgroups:
+            while int(ctl[0]) < n_workgroups:
                 if time.time() - t0 > 5.0:
-                    raise RuntimeError(f'hold_cus: only {int(started.item())} of {n_workgroups} holders became resident within 5 s')
-                time.sleep(0.005)
-        self._hold_keep = started
+                    self.release_cus()
+                    raise RuntimeError(f'hold_cus: only {int(ctl[0])} of {n_workgroups} holders became resident within 5 s')
+                time.sleep(0.002)
+            probe = torch.cuda.Event()
+            probe.record(cur)
+            t0 = time.time()
+            while not probe.query() and time.time() - t0 < 0.5:
+                time.sleep(0.002)
+            if probe.query():
+                self._hold_attempts = attempt + 1
+                return side
+            self.release_cus()                                   # the current stream sits behind the holders: try another stream
+            side.synchronize()
+        raise RuntimeError('hold_cus: no side stream runs concurrently with the current stream')
+
+    def release_cus(self):
+        """Ends the holders of the last hold_cus() (a store into pinned host memory the holders poll)."""
+        ctl = getattr(self, '_hold_ctl', None)
+        if ctl is not None:
+            ctl[1] = 1
 
     def set_layer_tile(self, frames: int):
         _lib.check(self.lib.dsd_set_layer_tile(self._h, int(frames)))

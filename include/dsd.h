@@ -204,8 +204,9 @@ int dsd_check(dsd_handle* h);
 
 /* Test hook: occupy `n_workgroups` compute units (one 64-thread workgroup with the whole 160 KiB of LDS each, so nothing else fits
  * beside it) for `milliseconds` of wall-clock time on `stream` - the "foreign kernel" the persistent loop's timeout exists for.
- * started: NULL, or a DEVICE counter every holder increments once it is resident (the caller polls it). */
-int dsd_debug_hold_cus(int32_t device, int32_t n_workgroups, int32_t milliseconds, uint32_t* started, void* stream);
+ * ctl: NULL, or two words the device can reach (device memory or pinned host memory): ctl[0] a counter every holder increments once it is resident (the caller polls it), ctl[1] a release
+ * word - the holders leave as soon as it is non-zero (or after `milliseconds`, whichever comes first). */
+int dsd_debug_hold_cus(int32_t device, int32_t n_workgroups, int32_t milliseconds, uint32_t* ctl, void* stream);
 
 /* Frames per workgroup of the residual-layer kernel: 0 = choose from the batch size, 32 or 64. */
 int dsd_set_layer_tile(dsd_handle* h, int32_t frames);

@@ -39,7 +39,7 @@ def main():
     dev = torch.device('cuda', 0)
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     g = torch.Generator(device=dev).manual_seed(7)
-    modes = [2] if '--default-only' in sys.argv else [2, 1, 0]       # automatic (the product), then forced persistent loop / per-layer kernels
+    modes = [2] if ('--default-only' in sys.argv or '--lat-splits' in sys.argv) else [2, 1, 0]       # automatic (the product), then forced persistent loop / per-layer kernels
     for B, T in shapes:
         conds = [torch.randn(B, T, 256, device=dev, generator=g).transpose(1, 2) for _ in range(2)]
         x_T = torch.randn(B, 1, 80, T, device=dev, generator=g)
@@ -70,6 +70,22 @@ def main():
                 row['forced_' + ('persistent' if mode == 1 else 'per_layer')] = {'path': path, 'ms_per_pass': round(sec * 1e3, 3),
                                                                                 'frac_fp32_mfma_peak': round(tf / PEAK_TF, 4)}
         gd.denoise_fn.engine().set_loop_mode(2)
+        if '--lat-splits' in sys.argv:
+            # forced row splits of the latency kernels (also with more workgroups than CUs: they are ordinary launches)
+            eng = gd.denoise_fn.engine()
+            row['forced_lat'] = {}
+            for G in (2, 4, 8, 16):
+                eng.set_loop_mode(3)
+                eng.set_lat_split(G)
+                out = one()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    out = one()
+                torch.cuda.synchronize()
+                row['forced_lat'][f'G={eng.lat_split()}'] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+            eng.set_lat_split(-1)
+            eng.set_loop_mode(2)
         print(json.dumps(row), flush=True)
         del conds, x_T
 
