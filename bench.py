@@ -522,7 +522,16 @@ def main_fs2(args):
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_launch_ms': ms, 'flop_per_launch': flop,
                 'algorithmic_bytes_per_launch': 4 * B * T * (256 + 1024) + 4 * 1024 * 256 * 9,
                 'note': 'ffn_1 of TransformerFFNLayer (Conv1d 256 -> 1024, k = 9, * k**-0.5, gelu fused): the largest contraction of the model; eager launch '
-                        'incl. the output allocation and the ctypes call.  No PMC pass of this kernel is committed yet'}
+                        'incl. the output allocation and the ctypes call'}
+        try:                                                  # counters of THIS launch shape inside the whole forward (tools/gpu_fs2_prof.sh)
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'fs2_ffn1_pmc.json')))
+            roof['traffic'] = float(pj['hbm_bytes_per_launch']['total'])
+            roof['traffic_unit'] = 'bytes/launch'
+            roof['traffic_source'] = (f"profiles/fs2_ffn1_pmc.json (round {pj.get('round', '?')}, commit {pj.get('commit', '?')}): the k_fs_conv<2> dispatches "
+                                      'of at least 250 us of `bench.py --row fs2` = the four mel-rate ffn_1 launches per forward; FETCH_SIZE KiB x 1024 x 2 '
+                                      '(gfx950 wide-read correction) + WRITE_SIZE KiB x 1024')
+        except (OSError, KeyError, ValueError):
+            roof['note'] += '.  No PMC pass of this kernel is committed (profiles/fs2_ffn1_pmc.json)'
         value = world * B * T * args.steps / el
         res = {'metric': 'mel-frames/sec (whole node) through FastSpeech2 (encoder, predictors, length regulator, decoder, mel_out), teacher-forced, T=1024',
                'value': value, 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,

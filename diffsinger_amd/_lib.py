@@ -23,6 +23,7 @@ SYMBOLS = [
 # every symbol include/dsf.h declares (the FastSpeech2 conditioner ops)
 SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf_conv1d', 'dsf_layer_norm', 'dsf_attention',
                'dsf_ln_bwd_workspace_floats', 'dsf_layer_norm_bwd', 'dsf_attention_bwd_workspace_floats', 'dsf_attention_bwd',
+               'dsf_linear_rows_workspace_floats', 'dsf_linear_rows', 'dsf_linear_rows_bwd',
                'dsf_to_channel_major', 'dsf_from_channel_major', 'dsf_p_sample', 'dsf_denorm_spec',
                'dsf_conv1d_dilated', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad',
                'dsf_train_add_step', 'dsf_train_rowsum', 'dsf_train_gate', 'dsf_train_gate_bwd', 'dsf_train_res_skip', 'dsf_train_res_skip_bwd',
@@ -130,6 +131,10 @@ def load():
     lib.dsf_attention_bwd_workspace_floats.argtypes = [i32, i32, i32]
     lib.dsf_attention_bwd_workspace_floats.restype = i64
     lib.dsf_attention_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.dsf_linear_rows_workspace_floats.argtypes = [i32, i32, i32]
+    lib.dsf_linear_rows_workspace_floats.restype = i64
+    lib.dsf_linear_rows.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.dsf_linear_rows_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_to_channel_major.argtypes = [vp, i64, i64, i64, vp, i32, i32, i32, vp]
     lib.dsf_from_channel_major.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.dsf_p_sample.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]

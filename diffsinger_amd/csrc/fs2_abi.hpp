@@ -136,6 +136,60 @@ static void fs_bmm(hipStream_t s, const float* A, const float* Bm, float* C, int
     hipLaunchKernelGGL(k_fs_bmm, dim3((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32), (unsigned)(outer * inner)), dim3(256), 0, s, p);
 }
 
+// torch.nn.Linear on a handful of ROWS (the step-embedding MLP and the layers' step projections of the denoiser under training:
+// usr/diff/net.py:94-98, :119-120, :67 - [B, in] x [in, out] with B = the batch size): y = x W^T + b, and its three gradients.  Vector-ALU
+// products (k_fs_bmm): the work is a few MFLOP, the point is that no vendor BLAS sits on the path.  A product with few output tiles and a
+// long contraction (dx of the 20 stacked step projections: 8 x 256 outputs over K = 5120) is split over K as the batch index of k_fs_bmm;
+// the partial products are added in split order (k_fs_colsum: deterministic).
+static int lin_splits(int M, int N, int K) {
+    const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
+    if (tiles >= 64) return 1;
+    for (int sp : {32, 16, 8, 4, 2})
+        if (K % (sp * 32) == 0 && K / sp >= 64) return sp;
+    return 1;
+}
+
+static void lin_product(hipStream_t s, const float* A, const float* Bm, float* C, float* ws, int M, int N, int K, long long am, long long ak, long long bk,
+                        long long bn) {
+    const int sp = ws ? lin_splits(M, N, K) : 1;
+    if (sp == 1) {
+        fs_bmm(s, A, Bm, C, M, N, K, am, ak, bk, bn, N, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1.f);
+        return;
+    }
+    const long long kc = K / sp;
+    fs_bmm(s, A, Bm, ws, M, N, (int)kc, am, ak, bk, bn, N, 1, sp, 1, kc * ak, 0, kc * bk, 0, (long long)M * N, 0, 1.f);
+    hipLaunchKernelGGL(k_fs_colsum, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, ws, C, sp, M * N, M * N);
+}
+
+extern "C" int64_t dsf_linear_rows_workspace_floats(int32_t rows, int32_t n_in, int32_t n_out) {
+    if (rows < 1 || n_in < 1 || n_out < 1) return -1;
+    return (int64_t)32 * rows * std::max(n_in, n_out);
+}
+
+extern "C" int dsf_linear_rows(const float* x, const float* w, const float* bias, float* y, float* ws, int32_t rows, int32_t n_in, int32_t n_out,
+                               void* stream) {
+    if (!x || !w || !y) return fail(DSD_ERR_INVALID, "dsf_linear_rows: null argument");
+    if (rows < 1 || n_in < 1 || n_out < 1) return fail(DSD_ERR_INVALID, "dsf_linear_rows: empty shape");
+    hipStream_t s = (hipStream_t)stream;
+    lin_product(s, x, w, y, ws, rows, n_out, n_in, n_in, 1, 1, n_in);                       // y[m][o] = sum_i x[m][i] w[o][i]
+    if (bias) hipLaunchKernelGGL(k_fs_add_row_bias, dim3((unsigned)((n_out + 255) / 256), (unsigned)rows), dim3(256), 0, s, y, bias, n_out);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+// dy [rows][n_out] -> dx [rows][n_in] (or NULL), dw [n_out][n_in] (or NULL), db [n_out] (or NULL; fixed-order column sum)
+extern "C" int dsf_linear_rows_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, float* ws, int32_t rows,
+                                   int32_t n_in, int32_t n_out, void* stream) {
+    if (!x || !w || !dy) return fail(DSD_ERR_INVALID, "dsf_linear_rows_bwd: null argument");
+    if (rows < 1 || n_in < 1 || n_out < 1) return fail(DSD_ERR_INVALID, "dsf_linear_rows_bwd: empty shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) lin_product(s, dy, w, dx, ws, rows, n_in, n_out, n_out, 1, n_in, 1);                // dx[m][i] = sum_o dy[m][o] w[o][i]
+    if (dw) lin_product(s, dy, x, dw, nullptr, n_out, n_in, rows, 1, n_out, n_in, 1);          // dw[o][i] = sum_m dy[m][o] x[m][i]
+    if (db) hipLaunchKernelGGL(k_fs_colsum, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, dy, db, rows, n_out, n_out);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
 extern "C" int dsf_attention_bwd(const float* qkv, const uint8_t* key_pad, const float* dout, float* dqkv, float* ws, int32_t B, int32_t C,
                                  int32_t heads, int32_t T, void* stream) {
     if (!qkv || !dout || !dqkv || !ws) return fail(DSD_ERR_INVALID, "dsf_attention_bwd: null argument");

@@ -110,6 +110,12 @@ __global__ __launch_bounds__(256) void k_fs_colsum(const float* __restrict__ par
     out[c] = s;
 }
 
+// y[r][c] += bias[c]
+__global__ __launch_bounds__(256) void k_fs_add_row_bias(float* __restrict__ y, const float* __restrict__ bias, int ncol) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < ncol) y[(size_t)blockIdx.y * ncol + c] += bias[c];
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // strided batched matrix product C[m][n] = alpha * sum_k A[m][k] B[k][n]
 // ------------------------------------------------------------------------------------------------------------

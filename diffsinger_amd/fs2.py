@@ -644,9 +644,9 @@ def f0_to_coarse(f0):
 class FastSpeech2(nn.Module):
     def __init__(self, dictionary, out_dims=None):
         super().__init__()
-        for k in ('use_spk_id', 'use_spk_embed', 'use_energy_embed', 'pitch_ar'):
-            if hparams.get(k):
-                raise NotImplementedError(f'hparams[{k!r}] is not supported by the HIP FastSpeech2')
+        if hparams.get('pitch_ar'):
+            # fs2.py:215 passes two arguments to PitchPredictor.forward (tts_modules.py:222 takes one): the option raises in the reference itself
+            raise NotImplementedError("hparams['pitch_ar'] is a dead option of the reference (TypeError at modules/fastspeech/fs2.py:215)")
         if hparams['encoder_type'] != 'fft' or hparams['decoder_type'] != 'fft':
             raise NotImplementedError('encoder_type / decoder_type other than fft')
         self.dictionary = dictionary
@@ -660,6 +660,13 @@ class FastSpeech2(nn.Module):
         self.out_dims = hparams['audio_num_mel_bins'] if out_dims is None else out_dims
         self.mel_out = Linear(H, self.out_dims, bias=True)
         self._pmel = PackedWeight()
+        if hparams.get('use_spk_id'):                                   # fs2.py:37-44
+            self.spk_embed_proj = Embedding(hparams['num_spk'] + 1, H)
+            if hparams.get('use_split_spk_id'):
+                self.spk_embed_f0 = Embedding(hparams['num_spk'] + 1, H)
+                self.spk_embed_dur = Embedding(hparams['num_spk'] + 1, H)
+        elif hparams.get('use_spk_embed'):
+            self.spk_embed_proj = _HipLinear(256, H, bias=True)
         ph = hparams['predictor_hidden'] if hparams['predictor_hidden'] > 0 else H
         self.dur_predictor = DurationPredictor(H, n_chans=ph, n_layers=hparams['dur_predictor_layers'],
                                                dropout_rate=hparams['predictor_dropout'], padding=hparams['ffn_padding'],
@@ -675,12 +682,16 @@ class FastSpeech2(nn.Module):
                     PitchPredictor(h, n_chans=ph, n_layers=hparams['predictor_layers'], dropout_rate=hparams['predictor_dropout'],
                                    odim=odim, padding=hparams['ffn_padding'], kernel_size=hparams['predictor_kernel']))
                 self.cwt_stats_layers = nn.Sequential(_HipLinear(H, h), nn.ReLU(), _HipLinear(h, h), nn.ReLU(), _HipLinear(h, 2))
-            elif hparams['pitch_type'] == 'frame':
+            else:                                                       # 'frame': (f0, uv) per frame; 'ph': f0 per phone (fs2.py:67-74)
                 self.pitch_predictor = PitchPredictor(H, n_chans=ph, n_layers=hparams['predictor_layers'],
-                                                      dropout_rate=hparams['predictor_dropout'], odim=2,
+                                                      dropout_rate=hparams['predictor_dropout'],
+                                                      odim=2 if hparams['pitch_type'] == 'frame' else 1,
                                                       padding=hparams['ffn_padding'], kernel_size=hparams['predictor_kernel'])
-            else:
-                raise NotImplementedError(f"pitch_type {hparams['pitch_type']}")
+        if hparams.get('use_energy_embed'):                             # fs2.py:75-82; EnergyPredictor is PitchPredictor (tts_modules.py:253-254)
+            self.energy_embed = Embedding(256, H, self.padding_idx)
+            self.energy_predictor = PitchPredictor(H, n_chans=ph, n_layers=hparams['predictor_layers'],
+                                                   dropout_rate=hparams['predictor_dropout'], odim=1,
+                                                   padding=hparams['ffn_padding'], kernel_size=hparams['predictor_kernel'])
 
     def _build_encoder(self):
         return FastspeechEncoder(self.encoder_embed_tokens, self.hidden_size, hparams['enc_layers'], hparams['enc_ffn_kernel_size'],
@@ -698,22 +709,42 @@ class FastSpeech2(nn.Module):
         inputs (`predictor_grad`, fs2.py:153, :194) is part of the graph."""
         if infer or not torch.is_grad_enabled():
             with torch.no_grad():
-                return self._forward(txt_tokens, mel2ph, f0, uv, skip_decoder, infer, **kwargs)
-        return self._forward(txt_tokens, mel2ph, f0, uv, skip_decoder, infer, **kwargs)
+                return self._forward(txt_tokens, mel2ph, f0, uv, skip_decoder, infer, spk_embed=spk_embed, energy=energy,
+                                     spk_embed_dur_id=spk_embed_dur_id, spk_embed_f0_id=spk_embed_f0_id, **kwargs)
+        return self._forward(txt_tokens, mel2ph, f0, uv, skip_decoder, infer, spk_embed=spk_embed, energy=energy,
+                             spk_embed_dur_id=spk_embed_dur_id, spk_embed_f0_id=spk_embed_f0_id, **kwargs)
 
-    def _forward(self, txt_tokens, mel2ph, f0, uv, skip_decoder, infer, **kwargs):
+    def _speaker(self, spk_embed, spk_embed_dur_id, spk_embed_f0_id):
+        """fs2.py:107-121 -> (spk_embed_dur, spk_embed_f0, spk_embed), each [B,1,H] or 0."""
+        if hparams.get('use_spk_embed'):
+            e = self.spk_embed_proj(spk_embed)[:, None, :]
+            return e, e, e
+        if hparams.get('use_spk_id'):
+            sid = spk_embed
+            e = self.spk_embed_proj(sid)[:, None, :]
+            if not hparams.get('use_split_spk_id'):
+                return e, e, e
+            return (self.spk_embed_dur(sid if spk_embed_dur_id is None else spk_embed_dur_id)[:, None, :],
+                    self.spk_embed_f0(sid if spk_embed_f0_id is None else spk_embed_f0_id)[:, None, :], e)
+        return 0, 0, 0
+
+    def _forward(self, txt_tokens, mel2ph, f0, uv, skip_decoder, infer, spk_embed=None, energy=None, spk_embed_dur_id=None,
+                 spk_embed_f0_id=None, **kwargs):
         ret = {}
         encoder_out = self._encode(txt_tokens, **kwargs)                                        # [B,T_txt,H]
         src_nonpadding = (txt_tokens > 0).float()[:, :, None]
-        dur_inp = encoder_out * src_nonpadding
+        spk_dur, spk_f0, spk = self._speaker(spk_embed, spk_embed_dur_id, spk_embed_f0_id)
+        dur_inp = (encoder_out + spk_dur) * src_nonpadding
         mel2ph = self.add_dur(dur_inp, mel2ph, txt_tokens, ret)
         decoder_inp = F.pad(encoder_out, [0, 0, 1, 0])
         decoder_inp = torch.gather(decoder_inp, 1, mel2ph[..., None].repeat([1, 1, encoder_out.shape[-1]]))
         tgt_nonpadding = (mel2ph > 0).float()[:, :, None]
-        pitch_inp = decoder_inp * tgt_nonpadding
+        pitch_inp = (decoder_inp + spk_f0) * tgt_nonpadding
         if hparams['use_pitch_embed']:
-            decoder_inp = decoder_inp + self.add_pitch(pitch_inp, f0, uv, mel2ph, ret, encoder_out=encoder_out * src_nonpadding)
-        ret['decoder_inp'] = decoder_inp = decoder_inp * tgt_nonpadding
+            decoder_inp = decoder_inp + self.add_pitch(pitch_inp, f0, uv, mel2ph, ret, encoder_out=(encoder_out + spk_f0) * src_nonpadding)
+        if hparams.get('use_energy_embed'):
+            decoder_inp = decoder_inp + self.add_energy(pitch_inp, energy, ret)
+        ret['decoder_inp'] = decoder_inp = (decoder_inp + spk) * tgt_nonpadding
         if skip_decoder:
             return ret
         ret['mel_out'] = self.run_decoder(decoder_inp, tgt_nonpadding, ret, infer=infer, **kwargs)
@@ -738,8 +769,26 @@ class FastSpeech2(nn.Module):
         ret['mel2ph'] = mel2ph
         return mel2ph
 
+    def add_energy(self, decoder_inp, energy, ret):
+        """fs2.py:174-181."""
+        decoder_inp = self._scale_grad(decoder_inp)
+        ret['energy_pred'] = energy_pred = self.energy_predictor(decoder_inp)[:, :, 0]
+        if energy is None:
+            energy = energy_pred
+        energy = torch.clamp(energy * 256 // 4, max=255).long()
+        return self.energy_embed(energy)
+
     def add_pitch(self, decoder_inp, f0, uv, mel2ph, ret, encoder_out=None):
         """fs2.py:183-231."""
+        if hparams['pitch_type'] == 'ph':                                # :184-196: predicted and quantised per phone, gathered to the frames
+            pitch_pred_inp = self._scale_grad(encoder_out)
+            pitch_padding = encoder_out.sum().abs() == 0
+            ret['pitch_pred'] = pitch_pred = self.pitch_predictor(pitch_pred_inp)
+            if f0 is None:
+                f0 = pitch_pred[:, :, 0]
+            ret['f0_denorm'] = f0_denorm = denorm_f0(f0, None, hparams, pitch_padding=pitch_padding)
+            pitch = F.pad(f0_to_coarse(f0_denorm), [1, 0])
+            return self.pitch_embed(torch.gather(pitch, 1, mel2ph))
         decoder_inp = self._scale_grad(decoder_inp)
         pitch_padding = mel2ph == 0
         given = f0 is not None

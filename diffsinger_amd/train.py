@@ -6,7 +6,8 @@ MFMA convolution kernel with the flipped, transposed weight) and its weight / bi
 contraction over frames on fp32 MFMA, reduced in a fixed order -> deterministic) - > 99 % of the FLOPs of a training step.
 The element-wise pieces of the residual block (x + step, sigmoid * tanh gate, residual / skip update) are fused HIP kernels
 with hand-written backward too (`dsf_train_*`).  What is left to torch autograd: the sum of the two convolution outputs, the
-two ReLUs and the 1/sqrt(L) scale of the head, the step-embedding MLP on [B, C] vectors, the L1 loss, and the optimiser.  DDP works unchanged on top
+two ReLUs and the 1/sqrt(L) scale of the head, the Mish of the step-embedding MLP (its two Linear layers and the layers' step
+projections are `dsf_linear_rows`), the L1 loss, and the optimiser.  DDP works unchanged on top
 (gradients are ordinary `.grad` tensors; the all-reduce is torch.distributed's, RCCL on ROCm).
 
 This is the functional slice of row f3, not yet the fused one: activations live channel-major [B][C][TS] (TS = T up to 32, zero
@@ -26,6 +27,47 @@ from .fs2 import PackedWeight, padded_frames
 
 def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _LinearRows(torch.autograd.Function):
+    """torch.nn.Linear on [rows, in] with rows = the batch size: the step-embedding MLP and the layers' step projections (usr/diff/net.py:
+    94-98, :119-120, :67).  dsf_linear_rows / dsf_linear_rows_bwd: plain row-major products on the vector ALUs - no vendor BLAS on the path."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x, weight = x.contiguous(), weight.contiguous()
+        rows, n_in = x.shape
+        n_out = weight.shape[0]
+        y = torch.empty(rows, n_out, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.dsf_linear_rows_workspace_floats(rows, n_in, n_out), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.dsf_linear_rows(x.data_ptr(), weight.data_ptr(), bias.contiguous().data_ptr() if bias is not None else None, y.data_ptr(),
+                                           ws.data_ptr(), rows, n_in, n_out, _stream(x.device)), 'dsf_linear_rows')
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        rows, n_in = x.shape
+        n_out = weight.shape[0]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        db = torch.empty(n_out, device=x.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        ws = torch.empty(lib.dsf_linear_rows_workspace_floats(rows, n_in, n_out), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.dsf_linear_rows_bwd(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), ptr(dx), ptr(dw), ptr(db), ws.data_ptr(), rows, n_in,
+                                               n_out, _stream(x.device)), 'dsf_linear_rows_bwd')
+        return dx, dw, db
+
+
+def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    return _LinearRows.apply(x, weight, bias)
 
 
 class _Conv1dCM(torch.autograd.Function):
@@ -214,13 +256,12 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
     xm = F.pad(spec[:, 0], pad)                                     # [B][M][TS], zero tail
     cm = F.pad(cond, pad).contiguous()                              # [B][H][TS]
     x = F.relu(conv('in', xm, net.input_projection))                # :116-118 (every conv output has the zero tail; relu keeps it)
-    # the step-embedding MLP and the layers' step projections (net.py:94-98, :119-120, :67) are [B, C] x [C, C'] products on B rows - torch
-    # linear ops (rocBLAS), 0.4 % of a step.  Round 3 routed them through the convolution operators (utterances as the frames of one row): every
-    # call then pays layout changes, a weight re-pack per optimiser step and a 16-way split-K reduction for three rows - +0.37 ms per 8 x 1024
-    # step (profiles/r15_bench_row_train.json: 6.40 vs 6.03 ms) - and was reverted
+    # the step-embedding MLP and the layers' step projections (net.py:94-98, :119-120, :67): [B, C] x [C, C'] products on B rows through
+    # dsf_linear_rows (own vector-ALU kernels; round 2 left them on rocBLAS, a first attempt through the convolution operators cost +0.37 ms
+    # per step in layout changes and re-packs and was reverted)
     d = step_embedding(diffusion_step, net.residual_channels)       # :119
-    h = F.linear(d, net.mlp[0].weight, net.mlp[0].bias)
-    d = F.linear(h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)      # :120 (Mish)
+    h = linear_rows(d, net.mlp[0].weight, net.mlp[0].bias)
+    d = linear_rows(h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)   # :120 (Mish)
     from . import train_fused
     if train_fused.enabled() and train_fused.supported(net):
         # the whole residual stack as ONE autograd node on the fused kernels (csrc/train_kernels.hpp); the step projections of all layers
@@ -228,12 +269,12 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
         layers = list(net.residual_layers)
         wd = torch.cat([l.diffusion_projection.weight for l in layers], 0)
         bd = torch.cat([l.diffusion_projection.bias for l in layers], 0)
-        step_all = F.linear(d, wd, bd).view(B, len(layers), net.residual_channels)
+        step_all = linear_rows(d, wd, bd).view(B, len(layers), net.residual_channels)
         skip = train_fused.residual_stack(net, x, cm, step_all, T)
     else:
         skip = None
         for l, layer in enumerate(net.residual_layers):             # ResidualBlock.forward :66-78
-            ds = F.linear(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)
+            ds = linear_rows(d, layer.diffusion_projection.weight, layer.diffusion_projection.bias)
             y = _AddStep.apply(x, ds, T)
             a = conv(f'l{l}.dc', y, layer.dilated_conv, layer.dilation) + conv(f'l{l}.cp', cm, layer.conditioner_projection)
             g = _Gate.apply(a, T)

@@ -65,6 +65,16 @@ int64_t dsf_attention_bwd_workspace_floats(int32_t B, int32_t heads, int32_t T);
 int dsf_attention_bwd(const float* qkv, const uint8_t* key_pad, const float* dout, float* dqkv, float* ws, int32_t B, int32_t C, int32_t heads,
                       int32_t T, void* stream);
 
+/* torch.nn.Linear on a handful of rows - the step-embedding MLP and the layers' step projections of the denoiser under training
+ * (usr/diff/net.py:94-98, :119-120, :67): y [rows][n_out] = x [rows][n_in] w[n_out][n_in]^T + bias (bias may be NULL), and the gradients
+ * (each output may be NULL): dx = dy w, dw = dy^T x, db = column sums of dy in row order.  Plain row-major fp32, no packing.
+ * ws: NULL, or dsf_linear_rows_workspace_floats(rows, n_in, n_out) floats - with it a long contraction behind few outputs is split over K
+ * and the partial products are added in a fixed order. */
+int64_t dsf_linear_rows_workspace_floats(int32_t rows, int32_t n_in, int32_t n_out);
+int dsf_linear_rows(const float* x, const float* w, const float* bias, float* y, float* ws, int32_t rows, int32_t n_in, int32_t n_out, void* stream);
+int dsf_linear_rows_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, float* ws, int32_t rows, int32_t n_in,
+                        int32_t n_out, void* stream);
+
 /* Layout changes at the boundary: the reference's [B,T,C] tensors (any element strides) <-> channel-major. */
 int dsf_to_channel_major(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_t, float* out, int32_t B, int32_t C,
                          int32_t T, void* stream);

@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LOSS_KEYS = ('decoder_inp', 'dur', 'pitch_pred', 'cwt', 'f0_mean', 'f0_std')
+LOSS_KEYS = ('decoder_inp', 'dur', 'pitch_pred', 'cwt', 'f0_mean', 'f0_std', 'energy_pred')
 
 
 def loss_of(ret, seed):
@@ -40,7 +40,7 @@ def main(name):
     from tests import fs2_helpers as FH
     case, m_hip, hp_ours, params, inp = FH.case_setup(name)
     assert case['mode'] == 'teacher', 'the training forward is teacher-forced (mel2ph, f0, uv given)'
-    ref = Reference(presets()[case['preset']]['source'])
+    ref = Reference(presets()[case['preset']]['source'], overrides=case.get('overrides'))
     hp = ref.hparams
     hp['cwt_scales'] = np.arange(10)
     enc = ref.TokenTextEncoder(None, vocab_list=[f'p{i}' for i in range(VOCAB - 3)], replace_oov=',')

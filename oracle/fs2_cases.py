@@ -22,9 +22,20 @@ CASES = {
     'fs2_midi_e2e_free': dict(preset='opencpop_ds1000', mode='free', B=3, T_txt=18, seed=206),
     # ... and teacher-forced: the forward of the e2e TRAINING step (BASELINE configs[3]; usr/diffsinger_task.py:273-300)
     'fs2_midi_e2e_teacher': dict(preset='opencpop_ds1000', mode='teacher', B=2, T_txt=20, seed=207),
+    # options no shipped DiffSpeech / DiffSinger YAML enables (configs/singing/base.yaml:34 ships use_spk_embed: true, the usr/ configs
+    # override it): `overrides` are applied to the reference's hparams and to ours alike
+    #   projected speaker d-vector + energy embedding (fs2.py:45-46, :75-82, :107-108, :139-140), energy supplied
+    'fs2_popcs_spk_energy_teacher': dict(preset='popcs_ds_beta6', mode='teacher', B=2, T_txt=16, seed=208,
+                                         overrides={'use_spk_embed': True, 'use_energy_embed': True}),
+    #   speaker ids with separate tables for the duration / pitch predictors (:37-42, :109-119), energy predicted
+    'fs2_lj_spkid_energy_free': dict(preset='lj_ds_beta6', mode='free', B=3, T_txt=14, seed=209,
+                                     overrides={'use_spk_id': True, 'use_split_spk_id': True, 'num_spk': 5, 'use_energy_embed': True}),
+    #   phone-level pitch (:184-196): one f0 per phone, its bin gathered to the frames
+    'fs2_popcs_ph_teacher': dict(preset='popcs_ds_beta6', mode='teacher', B=2, T_txt=18, seed=210, overrides={'pitch_type': 'ph'}),
+    'fs2_popcs_ph_free': dict(preset='popcs_ds_beta6', mode='free', B=2, T_txt=13, seed=211, overrides={'pitch_type': 'ph'}),
 }
 
-OUT_KEYS = ['encoder_out', 'mel2ph', 'dur', 'decoder_inp', 'mel_out', 'pitch_pred', 'cwt', 'f0_denorm']
+OUT_KEYS = ['encoder_out', 'mel2ph', 'dur', 'decoder_inp', 'mel_out', 'pitch_pred', 'cwt', 'f0_denorm', 'energy_pred']
 
 
 def synth_params(shapes: dict, seed: int) -> dict:
@@ -47,12 +58,14 @@ def synth_params(shapes: dict, seed: int) -> dict:
             out[k] = 1 + 0.1 * torch.randn(shape, generator=g)
         else:                                           # biases
             out[k] = 0.1 * torch.randn(shape, generator=g)
-    for k in ('encoder_embed_tokens.weight', 'encoder.embed_tokens.weight', 'pitch_embed.weight', 'midi_embed.weight'):
+    for k in ('encoder_embed_tokens.weight', 'encoder.embed_tokens.weight', 'pitch_embed.weight', 'midi_embed.weight', 'energy_embed.weight'):
         if k in out:
             out[k][0] = 0                               # padding_idx row
     if 'encoder.embed_tokens.weight' in out:
         out['encoder.embed_tokens.weight'] = out['encoder_embed_tokens.weight']      # one shared tensor in the module
     out['dur_predictor.linear.bias'] = out['dur_predictor.linear.bias'] + 1.2        # ~2 frames / phone: no empty utterance
+    if 'energy_predictor.linear.bias' in out:
+        out['energy_predictor.linear.bias'] = out['energy_predictor.linear.bias'] + 2.0   # predicted energy > 0 (a negative one indexes the table out of range, fs2.py:179)
     return out
 
 
@@ -78,4 +91,19 @@ def make_inputs(case: dict, use_midi: bool) -> dict:
         uv = (torch.rand(B, T, generator=g) < 0.2).float()
         inp['uv'] = uv
         inp['f0'] = (torch.rand(B, T, generator=g) * 2 + 6.5) * (1 - uv)      # log2 Hz, 0 where unvoiced
+    ov = case.get('overrides', {})
+    g2 = torch.Generator().manual_seed(case['seed'] + 77)                   # (the base cases' draws stay what they were)
+    if ov.get('pitch_type') == 'ph' and case['mode'] == 'teacher':
+        del inp['uv']
+        inp['f0'] = (torch.rand(B, Tt, generator=g2) * 2 + 6.5) * valid      # one value per phone
+    if ov.get('use_spk_embed'):
+        inp['spk_embed'] = torch.randn(B, 256, generator=g2)
+    if ov.get('use_spk_id'):
+        n = ov.get('num_spk', 1) + 1
+        inp['spk_embed'] = torch.randint(0, n, (B,), generator=g2)
+        if ov.get('use_split_spk_id'):
+            inp['spk_embed_dur_id'] = torch.randint(0, n, (B,), generator=g2)
+            inp['spk_embed_f0_id'] = torch.randint(0, n, (B,), generator=g2)
+    if ov.get('use_energy_embed') and case['mode'] == 'teacher':
+        inp['energy'] = torch.rand(B, inp['mel2ph'].shape[1], generator=g2) * 3.5 * (inp['mel2ph'] > 0)
     return inp

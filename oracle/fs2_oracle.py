@@ -267,8 +267,22 @@ def scale_grad(x, g):
 
 def add_pitch(p, hp, decoder_inp, f0, uv, mel2ph, ret, encoder_out):
     """FastSpeech2.add_pitch (fs2.py:183-231)."""
-    if hp['pitch_type'] == 'ph' or hp.get('pitch_ar'):
-        raise NotImplementedError('pitch_type ph / pitch_ar')
+    if hp.get('pitch_ar'):
+        # fs2.py:215 calls self.pitch_predictor(decoder_inp, f0 ...) - PitchPredictor.forward (tts_modules.py:222) takes one argument:
+        # the option raises a TypeError in the reference itself
+        raise NotImplementedError('pitch_ar: dead option of the reference (TypeError at fs2.py:215)')
+    if hp['pitch_type'] == 'ph':
+        # fs2.py:184-196: prediction and quantisation at the PHONE rate, the bins gathered to the frames through mel2ph
+        pp_inp = scale_grad(encoder_out, hp['predictor_grad'])
+        pitch_padding = encoder_out.sum().abs() == 0
+        ret['pitch_pred'] = pp = pitch_predictor(p, 'pitch_predictor.', pp_inp, hp['predictor_layers'], hp['predictor_kernel'])
+        if f0 is None:
+            f0 = pp[:, :, 0]
+        ret['f0_denorm'] = f0_denorm = denorm_f0(f0, None, hp, pitch_padding=pitch_padding)
+        pitch = F.pad(f0_to_coarse(f0_denorm.clone()), [1, 0])
+        pitch = torch.gather(pitch, 1, mel2ph)
+        ret['pitch_coarse'] = pitch
+        return F.embedding(pitch, p['pitch_embed.weight'], 0)
     decoder_inp = scale_grad(decoder_inp, hp['predictor_grad'])
     pitch_padding = mel2ph == 0
     given_f0 = f0 is not None
@@ -308,12 +322,21 @@ def add_pitch(p, hp, decoder_inp, f0, uv, mel2ph, ret, encoder_out):
 # ----------------------------------------------------------------------------------------------
 # the model
 # ----------------------------------------------------------------------------------------------
+def add_energy(p, hp, decoder_inp, energy, ret):
+    """FastSpeech2.add_energy (fs2.py:174-181); EnergyPredictor is PitchPredictor (tts_modules.py:253-254)."""
+    decoder_inp = scale_grad(decoder_inp, hp['predictor_grad'])
+    ret['energy_pred'] = energy_pred = pitch_predictor(p, 'energy_predictor.', decoder_inp, hp['predictor_layers'], hp['predictor_kernel'])[:, :, 0]
+    if energy is None:
+        energy = energy_pred
+    energy = torch.clamp(energy * 256 // 4, max=255).long()
+    ret['energy_coarse'] = energy
+    return F.embedding(energy, p['energy_embed.weight'], 0)
+
+
 def fs2_forward(p: Dict[str, torch.Tensor], hp: dict, txt_tokens, mel2ph=None, f0=None, uv=None, skip_decoder=False,
-                pitch_midi=None, midi_dur=None, is_slur=None) -> Dict[str, torch.Tensor]:
+                pitch_midi=None, midi_dur=None, is_slur=None, spk_embed=None, energy=None, spk_embed_dur_id=None,
+                spk_embed_f0_id=None) -> Dict[str, torch.Tensor]:
     """FastSpeech2.forward (fs2.py:93-149) / FastSpeech2MIDI.forward (diffsinger_midi/fs2.py:55-118), infer=True."""
-    for k in ('use_spk_id', 'use_spk_embed', 'use_energy_embed'):
-        if hp.get(k):
-            raise NotImplementedError(k)
     ret = {}
     if hp.get('use_midi'):
         midi_emb = F.embedding(pitch_midi, p['midi_embed.weight'], 0)
@@ -324,7 +347,22 @@ def fs2_forward(p: Dict[str, torch.Tensor], hp: dict, txt_tokens, mel2ph=None, f
         encoder_out = encoder(p, hp, txt_tokens)
     ret['encoder_out'] = encoder_out
     src_nonpadding = (txt_tokens > 0).float()[:, :, None]
-    dur_inp = scale_grad(encoder_out * src_nonpadding, hp['predictor_grad'])
+    # speaker conditioning (fs2.py:107-121): a projected d-vector, or embedding rows by speaker id (optionally separate tables for the
+    # duration and the pitch predictors)
+    if hp.get('use_spk_embed'):
+        spk_dur = spk_f0 = spk = F.linear(spk_embed, p['spk_embed_proj.weight'], p['spk_embed_proj.bias'])[:, None, :]
+    elif hp.get('use_spk_id'):
+        sid = spk_embed
+        spk_embed_dur_id = sid if spk_embed_dur_id is None else spk_embed_dur_id
+        spk_embed_f0_id = sid if spk_embed_f0_id is None else spk_embed_f0_id
+        spk = F.embedding(sid, p['spk_embed_proj.weight'])[:, None, :]
+        spk_dur = spk_f0 = spk
+        if hp.get('use_split_spk_id'):
+            spk_dur = F.embedding(spk_embed_dur_id, p['spk_embed_dur.weight'])[:, None, :]
+            spk_f0 = F.embedding(spk_embed_f0_id, p['spk_embed_f0.weight'])[:, None, :]
+    else:
+        spk_dur = spk_f0 = spk = 0
+    dur_inp = scale_grad((encoder_out + 0 + spk_dur) * src_nonpadding, hp['predictor_grad'])
     if mel2ph is None:
         dur, xs = duration_predictor_inference(p, hp, dur_inp, txt_tokens == 0)
         ret['dur'], ret['dur_choice'] = xs, dur
@@ -340,10 +378,12 @@ def fs2_forward(p: Dict[str, torch.Tensor], hp: dict, txt_tokens, mel2ph=None, f
     decoder_inp = F.pad(encoder_out, [0, 0, 1, 0])
     decoder_inp = torch.gather(decoder_inp, 1, mel2ph[..., None].repeat([1, 1, C]))
     tgt_nonpadding = (mel2ph > 0).float()[:, :, None]
-    pitch_inp = decoder_inp * tgt_nonpadding
+    pitch_inp = (decoder_inp + 0 + spk_f0) * tgt_nonpadding
     if hp['use_pitch_embed']:
-        decoder_inp = decoder_inp + add_pitch(p, hp, pitch_inp, f0, uv, mel2ph, ret, encoder_out * src_nonpadding)
-    ret['decoder_inp'] = decoder_inp = decoder_inp * tgt_nonpadding
+        decoder_inp = decoder_inp + add_pitch(p, hp, pitch_inp, f0, uv, mel2ph, ret, (encoder_out + 0 + spk_f0) * src_nonpadding)
+    if hp.get('use_energy_embed'):
+        decoder_inp = decoder_inp + add_energy(p, hp, pitch_inp, energy, ret)
+    ret['decoder_inp'] = decoder_inp = (decoder_inp + spk) * tgt_nonpadding
     if skip_decoder:
         return ret
     x = fft_blocks(p, 'decoder.', decoder_inp, hp['dec_layers'], hp['num_heads'], hp['dec_ffn_kernel_size'], hp['ffn_act'])

@@ -23,7 +23,7 @@ def run_case(name):
     from diffsinger_amd.synth import presets
     from tests import fs2_helpers as FH
     case, m_hip, hp_ours, params, inp = FH.case_setup(name)
-    ref = Reference(presets()[case['preset']]['source'])
+    ref = Reference(presets()[case['preset']]['source'], overrides=case.get('overrides'))
     hp = ref.hparams
     hp['cwt_scales'] = np.arange(10)                 # only its length is used (utils/cwt.py:118-125); set by the binarizer normally
     for k, v in hp_ours.items():                     # the preset really is the YAML

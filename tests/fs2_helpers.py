@@ -16,6 +16,7 @@ def build_module(case_name):
     case = CASES[case_name]
     hparams.clear()
     diffsinger_amd.use_preset(case['preset'])
+    hparams.update(case.get('overrides', {}))
     from diffsinger_amd import fs2
     cls = fs2.FastSpeech2MIDI if hparams.get('use_midi') else fs2.FastSpeech2
     return cls(VOCAB, 80).eval(), dict(hparams)

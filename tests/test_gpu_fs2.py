@@ -125,7 +125,7 @@ def test_fs2_matches_reference(name):
     g = FH.load_golden(name)
     out = _run_hip(name)
     np.testing.assert_array_equal(out['mel2ph'], g['mel2ph'])
-    for k in ('dur', 'pitch_pred', 'cwt', 'decoder_inp', 'mel_out'):
+    for k in ('dur', 'pitch_pred', 'cwt', 'energy_pred', 'decoder_inp', 'mel_out'):
         if k not in g:
             continue
         assert out[k].shape == g[k].shape, (k, out[k].shape, g[k].shape)

@@ -44,6 +44,31 @@ def test_conv_backward_operators(B, T, Ci, Co, K, dil):
     assert e['y'] <= 2e-5 and e['dx'] <= 2e-5 and e['dw'] <= 2e-5 and e['db'] <= 2e-5
 
 
+@pytest.mark.parametrize('rows,n_in,n_out', [(8, 256, 1024), (3, 1024, 256), (5, 256, 20 * 256), (1, 384, 384), (48, 100, 70)])
+def test_linear_rows_forward_and_gradients(rows, n_in, n_out):
+    """dsf_linear_rows / dsf_linear_rows_bwd (the step-embedding MLP and the layers' step projections under training, usr/diff/net.py:94-98,
+    :119-120, :67) against torch's Linear on the CPU: fp32, sums over up to 5120 terms in k order - 5e-6 relative to the tensor's max-abs."""
+    from diffsinger_amd.train import linear_rows
+    g = torch.Generator().manual_seed(rows + n_out)
+    x = torch.randn(rows, n_in, generator=g).requires_grad_(True)
+    w = (torch.randn(n_out, n_in, generator=g) * n_in ** -0.5).requires_grad_(True)
+    b = (torch.randn(n_out, generator=g) * 0.1).requires_grad_(True)
+    y = F.linear(x, w, b)
+    dy = torch.randn(rows, n_out, generator=g)
+    y.backward(dy)
+    d = torch.device('cuda', 0)
+    xd, wd, bd = (t.detach().to(d).requires_grad_(True) for t in (x, w, b))
+    yd = linear_rows(xd, wd, bd)
+    yd.backward(dy.to(d))
+    rel = lambda got, want: float((got.cpu() - want).abs().max() / want.abs().max())
+    e = {'y': rel(yd.detach(), y.detach()), 'dx': rel(xd.grad, x.grad), 'dw': rel(wd.grad, w.grad), 'db': rel(bd.grad, b.grad)}
+    print(f'linear_rows {rows}x{n_in}->{n_out}: {e}')
+    assert max(e.values()) <= 5e-6, e
+    # no bias, input without gradient (the first MLP layer reads the sinusoidal embedding)
+    y2 = linear_rows(xd.detach(), wd, None)
+    assert rel(y2.detach(), F.linear(x, w).detach()) <= 5e-6
+
+
 @pytest.mark.parametrize('preset,B,T', [('opencpop_ds60_rel', 2, 50), ('lj_ds_beta6', 3, 96)])
 def test_p_losses_and_all_parameter_gradients(preset, B, T):
     import diffsinger_amd

@@ -287,7 +287,11 @@ def test_p_losses_variants_on_the_fused_path(loss_type, masked):
     cfg = H.net_config(pre)
     params = {k: v.clone().requires_grad_(True) for k, v in H.oracle_params(cfg).items()}
     B, T = 3, 77
-    g = torch.Generator().manual_seed(23)
+    # The seed is chosen for CONDITIONING: the loss is a mean over 18 480 elements (gradients ~1e-4), so one ReLU whose pre-activation sits
+    # within the forward's 3e-6 of zero and falls on the other side changes skip_projection.weight's gradient by 5 % of its max (seed 23:
+    # min |pre-activation| 8.4e-8, element (0, 41, 47) - found with tools/diag_linear_rows.py when the step MLP moved off rocBLAS and its
+    # outputs moved by 6e-7).  The margin of this seed is asserted below on the oracle.
+    g = torch.Generator().manual_seed(26)
     x0 = torch.clamp(torch.randn(B, 1, 80, T, generator=g) * 0.5, -1, 1)
     noise = torch.randn(B, 1, 80, T, generator=g)
     cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
@@ -296,7 +300,17 @@ def test_p_losses_variants_on_the_fused_path(loss_type, masked):
     keep[1, :, 50:] = 0
     keep[2, :, 10:] = 0
     sch = O.make_schedule(H.betas_for(pre))
-    eps_ref = O.diffnet_forward(params, cfg, O.q_sample(sch, x0, t, noise), t, cond)
+    margins, relu0 = [], F.relu
+
+    def relu_probe(x, *a, **kw):
+        margins.append(float(x.detach().abs().min()))
+        return relu0(x, *a, **kw)
+    F.relu = relu_probe                                                 # (oracle.F is this module)
+    try:
+        eps_ref = O.diffnet_forward(params, cfg, O.q_sample(sch, x0, t, noise), t, cond)
+    finally:
+        F.relu = relu0
+    assert len(margins) == 2 and min(margins) >= 8e-6, f'ill-conditioned case: a ReLU pre-activation within {min(margins):.1e} of zero'
     if loss_type == 'l1':
         loss_ref = ((noise - eps_ref).abs() * keep.unsqueeze(1)).mean() if masked else (noise - eps_ref).abs().mean()
     else:

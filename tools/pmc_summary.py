@@ -1,7 +1,7 @@
 """Developer tool: reduce rocprofv3 --pmc passes (csv `*counter_collection.csv` or rocpd sqlite) over ONE kernel to
 per-dispatch averages, and derive the HBM traffic per launch for bench.py's `roofline.traffic`.
 
-    python tools/pmc_summary.py <dir with the pass outputs> <kernel substring> <out.txt> <out.json> [key=value ...]
+    python tools/pmc_summary.py <dir with the pass outputs> <kernel substring> <out.txt> <out.json> [key=value ...] [min_us=<dur>]
 
 Units / corrections (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC slots"): FETCH_SIZE and WRITE_SIZE are reported in KiB;
 on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) coalesced reads at 64 bytes, i.e. reports half the
@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 
-def from_csv(root, kern):
+def from_csv(root, kern, min_us=0.0):
     acc = defaultdict(list)
     dur = defaultdict(list)
     for path in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
@@ -24,6 +24,12 @@ def from_csv(root, kern):
             for row in csv.DictReader(f):
                 if kern not in row.get('Kernel_Name', ''):
                     continue
+                if min_us > 0:          # one shape of a kernel that is launched with many: keep the dispatches at least this long
+                    try:
+                        if (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3 < min_us:
+                            continue
+                    except (KeyError, ValueError):
+                        continue
                 name = row['Counter_Name']
                 acc[name].append(float(row['Counter_Value']))
                 try:
@@ -82,7 +88,11 @@ def from_db(root, kern):
 
 
 def main(root, kern, out_txt, out_json, *extras):
-    acc, dur = from_csv(root, kern)
+    min_us = 0.0
+    for kv in extras:
+        if kv.startswith('min_us='):
+            min_us = float(kv.split('=', 1)[1])
+    acc, dur = from_csv(root, kern, min_us)
     src = 'csv'
     if not acc:
         acc, dur = from_db(root, kern)
@@ -101,6 +111,8 @@ def main(root, kern, out_txt, out_json, *extras):
     for kv in extras:                       # e.g. frames=8192 kernel_tag='k_layer<1,false>' round=r01b
         k, v = kv.split('=', 1)
         js[k] = int(v) if v.isdigit() else v
+    if min_us > 0:
+        lines.insert(1, f'# only dispatches of at least {min_us:g} us (one shape of the kernel)')
     if 'FETCH_SIZE' in avg and 'WRITE_SIZE' in avg:
         fetch = avg['FETCH_SIZE'] * 1024 * 2
         write = avg['WRITE_SIZE'] * 1024
