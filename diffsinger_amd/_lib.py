@@ -25,7 +25,7 @@ SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf
                'dsf_ln_bwd_workspace_floats', 'dsf_layer_norm_bwd', 'dsf_attention_bwd_workspace_floats', 'dsf_attention_bwd',
                'dsf_linear_rows_workspace_floats', 'dsf_linear_rows', 'dsf_linear_rows_bwd',
                'dsf_to_channel_major', 'dsf_from_channel_major', 'dsf_p_sample', 'dsf_denorm_spec',
-               'dsf_conv1d_dilated', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad',
+               'dsf_conv1d_dilated', 'dsf_set_conv_split', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad',
                'dsf_train_add_step', 'dsf_train_rowsum', 'dsf_train_gate', 'dsf_train_gate_bwd', 'dsf_train_res_skip', 'dsf_train_res_skip_bwd',
                'dsf_channel_affine', 'dsf_group_norm', 'dsf_adamw_step',
                'dsf_stack_workspace_floats', 'dsf_set_stack_mode', 'dsf_stack_offsets', 'dsf_stack_forward', 'dsf_stack_backward', 'dsf_wgrad2_workspace_floats', 'dsf_conv1d_wgrad2', 'dsf_wgrad_probe', 'dsf_wgrad_probe_read']
@@ -131,6 +131,7 @@ def load():
     lib.dsf_attention_bwd_workspace_floats.argtypes = [i32, i32, i32]
     lib.dsf_attention_bwd_workspace_floats.restype = i64
     lib.dsf_attention_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.dsf_set_conv_split.argtypes = [i32]
     lib.dsf_linear_rows_workspace_floats.argtypes = [i32, i32, i32]
     lib.dsf_linear_rows_workspace_floats.restype = i64
     lib.dsf_linear_rows.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]

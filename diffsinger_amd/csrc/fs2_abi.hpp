@@ -9,6 +9,21 @@ static inline int fs_ts(int T) { return (T + 31) / 32 * 32; }
 // Row blocks per wave of k_fs_conv (fixes the packed weight layout): 2 = 256 rows per workgroup, two workgroups per CU.  (4 - 512 rows, one
 // workgroup per CU - was measured slower on the wide layers in round 1, profiles/r01s_*, and its instantiation was dropped in round 3.)
 static inline int fs_nmb(int Co) { (void)Co; return 2; }
+static int g_fs_conv_split = -1;           // -1: by grid size (default), 0: never, 1: wherever the shape allows it (tests / A-B)
+extern "C" int dsf_set_conv_split(int32_t mode) {
+    if (mode < -1 || mode > 1) return fail(DSD_ERR_INVALID, "dsf_set_conv_split: mode must be -1 (by grid size), 0 or 1");
+    g_fs_conv_split = mode;
+    return DSD_OK;
+}
+static int fs_ncu() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
 
 extern "C" int dsf_padded_frames(int32_t T) { return fs_ts(T); }
 
@@ -59,6 +74,7 @@ static int fs_conv_launch(const float* in, const float* wpacked, const float* bi
         return fail(DSD_ERR_INVALID, "dsf_conv1d: bad shape (B=%d T=%d Ci=%d Co=%d K=%d dil=%d act=%d)", B, T, Ci, Co, KT, dil, act);
     if (first_on_device(10)) {
         (void)hipFuncSetAttribute((const void*)k_fs_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_fs_conv_ks, hipFuncAttributeMaxDynamicSharedMemorySize, kFsConvLdsBytes);
     }
     FsConvParams p{};
     p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.keep = keep;
@@ -66,6 +82,14 @@ static int fs_conv_launch(const float* in, const float* wpacked, const float* bi
     p.scale = scale; p.act = act;
     const int nmb = fs_nmb(Co);
     const dim3 grid((unsigned)(p.TS / 32), (unsigned)B, (unsigned)((Co + 128 * nmb - 1) / (128 * nmb)));
+    // small grids (at most one workgroup for every second CU): 64-row workgroups whose waves split the contraction (k_fs_conv_ks)
+    const long long wgs = (long long)grid.x * grid.y * grid.z;
+    if (Ci % 32 == 0 && (g_fs_conv_split == 1 || (g_fs_conv_split < 0 && 2 * wgs <= fs_ncu()))) {
+        const dim3 gks(grid.x, grid.y, (unsigned)((Co + 63) / 64));
+        hipLaunchKernelGGL(k_fs_conv_ks, gks, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
+        HIP_TRY(hipGetLastError());
+        return DSD_OK;
+    }
     hipLaunchKernelGGL((k_fs_conv<2>), grid, dim3(kThreads), kFsConvLdsBytes, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return DSD_OK;

@@ -143,6 +143,98 @@ __global__ __launch_bounds__(kThreads, NMB == 4 ? 1 : 2) void k_fs_conv(const Fs
 }
 constexpr int kFsConvLdsBytes = kFsSlab * kFsLD * (int)sizeof(float);
 
+// The same convolution for SMALL GRIDS (the phone-rate encoder of a batch, everything of a single utterance): k_fs_conv gives a workgroup 256
+// output rows x 32 frames and lets every wave walk the whole contraction - with 32 to 128 workgroups on 256 CUs the launch lasts as long as
+// ONE such chain (K = 2304: 61 us of dependent MFMAs).  Here a workgroup owns 64 rows x 32 frames (blockIdx.z = the 64-row group, the packed
+// weights are read where they lie) and its four waves split every slab's chunk range four ways; the partial blocks meet in LDS, are added in
+// wave order (fixed: deterministic) and each wave finishes 8 rows of both 32-row blocks.  4 x the workgroups, a quarter of the chain each.
+// Needs slabs whose channel count is a multiple of 32 (Ci % 32 == 0).
+__global__ __launch_bounds__(kThreads, 2) void k_fs_conv_ks(const FsConvParams p) {
+    constexpr int NMB = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [kFsSlab][kFsLD]; behind the contraction: [4 waves][2][16][64] partials
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * 32, b = blockIdx.y, rg = blockIdx.z;  // rg = 64-row group (mtile * 4 + w4 of k_fs_conv)
+    const int nchunk_total = (p.Ci / 8) * p.KT;
+    f32x16 acc[NMB][1];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][0][r] = 0.f;
+    const float* inb = p.in + (size_t)b * p.Ci * p.TS;
+    constexpr int NIT = kFsSlab * (kFsLD / 4) / kThreads;
+    float4 sv[NIT];
+    auto request = [&](int c0, int nc) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * kThreads + tid, row = idx / (kFsLD / 4), g = idx - row * (kFsLD / 4);
+            const int t = t0 - kFsHalo + 4 * g;
+            const bool ok = (row < nc) && (t >= 0) && (t < p.TS);
+            const float4 v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + (ok ? row : 0)) * p.TS + (ok ? t : t0));
+            sv[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        DSD_SB();
+    };
+    request(0, min(kFsSlab, p.Ci));
+    for (int c0 = 0; c0 < p.Ci; c0 += kFsSlab) {
+        const int nc = min(kFsSlab, p.Ci - c0);
+        const int g4 = nc / 32;                                        // 8-channel groups per wave
+        const int nq = g4 * p.KT;                                      // chunks per wave
+        const float4* ap = p.wp + ((size_t)rg * nchunk_total + (size_t)(c0 / 8) * p.KT + (size_t)w * nq) * (NMB * 64);
+        FsTapB bof(smem + (w * g4 * 8 + 4 * h) * kFsLD + kFsHalo + j - p.pad, p.KT, p.dil, nq);
+        GemmPipe<NMB, 1, kFsLD, NMB * 64, 6, FsTapB> pipe(ap, lane, nq, bof);
+        pipe.start_a();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * kThreads + tid, row = idx / (kFsLD / 4), g = idx - row * (kFsLD / 4);
+            if (row < nc) *reinterpret_cast<float4*>(smem + row * kFsLD + 4 * g) = sv[it];
+        }
+        __syncthreads();
+        if (c0 + kFsSlab < p.Ci) request(c0 + kFsSlab, min(kFsSlab, p.Ci - c0 - kFsSlab));
+        pipe.start_b();
+        pipe.run_blocks(acc, nq);
+        __syncthreads();
+    }
+    // partial blocks -> LDS [wave][mb][r][lane] (conflict-free: lanes contiguous), summed in wave order by the wave that finishes the rows
+    float* part = smem;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[((w * NMB + mb) * 16 + r) * 64 + lane] = acc[mb][0][r];
+    __syncthreads();
+    const int t = t0 + j;
+    const bool tv = t < p.T;
+    float kp = 1.f;
+    if (p.keep && tv) kp = p.keep[(size_t)b * p.T + t];
+    float sum[NMB][4], bv[NMB][4], rv[NMB][4];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * w + q;
+            const int row = rg * 64 + 32 * mb + frag_row(r, h);
+            const int rc = (row < p.Co) ? row : 0;
+            bv[mb][q] = p.bias ? p.bias[rc] : 0.f;
+            rv[mb][q] = p.res ? p.res[((size_t)b * p.Co + rc) * p.TS + t] : 0.f;
+            float s = part[((0 * NMB + mb) * 16 + r) * 64 + lane];
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) s += part[((ww * NMB + mb) * 16 + r) * 64 + lane];
+            sum[mb][q] = s;
+        }
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = rg * 64 + 32 * mb + frag_row(4 * w + q, h);
+            float v = (sum[mb][q] + bv[mb][q]) * p.scale;
+            if (p.act == FS_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == FS_ACT_GELU) v = v * 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+            else if (p.act == FS_ACT_MISH) v = v * tanhf((v > 20.f) ? v : log1pf(expf(v)));
+            v = (v + rv[mb][q]) * kp;
+            if (row < p.Co) p.out[((size_t)b * p.Co + row) * p.TS + t] = tv ? v : 0.f;
+        }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // LayerNorm over C = 256 channels of every frame column
 // ------------------------------------------------------------------------------------------------------------

@@ -83,6 +83,12 @@ class PackedWeight:
         return self.buf
 
 
+def set_conv_split(mode: int):
+    """Kernel choice of conv1d_cm: -1 by grid size (default: small grids run k_fs_conv_ks, 64-row workgroups whose waves split the contraction),
+    0 never, 1 wherever the shape allows it.  Process-wide (dsf_set_conv_split); for tests and A/B measurements."""
+    _lib.check(_lib.load().dsf_set_conv_split(int(mode)), 'dsf_set_conv_split')
+
+
 def conv1d_cm(x: torch.Tensor, T: int, weight: torch.Tensor, packed: PackedWeight, bias: Optional[torch.Tensor] = None, *,
               scale: float = 1.0, act: str = 'none', residual: Optional[torch.Tensor] = None, keep: Optional[torch.Tensor] = None):
     """y = act(scale * (W * x + bias)) (+ residual) (* keep): nn.Conv1d 'SAME' / nn.Linear on a cm tensor."""

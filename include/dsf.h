@@ -80,6 +80,12 @@ int dsf_to_channel_major(const float* x, int64_t stride_b, int64_t stride_c, int
                          int32_t T, void* stream);
 int dsf_from_channel_major(const float* in, float* out /* [B][T][C] contiguous */, int32_t B, int32_t C, int32_t T, void* stream);
 
+/* dsf_conv1d / dsf_conv1d_dilated pick their kernel by grid size: launches with at most one workgroup for every second CU (the phone-rate
+ * encoder, everything of a single utterance) run 64-row workgroups whose waves split the contraction (k_fs_conv_ks; partial sums added in a
+ * fixed order - results differ from the other kernel by summation order only).  mode: -1 by grid size (default), 0 never, 1 wherever the
+ * shape allows it (Ci a multiple of 32).  Process-wide; for tests and A/B measurements. */
+int dsf_set_conv_split(int32_t mode);
+
 /* The same convolution with a dilation (kernel K odd, dil * (K-1)/2 <= 8): the DiffNet dilated_conv (usr/diff/net.py:62) as a
  * stand-alone operator of the TRAINING path, and the data gradient of any of these convolutions (= the convolution with the
  * flipped, transposed weight). */

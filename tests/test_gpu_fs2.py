@@ -56,15 +56,45 @@ def test_conv1d(B, T, Ci, Co, K, act, scale, use_res, use_keep):
     d = _dev()
     xc = fs2.to_cm(x.to(d))
     assert float(xc[:, :, T:].abs().max() if xc.shape[2] > T else 0) == 0
-    out = fs2.conv1d_cm(xc, T, w.to(d), fs2.PackedWeight(), bias.to(d), scale=scale, act=act,
-                        residual=fs2.to_cm(res.to(d)) if res is not None else None, keep=keep.to(d).contiguous() if keep is not None else None)
-    assert out.shape == (B, Co, fs2.padded_frames(T))
-    if out.shape[2] > T:
-        assert float(out[:, :, T:].abs().max()) == 0                    # the zero-tail invariant
-    got = fs2.from_cm(out, T).cpu()
-    err = float((got - ref).abs().max())
-    print(f'conv Ci={Ci} Co={Co} K={K} act={act}: max-abs err {err:.3e} (max|ref| {float(ref.abs().max()):.2f})')
-    assert err <= 2e-5
+    outs = {}
+    try:
+        # both kernels on every shape: 256-row workgroups (k_fs_conv) and the small-grid form whose waves split the contraction (k_fs_conv_ks)
+        for mode in (0, 1):
+            fs2.set_conv_split(mode)
+            out = fs2.conv1d_cm(xc, T, w.to(d), fs2.PackedWeight(), bias.to(d), scale=scale, act=act,
+                                residual=fs2.to_cm(res.to(d)) if res is not None else None, keep=keep.to(d).contiguous() if keep is not None else None)
+            assert out.shape == (B, Co, fs2.padded_frames(T))
+            if out.shape[2] > T:
+                assert float(out[:, :, T:].abs().max()) == 0                # the zero-tail invariant
+            got = outs[mode] = fs2.from_cm(out, T).cpu()
+            err = float((got - ref).abs().max())
+            print(f'conv Ci={Ci} Co={Co} K={K} act={act} split={mode}: max-abs err {err:.3e} (max|ref| {float(ref.abs().max()):.2f})')
+            assert err <= 2e-5
+    finally:
+        fs2.set_conv_split(-1)
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-5
+
+
+def test_conv1d_kernel_choice_by_grid_size():
+    """Automatic mode: a launch with few workgroups takes the K-split kernel, a chip-filling one the 256-row kernel - each bit-identical to its
+    forced form."""
+    from diffsinger_amd import fs2
+    d = _dev()
+    g = torch.Generator(device=d).manual_seed(3)
+    w = torch.randn(256, 256, 3, device=d, generator=g) * 0.03
+    bias = torch.randn(256, device=d, generator=g) * 0.1
+    for B, T, forced in ((2, 100, 1), (8, 1024, 0)):
+        xc = fs2.to_cm(torch.randn(B, T, 256, device=d, generator=g))
+        auto = fs2.conv1d_cm(xc, T, w, fs2.PackedWeight(), bias)
+        try:
+            fs2.set_conv_split(forced)
+            same = fs2.conv1d_cm(xc, T, w, fs2.PackedWeight(), bias)
+            fs2.set_conv_split(1 - forced)
+            other = fs2.conv1d_cm(xc, T, w, fs2.PackedWeight(), bias)
+        finally:
+            fs2.set_conv_split(-1)
+        assert torch.equal(auto, same), (B, T)
+        assert not torch.equal(auto, other) and float((auto - other).abs().max()) <= 2e-5
 
 
 @pytest.mark.parametrize('eps,relu_in,use_keep', [(1e-5, False, False), (1e-5, False, True), (1e-12, True, True)])
