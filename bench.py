@@ -481,6 +481,9 @@ def main_fs2(args):
     m = m.to(device)
     tok = tok.to(device)
     kw = {k: v.to(device) for k, v in kw.items()}
+    if args.conv_split != -1:
+        from diffsinger_amd import fs2 as _fs2
+        _fs2.set_conv_split(args.conv_split)
 
     def step():
         return m(tok, infer=True, **{k: (v.clone() if k == 'f0' else v) for k, v in kw.items()})
@@ -561,6 +564,8 @@ def main():
     ap.add_argument('--config', type=int, choices=[2, 5], default=0,
                     help='BASELINE configuration of the headline run: 2 = configs[1] (8 x T=1024 per GPU; the default at --gpus 1), 5 = configs[4] '
                          '(512 utterances x T=2048 sharded across the GPUs, strong scaling; the default at --gpus > 1)')
+    ap.add_argument('--conv-split', type=int, choices=[-1, 0, 1], default=-1,
+                    help='--row fs2 A/B: kernel choice of the FastSpeech2 convolutions (-1 by grid size = the product, 0 never the K-split kernel, 1 always)')
     ap.add_argument('--chain', choices=['default', 'off', 'stage', 'resblock', 'pair'], default='default',
                     help='--row vocoder: how the ResBlock1 chains are launched (diffsinger_amd.vocoder.set_chain_mode); default = by channel count')
     ap.add_argument('--split', action='store_true', help='EXPERIMENT: residual layers as six bf16 plane products per fp32 product (fp32-class accuracy) '
