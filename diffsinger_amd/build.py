@@ -11,9 +11,9 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(PKG, 'csrc', 'dsd.hip')]
-DEPS = SRC + [os.path.join(PKG, 'csrc', f) for f in ('dsd_kernels.hpp', 'dsd_loop.hpp', 'dsd_lat.hpp', 'dsd_split.hpp', 'fs2_kernels.hpp', 'fs2_train.hpp', 'fs2_abi.hpp', 'train_kernels.hpp', 'train_loop.hpp', 'train_abi.hpp',
-                                                   'voc_kernels.hpp', 'voc_chain.hpp', 'voc_abi.hpp')] + [
-    os.path.join(os.path.dirname(PKG), 'include', f) for f in ('dsd.h', 'dsf.h', 'dsv.h')]
+# every header under csrc/ and include/ is a dependency (a fixed list went stale when pwg_kernels.hpp was added: its edits did not rebuild)
+DEPS = SRC + sorted(os.path.join(PKG, 'csrc', f) for f in os.listdir(os.path.join(PKG, 'csrc')) if f.endswith('.hpp')) + sorted(
+    os.path.join(os.path.dirname(PKG), 'include', f) for f in os.listdir(os.path.join(os.path.dirname(PKG), 'include')) if f.endswith('.h'))
 LIB = os.path.join(PKG, 'libdsdenoise.so')
 # -ffp-contract=off: hipcc's default (fast) fuses a*b+c into FMA wherever it likes, also across the __fmul_rn / __fadd_rn
 # "intrinsics" (plain operators to the optimiser) - the sampler arithmetic must round every product like the reference's

@@ -307,6 +307,7 @@ extern "C" int dsd_get_layer_tile(dsd_handle* h) { return h ? 32 * layer_nb(h) :
 
 // Function attributes (dynamic LDS above 64 KiB) belong to a DEVICE's code object: true the first time call site `site` is reached on the
 // current device - a process that drives several GPUs (the reference's DP threads, utils/pl_utils.py:146-154) sets them on each.
+// site ids in use (one per call site, never shared): 1, 2 dsd.hip; 10, 11 fs2_abi.hpp; 30 train_abi.hpp; 40 voc_abi.hpp (ParallelWaveGAN)
 static bool first_on_device(int site) {
     static std::mutex mu;
     static std::set<std::pair<int, int>> seen;

@@ -2,6 +2,7 @@
 // the library stays one translation unit (shares the error string, the HIP_TRY macros and the operand-packing kernel).
 #include "voc_kernels.hpp"
 #include "voc_chain.hpp"
+#include "pwg_kernels.hpp"
 
 #include "../../include/dsv.h"
 
@@ -232,6 +233,43 @@ extern "C" int dsv_sine_source(const float* f0, const float* rand_ini, const flo
     mp.T = T; mp.up = up; mp.L = L; mp.LS = LS; mp.H = H;
     mp.noise_std = noise_std; mp.sine_amp = sine_amp; mp.voiced_threshold = voiced_threshold;
     hipLaunchKernelGGL(k_voc_source, dim3((unsigned)((LS + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, mp);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// ParallelWaveGAN generator (csrc/pwg_kernels.hpp)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int dsv_pwg_layer(const float* x, const float* c, const float* w1_packed, const float* b1, const float* w2_packed, const float* b2,
+                             float* x_out, float* skip, int32_t B, int32_t L, int32_t n_aux, int32_t dil, int32_t first, void* stream) {
+    if (!x || !w1_packed || !w2_packed || !x_out || !skip || x == x_out) return fail(DSD_ERR_INVALID, "dsv_pwg_layer: null argument / in-place call");
+    if (B < 1 || B > 65535 || L < 1 || dil < 1 || n_aux < 0 || n_aux > kPwgMaxAux || (n_aux % 8) || (n_aux && !c))
+        return fail(DSD_ERR_INVALID, "dsv_pwg_layer: bad shape (B=%d L=%d dil=%d aux=%d: aux channels a multiple of 8, at most %d)", B, L, dil, n_aux, kPwgMaxAux);
+    if (first_on_device(40)) HIP_TRY(hipFuncSetAttribute((const void*)k_pwg_layer, hipFuncAttributeMaxDynamicSharedMemorySize, kPwgLayerLdsBytes));
+    PwgLayerParams p{};
+    p.x = x; p.c = n_aux ? c : nullptr; p.w1p = reinterpret_cast<const float4*>(w1_packed); p.b1 = b1;
+    p.w2p = reinterpret_cast<const float4*>(w2_packed); p.b2 = b2; p.x_out = x_out; p.skip = skip;
+    p.L = L; p.LS = voc_ls(L); p.dil = dil; p.naux = n_aux; p.first = first ? 1 : 0;
+    hipLaunchKernelGGL(k_pwg_layer, dim3((unsigned)(p.LS / 32), (unsigned)B), dim3(kThreads), kPwgLayerLdsBytes, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsv_pwg_upsample(const float* in, const float* filter, float* out, int64_t rows, int32_t L_in, int32_t scale, void* stream) {
+    if (!in || !filter || !out) return fail(DSD_ERR_INVALID, "dsv_pwg_upsample: null argument");
+    if (rows < 1 || rows > 65535 || L_in < 1 || scale < 1 || scale > 64) return fail(DSD_ERR_INVALID, "dsv_pwg_upsample: bad shape (rows=%lld L=%d scale=%d)", (long long)rows, L_in, scale);
+    const int LS_in = voc_ls(L_in), LS_out = voc_ls(L_in * scale);
+    hipLaunchKernelGGL(k_pwg_upsample, dim3((unsigned)((LS_out + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, in, filter, out, L_in,
+                       LS_in, scale, LS_out);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsv_pwg_first(const float* z, const float* w, const float* bias, float* out, int32_t B, int32_t C, int32_t L, void* stream) {
+    if (!z || !w || !out) return fail(DSD_ERR_INVALID, "dsv_pwg_first: null argument");
+    if (B < 1 || B > 65535 || C < 1 || C > 65535 || L < 1) return fail(DSD_ERR_INVALID, "dsv_pwg_first: bad shape");
+    const int LS = voc_ls(L);
+    hipLaunchKernelGGL(k_pwg_first, dim3((unsigned)((LS + 255) / 256), (unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream, z, w, bias, out, C, L, LS);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

@@ -493,21 +493,27 @@ def get_vocoder_cls(hp):
     """vocoders/base_vocoder.py:11-19: a registered name, or a dotted `package.Class` path (the shipped configs say
     `vocoder: vocoders.hifigan.HifiGAN`; inside the reference tree that import then finds the class `register_vocoders` rebound)."""
     import importlib
+    from . import pwg  # noqa: F401  (registers PWG: `vocoder: pwg` is the default of configs/tts/base.yaml:88)
     if hp['vocoder'] in VOCODERS:
         return VOCODERS[hp['vocoder']]
     pkg, cls_name = hp['vocoder'].rsplit('.', 1)
-    if cls_name in VOCODERS and pkg in ('vocoders.hifigan', 'diffsinger_amd.vocoder'):
+    if cls_name in VOCODERS and pkg in ('vocoders.hifigan', 'vocoders.pwg', 'diffsinger_amd.vocoder', 'diffsinger_amd.pwg'):
         return VOCODERS[cls_name]
     return getattr(importlib.import_module(pkg), cls_name)
 
 
-def register_vocoders(*registries, modules=()):
-    """Rebind HifiGAN in the reference's registry (vocoders.base_vocoder.VOCODERS) and, for configs that name the class by its dotted
-    path, in the modules that export it:   register_vocoders(vocoders.base_vocoder.VOCODERS, modules=[vocoders.hifigan])"""
+def register_vocoders(*registries, modules=(), pwg_modules=()):
+    """Rebind HifiGAN and PWG in the reference's registry (vocoders.base_vocoder.VOCODERS) and, for configs that name a class by its dotted
+    path, in the modules that export it:
+        register_vocoders(vocoders.base_vocoder.VOCODERS, modules=[vocoders.hifigan], pwg_modules=[vocoders.pwg])"""
+    from .pwg import PWG
     for reg in registries:
         reg['hifigan'] = reg['HifiGAN'] = HifiGAN
+        reg['pwg'] = reg['PWG'] = PWG
     for mod in modules:
         mod.HifiGAN = HifiGAN
+    for mod in pwg_modules:
+        mod.PWG = PWG
     return registries
 
 

@@ -110,6 +110,22 @@ int dsv_sine_source(const float* f0, const float* rand_ini, const float* noise, 
                     float* har, int32_t B, int32_t T, int32_t up, int32_t H, float sample_rate, float sine_amp, float noise_std,
                     float voiced_threshold, void* stream);
 
+/* ParallelWaveGAN generator (vocoders/pwg.py; modules/parallel_wavegan/models/parallel_wavegan.py:21-177) - residual_channels 64, gate_channels
+ * 128, skip_channels 64, kernel_size 3 (the configuration the reference ships and trains); activations [B][C][LS(L)] like the HiFi-GAN ops.
+ * dsv_pwg_first: first_conv, Conv1d1x1(1, C) on the noise z [B][LS]: out[b][c][t] = w[c] z[b][t] + bias[c].
+ * dsv_pwg_upsample: one stage of UpsampleNetwork (layers/upsample.py:96-117) on `rows` = B * C rows: nearest-neighbour stretch by `scale`, then the
+ *   (2 scale + 1)-tap filter the Conv2d(1, 1, (1, 2 scale + 1), padding (0, scale), bias=False) shares between all rows.
+ * dsv_pwg_layer: one ResidualBlock (layers/residual_block.py:96-129):
+ *     a = conv(x; kernel 3, dilation dil, 'same') + b1 + conv1x1_aux(c);  z = tanh(a[0:64]) * sigmoid(a[64:128])
+ *     x_out = (conv1x1_out(z) + x) * sqrt(0.5);   skip = (first ? 0 : skip) + conv1x1_skip(z)
+ *   w1_packed = dsv_pack_weight of the [128][3 * 64 + n_aux][1] matrix whose columns are tap * 64 + ci (tap 0 reads t - dil) followed by the aux
+ *   channels; w2_packed = dsv_pack_weight of [128][64][1], rows 0..63 conv1x1_out, 64..127 conv1x1_skip; b1 [128] / b2 [128] may be NULL.
+ *   Any dilation (the generator's run to 512 samples); x_out must not alias x. */
+int dsv_pwg_first(const float* z, const float* w, const float* bias, float* out, int32_t B, int32_t C, int32_t L, void* stream);
+int dsv_pwg_upsample(const float* in, const float* filter, float* out, int64_t rows, int32_t L_in, int32_t scale, void* stream);
+int dsv_pwg_layer(const float* x, const float* c, const float* w1_packed, const float* b1, const float* w2_packed, const float* b2, float* x_out,
+                  float* skip, int32_t B, int32_t L, int32_t n_aux, int32_t dil, int32_t first, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

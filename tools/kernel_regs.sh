@@ -3,7 +3,7 @@
 set -e
 D=$(mktemp -d)
 SO=${2:-$(dirname $0)/../diffsinger_amd/libdsdenoise.so}
-/opt/rocm/lib/llvm/bin/llvm-objcopy --dump-section .hip_fatbin=$D/fat.bin $SO 2>/dev/null
+cp $SO $D/lib.so && /opt/rocm/lib/llvm/bin/llvm-objcopy --dump-section .hip_fatbin=$D/fat.bin $D/lib.so 2>/dev/null   # on a COPY: objcopy rewrites its input (and its mtime: the build then looks up to date)
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$D/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$D/dev.co
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $D/dev.co | python3 -c "
 import sys,re
