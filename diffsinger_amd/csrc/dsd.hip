@@ -286,10 +286,14 @@ extern "C" int dsd_set_layer_tile(dsd_handle* h, int32_t frames) {
 extern "C" int64_t dsd_device_bytes(dsd_handle* h) { return h ? h->bytes + h->bytes_ws : 0; }
 
 // Row split G of the latency kernels for the prepared batch, 0 = not on that path.  Automatic mode: the largest G in {16, 8, 4, 2} that
-// still gives every workgroup a CU of its own - i.e. only batches that leave at least half of the chip idle.
+// still gives every workgroup a CU of its own - i.e. batches that leave at least half of the chip idle - and G = 8 for the band above it
+// (between half and 5/8 of the CU count in tiles: 129-160 on 256 CUs, e.g. ONE phrase of 4200-5000 frames or 5 x 1024): the persistent loop
+// leaves 37-50 % of the CUs without a tile there, 8 x ntiles workgroups in at most five grid waves measured 115-121 ms against its 127 ms
+// per K = 100 call (profiles/r47_midsize_paths.jsonl); one more grid wave (163 tiles) and the loop wins again.
 static int lat_g(const dsd_handle* h) {
     if (h->split_mode || h->layer_tile_req || h->lat_req == 0 || h->loop_mode < 2) return 0;
     int g = (16 * h->ntiles <= h->n_cu) ? 16 : (8 * h->ntiles <= h->n_cu) ? 8 : (4 * h->ntiles <= h->n_cu) ? 4 : (2 * h->ntiles <= h->n_cu) ? 2 : 0;
+    if (g == 0 && h->loop_mode == 2 && h->ntiles < h->n_cu && 8 * h->ntiles <= 5 * h->n_cu) g = 8;
     if (h->loop_mode == 3 && g == 0) g = 2;
     if (g && (h->lat_req == 2 || h->lat_req == 4 || h->lat_req == 8 || h->lat_req == 16)) g = h->lat_req;
     return g;

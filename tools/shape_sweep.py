@@ -39,7 +39,7 @@ def main():
     dev = torch.device('cuda', 0)
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     g = torch.Generator(device=dev).manual_seed(7)
-    modes = [2] if ('--default-only' in sys.argv or '--lat-splits' in sys.argv) else [2, 1, 0]       # automatic (the product), then forced persistent loop / per-layer kernels
+    modes = [2] if '--default-only' in sys.argv else [2, 1, 0]       # automatic (the product), then forced persistent loop / per-layer kernels
     for B, T in shapes:
         conds = [torch.randn(B, T, 256, device=dev, generator=g).transpose(1, 2) for _ in range(2)]
         x_T = torch.randn(B, 1, 80, T, device=dev, generator=g)
@@ -74,7 +74,7 @@ def main():
             # forced row splits of the latency kernels (also with more workgroups than CUs: they are ordinary launches)
             eng = gd.denoise_fn.engine()
             row['forced_lat'] = {}
-            for G in (2, 4, 8, 16):
+            for G in (4, 8):
                 eng.set_loop_mode(3)
                 eng.set_lat_split(G)
                 out = one()
