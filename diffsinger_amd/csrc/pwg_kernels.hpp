@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_pwg_layer(const PwgLayerParams 
             const float v = xb[(size_t)ci * p.LS + (ok ? t : t0)];
             xv[i] = ok ? v : 0.f;
         }
-        const float* cb = p.c + (size_t)b * p.naux * p.LS;
+        const float* cb = p.naux ? p.c + (size_t)b * p.naux * p.LS : nullptr;
         const int tc = t0 + col;
 #pragma unroll
         for (int i = 0; i < kPwgMaxAux / 8; ++i) {
