@@ -1,6 +1,7 @@
 # GPU box: the evidence round of the CURRENT binary - whole GPU suite + smoke, headline bench (+ CPU baseline), k_loop timeline, rocprofv3 kernel
 # stats of the bench command, the three PMC passes over k_loop (separate --pmc runs, kernel-trace only) -> loop_pmc.json, machine ceilings
-# (bare fp32 MFMA stream, HBM read / copy), small-batch shape sweep, row benches (vocoder / fs2 / train), all-config throughput.
+# (bare fp32 MFMA stream, HBM read / copy), shape sweep, row benches (vocoder / fs2 / train), all-config throughput, one utterance end to end,
+# ParallelWaveGAN, vocoder and FastSpeech2 kernel stats + PMC passes.
 #   usage: bash tools/gpu_evidence.sh <tag> [nopytest]
 set -x
 export TMPDIR=/tmp
@@ -17,11 +18,14 @@ timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench
 timeout 200 python tools/loop_timeline.py $O/loop_timeline.json > $O/loop_timeline.txt 2>&1
 [ -x tools/mfma_probe4.bin ] && timeout 120 tools/mfma_probe4.bin > $O/mfma_probe4.txt 2>&1
 [ -x tools/hbm_probe.bin ] && timeout 120 tools/hbm_probe.bin > $O/hbm_probe.txt 2>&1
-timeout 300 python tools/shape_sweep.py 3 1x512,1x1550,4x777,8x1024,16x2048 > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
+timeout 400 python tools/shape_sweep.py 3 1x512,1x1000,1x1550,4x777,3x1550,1x5000,8x1024,16x2048 > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
 for row in vocoder fs2 train; do
 timeout 300 python bench.py --row $row --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_row_$row.json 2> $O/bench_row_$row.err
 done
 timeout 400 python tools/bench_configs.py 3 > $O/configs_throughput.jsonl 2> $O/configs_throughput.err
+timeout 200 python tools/bench_single.py 10 100 8 > $O/single_utterance.jsonl 2> $O/single_utterance.err
+timeout 200 python tools/bench_single.py 10 60 8 >> $O/single_utterance.jsonl 2>> $O/single_utterance.err
+timeout 200 python tools/bench_pwg.py 5 > $O/bench_pwg.jsonl 2> $O/bench_pwg.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/prof/*.db $O/prof/*/*.db 2>/dev/null | head -1) > $O/bench_n1_kernel_stats.txt 2>> $O/prof.log
@@ -39,6 +43,8 @@ for k in 8 16 32; do
 python $R/tools/pmc_summary.py $O/pmc_voc "k_voc_chain<$k" $O/voc_chain_${k}ch_pmc.txt $O/voc_chain_${k}ch_pmc.json "kernel_tag=k_voc_chain<$k" round=$TAG commit=$git_rev >> $O/pmc_summary.log 2>&1
 done
 timeout 200 python tools/voc_chain_timeline.py > $O/voc_chain_timeline.txt 2>&1
+# FastSpeech2 row: kernel stats + the PMC passes over the mel-rate ffn_1 launches (bench.py --row fs2 reads fs2_ffn1_pmc.json)
+cd $R; bash tools/gpu_fs2_prof.sh $TAG/fs2 > $O/fs2_prof.log 2>&1; cp $O/fs2/fs2_ffn1_pmc.json $O/fs2/fs2_ffn1_pmc.txt $O/fs2/fs2_kernel_stats.txt $O/ 2>/dev/null; rm -rf $O/fs2
 rm -rf $O/prof $O/prof_voc
 find $O/pmc $O/pmc_voc -name '*.db' -delete
 du -sh $O
