@@ -70,3 +70,23 @@ def test_cxx_host_example_builds_against_the_header(tmp_path):
     if not torch.cuda.is_available():
         run = subprocess.run([exe, '1', '32', '2'], capture_output=True, text=True)
         assert run.returncode != 0 and 'hipSetDevice' in run.stderr
+
+
+def test_build_dependencies_cover_every_included_header():
+    """diffsinger_amd/build.py rebuilds when a dependency is newer than the .so: every header dsd.hip includes (transitively) must be one -
+    a header missing from a fixed list (pwg_kernels.hpp, round 3) let GPU runs test a stale binary."""
+    import os
+    import re
+    from diffsinger_amd import build as B
+    csrc = os.path.join(B.PKG, 'csrc')
+    seen, todo = set(), [os.path.join(csrc, 'dsd.hip')]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.isfile(f):
+            continue
+        seen.add(f)
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(f).read()):
+            todo.append(os.path.normpath(os.path.join(os.path.dirname(f), inc)))
+    deps = {os.path.normpath(d) for d in B.DEPS}
+    missing = sorted(os.path.relpath(f, B.PKG) for f in seen if f not in deps)
+    assert not missing, missing
