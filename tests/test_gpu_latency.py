@@ -158,3 +158,28 @@ def test_latency_path_repeated_calls_and_many_tiles():
     ref = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
     eng.set_loop_mode(2)
     assert torch.equal(outs[0], ref)                         # G = 4: bit-identical to the per-layer kernels
+
+
+def test_midsize_band_runs_g8_on_several_grid_waves_and_matches_the_persistent_loop():
+    """129-160 tiles (here 3 x 1550 = 147): the automatic choice is G = 8 with 1176 workgroups on 256 CUs (they are ordinary launches: no
+    co-residency requirement).  Same mel as the persistent loop and the per-layer kernels up to the reduction order of the K split; the
+    oracle on one utterance."""
+    K, B, T = 8, 3, 1550
+    gd, _, _ = build_hip('lj_ds_beta6', K)
+    inp = make_inputs(64, B, T, n_noise=K)
+    cond, x_T, noise = inp['cond'].to(DEV), inp['x_T'].to(DEV), inp['noise'].to(DEV)
+    eng = gd._engine(cond)
+    assert eng.lat_split() == 8 and eng.loop_mode() == 0
+    out = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).clone()
+    again = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
+    assert torch.equal(out, again)
+    refs = {}
+    for mode in (1, 0):
+        eng.set_loop_mode(mode)
+        refs[mode] = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).clone()
+        assert eng.lat_split() == 0
+    eng.set_loop_mode(2)
+    assert torch.equal(refs[0], refs[1])
+    d = float((out - refs[1]).abs().max())
+    print(f'3 x 1550 (147 tiles), G = 8 vs the persistent loop after {K} steps: max-abs mel difference {d:.3e}')
+    assert d <= 2e-5
