@@ -173,7 +173,7 @@ extern "C" int32_t dsv_chain_supported(int32_t C, int32_t nres, int32_t npairs, 
     if (!convs || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs) return 0;
     int n = 0, hh = 0, rc = -1;
     if (C == 8) rc = voc_chain_geometry<8, 4, 2>(convs, nres, npairs, &n, &hh);
-    else if (C == 16) rc = voc_chain_geometry<16, 2, 3>(convs, nres, npairs, &n, &hh);
+    else if (C == 16) rc = voc_chain_geometry<16, 2, 2>(convs, nres, npairs, &n, &hh);
     else if (C == 32) rc = voc_chain_geometry<32, 1, 4>(convs, nres, npairs, &n, &hh);
     return rc == 0 ? n : 0;
 }
@@ -200,7 +200,7 @@ extern "C" int dsv_resblock_chain(const float* in, const float* wpacked, const f
         p.conv[i].pad = (c.K - 1) * c.dil / 2;
     }
     if (C == 8) return voc_chain_launch<8, 4, 2>(p, convs, B, (hipStream_t)stream);
-    if (C == 16) return voc_chain_launch<16, 2, 3>(p, convs, B, (hipStream_t)stream);
+    if (C == 16) return voc_chain_launch<16, 2, 2>(p, convs, B, (hipStream_t)stream);
     return voc_chain_launch<32, 1, 4>(p, convs, B, (hipStream_t)stream);
 }
 
