@@ -50,7 +50,7 @@ struct LatParams {
     int T, ntile32, ntiles, dil, first, last;
 };
 
-constexpr int kLatConvLdsBytes = (kC * (32 + 2 * kHalo) + 3 * 32 * 32) * (int)sizeof(float);     // y tile + K-half partials [2] + filter [1..2]
+constexpr int kLatConvLdsBytes = (kC * (32 + 2 * kHalo) + 4 * 32 * 32) * (int)sizeof(float);     // y tile + K partials [2] (G = 8) / [4] (G = 16) / filter [1..2]
 constexpr int kLatOutLdsBytes = (kC * 32 + 3 * 32 * 32) * (int)sizeof(float);                     // gate tile + K partials [2] (G = 8) / [3] (G = 16)
 
 // workgroup -> (tile, g): the G workgroups of a tile read the same x / gate tile, so they are placed behind the same L2 (workgroups
@@ -155,14 +155,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
     if (p.T > 0) {          // always true; a load in its own block cannot be sunk into the (conditional) blocks of its uses behind the MFMAs
         if (G == 16) {
             // gate row 16 g + i sits in the standard block (w4, mb0) at row 16 (g & 1) + i: register r of THIS lane there is r + 8 (g & 1) ->
-            // quads q' = q + 2 (g & 1), q = 0, 1; the filter rows are the same quads of block mb0 + 2.  Only wave 0 finishes the block.
-            if (wv == 0) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    cv[q] = cpl[(mb0 * 4 + q + 2 * (g & 1)) * 64];
-                    cf[q] = cpl[((mb0 + 2) * 4 + q + 2 * (g & 1)) * 64];
-                }
-            }
+            // quads q' = q + 2 (g & 1), q = 0, 1; the filter rows are the same quads of block mb0 + 2.  Wave wv finishes registers 2 wv, 2 wv + 1
+            // (and their filter partners): quad wv >> 1, components 2 (wv & 1), + 1
+            cv[0] = cpl[(mb0 * 4 + (wv >> 1) + 2 * (g & 1)) * 64];
+            cf[0] = cpl[((mb0 + 2) * 4 + (wv >> 1) + 2 * (g & 1)) * 64];
+        } else if (G == 8) {
+            // wave wv finishes registers 4 wv .. 4 wv + 3 of the gate block (g & 1) and of its filter block: quad wv of both
+            cv[0] = cpl[((g & 1) * 4 + wv) * 64];
+            cf[0] = cpl[(((g & 1) + 2) * 4 + wv) * 64];
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -177,13 +177,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
 
     float* gout = p.gbuf + (size_t)tile * TILE;
     if (G == 16) {
-        lat_ksum4(acc[0][0], red, wv, j, h);
-        if (wv == 0) {
+        // the four K partials meet in LDS; every wave adds them - in wave order ((p0 + p1) + p2) + p3, the order of lat_ksum4 - for TWO of the
+        // eight gate registers and their filter partners and finishes those rows (sigmoid and tanh of all eight on wave 0 alone were
+        // ~0.6 us of every layer)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float gv = sigmoid_f(acc[0][0][r] + f4at(cv[r >> 2], r & 3)) * tanh_f(acc[0][0][r + 8] + f4at(cf[r >> 2], r & 3));
-                gout[(16 * g + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = gv;
-            }
+        for (int r = 0; r < 16; ++r) red[wv * 1024 + frag_row(r, h) * 32 + j] = acc[0][0][r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = 2 * wv + q;
+            const float* pg = red + frag_row(r, h) * 32 + j;
+            const float* pf = red + frag_row(r + 8, h) * 32 + j;
+            const float ag = ((pg[0] + pg[1024]) + pg[2048]) + pg[3072];
+            const float af = ((pf[0] + pf[1024]) + pf[2048]) + pf[3072];
+            const float gv = sigmoid_f(ag + f4at(cv[0], r & 3)) * tanh_f(af + f4at(cf[0], r & 3));
+            gout[(16 * g + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = gv;
         }
         return;
     }
@@ -198,22 +206,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
         return;
     }
     if (G == 8) {
-        // sum the two K halves: the second-half waves hand their partial block to the first-half wave of the same role
-        float* part = red + (wv & 1) * 1024;
-        if (wv >= 2) {
+        // waves 0 / 1 hold the first K half of the gate / filter block, waves 2 / 3 the second: the four partial blocks meet in LDS and every
+        // wave finishes FOUR registers of the pair - first half + second half (the order of the two-wave form this replaces, bit for bit),
+        // sigmoid(gate) * tanh(filter) (net.py:73-74).  One barrier instead of two, the transcendental work on four waves instead of two.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[frag_row(r, h) * 32 + j] = acc[0][0][r];
-        }
+        for (int r = 0; r < 16; ++r) red[wv * 1024 + frag_row(r, h) * 32 + j] = acc[0][0][r];
         __syncthreads();
-        if (wv < 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][0][r] + part[frag_row(r, h) * 32 + j];
+        for (int qq = 0; qq < 4; ++qq) {
+            const int row = frag_row(4 * wv + qq, h);
+            const float* pr = red + row * 32 + j;
+            const float ag = pr[0] + pr[2048], af = pr[1024] + pr[3072];
+            const float gv = sigmoid_f(ag + f4at(cv[0], qq)) * tanh_f(af + f4at(cf[0], qq));
+            gout[(64 * w4 + 32 * (g & 1) + row) * 32 + j] = gv;
         }
+        return;
     }
-    // filter waves -> tanh(filter pre-activation) through LDS -> gate waves: sigmoid(gate pre-activation) * tanh(.)   (net.py:73-74)
-    const bool is_filter = (G == 4) ? (wv >= 2) : (wv == 1);
-    const bool is_gate = (G == 4) ? (wv < 2) : (wv == 0);
-    float* fx = (G == 4) ? red + (wv & 1) * 1024 : red + 2048;        // G = 4: two filter blocks (no K-half partials there); G = 8: one, behind them
+    // G = 4: filter waves -> tanh(filter pre-activation) through LDS -> gate waves: sigmoid(gate pre-activation) * tanh(.)   (net.py:73-74)
+    const bool is_filter = (wv >= 2);
+    const bool is_gate = (wv < 2);
+    float* fx = red + (wv & 1) * 1024;                                  // two filter blocks
     if (is_filter) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) fx[frag_row(r, h) * 32 + j] = tanh_f(acc[0][0][r] + f4at(cv[r >> 2], r & 3));
@@ -378,7 +390,7 @@ struct LatHeadParams {
     int ntiles;
 };
 constexpr int kLatHeadALdsBytes = (kC * 32 + 3 * 32 * 32) * (int)sizeof(float);
-constexpr int kLatHeadBLdsBytes = (kC * 32 + 3 * 32 * 32) * (int)sizeof(float);
+constexpr int kLatHeadBLdsBytes = (kC * 32 + 4 * 32 * 32) * (int)sizeof(float);
 constexpr int kLatHeadCLdsBytes = kMPad * 32 * (int)sizeof(float);
 
 // partial blocks of waves 1..3 -> wave 0: ((own + p1) + p2) + p3
@@ -462,17 +474,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_head_b(const LatHeadParams 
         for (int it = 0; it < 8; ++it) reinterpret_cast<float4*>(htile)[it * kThreads + tid] = v[it];
     }
     __syncthreads();
-    // what the sampler update reads besides eps, at the positions wave 0 finishes: requested in front of the contraction
+    // what the sampler update reads besides eps, at the positions THIS wave finishes (registers 4 wv .. 4 wv + 3 of the block: the sampler
+    // arithmetic - with the in-kernel Philox draw ~150 instructions per element - used to run on wave 0 alone, 16 elements per lane, and made
+    // this kernel 12.5 us of a 258 us evaluation): requested in front of the contraction
     const int t = t0 + j;
-    HeadPre pre[16];
-    if (wv == 0) {
+    HeadPre pre[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = 32 * g + frag_row(r, h);
-            const bool ok = (m < p.M) && (t < p.T);
-            const size_t idx = ((size_t)b * p.M + (ok ? m : 0)) * p.T + (ok ? t : 0);
-            head_prefetch<MODE>(p, idx, pre[r]);
-        }
+    for (int qq = 0; qq < 4; ++qq) {
+        const int m = 32 * g + frag_row(4 * wv + qq, h);
+        const bool ok = (m < p.M) && (t < p.T);
+        const size_t idx = ((size_t)b * p.M + (ok ? m : 0)) * p.T + (ok ? t : 0);
+        head_prefetch<MODE>(p, idx, pre[qq]);
     }
     DSD_SB();
     f32x16 acc[1][1];
@@ -483,18 +495,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_head_b(const LatHeadParams 
     }
     pipe.start_b();
     pipe.run(acc, 0, 8);
-    lat_ksum4(acc[0][0], red, wv, j, h);
-    if (wv == 0) {
-        float* pt = q.pbuf + (size_t)tile * (kMPad * 32);
+    // the four K partials meet in LDS; every wave adds them for ITS four registers in wave order ((p0 + p1) + p2) + p3 - the order of
+    // lat_ksum4, bit for bit - and finishes those rows
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = 32 * g + frag_row(r, h);
-            const bool ok = (m < p.M) && (t < p.T);
-            const size_t idx = ((size_t)b * p.M + m) * p.T + t;
-            float xn = 0.f;
-            if (ok) xn = head_apply<MODE>(p, acc[0][0][r], idx, pre[r]);
-            pt[m * 32 + j] = ok ? xn : 0.f;
-        }
+    for (int r = 0; r < 16; ++r) red[wv * 1024 + frag_row(r, h) * 32 + j] = acc[0][0][r];
+    __syncthreads();
+    float* pt = q.pbuf + (size_t)tile * (kMPad * 32);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const int row = frag_row(4 * wv + qq, h), m = 32 * g + row;
+        const float* pr = red + row * 32 + j;
+        const float eps = ((pr[0] + pr[1024]) + pr[2048]) + pr[3072];
+        const bool ok = (m < p.M) && (t < p.T);
+        const size_t idx = ((size_t)b * p.M + m) * p.T + t;
+        float xn = 0.f;
+        if (ok) xn = head_apply<MODE>(p, eps, idx, pre[qq]);
+        pt[m * 32 + j] = ok ? xn : 0.f;
     }
 }
 
