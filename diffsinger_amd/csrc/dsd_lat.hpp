@@ -222,18 +222,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
         }
         return;
     }
-    // G = 4: waves 0, 1 hold the two gate blocks, waves 2, 3 their filter blocks.  All four write their pre-activations (+ the conditioner term)
-    // to LDS; behind the ONE barrier wave wv finishes half of gate block wv >> 1: sigmoid(gate) * tanh(filter) (net.py:73-74) - the same
-    // arithmetic per element as the two-phase form (filter waves' tanh, barrier, gate waves' sigmoid), on four waves at once
+    // G = 4: filter waves -> tanh(filter pre-activation) through LDS -> gate waves: sigmoid(gate pre-activation) * tanh(.)   (net.py:73-74)
+    const bool is_filter = (wv >= 2);
+    const bool is_gate = (wv < 2);
+    float* fx = red + (wv & 1) * 1024;                                  // two filter blocks
+    if (is_filter) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wv * 1024 + frag_row(r, h) * 32 + j] = acc[0][0][r] + f4at(cv[r >> 2], r & 3);
+        for (int r = 0; r < 16; ++r) fx[frag_row(r, h) * 32 + j] = tanh_f(acc[0][0][r] + f4at(cv[r >> 2], r & 3));
+    }
     __syncthreads();
-    const int gb = wv >> 1, hw = wv & 1;
+    if (is_gate) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int row = frag_row(8 * hw + q, h);
-        const float gv = sigmoid_f(red[gb * 1024 + row * 32 + j]) * tanh_f(red[(gb + 2) * 1024 + row * 32 + j]);
-        gout[(64 * w4 + 32 * gb + row) * 32 + j] = gv;
+        for (int r = 0; r < 16; ++r) {
+            const float gv = sigmoid_f(acc[0][0][r] + f4at(cv[r >> 2], r & 3)) * fx[frag_row(r, h) * 32 + j];
+            gout[(64 * w4 + 32 * mb0 + frag_row(r, h)) * 32 + j] = gv;
+        }
     }
 }
 
