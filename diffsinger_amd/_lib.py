@@ -8,17 +8,17 @@ import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdsdenoise.so')
 
-DSD_ABI_VERSION = 3
+DSD_ABI_VERSION = 4
 
 # every symbol include/dsd.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
-    'dsd_abi_version', 'dsd_last_error', 'dsd_create', 'dsd_destroy', 'dsd_load_weights', 'dsd_set_schedule',
+    'dsd_abi_version', 'dsd_last_error', 'dsd_build_id', 'dsd_create', 'dsd_destroy', 'dsd_load_weights', 'dsd_set_schedule',
     'dsd_get_schedule_table', 'dsd_set_spec_range', 'dsd_prepare', 'dsd_denoise', 'dsd_q_sample',
     'dsd_sample_ddpm', 'dsd_p_sample', 'dsd_sample_plms', 'dsd_norm_spec', 'dsd_denorm_spec',
     'dsd_set_use_graph', 'dsd_set_layer_tile', 'dsd_time_layer_kernel', 'dsd_debug_layer_timeline', 'dsd_device_bytes',
     'dsd_get_layer_tile', 'dsd_set_loop_mode', 'dsd_get_loop_mode', 'dsd_loop_timeouts', 'dsd_debug_loop_timeline', 'dsd_set_noise_seed', 'dsd_philox_normal',
     'dsd_set_split_mode', 'dsd_get_split_mode', 'dsd_debug_layer', 'dsd_loop_launches', 'dsd_p_sample_ex', 'dsd_set_lat_split', 'dsd_get_lat_split',
-    'dsd_check', 'dsd_debug_hold_cus',
+    'dsd_check', 'dsd_loop_parked', 'dsd_debug_hold_cus',
 ]
 # every symbol include/dsf.h declares (the FastSpeech2 conditioner ops)
 SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf_conv1d', 'dsf_layer_norm', 'dsf_attention',
@@ -80,6 +80,7 @@ def load():
     h = C.c_void_p
     lib.dsd_abi_version.restype = C.c_int
     lib.dsd_last_error.restype = C.c_char_p
+    lib.dsd_build_id.restype = C.c_char_p
     lib.dsd_create.argtypes = [C.POINTER(DsdConfig), C.c_int, C.POINTER(h)]
     lib.dsd_destroy.argtypes = [h]
     lib.dsd_destroy.restype = None
@@ -107,6 +108,7 @@ def load():
     lib.dsd_loop_timeouts.argtypes = [h, C.c_void_p]
     lib.dsd_loop_launches.argtypes = [h]
     lib.dsd_check.argtypes = [h]
+    lib.dsd_loop_parked.argtypes = [h]
     lib.dsd_debug_hold_cus.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.dsd_set_lat_split.argtypes = [h, C.c_int32]
     lib.dsd_get_lat_split.argtypes = [h]
@@ -185,6 +187,11 @@ def load():
         raise RuntimeError(f'libdsdenoise ABI {lib.dsd_abi_version()} != binding {DSD_ABI_VERSION}: rebuild')
     _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """sha256 of the sources the loaded library was compiled from (dsd_build_id, include/dsd.h)."""
+    return load().dsd_build_id().decode()
 
 
 def check(rc: int, what: str = ''):

@@ -21,18 +21,51 @@ LIB = os.path.join(PKG, 'libdsdenoise.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off']
 
 
+_ID_TAG = b'DSD_BUILD_ID='
+
+
+def source_hash() -> str:
+    """sha256 over every source the library is compiled from (csrc/*.hip, csrc/*.hpp, include/*.h: names and bytes, sorted) and the
+    compiler flags.  The build bakes it into the .so (`dsd_build_id()`, include/dsd.h): a binary proves which tree it came from."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(PKG)
+    for f in sorted(DEPS):
+        h.update(os.path.relpath(f, root).encode() + b'\0')
+        h.update(open(f, 'rb').read())
+        h.update(b'\0')
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def binary_id(path: str = LIB):
+    """The build id baked into a built library, read from the file's bytes (no dlopen); None when absent."""
+    try:
+        blob = open(path, 'rb').read()
+    except OSError:
+        return None
+    i = blob.find(_ID_TAG)
+    if i < 0:
+        return None
+    j = i + len(_ID_TAG)
+    return blob[j:j + 64].decode('ascii', 'replace')
+
+
 def up_to_date() -> bool:
-    return os.path.isfile(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
+    """The binary is current when the hash it carries equals the hash of the tree - not when its mtime is newer (a snapshot copy, a
+    checkout or a touched file says nothing about contents)."""
+    return binary_id() == source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if up_to_date() and not force:
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + ['-o', LIB] + SRC
+    cmd = [hipcc] + FLAGS + [f'-DDSD_BUILD_ID_STR="{source_hash()}"', '-o', LIB] + SRC
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    assert binary_id() == source_hash(), 'the built library does not carry the hash of the tree it was built from'
     return LIB
 
 

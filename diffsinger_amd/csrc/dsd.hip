@@ -120,7 +120,8 @@ struct dsd_handle {
     // memory: the next call into the handle - or dsd_check - reads it without synchronising anything and fails loudly
     unsigned* sticky_host = nullptr;
     unsigned* sticky_dev = nullptr;
-    bool persist_off = false;         // set when a timeout was reported: the handle stays on the hipGraph path until dsd_set_loop_mode
+    bool persist_off = false;         // set when a timeout was reported: the handle is PARKED on the hipGraph path ...
+    int parked_calls = 0;             // ... for kParkedCalls sampling calls (or until dsd_set_loop_mode), then the persistent path is re-armed
     float* loop_halo = nullptr;       // [2][ntiles][2][256][8]
     int loop_cap_tiles = 0;
     int loop_tmo_at = -1;             // index of the timeout word of the LAST persistent run inside loop_flags (its ntiles), -1: none yet
@@ -132,6 +133,10 @@ struct dsd_handle {
     uint4 *w1s = nullptr, *w2s = nullptr;     // bf16 weight planes in 32x32x16 fragment order, [L][4][48|16][4][3][64]
 };
 
+// After a reported timeout the handle runs this many sampling loops on the hipGraph path before it tries the persistent loop again: a
+// long-lived server that was starved ONCE (a foreign kernel held CUs) must not run the slower path for the rest of its life, and one that is
+// starved all the time pays one failed loop in kParkedCalls + 1.
+static const int kParkedCalls = 16;
 static const int kSlack = 64;   // floats of slack in front of / behind the x buffers (masked halo loads)
 
 template <typename T>
@@ -203,6 +208,12 @@ static void free_workspace(dsd_handle* h) {
     h->prepared = false;
 }
 
+#ifndef DSD_BUILD_ID_STR
+#define DSD_BUILD_ID_STR "unknown"
+#endif
+// tag + id in one array: build.py finds the id in the file's bytes without loading the library
+extern "C" { __attribute__((used, visibility("default"))) const char dsd_build_id_blob[] = "DSD_BUILD_ID=" DSD_BUILD_ID_STR; }
+extern "C" const char* dsd_build_id(void) { return dsd_build_id_blob + 13; }
 extern "C" int dsd_abi_version(void) { return DSD_ABI_VERSION; }
 extern "C" const char* dsd_last_error(void) { return g_err.c_str(); }
 
@@ -360,11 +371,12 @@ static int check_sticky(dsd_handle* h, const char* who) {
     if (v == 0u) return DSD_OK;
     __atomic_store_n(h->sticky_host, 0u, __ATOMIC_RELEASE);
     h->persist_off = true;
+    h->parked_calls = 0;
     return fail(DSD_ERR_TIMEOUT,
                 "%s: %u persistent K-step loop launch(es) of an EARLIER call on this handle hit the inter-workgroup spin bound (a foreign kernel held "
                 "compute units the loop needs: another process on this GPU, a collective or another model on a side stream) - the mel / x tiles "
-                "those calls returned are NaN.  The handle now runs the hipGraph path (per-layer kernels) until dsd_set_loop_mode is called: "
-                "repeat the call", who, v);
+                "those calls returned are NaN.  The handle is parked on the hipGraph path (per-layer kernels) for the next %d sampling calls "
+                "(dsd_loop_parked; dsd_set_loop_mode re-arms at once): repeat the call", who, v, kParkedCalls);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1019,6 +1031,7 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
         }
         HIP_TRY(hipGraphLaunch(it->second, s));
     }
+    if (h->persist_off && ++h->parked_calls >= kParkedCalls) { h->persist_off = false; h->parked_calls = 0; }     // re-arm the persistent path
     HIP_TRY(hipMemcpyAsync(x, h->xs, bmt * 4, hipMemcpyDeviceToDevice, s));
     return DSD_OK;
 }
@@ -1108,8 +1121,11 @@ extern "C" int dsd_set_loop_mode(dsd_handle* h, int32_t mode) {
         return fail(DSD_ERR_INVALID, "dsd_set_loop_mode: mode must be 0 (per-layer kernels), 1 (persistent loop), 2 (automatic) or 3 (latency kernels)");
     h->loop_mode = mode;
     h->persist_off = false;           // an explicit choice re-arms the persistent path after a reported timeout
+    h->parked_calls = 0;
     return DSD_OK;
 }
+
+extern "C" int dsd_loop_parked(dsd_handle* h) { return (h && h->persist_off) ? kParkedCalls - h->parked_calls : 0; }
 
 extern "C" int dsd_set_lat_split(dsd_handle* h, int32_t g) {
     if (!h || !(g == -1 || g == 0 || g == 2 || g == 4 || g == 8 || g == 16))

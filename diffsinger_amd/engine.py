@@ -161,6 +161,11 @@ class DenoiserEngine:
             torch.cuda.current_stream(self.device).synchronize()
         _lib.check(self.lib.dsd_check(self._h), 'persistent loop')
 
+    def parked(self) -> int:
+        """Sampling calls this engine still runs on the hipGraph path after a reported persistent-loop timeout (0 = not parked); it
+        returns to the persistent loop by itself after that many calls, or at once with set_loop_mode()."""
+        return self.lib.dsd_loop_parked(self._h)
+
     def hold_cus(self, n_workgroups: int, milliseconds: int, stream: Optional[torch.cuda.Stream] = None):
         """Test hook: a foreign kernel that occupies `n_workgroups` compute units for `milliseconds` or until release_cus(), whichever comes
         first, on a side stream that really runs BESIDE the current stream; returns that stream once every holder is resident.

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DSD_ABI_VERSION 3
+#define DSD_ABI_VERSION 4
 
 typedef struct dsd_handle dsd_handle;
 
@@ -75,6 +75,10 @@ typedef struct dsd_weights {
 
 int dsd_abi_version(void);
 const char* dsd_last_error(void);
+/* sha256 (64 hex digits) of the sources this binary was compiled from - every .hip / .hpp under csrc/, every .h under include/ and the compiler flags, as
+ * diffsinger_amd/build.py source_hash() computes it; "unknown" for a build that did not go through build.py.  smoke() and every bench line
+ * print it and compare it with the hash of the tree they run from: the binary proves its source. */
+const char* dsd_build_id(void);
 
 /* DiffNet.__init__ (usr/diff/net.py:82-105): validates the configuration and binds the handle to `device`. */
 int dsd_create(const dsd_config* cfg, int device, dsd_handle** out);
@@ -197,10 +201,12 @@ int dsd_loop_timeouts(dsd_handle* h, void* stream);
  * dsd_check reads that word WITHOUT synchronising anything: DSD_OK, or DSD_ERR_TIMEOUT when a persistent loop that has finished since the
  * last report hit its spin bound (its result tiles are NaN).  Every data-path entry point (dsd_prepare, dsd_denoise, dsd_sample_*,
  * dsd_denorm_spec, ...) makes the same check first, so a timeout of call n surfaces at call n + 1 at the latest; a caller that wants it
- * at call n synchronises its stream (it does anyway before reading the mel) and calls dsd_check.  Reporting consumes the flag and parks
- * the handle on the hipGraph path (per-layer kernels, no co-residency requirement) so that the retry succeeds; dsd_set_loop_mode re-arms
- * the persistent path. */
+ * at call n synchronises its stream (it does anyway before reading the mel) and calls dsd_check.  Reporting consumes the flag and PARKS
+ * the handle on the hipGraph path (per-layer kernels, no co-residency requirement) so that the retry succeeds.  A parked handle returns to
+ * the persistent path by itself after 16 sampling calls (a server starved once is not slower for the rest of its life), or at once with
+ * dsd_set_loop_mode.  dsd_loop_parked: sampling calls left on the hipGraph path, 0 = not parked. */
 int dsd_check(dsd_handle* h);
+int dsd_loop_parked(dsd_handle* h);
 
 /* Test hook: occupy `n_workgroups` compute units (one 64-thread workgroup with the whole 160 KiB of LDS each, so nothing else fits
  * beside it) for `milliseconds` of wall-clock time on `stream` - the "foreign kernel" the persistent loop's timeout exists for.

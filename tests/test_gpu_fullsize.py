@@ -133,6 +133,28 @@ def test_zero_final_projection_closed_form_full_size():
     assert float((mel.cpu() - O.denorm_spec(x[:, 0].transpose(1, 2), smin, smax)).abs().max()) <= 1e-5
 
 
+def test_config5_shape_row_vs_oracle():
+    """BASELINE configs[4]'s per-GPU micro-batch: 16 utterances x T=2048, K=100 DDPM (1024 tiles = four persistent launches of whole
+    utterances).  One row of the batch against the oracle on identical (x_T, cond, noise[K]) - usr/diff/shallow_diffusion_tts.py:248-276."""
+    gd, cfg, pre, p, sch, smin, smax = _setup('lj_ds_beta6', 100)
+    B, T, K = 16, 2048, 100
+    g = torch.Generator().manual_seed(5005)
+    cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, generator=g)
+    b = 13
+    gn = torch.Generator(device='cuda').manual_seed(77)
+    noise = torch.randn(K, B, 1, 80, T, device='cuda', generator=gn)            # 1.05 GB: drawn on the device, row b copied back for the oracle
+    with torch.no_grad():
+        full = gd.inference(_dev_cond(cond), x_T=x_T.cuda(), noise=noise, K_step=K, pndm_speedup=0).cpu()
+        eng = gd.denoise_fn.engine()
+        assert eng.loop_mode() == 1 and eng.loop_launches() == 4 and eng.loop_timeouts() == 0
+        nb = noise[:, b:b + 1].cpu()
+        want = O.infer_mel(p, cfg, sch, cond[b:b + 1], smin, smax, k_step=K, noises=list(nb), x_T=x_T[b:b + 1])
+    err = float((full[b:b + 1] - want).abs().max())
+    print(f'config 5 shape (16 x 2048, K = 100) row {b}: max-abs mel err vs oracle {err:.3e}')
+    assert torch.isfinite(full).all() and err <= 1e-4
+
+
 def test_graph_eager_and_tiles_agree_at_config5_shape():
     """One GPU's micro-batch of BASELINE configs[4] (16 utterances x T=2048): graph == eager, 32- == 64-frame tiles,
     bit for bit (K shortened: the property is per step)."""
