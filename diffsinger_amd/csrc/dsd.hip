@@ -3,6 +3,7 @@
 #include "dsd_kernels.hpp"
 #include "dsd_loop.hpp"
 #include "dsd_lat.hpp"
+#include "dsd_loop_rs.hpp"
 #include "dsd_split.hpp"
 
 #include <cmath>
@@ -127,6 +128,10 @@ struct dsd_handle {
     int loop_tmo_at = -1;             // index of the timeout word of the LAST persistent run inside loop_flags (its ntiles), -1: none yet
     unsigned long long* loop_dbg = nullptr;   // debug: stamps of one phase (dsd_debug_loop_timeline)
     int loop_dbg_phase = 0;
+    // row-split persistent loop (dsd_loop_rs.hpp): -1 by batch size (default), 0 never, 2 / 4 / 8 / 16 forced (dsd_set_rs_split)
+    int rs_req = 0;                   // (bring-up default: off until the GPU suite has run on it)
+    float* rs_ring = nullptr;         // the six exchange rings of the prepared batch, sentinel-filled before every launch
+    int rs_cap_tiles = 0;
 
     // EXPERIMENT (dsd_split.hpp): residual layers on the bf16 matrix pipe with fp32-class accuracy; per-layer kernel path only
     bool split_mode = false;
@@ -199,8 +204,8 @@ static void free_workspace(dsd_handle* h) {
     dev_free(h->xs); dev_free(h->xtmp); dev_free(h->gbuf);
     for (auto& e : h->ering) dev_free(e);
     dev_free(h->t_dev); dev_free(h->coef_dev); dev_free(h->eps_tmp);
-    dev_free(h->loop_flags); dev_free(h->loop_halo);
-    h->loop_cap_tiles = 0;
+    dev_free(h->loop_flags); dev_free(h->loop_halo); dev_free(h->rs_ring);
+    h->loop_cap_tiles = 0; h->rs_cap_tiles = 0;
     h->loop_tmo_at = -1;
     h->xa = h->xb = nullptr;
     h->cap_frames = 0; h->cap_B = 0; h->cap_spec = 0;
@@ -236,6 +241,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     h->nk_in = (cfg->mel_bins + 7) / 8;
     if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);     // the same choice as dsd_set_loop_mode, for an unmodified host
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
+    if (const char* ev = std::getenv("DSD_RS")) h->rs_req = std::atoi(ev);                   // the same choice as dsd_set_rs_split
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
         if (e > 3) { delete h; return fail(DSD_ERR_INVALID, "dsd_create: dilation 2^%d exceeds the supported maximum %d", e, kHalo); }
@@ -252,6 +258,14 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_rs<2, HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_rs<4, HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_rs<8, HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_rs<16, HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_rs<2, HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_rs<4, HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_rs<8, HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_rs<16, HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -921,12 +935,14 @@ static hipEvent_t g_loop_ev[kMaxDevices];
 static hipStream_t g_loop_stream[kMaxDevices];
 static bool g_loop_has[kMaxDevices];
 
+static int rs_g(const dsd_handle* h);
+
 // true when the prepared batch can run as the persistent loop: 32-frame tiles, a whole utterance fits the co-resident grid
 static bool loop_applicable(const dsd_handle* h) {
     if (!((h->loop_mode == 1 || h->loop_mode == 2) && !h->persist_off && !h->split_mode && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 &&
           h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers)) return false;
     if (h->loop_mode == 2) {
-        if (lat_g(h)) return false;
+        if (rs_g(h) || lat_g(h)) return false;
         // chunks of whole utterances may leave much of the chip idle (T = 5000: 157 tiles per launch on 256 CUs); the per-layer kernels
         // have no such constraint, only the wave quantisation of their grid, and cost ~5 % more at equal occupancy
         const int upc = std::max(1, h->n_cu / h->ntile32), chunks = (h->B + upc - 1) / upc;
@@ -937,21 +953,11 @@ static bool loop_applicable(const dsd_handle* h) {
     return true;
 }
 
+static int get_plan(dsd_handle* h, int kind, int k_step, int interval, dsd_handle::LoopPlan** out);
+
 static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hipStream_t s) {
-    const GraphKey key{kind, h->B, h->T, k_step, interval, 32};
-    auto it = h->plans.find(key);
-    if (it == h->plans.end()) {
-        std::vector<HeadParams> ev; std::vector<int> ts;
-        plan_evals(h, kind, k_step, interval, ev, ts);
-        dsd_handle::LoopPlan pl;
-        pl.n_evals = (int)ev.size();
-        HIP_TRY(hipMalloc((void**)&pl.evals, ev.size() * sizeof(HeadParams)));
-        HIP_TRY(hipMalloc((void**)&pl.eval_t, ts.size() * sizeof(int)));
-        HIP_TRY(hipMemcpy(pl.evals, ev.data(), ev.size() * sizeof(HeadParams), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(pl.eval_t, ts.data(), ts.size() * sizeof(int), hipMemcpyHostToDevice));
-        if (h->plans.size() >= 8) drop_graphs(h);
-        it = h->plans.emplace(key, pl).first;
-    }
+    dsd_handle::LoopPlan* plan = nullptr;
+    DSD_TRY(get_plan(h, kind, k_step, interval, &plan));
     if (h->loop_cap_tiles < h->ntiles) {
         dev_free(h->loop_flags); dev_free(h->loop_halo);
         h->loop_tmo_at = -1;
@@ -966,7 +972,7 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
     p.L = h->L; p.T = h->T; p.TS = h->TS; p.ntile32 = h->ntile32; p.ntiles_total = h->ntiles;
     for (int l = 0; l < h->L; ++l) p.dil[l] = (unsigned char)h->dil[l];
     p.head = head_base(h);
-    p.evals = it->second.evals; p.eval_t = it->second.eval_t; p.n_evals = it->second.n_evals;
+    p.evals = plan->evals; p.eval_t = plan->eval_t; p.n_evals = plan->n_evals;
     p.spec0 = h->xs;
     p.flags = h->loop_flags; p.halo = h->loop_halo; p.tmo = h->loop_flags + h->ntiles;
     h->loop_tmo_at = h->ntiles;
@@ -1000,6 +1006,103 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
     return DSD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// row-split persistent loop (dsd_loop_rs.hpp)
+// ------------------------------------------------------------------------------------------------------------
+// G of the row-split persistent loop for the prepared batch, 0 = not on that path.  It takes the batches the latency kernels were built for -
+// ntiles * G <= CU count with G in {16, 8, 4, 2}, i.e. batches that leave at least half of the chip idle (the reference's own inference shape: one
+// utterance per device) - as ONE launch instead of 43 hipGraph nodes per evaluation.  Like every persistent path it needs hipGraph mode on (the
+// switch tests use to reach the eager per-layer kernels), automatic loop mode, and a handle that is not parked after a reported timeout.
+static int rs_g(const dsd_handle* h) {
+    if (h->rs_req == 0 || h->loop_mode != 2 || h->persist_off || h->split_mode || h->layer_tile_req || !h->use_graph || h->lat_req >= 0) return 0;
+    if (h->L < 2 || h->L > kLoopMaxLayers || h->n_cu < 8) return 0;
+    int g = (16 * h->ntiles <= h->n_cu) ? 16 : (8 * h->ntiles <= h->n_cu) ? 8 : (4 * h->ntiles <= h->n_cu) ? 4 : (2 * h->ntiles <= h->n_cu) ? 2 : 0;
+    if (g && h->rs_req > 0) g = (h->rs_req * h->ntiles <= h->n_cu) ? h->rs_req : 0;
+    return g;
+}
+
+static size_t rs_ring_floats(int ntiles) { return (size_t)ntiles * 3 * (5 * 32 * kC + 32 * kMPad); }
+
+template <int G>
+static void launch_rs(int kind, const RsParams& p, hipStream_t s) {
+    const dim3 grid((unsigned)lat_grid(p.ntiles, G));
+    if (kind == 0) hipLaunchKernelGGL((k_loop_rs<G, HEAD_DDPM>), grid, dim3(kThreads), kRsLdsBytes, s, p);
+    else hipLaunchKernelGGL((k_loop_rs<G, HEAD_PLMS>), grid, dim3(kThreads), kRsLdsBytes, s, p);
+}
+
+static int get_plan(dsd_handle* h, int kind, int k_step, int interval, dsd_handle::LoopPlan** out) {
+    const GraphKey key{kind, h->B, h->T, k_step, interval, 32};
+    auto it = h->plans.find(key);
+    if (it == h->plans.end()) {
+        std::vector<HeadParams> ev; std::vector<int> ts;
+        plan_evals(h, kind, k_step, interval, ev, ts);
+        dsd_handle::LoopPlan pl;
+        pl.n_evals = (int)ev.size();
+        HIP_TRY(hipMalloc((void**)&pl.evals, ev.size() * sizeof(HeadParams)));
+        HIP_TRY(hipMalloc((void**)&pl.eval_t, ts.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(pl.evals, ev.data(), ev.size() * sizeof(HeadParams), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(pl.eval_t, ts.data(), ts.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (h->plans.size() >= 8) drop_graphs(h);
+        it = h->plans.emplace(key, pl).first;
+    }
+    *out = &it->second;
+    return DSD_OK;
+}
+
+static int run_rs(dsd_handle* h, int G, int kind, int k_step, int interval, hipStream_t s) {
+    dsd_handle::LoopPlan* plan = nullptr;
+    DSD_TRY(get_plan(h, kind, k_step, interval, &plan));
+    if (h->loop_cap_tiles < h->ntiles) {
+        dev_free(h->loop_flags); dev_free(h->loop_halo);
+        h->loop_tmo_at = -1;
+        DSD_TRY(dev_alloc(h, &h->loop_flags, (size_t)h->ntiles + 64, true));
+        DSD_TRY(dev_alloc(h, &h->loop_halo, (size_t)2 * h->ntiles * 2 * kC * 8, true));
+        h->loop_cap_tiles = h->ntiles;
+    }
+    if (h->rs_cap_tiles < h->ntiles) {
+        dev_free(h->rs_ring);
+        DSD_TRY(dev_alloc(h, &h->rs_ring, rs_ring_floats(h->ntiles), true));
+        h->rs_cap_tiles = h->ntiles;
+    }
+    // every polled word starts as "not arrived" (sentinel), the timeout word as zero: re-initialised before EVERY launch
+    HIP_TRY(hipMemsetAsync(h->rs_ring, 0xff, rs_ring_floats(h->ntiles) * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(h->loop_flags, 0, ((size_t)h->ntiles + 64) * sizeof(unsigned), s));
+    RsParams p{};
+    p.w1p = h->w1p; p.w1q = h->w1q; p.w2p = h->w2p; p.b2raw = h->b2raw; p.cp = h->cp; p.cp_lstride = (size_t)h->ntiles * 4096;
+    p.ds_table = h->ds_table;
+    p.L = h->L; p.T = h->T; p.TS = h->TS; p.ntile32 = h->ntile32; p.ntiles = h->ntiles;
+    for (int l = 0; l < h->L; ++l) p.dil[l] = (unsigned char)h->dil[l];
+    p.head = head_base(h);
+    p.evals = plan->evals; p.eval_t = plan->eval_t; p.n_evals = plan->n_evals;
+    p.spec0 = h->xs;
+    const size_t slot = (size_t)h->ntiles * 3 * 32 * kC;
+    p.xb = h->rs_ring; p.x0b = p.xb + slot; p.gb = p.x0b + slot; p.sb = p.gb + slot; p.hb = p.sb + slot; p.pb = p.hb + slot;
+    p.tmo = h->loop_flags + h->ntiles;
+    h->loop_tmo_at = h->ntiles;
+    p.dbg = h->loop_dbg; p.dbg_phase = h->loop_dbg_phase;
+    // one persistent launch at a time per device (see run_persistent)
+    const int dv = (h->device >= 0 && h->device < kMaxDevices) ? h->device : 0;
+    std::lock_guard<std::mutex> guard(g_loop_mu[dv]);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool guarded = (cap == hipStreamCaptureStatusNone);
+    if (guarded) {
+        if (!g_loop_ev[dv]) HIP_TRY(hipEventCreateWithFlags(&g_loop_ev[dv], hipEventDisableTiming));
+        if (g_loop_has[dv] && g_loop_stream[dv] != s) HIP_TRY(hipStreamWaitEvent(s, g_loop_ev[dv], 0));
+    }
+    if (G == 16) launch_rs<16>(kind, p, s); else if (G == 8) launch_rs<8>(kind, p, s); else if (G == 4) launch_rs<4>(kind, p, s); else launch_rs<2>(kind, p, s);
+    HIP_TRY(hipGetLastError());
+    DSD_TRY(sticky_alloc(h));
+    hipLaunchKernelGGL(k_latch_tmo, dim3(1), dim3(1), 0, s, (const unsigned*)p.tmo, h->sticky_dev);
+    HIP_TRY(hipGetLastError());
+    if (guarded) {
+        HIP_TRY(hipEventRecord(g_loop_ev[dv], s));
+        g_loop_stream[dv] = s;
+        g_loop_has[dv] = true;
+    }
+    return DSD_OK;
+}
+
 static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k_step, int interval, hipStream_t s) {
     const size_t bmt = (size_t)h->B * h->M * h->T;
     HIP_TRY(hipMemcpyAsync(h->xs, x, bmt * 4, hipMemcpyDeviceToDevice, s));
@@ -1008,7 +1111,9 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
         if (!noise) hipLaunchKernelGGL(k_set_seed, dim3(1), dim3(1), 0, s, h->seed_cell, h->noise_seed);
         HIP_TRY(hipGetLastError());
     }
-    if (loop_applicable(h)) {
+    if (const int G = rs_g(h)) {
+        DSD_TRY(run_rs(h, G, kind, k_step, interval, s));
+    } else if (loop_applicable(h)) {
         DSD_TRY(run_persistent(h, kind, k_step, interval, s));
     } else if (!h->use_graph) {
         DSD_TRY(kind == 0 ? enqueue_ddpm(h, k_step, s) : enqueue_plms(h, k_step, interval, s));
@@ -1134,7 +1239,16 @@ extern "C" int dsd_set_lat_split(dsd_handle* h, int32_t g) {
     return DSD_OK;
 }
 
-extern "C" int dsd_get_lat_split(dsd_handle* h) { return (h && h->prepared) ? lat_g(h) : 0; }
+extern "C" int dsd_get_lat_split(dsd_handle* h) { return (h && h->prepared && !rs_g(h)) ? lat_g(h) : 0; }
+
+extern "C" int dsd_set_rs_split(dsd_handle* h, int32_t g) {
+    if (!h || !(g == -1 || g == 0 || g == 2 || g == 4 || g == 8 || g == 16))
+        return fail(DSD_ERR_INVALID, "dsd_set_rs_split: g must be -1 (by batch size), 0 (never), 2, 4, 8 or 16");
+    h->rs_req = g;
+    return DSD_OK;
+}
+
+extern "C" int dsd_get_rs_split(dsd_handle* h) { return (h && h->prepared) ? rs_g(h) : 0; }
 
 extern "C" int dsd_get_loop_mode(dsd_handle* h) { return (h && h->prepared && loop_applicable(h)) ? 1 : 0; }
 
@@ -1181,23 +1295,26 @@ extern "C" int dsd_debug_loop_timeline(dsd_handle* h, float* x, const float* noi
                                        int32_t max_wg, int32_t* n_wg, void* stream) {
     DSD_TRY(check_ready(h, "dsd_debug_loop_timeline", true));
     if (!x || !noise || !out || !n_wg) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: null argument");
-    if (!loop_applicable(h)) return fail(DSD_ERR_STATE, "dsd_debug_loop_timeline: the prepared batch does not take the persistent path");
+    const int rsg = rs_g(h);
+    if (!rsg && !loop_applicable(h)) return fail(DSD_ERR_STATE, "dsd_debug_loop_timeline: the prepared batch does not take a persistent path");
     if (k_step < 2 || phase / h->L >= k_step - 1) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: pick a phase of an evaluation that is not the last");
-    if (h->ntiles > h->n_cu || h->ntiles > max_wg) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: needs a single-launch batch (%d tiles)", h->ntiles);
+    // one stamp block per workgroup: the persistent loop has one workgroup per tile, the row-split loop lat_grid(ntiles, G) (dsd_loop_rs.hpp)
+    const int nwg = rsg ? lat_grid(h->ntiles, rsg) : h->ntiles;
+    if (h->ntiles > h->n_cu || nwg > max_wg) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: needs a single-launch batch (%d workgroups)", nwg);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     DSD_TRY(build_step_table(h, h->n_sched, s));
-    HIP_TRY(hipMalloc((void**)&h->loop_dbg, (size_t)h->ntiles * 64 * 8));
-    HIP_TRY(hipMemsetAsync(h->loop_dbg, 0, (size_t)h->ntiles * 64 * 8, s));
+    HIP_TRY(hipMalloc((void**)&h->loop_dbg, (size_t)nwg * 64 * 8));
+    HIP_TRY(hipMemsetAsync(h->loop_dbg, 0, (size_t)nwg * 64 * 8, s));
     h->loop_dbg_phase = phase;
     const int rc = run_loop(h, 0, x, noise, k_step, 0, s);
     hipError_t e = hipStreamSynchronize(s);
-    if (e == hipSuccess) e = hipMemcpy(out, h->loop_dbg, (size_t)h->ntiles * 64 * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out, h->loop_dbg, (size_t)nwg * 64 * 8, hipMemcpyDeviceToHost);
     (void)hipFree(h->loop_dbg);
     h->loop_dbg = nullptr;
     if (rc != DSD_OK) return rc;
     if (e != hipSuccess) return fail(DSD_ERR_HIP, "dsd_debug_loop_timeline: %s", hipGetErrorString(e));
-    *n_wg = h->ntiles;
+    *n_wg = nwg;
     return DSD_OK;
 }
 

@@ -108,6 +108,14 @@ class DenoiserEngine:
         """G of the latency kernels the prepared batch runs with, 0 = not on that path."""
         return self.lib.dsd_get_lat_split(self._h)
 
+    def set_rs_split(self, g: int):
+        """Row-split persistent loop (csrc/dsd_loop_rs.hpp): -1 by batch size, 0 never, 2 / 4 / 8 / 16 forced."""
+        _lib.check(self.lib.dsd_set_rs_split(self._h, int(g)), 'dsd_set_rs_split')
+
+    def rs_split(self) -> int:
+        """G of the row-split persistent loop the prepared batch runs with, 0 = another path."""
+        return self.lib.dsd_get_rs_split(self._h)
+
     def set_loop_mode(self, mode: int):
         """2 (default): automatic - latency kernels for small batches, else the persistent loop / per-layer kernels by chip occupancy;
         1: the whole K-step loop as one persistent kernel when the batch allows it; 0: per-layer kernels; 3: latency kernels."""

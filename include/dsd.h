@@ -180,6 +180,16 @@ int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
 int dsd_loop_launches(dsd_handle* h);
 int dsd_set_lat_split(dsd_handle* h, int32_t g);
 int dsd_get_lat_split(dsd_handle* h);
+/* The ROW-SPLIT PERSISTENT loop (csrc/dsd_loop_rs.hpp): the batches the latency kernels serve (32-frame tiles x G <= CU count, G = 16 / 8 / 4 / 2:
+ * the reference's own inference shape, one utterance per device, configs/tts/fs2.yaml:70) as ONE launch for the whole K-step loop
+ * (usr/diff/shallow_diffusion_tts.py:261-270) - the G workgroups of a tile stay resident and exchange gate rows and x' rows through
+ * sentinel-tagged rings in device memory instead of through 43 kernel boundaries per evaluation.  Same arithmetic and summation order as the
+ * kernels it replaces (G = 2 / 4: bit-identical to modes 0 / 1; G = 8 / 16: bit-identical to the latency kernels).  Applies in loop mode 2 with
+ * hipGraph mode on and no forced latency split; failures are loud exactly like the persistent loop's (dsd_check).
+ * dsd_set_rs_split: g = -1 by batch size, 0 never, 2 / 4 / 8 / 16 forced (ignored when the batch does not fit g workgroups per tile);
+ * dsd_get_rs_split: G the prepared batch runs with on this path, 0 = another path.  Environment: DSD_RS=<g> at dsd_create. */
+int dsd_set_rs_split(dsd_handle* h, int32_t g);
+int dsd_get_rs_split(dsd_handle* h);
 
 /* EXPERIMENT (csrc/dsd_split.hpp; default off, env DSD_SPLIT=1 turns it on at creation): the residual layers on
  * the bf16 matrix pipe with fp32-class accuracy - every fp32 operand is the exact sum of three bf16 planes, the six plane products

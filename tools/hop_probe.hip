@@ -49,7 +49,9 @@ struct Params {
 
 template <int G, int PROTO>
 __global__ __launch_bounds__(256, 1) void k_hop(const Params p) {
+    extern __shared__ unsigned hold_lds[];      // 100 KiB requested at launch: one workgroup per CU, like the kernel this probe stands for
     const int tid = threadIdx.x;
+    if (p.phases < 0) hold_lds[tid] = tid;
     const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
     const int tile = (k / G) * 8 + xcd, g = k % G;
     if (tile >= p.ntiles) return;
@@ -179,7 +181,8 @@ static int run(int phases, int work_ticks, int jitter_ticks, int halo) {
         CK(hipMemset(err, 0, 64));
         Params p{buf, flags, err, cyc, ntiles, phases, work_ticks, jitter_ticks, halo};
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_hop<G, PROTO>), dim3(256), dim3(256), 0, 0, p);
+        CK(hipFuncSetAttribute((const void*)k_hop<G, PROTO>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        hipLaunchKernelGGL((k_hop<G, PROTO>), dim3(256), dim3(256), 100 * 1024, 0, p);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms = 0;
