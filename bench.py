@@ -562,6 +562,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cfg5-shard', action='store_true', help='skip the configs[4] shard leg of the N = 1 line (~5 s)')
     ap.add_argument('--tile', type=int, default=0, help='frames per workgroup of the layer kernel (0 auto, 32, 64)')
     ap.add_argument('--row', choices=['path', 'vocoder', 'train', 'fs2'], default='path',
                     help='path: the headline hot path (default); vocoder: SURVEY 8 row f2; train: row f3 (denoiser p_losses forward + backward); '
@@ -737,6 +738,25 @@ def main_path(args):
                          'what': f"rank 0's shard ({len(mine)} of {CFG5_UTTS} utterances x T={T}, micro-batches of {B}) sampled alone after the timed "
                                  f'region, no gather: the per-GPU rate of BASELINE configs[4]; ideal at N={world} = {world} x this'}
         dist.barrier()
+    per_rank = None
+    if cfg == 5:
+        # every rank reports what IT did: its RCCL world, its shard (utterances, frames) and the wall time of that shard sampled once more,
+        # all ranks at the same time, no gather - whoever reads the line sees imbalance or a slow device directly
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        local_only()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        mine_rep = {'rank': rank, 'rccl_world': dist.get_world_size() if world > 1 else 1, 'backend': dist.get_backend() if world > 1 else None,
+                    'device': torch.cuda.get_device_name(device), 'utterances': len(mine), 'frames': len(mine) * T, 'shard_s': dt,
+                    'mel_frames_per_s': len(mine) * T / dt}
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine_rep)
+        else:
+            per_rank = [mine_rep]
 
     # roofline of the dominant kernel, measured live with HIP events on the launch stream (torch's current stream IS the
     # stream every dsd_* call is enqueued on).  Persistent path: the kernel is k_loop, ONE launch = the whole 100-step loop
@@ -827,6 +847,7 @@ def main_path(args):
             conf = {'workload': workload, 'preset': PRESET, 'utterances_total': CFG5_UTTS, 'utterances_per_gpu': len(mine), 'frames': T, 'micro_batch': B}
         conf.update({'k_step': K, 'sampler': 'ddpm', 'layer_tile_frames': eng.layer_tile(),
                      'loop': 'persistent kernel (k_loop)' if eng.loop_mode() == 1 else 'hipGraph of per-layer kernels',
+                     'loop_parked': eng.parked(),
                      'timed_step': 'dsd_prepare (cond re-layout + hoisted conditioner projection, fresh cond every step) + K-step loop + denorm'
                                    + (' + gather' if world > 1 else ''),
                      'sharding': f'utterances r::W, RCCL gather of mels to rank 0 (backend {dist.get_backend()}, world {dist.get_world_size()})'
@@ -839,8 +860,12 @@ def main_path(args):
             'data': 'synthetic', 'config': conf, 'roofline': roof,
             'model_tflops_ref_accounting': frames_per_step * K * F_EVAL_REF * args.steps / el / 1e12,
         }
+        res['workload_id'] = 'configs[1]: 8 x T=1024 per GPU (weak)' if cfg == 2 else f'configs[4]: {CFG5_UTTS} x T={CFG5_T} total (strong)'
+        res['T'] = T
         if scale_ref is not None:
             res['scale_ref_n1'] = scale_ref
+        if per_rank is not None:
+            res['per_rank'] = per_rank
         try:
             fixture = parity_check(device)
         except Exception as e:          # fixtures missing etc. - report, do not hide
@@ -852,6 +877,26 @@ def main_path(args):
             res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
         else:
             res['parity'] = fixture
+        if world == 1 and cfg == 2 and not args.no_cfg5_shard:
+            # the N > 1 lines run BASELINE configs[4] (512 x T=2048, strong): one GPU's shard of the 8-GPU run - 64 utterances x T=2048 in
+            # micro-batches of 16, no gather - sampled here after everything else, so that a 1/2/4/8 curve can be normalised on ONE workload
+            # from the N = 1 line alone (value x 8 = the ideal of the N = 8 line)
+            try:
+                del conds, x_T, noise
+                torch.cuda.empty_cache()
+                _, local5, mine5, _, _, _ = cfg5_workload(gd, 0, 8, device)
+                local5()                                                   # warm: workspace growth to 16 x 2048, plan upload
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                local5()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                res['cfg5_shard_n1'] = {'value': len(mine5) * CFG5_T / dt, 'unit': 'mel-frames/s', 'n_gpus': 1, 'seconds': dt,
+                                        'what': f"rank 0's shard of BASELINE configs[4] at 8 GPUs ({len(mine5)} of {CFG5_UTTS} utterances x T={CFG5_T}, "
+                                                f'micro-batches of {CFG5_MICRO}, K={K_STEPS}), no gather: the per-GPU rate of the workload the N > 1 '
+                                                f'lines run; N x this is their ideal'}
+            except Exception as e:
+                res['cfg5_shard_n1'] = {'error': repr(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

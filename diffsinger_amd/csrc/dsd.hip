@@ -717,7 +717,7 @@ template <int MODE>
 static int launch_head(dsd_handle* h, const HeadParams& p, bool fuse, hipStream_t s) {
     if (MODE != HEAD_EPS && lat_g(h) >= 8) {
         // G = 8 latency path: the head row-split like the layers (dsd_lat.hpp): skip projection on 8 workgroups per tile -> final projection +
-        // sampler update on 3 -> next input projection on 8.  hbuf = the gate buffer (free behind the last layer), pbuf = the x buffer
+        // sampler update on 3 of the 4 workgroups per tile of its grid (lat_grid(ntiles, 4); the fourth returns) -> next input projection on 8.  hbuf = the gate buffer (free behind the last layer), pbuf = the x buffer
         // the last layer read (the other one receives the next x)
         LatHeadParams q{};
         q.hp = p; q.hbuf = h->gbuf; q.pbuf = h->xb; q.ntiles = h->ntiles;

@@ -1,4 +1,4 @@
-"""Multi-GPU inference: utterances shard across ranks, one RCCL gather collates the finished mels.
+"""Multi-GPU inference: utterances shard across ranks, one RCCL gather collates the finished mels (equal or different lengths).
 
 The path shards naturally: every op of the denoiser and sampler is per-utterance, so rank
 r takes utterances r, r+W, r+2W, ... (what the reference's DDP inference does with batches, tasks/tts/tts.py:
@@ -58,12 +58,104 @@ def gather_mels(local: torch.Tensor, n_items: int, dst: int = 0, group=None, ord
     return None
 
 
-def sharded_inference(model, conds: Sequence[torch.Tensor], *, micro_batch: int = 16, group=None, dst: int = 0, **infer_kw):
-    """Run `model.inference` over a list of equal-length utterance conditioners [H,T] (already on this rank's
-    device), sharded r::W, in micro-batches, and gather the mels on `dst` in original order.
-    Per-batch keyword tensors (x_T, noise, fs2_mels, ...) are passed as callables `idx_list -> batched tensor`."""
+def plan_ragged(lengths: Sequence[int], world: int, *, micro_batch: int = 16, max_frames: Optional[int] = None):
+    """Length-aware work split for utterances of DIFFERENT lengths (frames).  Returns (batches, owner):
+
+      batches  micro-batches of utterance indices, formed from the lengths ALONE (never from the world size): utterances sorted by length,
+               consecutive ones that share a 32-frame bucket (ceil32(T): the denoiser's tile, so padding inside a micro-batch costs no extra
+               tile) are grouped up to `micro_batch` utterances and `max_frames` padded frames (B x ceil32(T_max), the reference's
+               max_tokens: utils/__init__.py:89-142 batch_by_size over length-sorted indices, tasks/tts/tts.py:64-69).  A micro-batch runs
+               at T = its longest utterance; the shorter ones are zero-padded inside it only.
+      owner    owner[k] = rank of micro-batch k: longest-processing-time greedy on padded frames (heaviest micro-batch first, always to the
+               least loaded rank; ties to the lower rank) - not r::W, which is blind to length (the reference's DDP split
+               batches[rank::world], tasks/tts/tts.py:85-88, shards token-budgeted batches and is balanced for the same reason).
+
+    Because the micro-batches do not depend on `world`, utterance i is computed inside the same micro-batch at every world size: the collated
+    result is bit-identical to the single-process run."""
+    n = len(lengths)
+    order = sorted(range(n), key=lambda i: (int(lengths[i]), i))
+    ceil32 = lambda t: (int(t) + 31) // 32 * 32
+    batches: List[List[int]] = []
+    cur: List[int] = []
+    for i in order:
+        ts = ceil32(lengths[i])
+        if cur and (ceil32(lengths[cur[0]]) != ts or len(cur) >= micro_batch or (max_frames is not None and (len(cur) + 1) * ts > max_frames)):
+            batches.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        batches.append(cur)
+    cost = [len(bt) * ceil32(max(lengths[i] for i in bt)) for bt in batches]
+    load = [0] * world
+    owner = [0] * len(batches)
+    for k in sorted(range(len(batches)), key=lambda k: (-cost[k], k)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[k] = r
+        load[r] += cost[k]
+    return batches, owner
+
+
+def pad_stack(tensors: Sequence[torch.Tensor], T: int) -> torch.Tensor:
+    """Stack tensors whose LAST axis is the frame axis (lengths <= T) into one batch, zero-padded to T."""
+    out = tensors[0].new_zeros((len(tensors),) + tuple(tensors[0].shape[:-1]) + (T,))
+    for b, t in enumerate(tensors):
+        out[b, ..., :t.shape[-1]] = t
+    return out
+
+
+def _run_checked(model, run_shard, rank):
+    """run_shard() with the loud-failure contract of the persistent loops (include/dsd.h dsd_check): a loop starved by a foreign kernel
+    raises 'spin bound'; every rank must still arrive at the collective, so the shard is repeated - the engine is parked on the hipGraph
+    path (no co-residency requirement) since the report.  Loops of LATER micro-batches may have been enqueued against the same foreign kernel
+    and latch their timeout after the report: drain the stream and swallow those late reports before every retry."""
+    try:
+        return run_shard()
+    except RuntimeError as e:
+        if 'spin bound' not in str(e):
+            raise
+        first = e
+    import warnings
+    warnings.warn(f'rank {rank}: {first}  -- repeating the shard on the hipGraph path')
+    for attempt in range(3):
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+        if hasattr(model, 'check_loops'):
+            try:
+                model.check_loops()
+            except RuntimeError as late:
+                if 'spin bound' not in str(late):
+                    raise
+        try:
+            return run_shard()
+        except RuntimeError as e:
+            if 'spin bound' not in str(e) or attempt == 2:
+                raise
+    raise first
+
+
+def sharded_inference(model, conds: Sequence[torch.Tensor], *, micro_batch: int = 16, group=None, dst: int = 0, lengths: Optional[Sequence[int]] = None,
+                      max_frames: Optional[int] = None, **infer_kw):
+    """Run `model.inference` over a list of utterance conditioners [H,T_i] (already on this rank's device; a rank only needs ITS utterances'
+    conditioners, the others may be None when `lengths` is given), sharded over the ranks, in micro-batches, and collate the mels on `dst`.
+
+    Equal lengths (the bench's BASELINE configs[4]): utterances r::W (what the reference's DDP inference does with batches,
+    tasks/tts/tts.py:85-88), one gather; returns [n, T, M] on `dst` in original order, None elsewhere.
+    Different lengths (real test sets: LJSpeech 200-1550 frames): `plan_ragged` - length-sorted, 32-frame-bucketed, frame-budgeted
+    micro-batches dealt to the ranks by a longest-processing-time greedy on frames; ONE padded gather of every rank's flat [frames, M]
+    buffer, no lengths exchange (every rank computes the same plan); returns on `dst` the list of n mels [T_i, M] in original order (views
+    of the receive buffer), None elsewhere.
+    Per-batch keyword tensors (x_T, noise, fs2_mels, ...) are passed as callables `idx_list -> batched tensor` (ragged: padded to the
+    longest utterance of idx_list along the frame axis, see pad_stack)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if lengths is None:             # (a rank may hold None for utterances it does not own: those then have the common length)
+        some_ = next(c for c in conds if c is not None)
+        lengths = [(c.shape[-1] if c is not None else some_.shape[-1]) for c in conds]
+    lengths = [int(v) for v in lengths]
+    if len(lengths) != len(conds):
+        raise ValueError('lengths must have one entry per utterance')
+    if len(set(lengths)) > 1:
+        return _sharded_inference_ragged(model, conds, lengths, world, rank, micro_batch, max_frames, group, dst, infer_kw)
     mine = shard_indices(len(conds), rank, world)
 
     def run_shard():
@@ -77,22 +169,59 @@ def sharded_inference(model, conds: Sequence[torch.Tensor], *, micro_batch: int 
             model.check_loops()             # ONE wait per shard: a persistent loop starved by a foreign kernel must not reach the gather as NaN
         return outs
 
-    try:
-        outs = run_shard()
-    except RuntimeError as e:
-        if 'spin bound' not in str(e):
-            raise
-        # every rank must still arrive at the collective: repeat this rank's shard - the engine is parked on the hipGraph path (per-layer
-        # kernels, no co-residency requirement) since the report - and only raise if that fails as well
-        import warnings
-        warnings.warn(f'rank {rank}: {e}  -- repeating the shard on the hipGraph path')
-        outs = run_shard()
+    outs = _run_checked(model, run_shard, rank)
     some = next(c for c in conds if c is not None)          # a rank only needs ITS utterances' conditioners; the others may be None
     T = some.shape[-1]
     local = torch.cat(outs) if outs else torch.zeros(0, T, model.mel_bins, device=some.device)
     if world == 1:
         return local
     return gather_mels(local, len(conds), dst=dst, group=group)
+
+
+def _sharded_inference_ragged(model, conds, lengths, world, rank, micro_batch, max_frames, group, dst, infer_kw):
+    batches, owner = plan_ragged(lengths, world, micro_batch=micro_batch, max_frames=max_frames)
+    my_batches = [bt for bt, r in zip(batches, owner) if r == rank]
+    some = next(c for c in conds if c is not None)
+    M = model.mel_bins
+
+    def run_shard():
+        outs = []
+        for idx in my_batches:
+            T_run = max(lengths[i] for i in idx)
+            cond = pad_stack([conds[i] for i in idx], T_run)
+            kw = {k: (v(idx) if callable(v) else v) for k, v in infer_kw.items()}
+            mel = model.inference(cond, **kw)                                   # [B, T_run, M]
+            outs.extend(mel[b, :lengths[i]] for b, i in enumerate(idx))
+        if hasattr(model, 'check_loops'):
+            model.check_loops()
+        return outs
+
+    outs = _run_checked(model, run_shard, rank)
+    # every rank knows every rank's utterances and lengths (the plan is a function of `lengths` and `world`): one gather of flat
+    # [frames, M] buffers padded to the heaviest rank, no lengths collective
+    seq = [[i for bt, r in zip(batches, owner) if r == rr for i in bt] for rr in range(world)]
+    frames = [sum(lengths[i] for i in s_) for s_ in seq]
+    if world == 1:
+        out = [None] * len(conds)
+        for i, m in zip(seq[0], outs):
+            out[i] = m
+        return out
+    F = max(frames)
+    flat = torch.zeros(F, M, dtype=torch.float32, device=some.device)
+    if outs:
+        flat[:frames[rank]] = torch.cat(outs)
+    if rank == dst:
+        recv = torch.empty(world, F, M, dtype=flat.dtype, device=flat.device)
+        dist.gather(flat, gather_list=list(recv.unbind(0)), dst=dst, group=group)
+        out = [None] * len(conds)
+        for rr in range(world):
+            pos = 0
+            for i in seq[rr]:
+                out[i] = recv[rr, pos:pos + lengths[i]]
+                pos += lengths[i]
+        return out
+    dist.gather(flat, gather_list=None, dst=dst, group=group)
+    return None
 
 
 def _collective_device(group=None) -> torch.device:

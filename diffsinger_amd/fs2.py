@@ -17,9 +17,10 @@ movement on [B,T,C] tensors and uses torch indexing ops on the device.  forward(
 backward runs on HIP kernels as well (joint training of the e2e configurations); no CPU path: the ops raise when the tensors are
 not on the MI355X.
 
-Not covered (raise NotImplementedError): speaker embeddings (use_spk_id / use_spk_embed), energy embedding, pitch_ar,
-pitch_type 'ph', dur_loss other than 'mse', ffn_padding 'LEFT', norm 'bn' - none is used by a shipped DiffSpeech / DiffSinger
-config."""
+Covered besides the shipped configurations: speaker d-vectors / speaker ids (use_spk_embed / use_spk_id), the energy embedding and
+phone-level pitch (pitch_type 'ph').  Not covered (raise NotImplementedError): pitch_ar (raises in the reference itself: fs2.py:215 passes
+two arguments to PitchPredictor.forward), dur_loss other than 'mse', ffn_padding 'LEFT', norm 'bn' - none is used by a shipped
+DiffSpeech / DiffSinger config."""
 from __future__ import annotations
 
 import math

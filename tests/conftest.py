@@ -16,10 +16,9 @@ def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no device is visible, e.g. a plain `pytest tests/` here.
     Convention for kernels written while no GPU is at hand: their tests go to tests/test_gpu_zz_*.py, which stay out of the default
     `-m gpu` run (a fault in a never-run kernel would take the whole verified suite's process down with it) until DSD_RUN_UNVERIFIED=1
-    is set; a module that has passed on the hardware is renamed into the default suite, one that fails is deleted with its kernels
-    (round 2: split-layer, fused-AdamW and frame-major-loop modules promoted, the split-conv prototype deleted).  At present: test_gpu_zz_lat_bf.py (its kernel has run - probe - the module has not) and test_gpu_zz_conv_inc.py (kernels not yet run); tools/gpu_next_promote.sh is their first call."""
+    is set; a module that has passed on the hardware is renamed into the default suite, one that fails is deleted with its kernels."""
     if not os.environ.get('DSD_RUN_UNVERIFIED'):
-        hold = pytest.mark.skip(reason='kernel not yet run on hardware: set DSD_RUN_UNVERIFIED=1 (tools/gpu_round2_first.sh does)')
+        hold = pytest.mark.skip(reason='kernel not yet run on hardware: set DSD_RUN_UNVERIFIED=1')
         for item in items:
             if os.path.basename(str(item.fspath)).startswith('test_gpu_zz_'):
                 item.add_marker(hold)

@@ -1,0 +1,117 @@
+"""CPU, world_size 2 and 3 over gloo: utterances of DIFFERENT lengths through diffsinger_amd/dist.py ("variable-length
+utterances: padded buffer + lengths").  LJSpeech-like lengths (200-1550 frames, configs/tts/base.yaml:35-39 max_frames
+1550): length-sorted, 32-frame-bucketed, frame-budgeted micro-batches (the reference's batch_by_size, utils/__init__.py:89-142) dealt to the
+ranks by a longest-processing-time greedy on frames, ONE padded gather.  Checked: original order, exact equality with the single-process run
+(the stand-in sampler's output depends on the micro-batch an utterance is computed in - its size and padded length - so equality proves that
+the micro-batches do not depend on the world size), rank balance max / mean <= 1.05."""
+import os
+import random
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffsinger_amd.dist import pad_stack, plan_ragged, sharded_inference
+
+N, H, M, MICRO, BUDGET = 96, 4, 5, 8, 8192
+
+
+class _Sampler:
+    """mel[b, t, m] = cond[b, :, t].mean() + 0.001 m + x_T[b, 0, m, t] + 1e-3 * T_run + 1e-2 * B: a function of the utterance AND of the
+    micro-batch it is computed in (like the real sampler, whose padded tail sees the micro-batch's length)."""
+    mel_bins = M
+
+    def __init__(self):
+        self.frames = 0
+
+    def inference(self, cond, x_T=None):
+        B, _, T = cond.shape
+        assert x_T.shape == (B, 1, M, T)
+        self.frames += B * ((T + 31) // 32 * 32)
+        return cond.mean(1)[:, :, None] + 0.001 * torch.arange(M)[None, None, :] + x_T[:, 0].transpose(1, 2) + 1e-3 * T + 1e-2 * B
+
+
+def _inputs():
+    rnd = random.Random(7)
+    lengths = [rnd.randint(200, 1550) for _ in range(N)]
+    g = torch.Generator().manual_seed(3)
+    conds = [torch.randn(H, t, generator=g) for t in lengths]
+    xs = [torch.randn(1, M, t, generator=g) for t in lengths]
+    return lengths, conds, xs
+
+
+def _run(world_rank=None):
+    lengths, conds, xs = _inputs()
+    m = _Sampler()
+    out = sharded_inference(m, conds, micro_batch=MICRO, max_frames=BUDGET, dst=0,
+                            x_T=lambda idx: pad_stack([xs[i] for i in idx], max(lengths[i] for i in idx)))
+    return out, m.frames, lengths
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        out, frames, lengths = _run()
+        fr = torch.tensor([float(frames)])
+        allf = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(allf, fr)
+        if rank == 0:
+            q.put((torch.cat(out).numpy().copy(), [float(v) for v in allf]))      # (by value: the worker exits before the parent reads)
+        else:
+            assert out is None
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_ragged_lengths_equal_the_single_process_run_and_are_balanced(world):
+    want, frames1, lengths = _run()
+    assert [w.shape for w in want] == [(t, M) for t in lengths]
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    flat, per_rank = q.get()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    got = list(torch.from_numpy(flat).split(lengths))
+    assert len(got) == N
+    for i in range(N):
+        assert got[i].shape == (lengths[i], M)
+        assert torch.equal(got[i], want[i]), i                          # original order, bit-identical to world 1
+    assert sum(per_rank) == frames1                                      # the same micro-batches, only dealt out
+    balance = max(per_rank) / (sum(per_rank) / world)
+    print(f'world {world}: padded frames per rank {per_rank}, max / mean {balance:.4f}; padding overhead {frames1 / sum(lengths):.4f}')
+    assert balance <= 1.05
+
+
+def test_plan_is_a_partition_bucketed_and_world_independent():
+    rnd = random.Random(1)
+    lengths = [rnd.randint(200, 1550) for _ in range(512)]
+    b1, _ = plan_ragged(lengths, 1, micro_batch=16, max_frames=8192)
+    for world in (2, 4, 8):
+        b, owner = plan_ragged(lengths, world, micro_batch=16, max_frames=8192)
+        assert b == b1                                                   # micro-batches never depend on the world size
+        assert sorted(i for bt in b for i in bt) == list(range(512))
+        load = [0] * world
+        for bt, r in zip(b, owner):
+            ts = {(lengths[i] + 31) // 32 for i in bt}
+            assert len(ts) == 1 and len(bt) <= 16 and len(bt) * 32 * ts.pop() <= 8192       # one 32-frame bucket, within both budgets
+            load[r] += len(bt) * ((max(lengths[i] for i in bt) + 31) // 32 * 32)
+        assert max(load) / (sum(load) / world) <= 1.05, (world, load)
+    # equal lengths stay on the reference's r::W split (bench configs[4]); a single utterance is one batch on rank 0
+    assert plan_ragged([100], 4)[1] == [0]
