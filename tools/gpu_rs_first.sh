@@ -9,7 +9,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 [ -x tools/hop_probe.bin ] && timeout 120 tools/hop_probe.bin 2000 > $O/hop_probe.jsonl 2> $O/hop_probe.err
-( time DSD_RUN_UNVERIFIED=1 timeout 900 python -m pytest tests/test_gpu_zz_rs.py -m gpu -x -q -rf -s > $O/pytest_rs.txt 2>&1 ) 2> $O/pytest_rs_time.txt
+( time DSD_RUN_UNVERIFIED=1 timeout 900 python -m pytest tests/test_gpu_rs.py -m gpu -x -q -rf -s > $O/pytest_rs.txt 2>&1 ) 2> $O/pytest_rs_time.txt
 tail -5 $O/pytest_rs.txt
 timeout 300 python tools/rs_timeline.py 1x512 $O/rs_timeline_1x512.json > $O/rs_timeline_1x512.txt 2>&1
 timeout 300 python tools/rs_timeline.py 1x1550 $O/rs_timeline_1x1550.json > $O/rs_timeline_1x1550.txt 2>&1
