@@ -131,7 +131,70 @@ def cpu_baseline(gd, pre, cond, x_T, noise, mel_hip, kernel):
     par = {'case': f'the timed batch itself: {B} x {T} frames, K={K_STEPS} DDPM from the Gaussian start, de-normalised mel [B,T,80] of the last timed '
                    'step vs oracle.infer_mel on the same (x_T, cond, noise[K]) and weights', 'kernel': kernel,
            'max_abs_mel_err': err, 'tolerance': 1e-4, 'elements': int(mel.numel())}
-    return base, par
+    return base, par, mel
+
+
+def secondary_split(gd, eng, pre, cond, x_T, noise, mel_f32, mel_oracle, args):
+    """The labelled EXPERIMENT line (`secondary`, never the headline): the SAME timed step with the residual layers' contractions on the bf16
+    matrix pipe at fp32-class accuracy (csrc/dsd_loop_split.hpp: every fp32 operand = 3 exact bf16 planes, 6 plane products per product, fp32
+    accumulate) - what the north star's 1e-4 budget buys beyond the fp32 MFMA ceiling.  Reports its rate, its roofline against the dense bf16
+    peak / 6, and - for BOTH paths, on utterance 0 of the timed batch - the error against the fp32 oracle and against an fp64 evaluation of
+    the oracle (the same function in double: the parameters, inputs and noise cast up, the fp32 schedule tables as constants)."""
+    from oracle import diffnet_oracle as O
+    eng.set_split_mode(True)
+    try:
+        run = lambda: gd.inference(cond, x_T=x_T, noise=noise, K_step=K_STEPS, pndm_speedup=0)
+        mel_sp = run()
+        torch.cuda.synchronize()
+        assert eng.loop_mode() == 1 and eng.loop_timeouts() == 0, 'the split-precision run did not take the persistent loop'
+        conds2 = [cond, cond.clone()]                     # fresh cond tensor every step: dsd_prepare stays inside the timed step
+        n = 5
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            gd.inference(conds2[i & 1], x_T=x_T, noise=noise, K_step=K_STEPS, pndm_speedup=0)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / n
+        B, T = x_T.shape[0], x_T.shape[-1]
+        xs = x_T[:, 0].contiguous().clone()
+        nz = noise[:, :, 0]
+        eng.prepare(cond)
+        eng.sample_ddpm(xs, nz, K_STEPS)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(3):
+            eng.sample_ddpm(xs, nz, K_STEPS)
+        ev1.record()
+        ev1.synchronize()
+        ms_call = ev0.elapsed_time(ev1) / 3
+        achieved = B * T * K_STEPS * F_EVAL_EXEC / (ms_call * 1e-3) / 1e12
+    finally:
+        eng.set_split_mode(False)
+    # fp64 evaluation of the oracle on utterance 0 (~35 s on 16 host threads)
+    cfg = O.NetConfig(80, 256, 256, 20, 1)
+    p64 = {k: v.detach().to('cpu', torch.float64) for k, v in gd.denoise_fn.state_dict().items()}
+    sch = O.make_schedule(O.linear_beta_schedule(pre['timesteps'], pre['max_beta']))
+    smin = torch.tensor(pre['spec_min'], dtype=torch.float64)[None, None, :]
+    smax = torch.tensor(pre['spec_max'], dtype=torch.float64)[None, None, :]
+    c0 = cond[0:1].detach().cpu().double()
+    t0 = time.perf_counter()
+    m64 = O.infer_mel(p64, cfg, sch, c0, smin, smax, k_step=K_STEPS, noises=list(noise[:, 0:1].detach().cpu().double()), x_T=x_T[0:1].detach().cpu().double())
+    t64 = time.perf_counter() - t0
+    err = lambda a, b: float((a.detach().cpu().double() - b.double()).abs().max())
+    peak = 2500.0 / 6
+    return {
+        'label': 'EXPERIMENT, not the headline: residual layers on the bf16 matrix pipe at fp32-class accuracy (dsd_set_split_mode; csrc/dsd_loop_split.hpp)',
+        'dtype': 'f32 as 3 exact bf16 planes, 6 plane products per product (i + j <= 2), f32 accumulate; head, sampler and state in f32',
+        'metric': BASELINE_METRIC, 'value': B * T / sec, 'unit': 'mel-frames/s', 'ms_per_step': sec * 1e3, 'steps': n,
+        'workload': f'the timed step of this line (dsd_prepare + K={K_STEPS} loop + denorm, {B} x {T} frames)',
+        'roofline': {'bound': 'mfma', 'kernel': 'k_loop_split<1>', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent)', 'frac': achieved / peak,
+                     'avg_launch_ms': ms_call, 'note': 'executed fp32-equivalent FLOPs (21 053 440 / frame / evaluation) over the whole sampling call (HIP events); '
+                                                       'peak = dense bf16 MFMA peak 2500 TFLOP/s / 6 plane products; the head (2 % of the fp32 launch) runs on the fp32 pipe'},
+        'parity': {'case': 'the timed batch (all 8 utterances) vs the fp32 oracle; utterance 0 vs an fp64 evaluation of the oracle, both paths', 'tolerance': 1e-4,
+                   'split_vs_oracle_f32': err(mel_sp, mel_oracle), 'f32_vs_oracle_f32': err(mel_f32, mel_oracle),
+                   'split_vs_oracle_f64_utt0': err(mel_sp[0:1], m64), 'f32_vs_oracle_f64_utt0': err(mel_f32[0:1], m64),
+                   'oracle_f32_vs_oracle_f64_utt0': err(mel_oracle[0:1], m64), 'f64_oracle_seconds': t64},
+    }
 
 
 def pmc_traffic(kernel: str, frames: int):
@@ -562,6 +625,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the labelled split-precision line (`secondary`) of the N = 1 run (~45 s, mostly its fp64 oracle)')
     ap.add_argument('--no-cfg5-shard', action='store_true', help='skip the configs[4] shard leg of the N = 1 line (~5 s)')
     ap.add_argument('--tile', type=int, default=0, help='frames per workgroup of the layer kernel (0 auto, 32, 64)')
     ap.add_argument('--row', choices=['path', 'vocoder', 'train', 'fs2'], default='path',
@@ -786,7 +850,7 @@ def main_path(args):
             flop = frames * K * F_EVAL_EXEC / launches
             achieved = frames * K * F_EVAL_EXEC / (ms_call * 1e-3) / 1e12
             frames_l = frames / launches
-            kname = 'k_loop<1>'
+            kname = 'k_loop_split<1>' if args.split else 'k_loop<1>'
             alg_bytes = int(K * (frames * (20 * 2048 + 2 * 320 + 320) + launches * L_LAYERS * 2 * 1024 * 1024 + frames // 32 * L_LAYERS * 2 * 16384) / launches)
             note = (f'one launch = the whole K=100 reverse loop (100 x (20 residual layers + head + sampler update + next input '
                     f'projection)) for a chunk of whole utterances; this batch of {B} x {T} = {launches} launch(es) of on average {frames_l:.0f} frames; '
@@ -872,9 +936,15 @@ def main_path(args):
             fixture = {'error': repr(e)}
         if world == 1 and cfg == 2 and not args.no_cpu_baseline:
             # ONE oracle run over the timed batch: the CPU rate of the workload and the parity of the kernel whose roofline is reported
-            res['cpu_baseline'], res['parity'] = cpu_baseline(gd, pre, conds[count[0] & 1], x_T, noise, out, roof['kernel'])
+            last = count[0] & 1
+            res['cpu_baseline'], res['parity'], mel_oracle = cpu_baseline(gd, pre, conds[last], x_T, noise, out, roof['kernel'])
             res['parity']['fixture'] = fixture
             res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
+            if not args.no_secondary and not args.split:
+                try:
+                    res['secondary'] = secondary_split(gd, eng, pre, conds[last], x_T, noise, out, mel_oracle, args)
+                except Exception as e:
+                    res['secondary'] = {'error': repr(e)}
         else:
             res['parity'] = fixture
         if world == 1 and cfg == 2 and not args.no_cfg5_shard:

@@ -5,6 +5,7 @@
 #include "dsd_lat.hpp"
 #include "dsd_loop_rs.hpp"
 #include "dsd_split.hpp"
+#include "dsd_loop_split.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -136,6 +137,7 @@ struct dsd_handle {
     // EXPERIMENT (dsd_split.hpp): residual layers on the bf16 matrix pipe with fp32-class accuracy; per-layer kernel path only
     bool split_mode = false;
     uint4 *w1s = nullptr, *w2s = nullptr;     // bf16 weight planes in 32x32x16 fragment order, [L][4][48|16][4][3][64]
+    uint4* w1c = nullptr;                     // the conv planes once more, centre-tap chunks first (the persistent split loop, dsd_loop_split.hpp)
 };
 
 // After a reported timeout the handle runs this many sampling loops on the hipGraph path before it tries the persistent loop again: a
@@ -282,7 +284,7 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     free_workspace(h);
-    dev_free(h->w1s); dev_free(h->w2s);
+    dev_free(h->w1s); dev_free(h->w2s); dev_free(h->w1c);
     dev_free(h->w1q); dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->bskp); dev_free(h->b2raw); dev_free(h->bsum);
     dev_free(h->winp); dev_free(h->binp); dev_free(h->wsp); dev_free(h->bsp); dev_free(h->woutp); dev_free(h->boutp);
     dev_free(h->mlp0_w); dev_free(h->mlp0_b); dev_free(h->mlp2_w); dev_free(h->mlp2_b); dev_free(h->dp_w); dev_free(h->dp_b);
@@ -939,7 +941,7 @@ static int rs_g(const dsd_handle* h);
 
 // true when the prepared batch can run as the persistent loop: 32-frame tiles, a whole utterance fits the co-resident grid
 static bool loop_applicable(const dsd_handle* h) {
-    if (!((h->loop_mode == 1 || h->loop_mode == 2) && !h->persist_off && !h->split_mode && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 &&
+    if (!((h->loop_mode == 1 || h->loop_mode == 2) && !h->persist_off && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 &&
           h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers)) return false;
     if (h->loop_mode == 2) {
         if (rs_g(h) || lat_g(h)) return false;
@@ -991,7 +993,12 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
     for (int b0 = 0; b0 < h->B; b0 += utt_per_chunk) {
         const int nb = std::min(utt_per_chunk, h->B - b0);
         p.tile_base = b0 * h->ntile32; p.n_tiles = nb * h->ntile32;
-        if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
+        if (h->split_mode) {
+            // EXPERIMENT (dsd_loop_split.hpp): the same loop with the layers' contractions as six bf16 plane products per fp32 product
+            const LoopSplitParams q{p, h->w1c, h->w2s};
+            if (kind == 0) hipLaunchKernelGGL((k_loop_split<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopSplitLdsBytes, s, q);
+            else hipLaunchKernelGGL((k_loop_split<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopSplitLdsBytes, s, q);
+        } else if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         else hipLaunchKernelGGL((k_loop<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         HIP_TRY(hipGetLastError());
     }
@@ -1160,6 +1167,8 @@ static void split_kernel_attrs() {
     if (first_on_device(1)) {
         (void)hipFuncSetAttribute((const void*)k_layer_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLayerLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_layer_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLayerLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_split<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopSplitLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_split<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopSplitLdsBytes);
     }
 }
 
@@ -1169,14 +1178,18 @@ static int pack_split_planes(dsd_handle* h, hipStream_t s) {
     if (!h->w1s) {
         DSD_TRY(dev_alloc(h, &h->w1s, (size_t)L * 4 * 48 * 12 * 64 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->w2s, (size_t)L * 4 * 16 * 12 * 64 + kWeightSlack));
+        DSD_TRY(dev_alloc(h, &h->w1c, (size_t)L * 4 * 48 * 12 * 64 + kWeightSlack));
+        HIP_TRY(hipMemsetAsync(h->w1c + (size_t)L * 4 * 48 * 12 * 64, 0, (size_t)kWeightSlack * 16, s));
         HIP_TRY(hipMemsetAsync(h->w1s + (size_t)L * 4 * 48 * 12 * 64, 0, (size_t)kWeightSlack * 16, s));
         HIP_TRY(hipMemsetAsync(h->w2s + (size_t)L * 4 * 16 * 12 * 64, 0, (size_t)kWeightSlack * 16, s));
     }
     for (int l = 0; l < L; ++l) {
         hipLaunchKernelGGL(k_pack_split, dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256),
-                           reinterpret_cast<su16*>(h->w1s + (size_t)l * 4 * 48 * 12 * 64), 4, 16, 3);
+                           reinterpret_cast<su16*>(h->w1s + (size_t)l * 4 * 48 * 12 * 64), 4, 16, 3, 0);
+        hipLaunchKernelGGL(k_pack_split, dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256),
+                           reinterpret_cast<su16*>(h->w1c + (size_t)l * 4 * 48 * 12 * 64), 4, 16, 3, 1);
         hipLaunchKernelGGL(k_pack_split, dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256),
-                           reinterpret_cast<su16*>(h->w2s + (size_t)l * 4 * 16 * 12 * 64), 4, 16, 1);
+                           reinterpret_cast<su16*>(h->w2s + (size_t)l * 4 * 16 * 12 * 64), 4, 16, 1, 0);
     }
     HIP_TRY(hipGetLastError());
     return DSD_OK;

@@ -40,7 +40,9 @@ __device__ __forceinline__ void sp_split3(float x, su16& a, su16& b, su16& c) {
 // fp32 fragment-order weights (k_pack_a, 32x32x2: [w][chunk8][mb 4][lane][4], chunk8 = conv_chunk(k8, tap) for the dilated conv, = k8 for
 // the projections; lane (i, h), s -> channel 8 k8 + 4 h + s)
 // -> bf16 planes in 32x32x16 fragment order [w][chunk16 = ntap * g + tap][mb 4][plane 3][lane (i, h')][e 8], channel 16 g + 8 h' + e.
-__global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ dst, int nw, int ng, int ntap) {
+// centre_first (ntap == 3, the persistent split loop dsd_loop_split.hpp): destination chunk order = the ng centre-tap chunks, then the (-dil, +dil)
+// pairs of every group - like conv_chunk() for the fp32 stream - instead of "taps of one group consecutive".
+__global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ dst, int nw, int ng, int ntap, int centre_first) {
     const size_t n = (size_t)nw * ng * ntap * 4 * 64 * 8;              // (w, chunk16, mb, lane, e)
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = idx & 7, lane = (idx >> 3) & 63;
@@ -48,7 +50,11 @@ __global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ d
         const int mb = r & 3; r >>= 2;
         const int c16 = r % (ng * ntap); r /= (ng * ntap);
         const int w = (int)r;
-        const int g = c16 / ntap, tap = c16 - g * ntap;
+        int g = c16 / ntap, tap = c16 - g * ntap;
+        if (centre_first && ntap == 3) {
+            if (c16 < ng) { g = c16; tap = 1; }
+            else { const int ix = c16 - ng; g = ix >> 1; tap = (ix & 1) * 2; }
+        }
         const int i = lane & 31, hp = lane >> 5;
         const int k8 = 2 * g + hp, c8 = (ntap == 3) ? conv_chunk(k8, tap) : ntap * k8 + tap;    // source chunk (the fp32 stream's order)
         const int lane_src = i + 32 * (e >> 2), s = e & 3;

@@ -191,10 +191,12 @@ int dsd_get_lat_split(dsd_handle* h);
 int dsd_set_rs_split(dsd_handle* h, int32_t g);
 int dsd_get_rs_split(dsd_handle* h);
 
-/* EXPERIMENT (csrc/dsd_split.hpp; default off, env DSD_SPLIT=1 turns it on at creation): the residual layers on
+/* EXPERIMENT (csrc/dsd_split.hpp, csrc/dsd_loop_split.hpp; default off, env DSD_SPLIT=1 turns it on at creation): the residual layers on
  * the bf16 matrix pipe with fp32-class accuracy - every fp32 operand is the exact sum of three bf16 planes, the six plane products
- * with i + j <= 2 are accumulated in fp32 (2.7x the fp32 MFMA rate).  Applies to the per-layer kernel path (the persistent loop is
- * bypassed while it is on, 32-frame tiles); in / head / sampler kernels are unchanged.  Enqueues the weight-plane packing on `stream`. */
+ * with i + j <= 2 are accumulated in fp32 (2.7x the fp32 MFMA rate).  Applies to the persistent loop (k_loop_split: the same loop, x /
+ * skip sum / halo exchange / head / sampler in fp32) and to the per-layer kernel path (k_layer_split, 32-frame tiles); the latency and
+ * row-split paths are bypassed while it is on.  Never the headline dtype: bench.py reports it as a labelled `secondary` line with its error
+ * against an fp64 evaluation of the oracle beside the fp32 path's.  Enqueues the weight-plane packing on `stream`. */
 int dsd_set_split_mode(dsd_handle* h, int32_t on, void* stream);
 int dsd_get_split_mode(dsd_handle* h);
 
