@@ -143,6 +143,7 @@ def secondary_split(gd, eng, pre, cond, x_T, noise, mel_f32, mel_oracle, args):
     from oracle import diffnet_oracle as O
     eng.set_split_mode(True)
     try:
+        cond = cond.clone()                               # a fresh tensor: the conditioner projection is prepared again for THIS cond
         run = lambda: gd.inference(cond, x_T=x_T, noise=noise, K_step=K_STEPS, pndm_speedup=0)
         mel_sp = run()
         torch.cuda.synchronize()

@@ -37,6 +37,7 @@ class DenoiserEngine:
         _lib.check(self.lib.dsd_create(C.byref(cfg), self.device.index or 0, C.byref(h)), 'dsd_create')
         self._h = h
         self.prepared_shape = None
+        self.prepare_serial = 0           # bumped by every prepare(): lets a cache of 'what is prepared' (DiffNet.bind_cond) notice a direct call
         self.n_sched = 0
 
     def close(self):
@@ -236,6 +237,7 @@ class DenoiserEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dsd_prepare(self._h, B, T, cond.data_ptr(), sb, sh, st, _stream_ptr(self.device)), 'dsd_prepare')
         self.prepared_shape = (B, T)
+        self.prepare_serial += 1
 
     def _spec(self, x: torch.Tensor, name='x') -> torch.Tensor:
         if self.prepared_shape is None:

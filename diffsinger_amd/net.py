@@ -103,10 +103,12 @@ class DiffNet(nn.Module):
         # tensor is kept referenced while cached - otherwise the caching allocator may hand its address to a
         # different conditioner (same pointer, version 0, same shape) and the stale projections would be reused.
         tag = (cond.data_ptr(), cond._version, tuple(cond.shape), cond.stride())
-        if self._cond_ref is None or tag != self._cond_tag or eng.prepared_shape != (cond.shape[0], cond.shape[2]):
+        if (self._cond_ref is None or tag != self._cond_tag or eng.prepared_shape != (cond.shape[0], cond.shape[2])
+                or eng.prepare_serial != getattr(self, '_cond_serial', -1)):      # (someone prepared the engine directly since: bench / tools)
             eng.prepare(cond)
             self._cond_tag = tag
             self._cond_ref = cond
+            self._cond_serial = eng.prepare_serial
         return eng
 
     def fused(self) -> bool:

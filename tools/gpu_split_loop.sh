@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT; TAG=${1:-r02}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-( time DSD_RUN_UNVERIFIED=1 timeout 900 python -m pytest tests/test_gpu_zz_split_loop.py -m gpu -x -q -rf -s > $O/pytest_split_loop.txt 2>&1 ) 2> $O/pytest_split_loop_time.txt
+( time DSD_RUN_UNVERIFIED=1 timeout 900 python -m pytest tests/test_gpu_split_loop.py -m gpu -x -q -rf -s > $O/pytest_split_loop.txt 2>&1 ) 2> $O/pytest_split_loop_time.txt
 tail -12 $O/pytest_split_loop.txt | cut -c1-300
 timeout 600 python -m pytest tests/test_gpu_split_layer.py -m gpu -q -rf -s > $O/pytest_split_layer.txt 2>&1
 tail -5 $O/pytest_split_layer.txt | cut -c1-300
