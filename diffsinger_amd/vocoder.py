@@ -550,6 +550,44 @@ def load_model(config_path, checkpoint_path, device=None):
     return model, config, device
 
 
+def _hann_periodic(win_length: int, n_fft: int) -> np.ndarray:
+    """scipy.signal.get_window('hann', win_length, fftbins=True), zero-padded on both sides to n_fft (librosa.util.pad_center)."""
+    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_length) / win_length)
+    lpad = (n_fft - win_length) // 2
+    return np.pad(w, (lpad, n_fft - win_length - lpad))
+
+
+def denoise(wav: np.ndarray, v: float = 0.1, *, fft_size: int, hop_size: int, win_size: int) -> np.ndarray:
+    """The reference's spectral-subtraction post-filter (vocoders/vocoder_utils.py:7-15), applied ON THE HOST to the waveform the
+    generator returned, as there: magnitude of a centred Hann STFT minus `v`, clipped at 0, phases kept, inverse STFT.
+
+    The reference calls librosa 0.8.0 (requirements.txt:2), which is not in this image: this is a numpy restatement of librosa's
+    published stft / istft for the arguments used there - window 'hann' (periodic) padded to n_fft, center=True with
+    pad_mode='constant', frames of n_fft at hop_length, rfft in double, spectrum kept as complex64; inverse: irfft x window overlap-added
+    into a float32 signal, divided by the window sum-of-squares where it exceeds `tiny`, trimmed by n_fft // 2 on both sides.
+    PARITY UNPINNED against librosa itself (absent); pinned against an independent implementation (torch.stft / torch.istft) in
+    tests/test_vocoder_host.py."""
+    wav = np.asarray(wav, dtype=np.float32).reshape(-1)
+    n_fft, hop = int(fft_size), int(hop_size)
+    win = _hann_periodic(int(win_size), n_fft)
+    y = np.pad(wav, n_fft // 2, mode='constant')
+    n_frames = 1 + (len(y) - n_fft) // hop
+    idx = np.arange(n_fft)[:, None] + hop * np.arange(n_frames)[None, :]
+    spec = np.fft.rfft(win[:, None] * y[idx], axis=0).astype(np.complex64)             # [1 + n_fft / 2, n_frames]
+    mag = np.clip(np.abs(spec) - v, a_min=0, a_max=None)
+    spec = mag * np.exp(1j * np.angle(spec))
+    frames = win[:, None] * np.fft.irfft(spec, n=n_fft, axis=0)
+    out = np.zeros(n_fft + hop * (n_frames - 1), dtype=np.float32)
+    wss = np.zeros_like(out)
+    wsq = (win * win).astype(np.float32)
+    for k in range(n_frames):
+        out[k * hop:k * hop + n_fft] += frames[:, k].astype(np.float32)
+        wss[k * hop:k * hop + n_fft] += wsq
+    nz = wss > np.finfo(np.float32).tiny
+    out[nz] /= wss[nz]
+    return out[n_fft // 2:len(out) - n_fft // 2]
+
+
 @register_vocoder
 class HifiGAN:
     """vocoders/hifigan.py:40-69.  HifiGAN() discovers the checkpoint like the reference does (hparams['vocoder_ckpt']: config.yaml +
@@ -589,9 +627,6 @@ class HifiGAN:
 
     def spec2wav(self, mel, **kwargs):
         from .hparams import hparams
-        if hparams.get('vocoder_denoise_c', 0.0) > 0:
-            raise NotImplementedError("hparams['vocoder_denoise_c'] > 0: the spectral-subtraction post-filter (vocoders/vocoder_utils.denoise, librosa STFT on "
-                                      "the host) is not part of this package - run it on the returned waveform")
         with torch.no_grad():
             c = torch.as_tensor(mel, dtype=torch.float32).unsqueeze(0).transpose(2, 1).to(self.device)
             f0 = kwargs.get('f0')
@@ -600,4 +635,8 @@ class HifiGAN:
                 y = self.model(c, f0).view(-1)
             else:
                 y = self.model(c).view(-1)
-        return y.cpu().numpy()
+        wav_out = y.cpu().numpy()
+        if hparams.get('vocoder_denoise_c', 0.0) > 0:                       # vocoders/hifigan.py:63-64
+            wav_out = denoise(wav_out, v=hparams['vocoder_denoise_c'], fft_size=hparams['fft_size'], hop_size=hparams['hop_size'],
+                              win_size=hparams['win_size'])
+        return wav_out

@@ -221,3 +221,32 @@ def test_taps_beyond_the_staged_window_are_refused():
     m.remove_weight_norm()
     m._ops = HeaderFormulaOps()
     assert m(torch.zeros(1, 80, 4)).shape[0] == 1          # reach 36: accepted
+
+
+def test_denoise_post_filter_matches_an_independent_stft_and_is_identity_at_zero():
+    """vocoders/vocoder_utils.py:7-15 (librosa 0.8.0 stft -> |S| - v clipped at 0, phase kept -> istft) restated in numpy
+    (diffsinger_amd.vocoder.denoise; librosa is absent here) against torch.stft / torch.istft with the same arguments."""
+    import numpy as np
+    import torch
+    from diffsinger_amd.vocoder import denoise
+    g = torch.Generator().manual_seed(4)
+    for n_fft, hop, win, n in ((512, 128, 512, 24000), (1024, 256, 1024, 22050), (1024, 256, 800, 9000)):
+        wav = (torch.randn(n, generator=g) * 0.1 + 0.3 * torch.sin(torch.arange(n) * 0.05)).numpy().astype(np.float32)
+        window = torch.zeros(n_fft, dtype=torch.float64)
+        lp = (n_fft - win) // 2
+        window[lp:lp + win] = torch.hann_window(win, periodic=True, dtype=torch.float64)
+        for v in (0.0, 0.1, 0.5):
+            got = denoise(wav, v=v, fft_size=n_fft, hop_size=hop, win_size=win)
+            S = torch.stft(torch.from_numpy(wav).double(), n_fft, hop_length=hop, win_length=n_fft, window=window, center=True, pad_mode='constant',
+                           onesided=True, return_complex=True)
+            S = torch.polar(torch.clamp(S.abs() - v, min=0), S.angle())
+            want = torch.istft(S, n_fft, hop_length=hop, win_length=n_fft, window=window, center=True).numpy()
+            m = min(len(got), len(want))
+            assert abs(len(got) - len(want)) <= hop and m > n - 2 * n_fft
+            edge = n_fft                                           # (librosa keeps the ramp-up samples torch trims differently: compare the interior)
+            err = float(np.abs(got[edge:m - edge] - want[edge:m - edge]).max())
+            assert err < 2e-5, (n_fft, hop, win, v, err)
+            if v == 0.0:
+                assert float(np.abs(got[edge:m - edge] - wav[edge:m - edge]).max()) < 2e-5     # no subtraction: the filter is the identity
+            else:
+                assert float(np.abs(got).mean()) < float(np.abs(wav).mean())                  # energy went down
