@@ -192,7 +192,7 @@ def secondary_split(gd, eng, pre, cond, x_T, noise, mel_f32, mel_oracle, args):
                      'avg_launch_ms': ms_call, 'note': 'executed fp32-equivalent FLOPs (21 053 440 / frame / evaluation) over the whole sampling call (HIP events); '
                                                        'peak = dense bf16 MFMA peak 2500 TFLOP/s / 6 plane products; the head (2 % of the fp32 launch) runs on the fp32 pipe'},
         'parity': {'case': 'the timed batch (all 8 utterances) vs the fp32 oracle; utterance 0 vs an fp64 evaluation of the oracle, both paths', 'tolerance': 1e-4,
-                   'split_vs_oracle_f32': err(mel_sp, mel_oracle), 'f32_vs_oracle_f32': err(mel_f32, mel_oracle),
+                   'split_vs_f32_hip': err(mel_sp, mel_f32.detach().cpu()), 'split_vs_oracle_f32': err(mel_sp, mel_oracle), 'f32_vs_oracle_f32': err(mel_f32, mel_oracle),
                    'split_vs_oracle_f64_utt0': err(mel_sp[0:1], m64), 'f32_vs_oracle_f64_utt0': err(mel_f32[0:1], m64),
                    'oracle_f32_vs_oracle_f64_utt0': err(mel_oracle[0:1], m64), 'f64_oracle_seconds': t64},
     }

@@ -219,8 +219,10 @@ static void free_workspace(dsd_handle* h) {
 #define DSD_BUILD_ID_STR "unknown"
 #endif
 // tag + id in one array: build.py finds the id in the file's bytes without loading the library
+#if !defined(__HIP_DEVICE_COMPILE__)       // host side only: the device code object does not change with the id
 extern "C" { __attribute__((used, visibility("default"))) const char dsd_build_id_blob[] = "DSD_BUILD_ID=" DSD_BUILD_ID_STR; }
 extern "C" const char* dsd_build_id(void) { return dsd_build_id_blob + 13; }
+#endif
 extern "C" int dsd_abi_version(void) { return DSD_ABI_VERSION; }
 extern "C" const char* dsd_last_error(void) { return g_err.c_str(); }
 
