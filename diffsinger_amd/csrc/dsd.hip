@@ -997,8 +997,7 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
         p.tile_base = b0 * h->ntile32; p.n_tiles = nb * h->ntile32;
         if (h->split_mode) {
             // EXPERIMENT (dsd_loop_split.hpp): the same loop with the layers' contractions as six bf16 plane products per fp32 product
-            static const int rot_env = std::getenv("DSD_SPLIT_ROT") ? std::atoi(std::getenv("DSD_SPLIT_ROT")) : 0;     // experiment switch (A/B in one process: tools only)
-            const LoopSplitParams q{p, h->w1c, h->w2s, rot_env};
+            const LoopSplitParams q{p, h->w1c, h->w2s};
             if (kind == 0) hipLaunchKernelGGL((k_loop_split<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopSplitLdsBytes, s, q);
             else hipLaunchKernelGGL((k_loop_split<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopSplitLdsBytes, s, q);
         } else if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);

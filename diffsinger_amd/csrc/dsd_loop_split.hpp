@@ -26,32 +26,22 @@ constexpr int kSpConvCentre = 16;           // centre-tap chunks (16 channels ea
 constexpr int kLoopSplitLdsBytes = (3 * kSpYPlane + 3 * kSpGPlane) * 2 + (kMPad * 32 + 2 * kC) * (int)sizeof(float);
 static_assert(3 * kSpYPlane * 2 >= kC * 32 * 4 && 3 * kSpGPlane * 2 >= kC * 32 * 4, "the head reuses the plane regions as fp32 [256][32] tiles");
 
-// Chunk ROTATION (experiment, LoopSplitParams::rot): the 32 workgroups behind one L2 walk the same weight stream in lock-step, so every
-// 128-byte line is requested 32 times at the same moment and each L2 channel serves its lines serially - the queueing shows up as ~1.5 us of
-// load latency that two stages of prefetch cannot cover (profiles/r4_04_loop_split_pmc.txt: matrix pipe busy 0.42).  With rot != 0 workgroup k
-// of an XCD starts its K loops k chunks further on (inside the centre group / the outer group / the output projection, so the halo schedule
-// is untouched): the same lines, requested at different times.  The summation order then depends on the tile's position.
-__device__ __forceinline__ int sp_phys_conv(int kc, int rot) {
-    const int kcc = (kc < 48) ? kc : 47;
-    return (kcc < kSpConvCentre) ? ((kcc + rot) & 15) : kSpConvCentre + ((kcc - kSpConvCentre + 2 * rot) & 31);      // (the outer group rotates by whole (-dil, +dil) pairs)
-}
-__device__ __forceinline__ int sp_phys_out(int kc, int rot) { return (((kc < 16) ? kc : 15) + rot) & 15; }
-
 // B functors over the bf16 plane tiles (plane 0; plane pl at + pl * bplane elements)
 struct SConvB {
-    const su16* yc; int dilrow, rot;        // yc = this lane's (frame row kHalo + j, channel 8 h); dilrow = dil * kSpRS
-    __device__ __forceinline__ int phys(int kc) const { return sp_phys_conv(kc, rot); }
+    const su16* yc; int dilrow;             // yc = this lane's (frame row kHalo + j, channel 8 h); dilrow = dil * kSpRS
     __device__ __forceinline__ const su16* operator()(int it, int u) const {
-        const int kc = phys(6 * it + u);
+        const int kc = 6 * it + u;
         const int idx = kc - kSpConvCentre;
         const int oc = kc * 16, oo = (idx >> 1) * 16 + ((idx & 1) ? dilrow : -dilrow);
         return yc + ((kc < kSpConvCentre) ? oc : oo);
     }
 };
 struct STileB {
-    const su16* base; int n, rot;
-    __device__ __forceinline__ int phys(int kc) const { return sp_phys_out(kc, rot); }
-    __device__ __forceinline__ const su16* operator()(int it, int u) const { return base + phys(6 * it + u) * 16; }
+    const su16* base; int n;
+    __device__ __forceinline__ const su16* operator()(int it, int u) const {
+        const int kc = 6 * it + u;
+        return base + ((kc < n) ? kc : n - 1) * 16;
+    }
 };
 
 // Operand pipeline of the split contractions with run(begin, end) like GemmPipe: STAGES register stages of the weight planes (chunk
@@ -72,7 +62,7 @@ struct SplitPipeR {
           bplane(bplane_) {}
     __device__ __forceinline__ void lda(uint4 (&dst)[NMB][3], int kc) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const int kcc = bof.phys(kc);                                      // (clamped: prefetches past the end re-read the last chunk)
+        const int kcc = (kc < n) ? kc : n - 1;                             // prefetches past the end re-read the last chunk
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
@@ -171,7 +161,6 @@ struct LoopSplitParams {
     LoopParams lp;              // everything k_loop takes (w1p / w2p unused here)
     const uint4* w1c;           // conv planes, centre-first chunk order: [L][w4][48][mb4][3][lane64]
     const uint4* w2s;           // out-projection planes:                 [L][w4][16][mb4][3][lane64]
-    int rot;                    // 1: chunk rotation by workgroup (above)
 };
 
 template <int MODE>
@@ -201,7 +190,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
 
     float4 xq[2][4], skp[2][4];
     const int ch0 = 64 * w + 4 * h;
-    const int rot = ps.rot ? (int)(blockIdx.x >> 3) : 0;
 
     auto timed_out = [&]() -> bool { return __hip_atomic_load((gu32*)p.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; };
 
@@ -266,7 +254,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
             const float* dsl = dsbuf + (ph & 1) * kC;
             LOOP_STAMP(0);
             // (c) weight planes of the conv: requested before anything of this phase exists
-            const SConvB bof1{yp + (kHalo + j) * kSpRS + 8 * h, (int)p.dil[l] * kSpRS, rot};
+            const SConvB bof1{yp + (kHalo + j) * kSpRS + 8 * h, (int)p.dil[l] * kSpRS};
             SplitPipeR<4, 0, 3, SConvB> pipe1(ps.w1c + ((size_t)l * 4 + w) * (48 * 12 * 64), lane, 48, bof1, kSpYPlane);
             pipe1.start_a();
             // (b) own frames of y = x + step_proj (zero at frames >= T) as planes: the lane's 32 channels of frame j
@@ -355,7 +343,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                 const int tn_ = last ? p.eval_t[min(e + 1, p.n_evals - 1)] : t_e, ln_ = last ? 0 : l + 1;
                 if (more) ds_next = ld4_u(p.ds_table + ((size_t)tn_ * p.L + ln_) * kC, tid * 4);
             }
-            const STileB bof2{gp + j * kSpRS + 8 * h, 16, rot};
+            const STileB bof2{gp + j * kSpRS + 8 * h, 16};
             // gate (net.py:73-74) in registers -> gate planes
             auto do_gate = [&]() {
 #pragma unroll
