@@ -126,8 +126,6 @@ static int tr_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)(k_tr_wgrad<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tr_wg_lds_bytes<2>()));
-    HIP_TRY(hipFuncSetAttribute((const void*)(k_tr_wgrad<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tr_wg_lds_bytes<2>()));
     return DSD_OK;
 }
 
@@ -147,10 +145,8 @@ static TrProbe& tr_probe() { static TrProbe p; return p; }
 // fix: some B operand is not padded against its tap shift (k_tr_wgrad<true>)
 static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int T, int TS, bool fix) {
     wp.B = B; wp.T = T; wp.TS = TS;
-    // column halves per output tile (k_tr_wgrad<FIX, NH>): 2 = two workgroups per CU (default); DSF_WGRAD_NH=1 restores the whole-tile kernel
-    static const int nh = (std::getenv("DSF_WGRAD_NH") && std::atoi(std::getenv("DSF_WGRAD_NH")) == 1) ? 1 : 2;
     wp.nsplit = tr_nsplit(ndesc, B * TS / 32);
-    const int total = ndesc * nh * wp.nsplit;
+    const int total = ndesc * wp.nsplit;
     wp.ndesc = ndesc; wp.xcd_q = total / 8; wp.xcd_r = total % 8;
     TrProbe& pr = tr_probe();
     const bool probe = pr.on && !fix;
@@ -163,10 +159,7 @@ static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int 
         }
         HIP_TRY(hipEventRecord(pr.ev[pr.used].first, s));
     }
-    if (nh == 2) {
-        if (fix) hipLaunchKernelGGL((k_tr_wgrad<true, 2>), dim3((unsigned)total), dim3(kThreads), tr_wg_lds_bytes<2>(), s, wp);
-        else hipLaunchKernelGGL((k_tr_wgrad<false, 2>), dim3((unsigned)total), dim3(kThreads), tr_wg_lds_bytes<2>(), s, wp);
-    } else if (fix) hipLaunchKernelGGL(k_tr_wgrad<true>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
+    if (fix) hipLaunchKernelGGL(k_tr_wgrad<true>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
     else hipLaunchKernelGGL(k_tr_wgrad<false>, dim3((unsigned)total), dim3(kThreads), kTrWgLdsBytes, s, wp);
     HIP_TRY(hipGetLastError());
     if (probe) {

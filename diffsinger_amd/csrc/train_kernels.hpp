@@ -593,22 +593,18 @@ struct TrWgParams {
                                 // behind one L2 contract (nearly) the same frames, so every operand line is fetched from the fabric by ~1.3 L2s, not 8
 };
 constexpr int kTrWgLD = 36;
-// NH = 1: a workgroup owns a whole 128 x 256 output tile; NH = 2 (round 4): the tile's two 128-column halves go to two workgroups - 64 instead of
-// 128 accumulator registers per lane, 74 instead of 111 KiB of LDS: TWO workgroups per CU, whose barrier-separated steps cover each other
-template <int NH> constexpr int tr_wg_stage() { return (128 + 256 / NH) * kTrWgLD; }
-template <int NH> constexpr int tr_wg_lds_bytes() { return 2 * tr_wg_stage<NH>() * (int)sizeof(float); }
-constexpr int kTrWgStage = tr_wg_stage<1>();
-constexpr int kTrWgLdsBytes = tr_wg_lds_bytes<1>();
+constexpr int kTrWgStage = (128 + 256) * kTrWgLD;
+constexpr int kTrWgLdsBytes = 2 * kTrWgStage * (int)sizeof(float);
 constexpr int kTrYPad = 8;      // zero floats on both sides of every row of the saved y (>= the largest tap shift): a shifted 16-byte load stays in its row
 
 struct __attribute__((aligned(4))) tr_f4u { float x, y, z, w; };       // a 16-byte load that is only dword-aligned
 
 // {1 MFMA, then up to NV VALU, 1 LDS write, 1 global load, 1 LDS read} x n: the non-MFMA work of a step is issued in the shadow of the MFMAs
 // (one wave per SIMD: nothing else would fill the pipe while this wave computes addresses or writes the next tile)
-template <int NV, bool DSW, bool VMEM, bool DSR, int NM = 32>
+template <int NV, bool DSW, bool VMEM, bool DSR>
 __device__ __forceinline__ void tr_interleave(int) {
 #pragma unroll
-    for (int i = 0; i < NM; ++i) {
+    for (int i = 0; i < 32; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (DSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
@@ -620,18 +616,12 @@ __device__ __forceinline__ void tr_interleave(int) {
 // FIX: the B rows are NOT padded (the stand-alone operator on a caller's tensor): the shifted load is clamped into the row and the first /
 // last tile of an utterance patches the elements when it writes the tile (a branch in the step).  The fused stack pads its y rows (kTrYPad)
 // and runs the branch-free form.
-template <bool FIX, int NH = 1>
-__global__ __launch_bounds__(kThreads, NH) void k_tr_wgrad(const TrWgParams p) {
+template <bool FIX>
+__global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
     constexpr int LD = kTrWgLD;
-    constexpr int NBQ = 8 / NH;             // 32-row groups of B a thread stages
-    constexpr int NBW = 4 / NH;             // 32-column blocks of a wave
-    constexpr int STAGE = tr_wg_stage<NH>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = xcd_item(blockIdx.x, p.xcd_q, p.xcd_r);
-    // (split, tile descriptor, column half): the workgroups of one tile - and of neighbouring tiles - contract the same frames
-    const int per_split = p.ndesc * NH;
-    const int split = item / per_split, rem = item - split * per_split;
-    const int desc = rem / NH, nh = rem - desc * NH;
+    const int split = item / p.ndesc, desc = item - split * p.ndesc;
     const TrWgTile& d = p.tile[desc];
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -639,16 +629,16 @@ __global__ __launch_bounds__(kThreads, NH) void k_tr_wgrad(const TrWgParams p) {
     const int tiles_per_utt = p.TS / 32, ntile = p.B * tiles_per_utt;
     const int per = (ntile + p.nsplit - 1) / p.nsplit;
     const int tile_lo = split * per, tile_hi = min(ntile, tile_lo + per);
-    f32x16 acc[2][NBW];
+    f32x16 acc[2][4];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
     // staging map: thread tid moves float4 column g = tid & 7 of rows (tid >> 3) + 32 q
     const int srow = tid >> 3, sg = tid & 7;
-    float4 av[4], bv[NBQ];
+    float4 av[4], bv[8];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     int a_valid = 0, b_shift = 0;
     const float a_scale = d.a_scale;
@@ -664,15 +654,15 @@ __global__ __launch_bounds__(kThreads, NH) void k_tr_wgrad(const TrWgParams p) {
         const int tb = t + shift;
         const int tbc = FIX ? min(max(tb, 0), p.TS - 4) : tb;
         b_shift = tb - tbc;
-        const float* bp = d.bsrc + (size_t)b * d.b_bstride + (size_t)((256 / NH) * nh + srow) * b_rs + tbc;
+        const float* bp = d.bsrc + (size_t)b * d.b_bstride + (size_t)srow * b_rs + tbc;
 #pragma unroll
-        for (int q = 0; q < NBQ; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const tr_f4u v = *reinterpret_cast<const tr_f4u*>(bp + (size_t)(32 * q) * b_rs);
             bv[q] = make_float4(v.x, v.y, v.z, v.w);
         }
     };
     auto stash = [&](int buf, float live) {
-        float* As = smem + buf * STAGE;
+        float* As = smem + buf * kTrWgStage;
         float* Bs = As + 128 * LD;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -684,7 +674,7 @@ __global__ __launch_bounds__(kThreads, NH) void k_tr_wgrad(const TrWgParams p) {
         }
         if (FIX && b_shift != 0) {
 #pragma unroll
-            for (int q = 0; q < NBQ; ++q) {
+            for (int q = 0; q < 8; ++q) {
                 const float4 v = bv[q];
                 float o[4];
 #pragma unroll
@@ -696,7 +686,7 @@ __global__ __launch_bounds__(kThreads, NH) void k_tr_wgrad(const TrWgParams p) {
             }
         }
 #pragma unroll
-        for (int q = 0; q < NBQ; ++q) *reinterpret_cast<float4*>(Bs + (srow + 32 * q) * LD + 4 * sg) = bv[q];
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(Bs + (srow + 32 * q) * LD + 4 * sg) = bv[q];
     };
     // Software pipeline over the 32-frame steps (one wave per SIMD: nothing else hides a bubble).  At the top of step k LDS buffer k & 1
     // holds tile k, the staging registers hold tile k + 1 (requested a whole step ago) and the fragments of chunk 0 are already in
@@ -707,14 +697,14 @@ __global__ __launch_bounds__(kThreads, NH) void k_tr_wgrad(const TrWgParams p) {
     // issued - they cover barrier skew and LDS latency.  The step is branch-free: behind the last tile the staging registers repeat it
     // (`live` = 0 keeps it out of the bias sums; the buffer it lands in is never multiplied).
     const int nstep = tile_hi - tile_lo;
-    float4 fa[2][2], fb[2][NBW];
+    float4 fa[2][2], fb[2][4];
     auto frags = [&](int set, int buf, int c) {
-        const float* ap = smem + buf * STAGE + (64 * wm + i) * LD + 4 * h + 8 * c;
-        const float* bp = smem + buf * STAGE + 128 * LD + (32 * NBW * wn + i) * LD + 4 * h + 8 * c;
+        const float* ap = smem + buf * kTrWgStage + (64 * wm + i) * LD + 4 * h + 8 * c;
+        const float* bp = smem + buf * kTrWgStage + 128 * LD + (128 * wn + i) * LD + 4 * h + 8 * c;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) fa[set][mb] = *reinterpret_cast<const float4*>(ap + 32 * mb * LD);
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) fb[set][nb] = *reinterpret_cast<const float4*>(bp + 32 * nb * LD);
+        for (int nb = 0; nb < 4; ++nb) fb[set][nb] = *reinterpret_cast<const float4*>(bp + 32 * nb * LD);
     };
     auto mma = [&](int set) {
 #pragma unroll
@@ -722,9 +712,8 @@ __global__ __launch_bounds__(kThreads, NH) void k_tr_wgrad(const TrWgParams p) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) acc[mb][nb] = mfma32(f4at(fa[set][mb], s), f4at(fb[set][nb], s), acc[mb][nb]);
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma32(f4at(fa[set][mb], s), f4at(fb[set][nb], s), acc[mb][nb]);
     };
-    constexpr int NM = 8 * NBW;             // MFMAs of a chunk
     if (nstep > 0) {
         fetch(tile_lo);
         stash(0, 1.f);
@@ -738,21 +727,21 @@ __global__ __launch_bounds__(kThreads, NH) void k_tr_wgrad(const TrWgParams p) {
             stash(cur ^ 1, live);
             fetch(min(tile_lo + k + 2, tile_hi - 1));
             mma(0);
-            if (!FIX) tr_interleave<4, true, true, true, NM>(0);
+            if (!FIX) tr_interleave<4, true, true, true>(0);
             DSD_SB();
             frags(0, cur, 2);
             mma(1);
-            tr_interleave<0, false, false, true, NM>(0);
+            tr_interleave<0, false, false, true>(0);
             DSD_SB();
             frags(1, cur, 3);
             mma(0);
-            tr_interleave<0, false, false, true, NM>(0);
+            tr_interleave<0, false, false, true>(0);
             DSD_SB();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
             frags(0, cur ^ 1, 0);
             mma(1);
-            tr_interleave<0, false, false, true, NM>(0);
+            tr_interleave<0, false, false, true>(0);
             DSD_SB();
         }
     }
@@ -760,11 +749,10 @@ __global__ __launch_bounds__(kThreads, NH) void k_tr_wgrad(const TrWgParams p) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                store4_wt(out, (64 * wm + 32 * mb + frag_row(r, h)) * 256 + (256 / NH) * nh + 32 * NBW * wn + 32 * nb + i, acc[mb][nb][r]);
-    if (d.out_bias && nh == 0) {
+            for (int r = 0; r < 16; ++r) store4_wt(out, (64 * wm + 32 * mb + frag_row(r, h)) * 256 + 128 * wn + 32 * nb + i, acc[mb][nb][r]);
+    if (d.out_bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float sb = bsum[q];
