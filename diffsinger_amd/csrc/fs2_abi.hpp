@@ -217,8 +217,11 @@ extern "C" int dsf_linear_rows_bwd(const float* x, const float* w, const float* 
 extern "C" int dsf_attention_bwd(const float* qkv, const uint8_t* key_pad, const float* dout, float* dqkv, float* ws, int32_t B, int32_t C,
                                  int32_t heads, int32_t T, void* stream) {
     if (!qkv || !dout || !dqkv || !ws) return fail(DSD_ERR_INVALID, "dsf_attention_bwd: null argument");
-    if (B < 1 || T < 1 || heads < 1 || C != heads * 128 || (int64_t)B * heads > 65535)
+    if (B < 1 || T < 1 || heads < 1 || C != heads * 128)
         return fail(DSD_ERR_INVALID, "dsf_attention_bwd: this build supports head_dim 128 (C=%d, heads=%d)", C, heads);
+    if ((int64_t)B * heads > 65535)
+        return fail(DSD_ERR_INVALID, "dsf_attention_bwd: B * heads = %lld exceeds the 65535 (batch, head) pairs of one launch: split the batch",
+                    (long long)B * heads);
     hipStream_t s = (hipStream_t)stream;
     const int TS = fs_ts(T), HD = 128, BH = B * heads;
     const long long ts = TS, tt = T;

@@ -57,7 +57,10 @@ int dsf_attention(const float* qkv, const uint8_t* key_pad, float* out, int32_t 
  * (zero tail), dgamma [C], dbeta [C] (overwritten; per-tile partial sums in ws, added in a fixed order: deterministic);
  * ws: dsf_ln_bwd_workspace_floats(B, T) floats.
  * dsf_attention_bwd: dout [B][C][TS] -> dqkv [B][3C][TS] (zero tail); the probabilities are recomputed ([B heads][T][T], twice, in ws:
- * dsf_attention_bwd_workspace_floats(B, heads, T) floats) - the attention of the model that is trained runs at the phone rate. */
+ * dsf_attention_bwd_workspace_floats(B, heads, T) floats) - the attention of the model that is trained runs at the phone rate.
+ * LIMITS: the workspace is QUADRATIC in T (2 x B x heads x T x T floats: 33 MB at the phone rate of the e2e step, B = 8, T = 128 - but
+ * 0.7-2 GB per layer for a mel-rate decoder, T = 1000-1500 with B in the tens: plain FastSpeech2 training at the mel rate should go layer by layer
+ * with a reused workspace, or tile the query axis above this call); B x heads <= 65535 per call (DSD_ERR_INVALID beyond, split the batch). */
 int64_t dsf_ln_bwd_workspace_floats(int32_t B, int32_t T);
 int dsf_layer_norm_bwd(const float* x, const float* gamma, const float* dy, const float* keep, float* dx, float* dgamma, float* dbeta, float* ws,
                        int32_t B, int32_t C, int32_t T, float eps, int32_t relu_in, void* stream);
