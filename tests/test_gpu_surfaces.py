@@ -229,3 +229,36 @@ def test_real_sampler_through_sharded_inference_on_rccl_world1():
         assert view.shape == (n, 1, T, 80) and torch.equal(view[:, 0], want)
     finally:
         dist.destroy_process_group()
+
+
+def test_utterances_of_different_lengths_through_sharded_inference_vs_the_oracle():
+    """Different lengths (diffsinger_amd/dist.py plan_ragged): length-sorted, 32-frame-bucketed micro-batches, the shorter utterances of a
+    micro-batch zero-padded to its longest - the reference's batched inference (collated, padded batches: tasks/tts/fs2.py:340-369,
+    utils/__init__.py:89-142).  Every utterance's mel against the ORACLE run on the same padded micro-batch, original order kept."""
+    from diffsinger_amd.dist import pad_stack, plan_ragged, sharded_inference
+    K = 8
+    gd, cfg, pre, p, sch = _lj(K)
+    lengths = [70, 91, 40, 96, 85, 33, 64, 90]
+    g = torch.Generator().manual_seed(77)
+    conds = [torch.randn(t, 256, generator=g).t() for t in lengths]                       # [H, T_i] views of [T_i, H]
+    xs = [torch.randn(1, 80, t, generator=g) for t in lengths]
+    nz = [torch.randn(K, 1, 80, t, generator=g) for t in lengths]
+    T_of = lambda idx: max(lengths[i] for i in idx)
+    got = sharded_inference(gd, [c.to(DEV) for c in conds], micro_batch=3, max_frames=8192, dst=0, K_step=K, pndm_speedup=0,
+                            x_T=lambda idx: pad_stack([xs[i] for i in idx], T_of(idx)).to(DEV),
+                            noise=lambda idx: torch.stack([pad_stack([nz[i][k] for i in idx], T_of(idx)) for k in range(K)]).to(DEV))
+    assert [tuple(m.shape) for m in got] == [(t, 80) for t in lengths]
+    smin = torch.tensor(pre['spec_min'], dtype=torch.float32)[None, None, :]
+    smax = torch.tensor(pre['spec_max'], dtype=torch.float32)[None, None, :]
+    batches, owner = plan_ragged(lengths, 1, micro_batch=3, max_frames=8192)
+    assert sorted(i for b in batches for i in b) == list(range(len(lengths))) and set(owner) == {0}
+    worst = 0.0
+    for idx in batches:
+        Tm = T_of(idx)
+        assert len({(lengths[i] + 31) // 32 for i in idx}) == 1                            # one 32-frame bucket per micro-batch
+        want = O.infer_mel(p, cfg, sch, pad_stack([conds[i] for i in idx], Tm), smin, smax, k_step=K,
+                           noises=[pad_stack([nz[i][k] for i in idx], Tm) for k in range(K)], x_T=pad_stack([xs[i] for i in idx], Tm))
+        for b, i in enumerate(idx):
+            worst = max(worst, float((got[i].cpu() - want[b, :lengths[i]]).abs().max()))
+    print(f'ragged micro-batches {batches}: max-abs mel err vs the oracle on the same padded batches {worst:.3e}')
+    assert worst <= 1e-4
