@@ -29,19 +29,17 @@ static_assert(3 * kSpYPlane * 2 >= kC * 32 * 4 && 3 * kSpGPlane * 2 >= kC * 32 *
 // B functors over the bf16 plane tiles (plane 0; plane pl at + pl * bplane elements)
 struct SConvB {
     const su16* yc; int dilrow;             // yc = this lane's (frame row kHalo + j, channel 8 h); dilrow = dil * kSpRS
-    __device__ __forceinline__ const su16* operator()(int it, int u) const {
-        const int kc = 6 * it + u;
+    __device__ __forceinline__ const su16* at(int kc) const {
         const int idx = kc - kSpConvCentre;
         const int oc = kc * 16, oo = (idx >> 1) * 16 + ((idx & 1) ? dilrow : -dilrow);
         return yc + ((kc < kSpConvCentre) ? oc : oo);
     }
+    __device__ __forceinline__ const su16* operator()(int it, int u) const { return at(6 * it + u); }
 };
 struct STileB {
     const su16* base; int n;
-    __device__ __forceinline__ const su16* operator()(int it, int u) const {
-        const int kc = 6 * it + u;
-        return base + ((kc < n) ? kc : n - 1) * 16;
-    }
+    __device__ __forceinline__ const su16* at(int kc) const { return base + ((kc < n) ? kc : n - 1) * 16; }
+    __device__ __forceinline__ const su16* operator()(int it, int u) const { return at(6 * it + u); }
 };
 
 // Operand pipeline of the split contractions with run(begin, end) like GemmPipe: STAGES register stages of the weight planes (chunk
@@ -49,6 +47,8 @@ struct STileB {
 template <int NMB, int MB0, int STAGES, typename BOff>
 struct SplitPipeR {
     static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
+    static constexpr int P = 6;
+    static constexpr int kChunkU4 = 12 * 64;          // uint4 per chunk and wave
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned aoff;
     int n;
@@ -111,6 +111,8 @@ struct SplitPipeR {
         pattern();
         DSD_SB();
     }
+    template <int BEGIN, int END>
+    __device__ __forceinline__ void run(f32x16 (&acc)[NMB]) { run(acc, BEGIN, END); }
     // chunks [begin, end); begin a multiple of 6
     __device__ __forceinline__ void run(f32x16 (&acc)[NMB], int begin, int end) {
         for (int it = begin / 6; 6 * it < end; ++it) {
@@ -129,6 +131,151 @@ struct SplitPipeR {
         }
     }
 };
+
+// The weights as FP32 on the wire, split into the three planes in registers beside the MFMAs (k_pack_split_f32's layout: 8 KiB per chunk
+// and wave, two 16-byte loads per row block and lane).  The plane stream is 6 bytes per weight and every CU of an XCD walks the whole layer
+// per evaluation (the matrix pipe waits for bytes, busy 0.42); this form moves 4.  The split is sp_split3's arithmetic
+// on pairs: v_cvt_pk_bf16_f32 (round to nearest even), the planes' fp32 values back by shift / mask, exact subtractions - 36 VALU
+// instructions per 8 weights, bit-identical planes, and per accumulator the same products in the same order as SplitPipeR: the two loops
+// agree bit for bit (tests/test_gpu_split_loop.py).  Row blocks go in PAIRS: the MFMAs of one pair (two accumulators alternating, 12
+// MFMAs) cover the split of the next pair's fragments; two sets of plane registers (48 VGPRs) beside STAGES x NMB x 8 of fp32 stages.
+// Period of the register rotation: 6 steps for 3 stages, 4 for 4.
+template <int NMB, int MB0, int STAGES, typename BOff>
+struct SplitPipeW {
+    static_assert(STAGES == 3 || STAGES == 4, "3 stages rotate with period 6, 4 with period 4");
+    static_assert(NMB == 4 || NMB == 2, "row blocks are processed in pairs");
+    static constexpr int P = (STAGES == 3) ? 6 : 4;
+    static constexpr int kChunkU4 = 8 * 64;           // uint4 per chunk and wave
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned aoff, aoff_hi;      // lane * 16 and + 4096: every load of a chunk = one of them + an immediate < 4096, ONE scalar offset per chunk
+    int n;
+    BOff bof;
+    int bplane;
+    float4 a[STAGES][NMB][2];
+    uint4 pl[2][2][3];           // [set][row block of the pair][plane]
+    sbf16x8 b[2][3];
+
+    __device__ __forceinline__ SplitPipeW(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u),
+          aoff_hi((unsigned)lane * 16u + 4096u), n(n_), bof(bof_), bplane(bplane_) {
+        asm volatile("" : "+v"(aoff_hi));                                   // keep it a register: folded back, every load would need its own scalar add
+    }
+    __device__ __forceinline__ void lda(float4 (&dst)[NMB][2], int kc) {
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const int kcc = (kc < n) ? kc : n - 1;
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int o = ((MB0 + mb) * 2 + hf) * 1024;
+                const f32x4_ v = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((o < 4096 ? aoff : aoff_hi) + (unsigned)(o & 4095)), kcc * 8192, 0));
+                dst[mb][hf] = make_float4(v.x, v.y, v.z, v.w);
+            }
+    }
+    __device__ __forceinline__ void ldb(sbf16x8 (&dst)[3], int kc) {
+        const su16* bp = bof.at(kc);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(bp + p * bplane));
+    }
+    // eight fp32 weights -> three plane fragments (sp_split3 on pairs).  The exact residuals stay single v_sub_f32: an empty asm on each
+    // result keeps hipcc from packing pairs of them into v_pk_add_f32, which beside MFMAs costs about three issue slots for two
+    // subtractions (MI355X_MICROARCH.md, "price of one filler beside MFMAs") - and issue slots are what bounds this pipe.
+    static __device__ __forceinline__ float sub_f32(float x, unsigned ybits) {
+        float r = x - __builtin_bit_cast(float, ybits);
+        asm("" : "+v"(r));
+        return r;
+    }
+    static __device__ __forceinline__ void split8(const float4 (&src)[2], uint4 (&dst)[3]) {
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        const float w[8] = {src[0].x, src[0].y, src[0].z, src[0].w, src[1].x, src[1].y, src[1].z, src[1].w};
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{w[2 * k], w[2 * k + 1]}), bf16x2_));
+            const float ra = sub_f32(w[2 * k], u0 << 16), rb = sub_f32(w[2 * k + 1], u0 & 0xffff0000u);
+            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{ra, rb}), bf16x2_));
+            const float sa = sub_f32(ra, u1 << 16), sb = sub_f32(rb, u1 & 0xffff0000u);
+            p0[k] = u0; p1[k] = u1;
+            p2[k] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{sa, sb}), bf16x2_));
+        }
+        dst[0] = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+        dst[1] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        dst[2] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+    }
+    // 12 MFMAs of a pair of row blocks: smallest plane products first, the two accumulators alternating
+    static __device__ __forceinline__ void mfma_pair(f32x16& c0, f32x16& c1, const uint4 (&pp)[2][3], const sbf16x8 (&bb)[3]) {
+        constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8, pp[0][TI[q]]), bb[TJ[q]], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8, pp[1][TI[q]]), bb[TJ[q]], c1, 0, 0, 0);
+        }
+    }
+    // one half step in program order: 12 MFMAs, each followed by a share of the loads and of the VALU instructions of two splits
+    template <int NVMEM, int NDS, int SYNC, int I = 0>
+    static __device__ __forceinline__ void pattern() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, SYNC);
+        if constexpr (I < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, SYNC);
+        if constexpr (I >= 8 && I < 8 + NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, SYNC);
+        __builtin_amdgcn_sched_group_barrier(0x002, (I % 3 == 2) ? 8 : 7, SYNC);           // the 88 VALU instructions of two splits over 12 gaps
+        if constexpr (I + 1 < 12) pattern<NVMEM, NDS, SYNC, I + 1>();
+    }
+    __device__ __forceinline__ void start_a() {
+#pragma unroll
+        for (int i = 0; i < STAGES - 1; ++i) lda(a[i], i);
+        DSD_SB();
+    }
+    __device__ __forceinline__ void start_b() {
+        ldb(b[0], 0);
+        split8(a[0][0], pl[0][0]);
+        split8(a[0][1], pl[0][1]);
+        DSD_SB();
+    }
+    template <int I>
+    __device__ __forceinline__ void step(f32x16 (&acc)[NMB], int kc) {
+        lda(a[(I + STAGES - 1) % STAGES], kc + STAGES - 1);
+        ldb(b[(I + 1) & 1], kc + 1);
+        if constexpr (NMB == 4) {
+            split8(a[I % STAGES][2], pl[1][0]);
+            split8(a[I % STAGES][3], pl[1][1]);
+            mfma_pair(acc[0], acc[1], pl[0], b[I & 1]);
+            pattern<2 * NMB, 3, 0>();
+            DSD_SB();
+            split8(a[(I + 1) % STAGES][0], pl[0][0]);
+            split8(a[(I + 1) % STAGES][1], pl[0][1]);
+            mfma_pair(acc[2], acc[3], pl[1], b[I & 1]);
+            pattern<0, 0, 1>();
+        } else {
+            split8(a[(I + 1) % STAGES][0], pl[(I + 1) & 1][0]);
+            split8(a[(I + 1) % STAGES][1], pl[(I + 1) & 1][1]);
+            mfma_pair(acc[0], acc[1], pl[I & 1], b[I & 1]);
+            pattern<2 * NMB, 3, 0>();
+        }
+        DSD_SB();
+    }
+    template <int I, int N>
+    __device__ __forceinline__ void steps(f32x16 (&acc)[NMB], int kc0) {
+        step<I>(acc, kc0 + I);
+        if constexpr (I + 1 < N) steps<I + 1, N>(acc, kc0);
+    }
+    // chunks [BEGIN, END), BEGIN a multiple of the period.  Compile-time bounds: whole periods are ONE basic block each (branches between the
+    // steps let hipcc's block passes move the split of the next fragments out from under the MFMAs), the tail is unrolled by its length.
+    template <int BEGIN, int END>
+    __device__ __forceinline__ void run(f32x16 (&acc)[NMB]) {
+        static_assert(BEGIN % P == 0 && END > BEGIN, "a segment starts on a period");
+        constexpr int kFull = (END - BEGIN) / P, kTail = (END - BEGIN) - kFull * P;
+        if constexpr (kFull > 0)
+            for (int kc0 = BEGIN; kc0 < BEGIN + kFull * P; kc0 += P) steps<0, P>(acc, kc0);
+        if constexpr (kTail > 0) steps<0, kTail>(acc, BEGIN + kFull * P);
+    }
+};
+
+// which pipe a loop instantiation streams its weights through: WF = 0 the bf16 planes (3 stages), 3 / 4 fp32 split in registers (3 / 4 stages)
+template <int WF, int NMB, int MB0, typename BOff>
+struct SplitPipeSel { typedef SplitPipeW<NMB, MB0, WF, BOff> type; };
+template <int NMB, int MB0, typename BOff>
+struct SplitPipeSel<0, NMB, MB0, BOff> { typedef SplitPipeR<NMB, MB0, 3, BOff> type; };
 
 // Cached loads through a buffer descriptor over a WAVE-UNIFORM base (SGPRs) + a 32-bit lane offset: no 64-bit per-lane address lives in
 // VGPRs.  In this kernel the arch-VGPR file is full (three stages of weight planes), and a spilled pointer is a scratch reload = a vector
@@ -159,12 +306,16 @@ __device__ __forceinline__ void sp_store4(su16* plane0, int plane_elems, int off
 
 struct LoopSplitParams {
     LoopParams lp;              // everything k_loop takes (w1p / w2p unused here)
-    const uint4* w1c;           // conv planes, centre-first chunk order: [L][w4][48][mb4][3][lane64]
-    const uint4* w2s;           // out-projection planes:                 [L][w4][16][mb4][3][lane64]
+    const uint4* w1c;           // conv weights, centre-first chunk order: planes [L][w4][48][mb4][3][lane64] (WF = 0) or fp32 [L][w4][48][mb4][2][lane64]
+    const uint4* w2s;           // out-projection weights:                planes [L][w4][16][mb4][3][lane64] (WF = 0) or fp32 [L][w4][16][mb4][2][lane64]
 };
 
-template <int MODE>
+template <int MODE, int WF>
 __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParams ps) {
+    typedef typename SplitPipeSel<WF, 4, 0, SConvB>::type Pipe1;
+    typedef typename SplitPipeSel<WF, 4, 0, STileB>::type Pipe2;
+    typedef typename SplitPipeSel<WF, 2, 2, STileB>::type Pipe2L;
+    constexpr int kSeg0 = Pipe1::P;            // chunks before the neighbour flags are tested (a multiple of the pipe's period)
     const LoopParams& p = ps.lp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     su16* yp = reinterpret_cast<su16*>(smem);               // [3][48][264] y planes; head: scaled skip sum [256][32] fp32
@@ -255,7 +406,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
             LOOP_STAMP(0);
             // (c) weight planes of the conv: requested before anything of this phase exists
             const SConvB bof1{yp + (kHalo + j) * kSpRS + 8 * h, (int)p.dil[l] * kSpRS};
-            SplitPipeR<4, 0, 3, SConvB> pipe1(ps.w1c + ((size_t)l * 4 + w) * (48 * 12 * 64), lane, 48, bof1, kSpYPlane);
+            Pipe1 pipe1(ps.w1c + ((size_t)l * 4 + w) * (48 * Pipe1::kChunkU4), lane, 48, bof1, kSpYPlane);
             pipe1.start_a();
             // (b) own frames of y = x + step_proj (zero at frames >= T) as planes: the lane's 32 channels of frame j
 #pragma unroll
@@ -282,7 +433,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             float4 cpv[4][4];
             pipe1.start_b();
-            pipe1.run(acc, 0, 6);
+            pipe1.template run<0, kSeg0>(acc);
             // (d2) both neighbours have published phase ph?
             if (fv < ph + 1u) {
                 const gu32* f = (const gu32*)(p.flags + tile + (lane ? 1 : -1));
@@ -309,7 +460,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                 }
             }
             DSD_SB();
-            pipe1.run(acc, 6, 12);
+            pipe1.template run<kSeg0, 12>(acc);
             // (e2) halo rows of y as planes: float4 index tid + 256 g = (frame 4 g + tid / 64, channels 4 (tid % 64) ..)
             {
                 const int c = 4 * (tid & 63);
@@ -327,7 +478,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
             }
             __syncthreads();
             LOOP_STAMP(2);
-            pipe1.run(acc, 12, 24);
+            pipe1.template run<12, 24>(acc);
             {
                 const float4* cpl = p.cp + (size_t)l * p.cp_lstride + ((size_t)tile * 4 + w) * (4 * 4 * 64);      // wave-uniform
 #pragma unroll
@@ -336,7 +487,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                     for (int q = 0; q < 4; ++q) cpv[mb][q] = ld16_u(cpl, ((mb * 4 + q) * 64 + lane) * 16);
             }
             DSD_SB();
-            pipe1.run(acc, 24, 48);
+            pipe1.template run<24, 48>(acc);
             float ds_next = 0.f;
             {
                 const bool more = !last || (e + 1 < p.n_evals);
@@ -361,9 +512,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                     }
             };
             LOOP_STAMP(3);
-            const uint4* w2l = ps.w2s + ((size_t)l * 4 + w) * (16 * 12 * 64);
+            const uint4* w2l = ps.w2s + ((size_t)l * 4 + w) * (16 * Pipe2::kChunkU4);
             if (!last) {
-                SplitPipeR<4, 0, 3, STileB> pipe2(w2l, lane, 16, bof2, kSpGPlane);
+                Pipe2 pipe2(w2l, lane, 16, bof2, kSpGPlane);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
@@ -375,13 +526,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                     for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
                 float4 bq[2][4];
                 pipe2.start_b();
-                pipe2.run(acc2, 0, 6);
+                pipe2.template run<0, kSeg0>(acc2);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bq[mb][q] = ld16_u(p.b2raw + (size_t)l * 2 * kC, (ch0 + 32 * mb + 8 * q) * 4);
                 DSD_SB();
-                pipe2.run(acc2, 6, 16);
+                pipe2.template run<kSeg0, 16>(acc2);
                 LOOP_STAMP(5);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
@@ -405,7 +556,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                 publish_finish(ph + 1u);
                 LOOP_STAMP(7);
             } else {
-                SplitPipeR<2, 2, 3, STileB> pipe2(w2l, lane, 16, bof2, kSpGPlane);
+                Pipe2L pipe2(w2l, lane, 16, bof2, kSpGPlane);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
@@ -415,7 +566,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
                 pipe2.start_b();
-                pipe2.run(acc2, 0, 16);
+                pipe2.template run<0, 16>(acc2);
                 dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)

@@ -77,3 +77,36 @@ def test_config2_against_the_fp32_and_the_fp64_oracle_and_rate():
     print(f'row 0 vs an fp64 evaluation of the oracle: split loop {e64_sp:.3e}, fp32 loop {e64_32:.3e}; '
           f'rate: split {mssp:.1f} ms per call = {B * T / mssp * 1e3:.0f} mel-frames/s, fp32 {ms32:.1f} ms = {B * T / ms32 * 1e3:.0f} mel-frames/s')
     assert e64_sp <= 1e-4 and e64_sp <= 2.0 * e64_32 + 1e-6
+
+
+def test_the_weight_stream_variants_agree_bit_for_bit_and_their_rates(monkeypatch):
+    """The loop streams its weights either as three bf16 planes (6 bytes per weight, DSD_SPLIT_W=0) or as fp32 split into the same planes in
+    registers beside the MFMAs (4 bytes, DSD_SPLIT_W=3 / 4: three / four register stages).  Same planes (round to nearest even, exact
+    residuals), same products in the same order per accumulator: the outputs must be IDENTICAL; only the time may differ."""
+    B, T, K = 8, 1024, 100
+    g = torch.Generator().manual_seed(77)
+    cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, generator=g)
+    noise = torch.randn(K, B, 1, 80, T, generator=g)
+    outs, ms = {}, {}
+    for wsrc in ('0', '3', '4'):
+        monkeypatch.setenv('DSD_SPLIT_W', wsrc)
+        gd, cfg, pre = build_hip('lj_ds_beta6', 100)
+        dcond = cond.transpose(1, 2).contiguous().cuda().transpose(1, 2)
+        dx, dn = x_T.cuda(), noise.cuda()
+        eng = gd._engine(dcond)
+        eng.set_split_mode(True)
+        run = lambda: gd.inference(dcond, x_T=dx, noise=dn, K_step=K, pndm_speedup=0)
+        out = run().clone()
+        assert eng.loop_mode() == 1 and eng.split_mode() == 1 and eng.loop_timeouts() == 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        ms[wsrc] = (time.perf_counter() - t0) / 3 * 1e3
+        outs[wsrc] = out.cpu()
+        assert torch.isfinite(outs[wsrc]).all()
+        del gd, eng
+    print('8 x 1024, K = 100, split loop by weight stream: ' + ', '.join(f'DSD_SPLIT_W={k}: {v:.1f} ms = {B * T / v * 1e3:.0f} mel-frames/s' for k, v in ms.items()))
+    assert torch.equal(outs['0'], outs['3']) and torch.equal(outs['0'], outs['4'])

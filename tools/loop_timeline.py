@@ -1,4 +1,5 @@
-"""Developer tool (GPU): phase timeline of the persistent K-step loop from in-kernel s_memtime stamps."""
+"""Developer tool (GPU): phase timeline of the persistent K-step loop from in-kernel s_memtime stamps.
+`--split`: the labelled split-precision loop (k_loop_split; its weight stream by DSD_SPLIT_W) - layer phases only."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,6 +13,10 @@ x = torch.randn(B, 80, T, device=dev, generator=g)
 noise = torch.randn(K, B, 80, T, device=dev, generator=g)
 eng = gd._engine(cond)
 eng.set_loop_mode(1)
+SPLIT = '--split' in sys.argv
+if SPLIT:
+    sys.argv.remove('--split')
+    eng.set_split_mode(True)
 summary = {'phase_cycles': [], 'head_cycles': [], 'mfma_issue_ideal_per_phase': 2048 * 64}
 for phase in (43, 44, 63):
     ts = eng.loop_timeline(x.clone(), noise, K, phase).astype(np.int64)
@@ -19,11 +24,17 @@ for phase in (43, 44, 63):
     names = ['weight prefetch issue, own columns of y, barrier', 'conv chunks 0-29 (centre taps) + flag poll, halo loads / writes, 2 barriers',
              'conv chunks 30-95', 'gate + barrier',
              'out-proj K=256', 'residual transpose, x\'', 'publish (drain, barrier, flag) + skip sum']
+    if SPLIT:
+        names = ['weight prefetch issue, own frames of y as planes, barrier', 'conv chunks 0-11 of 48 (centre taps) + flag poll, halo loads / plane writes, barrier',
+                 'conv chunks 12-47 + conditioner-projection loads', 'gate -> planes + barrier', 'out-proj 16 chunks', 'x\'',
+                 'publish (drain, barrier, flag) + skip sum']
     print(f'phase {phase} (layer {phase % 20}): {ts.shape[0]} workgroups, shader-clock ticks')
     for i, n in enumerate(names):
         print('  %-76s: mean %8.0f  min %8.0f  max %8.0f' % (n, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max()))
     print('  phase total: mean %.0f ; start skew across workgroups %.0f' % ((ts[:, :, 7] - ts[:, :, 0]).mean(), ts[:, :, 0].max() - ts[:, :, 0].min()))
     summary['phase_cycles'].append(float((ts[:, :, 7] - ts[:, :, 0]).mean()))
+    if SPLIT:
+        continue
     hd = ts[:, :, 8:16]
     hn = ['barrier behind the last layer + skip tile (bias, / sqrt(L), stage)', 'skip projection K=256 (2 row blocks / wave) + ReLU tile',
           'final-projection weight prefetch + barrier', 'final projection K=256 (waves 0-2)', 'sampler update: global reads, math, stores (waves 0-2)',
