@@ -188,7 +188,9 @@ def secondary_split(gd, eng, pre, cond, x_T, noise, mel_f32, mel_oracle, args):
         'dtype': 'f32 as 3 exact bf16 planes, 6 plane products per product (i + j <= 2), f32 accumulate; head, sampler and state in f32',
         'metric': BASELINE_METRIC, 'value': B * T / sec, 'unit': 'mel-frames/s', 'ms_per_step': sec * 1e3, 'steps': n,
         'workload': f'the timed step of this line (dsd_prepare + K={K_STEPS} loop + denorm, {B} x {T} frames)',
-        'roofline': {'bound': 'mfma', 'kernel': 'k_loop_split<1>', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent)', 'frac': achieved / peak,
+        'weight_stream': {'0': 'three bf16 planes, 6 bytes per weight', '4': 'fp32, 4 bytes per weight, split into the three planes in registers beside the MFMAs'}.get(
+            os.environ.get('DSD_SPLIT_W', '4'), 'default') + ' (DSD_SPLIT_W; bit-identical results)',
+        'roofline': {'bound': 'mfma', 'kernel': 'k_loop_split<1, %s>' % os.environ.get('DSD_SPLIT_W', '4'), 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent)', 'frac': achieved / peak,
                      'avg_launch_ms': ms_call, 'note': 'executed fp32-equivalent FLOPs (21 053 440 / frame / evaluation) over the whole sampling call (HIP events); '
                                                        'peak = dense bf16 MFMA peak 2500 TFLOP/s / 6 plane products; the head (2 % of the fp32 launch) runs on the fp32 pipe'},
         'parity': {'case': 'the timed batch (all 8 utterances) vs the fp32 oracle; utterance 0 vs an fp64 evaluation of the oracle, both paths', 'tolerance': 1e-4,
@@ -851,7 +853,7 @@ def main_path(args):
             flop = frames * K * F_EVAL_EXEC / launches
             achieved = frames * K * F_EVAL_EXEC / (ms_call * 1e-3) / 1e12
             frames_l = frames / launches
-            kname = 'k_loop_split<1>' if args.split else 'k_loop<1>'
+            kname = 'k_loop_split<1, %s>' % os.environ.get('DSD_SPLIT_W', '4') if args.split else 'k_loop<1>'
             alg_bytes = int(K * (frames * (20 * 2048 + 2 * 320 + 320) + launches * L_LAYERS * 2 * 1024 * 1024 + frames // 32 * L_LAYERS * 2 * 16384) / launches)
             note = (f'one launch = the whole K=100 reverse loop (100 x (20 residual layers + head + sampler update + next input '
                     f'projection)) for a chunk of whole utterances; this batch of {B} x {T} = {launches} launch(es) of on average {frames_l:.0f} frames; '

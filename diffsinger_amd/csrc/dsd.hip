@@ -139,7 +139,7 @@ struct dsd_handle {
     uint4 *w1s = nullptr, *w2s = nullptr;     // bf16 weight planes in 32x32x16 fragment order, [L][4][48|16][4][3][64]
     uint4* w1c = nullptr;                     // the conv planes once more, centre-tap chunks first (the persistent split loop, dsd_loop_split.hpp)
     uint4 *w1f = nullptr, *w2f = nullptr;     // fp32 in 32x32x16 fragment order, [L][4][48|16][4][2][64] (the split loop that splits its weights in registers)
-    int split_w = 4;                          // weight stream of the split loop: 0 = bf16 planes, 3 / 4 = fp32 split in registers, 3 / 4 stages (DSD_SPLIT_W)
+    int split_w = 4;                          // weight stream of the split loop: 4 = fp32, split into the planes in registers (four stages); 0 = bf16 planes (DSD_SPLIT_W)
 };
 
 // After a reported timeout the handle runs this many sampling loops on the hipGraph path before it tries the persistent loop again: a
@@ -247,7 +247,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     h->nk_in = (cfg->mel_bins + 7) / 8;
     if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);     // the same choice as dsd_set_loop_mode, for an unmodified host
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
-    if (const char* ev = std::getenv("DSD_SPLIT_W")) { const int v = std::atoi(ev); if (v == 0 || v == 3 || v == 4) h->split_w = v; }
+    if (const char* ev = std::getenv("DSD_SPLIT_W")) { const int v = std::atoi(ev); if (v == 0 || v == 4) h->split_w = v; }
     if (const char* ev = std::getenv("DSD_RS")) h->rs_req = std::atoi(ev);                   // the same choice as dsd_set_rs_split
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
@@ -1005,7 +1005,6 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
 #define DSD_LAUNCH_SPLIT(WF) do { if (kind == 0) hipLaunchKernelGGL((k_loop_split<HEAD_DDPM, WF>), grid, block, kLoopSplitLdsBytes, s, q); \
                                   else hipLaunchKernelGGL((k_loop_split<HEAD_PLMS, WF>), grid, block, kLoopSplitLdsBytes, s, q); } while (0)
             if (h->split_w == 4) DSD_LAUNCH_SPLIT(4);
-            else if (h->split_w == 3) DSD_LAUNCH_SPLIT(3);
             else DSD_LAUNCH_SPLIT(0);
 #undef DSD_LAUNCH_SPLIT
         } else if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
@@ -1180,7 +1179,7 @@ static void split_kernel_attrs() {
 #define DSD_SPLIT_ATTR(WF) do { \
             (void)hipFuncSetAttribute((const void*)k_loop_split<HEAD_DDPM, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopSplitLdsBytes); \
             (void)hipFuncSetAttribute((const void*)k_loop_split<HEAD_PLMS, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopSplitLdsBytes); } while (0)
-        DSD_SPLIT_ATTR(0); DSD_SPLIT_ATTR(3); DSD_SPLIT_ATTR(4);
+        DSD_SPLIT_ATTR(0); DSD_SPLIT_ATTR(4);
 #undef DSD_SPLIT_ATTR
     }
 }

@@ -12,8 +12,12 @@
 // head (skip projection, final projection, sampler update, next input projection) is the fp32 code of k_loop verbatim.  What changes:
 //   * y = x + step and the gate tile are written to LDS as three bf16 planes, frame-major [plane][frame][264] (a lane's 4 consecutive
 //     channels of a frame = one 8-byte write per plane; a fragment = 8 consecutive channels = one ds_read_b128 per plane);
-//   * the weights stream as bf16 planes in 32x32x16 fragment order [L][wave 4][chunk][row block 4][plane 3][lane 64] x 8 bf16 (6 bytes per
-//     weight instead of 4, through a pipe that is 2.7 x faster: three register stages of 12 KiB per wave);
+//   * the weights stream in 32x32x16 fragment order, in one of two forms (template parameter WF, DSD_SPLIT_W): as FP32, 4 bytes per
+//     weight, split into the three planes IN REGISTERS beside the MFMAs (SplitPipeW, four register stages of 8 KiB per wave; WF = 4, the
+//     default), or as the three bf16 planes themselves, 6 bytes per weight and no arithmetic (SplitPipeR, three stages of 12 KiB; WF = 0).
+//     Same planes, same products in the same order per accumulator: the two agree bit for bit.  Neither reaches the matrix pipe's rate -
+//     the plane stream waits for bytes (~54-64 cycles per MFMA instead of 32), the register split for the vector ALU (88 instructions
+//     per 12 MFMAs: 47 cycles per MFMA); DESIGN.md section 4b has the timelines;
 //   * K order of the dilated conv: the 16 centre-tap chunks first (they need no halo), then the (-dil, +dil) pairs - the loop fetches its
 //     neighbours' frames under the centre taps exactly like k_loop (a second packing of the conv planes, k_pack_split with centre_first).
 #pragma once
@@ -134,12 +138,12 @@ struct SplitPipeR {
 
 // The weights as FP32 on the wire, split into the three planes in registers beside the MFMAs (k_pack_split_f32's layout: 8 KiB per chunk
 // and wave, two 16-byte loads per row block and lane).  The plane stream is 6 bytes per weight and every CU of an XCD walks the whole layer
-// per evaluation (the matrix pipe waits for bytes, busy 0.42); this form moves 4.  The split is sp_split3's arithmetic
-// on pairs: v_cvt_pk_bf16_f32 (round to nearest even), the planes' fp32 values back by shift / mask, exact subtractions - 36 VALU
-// instructions per 8 weights, bit-identical planes, and per accumulator the same products in the same order as SplitPipeR: the two loops
-// agree bit for bit (tests/test_gpu_split_loop.py).  Row blocks go in PAIRS: the MFMAs of one pair (two accumulators alternating, 12
-// MFMAs) cover the split of the next pair's fragments; two sets of plane registers (48 VGPRs) beside STAGES x NMB x 8 of fp32 stages.
-// Period of the register rotation: 6 steps for 3 stages, 4 for 4.
+// per evaluation (the matrix pipe waits for bytes, busy 0.42); this form moves 4 and pays in vector-ALU
+// instructions.  The split is sp_split3's arithmetic on pairs: v_cvt_pk_bf16_f32 (round to nearest even), the planes' fp32 values back by
+// shift / mask, exact subtractions - 44 VALU instructions per 8 weights, bit-identical planes, and per accumulator the same products in
+// the same order as SplitPipeR: the two loops agree bit for bit (tests/test_gpu_split_loop.py).  Row blocks go in PAIRS: the MFMAs of one
+// pair (two accumulators alternating, 12 MFMAs) cover the split of the next pair's fragments; two sets of plane registers (48 VGPRs)
+// beside STAGES x NMB x 8 of fp32 stages.  Period of the register rotation: 6 steps for 3 stages, 4 for 4 (the loop instantiates 4).
 template <int NMB, int MB0, int STAGES, typename BOff>
 struct SplitPipeW {
     static_assert(STAGES == 3 || STAGES == 4, "3 stages rotate with period 6, 4 with period 4");
@@ -177,28 +181,36 @@ struct SplitPipeW {
 #pragma unroll
         for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(bp + p * bplane));
     }
-    // eight fp32 weights -> three plane fragments (sp_split3 on pairs).  The exact residuals stay single v_sub_f32: an empty asm on each
-    // result keeps hipcc from packing pairs of them into v_pk_add_f32, which beside MFMAs costs about three issue slots for two
-    // subtractions (MI355X_MICROARCH.md, "price of one filler beside MFMAs") - and issue slots are what bounds this pipe.
-    static __device__ __forceinline__ float sub_f32(float x, unsigned ybits) {
-        float r = x - __builtin_bit_cast(float, ybits);
-        asm("" : "+v"(r));
-        return r;
+    // eight fp32 weights -> three plane fragments (sp_split3 on pairs), STAGE by stage over the four pairs: 4 conversions, 8 plane values
+    // back as fp32 (shift / mask), 8 exact residuals, and again.  Two things the empty asm between the stages buys, both in issue slots -
+    // which are what bounds this pipe: (i) hipcc does not pack pairs of subtractions into v_pk_add_f32, which beside MFMAs costs about
+    // three slots for two subtractions (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); (ii) a v_cvt_pk_bf16_f32 never directly
+    // follows the v_sub_f32 that feeds it - that adjacency costs an s_nop, and a chain-by-chain order has eight of them per fragment.
+    static __device__ __forceinline__ void tie8(float (&r)[8]) {
+        asm("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
     }
-    static __device__ __forceinline__ void split8(const float4 (&src)[2], uint4 (&dst)[3]) {
+    static __device__ __forceinline__ void level(float (&r)[8], unsigned (&pk)[4]) {
         typedef float f32x2_ __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-        const float w[8] = {src[0].x, src[0].y, src[0].z, src[0].w, src[1].x, src[1].y, src[1].z, src[1].w};
-        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk[k] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{r[2 * k], r[2 * k + 1]}), bf16x2_));
+    }
+    static __device__ __forceinline__ void residual(float (&r)[8], const unsigned (&pk)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{w[2 * k], w[2 * k + 1]}), bf16x2_));
-            const float ra = sub_f32(w[2 * k], u0 << 16), rb = sub_f32(w[2 * k + 1], u0 & 0xffff0000u);
-            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{ra, rb}), bf16x2_));
-            const float sa = sub_f32(ra, u1 << 16), sb = sub_f32(rb, u1 & 0xffff0000u);
-            p0[k] = u0; p1[k] = u1;
-            p2[k] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{sa, sb}), bf16x2_));
+            r[2 * k] = r[2 * k] - __builtin_bit_cast(float, pk[k] << 16);
+            r[2 * k + 1] = r[2 * k + 1] - __builtin_bit_cast(float, pk[k] & 0xffff0000u);
         }
+        tie8(r);
+    }
+    static __device__ __forceinline__ void split8(const float4 (&src)[2], uint4 (&dst)[3]) {
+        float r[8] = {src[0].x, src[0].y, src[0].z, src[0].w, src[1].x, src[1].y, src[1].z, src[1].w};
+        unsigned p0[4], p1[4], p2[4];
+        level(r, p0);
+        residual(r, p0);
+        level(r, p1);
+        residual(r, p1);
+        level(r, p2);
         dst[0] = make_uint4(p0[0], p0[1], p0[2], p0[3]);
         dst[1] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
         dst[2] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
