@@ -42,7 +42,12 @@ __device__ __forceinline__ void sp_split3(float x, su16& a, su16& b, su16& c) {
 // -> bf16 planes in 32x32x16 fragment order [w][chunk16 = ntap * g + tap][mb 4][plane 3][lane (i, h')][e 8], channel 16 g + 8 h' + e.
 // centre_first (ntap == 3, the persistent split loop dsd_loop_split.hpp): destination chunk order = the ng centre-tap chunks, then the (-dil, +dil)
 // pairs of every group - like conv_chunk() for the fp32 stream - instead of "taps of one group consecutive".
-__global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ dst, int nw, int ng, int ntap, int centre_first) {
+// wave_stride / chunk_stride (in bf16 elements; 0 = the dense [w][chunk16] order above): the persistent loop keeps a layer's planes in
+// CONSUMPTION order [chunk16 of W1 then of W2][w][mb][plane][lane] - a chunk of all four waves is 48 KiB of consecutive lines, which is
+// what lets the workgroups of an XCD touch the stream ahead of themselves line by line (dsd_loop_split.hpp, L2 touch).
+__global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ dst, int nw, int ng, int ntap, int centre_first,
+                             long long wave_stride, long long chunk_stride) {
+    const size_t ws = wave_stride ? (size_t)wave_stride : (size_t)ng * ntap * 6144, cs = chunk_stride ? (size_t)chunk_stride : 6144;
     const size_t n = (size_t)nw * ng * ntap * 4 * 64 * 8;              // (w, chunk16, mb, lane, e)
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = idx & 7, lane = (idx >> 3) & 63;
@@ -61,7 +66,7 @@ __global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ d
         const float v = src[((((size_t)w * (2 * ng * ntap) + c8) * 4 + mb) * 64 + lane_src) * 4 + s];
         su16 p0, p1, p2;
         sp_split3(v, p0, p1, p2);
-        const size_t o = ((((size_t)w * (ng * ntap) + c16) * 4 + mb) * 3) * 512 + (size_t)lane * 8 + e;
+        const size_t o = (size_t)w * ws + (size_t)c16 * cs + (size_t)(mb * 3) * 512 + (size_t)lane * 8 + e;
         dst[o] = p0; dst[o + 512] = p1; dst[o + 1024] = p2;
     }
 }

@@ -5,6 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 B, T, K = 8, 1024, 6
+PHASES = None
+for a in list(sys.argv[1:]):
+    if a.startswith('--k='):
+        K = int(a[4:]); sys.argv.remove(a)
+    elif a.startswith('--phases='):
+        PHASES = tuple(int(v) for v in a[9:].split(',')); sys.argv.remove(a)
 dev = torch.device('cuda', 0)
 gd, pre = bench.build_model(dev)
 g = torch.Generator(device=dev).manual_seed(1)
@@ -18,7 +24,7 @@ if SPLIT:
     sys.argv.remove('--split')
     eng.set_split_mode(True)
 summary = {'phase_cycles': [], 'head_cycles': [], 'mfma_issue_ideal_per_phase': 2048 * 64}
-for phase in (43, 44, 63):
+for phase in PHASES or ((43, 44, 63) if not SPLIT else (43, 44, 63, 83)):
     ts = eng.loop_timeline(x.clone(), noise, K, phase).astype(np.int64)
     d = np.diff(ts[:, :, :8], axis=2)
     names = ['weight prefetch issue, own columns of y, barrier', 'conv chunks 0-29 (centre taps) + flag poll, halo loads / writes, 2 barriers',
@@ -34,6 +40,14 @@ for phase in (43, 44, 63):
     print('  phase total: mean %.0f ; start skew across workgroups %.0f' % ((ts[:, :, 7] - ts[:, :, 0]).mean(), ts[:, :, 0].max() - ts[:, :, 0].min()))
     summary['phase_cycles'].append(float((ts[:, :, 7] - ts[:, :, 0]).mean()))
     if SPLIT:
+        # slots 8 / 9 and 10 / 11: (s_memtime, s_memrealtime at 100 MHz) at this phase and one evaluation (20 layers + a head) later
+        d_clk, d_ref = (ts[:, :, 10] - ts[:, :, 8]).astype(np.float64), (ts[:, :, 11] - ts[:, :, 9]).astype(np.float64)
+        ok = d_ref > 0
+        if ok.any():
+            ghz = d_clk[ok] / d_ref[ok] * 0.1
+            print('  shader clock over the next evaluation: %.3f GHz (min %.3f, max %.3f); the evaluation: %.0f ticks = %.1f us'
+                  % (ghz.mean(), ghz.min(), ghz.max(), d_clk[ok].mean(), d_ref[ok].mean() * 0.01))
+            summary.setdefault('shader_clock_ghz', []).append(float(ghz.mean()))
         continue
     hd = ts[:, :, 8:16]
     hn = ['barrier behind the last layer + skip tile (bias, / sqrt(L), stage)', 'skip projection K=256 (2 row blocks / wave) + ReLU tile',
