@@ -27,7 +27,8 @@
 namespace dsd {
 
 constexpr int kSpConvCentre = 16;           // centre-tap chunks (16 channels each) of the dilated conv
-constexpr int kLoopSplitLdsBytes = (3 * kSpYPlane + 3 * kSpGPlane) * 2 + (kMPad * 32 + 2 * kC) * (int)sizeof(float);
+constexpr int kLoopTouchLds = 1024;         // 256 bytes per wave at the START of the LDS: where the L2 touches land (never read)
+constexpr int kLoopSplitLdsBytes = kLoopTouchLds + (3 * kSpYPlane + 3 * kSpGPlane) * 2 + (kMPad * 32 + 2 * kC) * (int)sizeof(float);
 static_assert(3 * kSpYPlane * 2 >= kC * 32 * 4 && 3 * kSpGPlane * 2 >= kC * 32 * 4, "the head reuses the plane regions as fp32 [256][32] tiles");
 
 // B functors over the bf16 plane tiles (plane 0; plane pl at + pl * bplane elements)
@@ -46,24 +47,60 @@ struct STileB {
     __device__ __forceinline__ const su16* operator()(int it, int u) const { return at(6 * it + u); }
 };
 
+// L2 touch of the weight stream.  Every CU of an XCD walks the same 3.1 MB of planes per layer in near lock step, so what is in flight towards
+// the XCD's L2 is ONE CU's register window (96 KiB) - the other 31 CUs ask for the same lines - and at ~2 us of miss latency that is what
+// bounds the plane stream (the time of a layer phase does not move with the shader clock).  With the stream in
+// consumption order a chunk of all four waves is 384 consecutive lines; the 128 waves of the XCD's 32 workgroups take turns fetching 64 of
+// them each (one dword per line, `buffer_load_dword ... lds` into a 256-byte scratch per wave: no destination register to keep alive),
+// `ahead` chunks in front of the chunk being multiplied: the window towards the L2 becomes ahead x 48 KiB for 6 instructions per chunk
+// and XCD.  The instruction is invisible to hipcc's vmcnt bookkeeping, which only makes its waits stricter (an unknown younger load).
+// Active when the launch has exactly 32 workgroups per XCD (the turn is a 7-bit counter) and ahead > 0.
+struct L2Touch {
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    i32x4_ rs;                   // raw buffer over all layers' stream
+    unsigned q;                  // 4 * workgroup-in-XCD + wave: whose turn it is goes by (q - instructions-per-chunk * chunk) mod 128
+    int dis;                     // 0, or 128: never this wave's turn
+    unsigned ahead, gtot;        // chunks; chunks in the whole stream (64 per layer)
+    unsigned lds, lane128;       // LDS byte address of this wave's scratch; lane * 128
+    __device__ __forceinline__ void issue(unsigned soff) const {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"                                  // "m0 is a reserved register": hipcc keeps nothing in it across statements
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(lds), "v"(lane128), "s"(rs), "s"(soff) : "m0");
+#pragma clang diagnostic pop
+    }
+};
+
 // Operand pipeline of the split contractions with run(begin, end) like GemmPipe: STAGES register stages of the weight planes (chunk
 // kc + STAGES - 1 requested while chunk kc is multiplied), B planes one chunk ahead, loads interleaved behind the first MFMAs of a step.
 template <int NMB, int MB0, int STAGES, typename BOff>
 struct SplitPipeR {
     static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
     static constexpr int P = 6;
-    static constexpr int kChunkU4 = 12 * 64;          // uint4 per chunk and wave
+    static constexpr int kChunkBytes = 4 * 12288;     // consumption order: a chunk of all four waves is 48 KiB of consecutive lines
+    static constexpr int kTouchPer = kChunkBytes / 8192;
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned aoff;
     int n;
     BOff bof;
     int bplane;
+    L2Touch tc;
+    unsigned gq;                 // index of this pipe's chunk 0 in the stream of all layers' chunks (64 per layer) + the touch's lead
     uint4 a[STAGES][NMB][3];
     sbf16x8 b[2][3];
 
-    __device__ __forceinline__ SplitPipeR(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_)
+    static __device__ __forceinline__ const uint4* wbase(const uint4* p, int l, int w, int) { return p + ((size_t)l * (64 * 4) + w) * 768; }
+    __device__ __forceinline__ SplitPipeR(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, const L2Touch& tc_, unsigned gbase_)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u), n(n_), bof(bof_),
-          bplane(bplane_) {}
+          bplane(bplane_), tc(tc_), gq(gbase_ + tc_.ahead) {}
+    // L2 touch (see L2Touch): wave q of the XCD fetches 64 lines of the chunk `ahead` steps in front of everybody, when it is its turn
+    __device__ __forceinline__ void touch(int kc) {
+        unsigned g = gq + (unsigned)kc;
+        const int t = (int)((tc.q - (unsigned)kTouchPer * g) & 127u) | tc.dis;
+        if (t < kTouchPer) {
+            if (g >= tc.gtot) g -= tc.gtot;                                  // kTouchPer * gtot is a multiple of 128: the turn does not move
+            tc.issue(g * (unsigned)kChunkBytes + (unsigned)t * 8192u);
+        }
+    }
     __device__ __forceinline__ void lda(uint4 (&dst)[NMB][3], int kc) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const int kcc = (kc < n) ? kc : n - 1;                             // prefetches past the end re-read the last chunk
@@ -71,7 +108,7 @@ struct SplitPipeR {
         for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kcc * 12288 + ((MB0 + mb) * 3 + pl) * 1024, 0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kcc * kChunkBytes + ((MB0 + mb) * 3 + pl) * 1024, 0);
                 dst[mb][pl] = make_uint4(v.x, v.y, v.z, v.w);
             }
     }
@@ -104,6 +141,7 @@ struct SplitPipeR {
     }
     template <int I>
     __device__ __forceinline__ void step(f32x16 (&acc)[NMB], int it) {
+        touch(6 * it + I);
         lda(a[(I + STAGES - 1) % STAGES], 6 * it + I + STAGES - 1);
         ldb(b[(I + 1) & 1], it, I + 1);
         constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // smallest plane products first
@@ -159,7 +197,8 @@ struct SplitPipeW {
     uint4 pl[2][2][3];           // [set][row block of the pair][plane]
     sbf16x8 b[2][3];
 
-    __device__ __forceinline__ SplitPipeW(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_)
+    static __device__ __forceinline__ const uint4* wbase(const uint4* p, int l, int w, int nchunks) { return p + ((size_t)l * 4 + w) * nchunks * kChunkU4; }
+    __device__ __forceinline__ SplitPipeW(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, const L2Touch&, unsigned)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u),
           aoff_hi((unsigned)lane * 16u + 4096u), n(n_), bof(bof_), bplane(bplane_) {
         asm volatile("" : "+v"(aoff_hi));                                   // keep it a register: folded back, every load would need its own scalar add
@@ -283,11 +322,133 @@ struct SplitPipeW {
     }
 };
 
-// which pipe a loop instantiation streams its weights through: WF = 0 the bf16 planes (3 stages), 3 / 4 fp32 split in registers (3 / 4 stages)
+// HYBRID stream: row blocks 0, 1 of a wave as planes (6 bytes per weight, no arithmetic), row blocks 2, 3 as fp32 split in registers (4
+// bytes, 44 VALU instructions per fragment) - 5 bytes per weight on the wire and 3.7 VALU instructions per MFMA.  The plane stream is
+// bound by bytes (48 KiB per chunk and CU through a 64 B / clk pipe = the 768 cycles the MFMAs take, before any inefficiency), the
+// register split by the vector ALU (7.3 per MFMA); half of each stays under both walls.  A (chunk, wave) block is 10 KiB:
+// [mb0 planes 3 KiB][mb1 planes 3 KiB][mb2 fp32 2 KiB][mb3 fp32 2 KiB], blocks in consumption order [chunk][wave] like the plane stream (a
+// chunk = 40 KiB = 320 lines = five L2-touch instructions).  Step kc: the 12 MFMAs of rows 0, 1 (planes straight from the stage registers)
+// cover the split of (kc + 1, mb2), the 12 MFMAs of rows 2, 3 the split of (kc + 1, mb3); two sets of plane registers for rows 2, 3.
+// Same planes, same products, same order per accumulator as the other two streams: bit-identical results.
+template <int NMB, int MB0, typename BOff>
+struct SplitPipeH {
+    static_assert((NMB == 4 && MB0 == 0) || (NMB == 2 && MB0 == 2), "all four row blocks, or the two fp32 ones (the last layer's skip half)");
+    typedef SplitPipeW<4, 0, 4, BOff> SW;            // split8 / mfma_pair
+    static constexpr int P = 6, S = 3;
+    static constexpr int kBlockBytes = 10240, kChunkBytes = 4 * kBlockBytes, kTouchPer = kChunkBytes / 8192;
+    static constexpr int NPL = (NMB == 4) ? 2 : 0;     // row blocks that arrive as planes
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned aoff;
+    int n;
+    BOff bof;
+    int bplane;
+    L2Touch tc;
+    unsigned gq;                 // global index of this pipe's chunk 0 + the touch's lead
+    uint4 ap[S][NPL ? NPL : 1][3];
+    float4 af[S][2][2];
+    uint4 pl[2][2][3];           // [set][row block 2 / 3][plane]
+    sbf16x8 b[2][3];
+
+    static __device__ __forceinline__ const uint4* wbase(const uint4* p, int l, int w, int) { return p + ((size_t)l * (64 * 4) + w) * (kBlockBytes / 16); }
+    __device__ __forceinline__ SplitPipeH(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, const L2Touch& tc_, unsigned gbase_)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u), n(n_), bof(bof_),
+          bplane(bplane_), tc(tc_), gq(gbase_ + tc_.ahead) {}
+    __device__ __forceinline__ void touch(int kc) {
+        unsigned g = gq + (unsigned)kc;
+        const int t = (int)((tc.q - (unsigned)kTouchPer * g) & 127u) | tc.dis;
+        if (t < kTouchPer) {
+            if (g >= tc.gtot) g -= tc.gtot;
+            tc.issue(g * (unsigned)kChunkBytes + (unsigned)t * 8192u);
+        }
+    }
+    template <int st>
+    __device__ __forceinline__ void lda(int kc) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const int kcc = (kc < n) ? kc : n - 1;
+#pragma unroll
+        for (int mb = 0; mb < NPL; ++mb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kcc * kChunkBytes + (mb * 3 + p) * 1024, 0);
+                ap[st][mb][p] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const f32x4_ v = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kcc * kChunkBytes + 6144 + (mb * 2 + hf) * 1024, 0));
+                af[st][mb][hf] = make_float4(v.x, v.y, v.z, v.w);
+            }
+    }
+    __device__ __forceinline__ void ldb(sbf16x8 (&dst)[3], int kc) {
+        const su16* bp = bof.at(kc);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(bp + p * bplane));
+    }
+    // 12 MFMAs, each followed by a share of NVMEM loads, NDS LDS reads and NVALU vector instructions (44 = one split, 88 = two)
+    template <int NVMEM, int NDS, int NVALU, int SYNC, int I = 0>
+    static __device__ __forceinline__ void pattern() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, SYNC);
+        if constexpr (I < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, SYNC);
+        if constexpr (I >= 12 - NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, SYNC);
+        __builtin_amdgcn_sched_group_barrier(0x002, (NVALU * (I + 1)) / 12 - (NVALU * I) / 12, SYNC);
+        if constexpr (I + 1 < 12) pattern<NVMEM, NDS, NVALU, SYNC, I + 1>();
+    }
+    __device__ __forceinline__ void start_a() {
+        lda<0>(0);
+        lda<1>(1);
+        DSD_SB();
+    }
+    __device__ __forceinline__ void start_b() {
+        ldb(b[0], 0);
+        SW::split8(af[0][0], pl[0][0]);
+        SW::split8(af[0][1], pl[0][1]);
+        DSD_SB();
+    }
+    template <int I>
+    __device__ __forceinline__ void step(f32x16 (&acc)[NMB], int kc) {
+        touch(kc);
+        lda<(I + S - 1) % S>(kc + S - 1);
+        ldb(b[(I + 1) & 1], kc + 1);
+        if constexpr (NMB == 4) {
+            SW::split8(af[(I + 1) % S][0], pl[(I + 1) & 1][0]);
+            SW::mfma_pair(acc[0], acc[1], ap[I % S], b[I & 1]);
+            pattern<10, 3, 44, 0>();
+            DSD_SB();
+            SW::split8(af[(I + 1) % S][1], pl[(I + 1) & 1][1]);
+            SW::mfma_pair(acc[2], acc[3], pl[I & 1], b[I & 1]);
+            pattern<0, 0, 44, 1>();
+        } else {
+            SW::split8(af[(I + 1) % S][0], pl[(I + 1) & 1][0]);
+            SW::split8(af[(I + 1) % S][1], pl[(I + 1) & 1][1]);
+            SW::mfma_pair(acc[0], acc[1], pl[I & 1], b[I & 1]);
+            pattern<4, 3, 88, 0>();
+        }
+        DSD_SB();
+    }
+    template <int I, int N>
+    __device__ __forceinline__ void steps(f32x16 (&acc)[NMB], int kc0) {
+        step<I>(acc, kc0 + I);
+        if constexpr (I + 1 < N) steps<I + 1, N>(acc, kc0);
+    }
+    template <int BEGIN, int END>
+    __device__ __forceinline__ void run(f32x16 (&acc)[NMB]) {
+        static_assert(BEGIN % P == 0 && END > BEGIN, "a segment starts on a period");
+        constexpr int kFull = (END - BEGIN) / P, kTail = (END - BEGIN) - kFull * P;
+        if constexpr (kFull > 0)
+            for (int kc0 = BEGIN; kc0 < BEGIN + kFull * P; kc0 += P) steps<0, P>(acc, kc0);
+        if constexpr (kTail > 0) steps<0, kTail>(acc, BEGIN + kFull * P);
+    }
+};
+
+// which pipe a loop instantiation streams its weights through: WF = 0 the bf16 planes (3 stages), 4 fp32 split in registers (4 stages), 5 the hybrid
 template <int WF, int NMB, int MB0, typename BOff>
 struct SplitPipeSel { typedef SplitPipeW<NMB, MB0, WF, BOff> type; };
 template <int NMB, int MB0, typename BOff>
 struct SplitPipeSel<0, NMB, MB0, BOff> { typedef SplitPipeR<NMB, MB0, 3, BOff> type; };
+template <int NMB, int MB0, typename BOff>
+struct SplitPipeSel<5, NMB, MB0, BOff> { typedef SplitPipeH<NMB, MB0, BOff> type; };
 
 // Cached loads through a buffer descriptor over a WAVE-UNIFORM base (SGPRs) + a 32-bit lane offset: no 64-bit per-lane address lives in
 // VGPRs.  In this kernel the arch-VGPR file is full (three stages of weight planes), and a spilled pointer is a scratch reload = a vector
@@ -318,8 +479,11 @@ __device__ __forceinline__ void sp_store4(su16* plane0, int plane_elems, int off
 
 struct LoopSplitParams {
     LoopParams lp;              // everything k_loop takes (w1p / w2p unused here)
-    const uint4* w1c;           // conv weights, centre-first chunk order: planes [L][w4][48][mb4][3][lane64] (WF = 0) or fp32 [L][w4][48][mb4][2][lane64]
-    const uint4* w2s;           // out-projection weights:                planes [L][w4][16][mb4][3][lane64] (WF = 0) or fp32 [L][w4][16][mb4][2][lane64]
+    const uint4* w1c;           // conv weights, centre-first chunk order: fp32 [L][w4][48][mb4][2][lane64] (WF = 4), or (WF = 0 / 5) ALL weights of the loop
+                                // in consumption order [L][64 = 48 conv + 16 out-projection chunks][w4][12 KiB of planes / 10 KiB hybrid]
+    const uint4* w2s;           // out-projection weights: fp32 [L][w4][16][mb4][2][lane64] (WF = 4), or (WF = 0 / 5) w1c + 48 chunks
+    unsigned wl_bytes;          // WF = 0 / 5: bytes of that buffer (the L2 touch's buffer bound)
+    int touch_ahead;            // WF = 0 / 5: chunks the L2 touch runs in front (0 = off)
 };
 
 template <int MODE, int WF>
@@ -330,7 +494,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
     constexpr int kSeg0 = Pipe1::P;            // chunks before the neighbour flags are tested (a multiple of the pipe's period)
     const LoopParams& p = ps.lp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    su16* yp = reinterpret_cast<su16*>(smem);               // [3][48][264] y planes; head: scaled skip sum [256][32] fp32
+    su16* yp = reinterpret_cast<su16*>(smem + kLoopTouchLds / 4);   // [3][48][264] y planes; head: scaled skip sum [256][32] fp32
     su16* gp = yp + 3 * kSpYPlane;                          // [3][32][264] gate planes; head: relu(skip_projection) [256][32] fp32
     float* xt = reinterpret_cast<float*>(gp + 3 * kSpGPlane);   // [96][32] spec tile of the in-projection
     float* dsbuf = xt + kMPad * 32;                         // [2][256]
@@ -344,6 +508,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
         const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
         const int q = p.n_tiles >> 3, r = p.n_tiles & 7;
         tl = xcd * q + min(xcd, r) + k;
+    }
+    L2Touch tc;
+    {
+        const unsigned long long wb = (unsigned long long)ps.w1c;
+        const bool en = (WF == 0 || WF == 5) && ps.touch_ahead > 0 && (p.n_tiles & 7) == 0 && (p.n_tiles >> 3) == 32;
+        tc.rs = L2Touch::i32x4_{(int)(unsigned)wb, (int)(unsigned)((wb >> 32) & 0xffffu), (int)ps.wl_bytes, 0x00020000};
+        tc.ahead = (unsigned)ps.touch_ahead;
+        tc.q = (unsigned)(4 * (int)(blockIdx.x >> 3) + w);
+        tc.dis = en ? 0 : 128;
+        tc.gtot = (unsigned)p.L * 64u;
+        tc.lds = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float*)smem + (unsigned)w * 256u;
+        tc.lane128 = (unsigned)lane * 128u;
     }
     const int tile = p.tile_base + tl;
     const int b = tile / p.ntile32, tn = tile - b * p.ntile32, t0 = tn * 32;
@@ -416,9 +592,15 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
             const bool last = (l == p.L - 1);
             const float* dsl = dsbuf + (ph & 1) * kC;
             LOOP_STAMP(0);
+            // the shader clock under THIS instruction mix: s_memtime beside the constant 100 MHz s_memrealtime, one evaluation apart
+            if (stamp && lane == 0 && (ph == (unsigned)p.dbg_phase || ph == (unsigned)p.dbg_phase + (unsigned)p.L)) {
+                unsigned long long* d = p.dbg + ((size_t)tl * 4 + w) * 16 + (ph == (unsigned)p.dbg_phase ? 8 : 10);
+                d[0] = __builtin_amdgcn_s_memtime();
+                d[1] = __builtin_amdgcn_s_memrealtime();
+            }
             // (c) weight planes of the conv: requested before anything of this phase exists
             const SConvB bof1{yp + (kHalo + j) * kSpRS + 8 * h, (int)p.dil[l] * kSpRS};
-            Pipe1 pipe1(ps.w1c + ((size_t)l * 4 + w) * (48 * Pipe1::kChunkU4), lane, 48, bof1, kSpYPlane);
+            Pipe1 pipe1(Pipe1::wbase(ps.w1c, l, w, 48), lane, 48, bof1, kSpYPlane, tc, (unsigned)l * 64u);
             pipe1.start_a();
             // (b) own frames of y = x + step_proj (zero at frames >= T) as planes: the lane's 32 channels of frame j
 #pragma unroll
@@ -524,9 +706,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                     }
             };
             LOOP_STAMP(3);
-            const uint4* w2l = ps.w2s + ((size_t)l * 4 + w) * (16 * Pipe2::kChunkU4);
+            const uint4* w2l = Pipe2::wbase(ps.w2s, l, w, 16);
             if (!last) {
-                Pipe2 pipe2(w2l, lane, 16, bof2, kSpGPlane);
+                Pipe2 pipe2(w2l, lane, 16, bof2, kSpGPlane, tc, (unsigned)l * 64u + 48u);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
@@ -568,7 +750,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                 publish_finish(ph + 1u);
                 LOOP_STAMP(7);
             } else {
-                Pipe2L pipe2(w2l, lane, 16, bof2, kSpGPlane);
+                Pipe2L pipe2(w2l, lane, 16, bof2, kSpGPlane, tc, (unsigned)l * 64u + 48u);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
