@@ -322,133 +322,11 @@ struct SplitPipeW {
     }
 };
 
-// HYBRID stream: row blocks 0, 1 of a wave as planes (6 bytes per weight, no arithmetic), row blocks 2, 3 as fp32 split in registers (4
-// bytes, 44 VALU instructions per fragment) - 5 bytes per weight on the wire and 3.7 VALU instructions per MFMA.  The plane stream is
-// bound by bytes (48 KiB per chunk and CU through a 64 B / clk pipe = the 768 cycles the MFMAs take, before any inefficiency), the
-// register split by the vector ALU (7.3 per MFMA); half of each stays under both walls.  A (chunk, wave) block is 10 KiB:
-// [mb0 planes 3 KiB][mb1 planes 3 KiB][mb2 fp32 2 KiB][mb3 fp32 2 KiB], blocks in consumption order [chunk][wave] like the plane stream (a
-// chunk = 40 KiB = 320 lines = five L2-touch instructions).  Step kc: the 12 MFMAs of rows 0, 1 (planes straight from the stage registers)
-// cover the split of (kc + 1, mb2), the 12 MFMAs of rows 2, 3 the split of (kc + 1, mb3); two sets of plane registers for rows 2, 3.
-// Same planes, same products, same order per accumulator as the other two streams: bit-identical results.
-template <int NMB, int MB0, typename BOff>
-struct SplitPipeH {
-    static_assert((NMB == 4 && MB0 == 0) || (NMB == 2 && MB0 == 2), "all four row blocks, or the two fp32 ones (the last layer's skip half)");
-    typedef SplitPipeW<4, 0, 4, BOff> SW;            // split8 / mfma_pair
-    static constexpr int P = 6, S = 3;
-    static constexpr int kBlockBytes = 10240, kChunkBytes = 4 * kBlockBytes, kTouchPer = kChunkBytes / 8192;
-    static constexpr int NPL = (NMB == 4) ? 2 : 0;     // row blocks that arrive as planes
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned aoff;
-    int n;
-    BOff bof;
-    int bplane;
-    L2Touch tc;
-    unsigned gq;                 // global index of this pipe's chunk 0 + the touch's lead
-    uint4 ap[S][NPL ? NPL : 1][3];
-    float4 af[S][2][2];
-    uint4 pl[2][2][3];           // [set][row block 2 / 3][plane]
-    sbf16x8 b[2][3];
-
-    static __device__ __forceinline__ const uint4* wbase(const uint4* p, int l, int w, int) { return p + ((size_t)l * (64 * 4) + w) * (kBlockBytes / 16); }
-    __device__ __forceinline__ SplitPipeH(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, const L2Touch& tc_, unsigned gbase_)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u), n(n_), bof(bof_),
-          bplane(bplane_), tc(tc_), gq(gbase_ + tc_.ahead) {}
-    __device__ __forceinline__ void touch(int kc) {
-        unsigned g = gq + (unsigned)kc;
-        const int t = (int)((tc.q - (unsigned)kTouchPer * g) & 127u) | tc.dis;
-        if (t < kTouchPer) {
-            if (g >= tc.gtot) g -= tc.gtot;
-            tc.issue(g * (unsigned)kChunkBytes + (unsigned)t * 8192u);
-        }
-    }
-    template <int st>
-    __device__ __forceinline__ void lda(int kc) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        typedef float f32x4_ __attribute__((ext_vector_type(4)));
-        const int kcc = (kc < n) ? kc : n - 1;
-#pragma unroll
-        for (int mb = 0; mb < NPL; ++mb)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kcc * kChunkBytes + (mb * 3 + p) * 1024, 0);
-                ap[st][mb][p] = make_uint4(v.x, v.y, v.z, v.w);
-            }
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const f32x4_ v = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kcc * kChunkBytes + 6144 + (mb * 2 + hf) * 1024, 0));
-                af[st][mb][hf] = make_float4(v.x, v.y, v.z, v.w);
-            }
-    }
-    __device__ __forceinline__ void ldb(sbf16x8 (&dst)[3], int kc) {
-        const su16* bp = bof.at(kc);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(bp + p * bplane));
-    }
-    // 12 MFMAs, each followed by a share of NVMEM loads, NDS LDS reads and NVALU vector instructions (44 = one split, 88 = two)
-    template <int NVMEM, int NDS, int NVALU, int SYNC, int I = 0>
-    static __device__ __forceinline__ void pattern() {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, SYNC);
-        if constexpr (I < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, SYNC);
-        if constexpr (I >= 12 - NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, SYNC);
-        __builtin_amdgcn_sched_group_barrier(0x002, (NVALU * (I + 1)) / 12 - (NVALU * I) / 12, SYNC);
-        if constexpr (I + 1 < 12) pattern<NVMEM, NDS, NVALU, SYNC, I + 1>();
-    }
-    __device__ __forceinline__ void start_a() {
-        lda<0>(0);
-        lda<1>(1);
-        DSD_SB();
-    }
-    __device__ __forceinline__ void start_b() {
-        ldb(b[0], 0);
-        SW::split8(af[0][0], pl[0][0]);
-        SW::split8(af[0][1], pl[0][1]);
-        DSD_SB();
-    }
-    template <int I>
-    __device__ __forceinline__ void step(f32x16 (&acc)[NMB], int kc) {
-        touch(kc);
-        lda<(I + S - 1) % S>(kc + S - 1);
-        ldb(b[(I + 1) & 1], kc + 1);
-        if constexpr (NMB == 4) {
-            SW::split8(af[(I + 1) % S][0], pl[(I + 1) & 1][0]);
-            SW::mfma_pair(acc[0], acc[1], ap[I % S], b[I & 1]);
-            pattern<10, 3, 44, 0>();
-            DSD_SB();
-            SW::split8(af[(I + 1) % S][1], pl[(I + 1) & 1][1]);
-            SW::mfma_pair(acc[2], acc[3], pl[I & 1], b[I & 1]);
-            pattern<0, 0, 44, 1>();
-        } else {
-            SW::split8(af[(I + 1) % S][0], pl[(I + 1) & 1][0]);
-            SW::split8(af[(I + 1) % S][1], pl[(I + 1) & 1][1]);
-            SW::mfma_pair(acc[0], acc[1], pl[I & 1], b[I & 1]);
-            pattern<4, 3, 88, 0>();
-        }
-        DSD_SB();
-    }
-    template <int I, int N>
-    __device__ __forceinline__ void steps(f32x16 (&acc)[NMB], int kc0) {
-        step<I>(acc, kc0 + I);
-        if constexpr (I + 1 < N) steps<I + 1, N>(acc, kc0);
-    }
-    template <int BEGIN, int END>
-    __device__ __forceinline__ void run(f32x16 (&acc)[NMB]) {
-        static_assert(BEGIN % P == 0 && END > BEGIN, "a segment starts on a period");
-        constexpr int kFull = (END - BEGIN) / P, kTail = (END - BEGIN) - kFull * P;
-        if constexpr (kFull > 0)
-            for (int kc0 = BEGIN; kc0 < BEGIN + kFull * P; kc0 += P) steps<0, P>(acc, kc0);
-        if constexpr (kTail > 0) steps<0, kTail>(acc, BEGIN + kFull * P);
-    }
-};
-
-// which pipe a loop instantiation streams its weights through: WF = 0 the bf16 planes (3 stages), 4 fp32 split in registers (4 stages), 5 the hybrid
+// which pipe a loop instantiation streams its weights through: WF = 0 the bf16 planes (3 stages), 4 fp32 split in registers (4 stages)
 template <int WF, int NMB, int MB0, typename BOff>
 struct SplitPipeSel { typedef SplitPipeW<NMB, MB0, WF, BOff> type; };
 template <int NMB, int MB0, typename BOff>
 struct SplitPipeSel<0, NMB, MB0, BOff> { typedef SplitPipeR<NMB, MB0, 3, BOff> type; };
-template <int NMB, int MB0, typename BOff>
-struct SplitPipeSel<5, NMB, MB0, BOff> { typedef SplitPipeH<NMB, MB0, BOff> type; };
 
 // Cached loads through a buffer descriptor over a WAVE-UNIFORM base (SGPRs) + a 32-bit lane offset: no 64-bit per-lane address lives in
 // VGPRs.  In this kernel the arch-VGPR file is full (three stages of weight planes), and a spilled pointer is a scratch reload = a vector
@@ -479,11 +357,11 @@ __device__ __forceinline__ void sp_store4(su16* plane0, int plane_elems, int off
 
 struct LoopSplitParams {
     LoopParams lp;              // everything k_loop takes (w1p / w2p unused here)
-    const uint4* w1c;           // conv weights, centre-first chunk order: fp32 [L][w4][48][mb4][2][lane64] (WF = 4), or (WF = 0 / 5) ALL weights of the loop
-                                // in consumption order [L][64 = 48 conv + 16 out-projection chunks][w4][12 KiB of planes / 10 KiB hybrid]
-    const uint4* w2s;           // out-projection weights: fp32 [L][w4][16][mb4][2][lane64] (WF = 4), or (WF = 0 / 5) w1c + 48 chunks
-    unsigned wl_bytes;          // WF = 0 / 5: bytes of that buffer (the L2 touch's buffer bound)
-    int touch_ahead;            // WF = 0 / 5: chunks the L2 touch runs in front (0 = off)
+    const uint4* w1c;           // conv weights, centre-first chunk order: fp32 [L][w4][48][mb4][2][lane64] (WF = 4), or (WF = 0) ALL weights of the loop
+                                // in consumption order [L][64 = 48 conv + 16 out-projection chunks][w4][12 KiB of planes]
+    const uint4* w2s;           // out-projection weights: fp32 [L][w4][16][mb4][2][lane64] (WF = 4), or (WF = 0) w1c + 48 chunks
+    unsigned wl_bytes;          // WF = 0: bytes of that buffer (the L2 touch's buffer bound)
+    int touch_ahead;            // WF = 0: chunks the L2 touch runs in front (0 = off)
 };
 
 template <int MODE, int WF>
@@ -512,7 +390,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
     L2Touch tc;
     {
         const unsigned long long wb = (unsigned long long)ps.w1c;
-        const bool en = (WF == 0 || WF == 5) && ps.touch_ahead > 0 && (p.n_tiles & 7) == 0 && (p.n_tiles >> 3) == 32;
+        const bool en = WF == 0 && ps.touch_ahead > 0 && (p.n_tiles & 7) == 0 && (p.n_tiles >> 3) == 32;
         tc.rs = L2Touch::i32x4_{(int)(unsigned)wb, (int)(unsigned)((wb >> 32) & 0xffffu), (int)ps.wl_bytes, 0x00020000};
         tc.ahead = (unsigned)ps.touch_ahead;
         tc.q = (unsigned)(4 * (int)(blockIdx.x >> 3) + w);

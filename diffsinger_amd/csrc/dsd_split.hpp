@@ -94,38 +94,6 @@ __global__ void k_pack_split_f32(const float* __restrict__ src, float* __restric
     }
 }
 
-// The hybrid stream of the persistent loop (dsd_loop_split.hpp, SplitPipeH): per (chunk16, wave) a 10 KiB block - row blocks 0, 1 as planes
-// ([mb][plane][lane] x 8 bf16, k_pack_split's fragment), row blocks 2, 3 as fp32 ([mb][half][lane] x 4 floats, k_pack_split_f32's) - blocks
-// in consumption order: dst + (chunk * 4 + w) * 10240 bytes; chunk order as k_pack_split.
-__global__ void k_pack_split_h(const float* __restrict__ src, unsigned char* __restrict__ dst, int nw, int ng, int ntap, int centre_first) {
-    const size_t n = (size_t)nw * ng * ntap * 4 * 64 * 8;              // (w, chunk16, mb, lane, e)
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx & 7, lane = (idx >> 3) & 63;
-        size_t r = idx >> 9;
-        const int mb = r & 3; r >>= 2;
-        const int c16 = r % (ng * ntap); r /= (ng * ntap);
-        const int w = (int)r;
-        int g = c16 / ntap, tap = c16 - g * ntap;
-        if (centre_first && ntap == 3) {
-            if (c16 < ng) { g = c16; tap = 1; }
-            else { const int ix = c16 - ng; g = ix >> 1; tap = (ix & 1) * 2; }
-        }
-        const int i = lane & 31, hp = lane >> 5;
-        const int k8 = 2 * g + hp, c8 = (ntap == 3) ? conv_chunk(k8, tap) : ntap * k8 + tap;
-        const int lane_src = i + 32 * (e >> 2), s = e & 3;
-        const float v = src[((((size_t)w * (2 * ng * ntap) + c8) * 4 + mb) * 64 + lane_src) * 4 + s];
-        unsigned char* blk = dst + ((size_t)c16 * 4 + w) * 10240;
-        if (mb < 2) {
-            su16 p0, p1, p2;
-            sp_split3(v, p0, p1, p2);
-            su16* o = reinterpret_cast<su16*>(blk + mb * 3072) + lane * 8 + e;
-            o[0] = p0; o[512] = p1; o[1024] = p2;
-        } else {
-            reinterpret_cast<float*>(blk + 6144 + (mb - 2) * 2048 + (e >> 2) * 1024)[lane * 4 + s] = v;
-        }
-    }
-}
-
 // Operand pipeline: STAGES (3 or 6) register stages of the weight stream (chunk kc + STAGES - 1 requested while chunk kc is multiplied; every
 // chunk is a first touch of the XCD's L2, the fp32 kernels needed ~5 k cycles of distance), B one chunk ahead,
 // loads interleaved one-by-one behind the first MFMAs of a step.  NMB row blocks starting at MB0 (the last layer computes the skip half only).
