@@ -135,11 +135,12 @@ def cpu_baseline(gd, pre, cond, x_T, noise, mel_hip, kernel):
 
 
 def secondary_split(gd, eng, pre, cond, x_T, noise, mel_f32, mel_oracle, args):
-    """The labelled EXPERIMENT line (`secondary`, never the headline): the SAME timed step with the residual layers' contractions on the bf16
-    matrix pipe at fp32-class accuracy (csrc/dsd_loop_split.hpp: every fp32 operand = 3 exact bf16 planes, 6 plane products per product, fp32
-    accumulate) - what the north star's 1e-4 budget buys beyond the fp32 MFMA ceiling.  Reports its rate, its roofline against the dense bf16
-    peak / 6, and - for BOTH paths, on utterance 0 of the timed batch - the error against the fp32 oracle and against an fp64 evaluation of
-    the oracle (the same function in double: the parameters, inputs and noise cast up, the fp32 schedule tables as constants)."""
+    """The labelled EXPERIMENT line (`secondary`, never the headline): the SAME timed step with the residual layers' contractions on the 16-bit
+    matrix pipe at fp32-class accuracy (csrc/dsd_loop_split.hpp; by default the pair format: every fp32 operand = two scaled fp16 planes, three
+    plane products per product, fp32 accumulate; DSD_SPLIT_W=0 / 4: three exact bf16 planes, six products) - what the north star's 1e-4 budget
+    buys beyond the fp32 MFMA ceiling.  Reports its rate, its roofline against the dense 16-bit peak / products, and - for BOTH paths, on
+    utterance 0 of the timed batch - the error against the fp32 oracle and against an fp64 evaluation of the oracle (the same function in
+    double: the parameters, inputs and noise cast up, the fp32 schedule tables as constants)."""
     from oracle import diffnet_oracle as O
     eng.set_split_mode(True)
     try:
@@ -182,17 +183,24 @@ def secondary_split(gd, eng, pre, cond, x_T, noise, mel_f32, mel_oracle, args):
     m64 = O.infer_mel(p64, cfg, sch, c0, smin, smax, k_step=K_STEPS, noises=list(noise[:, 0:1].detach().cpu().double()), x_T=x_T[0:1].detach().cpu().double())
     t64 = time.perf_counter() - t0
     err = lambda a, b: float((a.detach().cpu().double() - b.double()).abs().max())
-    peak = 2500.0 / 6
+    wsel = os.environ.get('DSD_SPLIT_W', '2')
+    fmt = {'2': {'dtype': 'f32 as 2 scaled fp16 planes (11 + 11 mantissa bits), 3 plane products per product, f32 accumulate; head, sampler and state in f32',
+                 'format': 'pair format: x = h0 + 2^-11 h1, product = h0 g0 + 2^-11 (h0 g1 + h1 g0) on v_mfma_f32_32x32x16_f16 (DSD_SPLIT_W=2, the default)',
+                 'products': 3, 'peak_note': 'peak = dense fp16 MFMA peak 2500 TFLOP/s / 3 plane products'}}.get(wsel, {
+           'dtype': 'f32 as 3 exact bf16 planes, 6 plane products per product (i + j <= 2), f32 accumulate; head, sampler and state in f32',
+           'format': 'three bf16 planes, six products on v_mfma_f32_32x32x16_bf16 (DSD_SPLIT_W=%s: %s)' % (
+               wsel, 'the planes on the wire' if wsel == '0' else 'fp32 weights on the wire, split into the planes in registers'),
+           'products': 6, 'peak_note': 'peak = dense bf16 MFMA peak 2500 TFLOP/s / 6 plane products'})
+    peak = 2500.0 / fmt['products']
     return {
-        'label': 'EXPERIMENT, not the headline: residual layers on the bf16 matrix pipe at fp32-class accuracy (dsd_set_split_mode; csrc/dsd_loop_split.hpp)',
-        'dtype': 'f32 as 3 exact bf16 planes, 6 plane products per product (i + j <= 2), f32 accumulate; head, sampler and state in f32',
+        'label': 'EXPERIMENT, not the headline: residual layers on the 16-bit matrix pipe at fp32-class accuracy (dsd_set_split_mode; csrc/dsd_loop_split.hpp)',
+        'dtype': fmt['dtype'],
         'metric': BASELINE_METRIC, 'value': B * T / sec, 'unit': 'mel-frames/s', 'ms_per_step': sec * 1e3, 'steps': n,
         'workload': f'the timed step of this line (dsd_prepare + K={K_STEPS} loop + denorm, {B} x {T} frames)',
-        'weight_stream': {'0': 'three bf16 planes, 6 bytes per weight', '4': 'fp32, 4 bytes per weight, split into the three planes in registers beside the MFMAs'}.get(
-            os.environ.get('DSD_SPLIT_W', '4'), 'default') + ' (DSD_SPLIT_W; bit-identical results)',
-        'roofline': {'bound': 'mfma', 'kernel': 'k_loop_split<1, %s>' % os.environ.get('DSD_SPLIT_W', '4'), 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent)', 'frac': achieved / peak,
+        'format': fmt['format'],
+        'roofline': {'bound': 'mfma', 'kernel': 'k_loop_split<1, %s>' % wsel, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent)', 'frac': achieved / peak,
                      'avg_launch_ms': ms_call, 'note': 'executed fp32-equivalent FLOPs (21 053 440 / frame / evaluation) over the whole sampling call (HIP events); '
-                                                       'peak = dense bf16 MFMA peak 2500 TFLOP/s / 6 plane products; the head (2 % of the fp32 launch) runs on the fp32 pipe'},
+                                                       + fmt['peak_note'] + '; the head (2 % of the fp32 launch) runs on the fp32 pipe'},
         'parity': {'case': 'the timed batch (all 8 utterances) vs the fp32 oracle; utterance 0 vs an fp64 evaluation of the oracle, both paths', 'tolerance': 1e-4,
                    'split_vs_f32_hip': err(mel_sp, mel_f32.detach().cpu()), 'split_vs_oracle_f32': err(mel_sp, mel_oracle), 'f32_vs_oracle_f32': err(mel_f32, mel_oracle),
                    'split_vs_oracle_f64_utt0': err(mel_sp[0:1], m64), 'f32_vs_oracle_f64_utt0': err(mel_f32[0:1], m64),
@@ -853,7 +861,7 @@ def main_path(args):
             flop = frames * K * F_EVAL_EXEC / launches
             achieved = frames * K * F_EVAL_EXEC / (ms_call * 1e-3) / 1e12
             frames_l = frames / launches
-            kname = 'k_loop_split<1, %s>' % os.environ.get('DSD_SPLIT_W', '4') if args.split else 'k_loop<1>'
+            kname = 'k_loop_split<1, %s>' % os.environ.get('DSD_SPLIT_W', '2') if args.split else 'k_loop<1>'
             alg_bytes = int(K * (frames * (20 * 2048 + 2 * 320 + 320) + launches * L_LAYERS * 2 * 1024 * 1024 + frames // 32 * L_LAYERS * 2 * 16384) / launches)
             note = (f'one launch = the whole K=100 reverse loop (100 x (20 residual layers + head + sampler update + next input '
                     f'projection)) for a chunk of whole utterances; this batch of {B} x {T} = {launches} launch(es) of on average {frames_l:.0f} frames; '

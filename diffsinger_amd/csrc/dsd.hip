@@ -139,9 +139,12 @@ struct dsd_handle {
     uint4 *w1s = nullptr, *w2s = nullptr;     // bf16 weight planes in 32x32x16 fragment order, [L][4][48|16][4][3][64]
     uint4* wlc = nullptr;                     // the planes once more for the persistent split loop (dsd_loop_split.hpp): a layer's 48 conv chunks (centre taps
                                               // first) + 16 out-projection chunks in consumption order, [L][64][wave 4][12 KiB]
+    uint4* wl2 = nullptr;                     // the pair format of the split loop: two fp16 planes, consumption order [L][64][wave 4][8 KiB]
     uint4 *w1f = nullptr, *w2f = nullptr;     // fp32 in 32x32x16 fragment order, [L][4][48|16][4][2][64] (the split loop that splits its weights in registers)
     int split_touch = 8;                      // plane stream of the split loop: chunks the L2 touch runs in front, 0 = off (DSD_SPLIT_TOUCH; dsd_loop_split.hpp)
-    int split_w = 0;                          // weight stream of the split loop: 4 = fp32, split into the planes in registers (four stages); 0 = bf16 planes (DSD_SPLIT_W)
+    // format / weight stream of the split loop (DSD_SPLIT_W; dsd_loop_split.hpp): 2 = the PAIR format, two scaled fp16 planes and three products
+    // per product (default); 0 = three bf16 planes, six products; 4 = those planes split in registers from fp32 weights (bit-identical to 0)
+    int split_w = 2;
 };
 
 // After a reported timeout the handle runs this many sampling loops on the hipGraph path before it tries the persistent loop again: a
@@ -250,7 +253,7 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);     // the same choice as dsd_set_loop_mode, for an unmodified host
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
     if (const char* ev = std::getenv("DSD_SPLIT_TOUCH")) { const int v = std::atoi(ev); if (v >= 0 && v <= 20) h->split_touch = v; }
-    if (const char* ev = std::getenv("DSD_SPLIT_W")) { const int v = std::atoi(ev); if (v == 0 || v == 4) h->split_w = v; }
+    if (const char* ev = std::getenv("DSD_SPLIT_W")) { const int v = std::atoi(ev); if (v == 0 || v == 2 || v == 4) h->split_w = v; }
     if (const char* ev = std::getenv("DSD_RS")) h->rs_req = std::atoi(ev);                   // the same choice as dsd_set_rs_split
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
@@ -292,7 +295,7 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     free_workspace(h);
-    dev_free(h->w1s); dev_free(h->w2s); dev_free(h->wlc); dev_free(h->w1f); dev_free(h->w2f);
+    dev_free(h->w1s); dev_free(h->w2s); dev_free(h->wlc); dev_free(h->wl2); dev_free(h->w1f); dev_free(h->w2f);
     dev_free(h->w1q); dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->bskp); dev_free(h->b2raw); dev_free(h->bsum);
     dev_free(h->winp); dev_free(h->binp); dev_free(h->wsp); dev_free(h->bsp); dev_free(h->woutp); dev_free(h->boutp);
     dev_free(h->mlp0_w); dev_free(h->mlp0_b); dev_free(h->mlp2_w); dev_free(h->mlp2_b); dev_free(h->dp_w); dev_free(h->dp_b);
@@ -1004,11 +1007,13 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
         if (h->split_mode) {
             // EXPERIMENT (dsd_loop_split.hpp): the same loop with the layers' contractions as six bf16 plane products per fp32 product
             const LoopSplitParams q = h->split_w == 4 ? LoopSplitParams{p, h->w1f, h->w2f, 0u, 0}
+                                      : h->split_w == 2 ? LoopSplitParams{p, h->wl2, h->wl2 + (size_t)48 * 4 * 512, (unsigned)((size_t)h->L * 64 * 4 * 8192), h->split_touch}
                                                         : LoopSplitParams{p, h->wlc, h->wlc + (size_t)48 * 4 * 768, (unsigned)((size_t)h->L * 64 * 4 * 12288), h->split_touch};
             const dim3 grid((unsigned)p.n_tiles), block(kThreads);
 #define DSD_LAUNCH_SPLIT(WF) do { if (kind == 0) hipLaunchKernelGGL((k_loop_split<HEAD_DDPM, WF>), grid, block, kLoopSplitLdsBytes, s, q); \
                                   else hipLaunchKernelGGL((k_loop_split<HEAD_PLMS, WF>), grid, block, kLoopSplitLdsBytes, s, q); } while (0)
             if (h->split_w == 4) DSD_LAUNCH_SPLIT(4);
+            else if (h->split_w == 2) DSD_LAUNCH_SPLIT(2);
             else DSD_LAUNCH_SPLIT(0);
 #undef DSD_LAUNCH_SPLIT
         } else if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
@@ -1183,7 +1188,7 @@ static void split_kernel_attrs() {
 #define DSD_SPLIT_ATTR(WF) do { \
             (void)hipFuncSetAttribute((const void*)k_loop_split<HEAD_DDPM, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopSplitLdsBytes); \
             (void)hipFuncSetAttribute((const void*)k_loop_split<HEAD_PLMS, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopSplitLdsBytes); } while (0)
-        DSD_SPLIT_ATTR(0); DSD_SPLIT_ATTR(4);
+        DSD_SPLIT_ATTR(0); DSD_SPLIT_ATTR(2); DSD_SPLIT_ATTR(4);
 #undef DSD_SPLIT_ATTR
     }
 }
@@ -1198,21 +1203,28 @@ static int pack_split_planes(dsd_handle* h, hipStream_t s) {
         HIP_TRY(hipMemsetAsync(h->wlc + (size_t)L * 64 * 4 * 768, 0, (size_t)kWeightSlack * 16, s));
         HIP_TRY(hipMemsetAsync(h->w1s + (size_t)L * 4 * 48 * 12 * 64, 0, (size_t)kWeightSlack * 16, s));
         HIP_TRY(hipMemsetAsync(h->w2s + (size_t)L * 4 * 16 * 12 * 64, 0, (size_t)kWeightSlack * 16, s));
+        DSD_TRY(dev_alloc(h, &h->wl2, (size_t)L * 64 * 4 * 512 + kWeightSlack));
+        HIP_TRY(hipMemsetAsync(h->wl2 + (size_t)L * 64 * 4 * 512, 0, (size_t)kWeightSlack * 16, s));
         DSD_TRY(dev_alloc(h, &h->w1f, (size_t)L * 4 * 48 * 8 * 64 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->w2f, (size_t)L * 4 * 16 * 8 * 64 + kWeightSlack));
         HIP_TRY(hipMemsetAsync(h->w1f + (size_t)L * 4 * 48 * 8 * 64, 0, (size_t)kWeightSlack * 16, s));
         HIP_TRY(hipMemsetAsync(h->w2f + (size_t)L * 4 * 16 * 8 * 64, 0, (size_t)kWeightSlack * 16, s));
     }
     for (int l = 0; l < L; ++l) {
-        hipLaunchKernelGGL(k_pack_split, dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256),
+        hipLaunchKernelGGL((k_pack_split<false>), dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256),
                            reinterpret_cast<su16*>(h->w1s + (size_t)l * 4 * 48 * 12 * 64), 4, 16, 3, 0, 0LL, 0LL);
         su16* lc = reinterpret_cast<su16*>(h->wlc + (size_t)l * 64 * 4 * 768);          // consumption order: chunk stride 4 x 6144, wave stride 6144
-        hipLaunchKernelGGL(k_pack_split, dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256), lc, 4, 16, 3, 1,
+        hipLaunchKernelGGL((k_pack_split<false>), dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256), lc, 4, 16, 3, 1,
                            6144LL, 4 * 6144LL);
-        hipLaunchKernelGGL(k_pack_split, dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256), lc + (size_t)48 * 4 * 6144,
+        hipLaunchKernelGGL((k_pack_split<false>), dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256), lc + (size_t)48 * 4 * 6144,
                            4, 16, 1, 0, 6144LL, 4 * 6144LL);
-        hipLaunchKernelGGL(k_pack_split, dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256),
+        hipLaunchKernelGGL((k_pack_split<false>), dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256),
                            reinterpret_cast<su16*>(h->w2s + (size_t)l * 4 * 16 * 12 * 64), 4, 16, 1, 0, 0LL, 0LL);
+        su16* l2 = reinterpret_cast<su16*>(h->wl2 + (size_t)l * 64 * 4 * 512);          // pair format: chunk stride 4 x 4096, wave stride 4096
+        hipLaunchKernelGGL((k_pack_split<true>), dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256), l2, 4, 16, 3, 1,
+                           4096LL, 4 * 4096LL);
+        hipLaunchKernelGGL((k_pack_split<true>), dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256), l2 + (size_t)48 * 4 * 4096,
+                           4, 16, 1, 0, 4096LL, 4 * 4096LL);
         hipLaunchKernelGGL(k_pack_split_f32, dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256),
                            reinterpret_cast<float*>(h->w1f + (size_t)l * 4 * 48 * 8 * 64), 4, 16, 3, 1);
         hipLaunchKernelGGL(k_pack_split_f32, dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256),

@@ -155,6 +155,7 @@ struct SplitPipeR {
     }
     template <int BEGIN, int END>
     __device__ __forceinline__ void run(f32x16 (&acc)[NMB]) { run(acc, BEGIN, END); }
+    __device__ __forceinline__ void finish(f32x16 (&)[NMB]) {}
     // chunks [begin, end); begin a multiple of 6
     __device__ __forceinline__ void run(f32x16 (&acc)[NMB], int begin, int end) {
         for (int it = begin / 6; 6 * it < end; ++it) {
@@ -312,6 +313,7 @@ struct SplitPipeW {
     }
     // chunks [BEGIN, END), BEGIN a multiple of the period.  Compile-time bounds: whole periods are ONE basic block each (branches between the
     // steps let hipcc's block passes move the split of the next fragments out from under the MFMAs), the tail is unrolled by its length.
+    __device__ __forceinline__ void finish(f32x16 (&)[NMB]) {}
     template <int BEGIN, int END>
     __device__ __forceinline__ void run(f32x16 (&acc)[NMB]) {
         static_assert(BEGIN % P == 0 && END > BEGIN, "a segment starts on a period");
@@ -322,11 +324,133 @@ struct SplitPipeW {
     }
 };
 
+// PAIR format (WF = 2): every fp32 operand as TWO fp16 planes, x = h0 + 2^-11 h1 (sp_split2h: 11 + 11 mantissa bits, the second plane scaled so
+// that it is a normal fp16), a product as h0 g0 + 2^-11 (h0 g1 + h1 g0) - three v_mfma_f32_32x32x16_f16 per 16-deep chunk instead of six bf16
+// ones, 4 bytes per weight on the wire instead of 6, two LDS reads per chunk instead of three.  The products are exact in fp32 (11 x 11
+// bits); what is dropped is h1 g1 (<= 2^-24 relative) and the operands' bits below 2^-22 - of the order of ONE rounding of the fp32 MFMA
+// chain, which rounds after every one of its K accumulations (tests/test_gpu_split_loop.py measures both against an fp64 evaluation).
+// The cross terms go to a second set of accumulators (their common factor 2^-11 is applied once, in finish()), so a wave holds
+// 2 x NMB x 16 accumulator registers.  Four register stages of 8 KiB per wave; blocks in consumption order like the plane stream
+// ([chunk][wave][mb][plane 2][lane] x 8 fp16: a chunk = 32 KiB = 256 lines = four L2-touch instructions).
+typedef _Float16 sh8 __attribute__((ext_vector_type(8)));
+template <int NMB, int MB0, typename BOff>
+struct SplitPipeF {
+    static constexpr int P = 4, S = 4;
+    static constexpr int kBlockBytes = 8192, kChunkBytes = 4 * kBlockBytes, kTouchPer = kChunkBytes / 8192;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned aoff;
+    int n;
+    BOff bof;
+    int bplane;
+    L2Touch tc;
+    unsigned gq;
+    uint4 a[S][NMB][2];
+    sh8 b[2][2];
+    f32x16 cross[NMB];           // h0 g1 + h1 g0, in units of 2^-11
+
+    static __device__ __forceinline__ const uint4* wbase(const uint4* p, int l, int w, int) { return p + ((size_t)l * (64 * 4) + w) * (kBlockBytes / 16); }
+    __device__ __forceinline__ SplitPipeF(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, const L2Touch& tc_, unsigned gbase_)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u), n(n_), bof(bof_),
+          bplane(bplane_), tc(tc_), gq(gbase_ + tc_.ahead) {
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cross[mb][r] = 0.f;
+    }
+    __device__ __forceinline__ void touch(int kc) {
+        unsigned g = gq + (unsigned)kc;
+        const int t = (int)((tc.q - (unsigned)kTouchPer * g) & 127u) | tc.dis;
+        if (t < kTouchPer) {
+            if (g >= tc.gtot) g -= tc.gtot;
+            tc.issue(g * (unsigned)kChunkBytes + (unsigned)t * 8192u);
+        }
+    }
+    template <int ST>
+    __device__ __forceinline__ void lda(int kc) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int kcc = (kc < n) ? kc : n - 1;
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff, kcc * kChunkBytes + ((MB0 + mb) * 2 + p) * 1024, 0);
+                a[ST][mb][p] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+    }
+    __device__ __forceinline__ void ldb(sh8 (&dst)[2], int kc) {
+        const su16* bp = bof.at(kc);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) dst[p] = __builtin_bit_cast(sh8, *reinterpret_cast<const uint4*>(bp + p * bplane));
+    }
+    __device__ __forceinline__ void pattern() {
+#pragma unroll
+        for (int i = 0; i < 2 * NMB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (3 * NMB - 2 * NMB - 2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 3 * NMB - 2 * NMB - 2, 0);
+    }
+    __device__ __forceinline__ void start_a() {
+        lda<0>(0);
+        lda<1>(1);
+        lda<2>(2);
+        DSD_SB();
+    }
+    __device__ __forceinline__ void start_b() {
+        ldb(b[0], 0);
+        DSD_SB();
+    }
+    template <int I>
+    __device__ __forceinline__ void step(f32x16 (&acc)[NMB], int kc) {
+        touch(kc);
+        lda<(I + S - 1) % S>(kc + S - 1);
+        ldb(b[(I + 1) & 1], kc + 1);
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+            cross[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sh8, a[I % S][mb][1]), b[I & 1][0], cross[mb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+            cross[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sh8, a[I % S][mb][0]), b[I & 1][1], cross[mb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sh8, a[I % S][mb][0]), b[I & 1][0], acc[mb], 0, 0, 0);
+        pattern();
+        DSD_SB();
+    }
+    template <int I, int N>
+    __device__ __forceinline__ void steps(f32x16 (&acc)[NMB], int kc0) {
+        step<I>(acc, kc0 + I);
+        if constexpr (I + 1 < N) steps<I + 1, N>(acc, kc0);
+    }
+    template <int BEGIN, int END>
+    __device__ __forceinline__ void run(f32x16 (&acc)[NMB]) {
+        static_assert(BEGIN % P == 0 && END > BEGIN, "a segment starts on a period");
+        constexpr int kFull = (END - BEGIN) / P, kTail = (END - BEGIN) - kFull * P;
+        if constexpr (kFull > 0)
+            for (int kc0 = BEGIN; kc0 < BEGIN + kFull * P; kc0 += P) steps<0, P>(acc, kc0);
+        if constexpr (kTail > 0) steps<0, kTail>(acc, BEGIN + kFull * P);
+    }
+    // acc = h0 g0 sum + 2^-11 x cross sum
+    __device__ __forceinline__ void finish(f32x16 (&acc)[NMB]) {
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = fmaf(cross[mb][r], kPairInv, acc[mb][r]);
+    }
+};
+
 // which pipe a loop instantiation streams its weights through: WF = 0 the bf16 planes (3 stages), 4 fp32 split in registers (4 stages)
 template <int WF, int NMB, int MB0, typename BOff>
 struct SplitPipeSel { typedef SplitPipeW<NMB, MB0, WF, BOff> type; };
 template <int NMB, int MB0, typename BOff>
 struct SplitPipeSel<0, NMB, MB0, BOff> { typedef SplitPipeR<NMB, MB0, 3, BOff> type; };
+template <int NMB, int MB0, typename BOff>
+struct SplitPipeSel<2, NMB, MB0, BOff> { typedef SplitPipeF<NMB, MB0, BOff> type; };
 
 // Cached loads through a buffer descriptor over a WAVE-UNIFORM base (SGPRs) + a 32-bit lane offset: no 64-bit per-lane address lives in
 // VGPRs.  In this kernel the arch-VGPR file is full (three stages of weight planes), and a spilled pointer is a scratch reload = a vector
@@ -353,6 +477,23 @@ __device__ __forceinline__ void sp_store4(su16* plane0, int plane_elems, int off
     *reinterpret_cast<su16x4*>(plane0 + off) = su16x4{a0[0], a0[1], a0[2], a0[3]};
     *reinterpret_cast<su16x4*>(plane0 + plane_elems + off) = su16x4{a1[0], a1[1], a1[2], a1[3]};
     *reinterpret_cast<su16x4*>(plane0 + 2 * plane_elems + off) = su16x4{a2[0], a2[1], a2[2], a2[3]};
+}
+
+// four consecutive channels of one frame in the pair format -> two 8-byte writes
+__device__ __forceinline__ void sp_store4h(su16* plane0, int plane_elems, int off, const float4& v) {
+    typedef su16 su16x4 __attribute__((ext_vector_type(4)));
+    su16 a0[4], a1[4];
+    sp_split2h(v.x, a0[0], a1[0]);
+    sp_split2h(v.y, a0[1], a1[1]);
+    sp_split2h(v.z, a0[2], a1[2]);
+    sp_split2h(v.w, a0[3], a1[3]);
+    *reinterpret_cast<su16x4*>(plane0 + off) = su16x4{a0[0], a0[1], a0[2], a0[3]};
+    *reinterpret_cast<su16x4*>(plane0 + plane_elems + off) = su16x4{a1[0], a1[1], a1[2], a1[3]};
+}
+template <int WF>
+__device__ __forceinline__ void sp_store4_wf(su16* plane0, int plane_elems, int off, const float4& v) {
+    if constexpr (WF == 2) sp_store4h(plane0, plane_elems, off, v);
+    else sp_store4(plane0, plane_elems, off, v);
 }
 
 struct LoopSplitParams {
@@ -390,7 +531,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
     L2Touch tc;
     {
         const unsigned long long wb = (unsigned long long)ps.w1c;
-        const bool en = WF == 0 && ps.touch_ahead > 0 && (p.n_tiles & 7) == 0 && (p.n_tiles >> 3) == 32;
+        const bool en = (WF == 0 || WF == 2) && ps.touch_ahead > 0 && (p.n_tiles & 7) == 0 && (p.n_tiles >> 3) == 32;
         tc.rs = L2Touch::i32x4_{(int)(unsigned)wb, (int)(unsigned)((wb >> 32) & 0xffffu), (int)ps.wl_bytes, 0x00020000};
         tc.ahead = (unsigned)ps.touch_ahead;
         tc.q = (unsigned)(4 * (int)(blockIdx.x >> 3) + w);
@@ -487,7 +628,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                 for (int q = 0; q < 4; ++q) {
                     const int c = ch0 + 32 * mb + 8 * q;
                     const float4 d = *reinterpret_cast<const float4*>(dsl + c);
-                    sp_store4(yp, kSpYPlane, (kHalo + j) * kSpRS + c, fm_add_masked(xq[mb][q], d, in_t));
+                    sp_store4_wf<WF>(yp, kSpYPlane, (kHalo + j) * kSpRS + c, fm_add_masked(xq[mb][q], d, in_t));
                 }
             __syncthreads();
             LOOP_STAMP(1);
@@ -544,7 +685,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                     for (int g = 0; g < 2; ++g) {
                         const int f = 4 * g + (tid >> 6);
                         const int t = side ? t0 + 32 + f : t0 - kHalo + f;
-                        sp_store4(yp, kSpYPlane, ((side ? kHalo + 32 : 0) + f) * kSpRS + c, fm_add_masked(hv[side][g], d, have && t < T));
+                        sp_store4_wf<WF>(yp, kSpYPlane, ((side ? kHalo + 32 : 0) + f) * kSpRS + c, fm_add_masked(hv[side][g], d, have && t < T));
                     }
                 }
             }
@@ -560,6 +701,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
             }
             DSD_SB();
             pipe1.template run<24, 48>(acc);
+            pipe1.finish(acc);
             float ds_next = 0.f;
             {
                 const bool more = !last || (e + 1 < p.n_evals);
@@ -580,7 +722,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                             const float vg = f4at(cpv[pr][q], ee), vf = f4at(cpv[pr + 2][q], ee);
                             g4[ee] = sigmoid_f(acc[pr][r] + vg) * tanh_f(acc[pr + 2][r] + vf);
                         }
-                        sp_store4(gp, kSpGPlane, j * kSpRS + ch0 + 32 * pr + 8 * q, make_float4(g4[0], g4[1], g4[2], g4[3]));
+                        sp_store4_wf<WF>(gp, kSpGPlane, j * kSpRS + ch0 + 32 * pr + 8 * q, make_float4(g4[0], g4[1], g4[2], g4[3]));
                     }
             };
             LOOP_STAMP(3);
@@ -605,6 +747,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                     for (int q = 0; q < 4; ++q) bq[mb][q] = ld16_u(p.b2raw + (size_t)l * 2 * kC, (ch0 + 32 * mb + 8 * q) * 4);
                 DSD_SB();
                 pipe2.template run<kSeg0, 16>(acc2);
+                pipe2.finish(acc2);
                 LOOP_STAMP(5);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
@@ -639,6 +782,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                     for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
                 pipe2.start_b();
                 pipe2.template run<0, 16>(acc2);
+                pipe2.finish(acc2);
                 dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)

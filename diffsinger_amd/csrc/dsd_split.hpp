@@ -37,6 +37,15 @@ __device__ __forceinline__ void sp_split3(float x, su16& a, su16& b, su16& c) {
     a = __builtin_bit_cast(su16, p0); b = __builtin_bit_cast(su16, p1); c = __builtin_bit_cast(su16, p2);
 }
 
+// The pair format (dsd_loop_split.hpp, SplitPipeF): x = h0 + 2^-11 * h1 with h0 = fp16(x) and h1 = fp16((x - h0) * 2^11) - 11 + 11 mantissa
+// bits, the second plane scaled up so that it stays out of the fp16 denormals for every x whose first plane is normal.
+constexpr float kPairScale = 2048.f, kPairInv = 1.f / 2048.f;
+__device__ __forceinline__ void sp_split2h(float x, su16& a, su16& b) {
+    const _Float16 h0 = (_Float16)x;
+    const _Float16 h1 = (_Float16)((x - (float)h0) * kPairScale);
+    a = __builtin_bit_cast(su16, h0); b = __builtin_bit_cast(su16, h1);
+}
+
 // fp32 fragment-order weights (k_pack_a, 32x32x2: [w][chunk8][mb 4][lane][4], chunk8 = conv_chunk(k8, tap) for the dilated conv, = k8 for
 // the projections; lane (i, h), s -> channel 8 k8 + 4 h + s)
 // -> bf16 planes in 32x32x16 fragment order [w][chunk16 = ntap * g + tap][mb 4][plane 3][lane (i, h')][e 8], channel 16 g + 8 h' + e.
@@ -45,9 +54,12 @@ __device__ __forceinline__ void sp_split3(float x, su16& a, su16& b, su16& c) {
 // wave_stride / chunk_stride (in bf16 elements; 0 = the dense [w][chunk16] order above): the persistent loop keeps a layer's planes in
 // CONSUMPTION order [chunk16 of W1 then of W2][w][mb][plane][lane] - a chunk of all four waves is 48 KiB of consecutive lines, which is
 // what lets the workgroups of an XCD touch the stream ahead of themselves line by line (dsd_loop_split.hpp, L2 touch).
+// PAIR: the two fp16 planes of the pair format instead of the three bf16 planes ([mb][plane 2][lane] x 8: 4096 elements per (chunk, wave)).
+template <bool PAIR = false>
 __global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ dst, int nw, int ng, int ntap, int centre_first,
                              long long wave_stride, long long chunk_stride) {
-    const size_t ws = wave_stride ? (size_t)wave_stride : (size_t)ng * ntap * 6144, cs = chunk_stride ? (size_t)chunk_stride : 6144;
+    constexpr int NPL = PAIR ? 2 : 3;
+    const size_t ws = wave_stride ? (size_t)wave_stride : (size_t)ng * ntap * (4 * NPL * 512), cs = chunk_stride ? (size_t)chunk_stride : (4 * NPL * 512);
     const size_t n = (size_t)nw * ng * ntap * 4 * 64 * 8;              // (w, chunk16, mb, lane, e)
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = idx & 7, lane = (idx >> 3) & 63;
@@ -64,10 +76,16 @@ __global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ d
         const int k8 = 2 * g + hp, c8 = (ntap == 3) ? conv_chunk(k8, tap) : ntap * k8 + tap;    // source chunk (the fp32 stream's order)
         const int lane_src = i + 32 * (e >> 2), s = e & 3;
         const float v = src[((((size_t)w * (2 * ng * ntap) + c8) * 4 + mb) * 64 + lane_src) * 4 + s];
-        su16 p0, p1, p2;
-        sp_split3(v, p0, p1, p2);
-        const size_t o = (size_t)w * ws + (size_t)c16 * cs + (size_t)(mb * 3) * 512 + (size_t)lane * 8 + e;
-        dst[o] = p0; dst[o + 512] = p1; dst[o + 1024] = p2;
+        const size_t o = (size_t)w * ws + (size_t)c16 * cs + (size_t)(mb * NPL) * 512 + (size_t)lane * 8 + e;
+        if constexpr (PAIR) {
+            su16 h0, h1;
+            sp_split2h(v, h0, h1);
+            dst[o] = h0; dst[o + 512] = h1;
+        } else {
+            su16 p0, p1, p2;
+            sp_split3(v, p0, p1, p2);
+            dst[o] = p0; dst[o + 512] = p1; dst[o + 1024] = p2;
+        }
     }
 }
 
