@@ -1,25 +1,26 @@
 // dsd_loop_split.hpp - EXPERIMENT, labelled as such everywhere it surfaces (bench.py `secondary`, dsd_set_split_mode): the persistent K-step loop
-// of dsd_loop.hpp with the two contractions of a residual layer on the bf16 matrix pipe at fp32-class accuracy - the only route past the fp32
+// of dsd_loop.hpp with the two contractions of a residual layer on the 16-bit matrix pipe at fp32-class accuracy - the only route past the fp32
 // MFMA ceiling k_loop sits at (0.98 of the bare v_mfma_f32_32x32x2_f32 stream).
 //
-// Arithmetic (dsd_split.hpp): every fp32 operand is the exact sum of three bf16 planes p0 + p1 + p2 (8 + 8 + 8 mantissa bits); a * b is taken
-// as the six plane products a_i * b_j with i + j <= 2, each exact in fp32, accumulated in fp32 on v_mfma_f32_32x32x16_bf16, smallest products
-// first: 6 x 32 = 192 matrix-pipe cycles per 16-deep k-chunk instead of 8 x 64 = 512.  The dropped products are <= 2^-24 relative: the error
-// against an fp64 evaluation is of the order of the fp32 MFMA chain's own rounding (tests/test_gpu_split_loop.py measures both).
+// Two arithmetic formats (template parameter WF of k_loop_split, DSD_SPLIT_W):
+//   * the PAIR format (WF = 2, the default; SplitPipeF): every fp32 operand as two fp16 planes, x = h0 + 2^-11 h1 (11 + 11 mantissa bits), a
+//     product as h0 g0 + 2^-11 (h0 g1 + h1 g0): three v_mfma_f32_32x32x16_f16 per 16-deep chunk, 4 bytes per weight;
+//   * three exact bf16 planes p0 + p1 + p2 (8 + 8 + 8 bits; dsd_split.hpp), a product as the six plane products with i + j <= 2, smallest first,
+//     on v_mfma_f32_32x32x16_bf16 - the planes on the wire (WF = 0, SplitPipeR: 6 bytes per weight) or fp32 on the wire and the same planes
+//     made in registers beside the MFMAs (WF = 4, SplitPipeW: 4 bytes, bit-identical to WF = 0).
+// Either way the products are exact in fp32 and accumulated in fp32; what is dropped is <= 2^-22 relative per product - of the order of the
+// fp32 MFMA chain's own rounding (tests/test_gpu_split_loop.py measures all of them against an fp64 evaluation of the oracle).
 //
 // Everything else IS k_loop: a workgroup owns a 32-frame tile for the whole loop, x and the running skip sum stay in fp32 registers in
 // accumulator-fragment order, the 8 halo frames travel in fp32 through the same write-through stores + per-tile phase flags + sc1 loads, the
 // head (skip projection, final projection, sampler update, next input projection) is the fp32 code of k_loop verbatim.  What changes:
-//   * y = x + step and the gate tile are written to LDS as three bf16 planes, frame-major [plane][frame][264] (a lane's 4 consecutive
+//   * y = x + step and the gate tile are written to LDS as 16-bit planes, frame-major [plane][frame][264] (a lane's 4 consecutive
 //     channels of a frame = one 8-byte write per plane; a fragment = 8 consecutive channels = one ds_read_b128 per plane);
-//   * the weights stream in 32x32x16 fragment order, in one of two forms (template parameter WF, DSD_SPLIT_W): as FP32, 4 bytes per
-//     weight, split into the three planes IN REGISTERS beside the MFMAs (SplitPipeW, four register stages of 8 KiB per wave; WF = 4, the
-//     default), or as the three bf16 planes themselves, 6 bytes per weight and no arithmetic (SplitPipeR, three stages of 12 KiB; WF = 0).
-//     Same planes, same products in the same order per accumulator: the two agree bit for bit.  Neither reaches the matrix pipe's rate -
-//     the plane stream waits for bytes (~54-64 cycles per MFMA instead of 32), the register split for the vector ALU (88 instructions
-//     per 12 MFMAs: 47 cycles per MFMA); DESIGN.md section 4b has the timelines;
+//   * the weights stream in 32x32x16 fragment order through register stages, for WF = 0 / 2 in CONSUMPTION order ([layer][chunk][wave]), which
+//     is what lets the workgroups of an XCD fetch the stream into their L2 ahead of themselves (L2Touch below);
 //   * K order of the dilated conv: the 16 centre-tap chunks first (they need no halo), then the (-dil, +dil) pairs - the loop fetches its
-//     neighbours' frames under the centre taps exactly like k_loop (a second packing of the conv planes, k_pack_split with centre_first).
+//     neighbours' frames under the centre taps exactly like k_loop.
+// DESIGN.md section 4b has the measurements: what bounds each stream, the shader clock under each, the road from 78 k to 130 k mel-frames/s.
 #pragma once
 #include "dsd_loop.hpp"
 #include "dsd_split.hpp"

@@ -192,11 +192,13 @@ int dsd_set_rs_split(dsd_handle* h, int32_t g);
 int dsd_get_rs_split(dsd_handle* h);
 
 /* EXPERIMENT (csrc/dsd_split.hpp, csrc/dsd_loop_split.hpp; default off, env DSD_SPLIT=1 turns it on at creation): the residual layers on
- * the bf16 matrix pipe with fp32-class accuracy - every fp32 operand is the exact sum of three bf16 planes, the six plane products
- * with i + j <= 2 are accumulated in fp32 (2.7x the fp32 MFMA rate).  Applies to the persistent loop (k_loop_split: the same loop, x /
- * skip sum / halo exchange / head / sampler in fp32) and to the per-layer kernel path (k_layer_split, 32-frame tiles); the latency and
- * row-split paths are bypassed while it is on.  Never the headline dtype: bench.py reports it as a labelled `secondary` line with its error
- * against an fp64 evaluation of the oracle beside the fp32 path's.  Enqueues the weight-plane packing on `stream`. */
+ * the 16-bit matrix pipe with fp32-class accuracy.  The persistent loop (k_loop_split: the same loop, x / skip sum / halo exchange / head /
+ * sampler in fp32) takes every fp32 operand as TWO scaled fp16 planes, x = h0 + 2^-11 h1, and a product as h0 g0 + 2^-11 (h0 g1 + h1 g0),
+ * accumulated in fp32 (the pair format; env DSD_SPLIT_W=2, the default) - or as three exact bf16 planes and the six products with i + j <= 2
+ * (DSD_SPLIT_W=0: the planes on the wire; 4: fp32 weights split into the same planes in registers, bit-identical), which is also what the
+ * per-layer kernel path does (k_layer_split, 32-frame tiles).  The latency and row-split paths are bypassed while the mode is on.  Never the
+ * headline dtype: bench.py reports it as a labelled `secondary` line with its error against an fp64 evaluation of the oracle beside the
+ * fp32 path's.  Enqueues the weight packing on `stream`. */
 int dsd_set_split_mode(dsd_handle* h, int32_t on, void* stream);
 int dsd_get_split_mode(dsd_handle* h);
 
