@@ -82,8 +82,10 @@ def test_config2_against_the_fp32_and_the_fp64_oracle_and_rate(monkeypatch):
     e64 = {k: float((v[0:1].double() - m64).abs().max()) for k, v in outs.items()}
     print('row 0 vs an fp64 evaluation of the oracle: ' + ', '.join(f'{k}: {v:.3e}' for k, v in e64.items()) + '; rate: '
           + ', '.join(f'{k}: {v:.1f} ms per call = {B * T / v * 1e3:.0f} mel-frames/s' for k, v in ms.items()))
+    r64 = {k: float((v[0:1].double() - m64).pow(2).mean().sqrt()) for k, v in outs.items()}
+    print('row 0, rms distance to the fp64 evaluation: ' + ', '.join(f'{k}: {v:.3e}' for k, v in r64.items()))
     for k in ('2', '0'):
-        assert e64[k] <= 1e-4 and e64[k] <= 2.0 * e64['f32'] + 1e-6
+        assert e64[k] <= 1e-4 and e64[k] <= 2.0 * e64['f32'] + 1e-6 and r64[k] <= 2.0 * r64['f32'] + 1e-7
 
 
 def test_the_weight_stream_variants_agree_bit_for_bit_and_their_rates(monkeypatch):
