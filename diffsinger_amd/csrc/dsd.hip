@@ -363,9 +363,11 @@ static bool first_on_device(int site) {
 // loud persistent-loop failures
 // ------------------------------------------------------------------------------------------------------------
 // One thread, enqueued behind every persistent loop: copies a raised timeout word into the handle's pinned host word (system scope).
+// Bit 1 of the word (kLoopRangeBit, dsd_loop_split.hpp: an activation left fp16's range in the pair format) goes to the second pinned word.
 __global__ void k_latch_tmo(const unsigned* tmo, unsigned* sticky) {
-    if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-        __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned v = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v & 2u) __hip_atomic_fetch_add(sticky + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (v != 0u) __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Debug / test hook kernel: holds a CU (all of its LDS) for `ticks` of the 100 MHz wall clock, or until the caller sets the release word
@@ -394,6 +396,14 @@ static int sticky_alloc(dsd_handle* h) {
 // handle on the hipGraph path (a retry of the same call then runs the per-layer kernels) and fails with DSD_ERR_TIMEOUT.
 static int check_sticky(dsd_handle* h, const char* who) {
     if (!h->sticky_host) return DSD_OK;
+    if (const unsigned r = __atomic_load_n(h->sticky_host + 1, __ATOMIC_ACQUIRE)) {
+        __atomic_store_n(h->sticky_host + 1, 0u, __ATOMIC_RELEASE);
+        __atomic_store_n(h->sticky_host, 0u, __ATOMIC_RELEASE);       // (the workgroups that saw the flag left their waits early: not timeouts)
+        return fail(DSD_ERR_RANGE,
+                    "%s: %u split-precision loop launch(es) of an EARLIER call on this handle met an activation outside fp16's range (|x| > 65504) - the "
+                    "pair format (two fp16 planes per operand, DSD_SPLIT_W=2) cannot hold it; the mel / x tiles those calls returned are NaN.  Turn "
+                    "the mode off (dsd_set_split_mode) or use the bf16 planes (DSD_SPLIT_W=0), whose range is fp32's", who, r);
+    }
     const unsigned v = __atomic_load_n(h->sticky_host, __ATOMIC_ACQUIRE);
     if (v == 0u) return DSD_OK;
     __atomic_store_n(h->sticky_host, 0u, __ATOMIC_RELEASE);

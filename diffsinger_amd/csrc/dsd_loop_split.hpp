@@ -480,9 +480,11 @@ __device__ __forceinline__ void sp_store4(su16* plane0, int plane_elems, int off
     *reinterpret_cast<su16x4*>(plane0 + 2 * plane_elems + off) = su16x4{a2[0], a2[1], a2[2], a2[3]};
 }
 
-// four consecutive channels of one frame in the pair format -> two 8-byte writes
-__device__ __forceinline__ void sp_store4h(su16* plane0, int plane_elems, int off, const float4& v) {
+// four consecutive channels of one frame in the pair format -> two 8-byte writes; `big` collects the largest magnitude stored (range guard)
+constexpr unsigned kLoopRangeBit = 2u;      // in the loop's timeout word: an activation left fp16's range
+__device__ __forceinline__ void sp_store4h(su16* plane0, int plane_elems, int off, const float4& v, float& big) {
     typedef su16 su16x4 __attribute__((ext_vector_type(4)));
+    big = fmaxf(big, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     su16 a0[4], a1[4];
     sp_split2h(v.x, a0[0], a1[0]);
     sp_split2h(v.y, a0[1], a1[1]);
@@ -492,8 +494,8 @@ __device__ __forceinline__ void sp_store4h(su16* plane0, int plane_elems, int of
     *reinterpret_cast<su16x4*>(plane0 + plane_elems + off) = su16x4{a1[0], a1[1], a1[2], a1[3]};
 }
 template <int WF>
-__device__ __forceinline__ void sp_store4_wf(su16* plane0, int plane_elems, int off, const float4& v) {
-    if constexpr (WF == 2) sp_store4h(plane0, plane_elems, off, v);
+__device__ __forceinline__ void sp_store4_wf(su16* plane0, int plane_elems, int off, const float4& v, float& big) {
+    if constexpr (WF == 2) sp_store4h(plane0, plane_elems, off, v, big);
     else sp_store4(plane0, plane_elems, off, v);
 }
 
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
 
     float4 xq[2][4], skp[2][4];
     const int ch0 = 64 * w + 4 * h;
+    float big = 0.f;                    // pair format: the largest |activation| this lane has written as planes (checked once per evaluation)
 
     auto timed_out = [&]() -> bool { return __hip_atomic_load((gu32*)p.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; };
 
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                 for (int q = 0; q < 4; ++q) {
                     const int c = ch0 + 32 * mb + 8 * q;
                     const float4 d = *reinterpret_cast<const float4*>(dsl + c);
-                    sp_store4_wf<WF>(yp, kSpYPlane, (kHalo + j) * kSpRS + c, fm_add_masked(xq[mb][q], d, in_t));
+                    sp_store4_wf<WF>(yp, kSpYPlane, (kHalo + j) * kSpRS + c, fm_add_masked(xq[mb][q], d, in_t), big);
                 }
             __syncthreads();
             LOOP_STAMP(1);
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                     for (int g = 0; g < 2; ++g) {
                         const int f = 4 * g + (tid >> 6);
                         const int t = side ? t0 + 32 + f : t0 - kHalo + f;
-                        sp_store4_wf<WF>(yp, kSpYPlane, ((side ? kHalo + 32 : 0) + f) * kSpRS + c, fm_add_masked(hv[side][g], d, have && t < T));
+                        sp_store4_wf<WF>(yp, kSpYPlane, ((side ? kHalo + 32 : 0) + f) * kSpRS + c, fm_add_masked(hv[side][g], d, have && t < T), big);
                     }
                 }
             }
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                             const float vg = f4at(cpv[pr][q], ee), vf = f4at(cpv[pr + 2][q], ee);
                             g4[ee] = sigmoid_f(acc[pr][r] + vg) * tanh_f(acc[pr + 2][r] + vf);
                         }
-                        sp_store4_wf<WF>(gp, kSpGPlane, j * kSpRS + ch0 + 32 * pr + 8 * q, make_float4(g4[0], g4[1], g4[2], g4[3]));
+                        sp_store4_wf<WF>(gp, kSpGPlane, j * kSpRS + ch0 + 32 * pr + 8 * q, make_float4(g4[0], g4[1], g4[2], g4[3]), big);
                     }
             };
             LOOP_STAMP(3);
@@ -796,6 +799,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
         }
 
         // ---- head (net.py:126-129) + sampler epilogue + the next evaluation's input projection: the fp32 code of k_loop ---------------------
+        if constexpr (WF == 2) {
+            // range guard of the pair format: fp16 holds |x| <= 65504.  Loud like a timeout: the word makes every workgroup finish early and
+            // return NaN tiles, the host reports DSD_ERR_RANGE (k_latch_tmo, check_sticky)
+            if (!(big <= 65504.f)) __hip_atomic_fetch_or((gu32*)p.tmo, kLoopRangeBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         HeadParams hp = p.evals[e];
         const bool fuse = (e + 1 < p.n_evals);
         float* stile = ytile;               // [256][32]

@@ -38,7 +38,8 @@ typedef enum dsd_status {
     DSD_ERR_HIP = -2,          /* a HIP runtime call failed */
     DSD_ERR_STATE = -3,        /* call order violated (weights / schedule / prepare missing) */
     DSD_ERR_NOMEM = -4,
-    DSD_ERR_TIMEOUT = -5       /* a persistent K-step loop of an EARLIER call hit its inter-workgroup spin bound (see dsd_check) */
+    DSD_ERR_TIMEOUT = -5,      /* a persistent K-step loop of an EARLIER call hit its inter-workgroup spin bound (see dsd_check) */
+    DSD_ERR_RANGE = -6         /* split mode, pair format: an activation of an EARLIER call left fp16's range (|x| > 65504); reported like a timeout */
 } dsd_status;
 
 /* The hparams DiffNet reads at construction (usr/diff/net.py:85-90) + audio_num_mel_bins (:82). */

@@ -119,3 +119,36 @@ def test_the_weight_stream_variants_agree_bit_for_bit_and_their_rates(monkeypatc
         del gd, eng
     print('8 x 1024, K = 100, split loop by weight stream: ' + ', '.join(f'DSD_SPLIT_W={k}: {v:.1f} ms = {B * T / v * 1e3:.0f} mel-frames/s' for k, v in ms.items()))
     assert torch.equal(outs['0'], outs['4'])
+
+
+def test_pair_format_range_guard_is_loud(monkeypatch):
+    """fp16 holds |x| <= 65504.  An input that drives an activation beyond that in the pair format must not come back as a quiet inf / garbage
+    mel: the loop flags it, returns NaN tiles, and the engine raises (DSD_ERR_RANGE) - at the call itself with check=True.  The same input
+    on the bf16 planes (DSD_SPLIT_W=0, fp32's range) and on the fp32 loop is finite; the handle is usable afterwards."""
+    B, T, K = 8, 1024, 2
+    g = torch.Generator().manual_seed(3)
+    cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, generator=g)
+    noise = torch.randn(K, B, 1, 80, T, generator=g)
+    for stream, loud in (('2', True), ('0', False)):
+        monkeypatch.setenv('DSD_SPLIT_W', stream)
+        gd, cfg, pre = build_hip('lj_ds_beta6', K)
+        dcond = cond.transpose(1, 2).contiguous().cuda().transpose(1, 2)
+        dn = noise.cuda()
+        eng = gd._engine(dcond)
+        eng.set_split_mode(True)
+        try:
+            ok = gd.inference(dcond, x_T=x_T.cuda(), noise=dn, K_step=K, pndm_speedup=0, check=True)
+            assert torch.isfinite(ok).all() and eng.loop_mode() == 1
+            huge = (x_T * 3e6).cuda()                           # the input projection carries it into the residual stream: y ~ 1e5 - 1e6
+            if loud:
+                with pytest.raises(RuntimeError, match="fp16's range"):
+                    gd.inference(dcond, x_T=huge, noise=dn, K_step=K, pndm_speedup=0, check=True)
+                again = gd.inference(dcond, x_T=x_T.cuda(), noise=dn, K_step=K, pndm_speedup=0, check=True)
+                assert torch.equal(again, ok) and eng.loop_mode() == 1           # not parked: nothing was wrong with the loop
+            else:
+                out = gd.inference(dcond, x_T=huge, noise=dn, K_step=K, pndm_speedup=0, check=True)
+                assert torch.isfinite(out).all()
+        finally:
+            eng.set_split_mode(False)
+        del gd, eng
