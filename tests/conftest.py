@@ -14,9 +14,9 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no device is visible, e.g. a plain `pytest tests/` here.
-    Convention for kernels written while no GPU is at hand: their tests go to tests/test_gpu_zz_*.py, which stay out of the default
-    `-m gpu` run (a fault in a never-run kernel would take the whole verified suite's process down with it) until DSD_RUN_UNVERIFIED=1
-    is set; a module that has passed on the hardware is renamed into the default suite, one that fails is deleted with its kernels."""
+    Quarantine hook (no such module exists at present - every kernel in the tree has run on the hardware): tests of a kernel written while
+    no GPU is at hand may go to tests/test_gpu_zz_*.py, which stays out of the default `-m gpu` run (a fault in a never-run kernel would
+    take the whole verified suite's process down with it) until DSD_RUN_UNVERIFIED=1 is set."""
     if not os.environ.get('DSD_RUN_UNVERIFIED'):
         hold = pytest.mark.skip(reason='kernel not yet run on hardware: set DSD_RUN_UNVERIFIED=1')
         for item in items:
