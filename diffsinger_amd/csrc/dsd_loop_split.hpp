@@ -445,7 +445,8 @@ struct SplitPipeF {
     }
 };
 
-// which pipe a loop instantiation streams its weights through: WF = 0 the bf16 planes (3 stages), 4 fp32 split in registers (4 stages)
+// which pipe a loop instantiation streams its weights through: WF = 2 the pair format (4 stages), 0 the bf16 planes (3 stages), 4 fp32 split in
+// registers into those planes (4 stages)
 template <int WF, int NMB, int MB0, typename BOff>
 struct SplitPipeSel { typedef SplitPipeW<NMB, MB0, WF, BOff> type; };
 template <int NMB, int MB0, typename BOff>
@@ -501,11 +502,11 @@ __device__ __forceinline__ void sp_store4_wf(su16* plane0, int plane_elems, int 
 
 struct LoopSplitParams {
     LoopParams lp;              // everything k_loop takes (w1p / w2p unused here)
-    const uint4* w1c;           // conv weights, centre-first chunk order: fp32 [L][w4][48][mb4][2][lane64] (WF = 4), or (WF = 0) ALL weights of the loop
-                                // in consumption order [L][64 = 48 conv + 16 out-projection chunks][w4][12 KiB of planes]
-    const uint4* w2s;           // out-projection weights: fp32 [L][w4][16][mb4][2][lane64] (WF = 4), or (WF = 0) w1c + 48 chunks
-    unsigned wl_bytes;          // WF = 0: bytes of that buffer (the L2 touch's buffer bound)
-    int touch_ahead;            // WF = 0: chunks the L2 touch runs in front (0 = off)
+    const uint4* w1c;           // conv weights, centre-first chunk order: fp32 [L][w4][48][mb4][2][lane64] (WF = 4), or (WF = 0 / 2) ALL weights of the loop
+                                // in consumption order [L][64 = 48 conv + 16 out-projection chunks][w4][12 KiB of bf16 planes / 8 KiB of fp16 planes]
+    const uint4* w2s;           // out-projection weights: fp32 [L][w4][16][mb4][2][lane64] (WF = 4), or (WF = 0 / 2) w1c + 48 chunks
+    unsigned wl_bytes;          // WF = 0 / 2: bytes of that buffer (the L2 touch's buffer bound)
+    int touch_ahead;            // WF = 0 / 2: chunks the L2 touch runs in front (0 = off)
 };
 
 template <int MODE, int WF>
