@@ -89,9 +89,10 @@ def test_config2_against_the_fp32_and_the_fp64_oracle_and_rate(monkeypatch):
 
 
 def test_the_weight_stream_variants_agree_bit_for_bit_and_their_rates(monkeypatch):
-    """The loop streams its weights either as three bf16 planes (6 bytes per weight, DSD_SPLIT_W=0) or as fp32 split into the same planes in
-    registers beside the MFMAs (4 bytes, DSD_SPLIT_W=4, the default).  Same planes (round to nearest even, exact residuals), same
-    products in the same order per accumulator: the outputs must be IDENTICAL; only the time may differ."""
+    """The bf16-plane format streams its weights either as the three planes (6 bytes per weight, DSD_SPLIT_W=0; with the L2 touch) or as fp32
+    split into the same planes in registers beside the MFMAs (4 bytes, DSD_SPLIT_W=4).  Same planes (round to nearest even, exact
+    residuals), same products in the same order per accumulator: the outputs must be IDENTICAL; only the time may differ.  (The pair
+    format, DSD_SPLIT_W=2, is a different arithmetic: its tests compare against the oracles.)"""
     B, T, K = 8, 1024, 100
     g = torch.Generator().manual_seed(77)
     cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
