@@ -55,14 +55,22 @@ struct STileB {
 // them each (one dword per line, `buffer_load_dword ... lds` into a 256-byte scratch per wave: no destination register to keep alive),
 // `ahead` chunks in front of the chunk being multiplied: the window towards the L2 becomes ahead x 48 KiB for 6 instructions per chunk
 // and XCD.  The instruction is invisible to hipcc's vmcnt bookkeeping, which only makes its waits stricter (an unknown younger load).
-// Active when the launch has exactly 32 workgroups per XCD (the turn is a 7-bit counter) and ahead > 0.
+// Whose turn: instruction number n = per * chunk + t (t < per instructions per chunk) belongs to wave n mod nwx of the XCD's nwx waves
+// (4 x its workgroups: blockIdx & 7 is the XCD); a wave keeps r = (q - per * chunk) mod nwx as a running counter - one subtraction and one
+// wrap per step, any number of workgroups - and fetches when r < per.  Active with at least two workgroups per XCD and ahead > 0.
 struct L2Touch {
     typedef int i32x4_ __attribute__((ext_vector_type(4)));
     i32x4_ rs;                   // raw buffer over all layers' stream
-    unsigned q;                  // 4 * workgroup-in-XCD + wave: whose turn it is goes by (q - instructions-per-chunk * chunk) mod 128
-    int dis;                     // 0, or 128: never this wave's turn
+    int r, nwx, per;             // the running turn counter, the XCD's waves, instructions per chunk (0: off, r stays out of reach)
     unsigned ahead, gtot;        // chunks; chunks in the whole stream (64 per layer)
     unsigned lds, lane128;       // LDS byte address of this wave's scratch; lane * 128
+    // the turn of the step that starts now (a fetch is due when it is < per); steps come in stream order, one call each
+    __device__ __forceinline__ int next() {
+        const int t = r;
+        r -= per;
+        if (r < 0) r += nwx;
+        return t;
+    }
     __device__ __forceinline__ void issue(unsigned soff) const {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"                                  // "m0 is a reserved register": hipcc keeps nothing in it across statements
@@ -84,21 +92,21 @@ struct SplitPipeR {
     int n;
     BOff bof;
     int bplane;
-    L2Touch tc;
+    L2Touch& tc;
     unsigned gq;                 // index of this pipe's chunk 0 in the stream of all layers' chunks (64 per layer) + the touch's lead
     uint4 a[STAGES][NMB][3];
     sbf16x8 b[2][3];
 
     static __device__ __forceinline__ const uint4* wbase(const uint4* p, int l, int w, int) { return p + ((size_t)l * (64 * 4) + w) * 768; }
-    __device__ __forceinline__ SplitPipeR(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, const L2Touch& tc_, unsigned gbase_)
+    __device__ __forceinline__ SplitPipeR(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, L2Touch& tc_, unsigned gbase_)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u), n(n_), bof(bof_),
           bplane(bplane_), tc(tc_), gq(gbase_ + tc_.ahead) {}
     // L2 touch (see L2Touch): wave q of the XCD fetches 64 lines of the chunk `ahead` steps in front of everybody, when it is its turn
     __device__ __forceinline__ void touch(int kc) {
-        unsigned g = gq + (unsigned)kc;
-        const int t = (int)((tc.q - (unsigned)kTouchPer * g) & 127u) | tc.dis;
+        const int t = tc.next();
         if (t < kTouchPer) {
-            if (g >= tc.gtot) g -= tc.gtot;                                  // kTouchPer * gtot is a multiple of 128: the turn does not move
+            unsigned g = gq + (unsigned)kc;
+            if (g >= tc.gtot) g -= tc.gtot;                                  // (the counter runs on: every chunk stays covered exactly once)
             tc.issue(g * (unsigned)kChunkBytes + (unsigned)t * 8192u);
         }
     }
@@ -190,6 +198,7 @@ struct SplitPipeW {
     static_assert(NMB == 4 || NMB == 2, "row blocks are processed in pairs");
     static constexpr int P = (STAGES == 3) ? 6 : 4;
     static constexpr int kChunkU4 = 8 * 64;           // uint4 per chunk and wave
+    static constexpr int kTouchPer = 0;               // no L2 touch on this stream (the vector ALU bounds it)
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned aoff, aoff_hi;      // lane * 16 and + 4096: every load of a chunk = one of them + an immediate < 4096, ONE scalar offset per chunk
     int n;
@@ -200,7 +209,7 @@ struct SplitPipeW {
     sbf16x8 b[2][3];
 
     static __device__ __forceinline__ const uint4* wbase(const uint4* p, int l, int w, int nchunks) { return p + ((size_t)l * 4 + w) * nchunks * kChunkU4; }
-    __device__ __forceinline__ SplitPipeW(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, const L2Touch&, unsigned)
+    __device__ __forceinline__ SplitPipeW(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, L2Touch&, unsigned)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u),
           aoff_hi((unsigned)lane * 16u + 4096u), n(n_), bof(bof_), bplane(bplane_) {
         asm volatile("" : "+v"(aoff_hi));                                   // keep it a register: folded back, every load would need its own scalar add
@@ -343,14 +352,14 @@ struct SplitPipeF {
     int n;
     BOff bof;
     int bplane;
-    L2Touch tc;
+    L2Touch& tc;
     unsigned gq;
     uint4 a[S][NMB][2];
     sh8 b[2][2];
     f32x16 cross[NMB];           // h0 g1 + h1 g0, in units of 2^-11
 
     static __device__ __forceinline__ const uint4* wbase(const uint4* p, int l, int w, int) { return p + ((size_t)l * (64 * 4) + w) * (kBlockBytes / 16); }
-    __device__ __forceinline__ SplitPipeF(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, const L2Touch& tc_, unsigned gbase_)
+    __device__ __forceinline__ SplitPipeF(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, L2Touch& tc_, unsigned gbase_)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u), n(n_), bof(bof_),
           bplane(bplane_), tc(tc_), gq(gbase_ + tc_.ahead) {
 #pragma unroll
@@ -359,9 +368,9 @@ struct SplitPipeF {
             for (int r = 0; r < 16; ++r) cross[mb][r] = 0.f;
     }
     __device__ __forceinline__ void touch(int kc) {
-        unsigned g = gq + (unsigned)kc;
-        const int t = (int)((tc.q - (unsigned)kTouchPer * g) & 127u) | tc.dis;
+        const int t = tc.next();
         if (t < kTouchPer) {
+            unsigned g = gq + (unsigned)kc;
             if (g >= tc.gtot) g -= tc.gtot;
             tc.issue(g * (unsigned)kChunkBytes + (unsigned)t * 8192u);
         }
@@ -535,11 +544,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
     L2Touch tc;
     {
         const unsigned long long wb = (unsigned long long)ps.w1c;
-        const bool en = (WF == 0 || WF == 2) && ps.touch_ahead > 0 && (p.n_tiles & 7) == 0 && (p.n_tiles >> 3) == 32;
+        const int xcd = (int)(blockIdx.x & 7), nwx = 4 * ((p.n_tiles - xcd + 7) >> 3), q = 4 * (int)(blockIdx.x >> 3) + w;
+        const bool en = Pipe1::kTouchPer > 0 && ps.touch_ahead > 0 && nwx >= 8;
         tc.rs = L2Touch::i32x4_{(int)(unsigned)wb, (int)(unsigned)((wb >> 32) & 0xffffu), (int)ps.wl_bytes, 0x00020000};
         tc.ahead = (unsigned)ps.touch_ahead;
-        tc.q = (unsigned)(4 * (int)(blockIdx.x >> 3) + w);
-        tc.dis = en ? 0 : 128;
+        tc.nwx = nwx;
+        tc.per = en ? Pipe1::kTouchPer : 0;
+        if (en) {                                                // the first step multiplies chunk 0: its fetch is for chunk `ahead`
+            int r0 = (q - Pipe1::kTouchPer * ps.touch_ahead) % nwx;
+            tc.r = r0 < 0 ? r0 + nwx : r0;
+        } else tc.r = 1 << 20;
         tc.gtot = (unsigned)p.L * 64u;
         tc.lds = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float*)smem + (unsigned)w * 256u;
         tc.lane128 = (unsigned)lane * 128u;
