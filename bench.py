@@ -58,6 +58,9 @@ F_LAYER_REF = F_LAYER_EXEC + 2 * 512 * 256            # + the conditioner projec
 F_EVAL_REF = 26_427_392                               # reference GEMM FLOP / frame / denoiser evaluation
 L_LAYERS = 20
 F_EVAL_EXEC = (L_LAYERS - 1) * F_LAYER_EXEC + (F_LAYER_EXEC - 2 * 256 * 256) + 2 * (256 * 256 + 80 * 256 + 80 * 256)   # 21 053 440
+# Winograd F(2,3) form of the dilated convolution (csrc/dsd_loop_wino.hpp, the default of the persistent loop): four [512 x 256] x [256 x 16 pairs]
+# products per 32-frame tile instead of three [512 x 256] x [256 x 32] - 524 288 multiply-add FLOP / frame / layer instead of 786 432
+F_EVAL_EXEC_WINO = F_EVAL_EXEC - L_LAYERS * (2 * 512 * 768 - 4 * 2 * 512 * 256 // 2)      # 15 810 560
 PEAK_FP32_MFMA_TFLOPS = 157.3
 
 
@@ -654,6 +657,10 @@ def main():
                     help='--row fs2 A/B: kernel choice of the FastSpeech2 convolutions (-1 by grid size = the product, 0 never the K-split kernel, 1 always)')
     ap.add_argument('--chain', choices=['default', 'off', 'stage', 'resblock', 'pair'], default='default',
                     help='--row vocoder: how the ResBlock1 chains are launched (diffsinger_amd.vocoder.set_chain_mode); default = by channel count')
+    ap.add_argument('--conv', choices=['winograd', 'direct'], default=None,
+                    help='convolution of the persistent loop: winograd F(2,3) (the default of the library) or the direct K = 768 form (A/B, rounds 1-4)')
+    ap.add_argument('--touch', type=int, default=-1, help='A/B: steps the L2 touch of the Winograd weight stream runs in front (0 = off, -1 = library default)')
+    ap.add_argument('--stages', type=int, default=-1, help='A/B: register stages of the Winograd weight stream (4 / 8, -1 = library default)')
     ap.add_argument('--split', action='store_true', help='EXPERIMENT: residual layers as six bf16 plane products per fp32 product (fp32-class accuracy) '
                                                           'on the bf16 matrix pipe; per-layer kernel path; the JSON line says so in dtype / config')
     args = ap.parse_args()
@@ -797,6 +804,8 @@ def main_path(args):
         frames_per_step = CFG5_UTTS * T
     eng = gd._engine(cond)
     eng.set_layer_tile(args.tile)
+    if args.conv or args.touch >= 0 or args.stages > 0:
+        eng.set_conv_mode(args.conv or 'winograd', args.touch, args.stages)
     if args.split:
         eng.set_split_mode(True)
 
@@ -861,20 +870,30 @@ def main_path(args):
             launches = eng.loop_launches()
             ms_call = ev0.elapsed_time(ev1) / reps                           # the whole call: every k_loop launch of the batch
             ms = ms_call / launches
+            wino = eng.conv_mode() == 1 and not args.split
+            f_exec = F_EVAL_EXEC_WINO if wino else F_EVAL_EXEC
             # whole-call FLOPs over whole-call time (chunks of whole utterances: the last launch of a batch may cover fewer frames than the
             # others - a per-launch figure from frames // launches would mislabel an average); per-launch numbers are AVERAGES
-            flop = frames * K * F_EVAL_EXEC / launches
-            achieved = frames * K * F_EVAL_EXEC / (ms_call * 1e-3) / 1e12
+            flop = frames * K * f_exec / launches
+            achieved = frames * K * f_exec / (ms_call * 1e-3) / 1e12
             frames_l = frames / launches
-            kname = 'k_loop_split<1, %s>' % os.environ.get('DSD_SPLIT_W', '2') if args.split else 'k_loop<1>'
-            alg_bytes = int(K * (frames * (20 * 2048 + 2 * 320 + 320) + launches * L_LAYERS * 2 * 1024 * 1024 + frames // 32 * L_LAYERS * 2 * 16384) / launches)
+            kname = 'k_loop_split<1, %s>' % os.environ.get('DSD_SPLIT_W', '2') if args.split else 'k_loop_wino<1, 8>' if wino else 'k_loop<1>'
+            w_layer = (2 * 1024 * 1024 + 512 * 1024) if wino else 2 * 1024 * 1024      # weight stream of a layer: 4 (3) x 512 KiB of conv + 512 KiB of out-projection
+            alg_bytes = int(K * (frames * (20 * 2048 + 2 * 320 + 320) + launches * L_LAYERS * w_layer + frames // 32 * L_LAYERS * 2 * 16384) / launches)
             note = (f'one launch = the whole K=100 reverse loop (100 x (20 residual layers + head + sampler update + next input '
                     f'projection)) for a chunk of whole utterances; this batch of {B} x {T} = {launches} launch(es) of on average {frames_l:.0f} frames; '
-                    'achieved = executed fp32 FLOPs of the WHOLE call / its duration (HIP events on the launch stream), per-launch fields are '
-                    'averages; executed = 21 053 440 FLOP / frame / evaluation (conditioner projection hoisted, dead residual half of the last layer '
-                    'dropped); the duration includes two device copies of the spec tensor, a flag memset and the one-thread timeout latch around '
+                    'achieved = EXECUTED fp32 FLOPs of the WHOLE call / its duration (HIP events on the launch stream), per-launch fields are '
+                    + ('averages; executed = 15 810 560 FLOP / frame / evaluation: the dilated convolution as Winograd F(2,3) along the frame axis (four '
+                       'K = 256 products per output pair instead of six; fp32 in, exact-fp32 MFMA, fp32 transforms), conditioner projection hoisted, dead '
+                       'residual half of the last layer dropped; achieved_direct_accounting credits the 21 053 440 FLOP of the direct form (what rounds '
+                       '1-4 executed), '
+                       if wino else
+                       'averages; executed = 21 053 440 FLOP / frame / evaluation (direct K = 768 convolution, conditioner projection hoisted, dead residual '
+                       'half of the last layer dropped); ')
+                    + 'the duration includes two device copies of the spec tensor, a flag memset and the one-thread timeout latch around '
                     'the launches; *_ref_accounting credits the reference 26 427 392 FLOP / frame / evaluation')
             ref_acc = frames * K * F_EVAL_REF / (ms_call * 1e-3) / 1e12
+            direct_acc = frames * K * F_EVAL_EXEC / (ms_call * 1e-3) / 1e12
             frames_k = int(frames_l)
         else:
             ms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
@@ -906,6 +925,9 @@ def main_path(args):
                 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                 'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': ms, 'flop_per_launch': flop, 'achieved_ref_accounting': ref_acc, 'note': note}
+        if persistent:
+            roof['achieved_direct_accounting'] = direct_acc
+            roof['flop_per_frame_per_evaluation'] = f_exec
         if persistent and cfg == 2:         # the per-layer kernel of the fallback path, for comparison with earlier rounds
             eng.set_loop_mode(0)
             lms = eng.time_layer_kernel(layer=-1, t=50, iters=190)
@@ -926,7 +948,9 @@ def main_path(args):
                         f'sharded r::W across {world} GPU(s) in micro-batches of {B}, one RCCL gather of the mels to rank 0')
             conf = {'workload': workload, 'preset': PRESET, 'utterances_total': CFG5_UTTS, 'utterances_per_gpu': len(mine), 'frames': T, 'micro_batch': B}
         conf.update({'k_step': K, 'sampler': 'ddpm', 'layer_tile_frames': eng.layer_tile(),
-                     'loop': 'persistent kernel (k_loop)' if eng.loop_mode() == 1 else 'hipGraph of per-layer kernels',
+                     'loop': ('persistent kernel (k_loop_wino)' if eng.conv_mode() == 1 else 'persistent kernel (k_loop)') if eng.loop_mode() == 1
+                             else 'hipGraph of per-layer kernels',
+                     'conv': 'winograd F(2,3)' if eng.conv_mode() == 1 else 'direct',
                      'loop_parked': eng.parked(),
                      'timed_step': 'dsd_prepare (cond re-layout + hoisted conditioner projection, fresh cond every step) + K-step loop + denorm'
                                    + (' + gather' if world > 1 else ''),

@@ -8,7 +8,7 @@ import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdsdenoise.so')
 
-DSD_ABI_VERSION = 4
+DSD_ABI_VERSION = 5
 
 # every symbol include/dsd.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
@@ -17,7 +17,7 @@ SYMBOLS = [
     'dsd_sample_ddpm', 'dsd_p_sample', 'dsd_sample_plms', 'dsd_norm_spec', 'dsd_denorm_spec',
     'dsd_set_use_graph', 'dsd_set_layer_tile', 'dsd_time_layer_kernel', 'dsd_debug_layer_timeline', 'dsd_device_bytes',
     'dsd_get_layer_tile', 'dsd_set_loop_mode', 'dsd_get_loop_mode', 'dsd_loop_timeouts', 'dsd_debug_loop_timeline', 'dsd_set_noise_seed', 'dsd_philox_normal',
-    'dsd_set_split_mode', 'dsd_get_split_mode', 'dsd_debug_layer', 'dsd_loop_launches', 'dsd_p_sample_ex', 'dsd_set_lat_split', 'dsd_get_lat_split', 'dsd_set_rs_split', 'dsd_get_rs_split',
+    'dsd_set_split_mode', 'dsd_get_split_mode', 'dsd_debug_layer', 'dsd_loop_launches', 'dsd_p_sample_ex', 'dsd_set_lat_split', 'dsd_get_lat_split', 'dsd_set_conv_mode', 'dsd_get_conv_mode',
     'dsd_check', 'dsd_loop_parked', 'dsd_debug_hold_cus',
 ]
 # every symbol include/dsf.h declares (the FastSpeech2 conditioner ops)
@@ -112,8 +112,8 @@ def load():
     lib.dsd_debug_hold_cus.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.dsd_set_lat_split.argtypes = [h, C.c_int32]
     lib.dsd_get_lat_split.argtypes = [h]
-    lib.dsd_set_rs_split.argtypes = [h, C.c_int32]
-    lib.dsd_get_rs_split.argtypes = [h]
+    lib.dsd_set_conv_mode.argtypes = [h, C.c_int32, C.c_int32, C.c_int32]
+    lib.dsd_get_conv_mode.argtypes = [h]
     lib.dsd_p_sample_ex.argtypes = [h, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p]
     lib.dsd_set_split_mode.argtypes = [h, C.c_int32, C.c_void_p]
     lib.dsd_get_split_mode.argtypes = [h]

@@ -3,9 +3,9 @@
 #include "dsd_kernels.hpp"
 #include "dsd_loop.hpp"
 #include "dsd_lat.hpp"
-#include "dsd_loop_rs.hpp"
 #include "dsd_split.hpp"
 #include "dsd_loop_split.hpp"
+#include "dsd_loop_wino.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -129,10 +129,13 @@ struct dsd_handle {
     int loop_tmo_at = -1;             // index of the timeout word of the LAST persistent run inside loop_flags (its ntiles), -1: none yet
     unsigned long long* loop_dbg = nullptr;   // debug: stamps of one phase (dsd_debug_loop_timeline)
     int loop_dbg_phase = 0;
-    // row-split persistent loop (dsd_loop_rs.hpp): -1 by batch size (default), 0 never, 2 / 4 / 8 / 16 forced (dsd_set_rs_split)
-    int rs_req = 0;                   // (bring-up default: off until the GPU suite has run on it)
-    float* rs_ring = nullptr;         // the six exchange rings of the prepared batch, sentinel-filled before every launch
-    int rs_cap_tiles = 0;
+    // the dilated convolution of the PERSISTENT loop (dsd_loop_wino.hpp): 1 = Winograd F(2,3) along the frame axis (default), 0 = the direct
+    // K = 768 contraction (k_loop: bit-identical to the per-layer kernels).  Every other path evaluates the direct form.
+    int conv_mode = 1;
+    float4* w1w = nullptr;            // transformed conv weights U0..U3 of all layers in consumption order [L][128 steps][w4][r4][lane64]
+    int wino_touch = 16;              // steps (16 KiB each) the L2 touch of that stream runs in front, 0 = off
+    int wino_stages = 8;              // register stages of that stream (8 or 4)
+    bool cp_wino = false;             // layout of the prepared batch's cp: the Winograd loop's accumulator order, or the 32x32 fragment order
 
     // EXPERIMENT (dsd_split.hpp): residual layers on the bf16 matrix pipe with fp32-class accuracy; per-layer kernel path only
     bool split_mode = false;
@@ -140,10 +143,9 @@ struct dsd_handle {
     uint4* wlc = nullptr;                     // the planes once more for the persistent split loop (dsd_loop_split.hpp): a layer's 48 conv chunks (centre taps
                                               // first) + 16 out-projection chunks in consumption order, [L][64][wave 4][12 KiB]
     uint4* wl2 = nullptr;                     // the pair format of the split loop: two fp16 planes, consumption order [L][64][wave 4][8 KiB]
-    uint4 *w1f = nullptr, *w2f = nullptr;     // fp32 in 32x32x16 fragment order, [L][4][48|16][4][2][64] (the split loop that splits its weights in registers)
     int split_touch = 8;                      // plane stream of the split loop: chunks the L2 touch runs in front, 0 = off (DSD_SPLIT_TOUCH; dsd_loop_split.hpp)
     // format / weight stream of the split loop (DSD_SPLIT_W; dsd_loop_split.hpp): 2 = the PAIR format, two scaled fp16 planes and three products
-    // per product (default); 0 = three bf16 planes, six products; 4 = those planes split in registers from fp32 weights (bit-identical to 0)
+    // per product (default); 0 = three bf16 planes, six products (the cross-check stream)
     int split_w = 2;
 };
 
@@ -213,8 +215,8 @@ static void free_workspace(dsd_handle* h) {
     dev_free(h->xs); dev_free(h->xtmp); dev_free(h->gbuf);
     for (auto& e : h->ering) dev_free(e);
     dev_free(h->t_dev); dev_free(h->coef_dev); dev_free(h->eps_tmp);
-    dev_free(h->loop_flags); dev_free(h->loop_halo); dev_free(h->rs_ring);
-    h->loop_cap_tiles = 0; h->rs_cap_tiles = 0;
+    dev_free(h->loop_flags); dev_free(h->loop_halo);
+    h->loop_cap_tiles = 0;
     h->loop_tmo_at = -1;
     h->xa = h->xb = nullptr;
     h->cap_frames = 0; h->cap_B = 0; h->cap_spec = 0;
@@ -253,8 +255,11 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     if (const char* ev = std::getenv("DSD_LOOP")) h->loop_mode = std::atoi(ev);     // the same choice as dsd_set_loop_mode, for an unmodified host
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
     if (const char* ev = std::getenv("DSD_SPLIT_TOUCH")) { const int v = std::atoi(ev); if (v >= 0 && v <= 20) h->split_touch = v; }
-    if (const char* ev = std::getenv("DSD_SPLIT_W")) { const int v = std::atoi(ev); if (v == 0 || v == 2 || v == 4) h->split_w = v; }
-    if (const char* ev = std::getenv("DSD_RS")) h->rs_req = std::atoi(ev);                   // the same choice as dsd_set_rs_split
+    if (const char* ev = std::getenv("DSD_SPLIT_W")) { const int v = std::atoi(ev); if (v == 0 || v == 2) h->split_w = v; }
+    if (const char* ev = std::getenv("DSD_CONV")) {                                           // the same choice as dsd_set_conv_mode
+        if (!std::strcmp(ev, "direct") || !std::strcmp(ev, "0")) h->conv_mode = 0;
+        else if (!std::strcmp(ev, "winograd") || !std::strcmp(ev, "1")) h->conv_mode = 1;
+    }
     for (int l = 0; l < h->L; ++l) {
         const int e = l % cfg->dilation_cycle_length;
         if (e > 3) { delete h; return fail(DSD_ERR_INVALID, "dsd_create: dilation 2^%d exceeds the supported maximum %d", e, kHalo); }
@@ -271,14 +276,10 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_rs<2, HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_rs<4, HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_rs<8, HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_rs<16, HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_rs<2, HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_rs<4, HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_rs<8, HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_rs<16, HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_DDPM, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_PLMS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_DDPM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_PLMS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -295,7 +296,7 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     free_workspace(h);
-    dev_free(h->w1s); dev_free(h->w2s); dev_free(h->wlc); dev_free(h->wl2); dev_free(h->w1f); dev_free(h->w2f);
+    dev_free(h->w1s); dev_free(h->w2s); dev_free(h->wlc); dev_free(h->wl2); dev_free(h->w1w);
     dev_free(h->w1q); dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->bskp); dev_free(h->b2raw); dev_free(h->bsum);
     dev_free(h->winp); dev_free(h->binp); dev_free(h->wsp); dev_free(h->bsp); dev_free(h->woutp); dev_free(h->boutp);
     dev_free(h->mlp0_w); dev_free(h->mlp0_b); dev_free(h->mlp2_w); dev_free(h->mlp2_b); dev_free(h->dp_w); dev_free(h->dp_b);
@@ -476,6 +477,8 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
         DSD_TRY(dev_alloc(h, &h->w1p, (size_t)L * 4 * 96 * 256 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->w1q, (size_t)L * 16 * 96 * 64 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->w2p, (size_t)L * 4 * 32 * 256 + kWeightSlack));
+        DSD_TRY(dev_alloc(h, &h->w1w, (size_t)L * kWnSteps * (kWnStepBytes / 16) + kWeightSlack));
+        HIP_TRY(hipMemsetAsync(h->w1w + (size_t)L * kWnSteps * (kWnStepBytes / 16), 0, (size_t)kWeightSlack * 16, s));
         DSD_TRY(dev_alloc(h, &h->wcp, (size_t)L * 4 * 32 * 256 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->b1p, (size_t)L * 4 * 4 * 8));
         DSD_TRY(dev_alloc(h, &h->bskp, (size_t)4 * 2 * 8));
@@ -503,6 +506,7 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
         // gate rows [0,C) / filter rows [C,2C) split across waves so each wave owns matching pairs
         DSD_TRY(pack_a(s, w->dilated_conv_w[l], h->w1p + (size_t)l * 4 * 96 * 256, 4, 3, 32, 4, 1, kC, 2 * kC, kC, 3 * kC, 3));
         DSD_TRY(pack_a(s, w->dilated_conv_w[l], h->w1q + (size_t)l * 16 * 96 * 64, 16, 3, 32, 1, 2, kC, 2 * kC, kC, 3 * kC, 3));
+        hipLaunchKernelGGL(k_pack_wino, dim3(1024), dim3(256), 0, s, w->dilated_conv_w[l], reinterpret_cast<float*>(h->w1w + (size_t)l * kWnSteps * (kWnStepBytes / 16)));
         DSD_TRY(pack_a(s, w->conditioner_projection_w[l], h->wcp + (size_t)l * 4 * 32 * 256, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1));
         DSD_TRY(pack_a(s, w->output_projection_w[l], h->w2p + (size_t)l * 4 * 32 * 256, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1));
         DSD_TRY(pack_bias(s, w->dilated_conv_b[l], w->conditioner_projection_b[l], h->b1p + (size_t)l * 128, 4, 4, 1, kC, 2 * kC));
@@ -597,6 +601,23 @@ extern "C" int dsd_set_spec_range(dsd_handle* h, const float* spec_min, const fl
 // ------------------------------------------------------------------------------------------------------------
 // prepare: workspace + hoisted conditioner projection
 // ------------------------------------------------------------------------------------------------------------
+static bool wino_applicable(const dsd_handle* h);
+
+// cp[l] = Wc_l cond + bc_l + bd_l of the prepared batch (condT stays in the workspace), in the 32x32 fragment order every per-layer / latency
+// kernel and k_loop read - or in the accumulator order of the Winograd loop (dsd_loop_wino.hpp)
+static int launch_condproj(dsd_handle* h, bool wino, hipStream_t s) {
+    CondProjParams p{h->condT, h->wcp, h->b1p, h->cp, h->TS, h->ntile32, h->ntiles, wino ? 1 : 0, {}};
+    for (int l = 0; l < h->L; ++l) p.dil[l] = (unsigned char)h->dil[l];
+    hipLaunchKernelGGL(k_condproj, dim3((unsigned)h->ntiles, h->L), dim3(kThreads), kC * 32 * 4, s, p);
+    HIP_TRY(hipGetLastError());
+    h->cp_wino = wino;
+    return DSD_OK;
+}
+// called (outside any capture) in front of every consumer of cp: re-lays it when the batch was prepared for the other convolution
+static int ensure_cp(dsd_handle* h, bool wino, hipStream_t s) {
+    return (h->cp_wino == wino) ? DSD_OK : launch_condproj(h, wino, s);
+}
+
 extern "C" int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* cond, int64_t sb, int64_t sh, int64_t st, void* stream) {
     if (!h || !cond) return fail(DSD_ERR_INVALID, "dsd_prepare: null argument");
     if (!h->has_weights) return fail(DSD_ERR_STATE, "dsd_prepare: call dsd_load_weights first");
@@ -633,11 +654,9 @@ extern "C" int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* con
 
     hipLaunchKernelGGL(k_cond_layout, dim3(ntile32, kC / 32, B), dim3(32, 8), 0, s, cond, h->condT, kC, T, TS, sb, sh, st);
     HIP_TRY(hipGetLastError());
-    CondProjParams p{h->condT, h->wcp, h->b1p, h->cp, TS, ntile32, (int)ntiles};
-    hipLaunchKernelGGL(k_condproj, dim3((unsigned)ntiles, h->L), dim3(kThreads), kC * 32 * 4, s, p);
-    HIP_TRY(hipGetLastError());
     h->prepared = true;
-    return DSD_OK;
+    // the hoisted conditioner projection in the accumulator order of the path this batch will take (a later switch of path re-lays it: ensure_cp)
+    return launch_condproj(h, wino_applicable(h), s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -791,6 +810,7 @@ extern "C" int dsd_denoise(dsd_handle* h, const float* x, const int32_t* t, floa
         DSD_TRY(pin_release(h, slot, s));
         t_dev = h->t_dev;
     }
+    DSD_TRY(ensure_cp(h, false, s));
     DSD_TRY(launch_inproj(h, x, s));
     DSD_TRY(launch_stack(h, t[0], t_dev, s));
     HeadParams p = head_base(h);
@@ -958,14 +978,12 @@ static hipEvent_t g_loop_ev[kMaxDevices];
 static hipStream_t g_loop_stream[kMaxDevices];
 static bool g_loop_has[kMaxDevices];
 
-static int rs_g(const dsd_handle* h);
-
 // true when the prepared batch can run as the persistent loop: 32-frame tiles, a whole utterance fits the co-resident grid
 static bool loop_applicable(const dsd_handle* h) {
     if (!((h->loop_mode == 1 || h->loop_mode == 2) && !h->persist_off && h->use_graph && layer_nb(h) == 1 && h->n_cu >= 8 &&
           h->ntile32 <= h->n_cu && h->L <= kLoopMaxLayers)) return false;
     if (h->loop_mode == 2) {
-        if (rs_g(h) || lat_g(h)) return false;
+        if (lat_g(h)) return false;
         // chunks of whole utterances may leave much of the chip idle (T = 5000: 157 tiles per launch on 256 CUs); the per-layer kernels
         // have no such constraint, only the wave quantisation of their grid, and cost ~5 % more at equal occupancy
         const int upc = std::max(1, h->n_cu / h->ntile32), chunks = (h->B + upc - 1) / upc;
@@ -975,6 +993,9 @@ static bool loop_applicable(const dsd_handle* h) {
     }
     return true;
 }
+
+// the prepared batch takes the persistent loop AND that loop evaluates the dilated convolution as Winograd F(2,3) (dsd_loop_wino.hpp)
+static bool wino_applicable(const dsd_handle* h) { return h->conv_mode == 1 && !h->split_mode && h->w1w && loop_applicable(h); }
 
 static int get_plan(dsd_handle* h, int kind, int k_step, int interval, dsd_handle::LoopPlan** out);
 
@@ -989,6 +1010,8 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
         h->loop_cap_tiles = h->ntiles;
     }
     HIP_TRY(hipMemsetAsync(h->loop_flags, 0, ((size_t)h->ntiles + 64) * sizeof(unsigned), s));
+    const bool wino = wino_applicable(h);
+    DSD_TRY(ensure_cp(h, wino, s));
     LoopParams p{};
     p.w1p = h->w1p; p.w2p = h->w2p; p.b2raw = h->b2raw; p.cp = h->cp; p.cp_lstride = (size_t)h->ntiles * 4096;
     p.ds_table = h->ds_table;
@@ -1016,16 +1039,22 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
         p.tile_base = b0 * h->ntile32; p.n_tiles = nb * h->ntile32;
         if (h->split_mode) {
             // EXPERIMENT (dsd_loop_split.hpp): the same loop with the layers' contractions as six bf16 plane products per fp32 product
-            const LoopSplitParams q = h->split_w == 4 ? LoopSplitParams{p, h->w1f, h->w2f, 0u, 0}
-                                      : h->split_w == 2 ? LoopSplitParams{p, h->wl2, h->wl2 + (size_t)48 * 4 * 512, (unsigned)((size_t)h->L * 64 * 4 * 8192), h->split_touch}
+            const LoopSplitParams q = h->split_w == 2 ? LoopSplitParams{p, h->wl2, h->wl2 + (size_t)48 * 4 * 512, (unsigned)((size_t)h->L * 64 * 4 * 8192), h->split_touch}
                                                         : LoopSplitParams{p, h->wlc, h->wlc + (size_t)48 * 4 * 768, (unsigned)((size_t)h->L * 64 * 4 * 12288), h->split_touch};
             const dim3 grid((unsigned)p.n_tiles), block(kThreads);
 #define DSD_LAUNCH_SPLIT(WF) do { if (kind == 0) hipLaunchKernelGGL((k_loop_split<HEAD_DDPM, WF>), grid, block, kLoopSplitLdsBytes, s, q); \
                                   else hipLaunchKernelGGL((k_loop_split<HEAD_PLMS, WF>), grid, block, kLoopSplitLdsBytes, s, q); } while (0)
-            if (h->split_w == 4) DSD_LAUNCH_SPLIT(4);
-            else if (h->split_w == 2) DSD_LAUNCH_SPLIT(2);
+            if (h->split_w == 2) DSD_LAUNCH_SPLIT(2);
             else DSD_LAUNCH_SPLIT(0);
 #undef DSD_LAUNCH_SPLIT
+        } else if (wino) {
+            // Winograd F(2,3) form of the dilated convolution (dsd_loop_wino.hpp): the default of this path
+            const LoopWinoParams q{p, h->w1w, (unsigned)((size_t)h->L * kWnSteps * kWnStepBytes), h->wino_touch};
+            const dim3 grid((unsigned)p.n_tiles), block(kThreads);
+#define DSD_LAUNCH_WINO(ST) do { if (kind == 0) hipLaunchKernelGGL((k_loop_wino<HEAD_DDPM, ST>), grid, block, kLoopWinoLdsBytes, s, q); \
+                                 else hipLaunchKernelGGL((k_loop_wino<HEAD_PLMS, ST>), grid, block, kLoopWinoLdsBytes, s, q); } while (0)
+            if (h->wino_stages == 4) DSD_LAUNCH_WINO(4); else DSD_LAUNCH_WINO(8);
+#undef DSD_LAUNCH_WINO
         } else if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         else hipLaunchKernelGGL((k_loop<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         HIP_TRY(hipGetLastError());
@@ -1039,30 +1068,6 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
         g_loop_has[dv] = true;
     }
     return DSD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// row-split persistent loop (dsd_loop_rs.hpp)
-// ------------------------------------------------------------------------------------------------------------
-// G of the row-split persistent loop for the prepared batch, 0 = not on that path.  It takes the batches the latency kernels were built for -
-// ntiles * G <= CU count with G in {16, 8, 4, 2}, i.e. batches that leave at least half of the chip idle (the reference's own inference shape: one
-// utterance per device) - as ONE launch instead of 43 hipGraph nodes per evaluation.  Like every persistent path it needs hipGraph mode on (the
-// switch tests use to reach the eager per-layer kernels), automatic loop mode, and a handle that is not parked after a reported timeout.
-static int rs_g(const dsd_handle* h) {
-    if (h->rs_req == 0 || h->loop_mode != 2 || h->persist_off || h->split_mode || h->layer_tile_req || !h->use_graph || h->lat_req >= 0) return 0;
-    if (h->L < 2 || h->L > kLoopMaxLayers || h->n_cu < 8) return 0;
-    int g = (16 * h->ntiles <= h->n_cu) ? 16 : (8 * h->ntiles <= h->n_cu) ? 8 : (4 * h->ntiles <= h->n_cu) ? 4 : (2 * h->ntiles <= h->n_cu) ? 2 : 0;
-    if (g && h->rs_req > 0) g = (h->rs_req * h->ntiles <= h->n_cu) ? h->rs_req : 0;
-    return g;
-}
-
-static size_t rs_ring_floats(int ntiles) { return (size_t)ntiles * 3 * (5 * 32 * kC + 32 * kMPad); }
-
-template <int G>
-static void launch_rs(int kind, const RsParams& p, hipStream_t s) {
-    const dim3 grid((unsigned)lat_grid(p.ntiles, G));
-    if (kind == 0) hipLaunchKernelGGL((k_loop_rs<G, HEAD_DDPM>), grid, dim3(kThreads), kRsLdsBytes, s, p);
-    else hipLaunchKernelGGL((k_loop_rs<G, HEAD_PLMS>), grid, dim3(kThreads), kRsLdsBytes, s, p);
 }
 
 static int get_plan(dsd_handle* h, int kind, int k_step, int interval, dsd_handle::LoopPlan** out) {
@@ -1084,60 +1089,6 @@ static int get_plan(dsd_handle* h, int kind, int k_step, int interval, dsd_handl
     return DSD_OK;
 }
 
-static int run_rs(dsd_handle* h, int G, int kind, int k_step, int interval, hipStream_t s) {
-    dsd_handle::LoopPlan* plan = nullptr;
-    DSD_TRY(get_plan(h, kind, k_step, interval, &plan));
-    if (h->loop_cap_tiles < h->ntiles) {
-        dev_free(h->loop_flags); dev_free(h->loop_halo);
-        h->loop_tmo_at = -1;
-        DSD_TRY(dev_alloc(h, &h->loop_flags, (size_t)h->ntiles + 64, true));
-        DSD_TRY(dev_alloc(h, &h->loop_halo, (size_t)2 * h->ntiles * 2 * kC * 8, true));
-        h->loop_cap_tiles = h->ntiles;
-    }
-    if (h->rs_cap_tiles < h->ntiles) {
-        dev_free(h->rs_ring);
-        DSD_TRY(dev_alloc(h, &h->rs_ring, rs_ring_floats(h->ntiles), true));
-        h->rs_cap_tiles = h->ntiles;
-    }
-    // every polled word starts as "not arrived" (sentinel), the timeout word as zero: re-initialised before EVERY launch
-    HIP_TRY(hipMemsetAsync(h->rs_ring, 0xff, rs_ring_floats(h->ntiles) * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(h->loop_flags, 0, ((size_t)h->ntiles + 64) * sizeof(unsigned), s));
-    RsParams p{};
-    p.w1p = h->w1p; p.w1q = h->w1q; p.w2p = h->w2p; p.b2raw = h->b2raw; p.cp = h->cp; p.cp_lstride = (size_t)h->ntiles * 4096;
-    p.ds_table = h->ds_table;
-    p.L = h->L; p.T = h->T; p.TS = h->TS; p.ntile32 = h->ntile32; p.ntiles = h->ntiles;
-    for (int l = 0; l < h->L; ++l) p.dil[l] = (unsigned char)h->dil[l];
-    p.head = head_base(h);
-    p.evals = plan->evals; p.eval_t = plan->eval_t; p.n_evals = plan->n_evals;
-    p.spec0 = h->xs;
-    const size_t slot = (size_t)h->ntiles * 3 * 32 * kC;
-    p.xb = h->rs_ring; p.x0b = p.xb + slot; p.gb = p.x0b + slot; p.sb = p.gb + slot; p.hb = p.sb + slot; p.pb = p.hb + slot;
-    p.tmo = h->loop_flags + h->ntiles;
-    h->loop_tmo_at = h->ntiles;
-    p.dbg = h->loop_dbg; p.dbg_phase = h->loop_dbg_phase;
-    // one persistent launch at a time per device (see run_persistent)
-    const int dv = (h->device >= 0 && h->device < kMaxDevices) ? h->device : 0;
-    std::lock_guard<std::mutex> guard(g_loop_mu[dv]);
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cap);
-    const bool guarded = (cap == hipStreamCaptureStatusNone);
-    if (guarded) {
-        if (!g_loop_ev[dv]) HIP_TRY(hipEventCreateWithFlags(&g_loop_ev[dv], hipEventDisableTiming));
-        if (g_loop_has[dv] && g_loop_stream[dv] != s) HIP_TRY(hipStreamWaitEvent(s, g_loop_ev[dv], 0));
-    }
-    if (G == 16) launch_rs<16>(kind, p, s); else if (G == 8) launch_rs<8>(kind, p, s); else if (G == 4) launch_rs<4>(kind, p, s); else launch_rs<2>(kind, p, s);
-    HIP_TRY(hipGetLastError());
-    DSD_TRY(sticky_alloc(h));
-    hipLaunchKernelGGL(k_latch_tmo, dim3(1), dim3(1), 0, s, (const unsigned*)p.tmo, h->sticky_dev);
-    HIP_TRY(hipGetLastError());
-    if (guarded) {
-        HIP_TRY(hipEventRecord(g_loop_ev[dv], s));
-        g_loop_stream[dv] = s;
-        g_loop_has[dv] = true;
-    }
-    return DSD_OK;
-}
-
 static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k_step, int interval, hipStream_t s) {
     const size_t bmt = (size_t)h->B * h->M * h->T;
     HIP_TRY(hipMemcpyAsync(h->xs, x, bmt * 4, hipMemcpyDeviceToDevice, s));
@@ -1146,13 +1097,13 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
         if (!noise) hipLaunchKernelGGL(k_set_seed, dim3(1), dim3(1), 0, s, h->seed_cell, h->noise_seed);
         HIP_TRY(hipGetLastError());
     }
-    if (const int G = rs_g(h)) {
-        DSD_TRY(run_rs(h, G, kind, k_step, interval, s));
-    } else if (loop_applicable(h)) {
+    if (loop_applicable(h)) {
         DSD_TRY(run_persistent(h, kind, k_step, interval, s));
     } else if (!h->use_graph) {
+        DSD_TRY(ensure_cp(h, false, s));
         DSD_TRY(kind == 0 ? enqueue_ddpm(h, k_step, s) : enqueue_plms(h, k_step, interval, s));
     } else {
+        DSD_TRY(ensure_cp(h, false, s));
         const GraphKey key{kind, h->B, h->T, k_step, interval, layer_nb(h) + 100 * lat_g(h)};
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
@@ -1198,47 +1149,44 @@ static void split_kernel_attrs() {
 #define DSD_SPLIT_ATTR(WF) do { \
             (void)hipFuncSetAttribute((const void*)k_loop_split<HEAD_DDPM, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopSplitLdsBytes); \
             (void)hipFuncSetAttribute((const void*)k_loop_split<HEAD_PLMS, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopSplitLdsBytes); } while (0)
-        DSD_SPLIT_ATTR(0); DSD_SPLIT_ATTR(2); DSD_SPLIT_ATTR(4);
+        DSD_SPLIT_ATTR(0); DSD_SPLIT_ATTR(2);
 #undef DSD_SPLIT_ATTR
     }
 }
 
-// bf16 weight planes of the split-precision layer kernel, derived on the device from the fp32 fragment-order weights
+// Weight planes of the split-precision kernels, derived on the device from the fp32 fragment-order weights: the bf16 planes of the per-layer
+// kernel (w1s / w2s) and ONE stream for the persistent split loop - the format split_w selects (the pair format, or the bf16 planes in
+// consumption order); the other one is packed only if the format is switched (DSD_SPLIT_W at dsd_create).
 static int pack_split_planes(dsd_handle* h, hipStream_t s) {
     const int L = h->L;
     if (!h->w1s) {
         DSD_TRY(dev_alloc(h, &h->w1s, (size_t)L * 4 * 48 * 12 * 64 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->w2s, (size_t)L * 4 * 16 * 12 * 64 + kWeightSlack));
-        DSD_TRY(dev_alloc(h, &h->wlc, (size_t)L * 64 * 4 * 768 + kWeightSlack));
-        HIP_TRY(hipMemsetAsync(h->wlc + (size_t)L * 64 * 4 * 768, 0, (size_t)kWeightSlack * 16, s));
         HIP_TRY(hipMemsetAsync(h->w1s + (size_t)L * 4 * 48 * 12 * 64, 0, (size_t)kWeightSlack * 16, s));
         HIP_TRY(hipMemsetAsync(h->w2s + (size_t)L * 4 * 16 * 12 * 64, 0, (size_t)kWeightSlack * 16, s));
+    }
+    if (h->split_w == 2 && !h->wl2) {
         DSD_TRY(dev_alloc(h, &h->wl2, (size_t)L * 64 * 4 * 512 + kWeightSlack));
         HIP_TRY(hipMemsetAsync(h->wl2 + (size_t)L * 64 * 4 * 512, 0, (size_t)kWeightSlack * 16, s));
-        DSD_TRY(dev_alloc(h, &h->w1f, (size_t)L * 4 * 48 * 8 * 64 + kWeightSlack));
-        DSD_TRY(dev_alloc(h, &h->w2f, (size_t)L * 4 * 16 * 8 * 64 + kWeightSlack));
-        HIP_TRY(hipMemsetAsync(h->w1f + (size_t)L * 4 * 48 * 8 * 64, 0, (size_t)kWeightSlack * 16, s));
-        HIP_TRY(hipMemsetAsync(h->w2f + (size_t)L * 4 * 16 * 8 * 64, 0, (size_t)kWeightSlack * 16, s));
+    }
+    if (h->split_w == 0 && !h->wlc) {
+        DSD_TRY(dev_alloc(h, &h->wlc, (size_t)L * 64 * 4 * 768 + kWeightSlack));
+        HIP_TRY(hipMemsetAsync(h->wlc + (size_t)L * 64 * 4 * 768, 0, (size_t)kWeightSlack * 16, s));
     }
     for (int l = 0; l < L; ++l) {
-        hipLaunchKernelGGL((k_pack_split<false>), dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256),
-                           reinterpret_cast<su16*>(h->w1s + (size_t)l * 4 * 48 * 12 * 64), 4, 16, 3, 0, 0LL, 0LL);
-        su16* lc = reinterpret_cast<su16*>(h->wlc + (size_t)l * 64 * 4 * 768);          // consumption order: chunk stride 4 x 6144, wave stride 6144
-        hipLaunchKernelGGL((k_pack_split<false>), dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256), lc, 4, 16, 3, 1,
-                           6144LL, 4 * 6144LL);
-        hipLaunchKernelGGL((k_pack_split<false>), dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256), lc + (size_t)48 * 4 * 6144,
-                           4, 16, 1, 0, 6144LL, 4 * 6144LL);
-        hipLaunchKernelGGL((k_pack_split<false>), dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256),
-                           reinterpret_cast<su16*>(h->w2s + (size_t)l * 4 * 16 * 12 * 64), 4, 16, 1, 0, 0LL, 0LL);
-        su16* l2 = reinterpret_cast<su16*>(h->wl2 + (size_t)l * 64 * 4 * 512);          // pair format: chunk stride 4 x 4096, wave stride 4096
-        hipLaunchKernelGGL((k_pack_split<true>), dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256), l2, 4, 16, 3, 1,
-                           4096LL, 4 * 4096LL);
-        hipLaunchKernelGGL((k_pack_split<true>), dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256), l2 + (size_t)48 * 4 * 4096,
-                           4, 16, 1, 0, 4096LL, 4 * 4096LL);
-        hipLaunchKernelGGL(k_pack_split_f32, dim3(1024), dim3(256), 0, s, reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256),
-                           reinterpret_cast<float*>(h->w1f + (size_t)l * 4 * 48 * 8 * 64), 4, 16, 3, 1);
-        hipLaunchKernelGGL(k_pack_split_f32, dim3(512), dim3(256), 0, s, reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256),
-                           reinterpret_cast<float*>(h->w2f + (size_t)l * 4 * 16 * 8 * 64), 4, 16, 1, 0);
+        const float* w1 = reinterpret_cast<const float*>(h->w1p + (size_t)l * 4 * 96 * 256);
+        const float* w2 = reinterpret_cast<const float*>(h->w2p + (size_t)l * 4 * 32 * 256);
+        hipLaunchKernelGGL((k_pack_split<false>), dim3(1024), dim3(256), 0, s, w1, reinterpret_cast<su16*>(h->w1s + (size_t)l * 4 * 48 * 12 * 64), 4, 16, 3, 0, 0LL, 0LL);
+        hipLaunchKernelGGL((k_pack_split<false>), dim3(512), dim3(256), 0, s, w2, reinterpret_cast<su16*>(h->w2s + (size_t)l * 4 * 16 * 12 * 64), 4, 16, 1, 0, 0LL, 0LL);
+        if (h->split_w == 0) {
+            su16* lc = reinterpret_cast<su16*>(h->wlc + (size_t)l * 64 * 4 * 768);       // consumption order: chunk stride 4 x 6144, wave stride 6144
+            hipLaunchKernelGGL((k_pack_split<false>), dim3(1024), dim3(256), 0, s, w1, lc, 4, 16, 3, 1, 6144LL, 4 * 6144LL);
+            hipLaunchKernelGGL((k_pack_split<false>), dim3(512), dim3(256), 0, s, w2, lc + (size_t)48 * 4 * 6144, 4, 16, 1, 0, 6144LL, 4 * 6144LL);
+        } else {
+            su16* l2 = reinterpret_cast<su16*>(h->wl2 + (size_t)l * 64 * 4 * 512);       // pair format: chunk stride 4 x 4096, wave stride 4096
+            hipLaunchKernelGGL((k_pack_split<true>), dim3(1024), dim3(256), 0, s, w1, l2, 4, 16, 3, 1, 4096LL, 4 * 4096LL);
+            hipLaunchKernelGGL((k_pack_split<true>), dim3(512), dim3(256), 0, s, w2, l2 + (size_t)48 * 4 * 4096, 4, 16, 1, 0, 4096LL, 4 * 4096LL);
+        }
     }
     HIP_TRY(hipGetLastError());
     return DSD_OK;
@@ -1271,6 +1219,7 @@ extern "C" int dsd_debug_layer(dsd_handle* h, int32_t layer, int32_t t, const fl
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     DSD_TRY(build_step_table(h, t + 1, s));
+    DSD_TRY(ensure_cp(h, false, s));
     float* xin = (layer & 1) ? h->xb : h->xa;
     float* xout = (layer & 1) ? h->xa : h->xb;
     hipLaunchKernelGGL(k_dbg_to_tiles, dim3((unsigned)h->ntiles), dim3(256), 0, s, const_cast<float*>(x_in), xin, h->TS, h->ntile32, 1);
@@ -1301,16 +1250,20 @@ extern "C" int dsd_set_lat_split(dsd_handle* h, int32_t g) {
     return DSD_OK;
 }
 
-extern "C" int dsd_get_lat_split(dsd_handle* h) { return (h && h->prepared && !rs_g(h)) ? lat_g(h) : 0; }
+extern "C" int dsd_get_lat_split(dsd_handle* h) { return (h && h->prepared) ? lat_g(h) : 0; }
 
-extern "C" int dsd_set_rs_split(dsd_handle* h, int32_t g) {
-    if (!h || !(g == -1 || g == 0 || g == 2 || g == 4 || g == 8 || g == 16))
-        return fail(DSD_ERR_INVALID, "dsd_set_rs_split: g must be -1 (by batch size), 0 (never), 2, 4, 8 or 16");
-    h->rs_req = g;
+extern "C" int dsd_set_conv_mode(dsd_handle* h, int32_t mode, int32_t touch_ahead, int32_t stages) {
+    if (!h || mode < 0 || mode > 1) return fail(DSD_ERR_INVALID, "dsd_set_conv_mode: mode must be 0 (direct K = 768 contraction) or 1 (Winograd F(2,3))");
+    if (touch_ahead < -1 || touch_ahead > 64) return fail(DSD_ERR_INVALID, "dsd_set_conv_mode: touch_ahead must be -1 (keep), 0 (off) .. 64 steps");
+    if (!(stages == -1 || stages == 4 || stages == 8)) return fail(DSD_ERR_INVALID, "dsd_set_conv_mode: stages must be -1 (keep), 4 or 8");
+    h->conv_mode = mode;
+    if (touch_ahead >= 0) h->wino_touch = touch_ahead;
+    if (stages > 0) h->wino_stages = stages;
     return DSD_OK;
 }
 
-extern "C" int dsd_get_rs_split(dsd_handle* h) { return (h && h->prepared) ? rs_g(h) : 0; }
+// 1 when the prepared batch runs the persistent loop with the Winograd convolution, 0 otherwise (direct form / another path)
+extern "C" int dsd_get_conv_mode(dsd_handle* h) { return (h && h->prepared && wino_applicable(h)) ? 1 : 0; }
 
 extern "C" int dsd_get_loop_mode(dsd_handle* h) { return (h && h->prepared && loop_applicable(h)) ? 1 : 0; }
 
@@ -1357,11 +1310,9 @@ extern "C" int dsd_debug_loop_timeline(dsd_handle* h, float* x, const float* noi
                                        int32_t max_wg, int32_t* n_wg, void* stream) {
     DSD_TRY(check_ready(h, "dsd_debug_loop_timeline", true));
     if (!x || !noise || !out || !n_wg) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: null argument");
-    const int rsg = rs_g(h);
-    if (!rsg && !loop_applicable(h)) return fail(DSD_ERR_STATE, "dsd_debug_loop_timeline: the prepared batch does not take a persistent path");
+    if (!loop_applicable(h)) return fail(DSD_ERR_STATE, "dsd_debug_loop_timeline: the prepared batch does not take a persistent path");
     if (k_step < 2 || phase / h->L >= k_step - 1) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: pick a phase of an evaluation that is not the last");
-    // one stamp block per workgroup: the persistent loop has one workgroup per tile, the row-split loop lat_grid(ntiles, G) (dsd_loop_rs.hpp)
-    const int nwg = rsg ? lat_grid(h->ntiles, rsg) : h->ntiles;
+    const int nwg = h->ntiles;                   // one stamp block per workgroup = per tile
     if (h->ntiles > h->n_cu || nwg > max_wg) return fail(DSD_ERR_INVALID, "dsd_debug_loop_timeline: needs a single-launch batch (%d workgroups)", nwg);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1399,6 +1350,7 @@ extern "C" int dsd_p_sample(dsd_handle* h, float* x, const float* noise, int32_t
     hipLaunchKernelGGL(k_set_cell, dim3(1), dim3(1), 0, s, h->noise_cell, noise);
     if (!noise) hipLaunchKernelGGL(k_set_seed, dim3(1), dim3(1), 0, s, h->seed_cell, h->noise_seed);
     HIP_TRY(hipGetLastError());
+    DSD_TRY(ensure_cp(h, false, s));
     DSD_TRY(launch_inproj(h, x, s));
     DSD_TRY(launch_stack(h, t, nullptr, s));
     HeadParams p = head_base(h);
@@ -1458,6 +1410,7 @@ extern "C" int dsd_time_layer_kernel(dsd_handle* h, int32_t layer, int32_t t, in
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     DSD_TRY(build_step_table(h, t + 1, s));
+    DSD_TRY(ensure_cp(h, false, s));
     // The launches are timed the way the sampling loop issues them: as nodes of ONE hipGraph (eager launches carry a
     // cache write-back / invalidate between kernels that graph nodes do not, ~10 % on this kernel).  layer < 0 walks
     // the non-last layers 0..L-2 in order, like one denoiser evaluation does.
@@ -1500,6 +1453,7 @@ extern "C" int dsd_debug_layer_timeline(dsd_handle* h, int32_t layer, int32_t t,
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     DSD_TRY(build_step_table(h, t + 1, s));
+    DSD_TRY(ensure_cp(h, false, s));
     const int nb = layer_nb(h);
     const int blocks = h->B * ((h->ntile32 + nb - 1) / nb);
     if (blocks > max_blocks) return fail(DSD_ERR_INVALID, "dsd_debug_layer_timeline: %d blocks > buffer %d", blocks, max_blocks);

@@ -637,8 +637,10 @@ struct CondProjParams {
     const float* condT;     // [B][H=256][TS], zero for t >= T
     const float4* wcp;      // [L][w4][kc32][mb4][lane64]
     const float4* b1p;      // [L][w4][mb4][h2][q4]  (dilated_conv.bias + conditioner_projection.bias)
-    float4* cp;             // [L][ntiles][w4][mb4][q4][lane64]
+    float4* cp;             // [L][ntiles][w4][mb4][q4][lane64], or (wino) [L][ntiles][w4][frame half 2][rb 8][lane64]
     int TS, ntile32, ntiles_total;
+    int wino;               // 1: the accumulator order of the Winograd loop (dsd_loop_wino.hpp), which depends on the layer's dilation
+    unsigned char dil[64];
 };
 
 __global__ __launch_bounds__(kThreads, 2) void k_condproj(const CondProjParams p) {
@@ -665,6 +667,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_condproj(const CondProjParams p
     const float4* ap = p.wcp + ((size_t)l * 4 + w) * (32 * 256);
     const float* cl = smem + 4 * h * LD + j;
     gemm_k<4, 1, LD, 256>(acc, ap, lane, 32, TileB{cl, 8 * LD, 32});
+    if (p.wino) {
+        // Winograd loop: lane (pair pr, k group g) of v_mfma_f32_16x16x4_f32 holds, for frame half hf (tE / tE + d) and row block rb (16 rows; 0-3
+        // gate, 4-7 filter), rows 4 g + {0..3}.  This lane's float4 (mb, q) = rows 32 (mb & 1) + 8 q + 4 h + {0..3} of the wave's 64 gate
+        // (mb < 2) / filter rows at frame j: rb = 2 (mb & 1) + (q >> 1) (+ 4), g = 2 (q & 1) + h, and frame j is half hf of pair pr.
+        const int e = __builtin_ctz((unsigned)p.dil[l]), d = 1 << e;
+        const int hf = (j >> e) & 1, pr = ((j >> (e + 1)) << e) | (j & (d - 1));
+        float4* out = p.cp + (((size_t)l * p.ntiles_total + tile) * 4 + w) * (2 * 8 * 64) + (size_t)hf * (8 * 64) + pr;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[(2 * (mb & 1) + (q >> 1) + 4 * (mb >> 1)) * 64 + 16 * (2 * (q & 1) + h)] = get4(acc[mb][0], q);
+        return;
+    }
     float4* out = p.cp + (((size_t)l * p.ntiles_total + tile) * 4 + w) * (4 * 4 * 64) + lane;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)

@@ -6,8 +6,8 @@
 //   * the PAIR format (WF = 2, the default; SplitPipeF): every fp32 operand as two fp16 planes, x = h0 + 2^-11 h1 (11 + 11 mantissa bits), a
 //     product as h0 g0 + 2^-11 (h0 g1 + h1 g0): three v_mfma_f32_32x32x16_f16 per 16-deep chunk, 4 bytes per weight;
 //   * three exact bf16 planes p0 + p1 + p2 (8 + 8 + 8 bits; dsd_split.hpp), a product as the six plane products with i + j <= 2, smallest first,
-//     on v_mfma_f32_32x32x16_bf16 - the planes on the wire (WF = 0, SplitPipeR: 6 bytes per weight) or fp32 on the wire and the same planes
-//     made in registers beside the MFMAs (WF = 4, SplitPipeW: 4 bytes, bit-identical to WF = 0).
+//     on v_mfma_f32_32x32x16_bf16, the planes on the wire (WF = 0, SplitPipeR: 6 bytes per weight) - the cross-check stream of the tests.  (A
+//     third stream - fp32 on the wire, split into the same planes in registers, bit-identical and slower - is in git at 138668f.)
 // Either way the products are exact in fp32 and accumulated in fp32; what is dropped is <= 2^-22 relative per product - of the order of the
 // fp32 MFMA chain's own rounding (tests/test_gpu_split_loop.py measures all of them against an fp64 evaluation of the oracle).
 //
@@ -184,156 +184,6 @@ struct SplitPipeR {
     }
 };
 
-// The weights as FP32 on the wire, split into the three planes in registers beside the MFMAs (k_pack_split_f32's layout: 8 KiB per chunk
-// and wave, two 16-byte loads per row block and lane).  The plane stream is 6 bytes per weight and every CU of an XCD walks the whole layer
-// per evaluation (the matrix pipe waits for bytes, busy 0.42); this form moves 4 and pays in vector-ALU
-// instructions.  The split is sp_split3's arithmetic on pairs: v_cvt_pk_bf16_f32 (round to nearest even), the planes' fp32 values back by
-// shift / mask, exact subtractions - 44 VALU instructions per 8 weights, bit-identical planes, and per accumulator the same products in
-// the same order as SplitPipeR: the two loops agree bit for bit (tests/test_gpu_split_loop.py).  Row blocks go in PAIRS: the MFMAs of one
-// pair (two accumulators alternating, 12 MFMAs) cover the split of the next pair's fragments; two sets of plane registers (48 VGPRs)
-// beside STAGES x NMB x 8 of fp32 stages.  Period of the register rotation: 6 steps for 3 stages, 4 for 4 (the loop instantiates 4).
-template <int NMB, int MB0, int STAGES, typename BOff>
-struct SplitPipeW {
-    static_assert(STAGES == 3 || STAGES == 4, "3 stages rotate with period 6, 4 with period 4");
-    static_assert(NMB == 4 || NMB == 2, "row blocks are processed in pairs");
-    static constexpr int P = (STAGES == 3) ? 6 : 4;
-    static constexpr int kChunkU4 = 8 * 64;           // uint4 per chunk and wave
-    static constexpr int kTouchPer = 0;               // no L2 touch on this stream (the vector ALU bounds it)
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned aoff, aoff_hi;      // lane * 16 and + 4096: every load of a chunk = one of them + an immediate < 4096, ONE scalar offset per chunk
-    int n;
-    BOff bof;
-    int bplane;
-    float4 a[STAGES][NMB][2];
-    uint4 pl[2][2][3];           // [set][row block of the pair][plane]
-    sbf16x8 b[2][3];
-
-    static __device__ __forceinline__ const uint4* wbase(const uint4* p, int l, int w, int nchunks) { return p + ((size_t)l * 4 + w) * nchunks * kChunkU4; }
-    __device__ __forceinline__ SplitPipeW(const uint4* wave_base, int lane, int n_, BOff bof_, int bplane_, L2Touch&, unsigned)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u),
-          aoff_hi((unsigned)lane * 16u + 4096u), n(n_), bof(bof_), bplane(bplane_) {
-        asm volatile("" : "+v"(aoff_hi));                                   // keep it a register: folded back, every load would need its own scalar add
-    }
-    __device__ __forceinline__ void lda(float4 (&dst)[NMB][2], int kc) {
-        typedef float f32x4_ __attribute__((ext_vector_type(4)));
-        const int kcc = (kc < n) ? kc : n - 1;
-#pragma unroll
-        for (int mb = 0; mb < NMB; ++mb)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int o = ((MB0 + mb) * 2 + hf) * 1024;
-                const f32x4_ v = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((o < 4096 ? aoff : aoff_hi) + (unsigned)(o & 4095)), kcc * 8192, 0));
-                dst[mb][hf] = make_float4(v.x, v.y, v.z, v.w);
-            }
-    }
-    __device__ __forceinline__ void ldb(sbf16x8 (&dst)[3], int kc) {
-        const su16* bp = bof.at(kc);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(bp + p * bplane));
-    }
-    // eight fp32 weights -> three plane fragments (sp_split3 on pairs), STAGE by stage over the four pairs: 4 conversions, 8 plane values
-    // back as fp32 (shift / mask), 8 exact residuals, and again.  Two things the empty asm between the stages buys, both in issue slots -
-    // which are what bounds this pipe: (i) hipcc does not pack pairs of subtractions into v_pk_add_f32, which beside MFMAs costs about
-    // three slots for two subtractions (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); (ii) a v_cvt_pk_bf16_f32 never directly
-    // follows the v_sub_f32 that feeds it - that adjacency costs an s_nop, and a chain-by-chain order has eight of them per fragment.
-    static __device__ __forceinline__ void tie8(float (&r)[8]) {
-        asm("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
-    }
-    static __device__ __forceinline__ void level(float (&r)[8], unsigned (&pk)[4]) {
-        typedef float f32x2_ __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pk[k] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{r[2 * k], r[2 * k + 1]}), bf16x2_));
-    }
-    static __device__ __forceinline__ void residual(float (&r)[8], const unsigned (&pk)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r[2 * k] = r[2 * k] - __builtin_bit_cast(float, pk[k] << 16);
-            r[2 * k + 1] = r[2 * k + 1] - __builtin_bit_cast(float, pk[k] & 0xffff0000u);
-        }
-        tie8(r);
-    }
-    static __device__ __forceinline__ void split8(const float4 (&src)[2], uint4 (&dst)[3]) {
-        float r[8] = {src[0].x, src[0].y, src[0].z, src[0].w, src[1].x, src[1].y, src[1].z, src[1].w};
-        unsigned p0[4], p1[4], p2[4];
-        level(r, p0);
-        residual(r, p0);
-        level(r, p1);
-        residual(r, p1);
-        level(r, p2);
-        dst[0] = make_uint4(p0[0], p0[1], p0[2], p0[3]);
-        dst[1] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
-        dst[2] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
-    }
-    // 12 MFMAs of a pair of row blocks: smallest plane products first, the two accumulators alternating
-    static __device__ __forceinline__ void mfma_pair(f32x16& c0, f32x16& c1, const uint4 (&pp)[2][3], const sbf16x8 (&bb)[3]) {
-        constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8, pp[0][TI[q]]), bb[TJ[q]], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8, pp[1][TI[q]]), bb[TJ[q]], c1, 0, 0, 0);
-        }
-    }
-    // one half step in program order: 12 MFMAs, each followed by a share of the loads and of the VALU instructions of two splits
-    template <int NVMEM, int NDS, int SYNC, int I = 0>
-    static __device__ __forceinline__ void pattern() {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, SYNC);
-        if constexpr (I < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, SYNC);
-        if constexpr (I >= 8 && I < 8 + NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, SYNC);
-        __builtin_amdgcn_sched_group_barrier(0x002, (I % 3 == 2) ? 8 : 7, SYNC);           // the 88 VALU instructions of two splits over 12 gaps
-        if constexpr (I + 1 < 12) pattern<NVMEM, NDS, SYNC, I + 1>();
-    }
-    __device__ __forceinline__ void start_a() {
-#pragma unroll
-        for (int i = 0; i < STAGES - 1; ++i) lda(a[i], i);
-        DSD_SB();
-    }
-    __device__ __forceinline__ void start_b() {
-        ldb(b[0], 0);
-        split8(a[0][0], pl[0][0]);
-        split8(a[0][1], pl[0][1]);
-        DSD_SB();
-    }
-    template <int I>
-    __device__ __forceinline__ void step(f32x16 (&acc)[NMB], int kc) {
-        lda(a[(I + STAGES - 1) % STAGES], kc + STAGES - 1);
-        ldb(b[(I + 1) & 1], kc + 1);
-        if constexpr (NMB == 4) {
-            split8(a[I % STAGES][2], pl[1][0]);
-            split8(a[I % STAGES][3], pl[1][1]);
-            mfma_pair(acc[0], acc[1], pl[0], b[I & 1]);
-            pattern<2 * NMB, 3, 0>();
-            DSD_SB();
-            split8(a[(I + 1) % STAGES][0], pl[0][0]);
-            split8(a[(I + 1) % STAGES][1], pl[0][1]);
-            mfma_pair(acc[2], acc[3], pl[1], b[I & 1]);
-            pattern<0, 0, 1>();
-        } else {
-            split8(a[(I + 1) % STAGES][0], pl[(I + 1) & 1][0]);
-            split8(a[(I + 1) % STAGES][1], pl[(I + 1) & 1][1]);
-            mfma_pair(acc[0], acc[1], pl[I & 1], b[I & 1]);
-            pattern<2 * NMB, 3, 0>();
-        }
-        DSD_SB();
-    }
-    template <int I, int N>
-    __device__ __forceinline__ void steps(f32x16 (&acc)[NMB], int kc0) {
-        step<I>(acc, kc0 + I);
-        if constexpr (I + 1 < N) steps<I + 1, N>(acc, kc0);
-    }
-    // chunks [BEGIN, END), BEGIN a multiple of the period.  Compile-time bounds: whole periods are ONE basic block each (branches between the
-    // steps let hipcc's block passes move the split of the next fragments out from under the MFMAs), the tail is unrolled by its length.
-    __device__ __forceinline__ void finish(f32x16 (&)[NMB]) {}
-    template <int BEGIN, int END>
-    __device__ __forceinline__ void run(f32x16 (&acc)[NMB]) {
-        static_assert(BEGIN % P == 0 && END > BEGIN, "a segment starts on a period");
-        constexpr int kFull = (END - BEGIN) / P, kTail = (END - BEGIN) - kFull * P;
-        if constexpr (kFull > 0)
-            for (int kc0 = BEGIN; kc0 < BEGIN + kFull * P; kc0 += P) steps<0, P>(acc, kc0);
-        if constexpr (kTail > 0) steps<0, kTail>(acc, BEGIN + kFull * P);
-    }
-};
-
 // PAIR format (WF = 2): every fp32 operand as TWO fp16 planes, x = h0 + 2^-11 h1 (sp_split2h: 11 + 11 mantissa bits, the second plane scaled so
 // that it is a normal fp16), a product as h0 g0 + 2^-11 (h0 g1 + h1 g0) - three v_mfma_f32_32x32x16_f16 per 16-deep chunk instead of six bf16
 // ones, 4 bytes per weight on the wire instead of 6, two LDS reads per chunk instead of three.  The products are exact in fp32 (11 x 11
@@ -454,12 +304,9 @@ struct SplitPipeF {
     }
 };
 
-// which pipe a loop instantiation streams its weights through: WF = 2 the pair format (4 stages), 0 the bf16 planes (3 stages), 4 fp32 split in
-// registers into those planes (4 stages)
+// which pipe a loop instantiation streams its weights through: WF = 2 the pair format (4 stages), 0 the bf16 planes (3 stages)
 template <int WF, int NMB, int MB0, typename BOff>
-struct SplitPipeSel { typedef SplitPipeW<NMB, MB0, WF, BOff> type; };
-template <int NMB, int MB0, typename BOff>
-struct SplitPipeSel<0, NMB, MB0, BOff> { typedef SplitPipeR<NMB, MB0, 3, BOff> type; };
+struct SplitPipeSel { typedef SplitPipeR<NMB, MB0, 3, BOff> type; };
 template <int NMB, int MB0, typename BOff>
 struct SplitPipeSel<2, NMB, MB0, BOff> { typedef SplitPipeF<NMB, MB0, BOff> type; };
 
@@ -511,11 +358,11 @@ __device__ __forceinline__ void sp_store4_wf(su16* plane0, int plane_elems, int 
 
 struct LoopSplitParams {
     LoopParams lp;              // everything k_loop takes (w1p / w2p unused here)
-    const uint4* w1c;           // conv weights, centre-first chunk order: fp32 [L][w4][48][mb4][2][lane64] (WF = 4), or (WF = 0 / 2) ALL weights of the loop
-                                // in consumption order [L][64 = 48 conv + 16 out-projection chunks][w4][12 KiB of bf16 planes / 8 KiB of fp16 planes]
-    const uint4* w2s;           // out-projection weights: fp32 [L][w4][16][mb4][2][lane64] (WF = 4), or (WF = 0 / 2) w1c + 48 chunks
-    unsigned wl_bytes;          // WF = 0 / 2: bytes of that buffer (the L2 touch's buffer bound)
-    int touch_ahead;            // WF = 0 / 2: chunks the L2 touch runs in front (0 = off)
+    const uint4* w1c;           // ALL weights of the loop in consumption order [L][64 = 48 conv (centre taps first) + 16 out-projection chunks][w4][12 KiB of
+                                // bf16 planes / 8 KiB of fp16 planes]
+    const uint4* w2s;           // out-projection weights: w1c + 48 chunks
+    unsigned wl_bytes;          // bytes of that buffer (the L2 touch's buffer bound)
+    int touch_ahead;            // chunks the L2 touch runs in front (0 = off)
 };
 
 template <int MODE, int WF>

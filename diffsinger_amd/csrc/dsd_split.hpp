@@ -89,29 +89,6 @@ __global__ void k_pack_split(const float* __restrict__ src, su16* __restrict__ d
     }
 }
 
-// The same fp32 fragment-order source -> fp32 in 32x32x16 FRAGMENT order, for the loop that splits the weights in registers
-// (dsd_loop_split.hpp, SplitPipeW): [w][chunk16][mb 4][half 2][lane (i, h')][4] floats, channel 16 g + 8 h' + 4 half + s - a lane's eight
-// weights of a 16-deep chunk as two 16-byte loads, 4 bytes per weight on the wire instead of the planes' 6.  Chunk order as k_pack_split.
-__global__ void k_pack_split_f32(const float* __restrict__ src, float* __restrict__ dst, int nw, int ng, int ntap, int centre_first) {
-    const size_t n = (size_t)nw * ng * ntap * 4 * 64 * 8;              // (w, chunk16, mb, half, lane, s)
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const int s = idx & 3, lane = (idx >> 2) & 63, half = (idx >> 8) & 1;
-        size_t r = idx >> 9;
-        const int mb = r & 3; r >>= 2;
-        const int c16 = r % (ng * ntap); r /= (ng * ntap);
-        const int w = (int)r;
-        int g = c16 / ntap, tap = c16 - g * ntap;
-        if (centre_first && ntap == 3) {
-            if (c16 < ng) { g = c16; tap = 1; }
-            else { const int ix = c16 - ng; g = ix >> 1; tap = (ix & 1) * 2; }
-        }
-        const int i = lane & 31, hp = lane >> 5;
-        const int k8 = 2 * g + hp, c8 = (ntap == 3) ? conv_chunk(k8, tap) : ntap * k8 + tap;
-        const int lane_src = i + 32 * half;                             // e = 4 half + s of the plane packing
-        dst[idx] = src[((((size_t)w * (2 * ng * ntap) + c8) * 4 + mb) * 64 + lane_src) * 4 + s];
-    }
-}
-
 // Operand pipeline: STAGES (3 or 6) register stages of the weight stream (chunk kc + STAGES - 1 requested while chunk kc is multiplied; every
 // chunk is a first touch of the XCD's L2, the fp32 kernels needed ~5 k cycles of distance), B one chunk ahead,
 // loads interleaved one-by-one behind the first MFMAs of a step.  NMB row blocks starting at MB0 (the last layer computes the skip half only).

@@ -109,13 +109,16 @@ class DenoiserEngine:
         """G of the latency kernels the prepared batch runs with, 0 = not on that path."""
         return self.lib.dsd_get_lat_split(self._h)
 
-    def set_rs_split(self, g: int):
-        """Row-split persistent loop (csrc/dsd_loop_rs.hpp): -1 by batch size, 0 never, 2 / 4 / 8 / 16 forced."""
-        _lib.check(self.lib.dsd_set_rs_split(self._h, int(g)), 'dsd_set_rs_split')
+    def set_conv_mode(self, mode, touch_ahead: int = -1, stages: int = -1):
+        """How the PERSISTENT loop evaluates the dilated convolution (csrc/dsd_loop_wino.hpp): 'winograd' / 1 (default) = Winograd F(2,3)
+        along the frame axis, 2/3 of the fp32 multiplications; 'direct' / 0 = the K = 768 contraction, bit-identical to the per-layer
+        kernels.  touch_ahead / stages: tuning knobs of the transformed-weight stream (-1 = keep)."""
+        m = {'direct': 0, 'winograd': 1}.get(mode, mode)
+        _lib.check(self.lib.dsd_set_conv_mode(self._h, int(m), int(touch_ahead), int(stages)), 'dsd_set_conv_mode')
 
-    def rs_split(self) -> int:
-        """G of the row-split persistent loop the prepared batch runs with, 0 = another path."""
-        return self.lib.dsd_get_rs_split(self._h)
+    def conv_mode(self) -> int:
+        """1 if the prepared batch runs the persistent loop with the Winograd convolution, else 0."""
+        return self.lib.dsd_get_conv_mode(self._h)
 
     def set_loop_mode(self, mode: int):
         """2 (default): automatic - latency kernels for small batches, else the persistent loop / per-layer kernels by chip occupancy;

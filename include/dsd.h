@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DSD_ABI_VERSION 4
+#define DSD_ABI_VERSION 5
 
 typedef struct dsd_handle dsd_handle;
 
@@ -175,29 +175,32 @@ int dsd_set_use_graph(dsd_handle* h, int32_t enable);
  * "concurrently" are serialised (each loop fills the chip anyway), never starved into the timeout.  Two PROCESSES sharing one GPU
  * cannot see each other: use mode 0 there (one process per device, as the reference's DDP runner does, is always safe).
  * dsd_loop_launches: k_loop launches per sampling call for the prepared batch (chunks of whole utterances; 0 = not on that path).
- * Environment: DSD_LOOP=<mode> at dsd_create is the same choice as dsd_set_loop_mode for a host that cannot be changed; DSD_SPLIT=1 turns the
- * split-precision experiment on (below).  There are no other switches: one kernel per job. */
+ * Environment (read at dsd_create, each the same choice as the setter named): DSD_LOOP=<mode> = dsd_set_loop_mode; DSD_CONV=direct|winograd =
+ * dsd_set_conv_mode; DSD_SPLIT=1 = dsd_set_split_mode with DSD_SPLIT_W=2|0 (format) and DSD_SPLIT_TOUCH=<chunks> (its L2 touch) - the
+ * split-precision experiment below.  These are all the environment switches. */
 int dsd_set_loop_mode(dsd_handle* h, int32_t mode);
 int dsd_loop_launches(dsd_handle* h);
 int dsd_set_lat_split(dsd_handle* h, int32_t g);
 int dsd_get_lat_split(dsd_handle* h);
-/* The ROW-SPLIT PERSISTENT loop (csrc/dsd_loop_rs.hpp): the batches the latency kernels serve (32-frame tiles x G <= CU count, G = 16 / 8 / 4 / 2:
- * the reference's own inference shape, one utterance per device, configs/tts/fs2.yaml:70) as ONE launch for the whole K-step loop
- * (usr/diff/shallow_diffusion_tts.py:261-270) - the G workgroups of a tile stay resident and exchange gate rows and x' rows through
- * sentinel-tagged rings in device memory instead of through 43 kernel boundaries per evaluation.  Same arithmetic and summation order as the
- * kernels it replaces (G = 2 / 4: bit-identical to modes 0 / 1; G = 8 / 16: bit-identical to the latency kernels).  Applies in loop mode 2 with
- * hipGraph mode on and no forced latency split; failures are loud exactly like the persistent loop's (dsd_check).
- * dsd_set_rs_split: g = -1 by batch size, 0 never, 2 / 4 / 8 / 16 forced (ignored when the batch does not fit g workgroups per tile);
- * dsd_get_rs_split: G the prepared batch runs with on this path, 0 = another path.  Environment: DSD_RS=<g> at dsd_create. */
-int dsd_set_rs_split(dsd_handle* h, int32_t g);
-int dsd_get_rs_split(dsd_handle* h);
+/* How the PERSISTENT loop evaluates the 3-tap dilated convolution (usr/diff/net.py:61,71):
+ *   1 (default) Winograd F(2,3) along the frame axis (csrc/dsd_loop_wino.hpp): for every output pair (t, t + d) four products with transformed
+ *     weights instead of six - 2/3 of the convolution's fp32 multiplications, the same dtype (exact-fp32 MFMA, fp32 transforms: weights summed
+ *     in fp64 and rounded once at load, inputs one fp32 add).  Results differ from the direct form by reduction order and those roundings
+ *     (~1e-5 on a K = 100 loop against a 1e-4 budget; tests/test_gpu_wino.py).
+ *   0 the direct K = 768 contraction (k_loop): bit-identical to loop modes 0 and the G = 2 / 4 latency kernels.
+ * Every other path (per-layer kernels, latency kernels, dsd_denoise / dsd_p_sample / training) evaluates the direct form.  touch_ahead: steps
+ * (16 KiB of the transformed-weight stream) the waves of an XCD fetch into their L2 ahead of themselves, 0 = off, -1 = keep (default 16);
+ * stages: register stages of that stream, 4 or 8, -1 = keep (default 8) - tuning knobs of tools/, results do not depend on them.
+ * dsd_get_conv_mode: 1 if the prepared batch runs the persistent loop with the Winograd form.  Environment: DSD_CONV=direct|winograd at dsd_create. */
+int dsd_set_conv_mode(dsd_handle* h, int32_t mode, int32_t touch_ahead, int32_t stages);
+int dsd_get_conv_mode(dsd_handle* h);
 
 /* EXPERIMENT (csrc/dsd_split.hpp, csrc/dsd_loop_split.hpp; default off, env DSD_SPLIT=1 turns it on at creation): the residual layers on
  * the 16-bit matrix pipe with fp32-class accuracy.  The persistent loop (k_loop_split: the same loop, x / skip sum / halo exchange / head /
  * sampler in fp32) takes every fp32 operand as TWO scaled fp16 planes, x = h0 + 2^-11 h1, and a product as h0 g0 + 2^-11 (h0 g1 + h1 g0),
  * accumulated in fp32 (the pair format; env DSD_SPLIT_W=2, the default) - or as three exact bf16 planes and the six products with i + j <= 2
- * (DSD_SPLIT_W=0: the planes on the wire; 4: fp32 weights split into the same planes in registers, bit-identical), which is also what the
- * per-layer kernel path does (k_layer_split, 32-frame tiles).  The latency and row-split paths are bypassed while the mode is on.  Never the
+ * (DSD_SPLIT_W=0: the planes on the wire - the cross-check stream of the tests), which is also what the
+ * per-layer kernel path does (k_layer_split, 32-frame tiles).  The latency path is bypassed while the mode is on.  Never the
  * headline dtype: bench.py reports it as a labelled `secondary` line with its error against an fp64 evaluation of the oracle beside the
  * fp32 path's.  Enqueues the weight packing on `stream`. */
 int dsd_set_split_mode(dsd_handle* h, int32_t on, void* stream);

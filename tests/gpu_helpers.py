@@ -24,7 +24,7 @@ def build_hip(preset_name, k_step=None, legacy=False):
     return gd.cuda().eval(), cfg, pre
 
 
-def run_hip_case(name, use_graph=True, tile=0, split=False, loop_mode=None, lat_split=None, rs_split=None):
+def run_hip_case(name, use_graph=True, tile=0, split=False, loop_mode=None, lat_split=None, conv=None):
     case, pre, cfg, k_step, inp, smin, smax = H.case_setup(name)
     gd, _, _ = build_hip(case['preset'], k_step, legacy=bool(case.get('legacy')))
     cond = inp['cond'].transpose(1, 2).contiguous().cuda().transpose(1, 2)      # [B,H,T] view of [B,T,H], like :238
@@ -35,8 +35,8 @@ def run_hip_case(name, use_graph=True, tile=0, split=False, loop_mode=None, lat_
         eng.set_loop_mode(loop_mode)
     if lat_split is not None:
         eng.set_lat_split(lat_split)
-    if rs_split is not None:
-        eng.set_rs_split(rs_split)               # row-split persistent loop: -1 by batch size, 0 never, G forced
+    if conv is not None:
+        eng.set_conv_mode(conv)                      # convolution of the persistent loop: 'winograd' (default) / 'direct'
     if split:
         eng.set_split_mode(True)                     # EXPERIMENT: layers on the bf16 matrix pipe, six plane products per fp32 product
     kind = case['kind']

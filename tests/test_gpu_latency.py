@@ -19,6 +19,13 @@ from tests import helpers as H
 from tests.gpu_helpers import build_hip, run_hip_case
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _direct_convolution(monkeypatch):
+    # this file compares the latency kernels with the persistent loop's DIRECT form (bit-identity for G = 2 / 4); the Winograd form of the
+    # persistent loop is tests/test_gpu_wino.py
+    monkeypatch.setenv('DSD_CONV', 'direct')
 DEV = 'cuda:0'
 
 
@@ -174,6 +181,7 @@ def test_midsize_band_runs_g8_on_several_grid_waves_and_matches_the_persistent_l
     again = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
     assert torch.equal(out, again)
     refs = {}
+    eng.set_conv_mode('direct')                      # the bit-identity anchor of the persistent path (the Winograd form: tests/test_gpu_wino.py)
     for mode in (1, 0):
         eng.set_loop_mode(mode)
         refs[mode] = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).clone()

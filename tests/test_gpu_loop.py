@@ -1,6 +1,7 @@
-"""GPU: the persistent K-step loop (csrc/dsd_loop.hpp: one kernel for the whole loop, x and the skip sum resident in
-registers, halo exchange between neighbouring workgroups) against the per-layer-kernel hipGraph path.  Same arithmetic in the
-same order -> BIT-identical; every inter-workgroup wait satisfied (no timeout); also against the reference fixtures."""
+"""GPU: the persistent K-step loop in its DIRECT-convolution form (csrc/dsd_loop.hpp, k_loop: one kernel for the whole loop, x and the skip
+sum resident in registers, halo exchange between neighbouring workgroups) against the per-layer-kernel hipGraph path.  Same arithmetic in the
+same order -> BIT-identical; every inter-workgroup wait satisfied (no timeout); also against the reference fixtures.  The Winograd form -
+the default of the persistent path - is tests/test_gpu_wino.py; this file is the bit-identity anchor."""
 import numpy as np
 import pytest
 import torch
@@ -8,6 +9,11 @@ import torch
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _direct_convolution(monkeypatch):
+    monkeypatch.setenv('DSD_CONV', 'direct')         # read at dsd_create: every engine of this file runs k_loop, not k_loop_wino
 
 
 def _run(name, loop_mode):

@@ -40,6 +40,7 @@ def test_seeded_loop_equals_explicit_noise_loop(B, T):
     eng = gd._engine(cond)
     noise = torch.stack([eng.philox_normal(seed, j, B * 80 * T).reshape(B, 1, 80, T) for j in range(K)])
     outs = {}
+    eng.set_conv_mode('direct')                      # persistent and per-layer paths bit-identical (Winograd form: tests/test_gpu_wino.py)
     for mode in (1, 0):
         eng.set_loop_mode(mode)
         with torch.no_grad():

@@ -1,0 +1,183 @@
+"""GPU: the persistent K-step loop with the dilated convolution as Winograd F(2,3) along the frame axis (csrc/dsd_loop_wino.hpp; the default of
+the persistent path) against the reference-generated fixtures, the oracle and the direct-form loop (k_loop, the bit-identity anchor of the
+per-layer kernels).  Same dtype as the reference (fp32 in, exact-fp32 MFMA, fp32 transforms); what differs from the direct form is the
+reduction order and one rounding per transformed operand - bounded here at 3e-5 on K = 100 loops, a third of the 1e-4 parity budget, which
+itself is asserted against the reference's own outputs."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _infer(gd, case, inp, cond, k_step):
+    with torch.no_grad():
+        if case['kind'] == 'plms':
+            return gd.inference(cond, x_T=inp['x_T'].cuda(), K_step=k_step, pndm_speedup=case['interval'])
+        if case['gaussian']:
+            return gd.inference(cond, x_T=inp['x_T'].cuda(), noise=inp['noise'].cuda(), K_step=k_step, pndm_speedup=0)
+        return gd.inference(cond, fs2_mels=inp['fs2_mel'].cuda(), q_noise=inp['q_noise'].cuda(), noise=inp['noise'].cuda(), K_step=k_step,
+                            pndm_speedup=0, gaussian_start=False)
+
+
+@pytest.mark.parametrize('name', ['ddpm_lj_k100', 'shallow_opencpop_k60', 'shallow_popcs_k51', 'plms_opencpop_i40', 'plms_opencpop_i250'])
+def test_winograd_loop_vs_reference_fixtures_and_the_direct_loop(name):
+    from tests.gpu_helpers import build_hip
+    case, pre, cfg, k_step, inp, smin, smax = H.case_setup(name)
+    gd, _, _ = build_hip(case['preset'], k_step)
+    cond = inp['cond'].transpose(1, 2).contiguous().cuda().transpose(1, 2)
+    eng = gd._engine(cond)
+    eng.set_loop_mode(1)
+    assert eng.loop_mode() == 1 and eng.conv_mode() == 1, 'Winograd is the default convolution of the persistent loop'
+    out = _infer(gd, case, inp, cond, k_step).cpu().numpy()
+    assert eng.loop_timeouts() == 0
+    eng.set_conv_mode('direct')
+    assert eng.conv_mode() == 0
+    direct = _infer(gd, case, inp, cond, k_step).cpu().numpy()
+    eng.set_conv_mode('winograd')
+    again = _infer(gd, case, inp, cond, k_step).cpu().numpy()            # cp is re-laid for the other form and back: same bits
+    np.testing.assert_array_equal(out, again)
+    g = H.load_golden(name)['out']
+    scale = max(1.0, float(np.abs(g).max())) if 'plms' in name else 1.0
+    e_g, e_d, e_gd = float(np.abs(out - g).max()) / scale, float(np.abs(out - direct).max()) / scale, float(np.abs(direct - g).max()) / scale
+    print(f'{name}: Winograd loop vs reference fixture {e_g:.3e} (direct loop {e_gd:.3e}), Winograd vs direct {e_d:.3e}')
+    assert e_g <= 1e-4 and e_d <= 3e-5
+    assert e_g <= 4.0 * max(e_gd, 2e-6), 'the Winograd form should not be more than a few times the direct form\'s distance from the reference'
+
+
+@pytest.mark.parametrize('B,T,K', [(8, 1024, 12), (5, 2048, 6), (3, 1000, 8), (2, 33, 5), (1, 5, 3)])
+def test_winograd_loop_full_width_all_dilations(B, T, K):
+    """Bench-size batches (256 workgroups at once), chunks of whole utterances, ragged T, a two-tile utterance with a one-frame tail, a one-tile
+    utterance - dilation cycle 4 (d = 1, 2, 4, 8: every pair order, halos up to 8 frames) against the direct loop."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from diffsinger_amd.synth import presets
+    pre = presets()['opencpop_ds60_rel']
+    hparams.clear()
+    diffsinger_amd.use_preset('opencpop_ds60_rel')
+    torch.manual_seed(3)
+    net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+    torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=100, K_step=K, loss_type='l1', spec_min=pre['spec_min'],
+                                          spec_max=pre['spec_max']).cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    cond = torch.randn(B, T, 256, device='cuda', generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, device='cuda', generator=g)
+    noise = torch.randn(K, B, 1, 80, T, device='cuda', generator=g)
+    eng = gd._engine(cond)
+    eng.set_loop_mode(1)
+    outs = {}
+    for mode in ('winograd', 'direct'):
+        eng.set_conv_mode(mode)
+        with torch.no_grad():
+            outs[mode] = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).cpu().numpy()
+        assert eng.loop_mode() == 1 and eng.conv_mode() == (1 if mode == 'winograd' else 0)
+        assert eng.loop_timeouts() == 0
+    assert np.isfinite(outs['winograd']).all()
+    d = float(np.abs(outs['winograd'] - outs['direct']).max())
+    print(f'{B} x {T}, K = {K}: Winograd vs direct loop max-abs mel difference {d:.3e}')
+    assert d <= 1e-5
+
+
+def test_results_do_not_depend_on_the_stream_knobs_and_seeded_noise_matches_explicit_noise():
+    """The L2 touch computes nothing and the register stages only move loads: every (touch lead, stages) setting gives the same bits; the
+    in-kernel Philox draw equals the explicit-noise loop fed with the same draws; replays are deterministic."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from diffsinger_amd.synth import presets
+    pre = presets()['opencpop_ds60_rel']
+    hparams.clear()
+    diffsinger_amd.use_preset('opencpop_ds60_rel')
+    torch.manual_seed(7)
+    net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+    torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+    B, T, K, seed = 8, 1000, 6, 24681357
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=100, K_step=K, loss_type='l1', spec_min=pre['spec_min'],
+                                          spec_max=pre['spec_max']).cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(9)
+    cond = torch.randn(B, T, 256, device='cuda', generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, device='cuda', generator=g)
+    eng = gd._engine(cond)
+    eng.set_loop_mode(1)
+    noise = torch.stack([eng.philox_normal(seed, j, B * 80 * T).reshape(B, 1, 80, T) for j in range(K)])
+    ref = None
+    for touch, stages in ((16, 8), (0, 8), (4, 8), (32, 8), (16, 4), (0, 4)):
+        eng.set_conv_mode('winograd', touch, stages)
+        with torch.no_grad():
+            out = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).cpu().numpy()
+        assert eng.conv_mode() == 1 and eng.loop_timeouts() == 0
+        if ref is None:
+            ref = out
+        np.testing.assert_array_equal(out, ref, err_msg=f'touch {touch}, stages {stages}')
+    eng.set_conv_mode('winograd', 16, 8)
+    with torch.no_grad():
+        seeded = gd.inference(cond, x_T=x_T, K_step=K, pndm_speedup=0, noise_seed=seed).cpu().numpy()
+    np.testing.assert_array_equal(seeded, ref)
+    assert np.isfinite(ref).all()
+
+
+def test_timed_batch_shape_k100_vs_oracle_row():
+    """BASELINE configs[1] (8 x 1024, K = 100 DDPM) on the Winograd loop: rows 0 and 5 against the oracle on identical (x_T, cond, noise)."""
+    from oracle import diffnet_oracle as O
+    from tests.gpu_helpers import build_hip
+    gd, cfg, pre = build_hip('lj_ds_beta6', k_step=100)
+    B, T, K = 8, 1024, 100
+    g = torch.Generator().manual_seed(17)
+    cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, generator=g)
+    noise = torch.randn(K, B, 1, 80, T, generator=g)
+    dcond = cond.transpose(1, 2).contiguous().cuda().transpose(1, 2)
+    with torch.no_grad():
+        mel = gd.inference(dcond, x_T=x_T.cuda(), noise=noise.cuda(), K_step=K, pndm_speedup=0).cpu()
+    eng = gd.denoise_fn.engine()
+    assert eng.loop_mode() == 1 and eng.conv_mode() == 1 and eng.loop_timeouts() == 0
+    sch = O.make_schedule(H.betas_for(pre))
+    smin = torch.tensor(pre['spec_min'], dtype=torch.float32)[None, None, :]
+    smax = torch.tensor(pre['spec_max'], dtype=torch.float32)[None, None, :]
+    p = H.oracle_params(cfg)
+    for b in (0, 5):
+        want = O.infer_mel(p, cfg, sch, cond[b:b + 1], smin, smax, k_step=K, noises=list(noise[:, b:b + 1]), x_T=x_T[b:b + 1])
+        err = float((mel[b:b + 1] - want).abs().max())
+        print(f'8 x 1024, K = 100 on the Winograd loop, row {b}: max-abs mel err vs oracle {err:.3e}')
+        assert err <= 1e-4
+
+
+def test_starved_winograd_loop_is_loud_and_the_retry_succeeds():
+    """The failure protocol of k_loop holds for the Winograd loop: 64 CUs held by a foreign kernel -> spin bound -> RuntimeError at the call
+    (check=True), handle parked on the hipGraph path (direct-form per-layer kernels), retry finite and within the forms' distance."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from diffsinger_amd.synth import presets
+    pre = presets()['lj_ds_beta6']
+    hparams.clear()
+    diffsinger_amd.use_preset('lj_ds_beta6')
+    torch.manual_seed(5)
+    net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+    torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+    B, T, K = 8, 1024, 3
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=100, K_step=K, loss_type='l1', spec_min=pre['spec_min'],
+                                          spec_max=pre['spec_max']).cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(8)
+    cond = torch.randn(B, T, 256, device='cuda', generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, device='cuda', generator=g)
+    noise = torch.randn(K, B, 1, 80, T, device='cuda', generator=g)
+    eng = gd._engine(cond)
+    eng.set_loop_mode(1)
+    run = lambda **kw: gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0, **kw)
+    ref = run(check=True).cpu().numpy()
+    assert eng.loop_mode() == 1 and eng.conv_mode() == 1 and np.isfinite(ref).all()
+    side = eng.hold_cus(64, 120000)
+    try:
+        with pytest.raises(RuntimeError, match='spin bound'):
+            run(check=True)
+        assert eng.loop_mode() == 0 and eng.conv_mode() == 0       # parked: per-layer kernels
+        out = run(check=True).cpu().numpy()                        # the retry, with the holders still resident
+        assert np.isfinite(out).all() and float(np.abs(out - ref).max()) <= 1e-5
+    finally:
+        eng.release_cus()
+        side.synchronize()
+    eng.set_loop_mode(1)
+    np.testing.assert_array_equal(run(check=True).cpu().numpy(), ref)
+    assert eng.loop_mode() == 1 and eng.conv_mode() == 1 and eng.loop_timeouts() == 0

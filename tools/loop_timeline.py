@@ -6,11 +6,18 @@ import numpy as np, torch
 import bench
 B, T, K = 8, 1024, 6
 PHASES = None
+CONV, TOUCH, STAGES = 'winograd', -1, -1
 for a in list(sys.argv[1:]):
     if a.startswith('--k='):
         K = int(a[4:]); sys.argv.remove(a)
     elif a.startswith('--phases='):
         PHASES = tuple(int(v) for v in a[9:].split(',')); sys.argv.remove(a)
+    elif a.startswith('--conv='):
+        CONV = a[7:]; sys.argv.remove(a)
+    elif a.startswith('--touch='):
+        TOUCH = int(a[8:]); sys.argv.remove(a)
+    elif a.startswith('--stages='):
+        STAGES = int(a[9:]); sys.argv.remove(a)
 dev = torch.device('cuda', 0)
 gd, pre = bench.build_model(dev)
 g = torch.Generator(device=dev).manual_seed(1)
@@ -19,17 +26,24 @@ x = torch.randn(B, 80, T, device=dev, generator=g)
 noise = torch.randn(K, B, 80, T, device=dev, generator=g)
 eng = gd._engine(cond)
 eng.set_loop_mode(1)
+eng.set_conv_mode(CONV, TOUCH, STAGES)
+WINO = eng.conv_mode() == 1
 SPLIT = '--split' in sys.argv
 if SPLIT:
     sys.argv.remove('--split')
     eng.set_split_mode(True)
-summary = {'phase_cycles': [], 'head_cycles': [], 'mfma_issue_ideal_per_phase': 2048 * 64}
+summary = {'phase_cycles': [], 'head_cycles': [], 'mfma_issue_ideal_per_phase': (2048 * 32 + 512 * 64) if WINO and not SPLIT else 2048 * 64,
+           'conv': 'winograd F(2,3)' if WINO else 'direct'}
 for phase in PHASES or ((43, 44, 63) if not SPLIT else (43, 44, 63, 83)):
     ts = eng.loop_timeline(x.clone(), noise, K, phase).astype(np.int64)
     d = np.diff(ts[:, :, :8], axis=2)
     names = ['weight prefetch issue, own columns of y, barrier', 'conv chunks 0-29 (centre taps) + flag poll, halo loads / writes, 2 barriers',
              'conv chunks 30-95', 'gate + barrier',
              'out-proj K=256', 'residual transpose, x\'', 'publish (drain, barrier, flag) + skip sum']
+    if WINO and not SPLIT:
+        names = ['weight prefetch issue, own frames of y (pair order), barrier', 'Winograd steps 0-39 of 128 (halo-free half: M1, M2) + flag poll, halo loads / writes, barrier',
+                 'steps 40-127: rest of the halo-free half, output transform, M0 / M3 half + conditioner-projection loads', 'gate + barrier',
+                 'out-proj K=256', 'residual, x\'', 'publish (drain, barrier, flag) + skip sum']
     if SPLIT:
         names = ['weight prefetch issue, own frames of y as planes, barrier', 'conv chunks 0-11 of 48 (centre taps) + flag poll, halo loads / plane writes, barrier',
                  'conv chunks 12-47 + conditioner-projection loads', 'gate -> planes + barrier', 'out-proj 16 chunks', 'x\'',

@@ -62,7 +62,7 @@ def main():
             sec = (time.perf_counter() - t0) / reps
             assert bool(torch.isfinite(out).all()) and eng.loop_timeouts() == 0
             tf = B * T * 100 * F_EXEC / sec / 1e12
-            path = (f'row-split persistent G={eng.rs_split()}' if eng.rs_split() else f'latency G={eng.lat_split()}' if eng.lat_split()
+            path = (f'latency G={eng.lat_split()}' if eng.lat_split()
                     else ('persistent' if eng.loop_mode() == 1 else f'per-layer tile {eng.layer_tile()}'))
             if mode == 2:
                 row.update({'path': path, 'ms_per_pass': round(sec * 1e3, 3), 'mel_frames_per_s': round(B * T / sec, 1),
