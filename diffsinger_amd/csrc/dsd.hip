@@ -276,10 +276,11 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_DDPM, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_PLMS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_DDPM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_PLMS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
+#define DSD_WINO_ATTR(M, ST, VV) (void)hipFuncSetAttribute((const void*)k_loop_wino<M, ST, VV>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes)
+        DSD_WINO_ATTR(HEAD_DDPM, 4, 0); DSD_WINO_ATTR(HEAD_DDPM, 4, 1); DSD_WINO_ATTR(HEAD_DDPM, 4, 3);
+        DSD_WINO_ATTR(HEAD_DDPM, 8, 0); DSD_WINO_ATTR(HEAD_DDPM, 8, 1); DSD_WINO_ATTR(HEAD_DDPM, 8, 3);
+        DSD_WINO_ATTR(HEAD_PLMS, 4, 3); DSD_WINO_ATTR(HEAD_PLMS, 8, 3);
+#undef DSD_WINO_ATTR
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -1051,8 +1052,13 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
             // Winograd F(2,3) form of the dilated convolution (dsd_loop_wino.hpp): the default of this path
             const LoopWinoParams q{p, h->w1w, (unsigned)((size_t)h->L * kWnSteps * kWnStepBytes), h->wino_touch};
             const dim3 grid((unsigned)p.n_tiles), block(kThreads);
-#define DSD_LAUNCH_WINO(ST) do { if (kind == 0) hipLaunchKernelGGL((k_loop_wino<HEAD_DDPM, ST>), grid, block, kLoopWinoLdsBytes, s, q); \
-                                 else hipLaunchKernelGGL((k_loop_wino<HEAD_PLMS, ST>), grid, block, kLoopWinoLdsBytes, s, q); } while (0)
+            // (bring-up: DSD_WINO_V = 0 / 1 / 3 selects how the waits are placed, DDPM only - results do not depend on it)
+            int vv = 3;
+            if (const char* ev = std::getenv("DSD_WINO_V")) vv = std::atoi(ev);
+#define DSD_LAUNCH_WINO(ST) do { if (kind != 0) hipLaunchKernelGGL((k_loop_wino<HEAD_PLMS, ST, 3>), grid, block, kLoopWinoLdsBytes, s, q); \
+                                 else if (vv == 0) hipLaunchKernelGGL((k_loop_wino<HEAD_DDPM, ST, 0>), grid, block, kLoopWinoLdsBytes, s, q); \
+                                 else if (vv == 1) hipLaunchKernelGGL((k_loop_wino<HEAD_DDPM, ST, 1>), grid, block, kLoopWinoLdsBytes, s, q); \
+                                 else hipLaunchKernelGGL((k_loop_wino<HEAD_DDPM, ST, 3>), grid, block, kLoopWinoLdsBytes, s, q); } while (0)
             if (h->wino_stages == 4) DSD_LAUNCH_WINO(4); else DSD_LAUNCH_WINO(8);
 #undef DSD_LAUNCH_WINO
         } else if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);

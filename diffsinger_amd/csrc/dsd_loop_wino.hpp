@@ -77,57 +77,78 @@ __global__ void k_pack_wino(const float* __restrict__ src, float* __restrict__ d
     }
 }
 
+// L2 touch of the transformed-weight stream by PERIODS (the mechanism of L2Touch, dsd_loop_split.hpp: one dword per 128-byte line through
+// `buffer_load_dword ... lds` into a 256-byte scratch, no destination register).  A period = 8 steps of all four waves = 128 KiB = 16 pieces of
+// 8 KiB; piece t of period n belongs to wave (16 n + t) mod nwx of the XCD's nwx waves.  A wave keeps r = (q - 16 n) mod nwx as a running
+// counter - ONE scalar test per period (the per-step form cost six scalar instructions per 16 MFMAs, and every instruction beside a 32-cycle
+// fp32 MFMA is paid for in matrix time: tools/mfma_filler_probe.hip) - and fetches the pieces t = r, r + nwx, ... < 16.
+struct L2TouchP {
+    L2Touch::i32x4_ rs;
+    int r, nwx, dec;             // running turn, the XCD's waves, 16 mod nwx (off: r out of reach, dec 0)
+    unsigned ahead, gtot;        // periods the touch runs in front; periods in the whole stream (16 per layer)
+    unsigned lds, lane128;
+    __device__ __forceinline__ void issue(unsigned soff) const {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(lds), "v"(lane128), "s"(rs), "s"(soff) : "m0");
+#pragma clang diagnostic pop
+    }
+    // gper: index of the period being multiplied in the stream of all layers' periods
+    __device__ __forceinline__ void period(unsigned gper) {
+        for (int t = r; t < 16; t += nwx) {
+            unsigned g = gper + ahead;
+            if (g >= gtot) g -= gtot;
+            issue(g * (unsigned)(8 * kWnStepBytes) + (unsigned)t * 8192u);
+        }
+        r -= dec;
+        if (r < 0) r += nwx;
+    }
+};
+
 // Operand pipeline of the Winograd contraction.  A: S register stages of one step (4 float4 = the four row blocks of a half) straight from
 // global / L2, step k + S - 1 requested while step k is multiplied.  B: the raw operand rows of the NEXT 16-channel chunk are read at the first
-// step of a group of four, transformed (one add each) at its last.  Periods of eight steps (two groups) are one basic block apart from the
-// L2 touch's turn test.
-template <int S>
+// step of a group of four, transformed (one add each) at its last.  Everything that walks - the stream offset, the chunk pointers into the y
+// tile, the touch's turn - is RUNNING state advanced once per period of eight steps, so that a step carries 16 MFMAs, 4 loads, one wait (V & 1:
+// all four fragments of the step are awaited together) and one scalar add.
+template <int S, int V>
 struct WinoPipe {
     static_assert(S == 4 || S == 8, "the register rotation has period 8");
-    static constexpr int kTouchPer = kWnStepBytes / 8192;
     __amdgpu_buffer_rsrc_t rsrc;    // over the whole stream behind this wave's 4 KiB of step 0 / layer 0
-    unsigned aoff, sbase;           // lane * 16; byte offset of this layer's step 0
-    const float *pE, *pO, *pOm, *pEp;
-    L2Touch& tc;
-    unsigned gq;                    // index of this layer's step 0 in the stream of all layers' steps + the touch's lead
+    unsigned aoff, so;              // lane * 16; byte offset of step 0 of the CURRENT period
+    const float *qE, *qO;           // halo-free half: rows E[p], O[p] at the chunk the next read takes
+    const float *rOm, *rO, *rEp, *rE;   // second half: rows O[p - d], O[p], E[p + d], E[p]
+    L2TouchP& tc;
+    unsigned gper;                  // index of the current period in the stream of all layers' periods
     float4 a[S][4];
     float4 raw[4];
     float v[2][2][4];               // [group parity][product][k step]
 
-    __device__ __forceinline__ WinoPipe(const float4* wave_base, int lane, int l, const float* pE_, const float* pO_, int dilrow, L2Touch& tc_)
+    __device__ __forceinline__ WinoPipe(const float4* wave_base, int lane, int l, const float* pE, const float* pO, int dilrow, L2TouchP& tc_)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u),
-          sbase((unsigned)l * (unsigned)(kWnSteps * kWnStepBytes)), pE(pE_), pO(pO_), pOm(pO_ - dilrow), pEp(pE_ + dilrow), tc(tc_),
-          gq((unsigned)l * (unsigned)kWnSteps + tc_.ahead) {}
+          so((unsigned)l * (unsigned)(kWnSteps * kWnStepBytes)), qE(pE), qO(pO), rOm(pO - dilrow - 4), rO(pO - 4), rEp(pE + dilrow - 4), rE(pE - 4),
+          tc(tc_), gper((unsigned)l * (unsigned)(kWnSteps / 8)) {}
 
-    __device__ __forceinline__ void touch(int k) {
-        const int t = tc.next();
-        if (t < kTouchPer) {
-            unsigned g = gq + (unsigned)k;
-            if (g >= tc.gtot) g -= tc.gtot;
-            tc.issue(g * (unsigned)kWnStepBytes + (unsigned)t * 8192u);
-        }
-    }
-    __device__ __forceinline__ void lda(float4 (&dst)[4], int k) {
+    template <int KOFF>
+    __device__ __forceinline__ void lda(float4 (&dst)[4]) {
         typedef float f32x4_ __attribute__((ext_vector_type(4)));
-        const int soff = (int)sbase + k * kWnStepBytes;                  // past the layer's last step: the next layer's first ones (or the slack)
+        const int soff = (int)so + KOFF * kWnStepBytes;                  // past the layer's last step: the next layer's first ones (or the slack)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const f32x4_ f = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff + r4 * 1024, soff, 0));
             dst[r4] = make_float4(f.x, f.y, f.z, f.w);
         }
     }
-    // raw operand rows of chunk c: half 0 (halo-free) E[p], O[p]; half 1 O[p - d], O[p], E[p + d], E[p]
-    template <int HALF>
-    __device__ __forceinline__ void ldb_raw(int c) {
-        const int o = 4 * (c & 15);
+    // raw operand rows of the next chunk (+ O floats): half 0 (halo-free) E[p], O[p]; half 1 O[p - d], O[p], E[p + d], E[p]
+    template <int HALF, int O>
+    __device__ __forceinline__ void ldb_raw() {
         if constexpr (HALF == 0) {
-            raw[0] = *reinterpret_cast<const float4*>(pE + o);
-            raw[1] = *reinterpret_cast<const float4*>(pO + o);
+            raw[0] = *reinterpret_cast<const float4*>(qE + O);
+            raw[1] = *reinterpret_cast<const float4*>(qO + O);
         } else {
-            raw[0] = *reinterpret_cast<const float4*>(pOm + o);
-            raw[1] = *reinterpret_cast<const float4*>(pO + o);
-            raw[2] = *reinterpret_cast<const float4*>(pEp + o);
-            raw[3] = *reinterpret_cast<const float4*>(pE + o);
+            raw[0] = *reinterpret_cast<const float4*>(rOm + O);
+            raw[1] = *reinterpret_cast<const float4*>(rO + O);
+            raw[2] = *reinterpret_cast<const float4*>(rEp + O);
+            raw[3] = *reinterpret_cast<const float4*>(rE + O);
         }
     }
     template <int HALF>
@@ -168,25 +189,29 @@ struct WinoPipe {
             __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         }
     }
-    template <int FROM = 0, int TO = S - 1>
+    template <int N, int I = 0>
     __device__ __forceinline__ void start_a() {
-#pragma unroll
-        for (int i = FROM; i < TO; ++i) lda(a[i], i);
-        DSD_SB();
+        lda<I>(a[I]);
+        if constexpr (I + 1 < N) start_a<N, I + 1>();
+        else DSD_SB();
     }
     __device__ __forceinline__ void start_b() {
-        ldb_raw<0>(0);
+        ldb_raw<0, 0>();
         transform<0>(v[0]);
+        qE += 4; qO += 4;                                               // the first group's read takes chunk 1
         DSD_SB();
     }
-    // step I of a period (k = k0 + I): product pos = (I >> 1) & 1 of the group's chunk, row blocks 4 (I & 1) .. + 3; NH = half of the NEXT group
+    // step I of a period: product pos = (I >> 1) & 1 of the group's chunk, row blocks 4 (I & 1) .. + 3; NH = half of the NEXT group
     template <int I, int NH>
-    __device__ __forceinline__ void step(f32x4w (&acc)[2][8], int k0) {
+    __device__ __forceinline__ void step(f32x4w (&acc)[2][8]) {
         constexpr int grp = I >> 2, pos = (I >> 1) & 1, hb = I & 1;
-        const int k = k0 + I;
-        touch(k);
-        lda(a[(I + S - 1) % S], k + S - 1);
-        if constexpr ((I & 3) == 0) ldb_raw<NH>((k >> 2) + 1);
+        if constexpr (V & 1) {
+            // ONE wait for the four fragments of this step (requested together S - 1 steps ago) instead of one in front of each of the first
+            // four MFMAs: the empty statement uses a register of every fragment
+            asm volatile("" : : "v"(a[I % S][0].x), "v"(a[I % S][1].x), "v"(a[I % S][2].x), "v"(a[I % S][3].x));
+        }
+        lda<I + S - 1>(a[(I + S - 1) % S]);
+        if constexpr ((I & 3) == 0) ldb_raw<NH, 4 * (I >> 2)>();
         if constexpr ((I & 3) == 3) transform<NH>(v[grp ^ 1]);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -197,16 +222,20 @@ struct WinoPipe {
         DSD_SB();
     }
     template <int NH0, int NH1>
-    __device__ __forceinline__ void period(f32x4w (&acc)[2][8], int k0) {
-        step<0, NH0>(acc, k0); step<1, NH0>(acc, k0); step<2, NH0>(acc, k0); step<3, NH0>(acc, k0);
-        step<4, NH1>(acc, k0); step<5, NH1>(acc, k0); step<6, NH1>(acc, k0); step<7, NH1>(acc, k0);
+    __device__ __forceinline__ void period(f32x4w (&acc)[2][8]) {
+        tc.period(gper);
+        step<0, NH0>(acc); step<1, NH0>(acc); step<2, NH0>(acc); step<3, NH0>(acc);
+        step<4, NH1>(acc); step<5, NH1>(acc); step<6, NH1>(acc); step<7, NH1>(acc);
+        ++gper;
+        so += 8u * (unsigned)kWnStepBytes;
+        if constexpr (NH0 == 0 || NH1 == 0) { qE += 8; qO += 8; }
+        if constexpr (NH0 == 1 || NH1 == 1) { rOm += 8; rO += 8; rEp += 8; rE += 8; }
     }
-    // steps [K0, K1), both multiples of 8; NH0 / NH1: the half the group behind the first / second group of a period belongs to
-    template <int K0, int K1, int NH0, int NH1>
+    // N periods; NH0 / NH1: the half the group behind the first / second group of a period belongs to
+    template <int N, int NH0, int NH1>
     __device__ __forceinline__ void run(f32x4w (&acc)[2][8]) {
-        static_assert(K0 % 8 == 0 && K1 % 8 == 0 && K1 > K0, "whole periods");
 #pragma nounroll
-        for (int k0 = K0; k0 < K1; k0 += 8) period<NH0, NH1>(acc, k0);
+        for (int n = 0; n < N; ++n) period<NH0, NH1>(acc);
     }
 };
 
@@ -217,7 +246,7 @@ struct LoopWinoParams {
     int touch_ahead;            // steps the L2 touch runs in front (0 = off)
 };
 
-template <int MODE, int S>
+template <int MODE, int S, int V>
 __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams pw) {
     constexpr int LDK = kFmLDK;
     const LoopParams& p = pw.lp;
@@ -236,20 +265,17 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
         const int q = p.n_tiles >> 3, r = p.n_tiles & 7;
         tl = xcd * q + min(xcd, r) + k;
     }
-    L2Touch tc;
+    L2TouchP tc;
     {
         const unsigned long long wb = (unsigned long long)pw.w1w;
         const int xcd = (int)(blockIdx.x & 7), nwx = 4 * ((p.n_tiles - xcd + 7) >> 3), q = 4 * (int)(blockIdx.x >> 3) + w;
         const bool en = pw.touch_ahead > 0 && nwx >= 8;
         tc.rs = L2Touch::i32x4_{(int)(unsigned)wb, (int)(unsigned)((wb >> 32) & 0xffffu), (int)pw.wl_bytes, 0x00020000};
-        tc.ahead = (unsigned)pw.touch_ahead;
+        tc.ahead = (unsigned)(pw.touch_ahead + 7) / 8u;         // the lead in periods
         tc.nwx = nwx;
-        tc.per = en ? WinoPipe<S>::kTouchPer : 0;
-        if (en) {                                                // the first step multiplies step 0: its fetch is for step `ahead`
-            int r0 = (q - WinoPipe<S>::kTouchPer * pw.touch_ahead) % nwx;
-            tc.r = r0 < 0 ? r0 + nwx : r0;
-        } else tc.r = 1 << 20;
-        tc.gtot = (unsigned)p.L * (unsigned)kWnSteps;
+        tc.dec = en ? 16 % nwx : 0;
+        tc.r = en ? q : 1 << 20;                                 // period 0: piece t belongs to wave t mod nwx
+        tc.gtot = (unsigned)p.L * (unsigned)(kWnSteps / 8);
         tc.lds = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float*)smem + (unsigned)w * 256u;
         tc.lane128 = (unsigned)lane * 128u;
     }
@@ -329,8 +355,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
             const int dil = (int)p.dil[l], de = __builtin_ctz((unsigned)dil);
 
             // (c) the weight stream does not depend on anything computed here: request its first steps now
-            WinoPipe<S> pipe1(pw.w1w + (size_t)w * 256, lane, l, ytile + pp * LDK + 64 * gg, ytile + kWnOBase + (8 + pp) * LDK + 64 * gg, dil * LDK, tc);
-            pipe1.template start_a<0, S - 1>();
+            WinoPipe<S, V> pipe1(pw.w1w + (size_t)w * 256, lane, l, ytile + pp * LDK + 64 * gg, ytile + kWnOBase + (8 + pp) * LDK + 64 * gg, dil * LDK, tc);
+            pipe1.template start_a<S - 1>();
 
             // (b) own frames of y = x + step_proj (zero at frames >= T: the conv's zero padding applies to y, net.py:69-71): the lane's 32
             //     channels of frame j as 8 ds_write_b128 into the frame's row of the pair-ordered tile
@@ -363,7 +389,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 for (int rb = 0; rb < 8; ++rb) acc[i][rb] = f32x4w{0.f, 0.f, 0.f, 0.f};
             float4 cpv[2][8];
             pipe1.start_b();
-            pipe1.template run<0, 8, 0, 0>(acc);
+            pipe1.template run<1, 0, 0>(acc);
             // (d2) both neighbours have published phase ph?  Lanes whose early read was too early poll (bounded, sticky timeout)
             if (fv < ph + 1u) {
                 const gu32* f = (const gu32*)(p.flags + tile + (lane ? 1 : -1));
@@ -391,7 +417,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 }
             }
             DSD_SB();
-            pipe1.template run<8, 40, 0, 0>(acc);
+            pipe1.template run<4, 0, 0>(acc);
             // (e2) halo rows: left frame f (t = t0 - 8 + f) is O[f - 8], right frame f (t = t0 + 32 + f) is E[16 + f]; float4 index
             //      tid + 256 g = (frame f = 4 g + tid / 64, channels 4 (tid % 64) ..)
             {
@@ -411,8 +437,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
             }
             __syncthreads();
             LOOP_STAMP(2);
-            pipe1.template run<40, 56, 0, 0>(acc);
-            pipe1.template run<56, 64, 0, 1>(acc);
+            pipe1.template run<2, 0, 0>(acc);
+            pipe1.template run<1, 0, 1>(acc);
             // output transform, first part: t = M1 + M2 (frame tE), u = M1 - M2 (frame tO); the second half accumulates M0 onto t, M3 onto u
 #pragma unroll
             for (int rb = 0; rb < 8; ++rb) {
@@ -421,7 +447,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 acc[1][rb] = m1 - m2;
             }
             DSD_SB();
-            pipe1.template run<64, 96, 1, 1>(acc);
+            pipe1.template run<4, 1, 1>(acc);
             {
                 const float4* cpl = p.cp + (size_t)l * p.cp_lstride + ((size_t)tile * 4 + w) * (2 * 8 * 64);       // wave-uniform
 #pragma unroll
@@ -430,7 +456,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                     for (int rb = 0; rb < 8; ++rb) cpv[hf][rb] = ld16_u(cpl, ((hf * 8 + rb) * 64 + lane) * 16);
             }
             DSD_SB();
-            pipe1.template run<96, 128, 1, 1>(acc);
+            pipe1.template run<4, 1, 1>(acc);
             // step projection of the NEXT phase (next layer, or layer 0 of the next evaluation)
             float ds_next = 0.f;
             {
@@ -459,7 +485,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
             LOOP_STAMP(3);
             if (!last) {
                 // output projection, all four row blocks (0,1 residual, 2,3 skip) in one pass
-                GemmPipe<4, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
+                GemmPipe<4, 1, LDK, 256, 6, TileBT, 1, true, (V & 2) != 0> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
@@ -503,7 +529,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 LOOP_STAMP(7);
             } else {
                 // last layer: only the skip half (net.py:126 reads the skips; the residual is dead)
-                GemmPipe<2, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256) + 2 * 64, lane, 32, bof2);
+                GemmPipe<2, 1, LDK, 256, 6, TileBT, 1, true, (V & 2) != 0> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256) + 2 * 64, lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();

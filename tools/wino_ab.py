@@ -21,10 +21,11 @@ for (B, T) in shapes:
     eng = gd._engine(cond)
     eng.set_loop_mode(1)
     ref = None
-    variants = [('direct', -1, -1)] + [('winograd', t, s) for s in (8, 4) for t in (16, 0, 4, 8, 32, 64)]
+    variants = [('direct', -1, -1, 3)] + [('winograd', t, s, v) for v in (3, 1, 0) for s in (4, 8) for t in (16, 0, 32)]
     if len(shapes) > 1:
-        variants = [('direct', -1, -1), ('winograd', 16, 8)]
-    for conv, touch, stages in variants:
+        variants = [('direct', -1, -1, 3), ('winograd', -1, -1, 3)]
+    for conv, touch, stages, vv in variants:
+        os.environ['DSD_WINO_V'] = str(vv)           # bring-up knob of the library: placement of the waits (read at every launch)
         eng.set_conv_mode(conv, touch, stages)
         eng.prepare(cond)
         xs = x.clone()
@@ -43,7 +44,8 @@ for (B, T) in shapes:
         wino = eng.conv_mode() == 1
         f = bench.F_EVAL_EXEC_WINO if wino else bench.F_EVAL_EXEC
         tf = B * T * K * f / (ms * 1e-3) / 1e12
-        print(json.dumps({'shape': [B, T], 'conv': conv, 'touch': touch, 'stages': stages, 'kernel': 'k_loop_wino' if wino else 'k_loop', 'launches': eng.loop_launches(),
+        print(json.dumps({'shape': [B, T], 'conv': conv, 'touch': touch, 'stages': stages, 'waits_v': vv, 'kernel': 'k_loop_wino' if wino else 'k_loop', 'launches': eng.loop_launches(),
                           'ms_per_call': round(ms, 3), 'mel_frames_per_s': round(B * T / ms * 1e3, 1), 'tflops_executed': round(tf, 2),
                           'frac_fp32_mfma_peak': round(tf / bench.PEAK_FP32_MFMA_TFLOPS, 4), 'max_abs_x_vs_direct': float((out - ref).abs().max())}), flush=True)
+    os.environ['DSD_WINO_V'] = '3'
     eng.set_conv_mode('winograd', 16, 8)
