@@ -216,6 +216,37 @@ def secondary_split(gd, eng, pre, cond, x_T, noise, mel_f32, mel_oracle, args):
     }
 
 
+def torch_rocm_eager_baseline(gd, cond, x_T):
+    """CONTEXT, never the target and never inside a timed region: what the reference's OWN code does on this chip.  The oracle is the bit-equal
+    restatement of DiffNet.forward + p_sample (usr/diff/net.py:107-130, usr/diff/shallow_diffusion_tts.py:134-166) in plain torch ops; with its
+    tensors on cuda:0 that is PyTorch-ROCm eager - MIOpen convolutions, rocBLAS linears, ~25 launches per residual layer - exactly what
+    `GaussianDiffusion.forward(infer=True)` of the reference would run on an MI355X (usr/diff/shallow_diffusion_tts.py:269-270).  2 warm-up
+    + 5 timed denoiser evaluations with the sampler's element-wise update on the timed batch, extrapolated x K."""
+    from oracle import diffnet_oracle as O
+    cfg = O.NetConfig(80, 256, 256, 20, 1)
+    dev = x_T.device
+    p = {k: v.detach().to(dev, torch.float32).contiguous() for k, v in gd.denoise_fn.state_dict().items()}
+    x = x_T.detach().clone()
+    c = cond.detach()
+    B, T = x.shape[0], x.shape[-1]
+    n = 5
+    with torch.no_grad():
+        for i in range(2):
+            O.diffnet_forward(p, cfg, x, torch.full((B,), K_STEPS - 1 - i, device=dev, dtype=torch.long), c)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            eps = O.diffnet_forward(p, cfg, x, torch.full((B,), K_STEPS - 1 - i, device=dev, dtype=torch.long), c)
+            x0 = (1.01 * x - 0.1 * eps).clamp_(-1., 1.)                 # the shape of p_sample's update: predict_start, clip, posterior mean, noise
+            x = 0.5 * x0 + 0.5 * x + 0.01 * torch.randn_like(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+    return {'value': B * T / (dt * K_STEPS), 'unit': 'mel-frames/s', 'sec_per_ddpm_step': dt,
+            'sample': f'{n} denoiser evaluations + sampler-shaped element-wise update of the timed batch ({B} x {T}) with the oracle\'s torch ops on cuda:0 '
+                      f'(PyTorch {torch.__version__} eager: MIOpen / rocBLAS), after the timed region; x {K_STEPS}',
+            'note': 'context, extrapolated: the reference\'s own operator sequence on this GPU - not a target, not the product path'}
+
+
 def pmc_traffic(kernel: str, frames: int):
     """HBM-side bytes per launch of the layer kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
     WRITE_SIZE runs of tools/gpu_pmc.sh at this very shape, corrected as MI355X_MICROARCH.md prescribes; reduced by
@@ -660,7 +691,6 @@ def main():
     ap.add_argument('--conv', choices=['winograd', 'direct'], default=None,
                     help='convolution of the persistent loop: winograd F(2,3) (the default of the library) or the direct K = 768 form (A/B, rounds 1-4)')
     ap.add_argument('--touch', type=int, default=-1, help='A/B: steps the L2 touch of the Winograd weight stream runs in front (0 = off, -1 = library default)')
-    ap.add_argument('--stages', type=int, default=-1, help='A/B: register stages of the Winograd weight stream (4 / 8, -1 = library default)')
     ap.add_argument('--split', action='store_true', help='EXPERIMENT: residual layers as six bf16 plane products per fp32 product (fp32-class accuracy) '
                                                           'on the bf16 matrix pipe; per-layer kernel path; the JSON line says so in dtype / config')
     args = ap.parse_args()
@@ -804,8 +834,8 @@ def main_path(args):
         frames_per_step = CFG5_UTTS * T
     eng = gd._engine(cond)
     eng.set_layer_tile(args.tile)
-    if args.conv or args.touch >= 0 or args.stages > 0:
-        eng.set_conv_mode(args.conv or 'winograd', args.touch, args.stages)
+    if args.conv or args.touch >= 0:
+        eng.set_conv_mode(args.conv or 'winograd', args.touch)
     if args.split:
         eng.set_split_mode(True)
 
@@ -877,7 +907,7 @@ def main_path(args):
             flop = frames * K * f_exec / launches
             achieved = frames * K * f_exec / (ms_call * 1e-3) / 1e12
             frames_l = frames / launches
-            kname = 'k_loop_split<1, %s>' % os.environ.get('DSD_SPLIT_W', '2') if args.split else 'k_loop_wino<1, 8>' if wino else 'k_loop<1>'
+            kname = 'k_loop_split<1, %s>' % os.environ.get('DSD_SPLIT_W', '2') if args.split else 'k_loop_wino<1, 4>' if wino else 'k_loop<1>'
             w_layer = (2 * 1024 * 1024 + 512 * 1024) if wino else 2 * 1024 * 1024      # weight stream of a layer: 4 (3) x 512 KiB of conv + 512 KiB of out-projection
             alg_bytes = int(K * (frames * (20 * 2048 + 2 * 320 + 320) + launches * L_LAYERS * w_layer + frames // 32 * L_LAYERS * 2 * 16384) / launches)
             note = (f'one launch = the whole K=100 reverse loop (100 x (20 residual layers + head + sampler update + next input '
@@ -980,6 +1010,11 @@ def main_path(args):
             res['cpu_baseline'], res['parity'], mel_oracle = cpu_baseline(gd, pre, conds[last], x_T, noise, out, roof['kernel'])
             res['parity']['fixture'] = fixture
             res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
+            try:
+                res['torch_rocm_eager_baseline'] = torch_rocm_eager_baseline(gd, conds[last], x_T)
+                res['speedup_vs_torch_rocm_eager'] = value / res['torch_rocm_eager_baseline']['value']
+            except Exception as e:
+                res['torch_rocm_eager_baseline'] = {'error': repr(e)}
             if not args.no_secondary and not args.split:
                 try:
                     res['secondary'] = secondary_split(gd, eng, pre, conds[last], x_T, noise, out, mel_oracle, args)

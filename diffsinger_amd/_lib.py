@@ -112,7 +112,7 @@ def load():
     lib.dsd_debug_hold_cus.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.dsd_set_lat_split.argtypes = [h, C.c_int32]
     lib.dsd_get_lat_split.argtypes = [h]
-    lib.dsd_set_conv_mode.argtypes = [h, C.c_int32, C.c_int32, C.c_int32]
+    lib.dsd_set_conv_mode.argtypes = [h, C.c_int32, C.c_int32]
     lib.dsd_get_conv_mode.argtypes = [h]
     lib.dsd_p_sample_ex.argtypes = [h, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p]
     lib.dsd_set_split_mode.argtypes = [h, C.c_int32, C.c_void_p]

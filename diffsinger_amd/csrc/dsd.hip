@@ -134,7 +134,6 @@ struct dsd_handle {
     int conv_mode = 1;
     float4* w1w = nullptr;            // transformed conv weights U0..U3 of all layers in consumption order [L][128 steps][w4][r4][lane64]
     int wino_touch = 16;              // steps (16 KiB each) the L2 touch of that stream runs in front, 0 = off
-    int wino_stages = 8;              // register stages of that stream (8 or 4)
     bool cp_wino = false;             // layout of the prepared batch's cp: the Winograd loop's accumulator order, or the 32x32 fragment order
 
     // EXPERIMENT (dsd_split.hpp): residual layers on the bf16 matrix pipe with fp32-class accuracy; per-layer kernel path only
@@ -276,11 +275,8 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
-#define DSD_WINO_ATTR(M, ST, VV) (void)hipFuncSetAttribute((const void*)k_loop_wino<M, ST, VV>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes)
-        DSD_WINO_ATTR(HEAD_DDPM, 4, 0); DSD_WINO_ATTR(HEAD_DDPM, 4, 1); DSD_WINO_ATTR(HEAD_DDPM, 4, 3);
-        DSD_WINO_ATTR(HEAD_DDPM, 8, 0); DSD_WINO_ATTR(HEAD_DDPM, 8, 1); DSD_WINO_ATTR(HEAD_DDPM, 8, 3);
-        DSD_WINO_ATTR(HEAD_PLMS, 4, 3); DSD_WINO_ATTR(HEAD_PLMS, 8, 3);
-#undef DSD_WINO_ATTR
+        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_DDPM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_PLMS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_DDPM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -333,7 +329,8 @@ extern "C" int64_t dsd_device_bytes(dsd_handle* h) { return h ? h->bytes + h->by
 static int lat_g(const dsd_handle* h) {
     if (h->split_mode || h->layer_tile_req || h->lat_req == 0 || h->loop_mode < 2) return 0;
     int g = (16 * h->ntiles <= h->n_cu) ? 16 : (8 * h->ntiles <= h->n_cu) ? 8 : (4 * h->ntiles <= h->n_cu) ? 4 : (2 * h->ntiles <= h->n_cu) ? 2 : 0;
-    if (g == 0 && h->loop_mode == 2 && h->ntiles < h->n_cu && 8 * h->ntiles <= 5 * h->n_cu) g = 8;
+    // (the band exists for the DIRECT-convolution loop only: the Winograd loop takes 104 ms per launch and wins it back - profiles/r5_03_shape_sweep.jsonl)
+    if (g == 0 && h->loop_mode == 2 && !(h->conv_mode == 1 && h->w1w) && h->ntiles < h->n_cu && 8 * h->ntiles <= 5 * h->n_cu) g = 8;
     if (h->loop_mode == 3 && g == 0) g = 2;
     if (g && (h->lat_req == 2 || h->lat_req == 4 || h->lat_req == 8 || h->lat_req == 16)) g = h->lat_req;
     return g;
@@ -368,8 +365,9 @@ static bool first_on_device(int site) {
 // Bit 1 of the word (kLoopRangeBit, dsd_loop_split.hpp: an activation left fp16's range in the pair format) goes to the second pinned word.
 __global__ void k_latch_tmo(const unsigned* tmo, unsigned* sticky) {
     const unsigned v = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // both bits independently: a launch can meet a range fault in one tile and a genuine spin-bound timeout in another
     if (v & 2u) __hip_atomic_fetch_add(sticky + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    else if (v != 0u) __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (v & ~2u) __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Debug / test hook kernel: holds a CU (all of its LDS) for `ticks` of the 100 MHz wall clock, or until the caller sets the release word
@@ -398,9 +396,11 @@ static int sticky_alloc(dsd_handle* h) {
 // handle on the hipGraph path (a retry of the same call then runs the per-layer kernels) and fails with DSD_ERR_TIMEOUT.
 static int check_sticky(dsd_handle* h, const char* who) {
     if (!h->sticky_host) return DSD_OK;
+    // a genuine timeout (bit 0 of a launch's word) is reported first and parks the handle; a range report of the same launches stays latched
+    // and is delivered by the next call.  (A range fault makes the other workgroups leave their waits EARLY - that raises no timeout bit.)
+    if (__atomic_load_n(h->sticky_host, __ATOMIC_ACQUIRE) == 0u)
     if (const unsigned r = __atomic_load_n(h->sticky_host + 1, __ATOMIC_ACQUIRE)) {
         __atomic_store_n(h->sticky_host + 1, 0u, __ATOMIC_RELEASE);
-        __atomic_store_n(h->sticky_host, 0u, __ATOMIC_RELEASE);       // (the workgroups that saw the flag left their waits early: not timeouts)
         return fail(DSD_ERR_RANGE,
                     "%s: %u split-precision loop launch(es) of an EARLIER call on this handle met an activation outside fp16's range (|x| > 65504) - the "
                     "pair format (two fp16 planes per operand, DSD_SPLIT_W=2) cannot hold it; the mel / x tiles those calls returned are NaN.  Turn "
@@ -989,7 +989,10 @@ static bool loop_applicable(const dsd_handle* h) {
         // have no such constraint, only the wave quantisation of their grid, and cost ~5 % more at equal occupancy
         const int upc = std::max(1, h->n_cu / h->ntile32), chunks = (h->B + upc - 1) / upc;
         const double u_p = (double)h->ntiles / ((double)chunks * h->n_cu);
-        const double u_l = 0.95 * (double)h->ntiles / ((double)((h->ntiles + h->n_cu - 1) / h->n_cu) * h->n_cu);
+        // (the per-layer kernels evaluate the direct convolution: at equal occupancy they take 1.05 x the direct loop's time and 1.29 x the
+        // Winograd loop's - 133 ms against 127 / 103.7 ms per 256 tiles)
+        const double rel = (h->conv_mode == 1 && h->w1w && !h->split_mode) ? 0.78 : 0.95;
+        const double u_l = rel * (double)h->ntiles / ((double)((h->ntiles + h->n_cu - 1) / h->n_cu) * h->n_cu);
         if (u_l > u_p) return false;
     }
     return true;
@@ -1052,15 +1055,8 @@ static int run_persistent(dsd_handle* h, int kind, int k_step, int interval, hip
             // Winograd F(2,3) form of the dilated convolution (dsd_loop_wino.hpp): the default of this path
             const LoopWinoParams q{p, h->w1w, (unsigned)((size_t)h->L * kWnSteps * kWnStepBytes), h->wino_touch};
             const dim3 grid((unsigned)p.n_tiles), block(kThreads);
-            // (bring-up: DSD_WINO_V = 0 / 1 / 3 selects how the waits are placed, DDPM only - results do not depend on it)
-            int vv = 3;
-            if (const char* ev = std::getenv("DSD_WINO_V")) vv = std::atoi(ev);
-#define DSD_LAUNCH_WINO(ST) do { if (kind != 0) hipLaunchKernelGGL((k_loop_wino<HEAD_PLMS, ST, 3>), grid, block, kLoopWinoLdsBytes, s, q); \
-                                 else if (vv == 0) hipLaunchKernelGGL((k_loop_wino<HEAD_DDPM, ST, 0>), grid, block, kLoopWinoLdsBytes, s, q); \
-                                 else if (vv == 1) hipLaunchKernelGGL((k_loop_wino<HEAD_DDPM, ST, 1>), grid, block, kLoopWinoLdsBytes, s, q); \
-                                 else hipLaunchKernelGGL((k_loop_wino<HEAD_DDPM, ST, 3>), grid, block, kLoopWinoLdsBytes, s, q); } while (0)
-            if (h->wino_stages == 4) DSD_LAUNCH_WINO(4); else DSD_LAUNCH_WINO(8);
-#undef DSD_LAUNCH_WINO
+            if (kind == 0) hipLaunchKernelGGL((k_loop_wino<HEAD_DDPM, 4>), grid, block, kLoopWinoLdsBytes, s, q);
+            else hipLaunchKernelGGL((k_loop_wino<HEAD_PLMS, 4>), grid, block, kLoopWinoLdsBytes, s, q);
         } else if (kind == 0) hipLaunchKernelGGL((k_loop<HEAD_DDPM>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         else hipLaunchKernelGGL((k_loop<HEAD_PLMS>), dim3((unsigned)p.n_tiles), dim3(kThreads), kLoopLdsBytes, s, p);
         HIP_TRY(hipGetLastError());
@@ -1258,13 +1254,11 @@ extern "C" int dsd_set_lat_split(dsd_handle* h, int32_t g) {
 
 extern "C" int dsd_get_lat_split(dsd_handle* h) { return (h && h->prepared) ? lat_g(h) : 0; }
 
-extern "C" int dsd_set_conv_mode(dsd_handle* h, int32_t mode, int32_t touch_ahead, int32_t stages) {
+extern "C" int dsd_set_conv_mode(dsd_handle* h, int32_t mode, int32_t touch_ahead) {
     if (!h || mode < 0 || mode > 1) return fail(DSD_ERR_INVALID, "dsd_set_conv_mode: mode must be 0 (direct K = 768 contraction) or 1 (Winograd F(2,3))");
     if (touch_ahead < -1 || touch_ahead > 64) return fail(DSD_ERR_INVALID, "dsd_set_conv_mode: touch_ahead must be -1 (keep), 0 (off) .. 64 steps");
-    if (!(stages == -1 || stages == 4 || stages == 8)) return fail(DSD_ERR_INVALID, "dsd_set_conv_mode: stages must be -1 (keep), 4 or 8");
     h->conv_mode = mode;
     if (touch_ahead >= 0) h->wino_touch = touch_ahead;
-    if (stages > 0) h->wino_stages = stages;
     return DSD_OK;
 }
 

@@ -90,9 +90,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NMB][NB], const float4 (
 // block and its filter block / a residual block and its skip block (the row-split kernels of dsd_lat.hpp).
 // BV: the B tile is FRAME-MAJOR ([frame][k], k contiguous; dsd_loop_fm.hpp): the four k values of a chunk a lane needs (k = 4h + s) are
 // ONE aligned ds_read_b128 instead of four ds_read_b32 at a stride of LD.
-// W1: ONE wait for the NMB fragments of a chunk (an empty statement in front of the chunk uses a register of each) instead of one in front of
-// each of its first NMB MFMAs - every instruction beside an fp32 MFMA is paid for in matrix time (tools/mfma_filler_probe.hip).
-template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff, int MBS = 1, bool BV = false, bool W1 = false>
+template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff, int MBS = 1, bool BV = false>
 struct GemmPipe {
     static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
     static_assert(!BV || NB == 1, "frame-major B tiles are one 32-frame block wide");
@@ -165,10 +163,6 @@ struct GemmPipe {
     __device__ __forceinline__ void start() { start_a(); start_b(); }
     template <int I>
     __device__ __forceinline__ void step(f32x16 (&acc)[NMB][NB], int it) {
-        if constexpr (W1) {
-            if constexpr (NMB == 4) asm volatile("" : : "v"(a[I % STAGES][0].x), "v"(a[I % STAGES][1].x), "v"(a[I % STAGES][2].x), "v"(a[I % STAGES][3].x));
-            else if constexpr (NMB == 2) asm volatile("" : : "v"(a[I % STAGES][0].x), "v"(a[I % STAGES][1].x));
-        }
         lda(a[(I + STAGES - 1) % STAGES], 6 * it + I + STAGES - 1);
         ldb(b[(I + 1) & 1], it, I + 1);
         mma_chunk<NMB, NB>(acc, a[I % STAGES], b[I & 1]);

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_split(const LoopSplitParam
                 for (int spins = 0;; ++spins) {
                     if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ph + 1u) break;
                     if ((spins & 255) == 255 && timed_out()) break;
-                    if (spins >= kLoopSpinLimit) { __hip_atomic_store((gu32*)p.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (spins >= kLoopSpinLimit) { __hip_atomic_fetch_or((gu32*)p.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // (fetch_or: a concurrent range bit survives)
                     __builtin_amdgcn_s_sleep(1);
                 }
             }

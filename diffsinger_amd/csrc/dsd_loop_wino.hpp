@@ -108,9 +108,11 @@ struct L2TouchP {
 // Operand pipeline of the Winograd contraction.  A: S register stages of one step (4 float4 = the four row blocks of a half) straight from
 // global / L2, step k + S - 1 requested while step k is multiplied.  B: the raw operand rows of the NEXT 16-channel chunk are read at the first
 // step of a group of four, transformed (one add each) at its last.  Everything that walks - the stream offset, the chunk pointers into the y
-// tile, the touch's turn - is RUNNING state advanced once per period of eight steps, so that a step carries 16 MFMAs, 4 loads, one wait (V & 1:
-// all four fragments of the step are awaited together) and one scalar add.
-template <int S, int V>
+// tile, the touch's turn - is RUNNING state advanced once per period of eight steps, so that a step carries 16 MFMAs, 4 loads, their waits and
+// one scalar add.  What the fillers cost beside a 32-cycle fp32 MFMA (tools/mfma_filler_probe.hip, profiles/r5_02_mfma_filler_probe.jsonl):
+// a satisfied s_waitcnt nothing, a ds_read_b128 under one cycle, a VECTOR-ALU instruction 8 cycles of matrix time (+ 5 for the first one
+// in a gap: the fp32 matrix pipe and the vector ALU do not overlap) - so the input transform's eight adds go into ONE gap of a group's last step.
+template <int S>
 struct WinoPipe {
     static_assert(S == 4 || S == 8, "the register rotation has period 8");
     __amdgpu_buffer_rsrc_t rsrc;    // over the whole stream behind this wave's 4 KiB of step 0 / layer 0
@@ -179,11 +181,8 @@ struct WinoPipe {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 12 - (NH ? 4 : 2), 0);
         } else if constexpr ((I & 3) == 3) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);          // the eight adds of the next chunk's input transform: one gap
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         } else {
             __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
@@ -205,11 +204,6 @@ struct WinoPipe {
     template <int I, int NH>
     __device__ __forceinline__ void step(f32x4w (&acc)[2][8]) {
         constexpr int grp = I >> 2, pos = (I >> 1) & 1, hb = I & 1;
-        if constexpr (V & 1) {
-            // ONE wait for the four fragments of this step (requested together S - 1 steps ago) instead of one in front of each of the first
-            // four MFMAs: the empty statement uses a register of every fragment
-            asm volatile("" : : "v"(a[I % S][0].x), "v"(a[I % S][1].x), "v"(a[I % S][2].x), "v"(a[I % S][3].x));
-        }
         lda<I + S - 1>(a[(I + S - 1) % S]);
         if constexpr ((I & 3) == 0) ldb_raw<NH, 4 * (I >> 2)>();
         if constexpr ((I & 3) == 3) transform<NH>(v[grp ^ 1]);
@@ -246,7 +240,7 @@ struct LoopWinoParams {
     int touch_ahead;            // steps the L2 touch runs in front (0 = off)
 };
 
-template <int MODE, int S, int V>
+template <int MODE, int S>
 __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams pw) {
     constexpr int LDK = kFmLDK;
     const LoopParams& p = pw.lp;
@@ -355,7 +349,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
             const int dil = (int)p.dil[l], de = __builtin_ctz((unsigned)dil);
 
             // (c) the weight stream does not depend on anything computed here: request its first steps now
-            WinoPipe<S, V> pipe1(pw.w1w + (size_t)w * 256, lane, l, ytile + pp * LDK + 64 * gg, ytile + kWnOBase + (8 + pp) * LDK + 64 * gg, dil * LDK, tc);
+            WinoPipe<S> pipe1(pw.w1w + (size_t)w * 256, lane, l, ytile + pp * LDK + 64 * gg, ytile + kWnOBase + (8 + pp) * LDK + 64 * gg, dil * LDK, tc);
             pipe1.template start_a<S - 1>();
 
             // (b) own frames of y = x + step_proj (zero at frames >= T: the conv's zero padding applies to y, net.py:69-71): the lane's 32
@@ -485,7 +479,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
             LOOP_STAMP(3);
             if (!last) {
                 // output projection, all four row blocks (0,1 residual, 2,3 skip) in one pass
-                GemmPipe<4, 1, LDK, 256, 6, TileBT, 1, true, (V & 2) != 0> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
+                GemmPipe<4, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
@@ -529,7 +523,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 LOOP_STAMP(7);
             } else {
                 // last layer: only the skip half (net.py:126 reads the skips; the residual is dead)
-                GemmPipe<2, 1, LDK, 256, 6, TileBT, 1, true, (V & 2) != 0> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256) + 2 * 64, lane, 32, bof2);
+                GemmPipe<2, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256) + 2 * 64, lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
                 __syncthreads();
@@ -601,7 +595,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
             pipe_o.start_b();
             pipe_o.run(acc, 0, 32);
             HEAD_STAMP(4);
-            const int t = t0 + j;
+            // (an opaque zero defined HERE keeps the 16 element indices - and the Philox products that hang on them - in this block: as loop
+            // invariants of the evaluation loop they would live, spilled to scratch, across every contraction of the kernel)
+            int oz;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+            const int t = t0 + j + oz;
             // sampler arithmetic (p_sample :134-166 / p_sample_plms :168-204): all global reads of the 16 elements first, then the math, then the stores
             size_t idxs[16];
             bool oks[16];

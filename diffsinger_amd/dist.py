@@ -105,9 +105,12 @@ def pad_stack(tensors: Sequence[torch.Tensor], T: int) -> torch.Tensor:
 
 def _run_checked(model, run_shard, rank):
     """run_shard() with the loud-failure contract of the persistent loops (include/dsd.h dsd_check): a loop starved by a foreign kernel
-    raises 'spin bound'; every rank must still arrive at the collective, so the shard is repeated - the engine is parked on the hipGraph
-    path (no co-residency requirement) since the report.  Loops of LATER micro-batches may have been enqueued against the same foreign kernel
-    and latch their timeout after the report: drain the stream and swallow those late reports before every retry."""
+    raises 'spin bound'; every rank must still arrive at the collective, so the shard is repeated - with the engine PINNED on the per-layer
+    hipGraph path (loop mode 0: no co-residency requirement) for the whole retry and its mode restored afterwards.  (The handle parks itself
+    after a report, but only for 16 sampling calls: a shard of more micro-batches than that - 96 ragged utterances in micro-batches of 8 -
+    would re-arm the persistent loop in the middle of the retry, against the same foreign kernel: ADVICE r4.)  Loops of LATER micro-batches
+    may have been enqueued against the same foreign kernel and latch their timeout after the report: drain the stream and swallow those
+    late reports before every retry."""
     try:
         return run_shard()
     except RuntimeError as e:
@@ -116,6 +119,18 @@ def _run_checked(model, run_shard, rank):
         first = e
     import warnings
     warnings.warn(f'rank {rank}: {first}  -- repeating the shard on the hipGraph path')
+    eng = getattr(getattr(model, 'denoise_fn', None), '_engine', None)
+    prev = eng.requested_loop_mode() if eng is not None and hasattr(eng, 'requested_loop_mode') else None
+    if prev is not None:
+        eng.set_loop_mode(0)
+    try:
+        return _retry_shard(model, run_shard, first)
+    finally:
+        if prev is not None:
+            eng.set_loop_mode(prev)                      # (an explicit choice also re-arms the persistent path for the next shard)
+
+
+def _retry_shard(model, run_shard, first):
     for attempt in range(3):
         if torch.cuda.is_available():
             torch.cuda.current_stream().synchronize()

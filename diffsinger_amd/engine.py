@@ -3,6 +3,7 @@ device tensors whose raw pointers, sizes and strides cross the C ABI, and the cu
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -109,12 +110,12 @@ class DenoiserEngine:
         """G of the latency kernels the prepared batch runs with, 0 = not on that path."""
         return self.lib.dsd_get_lat_split(self._h)
 
-    def set_conv_mode(self, mode, touch_ahead: int = -1, stages: int = -1):
+    def set_conv_mode(self, mode, touch_ahead: int = -1):
         """How the PERSISTENT loop evaluates the dilated convolution (csrc/dsd_loop_wino.hpp): 'winograd' / 1 (default) = Winograd F(2,3)
         along the frame axis, 2/3 of the fp32 multiplications; 'direct' / 0 = the K = 768 contraction, bit-identical to the per-layer
-        kernels.  touch_ahead / stages: tuning knobs of the transformed-weight stream (-1 = keep)."""
+        kernels.  touch_ahead: steps the L2 touch of the transformed-weight stream runs in front (0 = off, -1 = keep)."""
         m = {'direct': 0, 'winograd': 1}.get(mode, mode)
-        _lib.check(self.lib.dsd_set_conv_mode(self._h, int(m), int(touch_ahead), int(stages)), 'dsd_set_conv_mode')
+        _lib.check(self.lib.dsd_set_conv_mode(self._h, int(m), int(touch_ahead)), 'dsd_set_conv_mode')
 
     def conv_mode(self) -> int:
         """1 if the prepared batch runs the persistent loop with the Winograd convolution, else 0."""
@@ -124,6 +125,11 @@ class DenoiserEngine:
         """2 (default): automatic - latency kernels for small batches, else the persistent loop / per-layer kernels by chip occupancy;
         1: the whole K-step loop as one persistent kernel when the batch allows it; 0: per-layer kernels; 3: latency kernels."""
         _lib.check(self.lib.dsd_set_loop_mode(self._h, int(mode)), 'dsd_set_loop_mode')
+        self._loop_req = int(mode)
+
+    def requested_loop_mode(self) -> int:
+        """The mode last asked for with set_loop_mode (or DSD_LOOP at creation; default 2) - not the path the prepared batch takes (loop_mode())."""
+        return getattr(self, '_loop_req', int(os.environ.get('DSD_LOOP', '2') or 2))
 
     def loop_mode(self) -> int:
         return self.lib.dsd_get_loop_mode(self._h)

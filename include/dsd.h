@@ -189,10 +189,10 @@ int dsd_get_lat_split(dsd_handle* h);
  *     (~1e-5 on a K = 100 loop against a 1e-4 budget; tests/test_gpu_wino.py).
  *   0 the direct K = 768 contraction (k_loop): bit-identical to loop modes 0 and the G = 2 / 4 latency kernels.
  * Every other path (per-layer kernels, latency kernels, dsd_denoise / dsd_p_sample / training) evaluates the direct form.  touch_ahead: steps
- * (16 KiB of the transformed-weight stream) the waves of an XCD fetch into their L2 ahead of themselves, 0 = off, -1 = keep (default 16);
- * stages: register stages of that stream, 4 or 8, -1 = keep (default 8) - tuning knobs of tools/, results do not depend on them.
+ * (16 KiB of the transformed-weight stream) the waves of an XCD fetch into their L2 ahead of themselves, 0 = off, -1 = keep (default 16) - a
+ * tuning knob of tools/, results do not depend on it.
  * dsd_get_conv_mode: 1 if the prepared batch runs the persistent loop with the Winograd form.  Environment: DSD_CONV=direct|winograd at dsd_create. */
-int dsd_set_conv_mode(dsd_handle* h, int32_t mode, int32_t touch_ahead, int32_t stages);
+int dsd_set_conv_mode(dsd_handle* h, int32_t mode, int32_t touch_ahead);
 int dsd_get_conv_mode(dsd_handle* h);
 
 /* EXPERIMENT (csrc/dsd_split.hpp, csrc/dsd_loop_split.hpp; default off, env DSD_SPLIT=1 turns it on at creation): the residual layers on

@@ -115,3 +115,56 @@ def test_plan_is_a_partition_bucketed_and_world_independent():
         assert max(load) / (sum(load) / world) <= 1.05, (world, load)
     # equal lengths stay on the reference's r::W split (bench configs[4]); a single utterance is one batch on rank 0
     assert plan_ragged([100], 4)[1] == [0]
+
+
+def test_shard_retry_pins_the_engine_off_the_persistent_path_for_more_micro_batches_than_the_parking_lasts():
+    """a handle parks itself for 16 sampling calls after a reported timeout; a shard of MORE micro-batches than that used
+    to re-arm the persistent loop in the middle of the retry, against the foreign kernel that starved it - three failed retries, the rank
+    raises before the gather and the other ranks hang.  The retry now pins loop mode 0 (per-layer hipGraph: no co-residency requirement)
+    and restores the caller's mode afterwards.  Model of the engine's parking rule, no GPU."""
+    from diffsinger_amd.dist import _run_checked
+
+    class Eng:
+        def __init__(self):
+            self.req, self.parked, self.calls_log = 2, 0, []
+
+        def set_loop_mode(self, m):
+            self.req, self.parked = m, 0                 # an explicit choice re-arms (dsd_set_loop_mode)
+
+        def requested_loop_mode(self):
+            return self.req
+
+        def sample(self):                                # one micro-batch; the foreign kernel is resident all the time
+            persistent = self.req in (1, 2) and self.parked == 0
+            self.calls_log.append(persistent)
+            if persistent:
+                self.parked = 16                         # reported: parked for the next 16 calls (kParkedCalls)
+                raise RuntimeError('dsd_sample_ddpm: 1 persistent K-step loop launch(es) ... hit the inter-workgroup spin bound')
+            if self.parked:
+                self.parked -= 1
+
+    class Net:
+        pass
+
+    class Model:
+        def __init__(self):
+            self.denoise_fn = Net()
+            self.denoise_fn._engine = Eng()
+
+        def check_loops(self):
+            pass
+
+    m = Model()
+    eng = m.denoise_fn._engine
+
+    def run_shard():
+        for _ in range(24):                              # 24 micro-batches > 16
+            eng.sample()
+        return 'mels'
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        assert _run_checked(m, run_shard, 0) == 'mels'
+    assert eng.requested_loop_mode() == 2                # restored
+    assert eng.calls_log[0] is True and not any(eng.calls_log[1:])      # one starved loop, then 24 micro-batches on the per-layer path

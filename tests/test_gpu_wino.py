@@ -81,8 +81,8 @@ def test_winograd_loop_full_width_all_dilations(B, T, K):
     assert d <= 1e-5
 
 
-def test_results_do_not_depend_on_the_stream_knobs_and_seeded_noise_matches_explicit_noise():
-    """The L2 touch computes nothing and the register stages only move loads: every (touch lead, stages) setting gives the same bits; the
+def test_results_do_not_depend_on_the_touch_lead_and_seeded_noise_matches_explicit_noise():
+    """The L2 touch computes nothing: every lead (and off) gives the same bits; the
     in-kernel Philox draw equals the explicit-noise loop fed with the same draws; replays are deterministic."""
     import diffsinger_amd
     from diffsinger_amd import hparams
@@ -103,15 +103,15 @@ def test_results_do_not_depend_on_the_stream_knobs_and_seeded_noise_matches_expl
     eng.set_loop_mode(1)
     noise = torch.stack([eng.philox_normal(seed, j, B * 80 * T).reshape(B, 1, 80, T) for j in range(K)])
     ref = None
-    for touch, stages in ((16, 8), (0, 8), (4, 8), (32, 8), (16, 4), (0, 4)):
-        eng.set_conv_mode('winograd', touch, stages)
+    for touch in (16, 0, 4, 32, 64):
+        eng.set_conv_mode('winograd', touch)
         with torch.no_grad():
             out = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).cpu().numpy()
         assert eng.conv_mode() == 1 and eng.loop_timeouts() == 0
         if ref is None:
             ref = out
-        np.testing.assert_array_equal(out, ref, err_msg=f'touch {touch}, stages {stages}')
-    eng.set_conv_mode('winograd', 16, 8)
+        np.testing.assert_array_equal(out, ref, err_msg=f'touch {touch}')
+    eng.set_conv_mode('winograd', 16)
     with torch.no_grad():
         seeded = gd.inference(cond, x_T=x_T, K_step=K, pndm_speedup=0, noise_seed=seed).cpu().numpy()
     np.testing.assert_array_equal(seeded, ref)
@@ -181,3 +181,21 @@ def test_starved_winograd_loop_is_loud_and_the_retry_succeeds():
     eng.set_loop_mode(1)
     np.testing.assert_array_equal(run(check=True).cpu().numpy(), ref)
     assert eng.loop_mode() == 1 and eng.conv_mode() == 1 and eng.loop_timeouts() == 0
+
+
+def test_default_path_choice_with_the_winograd_loop():
+    """Automatic mode, default convolution: small batches keep the latency kernels (G = 16 / 8 / 4 / 2 while every workgroup finds a CU); the
+    129-160-tile band that the DIRECT loop left to G = 8 on several grid waves (113-117 ms against its 127) belongs to the Winograd loop
+    (104 ms per launch, profiles/r5_03_shape_sweep.jsonl); utterances whose chunking idles 40 % of the chip stay with the per-layer kernels."""
+    from tests.gpu_helpers import build_hip
+    gd, _, _ = build_hip('lj_ds_beta6', 100)
+    want = {(1, 512): (16, 0), (1, 1000): (8, 0), (1, 1550): (4, 0), (4, 777): (2, 0), (3, 1550): (0, 1), (1, 5000): (0, 1), (1, 5200): (0, 1),
+            (8, 1024): (0, 1), (5, 1550): (0, 1)}
+    for (B, T), (lat, loop) in want.items():
+        cond = torch.randn(B, T, 256, device='cuda').transpose(1, 2)
+        eng = gd._engine(cond)
+        assert (eng.lat_split(), eng.loop_mode()) == (lat, loop), ((B, T), eng.lat_split(), eng.loop_mode())
+        assert eng.conv_mode() == loop
+    cond = torch.randn(3, 5000, 256, device='cuda').transpose(1, 2)       # 157 tiles per utterance: one utterance per persistent launch = 61 % of the chip
+    eng = gd._engine(cond)
+    assert eng.lat_split() == 0 and eng.loop_mode() == 0 and eng.conv_mode() == 0      # per-layer kernels: 471 tiles = 92 % of two grid waves

@@ -6,7 +6,7 @@ import numpy as np, torch
 import bench
 B, T, K = 8, 1024, 6
 PHASES = None
-CONV, TOUCH, STAGES = 'winograd', -1, -1
+CONV, TOUCH = 'winograd', -1
 for a in list(sys.argv[1:]):
     if a.startswith('--k='):
         K = int(a[4:]); sys.argv.remove(a)
@@ -16,8 +16,6 @@ for a in list(sys.argv[1:]):
         CONV = a[7:]; sys.argv.remove(a)
     elif a.startswith('--touch='):
         TOUCH = int(a[8:]); sys.argv.remove(a)
-    elif a.startswith('--stages='):
-        STAGES = int(a[9:]); sys.argv.remove(a)
 dev = torch.device('cuda', 0)
 gd, pre = bench.build_model(dev)
 g = torch.Generator(device=dev).manual_seed(1)
@@ -26,7 +24,7 @@ x = torch.randn(B, 80, T, device=dev, generator=g)
 noise = torch.randn(K, B, 80, T, device=dev, generator=g)
 eng = gd._engine(cond)
 eng.set_loop_mode(1)
-eng.set_conv_mode(CONV, TOUCH, STAGES)
+eng.set_conv_mode(CONV, TOUCH)
 WINO = eng.conv_mode() == 1
 SPLIT = '--split' in sys.argv
 if SPLIT:

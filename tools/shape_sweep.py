@@ -18,7 +18,8 @@ import diffsinger_amd
 from diffsinger_amd import hparams
 from diffsinger_amd.synth import presets
 
-F_EXEC = 21_053_440
+F_EXEC = 21_053_440            # direct convolution (per-layer / latency kernels, k_loop)
+F_EXEC_WINO = 15_810_560       # Winograd F(2,3) convolution (k_loop_wino, the default of the persistent path)
 PEAK_TF = 157.3
 SHAPES = [(1, 512), (1, 1550), (4, 777), (8, 1000), (8, 1024), (5, 1550), (3, 5000), (2, 8000), (16, 2048)]
 
@@ -61,9 +62,10 @@ def main():
             torch.cuda.synchronize()
             sec = (time.perf_counter() - t0) / reps
             assert bool(torch.isfinite(out).all()) and eng.loop_timeouts() == 0
-            tf = B * T * 100 * F_EXEC / sec / 1e12
+            wino = eng.loop_mode() == 1 and eng.conv_mode() == 1
+            tf = B * T * 100 * (F_EXEC_WINO if wino else F_EXEC) / sec / 1e12
             path = (f'latency G={eng.lat_split()}' if eng.lat_split()
-                    else ('persistent' if eng.loop_mode() == 1 else f'per-layer tile {eng.layer_tile()}'))
+                    else (('persistent, Winograd conv' if wino else 'persistent, direct conv') if eng.loop_mode() == 1 else f'per-layer tile {eng.layer_tile()}'))
             if mode == 2:
                 row.update({'path': path, 'ms_per_pass': round(sec * 1e3, 3), 'mel_frames_per_s': round(B * T / sec, 1),
                             'tflops_executed': round(tf, 2), 'frac_fp32_mfma_peak': round(tf / PEAK_TF, 4)})
@@ -75,7 +77,7 @@ def main():
             # forced row splits of the latency kernels (also with more workgroups than CUs: they are ordinary launches)
             eng = gd.denoise_fn.engine()
             row['forced_lat'] = {}
-            for G in (4, 8):
+            for G in (2, 4, 8):
                 eng.set_loop_mode(3)
                 eng.set_lat_split(G)
                 out = one()

@@ -1,5 +1,5 @@
 """Developer tool (GPU): A/B of the persistent loop's convolution forms on BASELINE configs[1] (8 x 1024, K = 100 DDPM): the direct K = 768 form
-(k_loop) against the Winograd F(2,3) form (k_loop_wino) over the L2 touch's lead and the register stages of its weight stream.  One JSON line
+(k_loop) against the Winograd F(2,3) form (k_loop_wino) over the lead of the L2 touch of its weight stream.  One JSON line
 per variant: ms per sampling call (HIP events, 3 calls), mel-frames/s of the loop alone, executed TFLOP/s and the fraction of the fp32 MFMA
 peak, max-abs difference of the normalised x against the direct form."""
 import json, os, sys
@@ -21,12 +21,11 @@ for (B, T) in shapes:
     eng = gd._engine(cond)
     eng.set_loop_mode(1)
     ref = None
-    variants = [('direct', -1, -1, 3)] + [('winograd', t, s, v) for v in (3, 1, 0) for s in (4, 8) for t in (16, 0, 32)]
+    variants = [('direct', -1)] + [('winograd', t) for t in (16, 0, 8, 32)]
     if len(shapes) > 1:
-        variants = [('direct', -1, -1, 3), ('winograd', -1, -1, 3)]
-    for conv, touch, stages, vv in variants:
-        os.environ['DSD_WINO_V'] = str(vv)           # bring-up knob of the library: placement of the waits (read at every launch)
-        eng.set_conv_mode(conv, touch, stages)
+        variants = [('direct', -1), ('winograd', -1)]
+    for conv, touch in variants:
+        eng.set_conv_mode(conv, touch)
         eng.prepare(cond)
         xs = x.clone()
         eng.sample_ddpm(xs, noise, K)
@@ -44,8 +43,7 @@ for (B, T) in shapes:
         wino = eng.conv_mode() == 1
         f = bench.F_EVAL_EXEC_WINO if wino else bench.F_EVAL_EXEC
         tf = B * T * K * f / (ms * 1e-3) / 1e12
-        print(json.dumps({'shape': [B, T], 'conv': conv, 'touch': touch, 'stages': stages, 'waits_v': vv, 'kernel': 'k_loop_wino' if wino else 'k_loop', 'launches': eng.loop_launches(),
+        print(json.dumps({'shape': [B, T], 'conv': conv, 'touch': touch, 'kernel': 'k_loop_wino' if wino else 'k_loop', 'launches': eng.loop_launches(),
                           'ms_per_call': round(ms, 3), 'mel_frames_per_s': round(B * T / ms * 1e3, 1), 'tflops_executed': round(tf, 2),
                           'frac_fp32_mfma_peak': round(tf / bench.PEAK_FP32_MFMA_TFLOPS, 4), 'max_abs_x_vs_direct': float((out - ref).abs().max())}), flush=True)
-    os.environ['DSD_WINO_V'] = '3'
-    eng.set_conv_mode('winograd', 16, 8)
+    eng.set_conv_mode('winograd', 16)
