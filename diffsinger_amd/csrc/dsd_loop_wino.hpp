@@ -153,17 +153,31 @@ struct WinoPipe {
             raw[3] = *reinterpret_cast<const float4*>(rE + O);
         }
     }
+    // one add per operand, as v_pk_add_f32 on pairs: a vector-ALU instruction beside the fp32 MFMAs costs 8 cycles of matrix time whether it is
+    // packed or not (tools/mfma_filler_probe.hip) - four instructions per chunk and product pair instead of eight
     template <int HALF>
     __device__ __forceinline__ void transform(float (&dst)[2][4]) {
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        // (the differences as explicit v_pk_add_f32 with the second source negated: hipcc packs the sums and leaves half of the differences scalar)
+        auto pk_sub = [](f32x2_ a, f32x2_ b) -> f32x2_ {
+            f32x2_ d;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+            return d;
+        };
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 4; s += 2) {
+            const f32x2_ r0 = {f4at(raw[0], s), f4at(raw[0], s + 1)}, r1 = {f4at(raw[1], s), f4at(raw[1], s + 1)};
+            f32x2_ p0, p1;
             if constexpr (HALF == 0) {
-                dst[0][s] = f4at(raw[0], s) + f4at(raw[1], s);          // d1 + d2
-                dst[1][s] = f4at(raw[1], s) - f4at(raw[0], s);          // d2 - d1
+                p0 = r0 + r1;                                            // d1 + d2
+                p1 = pk_sub(r1, r0);                                     // d2 - d1
             } else {
-                dst[0][s] = f4at(raw[0], s) - f4at(raw[1], s);          // d0 - d2
-                dst[1][s] = f4at(raw[2], s) - f4at(raw[3], s);          // d3 - d1
+                const f32x2_ r2 = {f4at(raw[2], s), f4at(raw[2], s + 1)}, r3 = {f4at(raw[3], s), f4at(raw[3], s + 1)};
+                p0 = pk_sub(r0, r1);                                     // d0 - d2
+                p1 = pk_sub(r2, r3);                                     // d3 - d1
             }
+            dst[0][s] = p0[0]; dst[0][s + 1] = p0[1];
+            dst[1][s] = p1[0]; dst[1][s + 1] = p1[1];
         }
     }
     template <int I, int NH>
@@ -182,7 +196,7 @@ struct WinoPipe {
             __builtin_amdgcn_sched_group_barrier(0x008, 12 - (NH ? 4 : 2), 0);
         } else if constexpr ((I & 3) == 3) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);          // the eight adds of the next chunk's input transform: one gap
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);          // the four packed adds of the next chunk's input transform: one gap
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         } else {
             __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
@@ -328,18 +342,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 }
         }
     };
-    auto publish_finish = [&](unsigned phase) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store((gu32*)(p.flags + tile), phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto publish = [&](unsigned phase) { publish_issue(phase); publish_finish(phase); };
+    // The second half of a publication - every storing wave drained, barrier, ONE flag store - is NOT done where the stores are issued: it is
+    // merged into the top of the next layer, whose barrier behind the y tile it shares (k_loop pays a drain of ~1 us and a barrier of its own
+    // at the end of every layer: 2.6 k of its 147 k cycles; here the stores drain under the skip-sum update, the weight prefetch and the
+    // staging of y).  The protocol is unchanged: the flag of phase ph is raised after the stores of all four waves are visible.
     const bool stamp = p.dbg != nullptr;
 #define LOOP_STAMP(i) do { if (stamp && ph == (unsigned)p.dbg_phase && lane == 0) p.dbg[((size_t)tl * 4 + w) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define HEAD_STAMP(i) do { if (stamp && e == p.dbg_phase / p.L && lane == 0) p.dbg[((size_t)tl * 4 + w) * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
     unsigned ph = 0;
-    publish(0);
+    publish_issue(0);
     for (int e = 0; e < p.n_evals; ++e) {
         const int t_e = p.eval_t[e];
         for (int l = 0; l < p.L; ++l, ++ph) {
@@ -365,7 +377,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                         *reinterpret_cast<float4*>(yrow + c) = fm_add_masked(xq[mb][q], d, in_t);
                     }
             }
+            // (a) this tile's halo frames of phase ph (stored at the end of the previous phase / behind the head's input projection) are
+            //     visible once every wave has drained; the barrier is the one the y tile needs anyway
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (tid == 0) __hip_atomic_store((gu32*)(p.flags + tile), ph + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             LOOP_STAMP(1);
             // (d1) every wave reads the two neighbour flags now (lanes 0 / 1), tested behind the first period
             unsigned fv = 0xffffffffu;
@@ -482,6 +498,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 GemmPipe<4, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
+                dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barrier (that half was last read in phase ph - 1)
                 __syncthreads();
                 LOOP_STAMP(4);
                 f32x16 acc2[4][1];
@@ -510,8 +527,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                                                 (x.z + (v.z + bv.z)) * kInvSqrt2, (x.w + (v.w + bv.w)) * kInvSqrt2);
                     }
                 LOOP_STAMP(6);
-                dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barrier inside publish_finish()
-                publish_issue(ph + 1u);                             // the halo stores drain while the skip sum is updated
+                publish_issue(ph + 1u);                             // the halo stores drain under the skip sum, the next prefetch and y tile
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -519,13 +535,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                         const float4 a = get4(acc2[2 + ms][0], q), s = skp[ms][q];
                         skp[ms][q] = (l == 0) ? a : make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
                     }
-                publish_finish(ph + 1u);
                 LOOP_STAMP(7);
             } else {
                 // last layer: only the skip half (net.py:126 reads the skips; the residual is dead)
                 GemmPipe<2, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256) + 2 * 64, lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
+                dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barrier
                 __syncthreads();
                 f32x16 acc2[2][1];
 #pragma unroll
@@ -534,7 +550,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                     for (int r = 0; r < 16; ++r) acc2[m][0][r] = 0.f;
                 pipe2.start_b();
                 pipe2.run(acc2, 0, 32);
-                dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barriers of the head
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -663,7 +678,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
         HEAD_STAMP(5);
         __syncthreads();
         HEAD_STAMP(6);
-        if (fuse) { inproj_to_xq(); publish(ph); }
+        if (fuse) { inproj_to_xq(); publish_issue(ph); }
         HEAD_STAMP(7);
     }
 #undef LOOP_STAMP
