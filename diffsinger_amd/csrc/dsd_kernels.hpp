@@ -637,9 +637,11 @@ struct CondProjParams {
     const float* condT;     // [B][H=256][TS], zero for t >= T
     const float4* wcp;      // [L][w4][kc32][mb4][lane64]
     const float4* b1p;      // [L][w4][mb4][h2][q4]  (dilated_conv.bias + conditioner_projection.bias)
-    float4* cp;             // [L][ntiles][w4][mb4][q4][lane64], or (wino) [L][ntiles][w4][frame half 2][rb 8][lane64]
+    float4* cp;             // [L][ntiles][w4][mb4][q4][lane64], or (wino) [L][ntiles][w4][accumulator 2][rb 8][lane64]
     int TS, ntile32, ntiles_total;
-    int wino;               // 1: the accumulator order of the Winograd loop (dsd_loop_wino.hpp), which depends on the layer's dilation
+    int wino;               // 1: the INITIAL VALUES of the Winograd loop's two accumulator sets (dsd_loop_wino.hpp), in its accumulator order: for
+                            // the pair p of a layer with dilation d, (cp[tE] + cp[tO]) / 2 and (cp[tE] - cp[tO]) / 2 - the loop's output transform
+                            // (sum / difference of the sets) turns them back into cp[tE] and cp[tO]
     unsigned char dil[64];
 };
 
@@ -659,20 +661,49 @@ __global__ __launch_bounds__(kThreads, 2) void k_condproj(const CondProjParams p
     }
     f32x16 acc[4][1];
     const float4* bl = p.b1p + (((size_t)l * 4 + w) * 4) * 8 + h * 4;
+    // (Winograd order: columns 16 .. 31 are differences of two frames - the biases cancel there)
+    const float bsel = (p.wino && j >= 16) ? 0.f : 1.f;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) set4(acc[mb][0], q, bl[mb * 8 + q]);
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = bl[mb * 8 + q];
+            set4(acc[mb][0], q, make_float4(bv.x * bsel, bv.y * bsel, bv.z * bsel, bv.w * bsel));
+        }
     __syncthreads();
+    if (p.wino) {
+        // the conditioner tile in the loop's pair order: column c < 16 = (cond[tE(c)] + cond[tO(c)]) / 2, column 16 + c the half difference - by
+        // linearity the contraction then yields the half sum / half difference of the projection.  One thread per channel row.
+        const int e = __builtin_ctz((unsigned)p.dil[l]), d = 1 << e;
+        float* row = smem + tid * LD;
+        float v[32], o[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(row + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            // tE = ((c >> e) << (e + 1)) | (c & (d - 1)): a run-time dilation - select among the four compile-time forms
+            const int tE0 = 2 * c, tE1 = ((c >> 1) << 2) | (c & 1), tE2 = ((c >> 2) << 3) | (c & 3), tE3 = ((c >> 3) << 4) | (c & 7);
+            const float a = (e == 0) ? v[tE0] : (e == 1) ? v[tE1] : (e == 2) ? v[tE2] : v[tE3];
+            const float b = (e == 0) ? v[tE0 + 1] : (e == 1) ? v[tE1 + 2] : (e == 2) ? v[tE2 + 4] : v[tE3 + 8];
+            o[c] = 0.5f * (a + b);
+            o[16 + c] = 0.5f * (a - b);
+        }
+        (void)d;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(row + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        __syncthreads();
+    }
     const float4* ap = p.wcp + ((size_t)l * 4 + w) * (32 * 256);
     const float* cl = smem + 4 * h * LD + j;
     gemm_k<4, 1, LD, 256>(acc, ap, lane, 32, TileB{cl, 8 * LD, 32});
     if (p.wino) {
-        // Winograd loop: lane (pair pr, k group g) of v_mfma_f32_16x16x4_f32 holds, for frame half hf (tE / tE + d) and row block rb (16 rows; 0-3
-        // gate, 4-7 filter), rows 4 g + {0..3}.  This lane's float4 (mb, q) = rows 32 (mb & 1) + 8 q + 4 h + {0..3} of the wave's 64 gate
-        // (mb < 2) / filter rows at frame j: rb = 2 (mb & 1) + (q >> 1) (+ 4), g = 2 (q & 1) + h, and frame j is half hf of pair pr.
-        const int e = __builtin_ctz((unsigned)p.dil[l]), d = 1 << e;
-        const int hf = (j >> e) & 1, pr = ((j >> (e + 1)) << e) | (j & (d - 1));
+        // Winograd loop: lane (pair pr, k group g) of v_mfma_f32_16x16x4_f32 holds, for accumulator set i (0: half sum, 1: half difference) and row
+        // block rb (16 rows; 0-3 gate, 4-7 filter), rows 4 g + {0..3}.  This lane's float4 (mb, q) = rows 32 (mb & 1) + 8 q + 4 h + {0..3} of the
+        // wave's 64 gate (mb < 2) / filter rows in column j = 16 i + pr: rb = 2 (mb & 1) + (q >> 1) (+ 4), g = 2 (q & 1) + h.
+        const int hf = j >> 4, pr = j & 15;
         float4* out = p.cp + (((size_t)l * p.ntiles_total + tile) * 4 + w) * (2 * 8 * 64) + (size_t)hf * (8 * 64) + pr;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)

@@ -1,7 +1,7 @@
 """CPU model of the index algebra of the Winograd F(2,3) loop (csrc/dsd_loop_wino.hpp): the transformed-weight stream of k_pack_wino, the
 pair-ordered y tile, the per-lane operand reads and input transforms, the fragment maps of v_mfma_f32_16x16x4_f32, the two halves of the
 contraction with the output transform between them, the gate's (channel, frame) of every accumulator register and k_condproj's
-Winograd-order output - all restated lane by lane in numpy and compared with the reference's own operator (torch conv1d, usr/diff/net.py:61,71)
+Winograd-order output (the accumulators' initial values) - all restated lane by lane in numpy and compared with the reference's own operator (torch conv1d, usr/diff/net.py:61,71)
 for every dilation the kernel supports, with halo frames and a ragged tail.  A wrong shift, row, lane group or sign anywhere shows here, before
 the kernel ever reaches the GPU."""
 import numpy as np
@@ -79,7 +79,7 @@ def run_model(e, wt, y_ext, cp):
     pO = OBASE + (8 + pp) * LDK + 64 * gg
     out = np.zeros((2 * C, 32), np.float64)
     for w in range(4):
-        acc = np.zeros((2, 8, 64, 4), np.float64)
+        acc = cp[w].astype(np.float64).copy()            # the accumulator sets start from k_condproj's halves of the conditioner projection
         for st in range(STEPS):
             hb, pos, c, half = st & 1, (st >> 1) & 1, (st >> 2) & 15, st >> 6
             if st == 64:                                 # output transform between the halves
@@ -95,31 +95,34 @@ def run_model(e, wt, y_ext, cp):
                 assert not np.isnan(v).any(), 'an operand row that nobody wrote'
                 for r4 in range(4):
                     mfma16(stream[st, w, r4, :, s], v.astype(np.float32), acc[pos][4 * hb + r4])
-        # gate mapping: lane (p, g), acc[hf][rb][r] = row (gate rb < 4 / filter) 64 w + 16 (rb & 3) + 4 g + r, frame tE + hf d; + cp in the kernel's order
+        # gate mapping: lane (p, g), acc[hf][rb][r] = row (gate rb < 4 / filter) 64 w + 16 (rb & 3) + 4 g + r, frame tE + hf d
         tE = np.array([frame_of_pair(p, e) for p in pp])
         for hf in range(2):
             for rb in range(8):
                 for r in range(4):
                     rows = (0 if rb < 4 else C) + 64 * w + 16 * (rb & 3) + 4 * gg + r
-                    out[rows, tE + hf * d] += acc[hf][rb][:, r] + cp[w, hf, rb, lanes, r]
+                    out[rows, tE + hf * d] += acc[hf][rb][:, r]
     return out
 
 
 def condproj_wino(e, cpfull):
-    """k_condproj's Winograd-order output for one tile and layer: cpfull [2C][32] -> [w 4][hf 2][rb 8][lane 64][4]"""
+    """k_condproj's Winograd-order output for one tile and layer: the projection cpfull [2C][32] as the INITIAL VALUES of the loop's two
+    accumulator sets - column c < 16 of its (transformed) result is (cp[tE(c)] + cp[tO(c)]) / 2, column 16 + c the half difference (computed
+    there by linearity from the transformed conditioner tile; restated here on the result) -> [w 4][set 2][rb 8][lane 64][4]"""
     d = 1 << e
+    tE = np.array([frame_of_pair(p, e) for p in range(16)])
+    R = np.concatenate([0.5 * (cpfull[:, tE] + cpfull[:, tE + d]), 0.5 * (cpfull[:, tE] - cpfull[:, tE + d])], axis=1).astype(np.float32)
     out = np.full((4, 2, 8, 64, 4), np.nan, np.float32)
     for w in range(4):
         for lane in range(64):
             j, h = lane & 31, lane >> 5
-            hf = (j >> e) & 1
-            pr = ((j >> (e + 1)) << e) | (j & (d - 1))
+            i, pr = j >> 4, j & 15
             for mb in range(4):
                 for q in range(4):
                     rows = (0 if mb < 2 else C) + 64 * w + 32 * (mb & 1) + 8 * q + 4 * h + np.arange(4)
                     rb = 2 * (mb & 1) + (q >> 1) + 4 * (mb >> 1)
                     g = 2 * (q & 1) + h
-                    out[w, hf, rb, pr + 16 * g] = cpfull[rows, j]
+                    out[w, i, rb, pr + 16 * g] = R[rows, j]
     assert not np.isnan(out).any()
     return out
 
