@@ -117,7 +117,8 @@ template <int S>
 struct WinoPipe {
     static_assert(S == 4 || S == 8, "the register rotation has period 8");
     __amdgpu_buffer_rsrc_t rsrc;    // over the whole stream behind this wave's 4 KiB of step 0 / layer 0
-    unsigned aoff, so;              // lane * 16; byte offset of step 0 of the CURRENT period
+    unsigned vo[4], so;             // lane * 16 + 1024 r4 (kept in registers: rematerialised, they are four vector-ALU instructions per period beside
+                                    // the MFMAs); byte offset of step 0 of the CURRENT period
     const float *qE, *qO;           // halo-free half: rows E[p], O[p] at the chunk the next read takes
     const float *rOm, *rO, *rEp, *rE;   // second half: rows O[p - d], O[p], E[p + d], E[p]
     L2TouchP& tc;
@@ -127,9 +128,15 @@ struct WinoPipe {
     float v[2][2][4];               // [group parity][product][k step]
 
     __device__ __forceinline__ WinoPipe(const float4* wave_base, int lane, int l, const float* pE, const float* pO, int dilrow, L2TouchP& tc_)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wave_base), 0, 0x7ffffff0, 0x00020000)), aoff((unsigned)lane * 16u),
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wave_base), 0, 0x7ffffff0, 0x00020000)),
           so((unsigned)l * (unsigned)(kWnSteps * kWnStepBytes)), qE(pE), qO(pO), rOm(pO - dilrow - 4), rO(pO - 4), rEp(pE + dilrow - 4), rE(pE - 4),
-          tc(tc_), gper((unsigned)l * (unsigned)(kWnSteps / 8)) {}
+          tc(tc_), gper((unsigned)l * (unsigned)(kWnSteps / 8)) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            vo[r4] = (unsigned)lane * 16u + (unsigned)r4 * 1024u;
+            asm volatile("" : "+v"(vo[r4]));
+        }
+    }
 
     template <int KOFF>
     __device__ __forceinline__ void lda(float4 (&dst)[4]) {
@@ -137,7 +144,7 @@ struct WinoPipe {
         const int soff = (int)so + KOFF * kWnStepBytes;                  // past the layer's last step: the next layer's first ones (or the slack)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4_ f = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff + r4 * 1024, soff, 0));
+            const f32x4_ f = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[r4], soff, 0));
             dst[r4] = make_float4(f.x, f.y, f.z, f.w);
         }
     }
@@ -501,7 +508,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 GemmPipe<4, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
-                load_cp(l + 1);                                     // into the (dead) accumulators, under the out-projection
                 dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barrier (that half was last read in phase ph - 1)
                 __syncthreads();
                 LOOP_STAMP(4);
@@ -517,6 +523,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bq[mb][q] = *reinterpret_cast<const float4*>(p.b2raw + (size_t)l * 2 * kC + ch0 + 32 * mb + 8 * q);
+                load_cp(l + 1);                                     // into the (dead) accumulators of the convolution: 64 KiB per tile beside the MFMAs
                 DSD_SB();
                 pipe2.run(acc2, 6, 32);
                 LOOP_STAMP(5);

@@ -2,7 +2,7 @@
 # stats of the bench command, the three PMC passes over k_loop (separate --pmc runs, kernel-trace only) -> loop_pmc.json, machine ceilings
 # (bare fp32 MFMA stream, HBM read / copy), shape sweep, row benches (vocoder / fs2 / train), all-config throughput, one utterance end to end,
 # ParallelWaveGAN, vocoder and FastSpeech2 kernel stats + PMC passes.
-#   usage: bash tools/gpu_evidence.sh <tag> [nopytest]
+#   usage: bash tools/gpu_evidence.sh <tag> [nopytest|pytest] [core]      (core: skip the vocoder / FastSpeech2 PMC passes: those kernels did not change)
 set -x
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=${1:-r06}
@@ -16,23 +16,27 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 fi
 timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.err
 timeout 200 python tools/loop_timeline.py $O/loop_timeline.json > $O/loop_timeline.txt 2>&1
-[ -x tools/mfma_probe4.bin ] && timeout 120 tools/mfma_probe4.bin > $O/mfma_probe4.txt 2>&1
-[ -x tools/hbm_probe.bin ] && timeout 120 tools/hbm_probe.bin > $O/hbm_probe.txt 2>&1
-timeout 400 python tools/shape_sweep.py 3 1x512,1x1000,1x1550,4x777,3x1550,1x5000,8x1024,16x2048 > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
+# machine ceilings: the probes are compiled on the box (no binaries in the tree)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_probe4 tools/mfma_probe4.hip && timeout 120 /tmp/mfma_probe4 > $O/mfma_probe4.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/hbm_probe tools/hbm_probe.hip && timeout 120 /tmp/hbm_probe > $O/hbm_probe.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_filler_probe tools/mfma_filler_probe.hip && timeout 180 /tmp/mfma_filler_probe > $O/mfma_filler_probe.jsonl 2>&1
+timeout 200 python tools/wino_ab.py --shapes 2>/dev/null | grep "^{" > $O/wino_ab.jsonl
+timeout 600 python tools/shape_sweep.py 3 1x512,1x1000,1x1550,4x777,2x2048,3x1550,1x5000,1x8000,6x1024,8x1024,3x5000,16x2048 --lat-splits > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
 for row in vocoder fs2 train; do
 timeout 300 python bench.py --row $row --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_row_$row.json 2> $O/bench_row_$row.err
 done
 timeout 400 python tools/bench_configs.py 3 > $O/configs_throughput.jsonl 2> $O/configs_throughput.err
 timeout 200 python tools/bench_single.py 10 100 8 > $O/single_utterance.jsonl 2> $O/single_utterance.err
 timeout 200 python tools/bench_single.py 10 60 8 >> $O/single_utterance.jsonl 2>> $O/single_utterance.err
-timeout 200 python tools/bench_pwg.py 5 > $O/bench_pwg.jsonl 2> $O/bench_pwg.err
+[ "$3" != "core" ] && timeout 200 python tools/bench_pwg.py 5 > $O/bench_pwg.jsonl 2> $O/bench_pwg.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cfg5-shard > $O/prof.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/prof/*.db $O/prof/*/*.db 2>/dev/null | head -1) > $O/bench_n1_kernel_stats.txt 2>> $O/prof.log
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/pmc/fetch -o fetch -- python $R/tools/profile_loop.py 3 > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc/write -o write -- python $R/tools/profile_loop.py 3 > $O/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $O/pmc/sq -o sq -- python $R/tools/profile_loop.py 3 > $O/pmc_sq.log 2>&1
-python $R/tools/pmc_summary.py $O/pmc 'k_loop<1>' $O/loop_pmc.txt $O/loop_pmc.json frames=8192 'kernel_tag=k_loop<1>' round=$TAG commit=$git_rev > $O/pmc_summary.log 2>&1
+python $R/tools/pmc_summary.py $O/pmc 'k_loop_wino' $O/loop_pmc.txt $O/loop_pmc.json frames=8192 'kernel_tag=k_loop_wino<1, 4>' round=$TAG commit=$git_rev > $O/pmc_summary.log 2>&1
+if [ "$3" != "core" ]; then
 # vocoder row: kernel stats + FETCH / WRITE / SQ passes over the fused resblock-stage kernels (bench.py --row vocoder reads voc_chain_32ch_pmc.json)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_voc -o voc -- python $R/bench.py --row vocoder --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_voc.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/prof_voc/*.db $O/prof_voc/*/*.db 2>/dev/null | head -1) > $O/vocoder_kernel_stats.txt 2>> $O/prof_voc.log
@@ -45,6 +49,7 @@ done
 timeout 200 python tools/voc_chain_timeline.py > $O/voc_chain_timeline.txt 2>&1
 # FastSpeech2 row: kernel stats + the PMC passes over the mel-rate ffn_1 launches (bench.py --row fs2 reads fs2_ffn1_pmc.json)
 cd $R; bash tools/gpu_fs2_prof.sh $TAG/fs2 > $O/fs2_prof.log 2>&1; cp $O/fs2/fs2_ffn1_pmc.json $O/fs2/fs2_ffn1_pmc.txt $O/fs2/fs2_kernel_stats.txt $O/ 2>/dev/null; rm -rf $O/fs2
+fi
 rm -rf $O/prof $O/prof_voc
 find $O/pmc $O/pmc_voc -name '*.db' -delete
 du -sh $O
