@@ -21,7 +21,8 @@ import diffsinger_amd
 from diffsinger_amd import hparams
 from diffsinger_amd.synth import presets
 
-F_EXEC = 21_053_440          # executed FLOP / frame / evaluation
+F_EXEC = 21_053_440          # executed FLOP / frame / evaluation with the direct convolution
+F_EXEC_WINO = 15_810_560     # ... with the Winograd F(2,3) convolution of the persistent loop (the default)
 F_REF = 26_427_392           # reference FLOP / frame / evaluation
 
 
@@ -83,7 +84,9 @@ def run(name, preset, B, T, k_step, sampler, reps, interval=0, shallow=False, mi
     eng = gd.denoise_fn.engine()
     print(json.dumps({'config': name, 'preset': preset, 'B': B, 'T': T, 'micro_batch': nb, 'sampler': sampler, 'evaluations': evals,
                       'ms_per_pass': sec * 1e3, 'mel_frames_per_s': frames / sec,
-                      'tflops_executed': frames * evals * F_EXEC / sec / 1e12, 'tflops_ref_accounting': frames * evals * F_REF / sec / 1e12,
+                      'conv': 'winograd F(2,3)' if eng.conv_mode() == 1 else 'direct',
+                      'tflops_executed': frames * evals * (F_EXEC_WINO if eng.conv_mode() == 1 else F_EXEC) / sec / 1e12,
+                      'tflops_direct_accounting': frames * evals * F_EXEC / sec / 1e12, 'tflops_ref_accounting': frames * evals * F_REF / sec / 1e12,
                       'layer_tile_frames': eng.layer_tile(), 'device_bytes': eng.device_bytes()}), flush=True)
     del gd
     torch.cuda.empty_cache()
