@@ -508,6 +508,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 GemmPipe<4, 1, LDK, 256, 6, TileBT, 1, true> pipe2(p.w2p + ((size_t)l * 4 + w) * (32 * 256), lane, 32, bof2);
                 pipe2.start_a();
                 do_gate();
+                // the next layer's conditioner projection into the (dead) accumulators, under the out-projection.  (Issued HERE, in front of
+                // the barrier: beside the out-projection's MFMAs the 16 cold loads cost 2.5 k cycles of in-order waits, profiles/r5_07)
+                load_cp(l + 1);
                 dsbuf[((ph + 1u) & 1u) * kC + tid] = ds_next;       // visible behind the barrier (that half was last read in phase ph - 1)
                 __syncthreads();
                 LOOP_STAMP(4);
@@ -523,7 +526,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bq[mb][q] = *reinterpret_cast<const float4*>(p.b2raw + (size_t)l * 2 * kC + ch0 + 32 * mb + 8 * q);
-                load_cp(l + 1);                                     // into the (dead) accumulators of the convolution: 64 KiB per tile beside the MFMAs
                 DSD_SB();
                 pipe2.run(acc2, 6, 32);
                 LOOP_STAMP(5);
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_loop_wino(const LoopWinoParams 
         HEAD_STAMP(5);
         __syncthreads();
         HEAD_STAMP(6);
-        if (fuse) { load_cp(0); inproj_to_xq(); publish_issue(ph); }     // (layer 0's conditioner projection: under the input projection)
+        if (fuse) { inproj_to_xq(); publish_issue(ph); load_cp(0); }     // (layer 0's conditioner projection LAST: live across the in-projection, the 64 registers cost 35 spills in the sampler update)     // (layer 0's conditioner projection: under the input projection)
         HEAD_STAMP(7);
     }
 #undef LOOP_STAMP
