@@ -72,7 +72,6 @@ struct dsd_handle {
     int64_t bytes_ws = 0;    // ... + workspace of the prepared batch
 
     // packed weights (device)
-    float4* warena = nullptr;   // w1p | w1q | w2p in one allocation
     float4 *w1p = nullptr, *w2p = nullptr, *wcp = nullptr, *b1p = nullptr, *bskp = nullptr;
     float4* w1q = nullptr;      // dilated conv once more, 16 gate rows + their 16 filter rows per 32-row block (G = 16 latency kernels, dsd_lat.hpp)
     float *b2raw = nullptr, *bsum = nullptr;   // output_projection biases [L][2C]; sum over layers of their skip halves [C]
@@ -114,7 +113,6 @@ struct dsd_handle {
     // persistent loop unless its whole-utterance chunking wastes more of the chip than the per-layer kernels would; 3 latency kernels
     int loop_mode = 2;
     int lat_req = -1;           // row split of the latency kernels: -1 by batch size, 0 never, 2 / 4 / 8 forced (dsd_set_lat_split)
-    bool lat_tail = true;       // k_lat_out's overrun prefetches read the next layer's first conv chunks (DSD_LAT_TAIL=0: the stream's own continuation)
     float* gbuf = nullptr;      // [ntiles][C][32] gate tiles between k_lat_conv and k_lat_out
     int n_cu = 0;               // workgroups that are certainly co-resident at 1 per CU
     struct LoopPlan { HeadParams* evals = nullptr; int* eval_t = nullptr; int n_evals = 0; };
@@ -257,7 +255,6 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
     if (const char* ev = std::getenv("DSD_SPLIT")) h->split_mode = (std::atoi(ev) != 0);     // EXPERIMENT: split-precision layer kernel
     if (const char* ev = std::getenv("DSD_SPLIT_TOUCH")) { const int v = std::atoi(ev); if (v >= 0 && v <= 20) h->split_touch = v; }
     if (const char* ev = std::getenv("DSD_SPLIT_W")) { const int v = std::atoi(ev); if (v == 0 || v == 2) h->split_w = v; }
-    if (const char* ev = std::getenv("DSD_LAT_TAIL")) h->lat_tail = (std::atoi(ev) != 0);   // bring-up A/B of the next-node prefetch
     if (const char* ev = std::getenv("DSD_CONV")) {                                           // the same choice as dsd_set_conv_mode
         if (!std::strcmp(ev, "direct") || !std::strcmp(ev, "0")) h->conv_mode = 0;
         else if (!std::strcmp(ev, "winograd") || !std::strcmp(ev, "1")) h->conv_mode = 1;
@@ -297,7 +294,7 @@ extern "C" void dsd_destroy(dsd_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     dev_free(h->w1s); dev_free(h->w2s); dev_free(h->wlc); dev_free(h->wl2); dev_free(h->w1w);
-    dev_free(h->warena); h->w1q = h->w1p = h->w2p = nullptr; dev_free(h->wcp); dev_free(h->b1p); dev_free(h->bskp); dev_free(h->b2raw); dev_free(h->bsum);
+    dev_free(h->w1q); dev_free(h->w1p); dev_free(h->w2p); dev_free(h->wcp); dev_free(h->b1p); dev_free(h->bskp); dev_free(h->b2raw); dev_free(h->bsum);
     dev_free(h->winp); dev_free(h->binp); dev_free(h->wsp); dev_free(h->bsp); dev_free(h->woutp); dev_free(h->boutp);
     dev_free(h->mlp0_w); dev_free(h->mlp0_b); dev_free(h->mlp2_w); dev_free(h->mlp2_b); dev_free(h->dp_w); dev_free(h->dp_b);
     dev_free(h->ds_table); dev_free(h->spec_min_d); dev_free(h->spec_max_d);
@@ -478,12 +475,9 @@ extern "C" int dsd_load_weights(dsd_handle* h, const dsd_weights* w, void* strea
     hipStream_t s = (hipStream_t)stream;
     const int L = h->L, M = h->M;
     if (!h->w1p) {
-        // ONE allocation for the three streams of the latency / per-layer kernels: a contraction's overrun prefetches read the next node's
-        // first chunks through the same buffer descriptor (GemmPipe TAIL, dsd_lat.hpp)
-        const size_t n1p = (size_t)L * 4 * 96 * 256 + kWeightSlack, n1q = (size_t)L * 16 * 96 * 64 + kWeightSlack, n2p = (size_t)L * 4 * 32 * 256 + kWeightSlack;
-        DSD_TRY(dev_alloc(h, &h->warena, n1p + n1q + n2p));
-        HIP_TRY(hipMemsetAsync(h->warena, 0, (n1p + n1q + n2p) * sizeof(float4), s));
-        h->w1p = h->warena; h->w1q = h->w1p + n1p; h->w2p = h->w1q + n1q;
+        DSD_TRY(dev_alloc(h, &h->w1p, (size_t)L * 4 * 96 * 256 + kWeightSlack));
+        DSD_TRY(dev_alloc(h, &h->w1q, (size_t)L * 16 * 96 * 64 + kWeightSlack));
+        DSD_TRY(dev_alloc(h, &h->w2p, (size_t)L * 4 * 32 * 256 + kWeightSlack));
         DSD_TRY(dev_alloc(h, &h->w1w, (size_t)L * kWnSteps * (kWnStepBytes / 16) + kWeightSlack));
         HIP_TRY(hipMemsetAsync(h->w1w + (size_t)L * kWnSteps * (kWnStepBytes / 16), 0, (size_t)kWeightSlack * 16, s));
         DSD_TRY(dev_alloc(h, &h->wcp, (size_t)L * 4 * 32 * 256 + kWeightSlack));
@@ -700,10 +694,6 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
         q.t_dev = t_dev; q.t_uniform = t_uniform; q.ds_tstride = h->L * kC;
         q.T = h->T; q.ntile32 = h->ntile32; q.ntiles = h->ntiles; q.dil = h->dil[l];
         q.first = (l == 0); q.last = (l == h->L - 1);
-        q.arena = h->warena;
-        const bool tail = h->lat_tail && l + 1 < h->L;                // (the last layer's successor is the head: no stream to prefetch)
-        q.w1p_next = tail ? h->w1p + (size_t)(l + 1) * 4 * 96 * 256 : nullptr;
-        q.w1q_next = tail ? h->w1q + (size_t)(l + 1) * 16 * 96 * 64 : nullptr;
         if (G == 16) launch_lat<16>(q, s); else if (G == 8) launch_lat<8>(q, s); else if (G == 4) launch_lat<4>(q, s); else launch_lat<2>(q, s);
         HIP_TRY(hipGetLastError());
         return DSD_OK;

@@ -90,11 +90,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NMB][NB], const float4 (
 // block and its filter block / a residual block and its skip block (the row-split kernels of dsd_lat.hpp).
 // BV: the B tile is FRAME-MAJOR ([frame][k], k contiguous; dsd_loop_fm.hpp): the four k values of a chunk a lane needs (k = 4h + s) are
 // ONE aligned ds_read_b128 instead of four ds_read_b32 at a stride of LD.
-// TAIL (the latency kernels, dsd_lat.hpp): the STAGES - 1 prefetches that run past the end of the stream - their values are never used - read
-// the FIRST chunks of ANOTHER stream instead: the one the same (workgroup, wave) role of the NEXT kernel node starts with.  No instruction is
-// added; the lines are in this XCD's L2 when that node asks for them.  The descriptor then covers the whole weight arena (one allocation) and
-// both streams are byte offsets into it.
-template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff, int MBS = 1, bool BV = false, bool TAIL = false>
+template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff, int MBS = 1, bool BV = false>
 struct GemmPipe {
     static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
     static_assert(!BV || NB == 1, "frame-major B tiles are one 32-frame block wide");
@@ -102,27 +98,19 @@ struct GemmPipe {
     unsigned aoff;                 // this lane's byte offset inside a 1 KiB fragment row (lane * 16)
     int n;
     BOff bof;
-    int sbase = 0, tbase = 0, tstride = 0;     // TAIL: byte offsets of this stream / of the tail stream in the arena, chunk stride of the tail
     float4 a[STAGES][NMB];
     float b[2][4][NB];
 
     __device__ __forceinline__ GemmPipe(const float4* abase_uniform, int lane, int n_, BOff bof_)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(abase_uniform), 0, 0x7ffffff0, 0x00020000)),
-          aoff((unsigned)lane * 16u), n(n_), bof(bof_) { static_assert(!TAIL, "a tail stream needs the arena constructor"); }
-    // TAIL: arena = wave-uniform base of the allocation that holds BOTH streams (< 2 GiB apart)
-    __device__ __forceinline__ GemmPipe(const float4* arena_uniform, const float4* abase_uniform, const float4* tail_uniform, int tail_stride_f4, int lane,
-                                        int n_, BOff bof_)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(arena_uniform), 0, 0x7ffffff0, 0x00020000)),
-          aoff((unsigned)lane * 16u), n(n_), bof(bof_), sbase((int)((abase_uniform - arena_uniform) * 16)), tbase((int)((tail_uniform - arena_uniform) * 16)),
-          tstride(tail_stride_f4 * 16) { static_assert(TAIL, "arena constructor"); }
+          aoff((unsigned)lane * 16u), n(n_), bof(bof_) {}
 
     // buffer_load_dwordx4 v, voffset(lane), rsrc, soffset(chunk) offset:imm(row block): the chunk walk is one SALU
     // value, there is no per-lane 64-bit address arithmetic in the loop.  Prefetches run up to STAGES-1 chunks past
     // the end of the stream: the weight buffers carry that much slack (kWeightSlack) and the values are never used.
     __device__ __forceinline__ void lda(float4 (&dst)[NMB], int kc) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        int soff = kc * (ASTRIDE * 16);
-        if constexpr (TAIL) soff = (kc < n) ? sbase + soff : tbase + (kc - n) * tstride;
+        const int soff = kc * (ASTRIDE * 16);
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff + mb * (MBS * 1024), soff, 0);

@@ -48,13 +48,6 @@ struct LatParams {
     const int* t_dev;       // per-utterance step index, or nullptr -> t_uniform
     int t_uniform, ds_tstride;
     int T, ntile32, ntiles, dil, first, last;
-    // Prefetch for the NEXT graph node (GemmPipe TAIL): the prefetches of a contraction's last five steps, which run past the end of the weight
-    // stream, read the first chunks the same (workgroup, wave) role of the next node starts with - k_lat_conv -> this layer's w2p, k_lat_out ->
-    // the next layer's conv stream.  arena: base of the ONE allocation that holds w1p, w1q and w2p of every layer; nullptr in w1p_next (last
-    // layer: the head follows) = the tail is the stream's own continuation, as without the mechanism.
-    const float4* arena;
-    const float4* w1p_next;
-    const float4* w1q_next;
 };
 
 constexpr int kLatConvLdsBytes = (kC * (32 + 2 * kHalo) + 4 * 32 * 32) * (int)sizeof(float);     // y tile + K partials [2] (G = 8) / [4] (G = 16) / filter [1..2]
@@ -105,12 +98,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv(const LatParams p) {
     const ConvB<LD, BF> bof{ytile + 4 * h * LD + kHalo + j, dil, kbeg};
     constexpr int ASTR = (G == 16) ? 64 : 256;                      // float4 between consecutive chunks of the packed stream
     const float4* abase = (G == 16) ? p.w1q + ((size_t)g * 96 + kbeg) * 64 : p.w1p + (size_t)w4 * (96 * 256) + (size_t)kbeg * 256 + mb0 * 64;
-    // the tail: what this role's wave of k_lat_out<G> reads first (its abase: the same w4 / mb0, its own K split)
-    constexpr int KB2 = (G == 16) ? 8 : (G == 8) ? 16 : 0;             // out-projection chunks per K part
-    const int kbeg2 = (G == 16) ? KB2 * wv : (G == 8) ? KB2 * (wv >> 1) : 0;
-    const int mb2 = (G == 16) ? (g & 3) : mb0;
-    const float4* tail = p.w2p + (size_t)w4 * (32 * 256) + (size_t)kbeg2 * 256 + mb2 * 64;
-    GemmPipe<NMB, 1, LD, ASTR, 6, ConvB<LD, BF>, 2, false, true> pipe(p.arena, abase, tail, 256, lane, NCH, bof);
+    GemmPipe<NMB, 1, LD, ASTR, 6, ConvB<LD, BF>, 2> pipe(abase, lane, NCH, bof);
     pipe.start_a();
 
     // stage y = x + step_proj (zero at frames outside [0, T): the conv's zero padding applies to y, net.py:69-71)
@@ -277,30 +265,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
     const bool active = (G == 2) || !(p.last && mb0 < 2);
 
     const float* gl = gtile + kbeg * (8 * 32) + 4 * h * 32 + j;
-    // the tail: what this role's wave of the NEXT layer's k_lat_conv<G> reads first (its abase); last layer: the stream's own continuation
-    const float4* abase = p.w2p + (size_t)w4 * (32 * 256) + (size_t)kbeg * 256 + mb0 * 64;
-    const float4* tail = abase + (size_t)NCH * 256;
-    int tstr = 256;
-    if (p.w1p_next) {
-        if (G == 16) { tail = p.w1q_next + ((size_t)g * 96 + 24 * wv) * 64; tstr = 64; }
-        else if (G == 8) tail = p.w1p_next + (size_t)w4 * (96 * 256) + (size_t)(48 * (wv >> 1)) * 256 + mb0 * 64;
-        else tail = p.w1p_next + (size_t)w4 * (96 * 256) + mb0 * 64;
-    }
-    GemmPipe<NMB, 1, 32, 256, 6, TileB, 2, false, true> pipe(p.arena, abase, tail, tstr, lane, NCH, TileB{gl, 8 * 32, NCH});
+    GemmPipe<NMB, 1, 32, 256, 6, TileB, 2> pipe(p.w2p + (size_t)w4 * (32 * 256) + (size_t)kbeg * 256 + mb0 * 64, lane, NCH, TileB{gl, 8 * 32, NCH});
     // G = 16: a wave contracts over ONE quarter of the gate tile (8 chunks = 32 values per lane) and no other wave of the workgroup reads
     // that quarter - the B fragments come straight from global memory into registers, all requested at once behind the 8 A fragments;
     // there is no staging pass, no barrier in front of the contraction and nothing to wait for inside it
     float4 aq[(G == 16) ? 8 : 1][NMB];
     float bq[(G == 16) ? 8 : 1][4][1];
-    float4 tq[(G == 16) ? 5 : 1][NMB];      // G = 16 (no pipelined K loop, hence no overrun prefetches): the tail's first five chunks, requested behind the
-                                            // own fragments and kept alive until the contraction is done - their only purpose is the next node's L2
     if constexpr (G == 16) {
         if (active) {
             const float* __restrict__ gs = p.gbuf + (size_t)tile * TILE + kbeg * (8 * 32) + 4 * h * 32 + j;
 #pragma unroll
             for (int c = 0; c < 8; ++c) pipe.lda(aq[c], c);
-#pragma unroll
-            for (int c = 0; c < 5; ++c) pipe.lda(tq[c], NCH + c);
 #pragma unroll
             for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -350,7 +325,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_out(const LatParams p) {
         if (active) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) mma_chunk<NMB, 1>(acc, aq[c], bq[c]);
-            asm volatile("" : : "v"(tq[0][0].x), "v"(tq[1][0].x), "v"(tq[2][0].x), "v"(tq[3][0].x), "v"(tq[4][0].x));      // (keeps the tail requests)
         }
     } else if (active) {
         pipe.start_b();
