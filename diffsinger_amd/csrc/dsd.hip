@@ -6,6 +6,7 @@
 #include "dsd_split.hpp"
 #include "dsd_loop_split.hpp"
 #include "dsd_loop_wino.hpp"
+#include "dsd_lat_wino.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -275,6 +276,10 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_layer<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop<HEAD_PLMS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_lat_conv_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvWLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_lat_conv_w<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvWLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_lat_conv_w<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvWLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_lat_conv_w<16>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvWLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_DDPM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_PLMS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -673,7 +678,8 @@ static int launch_inproj(dsd_handle* h, const float* spec, hipStream_t s) {
 template <int G>
 static void launch_lat(const LatParams& p, hipStream_t s) {
     const dim3 grid((unsigned)lat_grid(p.ntiles, G));
-    hipLaunchKernelGGL((k_lat_conv<G>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
+    if (p.w1w) hipLaunchKernelGGL((k_lat_conv_w<G>), grid, dim3(kThreads), kLatConvWLdsBytes, s, p);      // Winograd F(2,3) convolution (the default)
+    else hipLaunchKernelGGL((k_lat_conv<G>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
     hipLaunchKernelGGL((k_lat_out<G>), grid, dim3(kThreads), kLatOutLdsBytes, s, p);
 }
 
@@ -694,6 +700,7 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
         q.t_dev = t_dev; q.t_uniform = t_uniform; q.ds_tstride = h->L * kC;
         q.T = h->T; q.ntile32 = h->ntile32; q.ntiles = h->ntiles; q.dil = h->dil[l];
         q.first = (l == 0); q.last = (l == h->L - 1);
+        q.w1w = (h->conv_mode == 1 && h->w1w) ? h->w1w + (size_t)l * kWnSteps * (kWnStepBytes / 16) : nullptr;
         if (G == 16) launch_lat<16>(q, s); else if (G == 8) launch_lat<8>(q, s); else if (G == 4) launch_lat<4>(q, s); else launch_lat<2>(q, s);
         HIP_TRY(hipGetLastError());
         return DSD_OK;
@@ -1106,7 +1113,7 @@ static int run_loop(dsd_handle* h, int kind, float* x, const float* noise, int k
         DSD_TRY(kind == 0 ? enqueue_ddpm(h, k_step, s) : enqueue_plms(h, k_step, interval, s));
     } else {
         DSD_TRY(ensure_cp(h, false, s));
-        const GraphKey key{kind, h->B, h->T, k_step, interval, layer_nb(h) + 100 * lat_g(h)};
+        const GraphKey key{kind, h->B, h->T, k_step, interval, layer_nb(h) + 100 * lat_g(h) + 10000 * ((h->conv_mode == 1 && h->w1w) ? 1 : 0)};      // (the latency nodes differ by convolution form)
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
             hipGraph_t g = nullptr;

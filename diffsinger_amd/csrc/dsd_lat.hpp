@@ -48,6 +48,7 @@ struct LatParams {
     const int* t_dev;       // per-utterance step index, or nullptr -> t_uniform
     int t_uniform, ds_tstride;
     int T, ntile32, ntiles, dil, first, last;
+    const float4* w1w;      // this layer's Winograd-transformed conv weights in the persistent loop's consumption order (k_lat_conv_w, dsd_lat_wino.hpp)
 };
 
 constexpr int kLatConvLdsBytes = (kC * (32 + 2 * kHalo) + 4 * 32 * 32) * (int)sizeof(float);     // y tile + K partials [2] (G = 8) / [4] (G = 16) / filter [1..2]

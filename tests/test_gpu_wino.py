@@ -177,3 +177,85 @@ def test_default_path_choice_with_the_winograd_loop():
     cond = torch.randn(3, 5000, 256, device='cuda').transpose(1, 2)       # 157 tiles per utterance: one utterance per persistent launch = 61 % of the chip
     eng = gd._engine(cond)
     assert eng.lat_split() == 0 and eng.loop_mode() == 0 and eng.conv_mode() == 0      # per-layer kernels: 471 tiles = 92 % of two grid waves
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# the latency kernels with the Winograd convolution (csrc/dsd_lat_wino.hpp: k_lat_conv_w<G>, the default for batches below half the chip)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('preset,layer', [('opencpop_ds60_rel', 0), ('opencpop_ds60_rel', 1), ('opencpop_ds60_rel', 2), ('opencpop_ds60_rel', 3),
+                                          ('lj_ds_beta6', 19)])
+def test_latency_winograd_layer_against_the_oracle_layer_every_split(preset, layer):
+    """ONE residual layer (usr/diff/net.py:66-78) through dsd_debug_layer on k_lat_conv_w<G> + k_lat_out<G> for every G, dilations 1 .. 8, ragged T,
+    the last layer (skips only) - against the oracle's layer, next to the direct-form kernels of the same G."""
+    from oracle import diffnet_oracle as O
+    from tests.gpu_helpers import build_hip
+    pre = H.presets()[preset]
+    cfg = H.net_config(pre)
+    gd, _, _ = build_hip(preset, pre['K_step'])
+    p = {k: v.detach().cpu() for k, v in gd.denoise_fn.state_dict().items()}
+    g = torch.Generator().manual_seed(300 + layer)
+    B, T, t = 2, 100, 37
+    x = torch.randn(B, 256, T, generator=g)
+    cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
+    with torch.no_grad():
+        d_emb = O.step_mlp(p, cfg, torch.full((B,), t))
+        want_x, want_skip = O.residual_layer(p, cfg, layer, x, cond, d_emb)
+    want_skip = want_skip - p[f'residual_layers.{layer}.output_projection.bias'][256:, None]       # the kernels add the skip biases once, in the head
+    eng = gd._engine(cond.cuda())
+    eng.prepare(cond.cuda())
+    eng.set_loop_mode(3)
+    last = layer == cfg.residual_layers - 1
+    for G in (2, 4, 8, 16):
+        eng.set_lat_split(G)
+        res = {}
+        for conv in ('winograd', 'direct'):
+            eng.set_conv_mode(conv)
+            assert eng.lat_split() == G
+            xo, sk = eng.debug_layer(layer, t, x.cuda())
+            res[conv] = float((sk.cpu() - want_skip).abs().max()) if last else max(float((sk.cpu() - want_skip).abs().max()),
+                                                                                      float((xo.cpu() - want_x).abs().max()))
+        print(f'{preset} layer {layer} (dilation {2 ** (layer % cfg.dilation_cycle_length)}) G={G}: max-abs err vs the oracle layer: Winograd '
+              f'{res["winograd"]:.3e}, direct {res["direct"]:.3e}')
+        assert res['winograd'] < 2e-5, G
+    eng.set_conv_mode('winograd')
+
+
+def test_one_utterance_k100_on_the_winograd_latency_kernels_vs_oracle_and_timing():
+    """The reference's own inference shape - ONE utterance (configs/tts/fs2.yaml:70), here 512 / 1000 / 1550 frames, K = 100 DDPM - on the default
+    path (latency kernels G = 16 / 8 / 4 with the Winograd convolution) against the oracle, and its time next to the direct-form kernels."""
+    import time
+    from oracle import diffnet_oracle as O
+    from diffsinger_amd.synth import make_inputs
+    from tests.gpu_helpers import build_hip
+    K = 100
+    gd, cfg, pre = build_hip('lj_ds_beta6', K)
+    sch = O.make_schedule(H.betas_for(pre))
+    smin = torch.tensor(pre['spec_min'], dtype=torch.float32)[None, None, :]
+    smax = torch.tensor(pre['spec_max'], dtype=torch.float32)[None, None, :]
+    p = H.oracle_params(cfg)
+    for T, G in ((512, 16), (1000, 8), (1550, 4)):
+        inp = make_inputs(70 + G, 1, T, n_noise=K)
+        cond, x_T, noise = inp['cond'].cuda(), inp['x_T'].cuda(), inp['noise'].cuda()
+        eng = gd._engine(cond)
+        outs, ms = {}, {}
+        for conv in ('winograd', 'direct'):
+            eng.set_conv_mode(conv)
+            assert eng.lat_split() == G and eng.loop_mode() == 0
+            with torch.no_grad():
+                outs[conv] = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).clone()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
+                torch.cuda.synchronize()
+            ms[conv] = (time.perf_counter() - t0) / 3 * 1e3
+        eng.set_conv_mode('winograd')
+        err = None
+        if T == 512:
+            want = O.infer_mel(p, cfg, sch, inp['cond'], smin, smax, k_step=K, noises=list(inp['noise']), x_T=inp['x_T'])
+            err = float((outs['winograd'].cpu() - want).abs().max())
+            assert err <= 1e-4
+        d = float((outs['winograd'] - outs['direct']).abs().max())
+        print(f'1 x {T}, K = 100 on the latency kernels G = {G}: Winograd {ms["winograd"]:.1f} ms, direct {ms["direct"]:.1f} ms per call; max-abs mel difference '
+              f'{d:.3e}' + (f'; Winograd vs oracle {err:.3e}' if err is not None else ''))
+        assert d <= 5e-5 and bool(torch.isfinite(outs['winograd']).all())

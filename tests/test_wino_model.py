@@ -177,3 +177,106 @@ def test_lds_bank_groups_of_the_operand_reads_and_row_writes():
                         a = row_of_frame(j, e) + 4 * h + 8 * q
                         banks |= {(a + k) % 32 for k in range(4)}
                     assert len(banks) == 32, (e, h, q, g8)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------------
+# the latency kernels' Winograd convolution (csrc/dsd_lat_wino.hpp): roles of the G x 4 waves of a tile, fragment offsets into the loop's
+# stream, K partials, the direct-layout index of the conditioner projection, the gate tile's (channel, frame)
+# ----------------------------------------------------------------------------------------------------------------------------------------
+def cp_direct_layout(cpfull):
+    """k_condproj's direct (32x32 fragment) order for one tile and layer: [w4][mb4][q4][lane64][4]; element (q, lane = (j, h), e) of (w, mb) is row
+    (gate mb < 2 / filter) 64 w + 32 (mb & 1) + 8 q + 4 h + e at frame j"""
+    out = np.zeros((4, 4, 4, 64, 4), np.float32)
+    for w in range(4):
+        for mb in range(4):
+            for q in range(4):
+                for lane in range(64):
+                    j, h = lane & 31, lane >> 5
+                    rows = (0 if mb < 2 else C) + 64 * w + 32 * (mb & 1) + 8 * q + 4 * h + np.arange(4)
+                    out[w, mb, q, lane] = cpfull[rows, j]
+    return out.reshape(-1, 4)
+
+
+def run_lat_model(G, e, wt, y_ext, cpfull):
+    d = 1 << e
+    ytile = np.full(NY, np.nan, np.float32)
+    for j in range(32):
+        ytile[row_of_frame(j, e):row_of_frame(j, e) + C] = y_ext[:, 8 + j]
+    for f in range(8):
+        ytile[OBASE + f * LDK:OBASE + f * LDK + C] = y_ext[:, f]
+        ytile[(16 + f) * LDK:(16 + f) * LDK + C] = y_ext[:, 40 + f]
+    stream = pack_wino(wt).reshape(-1, 64, 4)            # 1 KiB pieces: [(step * 4 + w) * 4 + r4][lane][s]
+    cpl = cp_direct_layout(cpfull)
+    lanes = np.arange(64)
+    pp, gg = lanes & 15, lanes >> 4
+    NRB = 4 if G == 2 else 2
+    NGB = NRB // 2
+    NCW = 4 if G == 16 else 8 if G == 8 else 16
+    tE = np.array([frame_of_pair(p, e) for p in pp])
+    gate_pre = np.full((2 * C, 32), np.nan, np.float64)
+    for g in range(G):
+        parts = {}
+        for wv in range(4):
+            B0 = 8 * g + 2 * wv if G == 2 else 4 * g + wv if G == 4 else 2 * g + (wv & 1) if G == 8 else g
+            c0 = 8 * (wv >> 1) if G == 8 else 4 * wv if G == 16 else 0
+            pE = pp * LDK + 64 * gg + 4 * c0
+            pO = OBASE + (8 + pp) * LDK + 64 * gg + 4 * c0
+            acc = np.zeros((2, NRB, 64, 4), np.float64)
+            for gi in range(2 * NCW):
+                half = 1 if gi >= NCW else 0
+                ci = gi - half * NCW
+                c = c0 + ci
+                if gi == NCW:
+                    m1, m2 = acc[0].copy(), acc[1].copy()
+                    acc[0], acc[1] = m1 + m2, m1 - m2
+                o = 4 * ci
+                for pos in range(2):
+                    for s in range(4):
+                        if half == 0:
+                            r0, r1 = ytile[pE + o + s], ytile[pO + o + s]
+                            v = (r0 + r1) if pos == 0 else (r1 - r0)
+                        else:
+                            v = (ytile[pO - d * LDK + o + s] - ytile[pO + o + s]) if pos == 0 else (ytile[pE + d * LDK + o + s] - ytile[pE + o + s])
+                        assert not np.isnan(v).any()
+                        for k in range(NRB):
+                            B, f = B0 + (k % NGB), k // NGB
+                            step = ((half * 16 + c) * 2 + pos) * 2 + f
+                            piece = (step * 4 + (B >> 2)) * 4 + (B & 3)
+                            mfma16(stream[piece, :, s], v.astype(np.float32), acc[pos][k])
+            parts[wv] = (B0, acc)
+        # K partials: G = 8: waves wv and wv ^ 2 share a block pair; G = 16: all four waves; G = 2 / 4: none
+        for wv in range(4):
+            B0, acc = parts[wv]
+            if G == 8:
+                if wv >= 2:
+                    continue
+                acc = parts[wv][1] + parts[wv + 2][1]
+            elif G == 16:
+                if wv > 0:
+                    continue
+                acc = ((parts[0][1] + parts[1][1]) + parts[2][1]) + parts[3][1]
+            for hf in range(2):
+                t = tE + hf * d
+                for k in range(NRB):
+                    B, f = B0 + (k % NGB), k // NGB
+                    base = (((B >> 2) * 4 + ((B & 3) >> 1) + 2 * f) * 4 + 2 * (B & 1) + (gg >> 1)) * 64 + 32 * (gg & 1)
+                    for r in range(4):
+                        rows = (C if f else 0) + 16 * B + 4 * gg + r
+                        gate_pre[rows, t] = acc[hf][k][:, r] + cpl[base + t, r]
+    assert not np.isnan(gate_pre).any(), 'rows or frames nobody computed'
+    return gate_pre
+
+
+@pytest.mark.parametrize('G', [2, 4, 8, 16])
+@pytest.mark.parametrize('e', [0, 3])
+def test_latency_winograd_conv_index_algebra(G, e):
+    d = 1 << e
+    g = torch.Generator().manual_seed(200 + 10 * G + e)
+    wt = torch.randn(2 * C, C, 3, generator=g) * 0.05
+    y = torch.randn(C, 48, generator=g)
+    y[:, 8 + 30:] = 0.0
+    cpfull = torch.randn(2 * C, 32, generator=g)
+    want = torch.nn.functional.conv1d(y[None], wt, dilation=d)[0][:, 8 - d:8 - d + 32] + cpfull
+    got = run_lat_model(G, e, wt.numpy(), y.numpy(), cpfull.numpy())
+    err = np.abs(got - want.double().numpy()).max()
+    assert err < 2e-5, err
