@@ -51,17 +51,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv_w(const LatParams p) {
     // step = ((half * 16 + c) * 2 + product) * 2 + (filter ? 1 : 0), piece (wave w = B >> 2, r4 = B & 3) of it
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(p.w1w), 0, 0x7ffffff0, 0x00020000);
     float4 a[STG][2][NRB];
+    // byte offset of a piece = step * 16 KiB + (w * 4 + r4) * 1 KiB: the block's part goes into the lane offset (one register per gate block, kept),
+    // the (half, chunk) part is ONE scalar per group, product and gate / filter are immediates
+    int vo[NGB];
+#pragma unroll
+    for (int k = 0; k < NGB; ++k) {
+        const int B = B0 + k;
+        vo[k] = lane * 16 + ((B >> 2) * 4 + (B & 3)) * 1024;
+        asm volatile("" : "+v"(vo[k]));
+    }
     auto lda = [&](float4 (&dst)[2][NRB], int gi) {
         typedef float f32x4_ __attribute__((ext_vector_type(4)));
-        const int half = (gi >= NCW) ? 1 : 0, c = c0 + gi - half * NCW;
+        const int cb = c0 + gi + ((gi >= NCW) ? 16 - NCW : 0);          // half * 16 + chunk
+        const int sg = cb * (4 * kWnStepBytes);
 #pragma unroll
         for (int pos = 0; pos < 2; ++pos)
 #pragma unroll
             for (int k = 0; k < NRB; ++k) {
-                const int B = B0 + (k % NGB), f = k / NGB;
-                const int step = ((half * 16 + c) * 2 + pos) * 2 + f;
-                const int soff = ((step * 4 + (B >> 2)) * 4 + (B & 3)) * 1024;
-                const f32x4_ v = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, soff, 0));
+                const f32x4_ v = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[k % NGB], sg + (pos * 2 + k / NGB) * kWnStepBytes, 0));
                 dst[pos][k] = make_float4(v.x, v.y, v.z, v.w);
             }
     };
@@ -70,42 +77,51 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv_w(const LatParams p) {
     for (int i = 0; i < STG - 1; ++i) lda(a[i], i);
     DSD_SB();
 
-    // stage y = x + step_proj in PAIR order (zero at frames outside [0, T): the conv's zero padding applies to y, net.py:69-71): thread = (channel
-    // row, four frames) of the tile-major x tile, four scalar writes into the frames' rows; the halo frames of both neighbour tiles: thread = channel
+    // stage y = x + step_proj in PAIR order (zero at frames outside [0, T): the conv's zero padding applies to y, net.py:69-71)
     const int tstep = p.t_dev ? p.t_dev[b] : p.t_uniform;
     const float* __restrict__ dsl = p.ds + (size_t)tstep * p.ds_tstride;
     const float* __restrict__ xt = p.x_in + (size_t)tile * TILE;
     {
-        float4 xv[8], hv[4];
+        // own frames: 512 items (channel quad c4, frame quad q), two per thread: four 16-byte loads (rows 4 c4 + e of the tile-major x tile: the
+        // eight lanes of a frame-quad row cover one 128-byte line), a 4 x 4 transpose in registers, four ds_write_b128 into the frames' rows.
+        // halo: 256 items (side, frame quad, c4), one per thread, the same way.
+        float4 xr[2][4], hr[4];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) xv[it] = reinterpret_cast<const float4*>(xt)[it * kThreads + tid];
+        for (int it = 0; it < 2; ++it) {
+            const int c4 = (tid >> 3) + 32 * it, q = tid & 7;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            hv[q] = has_left ? *reinterpret_cast<const float4*>(xt - TILE + tid * 32 + 24 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            hv[2 + q] = has_right ? *reinterpret_cast<const float4*>(xt + TILE + tid * 32 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = 0; e < 4; ++e) xr[it][e] = *reinterpret_cast<const float4*>(xt + (4 * c4 + e) * 32 + 4 * q);
+        }
+        const int hside = tid >> 7, hq = (tid >> 6) & 1, hc4 = tid & 63;
+        const bool hhave = hside ? has_right : has_left;
+        {
+            const float* src = hside ? xt + TILE + 4 * hq : xt - TILE + 24 + 4 * hq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                hr[e] = hhave ? *reinterpret_cast<const float4*>(src + (4 * hc4 + e) * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 32 + (tid >> 3), c4 = tid & 7, t = t0 + 4 * c4;
-            const float d = dsl[row];
-            const float4 v = xv[it];
-            ytile[wn_row_of_frame(4 * c4 + 0, de) + row] = (t + 0 < T) ? v.x + d : 0.f;
-            ytile[wn_row_of_frame(4 * c4 + 1, de) + row] = (t + 1 < T) ? v.y + d : 0.f;
-            ytile[wn_row_of_frame(4 * c4 + 2, de) + row] = (t + 2 < T) ? v.z + d : 0.f;
-            ytile[wn_row_of_frame(4 * c4 + 3, de) + row] = (t + 3 < T) ? v.w + d : 0.f;
-        }
-        const float d = dsl[tid];
+        for (int it = 0; it < 2; ++it) {
+            const int c4 = (tid >> 3) + 32 * it, q = tid & 7;
+            const float4 d = *reinterpret_cast<const float4*>(dsl + 4 * c4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = t0 + 4 * q + e < T;
+                const float4 v = make_float4(f4at(xr[it][0], e) + d.x, f4at(xr[it][1], e) + d.y, f4at(xr[it][2], e) + d.z, f4at(xr[it][3], e) + d.w);
+                *reinterpret_cast<float4*>(ytile + wn_row_of_frame(4 * q + e, de) + 4 * c4) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        {
             // left frame f (t = t0 - 8 + f) is row O[f - 8], right frame f (t = t0 + 32 + f) is row E[16 + f]
-            const bool right = q >= 2, have = right ? has_right : has_left;
-            const int f0 = 4 * (q & 1), t = right ? t0 + 32 + f0 : t0 - kHalo + f0;
-            float* dst = right ? ytile + (16 + f0) * LDK + tid : ytile + kWnOBase + f0 * LDK + tid;
-            const float4 v = hv[q];
-            dst[0 * LDK] = (have && t + 0 < T) ? v.x + d : 0.f;
-            dst[1 * LDK] = (have && t + 1 < T) ? v.y + d : 0.f;
-            dst[2 * LDK] = (have && t + 2 < T) ? v.z + d : 0.f;
-            dst[3 * LDK] = (have && t + 3 < T) ? v.w + d : 0.f;
+            const float4 d = *reinterpret_cast<const float4*>(dsl + 4 * hc4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = 4 * hq + e, t = hside ? t0 + 32 + f : t0 - kHalo + f;
+                const bool ok = hhave && t < T;
+                const float4 v = make_float4(f4at(hr[0], e) + d.x, f4at(hr[1], e) + d.y, f4at(hr[2], e) + d.z, f4at(hr[3], e) + d.w);
+                float* dst = hside ? ytile + (16 + f) * LDK + 4 * hc4 : ytile + kWnOBase + f * LDK + 4 * hc4;
+                *reinterpret_cast<float4*>(dst) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
     __syncthreads();
@@ -187,6 +203,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_lat_conv_w(const LatParams p) {
 #pragma unroll
                 for (int k = 0; k < NRB; ++k)
                     acc[pos][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(af[pos][k], s), v[pos][s], acc[pos][k], 0, 0, 0);
+        // the group's loads one by one behind its first MFMAs, then the LDS reads of the next operands, the packed adds in one gap
+#pragma unroll
+        for (int i = 0; i < 2 * NRB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NRB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NRB - 2 * NRB - 4 - 2 * NRB, 0);
         DSD_SB();
     };
 #pragma nounroll
