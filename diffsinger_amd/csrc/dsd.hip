@@ -279,7 +279,6 @@ extern "C" int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_lat_conv_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvWLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_lat_conv_w<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvWLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_lat_conv_w<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvWLdsBytes);
-        (void)hipFuncSetAttribute((const void*)k_lat_conv_w<16>, hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvWLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_DDPM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_loop_wino<HEAD_PLMS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopWinoLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_head<HEAD_EPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLdsBytes);
@@ -678,8 +677,11 @@ static int launch_inproj(dsd_handle* h, const float* spec, hipStream_t s) {
 template <int G>
 static void launch_lat(const LatParams& p, hipStream_t s) {
     const dim3 grid((unsigned)lat_grid(p.ntiles, G));
-    if (p.w1w) hipLaunchKernelGGL((k_lat_conv_w<G>), grid, dim3(kThreads), kLatConvWLdsBytes, s, p);      // Winograd F(2,3) convolution (the default)
-    else hipLaunchKernelGGL((k_lat_conv<G>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
+    bool wino = false;
+    if constexpr (G != 16) {
+        if (p.w1w) { hipLaunchKernelGGL((k_lat_conv_w<G>), grid, dim3(kThreads), kLatConvWLdsBytes, s, p); wino = true; }      // Winograd F(2,3) convolution
+    }
+    if (!wino) hipLaunchKernelGGL((k_lat_conv<G>), grid, dim3(kThreads), kLatConvLdsBytes, s, p);
     hipLaunchKernelGGL((k_lat_out<G>), grid, dim3(kThreads), kLatOutLdsBytes, s, p);
 }
 
@@ -700,7 +702,9 @@ static int launch_layer(dsd_handle* h, int l, int t_uniform, const int* t_dev, h
         q.t_dev = t_dev; q.t_uniform = t_uniform; q.ds_tstride = h->L * kC;
         q.T = h->T; q.ntile32 = h->ntile32; q.ntiles = h->ntiles; q.dil = h->dil[l];
         q.first = (l == 0); q.last = (l == h->L - 1);
-        q.w1w = (h->conv_mode == 1 && h->w1w) ? h->w1w + (size_t)l * kWnSteps * (kWnStepBytes / 16) : nullptr;
+        // the Winograd form of the convolution for G = 2 / 4 / 8 (4 x 777: 71.0 ms against 81.9, 1 x 1550: 45.3 against 50.2, 1 x 1000: 31.2 against 32.0);
+        // at G = 16 a wave's share is 128 short MFMAs and the direct kernel with its own packing stays ahead (24.6 ms against 25.0; profiles/r5_11_*)
+        q.w1w = (h->conv_mode == 1 && h->w1w && G != 16) ? h->w1w + (size_t)l * kWnSteps * (kWnStepBytes / 16) : nullptr;
         if (G == 16) launch_lat<16>(q, s); else if (G == 8) launch_lat<8>(q, s); else if (G == 4) launch_lat<4>(q, s); else launch_lat<2>(q, s);
         HIP_TRY(hipGetLastError());
         return DSD_OK;

@@ -2,8 +2,8 @@
 // row-split kernels) as Winograd F(2,3) along the frame axis - the arithmetic of the persistent loop (dsd_loop_wino.hpp) for the batches that
 // fill less than half of the chip: the reference's own inference shape, one utterance per device (configs/tts/fs2.yaml:70).
 //
-// k_lat_conv_w<G> replaces k_lat_conv<G> when the handle's convolution mode is Winograd (the default); k_lat_out<G> and the head kernels are
-// unchanged.  Same row ownership as the direct kernels in units of 16 rows: workgroup g of a tile computes 256 / G gate rows and THEIR filter
+// k_lat_conv_w<G> replaces k_lat_conv<G> for G = 2 / 4 / 8 when the handle's convolution mode is Winograd (the default; at G = 16 the direct kernel
+// is faster and stays: dsd.hip launch_layer); k_lat_out<G> and the head kernels are unchanged.  Same row ownership as the direct kernels in units of 16 rows: workgroup g of a tile computes 256 / G gate rows and THEIR filter
 // rows, so the gate never leaves a lane:
 //   G = 2: wave wv <- gate blocks 8 g + 2 wv, + 1 and their filter blocks, the whole K            (4 row blocks of 16)
 //   G = 4: wave wv <- gate block 4 g + wv and its filter block, the whole K                         (2 row blocks)
@@ -26,7 +26,7 @@ constexpr int kLatConvWLdsBytes = (kWnY + 4 * 1024) * (int)sizeof(float);      /
 
 template <int G>
 __global__ __launch_bounds__(kThreads, 2) void k_lat_conv_w(const LatParams p) {
-    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "row split");
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "row split (G = 16 is written and correct - tests/test_wino_model.py, profiles/r5_10 - but not instantiated: the direct kernel is faster there)");
     constexpr int LDK = kFmLDK, TILE = kC * 32;
     constexpr int NRB = (G == 2) ? 4 : 2;                      // row blocks of 16 per wave: NRB / 2 gate blocks + their filter blocks
     constexpr int NGB = NRB / 2;

@@ -185,8 +185,8 @@ def test_default_path_choice_with_the_winograd_loop():
 @pytest.mark.parametrize('preset,layer', [('opencpop_ds60_rel', 0), ('opencpop_ds60_rel', 1), ('opencpop_ds60_rel', 2), ('opencpop_ds60_rel', 3),
                                           ('lj_ds_beta6', 19)])
 def test_latency_winograd_layer_against_the_oracle_layer_every_split(preset, layer):
-    """ONE residual layer (usr/diff/net.py:66-78) through dsd_debug_layer on k_lat_conv_w<G> + k_lat_out<G> for every G, dilations 1 .. 8, ragged T,
-    the last layer (skips only) - against the oracle's layer, next to the direct-form kernels of the same G."""
+    """ONE residual layer (usr/diff/net.py:66-78) through dsd_debug_layer on k_lat_conv_w<G> + k_lat_out<G> for G = 2 / 4 / 8 (G = 16 keeps the direct
+    kernel in either mode), dilations 1 .. 8, ragged T, the last layer (skips only) - against the oracle's layer, next to the direct-form kernels."""
     from oracle import diffnet_oracle as O
     from tests.gpu_helpers import build_hip
     pre = H.presets()[preset]
@@ -222,7 +222,8 @@ def test_latency_winograd_layer_against_the_oracle_layer_every_split(preset, lay
 
 def test_one_utterance_k100_on_the_winograd_latency_kernels_vs_oracle_and_timing():
     """The reference's own inference shape - ONE utterance (configs/tts/fs2.yaml:70), here 512 / 1000 / 1550 frames, K = 100 DDPM - on the default
-    path (latency kernels G = 16 / 8 / 4 with the Winograd convolution) against the oracle, and its time next to the direct-form kernels."""
+    path (latency kernels; G = 8 / 4 with the Winograd convolution, G = 16 direct in either mode) against the oracle, and its time next to the
+    direct-form kernels."""
     import time
     from oracle import diffnet_oracle as O
     from diffsinger_amd.synth import make_inputs
