@@ -2,7 +2,10 @@
 registered in usr/diffsinger_task.py:23-27) on the HIP FastSpeech2 operators (include/dsf.h) - SURVEY.md section 8 row f4.
 
 Same constructor, parameter names and shapes as the reference class (a reference state_dict loads with strict=True), same
-call `forward(spec [B,1,M,T], diffusion_step [B], cond [B,H,T]) -> [B,1,M,T]`.  Inference only.  Every contraction (input
+call `forward(spec [B,1,M,T], diffusion_step [B], cond [B,H,T]) -> [B,1,M,T]` (inference: no graph) and `forward_train(...)`, the same
+function under autograd - the reference trains whatever `DIFF_DECODERS` returns (usr/diffsinger_task.py:23-27 with
+usr/diff/shallow_diffusion_tts.py:213-231); every operator here has its HIP backward (diffsinger_amd/fs2.py, train.py), so
+`GaussianDiffusion.p_losses` back-propagates through this denoiser like through the FastSpeech2 blocks it is made of.  Every contraction (input
 projection, step MLP, get_decode_inp, the FFT blocks, get_mel_out), LayerNorm and the attention core run as HIP kernels; the
 step's sinusoid, the channel concatenation and the position lookup are torch data movement on the device."""
 from __future__ import annotations
@@ -44,6 +47,13 @@ class FFT(FastspeechDecoder):
 
     @torch.no_grad()
     def forward(self, spec, diffusion_step, cond, padding_mask=None, attn_mask=None, return_hiddens=False):
+        return self._forward(spec, diffusion_step, cond, padding_mask, attn_mask, return_hiddens)
+
+    def forward_train(self, spec, diffusion_step, cond, padding_mask=None):
+        """The same function with autograd on: what `p_losses` differentiates (candidate_decoder.py:66-96 under the reference's training step)."""
+        return self._forward(spec, diffusion_step, cond, padding_mask)
+
+    def _forward(self, spec, diffusion_step, cond, padding_mask=None, attn_mask=None, return_hiddens=False):
         if attn_mask is not None or return_hiddens:
             raise NotImplementedError('attn_mask / return_hiddens')
         B, _, M, T = spec.shape

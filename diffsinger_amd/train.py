@@ -290,15 +290,17 @@ def p_losses(gd, x_start: torch.Tensor, t: torch.Tensor, cond: torch.Tensor, noi
              nonpadding: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:213-231)."""
     from .net import DiffNet
-    if not isinstance(gd.denoise_fn, DiffNet):
-        raise NotImplementedError(f'p_losses: training is implemented for the DiffNet denoiser (diff_decoder_type "wavenet"); '
-                                  f'{type(gd.denoise_fn).__name__} is inference-only here')
+    fused = isinstance(gd.denoise_fn, DiffNet)
+    if not fused and not hasattr(gd.denoise_fn, 'forward_train'):
+        raise NotImplementedError(f'p_losses: {type(gd.denoise_fn).__name__} has no training forward (DiffNet: the fused stack; FFT: forward_train)')
     if noise is None:
         noise = torch.randn_like(x_start)
     shape = (x_start.shape[0], 1, 1, 1)
     x_noisy = gd.sqrt_alphas_cumprod.gather(-1, t).reshape(shape) * x_start + \
         gd.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(shape) * noise                    # q_sample :206-211
-    x_recon = diffnet_forward_train(gd.denoise_fn, x_noisy, t, cond)
+    # the denoiser the registry returned (usr/diffsinger_task.py:23-27): DiffNet on the fused training stack, the FFT candidate on the
+    # FastSpeech2 operators under autograd
+    x_recon = diffnet_forward_train(gd.denoise_fn, x_noisy, t, cond) if fused else gd.denoise_fn.forward_train(x_noisy, t, cond)
     if gd.loss_type == 'l1':
         if nonpadding is not None:
             return ((noise - x_recon).abs() * nonpadding.unsqueeze(1)).mean()

@@ -62,3 +62,57 @@ def test_hip_fft_denoiser_and_ddpm_match_reference():
     e_x, e_m = float(np.abs(x.cpu().numpy() - g['x_final']).max()), float(np.abs(mel.cpu().numpy() - g['mel']).max())
     print(f'FFT-driven DDPM K={FH.K}: max-abs err x {e_x:.3e}, mel {e_m:.3e}')
     assert e_x <= 1e-4 and e_m <= 1e-4
+
+
+@pytest.mark.gpu
+def test_p_losses_through_the_fft_denoiser_every_gradient_vs_the_oracle_under_autograd():
+    """The reference trains whatever DIFF_DECODERS returns (usr/diffsinger_task.py:23-27, shallow_diffusion_tts.py:213-231): p_losses with the FFT
+    candidate as denoise_fn - q_sample, FFT.forward_train on the HIP operators (backward on HIP kernels), L1 - against the oracle (bit-equal to
+    the reference class, `test_oracle_matches_reference_fixture_bitwise`) under torch autograd on the CPU: the loss and EVERY parameter gradient."""
+    import diffsinger_amd
+    from diffsinger_amd.synth import presets
+    from oracle import diffnet_oracle as DO
+    from oracle import fft_decoder_oracle as O
+    m, hp, params = FH.build_module()
+    inp = FH.make_inputs()
+    d = torch.device('cuda', 0)
+    m = m.to(d)
+    pre = presets()[FH.PRESET]
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, m, timesteps=pre['timesteps'], K_step=pre['K_step'], loss_type='l1', spec_min=pre['spec_min'],
+                                          spec_max=pre['spec_max']).to(d)
+    gd.eval()                                                   # dropout off: the comparison is deterministic (the reference's dropout positions
+    for p in m.parameters():                                    # are covered by the FastSpeech2 training tests, tests/test_gpu_fs2_train.py)
+        p.requires_grad_(True)
+    g = torch.Generator().manual_seed(91)
+    x0 = torch.randn(FH.B, 1, 80, FH.T, generator=g).clamp_(-1, 1)
+    noise = torch.randn(FH.B, 1, 80, FH.T, generator=g)
+    t = torch.tensor([17, 3])
+    loss = gd.p_losses(x0.to(d), t.to(d), inp['cond'].to(d), noise=noise.to(d))
+    loss.backward()
+    # the oracle: the same q_sample + denoiser + L1 in plain torch on the CPU
+    sch = DO.make_schedule(H_betas(pre))
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items() if v.is_floating_point()}
+    po.update({k: v for k, v in params.items() if not v.is_floating_point()})
+    shape = (FH.B, 1, 1, 1)
+    x_noisy = sch['sqrt_alphas_cumprod'][t].reshape(shape) * x0 + sch['sqrt_one_minus_alphas_cumprod'][t].reshape(shape) * noise
+    want = (noise - O.fft_forward(po, hp, x_noisy, t, inp['cond'])).abs().mean()
+    want.backward()
+    print(f'p_losses through FFT: loss {float(loss):.7f} (oracle {float(want):.7f})')
+    assert abs(float(loss) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+    worst = ('', 0.0)
+    n = 0
+    for k, p in m.named_parameters():
+        if k not in po or po[k].grad is None:
+            continue
+        gw = po[k].grad
+        assert p.grad is not None, k
+        rel = float((p.grad.cpu() - gw).abs().max()) / max(float(gw.abs().max()), 1e-12)
+        worst = max(worst, (k, rel), key=lambda kv: kv[1])
+        n += 1
+    print(f'{n} parameter gradients, worst relative max-abs error {worst[1]:.3e} ({worst[0]})')
+    assert n >= 40 and worst[1] <= 2e-5
+
+
+def H_betas(pre):
+    from tests import helpers as H
+    return H.betas_for(pre)
