@@ -97,8 +97,8 @@ def test_p_losses_through_the_fft_denoiser_every_gradient_vs_the_oracle_under_au
     x_noisy = sch['sqrt_alphas_cumprod'][t].reshape(shape) * x0 + sch['sqrt_one_minus_alphas_cumprod'][t].reshape(shape) * noise
     want = (noise - O.fft_forward(po, hp, x_noisy, t, inp['cond'])).abs().mean()
     want.backward()
-    print(f'p_losses through FFT: loss {float(loss):.7f} (oracle {float(want):.7f})')
-    assert abs(float(loss) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+    print(f'p_losses through FFT: loss {float(loss.detach()):.7f} (oracle {float(want.detach()):.7f})')
+    assert abs(float(loss.detach()) - float(want.detach())) <= 2e-6 * max(1.0, abs(float(want.detach())))
     worst = ('', 0.0)
     n = 0
     for k, p in m.named_parameters():
