@@ -2,6 +2,7 @@
 // end of dsd.hip behind fs2_abi.hpp (one translation unit: shares fail(), HIP_TRY, fs_ts and the packing kernels).
 #include "train_kernels.hpp"
 #include "train_loop.hpp"
+#include "train_loop_wino.hpp"
 
 namespace {
 
@@ -32,6 +33,24 @@ extern "C" int dsf_set_stack_mode(int32_t mode) {
     g_tr_stack_mode = mode;
     return DSD_OK;
 }
+// The convolution of the persistent forward: 1 (default) Winograd F(2,3) along the frames (train_loop_wino.hpp: 2/3 of the multiplications) where
+// every dilation is 1, 2, 4 or 8; 0 the direct form (train_loop.hpp: bit-identical to the per-layer launches - the anchor of that test).
+static int g_tr_stack_conv = 1;
+static int g_tr_stack_touch = 16;       // steps the Winograd weight stream's L2 touch runs in front (the inference loop's default)
+extern "C" int dsf_set_stack_conv(int32_t mode) {
+    if (mode < 0 || mode > 1) return fail(DSD_ERR_INVALID, "dsf_set_stack_conv: 0 (direct) or 1 (Winograd F(2,3))");
+    g_tr_stack_conv = mode;
+    return DSD_OK;
+}
+extern "C" int dsf_get_stack_conv(void) { return g_tr_stack_conv; }
+static bool tr_wino_applies(const dsf_stack_weights* w, int L) {
+    if (g_tr_stack_conv != 1) return false;
+    for (int l = 0; l < L; ++l) {
+        const int d = w->dilations[l];
+        if (d != 1 && d != 2 && d != 4 && d != 8) return false;
+    }
+    return true;
+}
 static bool tr_persist_applies(int B, int ntile32) {
     const int mode = g_tr_stack_mode;
     if (mode == 0) return false;
@@ -46,7 +65,7 @@ static bool tr_persist_applies(int B, int ntile32) {
 }
 
 struct TrSave {             // offsets in floats into save_ws
-    size_t w1p, wcp, w2p, b1p, cp, X, Y, A, skip, bsum, iota, flags, total;
+    size_t w1p, wcp, w2p, b1p, cp, X, Y, A, skip, bsum, iota, flags, w1w, total;
     size_t cp_l, X_l, Y_l, A_l;      // per-layer strides
 };
 static TrSave tr_save_layout(int B, int TS, int L) {
@@ -65,6 +84,7 @@ static TrSave tr_save_layout(int B, int TS, int L) {
     s.bsum = o; o += 1024;
     s.iota = o; o += tr_al((size_t)B);
     s.flags = o; o += tr_al(ntiles + 64);       // phase flags + timeout word of the persistent forward (its halo buffers alias X)
+    s.w1w = o; o += (size_t)L * kWnSteps * (kWnStepBytes / 4) + kTrSlack;     // Winograd-transformed conv weights (train_loop_wino.hpp) + prefetch slack
     s.total = o;
     return s;
 }
@@ -119,6 +139,7 @@ static int tr_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_layer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, layer_lds_bytes<1>()));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_stack_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, kTrStackLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tr_stack_fwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, kTrStackWinoLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_gate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbGateLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
@@ -229,7 +250,7 @@ static int tr_persistent_chunks(hipStream_t s, int B, int ntile32, F launch) {
 }
 
 static int tr_forward_persistent(const float* x0, const float* step, const dsf_stack_weights* w, int B, int T, int L, float* ws, const TrSave& lay,
-                                 float* skip_out, hipStream_t s) {
+                                 float* skip_out, bool wino, hipStream_t s) {
     const int TS = fs_ts(T), ntile32 = TS / 32, ntiles = B * ntile32;
     unsigned* flags = reinterpret_cast<unsigned*>(ws + lay.flags);
     HIP_TRY(hipMemsetAsync(flags, 0, ((size_t)ntiles + 64) * sizeof(unsigned), s));
@@ -244,6 +265,17 @@ static int tr_forward_persistent(const float* x0, const float* step, const dsf_s
     for (int l = 0; l < L; ++l) p.dil[l] = (unsigned char)w->dilations[l];
     p.flags = flags; p.tmo = flags + ntiles;
     p.halo = ws + lay.X;                            // 2 x ntiles x 16 KiB = one layer of the (here unused) tile-major x buffers
+    if (wino) {
+        TrLoopWinoParams q{};
+        q.w1w = (const float4*)(ws + lay.w1w);
+        q.wl_bytes = (unsigned)((size_t)L * kWnSteps * kWnStepBytes);
+        q.touch_ahead = g_tr_stack_touch;
+        return tr_persistent_chunks(s, B, ntile32, [&](int tile_base, int n_tiles) {
+            p.tile_base = tile_base; p.n_tiles = n_tiles;
+            q.tp = p;
+            hipLaunchKernelGGL(k_tr_stack_fwd_w, dim3((unsigned)n_tiles), dim3(kThreads), kTrStackWinoLdsBytes, s, q);
+        });
+    }
     return tr_persistent_chunks(s, B, ntile32, [&](int tile_base, int n_tiles) {
         p.tile_base = tile_base; p.n_tiles = n_tiles;
         hipLaunchKernelGGL(k_tr_stack_fwd, dim3((unsigned)n_tiles), dim3(kThreads), kTrStackLdsBytes, s, p);
@@ -260,8 +292,16 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
     hipStream_t s = (hipStream_t)stream;
     const int TS = fs_ts(T), ntile32 = TS / 32, ntiles = B * ntile32;
     const TrSave lay = tr_save_layout(B, TS, L);
+    const bool persist = tr_persist_applies(B, ntile32);
+    const bool wino = persist && tr_wino_applies(w, L);
     // weights -> fragment order, all layers per launch (they change every optimiser step)
-    DSD_TRY(tr_pack_multi(s, w->dilated_conv_w, L, ws + lay.w1p, kTrW3, 4, 3, 32, 4, 1, kC, 2 * kC, kC, 3 * kC, 3, 0));
+    if (wino) {
+        hipLaunchKernelGGL(k_pack_wino_multi, dim3(256, (unsigned)L), dim3(256), 0, s, tr_ptrs(w->dilated_conv_w, L), ws + lay.w1w);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(ws + lay.w1w + (size_t)L * kWnSteps * (kWnStepBytes / 4), 0, kTrSlack * sizeof(float), s));
+    } else {
+        DSD_TRY(tr_pack_multi(s, w->dilated_conv_w, L, ws + lay.w1p, kTrW3, 4, 3, 32, 4, 1, kC, 2 * kC, kC, 3 * kC, 3, 0));
+    }
     DSD_TRY(tr_pack_multi(s, w->cond_w, L, ws + lay.wcp, kTrW1, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1, 0));
     DSD_TRY(tr_pack_multi(s, w->out_w, L, ws + lay.w2p, kTrW1, 4, 1, 32, 4, 1, kC, 2 * kC, kC, kC, 1, 0));
     {
@@ -272,7 +312,6 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_tr_bsum, dim3(1), dim3(256), 0, s, tr_ptrs(w->out_b, L), ws + lay.bsum, L);
-    const bool persist = tr_persist_applies(B, ntile32);
     int* iota = reinterpret_cast<int*>(ws + lay.iota);
     if (!persist) {
         hipLaunchKernelGGL(k_tr_iota, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, iota, B);
@@ -284,6 +323,8 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
         CondProjParams p{};
         p.condT = cond; p.wcp = (const float4*)(ws + lay.wcp); p.b1p = (const float4*)(ws + lay.b1p); p.cp = (float4*)(ws + lay.cp);
         p.TS = TS; p.ntile32 = ntile32; p.ntiles_total = ntiles;
+        p.wino = wino ? 1 : 0;                      // the Winograd forward takes it as its accumulators' initial values (dsd_kernels.hpp)
+        for (int l = 0; l < L; ++l) p.dil[l] = (unsigned char)w->dilations[l];
         hipLaunchKernelGGL(k_condproj, dim3((unsigned)ntiles, (unsigned)L), dim3(kThreads), kC * 32 * 4, s, p);
         HIP_TRY(hipGetLastError());
     }
@@ -292,7 +333,7 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
         hipLaunchKernelGGL(k_tr_zero_pads, dim3((unsigned)std::min<size_t>((rows * 2 * kTrYPad + 255) / 256, 8192)), dim3(256), 0, s, ws + lay.Y, rows, TS + 2 * kTrYPad);
         HIP_TRY(hipGetLastError());
     }
-    if (persist) return tr_forward_persistent(x0, step, w, B, T, L, ws, lay, skip_out, s);
+    if (persist) return tr_forward_persistent(x0, step, w, B, T, L, ws, lay, skip_out, wino, s);
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
         LayerParams p{};

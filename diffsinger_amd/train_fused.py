@@ -64,6 +64,8 @@ def _bind(lib):
     lib.dsf_stack_workspace_floats.argtypes = [i32, i32, i32, i32]
     lib.dsf_stack_workspace_floats.restype = i64
     lib.dsf_set_stack_mode.argtypes = [i32]
+    lib.dsf_set_stack_conv.argtypes = [i32]
+    lib.dsf_get_stack_conv.argtypes = []
     lib.dsf_stack_offsets.argtypes = [i32, i32, i32, i32, C.POINTER(i64), i32]
     lib.dsf_stack_forward.argtypes = [vp, vp, vp, C.POINTER(DsfStackWeights), i32, i32, i32, vp, vp, vp]
     lib.dsf_stack_backward.argtypes = [vp, vp, C.POINTER(DsfStackWeights), i32, i32, i32, vp, vp, C.POINTER(DsfStackGrads), vp, vp]
@@ -81,6 +83,21 @@ def set_stack_mode(mode: int):
     lib = _lib.load()
     _bind(lib)
     _lib.check(lib.dsf_set_stack_mode(int(mode)), 'dsf_set_stack_mode')
+
+
+def set_stack_conv(mode):
+    """The dilated convolution of the persistent forward (include/dsf.h dsf_set_stack_conv): 'wino' / 1 Winograd F(2,3) (default),
+    'direct' / 0 the direct form (bit-identical to the per-layer launches)."""
+    lib = _lib.load()
+    _bind(lib)
+    m = {'wino': 1, 'direct': 0}.get(mode, mode)
+    _lib.check(lib.dsf_set_stack_conv(int(m)), 'dsf_set_stack_conv')
+
+
+def stack_conv() -> str:
+    lib = _lib.load()
+    _bind(lib)
+    return 'wino' if lib.dsf_get_stack_conv() == 1 else 'direct'
 
 
 def _weights_struct(ws: List[torch.Tensor], L: int, dils: List[int]):

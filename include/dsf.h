@@ -141,7 +141,7 @@ int dsf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, doub
  *             step embedding, :67) -> skip [B][256][TS] = sum_l skip_l (the tensor :126 divides by sqrt(L)).  One conditioner-projection
  *             launch for all layers + the layers as ONE persistent launch per chunk of whole utterances (the tile ownership and
  *             neighbour exchange of the inference loop, csrc/train_loop.hpp) when an utterance fits one workgroup per CU and the chunks
- *             fill the chip, else the inference layer kernel per layer (dsf_set_stack_mode picks; the two are bit-identical);
+ *             fill the chip, else the inference layer kernel per layer (dsf_set_stack_mode picks; bit-identical with dsf_set_stack_conv(0));
  *             either saves y = x + step and the gate pre-activation of every layer into `save_ws` for the backward pass.  A neighbour
  *             wait that hits its (seconds-long) bound poisons `skip` with NaN instead of hanging.
  *   backward  dskip [B][256][TS] -> dx0, dstep [B][L][256], every weight / bias gradient of the stack (torch layouts, OVERWRITTEN),
@@ -170,6 +170,12 @@ int64_t dsf_stack_workspace_floats(int32_t B, int32_t T, int32_t L, int32_t whic
  * that fills the chip, else one launch per layer), 0 per-layer launches always (the A/B switch of the measurement), 2 persistent wherever an
  * utterance fits the co-resident grid (tests of the chunked form).  The workspace sizes do not depend on it. */
 int dsf_set_stack_mode(int32_t mode);
+/* The dilated convolution of the persistent forward (process-wide): 1 (default) Winograd F(2,3) along the frame axis - the inference loop's
+ * form (include/dsd.h dsd_set_conv_mode; csrc/train_loop_wino.hpp): exact-fp32 MFMA on 2/3 of the multiplications, used where every dilation
+ * is 1, 2, 4 or 8, results within the transforms' roundings of the direct form; 0 the direct form (csrc/train_loop.hpp: bit-identical to the
+ * per-layer launches).  The saved tensors keep their layouts; the workspace sizes do not depend on it. */
+int dsf_set_stack_conv(int32_t mode);
+int dsf_get_stack_conv(void);
 int dsf_stack_offsets(int32_t B, int32_t T, int32_t L, int32_t which, int64_t* out, int32_t n);
 int dsf_stack_forward(const float* x0, const float* cond, const float* step, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L,
                       float* save_ws, float* skip_out, void* stream);

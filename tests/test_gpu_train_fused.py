@@ -89,11 +89,23 @@ def _frag_to_rows(frag, ntiles):
     return out
 
 
+@pytest.fixture
+def stack_conv(request):
+    """the convolution of the persistent forward for one test (dsf_set_stack_conv), the default restored behind it"""
+    from diffsinger_amd import train_fused
+    train_fused.set_stack_conv(request.param)
+    yield request.param
+    train_fused.set_stack_conv('wino')
+
+
+@pytest.mark.parametrize('stack_conv', ['wino', 'direct'], indirect=True)
 @pytest.mark.parametrize('B,T,L,cycle', [(2, 50, 3, 4), (3, 96, 5, 1), (2, 70, 20, 4), (1, 5, 1, 1), (1, 32, 2, 4), (4, 33, 2, 2), (9, 129, 4, 3)])
-def test_stack_forward_and_backward(B, T, L, cycle):
+def test_stack_forward_and_backward(B, T, L, cycle, stack_conv):
+    """(these shapes take the persistent forward: with the Winograd convolution, csrc/train_loop_wino.hpp, and with the direct one)"""
     from diffsinger_amd import _lib, fs2, train_fused
     lib = _lib.load()
     train_fused._bind(lib)
+    assert train_fused.stack_conv() == stack_conv
     ws, dils = _make_stack(L, cycle, seed=L + T)
     g = torch.Generator().manual_seed(5 + T)
     x0 = torch.relu(torch.randn(B, 256, T, generator=g))
@@ -157,9 +169,10 @@ def test_stack_forward_and_backward(B, T, L, cycle):
 @pytest.mark.parametrize('B,T,L,cycle,dcond', [(9, 1000, 3, 4, False), (2, 50, 3, 4, True), (3, 96, 20, 4, False), (1, 5, 1, 1, True), (17, 500, 2, 2, True),
                                                (1, 200, 4, 1, False)])
 def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond):
-    """csrc/train_loop.hpp (the forward as ONE launch per chunk of whole utterances, neighbour exchange through flags)
-    against the per-layer launches: the skip sum, everything saved for the backward and every gradient are the same BITS; (9, 1000) and
-    (17, 500) take two chunks on a 256-CU part; dcond selects the caller-kept da_all layout of the backward."""
+    """csrc/train_loop.hpp (the forward as ONE launch per chunk of whole utterances, neighbour exchange through flags; the DIRECT convolution:
+    dsf_set_stack_conv(0)) against the per-layer launches: the skip sum, everything saved for the backward and every gradient are the same
+    BITS; (9, 1000) and (17, 500) take two chunks on a 256-CU part; dcond selects the caller-kept da_all layout of the backward.  The Winograd
+    forward (the default) on the same inputs: every one of those tensors within 3e-5 of the direct form's (relative to the tensor's max)."""
     from diffsinger_amd import _lib, fs2, train_fused
     lib = _lib.load()
     train_fused._bind(lib)
@@ -177,8 +190,9 @@ def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond):
     _lib.check(lib.dsf_stack_offsets(B, T, L, 0, off, 16))
     oY, oA, Yl, Al = off[6], off[7], off[12], off[13]
     got = {}
-    for mode in ('0', '2'):
-        train_fused.set_stack_mode(int(mode))
+    for mode in ('0', '2', 'w'):
+        train_fused.set_stack_mode(2 if mode == 'w' else int(mode))
+        train_fused.set_stack_conv('wino' if mode == 'w' else 'direct')
         xin, cin, sin = x0.clone().requires_grad_(True), cond.clone().requires_grad_(dcond), step.clone().requires_grad_(True)
         wd = [t.clone().requires_grad_(True) for t in wsrc]
         skip = train_fused._ResidualStack.apply(xin, cin, sin, T, dils, {}, *wd)
@@ -191,9 +205,17 @@ def test_persistent_kernels_equal_per_layer_launches(B, T, L, cycle, dcond):
         got[mode] = res
         torch.cuda.synchronize()
     train_fused.set_stack_mode(1)
-    assert all(bool(torch.isfinite(t).all()) for t in got['2'])
+    train_fused.set_stack_conv('wino')
+    assert all(bool(torch.isfinite(t).all()) for t in got['2']) and all(bool(torch.isfinite(t).all()) for t in got['w'])
     for i, (a, b) in enumerate(zip(got['0'], got['2'])):
         assert torch.equal(a, b), f'tensor {i} differs: {float((a - b).abs().max())}'
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(got['2'], got['w'])):
+        e = float((a - b).abs().max() / max(float(a.abs().max()), 1e-30))
+        worst = max(worst, e)
+        assert e <= 3e-5, f'Winograd forward: tensor {i} off by {e:.2e}'
+    assert worst > 0.0                                    # (it IS another kernel)
+    print(f'Winograd forward vs direct persistent forward, B={B} T={T} L={L}: worst tensor {worst:.2e}')
 
 
 def test_p_losses_gradients_fused_equals_operator_path(monkeypatch):

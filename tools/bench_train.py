@@ -1,6 +1,7 @@
 """Developer tool (GPU): one DiffNet training step (p_losses forward + backward, no optimiser) on the HIP operators of
 diffsinger_amd/train.py, next to the same autograd graph with torch's own conv1d (MIOpen / rocBLAS) on the same GPU.
-    python tools/bench_train.py [reps]"""
+    python tools/bench_train.py [reps]
+    python tools/bench_train.py [reps] --conv-ab      the fused stack with the Winograd / the direct convolution in its persistent forward"""
 import json
 import os
 import sys
@@ -40,7 +41,10 @@ def reference_style_forward(net, spec, t, cond):
     return F.conv1d(x, net.output_projection.weight, net.output_projection.bias)[:, None]
 
 
-def run(B, T, reps, torch_conv=False, reference_style=False, fused=True, graph=False):
+def run(B, T, reps, torch_conv=False, reference_style=False, fused=True, graph=False, conv=None):
+    from diffsinger_amd import train_fused
+    if conv is not None:
+        train_fused.set_stack_conv(conv)
     os.environ['DSD_TRAIN_FUSED'] = '1' if (fused and not torch_conv and not reference_style) else '0'
     pre = presets()['lj_ds_beta6']
     hparams.clear()
@@ -102,6 +106,8 @@ def run(B, T, reps, torch_conv=False, reference_style=False, fused=True, graph=F
     impl = ('reference-style PyTorch-ROCm eager graph (MIOpen convolutions, ATen element-wise ops)' if reference_style else
             'torch conv1d (MIOpen) inside the HIP graph (fused glue kept)' if torch_conv else
             'fused residual stack (dsf_stack_forward / dsf_stack_backward)' if fused else 'HIP operators (dsf_conv1d_dilated / dsf_conv1d_wgrad / dsf_train_*)')
+    if fused and not torch_conv and not reference_style:
+        impl += f', persistent forward convolution: {train_fused.stack_conv()}'
     print(json.dumps({'impl': impl + (' replayed as one hipGraph' if graph else ''),
                       'B': B, 'T': T, 'ms_per_step_fwd_bwd': sec * 1e3, 'frames_per_s': frames / sec,
                       'tflops_gemm': 3 * F_FWD * frames / sec / 1e12, 'loss': float(loss)}), flush=True)
@@ -111,6 +117,11 @@ def run(B, T, reps, torch_conv=False, reference_style=False, fused=True, graph=F
 
 if __name__ == '__main__':
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    if '--conv-ab' in sys.argv:
+        for B, T in ((8, 1024), (48, 512), (16, 1024)):
+            for conv in ('wino', 'direct', 'wino', 'direct'):
+                run(B, T, reps, conv=conv)
+        sys.exit(0)
     if '--hip-only' in sys.argv:                    # for rocprofv3 runs: only the HIP variant, one shape
         B, T = (int(v) for v in sys.argv[sys.argv.index('--hip-only') + 1].split('x'))
         run(B, T, reps, graph='--graph' in sys.argv)
