@@ -113,9 +113,13 @@ struct L2TouchP {
 // one scalar add.  What the fillers cost beside a 32-cycle fp32 MFMA (tools/mfma_filler_probe.hip, profiles/r5_02_mfma_filler_probe.jsonl):
 // a satisfied s_waitcnt nothing, a ds_read_b128 under one cycle, a VECTOR-ALU instruction 8 cycles of matrix time (+ 5 for the first one
 // in a gap: the fp32 matrix pipe and the vector ALU do not overlap) - so the input transform's eight adds go into ONE gap of a group's last step.
-template <int S>
+// CM = 0: the B tile is FRAME-MAJOR in pair order (this file's loop).  CM = LD > 0: the B tile is CHANNEL-MAJOR [k row][LD frames] (the
+// transposed convolution of the training backward, train_wino_bwd.hpp): lane (p, g) reads k rows 16 c + 4 s + g at frames tE(p) + {-d, 0, d, 2 d}
+// as ds_read_b32 - the pointers are frame pointers of row g, a chunk is 16 rows further.
+template <int S, int CM = 0>
 struct WinoPipe {
     static_assert(S == 4 || S == 8, "the register rotation has period 8");
+    static constexpr int kCS = CM ? 16 * CM : 4;        // floats between two chunks of the B tile
     __amdgpu_buffer_rsrc_t rsrc;    // over the whole stream behind this wave's 4 KiB of step 0 / layer 0
     unsigned vo[4], so;             // lane * 16 + 1024 r4 (kept in registers: rematerialised, they are four vector-ALU instructions per period beside
                                     // the MFMAs); byte offset of step 0 of the CURRENT period
@@ -131,6 +135,9 @@ struct WinoPipe {
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wave_base), 0, 0x7ffffff0, 0x00020000)),
           so((unsigned)l * (unsigned)(kWnSteps * kWnStepBytes)), qE(pE), qO(pO), rOm(pO - dilrow - 4), rO(pO - 4), rEp(pE + dilrow - 4), rE(pE - 4),
           tc(tc_), gper((unsigned)l * (unsigned)(kWnSteps / 8)) {
+        if constexpr (CM != 0) {                            // pE: row g at frame tE, pO = pE + d, dilrow = d (frames)
+            rOm = pE - dilrow - kCS; rO = pO - kCS; rEp = pO + dilrow - kCS; rE = pE - kCS;
+        }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             vo[r4] = (unsigned)lane * 16u + (unsigned)r4 * 1024u;
@@ -151,7 +158,15 @@ struct WinoPipe {
     // raw operand rows of the next chunk (+ O floats): half 0 (halo-free) E[p], O[p]; half 1 O[p - d], O[p], E[p + d], E[p]
     template <int HALF, int O>
     __device__ __forceinline__ void ldb_raw() {
-        if constexpr (HALF == 0) {
+        if constexpr (CM != 0) {
+            constexpr int OC = (O / 4) * kCS;
+            auto rd = [](const float* q) -> float4 { return make_float4(q[OC], q[OC + 4 * CM], q[OC + 8 * CM], q[OC + 12 * CM]); };
+            if constexpr (HALF == 0) {
+                raw[0] = rd(qE); raw[1] = rd(qO);
+            } else {
+                raw[0] = rd(rOm); raw[1] = rd(rO); raw[2] = rd(rEp); raw[3] = rd(rE);
+            }
+        } else if constexpr (HALF == 0) {
             raw[0] = *reinterpret_cast<const float4*>(qE + O);
             raw[1] = *reinterpret_cast<const float4*>(qO + O);
         } else {
@@ -199,7 +214,7 @@ struct WinoPipe {
 #pragma unroll
             for (int i = 0; i < (NH ? 4 : 2); ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, CM ? 4 : 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 12 - (NH ? 4 : 2), 0);
         } else if constexpr ((I & 3) == 3) {
@@ -219,7 +234,7 @@ struct WinoPipe {
     __device__ __forceinline__ void start_b() {
         ldb_raw<0, 0>();
         transform<0>(v[0]);
-        qE += 4; qO += 4;                                               // the first group's read takes chunk 1
+        qE += kCS; qO += kCS;                                           // the first group's read takes chunk 1
         DSD_SB();
     }
     // step I of a period: product pos = (I >> 1) & 1 of the group's chunk, row blocks 4 (I & 1) .. + 3; NH = half of the NEXT group
@@ -244,8 +259,8 @@ struct WinoPipe {
         step<4, NH1>(acc); step<5, NH1>(acc); step<6, NH1>(acc); step<7, NH1>(acc);
         ++gper;
         so += 8u * (unsigned)kWnStepBytes;
-        if constexpr (NH0 == 0 || NH1 == 0) { qE += 8; qO += 8; }
-        if constexpr (NH0 == 1 || NH1 == 1) { rOm += 8; rO += 8; rEp += 8; rE += 8; }
+        if constexpr (NH0 == 0 || NH1 == 0) { qE += 2 * kCS; qO += 2 * kCS; }
+        if constexpr (NH0 == 1 || NH1 == 1) { rOm += 2 * kCS; rO += 2 * kCS; rEp += 2 * kCS; rE += 2 * kCS; }
     }
     // N periods; NH0 / NH1: the half the group behind the first / second group of a period belongs to
     template <int N, int NH0, int NH1>

@@ -3,6 +3,7 @@
 #include "train_kernels.hpp"
 #include "train_loop.hpp"
 #include "train_loop_wino.hpp"
+#include "train_wino_bwd.hpp"
 
 namespace {
 
@@ -90,7 +91,7 @@ static TrSave tr_save_layout(int B, int TS, int L) {
 }
 
 struct TrBwd {              // offsets in floats into bwd_ws
-    size_t wotp, wdtp, da, g, dxp0, dxp1, dds_part, part, part_b, total;
+    size_t wotp, wdtp, da, g, dxp0, dxp1, dds_part, part, part_b, wdw, total;
 };
 static TrBwd tr_bwd_layout(int B, int TS, int L) {
     const size_t ntiles = (size_t)B * TS / 32, act = (size_t)B * kC * TS;
@@ -105,6 +106,7 @@ static TrBwd tr_bwd_layout(int B, int TS, int L) {
     s.dds_part = o; o += tr_al((size_t)L * ntiles * kC);
     s.part = o; o += (size_t)kTrWgMaxTiles * kTrMaxSplit * 128 * 256;
     s.part_b = o; o += tr_al((size_t)kTrWgMaxTiles * kTrMaxSplit * 128);
+    s.wdw = o; o += (size_t)L * kWnSteps * (kWnStepBytes / 4) + kTrSlack;     // Winograd-transformed transposed conv weights (train_wino_bwd.hpp) + prefetch slack
     s.total = o;
     return s;
 }
@@ -145,6 +147,10 @@ static int tr_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbConvLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_trb_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_fused_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedWinoLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_fused_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedWinoLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_fused_w<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedWinoLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trb_fused_w<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrbFusedWinoLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)k_tr_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrWgLdsBytes));
     return DSD_OK;
@@ -296,7 +302,7 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
     const bool wino = persist && tr_wino_applies(w, L);
     // weights -> fragment order, all layers per launch (they change every optimiser step)
     if (wino) {
-        hipLaunchKernelGGL(k_pack_wino_multi, dim3(256, (unsigned)L), dim3(256), 0, s, tr_ptrs(w->dilated_conv_w, L), ws + lay.w1w);
+        hipLaunchKernelGGL(k_pack_wino_multi, dim3(32, (unsigned)L), dim3(256), 0, s, tr_ptrs(w->dilated_conv_w, L), ws + lay.w1w);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(ws + lay.w1w + (size_t)L * kWnSteps * (kWnStepBytes / 4), 0, kTrSlack * sizeof(float), s));
     } else {
@@ -373,10 +379,17 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
     // transposed weights in fragment order, two 128-row groups of four row blocks: Wo^T [256 gate channels][512 output rows]; Wd^T flipped
     // [256 input channels][3 x 512]
     DSD_TRY(tr_pack_multi(s, w->out_w, L, bws + bl.wotp, kTrW1, 2, 1, 64, 4, 0, 0, kC, 2 * kC, 1, kC, 0));
+    // the transposed convolution as Winograd F(2,3) (train_wino_bwd.hpp) where every dilation is 1, 2, 4 or 8 and dsf_set_stack_conv says so
+    const bool wino = tr_wino_applies(w, L);
     {   // each K half (gate rows / filter rows of da) of every layer as its own [256 input channels] x [3 x 256] matrix, centre taps first
         const float* halves[2 * kTrMaxLayers];
         for (int l = 0; l < L; ++l) { halves[2 * l] = w->dilated_conv_w[l]; halves[2 * l + 1] = w->dilated_conv_w[l] + (size_t)kC * 3 * kC; }
-        DSD_TRY(tr_pack_multi(s, halves, 2 * L, bws + bl.wdtp, kTrW3 / 2, 2, 3, 32, 4, 0, 0, kC, kC, 3, 3 * kC, 1));
+        if (!wino) DSD_TRY(tr_pack_multi(s, halves, 2 * L, bws + bl.wdtp, kTrW3 / 2, 2, 3, 32, 4, 0, 0, kC, kC, 3, 3 * kC, 1));
+    }
+    if (wino) {
+        hipLaunchKernelGGL(k_pack_wino_bwd_multi, dim3(256, (unsigned)L), dim3(256), 0, s, tr_ptrs(w->dilated_conv_w, L), bws + bl.wdw);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(bws + bl.wdw + (size_t)L * kWnSteps * (kWnStepBytes / 4), 0, kTrSlack * sizeof(float), s));
     }
     float* dxp[2] = {bws + bl.dxp0, bws + bl.dxp1};           // dxp[k & 1]: gradient wrt the output x of layer k
     const long long da_bs = da_all ? (long long)L * 2 * kC * TS : (long long)2 * kC * TS;
@@ -461,8 +474,18 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         if (l > 0) {
             // transposed conv of layer l + gate derivative of layer l - 1 in one kernel (the dx tile stays in the workgroup)
             TrbFusedParams q{conv_params(l), gate_params(l - 1)};
-            if (last) hipLaunchKernelGGL(k_trb_fused<true>, grid, blk, kTrbFusedLdsBytes, s, q);
+            if (wino) {
+                const TrbFusedWinoParams qw{q, (const float4*)(bws + bl.wdw + (size_t)l * kWnSteps * (kWnStepBytes / 4)),
+                                            (unsigned)(kWnSteps * kWnStepBytes), g_tr_stack_touch};
+                if (last) hipLaunchKernelGGL(k_trb_fused_w<true>, grid, blk, kTrbFusedWinoLdsBytes, s, qw);
+                else hipLaunchKernelGGL(k_trb_fused_w<false>, grid, blk, kTrbFusedWinoLdsBytes, s, qw);
+            } else if (last) hipLaunchKernelGGL(k_trb_fused<true>, grid, blk, kTrbFusedLdsBytes, s, q);
             else hipLaunchKernelGGL(k_trb_fused<false>, grid, blk, kTrbFusedLdsBytes, s, q);
+        } else if (wino) {
+            TrbFusedParams q{conv_params(l), TrbGateParams{}};
+            const TrbFusedWinoParams qw{q, (const float4*)(bws + bl.wdw), (unsigned)(kWnSteps * kWnStepBytes), g_tr_stack_touch};
+            if (last) hipLaunchKernelGGL((k_trb_fused_w<true, false>), grid, blk, kTrbFusedWinoLdsBytes, s, qw);
+            else hipLaunchKernelGGL((k_trb_fused_w<false, false>), grid, blk, kTrbFusedWinoLdsBytes, s, qw);
         } else {
             const TrbConvParams p = conv_params(l);
             if (last) hipLaunchKernelGGL(k_trb_conv<true>, grid, blk, kTrbConvLdsBytes, s, p);

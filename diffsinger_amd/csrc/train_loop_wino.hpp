@@ -29,23 +29,39 @@ struct TrLoopWinoParams {
     int touch_ahead;            // steps the L2 touch runs in front (0 = off)
 };
 
-// k_pack_wino over the layers of a pointer table (the weights change every optimiser step: packed per forward call)
-__global__ void k_pack_wino_multi(const TrPtrs src, float* __restrict__ dst) {
-    const size_t n = (size_t)kWnSteps * 4 * 4 * 64 * 4;
-    const float* s = src.p[blockIdx.y];
-    float* d = dst + (size_t)blockIdx.y * n;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx & 3, lane = (idx >> 2) & 63, r4 = (idx >> 8) & 3, w = (idx >> 10) & 3, st = (int)(idx >> 12);
-        const int hb = st & 1, pos = (st >> 1) & 1, c = (st >> 2) & 15, half = st >> 6;
-        const int nn = lane & 15, g = lane >> 4, rb = 4 * hb + r4;
-        const int row = (rb < 4) ? 64 * w + 16 * rb + nn : kC + 64 * w + 16 * (rb - 4) + nn;
-        const int ch = 64 * g + 4 * c + e;
-        const float* wp = s + ((size_t)row * kC + ch) * 3;
-        const double g0 = wp[0], g1 = wp[1], g2 = wp[2];
-        double u;
-        if (half == 0) u = pos ? 0.5 * (g0 - g1 + g2) : 0.5 * (g0 + g1 + g2);
-        else u = pos ? g2 : g0;
-        d[idx] = (float)u;
+// k_pack_wino over the layers of a pointer table (the weights change every optimiser step: packed per forward call).  One workgroup per
+// (layer, wave w, row block rb): its 16 weight rows are 48 KiB contiguous in the source - read as float4 into LDS (row stride 772 floats: the 16
+// rows of a fragment column land in different banks), written as the 64 fragment rows (1 KiB each) of the steps that row block takes part in.
+// The arithmetic is k_pack_wino's (fp64 sums, one rounding): the same bits.
+constexpr int kPackWinoLD = 772;
+__global__ __launch_bounds__(256) void k_pack_wino_multi(const TrPtrs src, float* __restrict__ dst) {
+    __shared__ __attribute__((aligned(16))) float wt[16 * kPackWinoLD];
+    const int tid = threadIdx.x, w = blockIdx.x >> 3, rb = blockIdx.x & 7, hb = rb >> 2, r4 = rb & 3;
+    const int row0 = (rb < 4) ? 64 * w + 16 * rb : kC + 64 * w + 16 * (rb - 4);
+    const float4* s4 = reinterpret_cast<const float4*>(src.p[blockIdx.y] + (size_t)row0 * kC * 3);
+    for (int i = tid; i < 16 * 192; i += 256) {
+        const int r = i / 192, c4 = i - r * 192;
+        *reinterpret_cast<float4*>(wt + r * kPackWinoLD + 4 * c4) = s4[i];
+    }
+    __syncthreads();
+    float4* d = reinterpret_cast<float4*>(dst + (size_t)blockIdx.y * ((size_t)kWnSteps * 4 * 4 * 64 * 4));
+    const int lane = tid & 63, nn = lane & 15, g = lane >> 4;
+    for (int combo = tid >> 6; combo < 64; combo += 4) {            // combo = (half * 16 + c) * 2 + pos
+        const int pos = combo & 1, c = (combo >> 1) & 15, half = combo >> 5;
+        const float* wp = wt + nn * kPackWinoLD + (64 * g + 4 * c) * 3;
+        const float4 a = *reinterpret_cast<const float4*>(wp), b = *reinterpret_cast<const float4*>(wp + 4), cc = *reinterpret_cast<const float4*>(wp + 8);
+        const float t[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, cc.x, cc.y, cc.z, cc.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double g0 = t[3 * e], g1 = t[3 * e + 1], g2 = t[3 * e + 2];
+            double u;
+            if (half == 0) u = pos ? 0.5 * (g0 - g1 + g2) : 0.5 * (g0 + g1 + g2);
+            else u = pos ? g2 : g0;
+            o[e] = (float)u;
+        }
+        const int st = combo * 2 + hb;
+        d[(((size_t)st * 4 + w) * 4 + r4) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
