@@ -287,11 +287,22 @@ extern "C" int dsf_denorm_spec(const float* x, const float* mask, float* mel, co
 }
 
 // ---- training operators ---------------------------------------------------------------------
-static const int kWgSplits = 16;
+// Frame splits of a weight-gradient launch: 16, or - for the small 1 x 1 outputs (the denoiser's input / skip / output projections: <= 8 output
+// tiles, 128 workgroups of a kernel that runs two per CU; their partials are a few MiB) - as many as put two workgroups on every CU of a 256-CU
+// part, at most 64.  A function of the shape alone: the workspace query and the launch agree, and the summation order (hence every bit) does
+// not depend on the device.
+static int fs_wg_splits(int Co, int Ci, int KT) {
+    int ns = 16;
+    if (KT != 1) return ns;
+    const int tiles = ((Co + 127) / 128) * ((Ci + 63) / 64);
+    while (ns < 64 && tiles * ns < 512) ns *= 2;
+    return ns;
+}
 
 extern "C" int64_t dsf_wgrad_workspace_floats(int32_t Co, int32_t Ci, int32_t KT) {
     if (Co < 1 || Ci < 1 || KT < 1 || !(KT & 1) || KT > 2 * kFsHalo + 1) return -1;
-    return (int64_t)kWgSplits * Co * Ci * std::min(KT, 3) + (int64_t)kWgSplits * Co;
+    const int ns = fs_wg_splits(Co, Ci, KT);
+    return (int64_t)ns * Co * Ci * std::min(KT, 3) + (int64_t)ns * Co;
 }
 
 // Kernels wider than 3 taps (FastSpeech2: the k = 9 conv-FFN, the k = 5 pitch predictor) run as groups of three taps: the kernel computes the taps
@@ -305,6 +316,7 @@ extern "C" int dsf_conv1d_wgrad(const float* dy, const float* x, float* dw, floa
                     dil, kFsHalo);
     const int pad = dil * (KT - 1) / 2;
     const int gk = std::min(KT, 3);
+    const int kWgSplits = fs_wg_splits(Co, Ci, KT);
     float* part_b = workspace + (size_t)kWgSplits * Co * Ci * gk;
     const dim3 grid((unsigned)((Co + 127) / 128), (unsigned)((Ci + 63) / 64), (unsigned)kWgSplits);
     for (int tap0 = 0; tap0 < KT; tap0 += 3) {

@@ -584,6 +584,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_wgrad(const FsWgradParams p)
 __global__ void k_fs_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, size_t n, int nsplit, int accumulate) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s = accumulate ? dw[i] : 0.f;
+        // (the loads of eight splits in flight, the additions in split order: the bits do not depend on the unrolling)
+#pragma unroll 8
         for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
         dw[i] = s;
     }
@@ -598,6 +600,7 @@ __global__ void k_fs_wgrad_reduce_taps(const float* __restrict__ part, float* __
         const int k = (int)(i - row * ntap);
         float* d = dw + row * KT + tap0 + k;
         float s = accumulate ? *d : 0.f;
+#pragma unroll 8
         for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)sp * nrow + row) * gk + k];
         *d = s;
     }

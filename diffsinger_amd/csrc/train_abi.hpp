@@ -303,8 +303,7 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
     // weights -> fragment order, all layers per launch (they change every optimiser step)
     if (wino) {
         hipLaunchKernelGGL(k_pack_wino_multi, dim3(32, (unsigned)L), dim3(256), 0, s, tr_ptrs(w->dilated_conv_w, L), ws + lay.w1w);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemsetAsync(ws + lay.w1w + (size_t)L * kWnSteps * (kWnStepBytes / 4), 0, kTrSlack * sizeof(float), s));
+        HIP_TRY(hipGetLastError());           // (the slack behind the stream is only ever PREFETCHED past the last step, never multiplied: it needs no value)
     } else {
         DSD_TRY(tr_pack_multi(s, w->dilated_conv_w, L, ws + lay.w1p, kTrW3, 4, 3, 32, 4, 1, kC, 2 * kC, kC, 3 * kC, 3, 0));
     }
@@ -387,9 +386,8 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         if (!wino) DSD_TRY(tr_pack_multi(s, halves, 2 * L, bws + bl.wdtp, kTrW3 / 2, 2, 3, 32, 4, 0, 0, kC, kC, 3, 3 * kC, 1));
     }
     if (wino) {
-        hipLaunchKernelGGL(k_pack_wino_bwd_multi, dim3(256, (unsigned)L), dim3(256), 0, s, tr_ptrs(w->dilated_conv_w, L), bws + bl.wdw);
+        hipLaunchKernelGGL(k_pack_wino_bwd_multi, dim3(32, (unsigned)L), dim3(256), 0, s, tr_ptrs(w->dilated_conv_w, L), bws + bl.wdw);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemsetAsync(bws + bl.wdw + (size_t)L * kWnSteps * (kWnStepBytes / 4), 0, kTrSlack * sizeof(float), s));
     }
     float* dxp[2] = {bws + bl.dxp0, bws + bl.dxp1};           // dxp[k & 1]: gradient wrt the output x of layer k
     const long long da_bs = da_all ? (long long)L * 2 * kC * TS : (long long)2 * kC * TS;

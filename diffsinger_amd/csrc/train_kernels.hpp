@@ -14,6 +14,7 @@
 // Activations of the backward pass are channel-major [B][rows][TS] (frames contiguous, zero in [T, TS)) like the operator path of
 // train.py; accumulator fragments are written to it directly (a wave store instruction covers two 128-byte row segments).
 #pragma once
+#include <type_traits>
 #include "fs2_kernels.hpp"
 
 namespace dsd {
@@ -643,6 +644,62 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
     int a_valid = 0, b_shift = 0;
     const float a_scale = d.a_scale;
     const int shift = d.shift, b_rs = d.b_rs;
+    // The fused stack's form (!FIX) keeps the step free of vector-ALU work: beside an fp32 MFMA every vector instruction costs ~8 cycles of matrix
+    // time (tools/mfma_filler_probe.hip; the round-4 step carried 94 of them per 128 MFMAs).  Addresses: one buffer descriptor per operand whose
+    // base walks with the tile (scalar), the thread's offset is loop-invariant, the row groups are scalar offsets.  The scale of A multiplies the
+    // accumulators once at the end; frames >= T are masked only in an utterance's partial tile (a scalar branch).
+    const unsigned a_vo = (unsigned)(srow * p.TS + 4 * sg) * 4u, b_vo = (unsigned)(srow * b_rs + 4 * sg) * 4u;
+    int mask_t0 = 0;
+    int f_tile = tile_lo, f_b = tile_lo / tiles_per_utt, f_tn = tile_lo - f_b * tiles_per_utt;      // the next tile to fetch (scalar counters: no division in the step)
+    auto fetch_s = [&]() {
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const int b = __builtin_amdgcn_readfirstlane(f_b), t0 = __builtin_amdgcn_readfirstlane(f_tn * 32);
+        {                                                   // behind the last tile the staging registers repeat it (selects, no branch: the step stays ONE block)
+            const int adv = (f_tile + 1 < tile_hi) ? 1 : 0;
+            f_tile += adv;
+            const int tn1 = f_tn + adv, wrap = (tn1 == tiles_per_utt) ? 1 : 0;
+            f_tn = wrap ? 0 : tn1;
+            f_b += wrap;
+        }
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.a + (size_t)b * d.a_bstride + t0), 0, 0x7ffffff0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bsrc + (size_t)b * d.b_bstride + (t0 + shift)), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4_ f = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)a_vo, q * (32 * 4) * p.TS, 0));
+            av[q] = make_float4(f.x, f.y, f.z, f.w);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4_ f = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)b_vo, q * (32 * 4) * b_rs, 0));
+            bv[q] = make_float4(f.x, f.y, f.z, f.w);
+        }
+        mask_t0 = t0;
+    };
+    const bool has_bias = d.out_bias != nullptr;
+    // (a scalar branch at the TOP of a step: the utterance's partial tile, or a tile of padding - frames >= T carry no gradient)
+    auto mask_s = [&](int t0) {
+        if (t0 + 32 > p.T) {
+            const int valid = p.T - (t0 + 4 * sg);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = av[q];
+                v.x = (valid > 0) ? v.x : 0.f; v.y = (valid > 1) ? v.y : 0.f; v.z = (valid > 2) ? v.z : 0.f; v.w = (valid > 3) ? v.w : 0.f;
+                av[q] = v;
+            }
+        }
+    };
+    auto stash_s = [&](int buf, float live, bool bias) {
+        float* As = smem + buf * kTrWgStage;
+        float* Bs = As + 128 * LD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(As + (srow + 32 * q) * LD + 4 * sg) = av[q];
+        if (bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bsum[q] += live * ((av[q].x + av[q].y) + (av[q].z + av[q].w));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(Bs + (srow + 32 * q) * LD + 4 * sg) = bv[q];
+    };
     auto fetch = [&](int tile) {
         const int b = tile / tiles_per_utt, t0 = (tile - b * tiles_per_utt) * 32;
         const int t = t0 + 4 * sg;
@@ -714,20 +771,35 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma32(f4at(fa[set][mb], s), f4at(fb[set][nb], s), acc[mb][nb]);
     };
-    if (nstep > 0) {
-        fetch(tile_lo);
-        stash(0, 1.f);
-        fetch(min(tile_lo + 1, tile_hi - 1));
+    // the step loop; BIAS (a compile-time constant of the instance that runs: the row sums are only kept for tiles with a bias gradient)
+    auto loop = [&](auto bias_c) {
+        constexpr bool BIAS = decltype(bias_c)::value;
+        if constexpr (FIX) {
+            fetch(tile_lo);
+            stash(0, 1.f);
+            fetch(min(tile_lo + 1, tile_hi - 1));
+        } else {
+            fetch_s();
+            mask_s(mask_t0);
+            stash_s(0, 1.f, BIAS);
+            fetch_s();
+        }
         __syncthreads();
         frags(0, 0, 0);
         for (int k = 0; k < nstep; ++k) {
             const int cur = k & 1;
             const float live = (k + 1 < nstep) ? 1.f : 0.f;
+            if constexpr (!FIX) mask_s(mask_t0);
             frags(1, cur, 1);
-            stash(cur ^ 1, live);
-            fetch(min(tile_lo + k + 2, tile_hi - 1));
+            if constexpr (FIX) {
+                stash(cur ^ 1, live);
+                fetch(min(tile_lo + k + 2, tile_hi - 1));
+            } else {
+                stash_s(cur ^ 1, live, BIAS);
+                fetch_s();
+            }
             mma(0);
-            if (!FIX) tr_interleave<4, true, true, true>(0);
+            if (!FIX) tr_interleave<BIAS ? 1 : 0, true, true, true>(0);
             DSD_SB();
             frags(0, cur, 2);
             mma(1);
@@ -744,6 +816,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
             tr_interleave<0, false, false, true>(0);
             DSD_SB();
         }
+    };
+    if (nstep > 0) {
+        if (FIX || has_bias) loop(std::true_type{});
+        else loop(std::false_type{});
     }
     float* out = p.part + ((size_t)desc * p.nsplit + split) * (128 * 256);       // wave-uniform; write-through: the reduction kernel reads it next
 #pragma unroll
@@ -751,11 +827,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) store4_wt(out, (64 * wm + 32 * mb + frag_row(r, h)) * 256 + 128 * wn + 32 * nb + i, acc[mb][nb][r]);
+            for (int r = 0; r < 16; ++r) store4_wt(out, (64 * wm + 32 * mb + frag_row(r, h)) * 256 + 128 * wn + 32 * nb + i, FIX ? acc[mb][nb][r] : acc[mb][nb][r] * a_scale);
     if (d.out_bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float sb = bsum[q];
+            float sb = FIX ? bsum[q] : bsum[q] * a_scale;
             sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64); sb += __shfl_xor(sb, 4, 64);
             if (sg == 0) p.part_b[((size_t)desc * p.nsplit + split) * 128 + srow + 32 * q] = sb;
         }

@@ -25,21 +25,35 @@ namespace dsd {
 // Transformed, transposed, flipped conv weights in consumption order: dst[l][step 128][w4][r4][lane64][s4], step = ((half * 16 + c) * 2 + pos) * 2 + hb;
 // wave w = (wr = w & 1, wk = w >> 1); row block rb = 4 hb + r4: input channel ci = 128 wr + 16 rb + n, n = lane & 15; da row co = 256 wk + 16 c + 4 s + g,
 // g = lane >> 4.  half 0: U1, U2 (the halo-free products); half 1: U0 = g'0 = W[co][ci][2], U3 = g'2 = W[co][ci][0].  src = dilated_conv.weight [2C][C][3].
-__global__ void k_pack_wino_bwd_multi(const TrPtrs src, float* __restrict__ dst) {
-    const size_t n = (size_t)kWnSteps * 4 * 4 * 64 * 4;
-    const float* sp = src.p[blockIdx.y];
-    float* d = dst + (size_t)blockIdx.y * n;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx & 3, lane = (idx >> 2) & 63, r4 = (idx >> 8) & 3, w = (idx >> 10) & 3, st = (int)(idx >> 12);
-        const int hb = st & 1, pos = (st >> 1) & 1, c = (st >> 2) & 15, half = st >> 6;
-        const int nn = lane & 15, g = lane >> 4, rb = 4 * hb + r4, wr = w & 1, wk = w >> 1;
-        const int ci = 128 * wr + 16 * rb + nn, co = 256 * wk + 16 * c + 4 * e + g;
-        const float* wp = sp + ((size_t)co * kC + ci) * 3;
-        const double g0 = wp[2], g1 = wp[1], g2 = wp[0];
-        double u;
-        if (half == 0) u = pos ? 0.5 * (g0 - g1 + g2) : 0.5 * (g0 + g1 + g2);
-        else u = pos ? g2 : g0;
-        d[idx] = (float)u;
+// One workgroup per (layer, wave w, row block rb): its operands are the 16 input channels ci of the row block against the 256 da rows of the
+// wave's K half - 48 contiguous floats of each of 256 source rows, staged in LDS as [co 256][52] and written as the 64 fragment rows (1 KiB
+// each) of the steps the row block takes part in.  fp64 sums, one rounding.
+__global__ __launch_bounds__(256) void k_pack_wino_bwd_multi(const TrPtrs src, float* __restrict__ dst) {
+    constexpr int LDP = 52;
+    __shared__ __attribute__((aligned(16))) float wt[256 * LDP];
+    const int tid = threadIdx.x, w = blockIdx.x >> 3, rb = blockIdx.x & 7, hb = rb >> 2, r4 = rb & 3, wr = w & 1, wk = w >> 1;
+    const float* sp = src.p[blockIdx.y] + ((size_t)(256 * wk) * kC + 128 * wr + 16 * rb) * 3;
+    for (int i = tid; i < 256 * 12; i += 256) {
+        const int co = i / 12, c4 = i - co * 12;
+        *reinterpret_cast<float4*>(wt + co * LDP + 4 * c4) = *reinterpret_cast<const float4*>(sp + (size_t)co * kC * 3 + 4 * c4);
+    }
+    __syncthreads();
+    float4* d = reinterpret_cast<float4*>(dst + (size_t)blockIdx.y * ((size_t)kWnSteps * 4 * 4 * 64 * 4));
+    const int lane = tid & 63, nn = lane & 15, g = lane >> 4;
+    for (int combo = tid >> 6; combo < 64; combo += 4) {            // combo = (half * 16 + c) * 2 + pos
+        const int pos = combo & 1, c = (combo >> 1) & 15, half = combo >> 5;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* wp = wt + (16 * c + 4 * e + g) * LDP + 3 * nn;
+            const double g0 = wp[2], g1 = wp[1], g2 = wp[0];         // the taps flipped
+            double u;
+            if (half == 0) u = pos ? 0.5 * (g0 - g1 + g2) : 0.5 * (g0 + g1 + g2);
+            else u = pos ? g2 : g0;
+            o[e] = (float)u;
+        }
+        const int st = combo * 2 + hb;
+        d[(((size_t)st * 4 + w) * 4 + r4) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 

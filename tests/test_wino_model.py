@@ -280,3 +280,116 @@ def test_latency_winograd_conv_index_algebra(G, e):
     got = run_lat_model(G, e, wt.numpy(), y.numpy(), cpfull.numpy())
     err = np.abs(got - want.double().numpy()).max()
     assert err < 2e-5, err
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------------
+# the training kernels (csrc/train_loop_wino.hpp, train_wino_bwd.hpp): where the forward's accumulators land in the saved pre-activation (the
+# 32x32 fragment order the backward reads), and the transposed convolution of the backward: its weight stream, the channel-major da tile, the
+# wave roles (row half wr, K half wk), the exchange and the dy2 tile
+# ----------------------------------------------------------------------------------------------------------------------------------------
+def test_training_forward_saves_the_pre_activation_in_the_backward_fragment_order():
+    """k_tr_stack_fwd_w::save_a_and_gate: lane (p, g), accumulator (hf, rb) -> float4 index of a_frag [w][mb4][q4][h2][j32]; k_trb_fused reads
+    element (mb, q, lane = (j, h), e) as row (gate mb < 2 / filter) 32 (mb & 1) + 8 q + 4 h + e of the wave's 64, frame j."""
+    for e in range(4):
+        d = 1 << e
+        seen = set()
+        for lane in range(64):
+            pp, gg = lane & 15, lane >> 4
+            tE = frame_of_pair(pp, e)
+            for hf in range(2):
+                for rb in range(8):
+                    idx = (((rb >> 2) * 2 + ((rb & 3) >> 1)) * 4 + 2 * (rb & 1) + (gg >> 1)) * 64 + (gg & 1) * 32 + tE + hf * d
+                    mb, q, h, j = idx >> 8, (idx >> 6) & 3, (idx >> 5) & 1, idx & 31
+                    # what the Winograd accumulator holds: rows 16 (rb & 3) + 4 g + {0..3} of the gate (rb < 4) / filter rows, frame tE + hf d
+                    assert (mb >> 1) == (rb >> 2) and 32 * (mb & 1) + 8 * q + 4 * h == 16 * (rb & 3) + 4 * gg and j == tE + hf * d
+                    seen.add(idx)
+        assert seen == set(range(1024))                  # every float4 of the wave's 16 KiB written exactly once
+
+
+def pack_wino_bwd(wt):
+    """k_pack_wino_bwd_multi for one layer: wt [2C co][C ci][3] -> stream [step 128][w 4][r4 4][lane 64][s 4]"""
+    out = np.zeros((STEPS, 4, 4, 64, 4), np.float32)
+    w64 = wt.astype(np.float64)
+    for st in range(STEPS):
+        hb, pos, c, half = st & 1, (st >> 1) & 1, (st >> 2) & 15, st >> 6
+        for w in range(4):
+            wr, wk = w & 1, w >> 1
+            for r4 in range(4):
+                rb = 4 * hb + r4
+                for lane in range(64):
+                    nn, g = lane & 15, lane >> 4
+                    ci = 128 * wr + 16 * rb + nn
+                    co = 256 * wk + 16 * c + 4 * np.arange(4) + g
+                    g0, g1, g2 = w64[co, ci, 2], w64[co, ci, 1], w64[co, ci, 0]
+                    if half == 0:
+                        u = 0.5 * (g0 - g1 + g2) if pos else 0.5 * (g0 + g1 + g2)
+                    else:
+                        u = g2 if pos else g0
+                    out[st, w, r4, lane] = u.astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize('e', [0, 1, 2, 3])
+def test_training_backward_index_algebra_matches_the_conv_adjoint(e):
+    """k_trb_fused_w's convolution part lane by lane: dy[ci][t] = sum_co sum_tap W[co][ci][tap] da[co][t - (tap - 1) d] (the adjoint of net.py:71)
+    from the da tile [512][48] (frames -8 .. 39), through WinoPipe<S, LD = 48>'s reads, the K halves' exchange and the dy2 tile."""
+    d = 1 << e
+    LD = 48
+    g = torch.Generator().manual_seed(200 + e)
+    wt = torch.randn(2 * C, C, 3, generator=g) * 0.05
+    da = torch.randn(2 * C, LD, generator=g)
+    y = torch.zeros(1, C, 48, dtype=torch.float64, requires_grad=True)
+    # autograd of the forward conv over frames -8 .. 39 (zero padding outside does not matter for the 32 inner frames: the taps reach 8 at most)
+    out = torch.nn.functional.conv1d(y, wt.double(), padding=d, dilation=d)
+    out.backward(da.double()[None])
+    want = y.grad[0, :, 8:40].numpy()
+    stream = pack_wino_bwd(wt.numpy())
+    tile = da.numpy()
+    lanes = np.arange(64)
+    pp, gg = lanes & 15, lanes >> 4
+    tE = np.array([frame_of_pair(p, e) for p in pp])
+    dy2 = np.full((C, 32), np.nan)
+    fin = {}
+    for w in range(4):
+        wr, wk = w & 1, w >> 1
+        acc = np.zeros((2, 8, 64, 4))
+        rows_g = wk * C + gg                              # row g of the wave's K half
+        for st in range(STEPS):
+            hb, pos, c, half = st & 1, (st >> 1) & 1, (st >> 2) & 15, st >> 6
+            if st == 64:
+                m1, m2 = acc[0].copy(), acc[1].copy()
+                acc[0], acc[1] = m1 + m2, m1 - m2
+            for s in range(4):
+                r = rows_g + 16 * c + 4 * s
+                col = 8 + tE                              # the tile's frame 0 is column kHalo
+                if half == 0:
+                    r0, r1 = tile[r, col], tile[r, col + d]
+                    v = (r0 + r1) if pos == 0 else (r1 - r0)
+                else:
+                    v = (tile[r, col - d] - tile[r, col + d]) if pos == 0 else (tile[r, col + 2 * d] - tile[r, col])
+                for r4 in range(4):
+                    mfma16(stream[st, w, r4, :, s], v.astype(np.float32), acc[pos][4 * hb + r4])
+        fin[(wr, wk)] = acc
+    for wr in range(2):
+        for wk in range(2):                              # wave (wr, wk) finishes row blocks 4 wk .. 4 wk + 3: (K half 0) + (K half 1)
+            for hf in range(2):
+                for r4 in range(4):
+                    v = fin[(wr, 0)][hf][4 * wk + r4] + fin[(wr, 1)][hf][4 * wk + r4]
+                    for ee in range(4):
+                        rows = 128 * wr + 64 * wk + 16 * r4 + 4 * gg + ee
+                        assert np.isnan(dy2[rows, tE + hf * d]).all()
+                        dy2[rows, tE + hf * d] = v[:, ee]
+    assert not np.isnan(dy2).any()
+    err = np.abs(dy2 - want).max()
+    assert err < 2e-5, err
+
+
+def test_training_backward_reads_stay_inside_the_da_tile():
+    """the channel-major reads of WinoPipe<S, 48>: frames tE - d .. tE + 2 d of a 32-frame tile with 8 halo columns on both sides, rows of the wave's
+    K half; the chunk the pipe requests BEHIND the last one (it runs one chunk ahead) lies inside the workgroup's LDS"""
+    for e in range(4):
+        d = 1 << e
+        for p in range(16):
+            tE = frame_of_pair(p, e)
+            assert 8 + tE - d >= 0 and 8 + tE + 2 * d < 48
+    assert (2 * C + 16) * 48 * 4 <= (2 * C * 48 + 4 * 32 * 64) * 4      # chunk 16 of K half 1 = rows 512 .. 527: the exchange buffer behind the tile
