@@ -540,7 +540,7 @@ def main_train(args):
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': f'SURVEY 8 row f3: GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:213-231) of the DiffSpeech denoiser, '
                                       f'batch={B} x T={T} per GPU, forward + backward on the ' + ('fused residual-stack kernels (csrc/train_kernels.hpp)' if fused else 'HIP training operators'), 'preset': PRESET,
-                          'conv': (train_fused.stack_conv() + ' (persistent forward; the backward is the direct form)') if fused else 'direct',
+                          'conv': (train_fused.stack_conv() + ' (the persistent forward AND the transposed convolution of the backward)') if fused else 'direct',
                           'optimizer': 'not included (diffsinger_amd/train_dist.py)', 'sharding': 'replicas (no gradient exchange in this bench)'},
                'roofline': roof, 'model_tflops_gemm': world * B * T * 3 * F_TRAIN_FWD * args.steps / el / 1e12}
         if world == 1 and not args.no_cpu_baseline:

@@ -238,8 +238,20 @@ def step_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     return torch.cat((e.sin(), e.cos()), dim=-1)
 
 
-def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
-    """DiffNet.forward (usr/diff/net.py:107-130) under autograd.  spec [B,1,M,T], diffusion_step [B], cond [B,H,T] -> [B,1,M,T]."""
+def _step_embedding_rows(net, t: torch.Tensor, n_steps: int) -> torch.Tensor:
+    """step_embedding(t) as rows of a table over t = 0 .. n_steps - 1, made once per (device, size) by the same element-wise arithmetic (the
+    same bits): six tiny launches per step become one gather.  Only when the caller knows the schedule length (p_losses does)."""
+    tabs = net.__dict__.setdefault('_train_step_tables', {})
+    key = (str(t.device), int(n_steps))
+    tab = tabs.get(key)
+    if tab is None:
+        tab = tabs[key] = step_embedding(torch.arange(int(n_steps), device=t.device, dtype=t.dtype), net.residual_channels)
+    return tab.index_select(0, t.long())
+
+
+def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor, cond: torch.Tensor, n_steps: Optional[int] = None) -> torch.Tensor:
+    """DiffNet.forward (usr/diff/net.py:107-130) under autograd.  spec [B,1,M,T], diffusion_step [B], cond [B,H,T] -> [B,1,M,T].
+    n_steps: the schedule length when the caller knows it (every diffusion_step < n_steps): the step embedding then comes from a table."""
     if spec.device.type != 'cuda':
         raise RuntimeError('the HIP training path has no CPU path')
     B, _, M, T = spec.shape
@@ -253,15 +265,18 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
         return c(x, mod.weight, mod.bias, T, dil)
 
     pad = (0, TS - T)
-    xm = F.pad(spec[:, 0], pad)                                     # [B][M][TS], zero tail
-    cm = F.pad(cond, pad).contiguous()                              # [B][H][TS]
+    if TS == T:                                                     # (F.pad with nothing to pad still copies)
+        xm, cm = spec[:, 0].contiguous(), cond.contiguous()
+    else:
+        xm = F.pad(spec[:, 0], pad)                                 # [B][M][TS], zero tail
+        cm = F.pad(cond, pad).contiguous()                          # [B][H][TS]
     x = F.relu(conv('in', xm, net.input_projection))                # :116-118 (every conv output has the zero tail; relu keeps it)
     # the step-embedding MLP and the layers' step projections (net.py:94-98, :119-120, :67): [B, C] x [C, C'] products on B rows through
     # dsf_linear_rows (own vector-ALU kernels; round 2 left them on rocBLAS, a first attempt through the convolution operators cost +0.37 ms
     # per step in layout changes and re-packs and was reverted)
-    d = step_embedding(diffusion_step, net.residual_channels)       # :119
+    d = step_embedding(diffusion_step, net.residual_channels) if n_steps is None else _step_embedding_rows(net, diffusion_step, n_steps)   # :119
     h = linear_rows(d, net.mlp[0].weight, net.mlp[0].bias)
-    d = linear_rows(h * torch.tanh(F.softplus(h)), net.mlp[2].weight, net.mlp[2].bias)   # :120 (Mish)
+    d = linear_rows(F.mish(h), net.mlp[2].weight, net.mlp[2].bias)  # :120 (Mish = x tanh(softplus(x)): ATen's fused forward / backward kernels)
     from . import train_fused
     if train_fused.enabled() and train_fused.supported(net):
         # the whole residual stack as ONE autograd node on the fused kernels (csrc/train_kernels.hpp); the step projections of all layers
@@ -300,7 +315,7 @@ def p_losses(gd, x_start: torch.Tensor, t: torch.Tensor, cond: torch.Tensor, noi
         gd.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(shape) * noise                    # q_sample :206-211
     # the denoiser the registry returned (usr/diffsinger_task.py:23-27): DiffNet on the fused training stack, the FFT candidate on the
     # FastSpeech2 operators under autograd
-    x_recon = diffnet_forward_train(gd.denoise_fn, x_noisy, t, cond) if fused else gd.denoise_fn.forward_train(x_noisy, t, cond)
+    x_recon = diffnet_forward_train(gd.denoise_fn, x_noisy, t, cond, n_steps=gd.num_timesteps) if fused else gd.denoise_fn.forward_train(x_noisy, t, cond)
     if gd.loss_type == 'l1':
         if nonpadding is not None:
             return ((noise - x_recon).abs() * nonpadding.unsqueeze(1)).mean()
