@@ -44,7 +44,8 @@ def test_no_cpu_path_and_loud_failure_without_fastspeech2():
 
 
 def test_p_losses_says_so_for_an_inference_only_denoiser():
-    """the registered 'fft' candidate decoder has no training path - a clear NotImplementedError, not an AttributeError."""
+    """a denoiser without a training forward (neither DiffNet's fused stack nor a `forward_train` like the FFT candidate's, round 5)
+    gets a clear NotImplementedError from p_losses, not an AttributeError."""
     import diffsinger_amd
     from diffsinger_amd import hparams
     from diffsinger_amd.synth import presets
@@ -53,5 +54,5 @@ def test_p_losses_says_so_for_an_inference_only_denoiser():
     diffsinger_amd.use_preset('lj_ds_beta6')
     gd = diffsinger_amd.GaussianDiffusion(None, 80, torch.nn.Identity(), timesteps=10, K_step=10, loss_type='l1', spec_min=pre['spec_min'],
                                           spec_max=pre['spec_max'])
-    with pytest.raises(NotImplementedError, match='inference-only'):
+    with pytest.raises(NotImplementedError, match='no training forward'):
         gd.p_losses(torch.zeros(1, 1, 80, 8), torch.zeros(1, dtype=torch.long), torch.zeros(1, 256, 8))
