@@ -521,7 +521,7 @@ def main_train(args):
                     'note': 'every weight gradient of two residual layers per launch (dilated conv 3 taps, conditioner projection, output projection: '
                             '2 x 20 output tiles of 128 x 256, contracted over the frames in 6 splits = 240 workgroups); average over the launches of '
                             '3 steps, events on the launch stream around each launch (they include the gap to the previous kernel); the split-K '
-                            'reduction kernel behind it is not part of the figure.  Kernel times of the whole step: profiles/r03u_train_kernel_stats_8x1024.txt'}
+                            'reduction kernel behind it is not part of the figure.  Kernel times of the whole step: profiles/train_kernel_stats.txt'}
         else:
             roof = {'bound': 'mfma', 'kernel': 'k_fs_conv<2> (operator path)', 'achieved': None, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
                     'traffic': None, 'note': 'the fused stack is switched off (DSD_TRAIN_FUSED=0) or does not cover this DiffNet'}

@@ -11,7 +11,7 @@ mkdir -p $O
 cd $R
 git_rev=$(cat .git_rev 2>/dev/null || echo unknown)
 if [ "$2" != "nopytest" ]; then
-( time timeout 1500 python -m pytest tests -m gpu -q -rf > $O/pytest_gpu_full.txt 2>&1 ) 2> $O/pytest_gpu_time.txt; tail -40 $O/pytest_gpu_full.txt > $O/pytest_gpu.txt; cat $O/pytest_gpu_time.txt >> $O/pytest_gpu.txt
+( time timeout 1500 python -m pytest tests -m gpu -q -rf --durations=30 > $O/pytest_gpu_full.txt 2>&1 ) 2> $O/pytest_gpu_time.txt; tail -80 $O/pytest_gpu_full.txt > $O/pytest_gpu.txt; cat $O/pytest_gpu_time.txt >> $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 fi
 timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.err
@@ -36,6 +36,18 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_G
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc/write -o write -- python $R/tools/profile_loop.py 3 > $O/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $O/pmc/sq -o sq -- python $R/tools/profile_loop.py 3 > $O/pmc_sq.log 2>&1
 python $R/tools/pmc_summary.py $O/pmc 'k_loop_wino' $O/loop_pmc.txt $O/loop_pmc.json frames=8192 'kernel_tag=k_loop_wino<1, 4>' round=$TAG commit=$git_rev > $O/pmc_summary.log 2>&1
+# training row: the step with the Winograd / direct convolution kernels on three shapes, kernel times of the step, PMC passes over the step
+# (k_tr_wgrad<false> -> train_wgrad_pmc.json for bench.py --row train; the Winograd forward and data-gradient kernels beside it)
+timeout 300 python $R/tools/bench_train.py 10 --conv-ab 2>/dev/null | grep "^{" > $O/train_conv_ab.jsonl
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_tr -o tr -- python $R/tools/bench_train.py 8 --hip-only 8x1024 > $O/prof_tr.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $O/prof_tr/*.db $O/prof_tr/*/*.db 2>/dev/null | head -1) > $O/train_kernel_stats.txt 2>> $O/prof_tr.log
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/pmc_tr/fetch -o fetch -- python $R/tools/bench_train.py 3 --hip-only 8x1024 > $O/pmc_tr_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU -d $O/pmc_tr/write -o write -- python $R/tools/bench_train.py 3 --hip-only 8x1024 > $O/pmc_tr_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $O/pmc_tr/sq -o sq -- python $R/tools/bench_train.py 3 --hip-only 8x1024 > $O/pmc_tr_sq.log 2>&1
+python $R/tools/pmc_summary.py $O/pmc_tr 'k_tr_wgrad<false>' $O/train_wgrad_pmc.txt $O/train_wgrad_pmc.json 'kernel_tag=k_tr_wgrad<false>' shape=8x1024 round=$TAG commit=$git_rev >> $O/pmc_summary.log 2>&1
+python $R/tools/pmc_summary.py $O/pmc_tr 'k_trb_fused_w<false, true>' $O/train_trb_fused_w_pmc.txt $O/train_trb_fused_w_pmc.json 'kernel_tag=k_trb_fused_w<false, true>' shape=8x1024 round=$TAG commit=$git_rev >> $O/pmc_summary.log 2>&1
+python $R/tools/pmc_summary.py $O/pmc_tr 'k_tr_stack_fwd_w' $O/train_stack_fwd_w_pmc.txt $O/train_stack_fwd_w_pmc.json 'kernel_tag=k_tr_stack_fwd_w' shape=8x1024 round=$TAG commit=$git_rev >> $O/pmc_summary.log 2>&1
+rm -rf $O/prof_tr; find $O/pmc_tr -name '*.db' -delete
 if [ "$3" != "core" ]; then
 # vocoder row: kernel stats + FETCH / WRITE / SQ passes over the fused resblock-stage kernels (bench.py --row vocoder reads voc_chain_32ch_pmc.json)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_voc -o voc -- python $R/bench.py --row vocoder --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_voc.log 2>&1
