@@ -21,13 +21,9 @@ timeout 200 python tools/loop_timeline.py $O/loop_timeline.json > $O/loop_timeli
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/hbm_probe tools/hbm_probe.hip && timeout 120 /tmp/hbm_probe > $O/hbm_probe.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_filler_probe tools/mfma_filler_probe.hip && timeout 180 /tmp/mfma_filler_probe > $O/mfma_filler_probe.jsonl 2>&1
 timeout 200 python tools/wino_ab.py --shapes 2>/dev/null | grep "^{" > $O/wino_ab.jsonl
-timeout 600 python tools/shape_sweep.py 3 1x512,1x1000,1x1550,4x777,2x2048,3x1550,1x5000,1x8000,6x1024,8x1024,3x5000,16x2048 --lat-splits > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
 for row in vocoder fs2 train; do
 timeout 300 python bench.py --row $row --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_row_$row.json 2> $O/bench_row_$row.err
 done
-timeout 400 python tools/bench_configs.py 3 > $O/configs_throughput.jsonl 2> $O/configs_throughput.err
-timeout 200 python tools/bench_single.py 10 100 8 > $O/single_utterance.jsonl 2> $O/single_utterance.err
-timeout 200 python tools/bench_single.py 10 60 8 >> $O/single_utterance.jsonl 2>> $O/single_utterance.err
 [ "$3" != "core" ] && timeout 200 python tools/bench_pwg.py 5 > $O/bench_pwg.jsonl 2> $O/bench_pwg.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cfg5-shard > $O/prof.log 2>&1
@@ -48,6 +44,15 @@ python $R/tools/pmc_summary.py $O/pmc_tr 'k_tr_wgrad<false>' $O/train_wgrad_pmc.
 python $R/tools/pmc_summary.py $O/pmc_tr 'k_trb_fused_w<false, true>' $O/train_trb_fused_w_pmc.txt $O/train_trb_fused_w_pmc.json 'kernel_tag=k_trb_fused_w<false, true>' shape=8x1024 round=$TAG commit=$git_rev >> $O/pmc_summary.log 2>&1
 python $R/tools/pmc_summary.py $O/pmc_tr 'k_tr_stack_fwd_w' $O/train_stack_fwd_w_pmc.txt $O/train_stack_fwd_w_pmc.json 'kernel_tag=k_tr_stack_fwd_w' shape=8x1024 round=$TAG commit=$git_rev >> $O/pmc_summary.log 2>&1
 rm -rf $O/prof_tr; find $O/pmc_tr -name '*.db' -delete
+# the training row once more, now with THIS binary's traffic figure behind it
+[ -s $O/train_wgrad_pmc.json ] && cp $O/train_wgrad_pmc.json $R/profiles/train_wgrad_pmc.json && ( cd $R && timeout 300 python bench.py --row train --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_row_train.json 2> $O/bench_row_train.err )
+cd $R
+# (the long sweeps last: a call that runs out of budget has the headline evidence already)
+timeout 600 python tools/shape_sweep.py 3 1x512,1x1000,1x1550,4x777,2x2048,3x1550,1x5000,1x8000,6x1024,8x1024,3x5000,16x2048 --lat-splits > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
+timeout 400 python tools/bench_configs.py 3 > $O/configs_throughput.jsonl 2> $O/configs_throughput.err
+timeout 200 python tools/bench_single.py 10 100 8 > $O/single_utterance.jsonl 2> $O/single_utterance.err
+timeout 200 python tools/bench_single.py 10 60 8 >> $O/single_utterance.jsonl 2>> $O/single_utterance.err
+cd /tmp
 if [ "$3" != "core" ]; then
 # vocoder row: kernel stats + FETCH / WRITE / SQ passes over the fused resblock-stage kernels (bench.py --row vocoder reads voc_chain_32ch_pmc.json)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_voc -o voc -- python $R/bench.py --row vocoder --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_voc.log 2>&1
@@ -58,7 +63,7 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ
 for k in 8 16 32; do
 python $R/tools/pmc_summary.py $O/pmc_voc "k_voc_chain<$k" $O/voc_chain_${k}ch_pmc.txt $O/voc_chain_${k}ch_pmc.json "kernel_tag=k_voc_chain<$k" round=$TAG commit=$git_rev >> $O/pmc_summary.log 2>&1
 done
-timeout 200 python tools/voc_chain_timeline.py > $O/voc_chain_timeline.txt 2>&1
+timeout 200 python $R/tools/voc_chain_timeline.py > $O/voc_chain_timeline.txt 2>&1
 # FastSpeech2 row: kernel stats + the PMC passes over the mel-rate ffn_1 launches (bench.py --row fs2 reads fs2_ffn1_pmc.json)
 cd $R; bash tools/gpu_fs2_prof.sh $TAG/fs2 > $O/fs2_prof.log 2>&1; cp $O/fs2/fs2_ffn1_pmc.json $O/fs2/fs2_ffn1_pmc.txt $O/fs2/fs2_kernel_stats.txt $O/ 2>/dev/null; rm -rf $O/fs2
 fi
