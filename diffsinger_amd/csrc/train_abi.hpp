@@ -44,6 +44,9 @@ extern "C" int dsf_set_stack_conv(int32_t mode) {
     return DSD_OK;
 }
 extern "C" int dsf_get_stack_conv(void) { return g_tr_stack_conv; }
+// developer hook (tools/trb_timeline.py): s_memtime stamps of the Winograd data-gradient kernel, [workgroup][wave 4][8] per launch (the last launch wins)
+static unsigned long long* g_trb_dbg = nullptr;
+extern "C" int dsf_debug_trb_timeline(uint64_t* device_stamps) { g_trb_dbg = (unsigned long long*)device_stamps; return DSD_OK; }
 static bool tr_wino_applies(const dsf_stack_weights* w, int L) {
     if (g_tr_stack_conv != 1) return false;
     for (int l = 0; l < L; ++l) {
@@ -474,14 +477,14 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
             TrbFusedParams q{conv_params(l), gate_params(l - 1)};
             if (wino) {
                 const TrbFusedWinoParams qw{q, (const float4*)(bws + bl.wdw + (size_t)l * kWnSteps * (kWnStepBytes / 4)),
-                                            (unsigned)(kWnSteps * kWnStepBytes), g_tr_stack_touch};
+                                            (unsigned)(kWnSteps * kWnStepBytes), g_tr_stack_touch, (l == 1) ? g_trb_dbg : nullptr};
                 if (last) hipLaunchKernelGGL(k_trb_fused_w<true>, grid, blk, kTrbFusedWinoLdsBytes, s, qw);
                 else hipLaunchKernelGGL(k_trb_fused_w<false>, grid, blk, kTrbFusedWinoLdsBytes, s, qw);
             } else if (last) hipLaunchKernelGGL(k_trb_fused<true>, grid, blk, kTrbFusedLdsBytes, s, q);
             else hipLaunchKernelGGL(k_trb_fused<false>, grid, blk, kTrbFusedLdsBytes, s, q);
         } else if (wino) {
             TrbFusedParams q{conv_params(l), TrbGateParams{}};
-            const TrbFusedWinoParams qw{q, (const float4*)(bws + bl.wdw), (unsigned)(kWnSteps * kWnStepBytes), g_tr_stack_touch};
+            const TrbFusedWinoParams qw{q, (const float4*)(bws + bl.wdw), (unsigned)(kWnSteps * kWnStepBytes), g_tr_stack_touch, nullptr};
             if (last) hipLaunchKernelGGL((k_trb_fused_w<true, false>), grid, blk, kTrbFusedWinoLdsBytes, s, qw);
             else hipLaunchKernelGGL((k_trb_fused_w<false, false>), grid, blk, kTrbFusedWinoLdsBytes, s, qw);
         } else {

@@ -71,6 +71,7 @@ __global__ void k_tr_bsum(const TrPtrs ob, float* __restrict__ bsum, int L) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= kC) return;
     float acc = 0.f;
+#pragma unroll 4
     for (int l = 0; l < L; ++l) acc += ob.p[l][kC + c];
     bsum[c] = acc;
 }
@@ -84,7 +85,8 @@ __global__ void k_tr_iota(int* out, int n) {
 __global__ void k_tr_dds_reduce(const float* __restrict__ part, float* __restrict__ dds, int L, int ntile32, int ntiles) {
     const int b = blockIdx.x, l = blockIdx.y, c = threadIdx.x;
     float s = 0.f;
-    for (int tn = 0; tn < ntile32; ++tn) s += part[((size_t)l * ntiles + (size_t)b * ntile32 + tn) * kC + c];
+#pragma unroll 8
+    for (int tn = 0; tn < ntile32; ++tn) s += part[((size_t)l * ntiles + (size_t)b * ntile32 + tn) * kC + c];      // (eight loads in flight, the additions in tile order)
     dds[((size_t)b * L + l) * kC + c] = s;
 }
 
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_gate(const TrbGateParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float ag = f4at(av[mb][r >> 2], r & 3), af = f4at(av[mb + 2][r >> 2], r & 3);
-            const float sg_ = 1.f / (1.f + expf(-ag)), th = tanhf(af);
+            const float sg_ = sigmoid_f(ag), th = tanh_f(af);      // the forward's own functions (dsd_kernels.hpp): the gate the forward multiplied by, at a tenth of libm's instructions
             const float dg = fin[mb][r];
             const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
             store4_wt(dab, row * p.TS + t, ok ? dg * th * (sg_ * (1.f - sg_)) : 0.f);
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_fused(const TrbFusedParams 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float ag = f4at(av[mb][r >> 2], r & 3), af = f4at(av[mb + 2][r >> 2], r & 3);
-            const float sg_ = 1.f / (1.f + expf(-ag)), th = tanhf(af);
+            const float sg_ = sigmoid_f(ag), th = tanh_f(af);      // the forward's own functions (dsd_kernels.hpp): the gate the forward multiplied by, at a tenth of libm's instructions
             const float dg = fing[mb][r];
             const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
             store4_wt(dab, row * p.TS + t, ok ? dg * th * (sg_ * (1.f - sg_)) : 0.f);

@@ -62,6 +62,7 @@ struct TrbFusedWinoParams {
     const float4* wdw;          // this layer's transformed weights [128 steps][w4][r4][lane64]
     unsigned wl_bytes;          // bytes of one layer's stream (+ slack behind it): the L2 touch's buffer bound
     int touch_ahead;            // steps the L2 touch runs in front (0 = off)
+    unsigned long long* dbg;    // optional s_memtime stamps (dsf_debug_trb_timeline): [workgroup][wave 4][8]
 };
 constexpr int kTrbFusedWinoLdsBytes = kLoopTouchLds + kTrbConvLdsBytes;
 
@@ -117,6 +118,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_fused_w(const TrbFusedWinoP
         tc.lds = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float*)smem_all + (unsigned)w * 256u;
         tc.lane128 = (unsigned)lane * 128u;
     }
+    const bool stamp = qw.dbg != nullptr && lane == 0;
+    auto mark = [&](int k) { if (stamp) qw.dbg[((size_t)blockIdx.x * 4 + w) * 8 + k] = __builtin_amdgcn_s_memtime(); };
+    mark(0);
     // row g of this wave's K half at the pair's even frame (the tile's frame 0 is column kHalo)
     const float* pE = smem + (wk * kC + gg) * LD + kHalo + wn_frame_of_pair(pp, de);
     WinoPipe<S, LD> pipe(qw.wdw + (size_t)w * 256, lane, 0, pE, pE + dil, dil, tc);
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_fused_w(const TrbFusedWinoP
     // takes chunks 2 n + 1, 2 n + 2), so quarter q + 1 is written in front of period 2 q + 1
     write(0);
     __syncthreads();
+    mark(1);
     pipe.start_b();
     pipe.template run<1, 0, 0>(acc);
     write(1);
@@ -181,6 +186,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_fused_w(const TrbFusedWinoP
         acc[1][rb] = m1 - m2;
     }
     DSD_SB();
+    mark(2);
     // the skip rows of the next contraction's B tile are requested half way through the second half
     pipe.template run<4, 1, 1>(acc);
     constexpr int NCH = 32;
@@ -194,6 +200,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_fused_w(const TrbFusedWinoP
     }
     DSD_SB();
     pipe.template run<4, 1, 1>(acc);
+    mark(3);
     f32x4w fin[2][4];
     trb_exchange_w(acc, fin, xbuf, wr, wk, lane);          // its barrier: every wave is done reading the da tile
     if constexpr (GATE) pipeg.start_a();
@@ -248,6 +255,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_fused_w(const TrbFusedWinoP
     }
     if constexpr (!GATE) return;
     __syncthreads();
+    mark(4);
     // output-projection data gradient + gate derivative of layer l - 1 (k_trb_gate<false>)
     const int t = t0 + j;
     const bool ok = t < p.T;
@@ -258,8 +266,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_fused_w(const TrbFusedWinoP
         for (int r = 0; r < 16; ++r) accg[mb][0][r] = 0.f;
     pipeg.start_b();
     pipeg.run(accg, 0, NCH);
+    mark(5);
     f32x16 fing[2];
     trb_exchange(accg, fing, xbuf, wr, wk, lane);
+    mark(6);
     float* dab = pg.da + (size_t)b * pg.da_bstride;
     float* gb = pg.g + (size_t)b * kC * p.TS;
 #pragma unroll
@@ -267,13 +277,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_fused_w(const TrbFusedWinoP
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float ag = f4at(av[mb][r >> 2], r & 3), af = f4at(av[mb + 2][r >> 2], r & 3);
-            const float sg_ = 1.f / (1.f + expf(-ag)), th = tanhf(af);
+            const float sg_ = sigmoid_f(ag), th = tanh_f(af);      // the forward's own functions (dsd_kernels.hpp): the gate the forward multiplied by, at a tenth of libm's instructions
             const float dg = fing[mb][r];
             const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
             store4_wt(dab, row * p.TS + t, ok ? dg * th * (sg_ * (1.f - sg_)) : 0.f);
             store4_wt(dab, (kC + row) * p.TS + t, ok ? dg * sg_ * (1.f - th * th) : 0.f);
             store4_wt(gb, row * p.TS + t, ok ? sg_ * th : 0.f);
         }
+    mark(7);
 }
 
 }  // namespace dsd

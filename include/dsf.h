@@ -176,6 +176,9 @@ int dsf_set_stack_mode(int32_t mode);
  * per-layer launches).  The saved tensors keep their layouts; the workspace sizes do not depend on it. */
 int dsf_set_stack_conv(int32_t mode);
 int dsf_get_stack_conv(void);
+/* Developer hook (tools/trb_timeline.py): s_memtime stamps of the Winograd data-gradient kernel of layer 1, [workgroup][wave 4][8] uint64 per launch
+ * (NULL switches it off).  Not part of the operator surface. */
+int dsf_debug_trb_timeline(uint64_t* device_stamps);
 int dsf_stack_offsets(int32_t B, int32_t T, int32_t L, int32_t which, int64_t* out, int32_t n);
 int dsf_stack_forward(const float* x0, const float* cond, const float* step, const dsf_stack_weights* w, int32_t B, int32_t T, int32_t L,
                       float* save_ws, float* skip_out, void* stream);
