@@ -308,6 +308,16 @@ __device__ __forceinline__ void store16(float4* base_uniform, int idx, const flo
     }
 }
 
+// A wave-uniform pointer, made PROVABLY uniform: where hipcc moves a scalar address chain to the vector ALU (k_trb_fused_w: `base + w * 4096`
+// ended up in VGPRs) a buffer descriptor built from it is "divergent" and EVERY load through it becomes a waterfall loop - four readfirstlanes,
+// two compares and a branch per load, 59 instead of 37 cycles per MFMA in that kernel's convolution (profiles/r5_25_trb_timeline.txt).
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
 // 4-byte WRITE-THROUGH store (sc1) at float index idx behind a wave-uniform base: outputs of the training kernels that the NEXT kernel reads
 // leave the L2 as they are written instead of in the release at the kernel boundary
 __device__ __forceinline__ void store4_wt(float* base_uniform, int idx, float v) {

@@ -113,16 +113,6 @@ struct L2TouchP {
 // one scalar add.  What the fillers cost beside a 32-cycle fp32 MFMA (tools/mfma_filler_probe.hip, profiles/r5_02_mfma_filler_probe.jsonl):
 // a satisfied s_waitcnt nothing, a ds_read_b128 under one cycle, a VECTOR-ALU instruction 8 cycles of matrix time (+ 5 for the first one
 // in a gap: the fp32 matrix pipe and the vector ALU do not overlap) - so the input transform's eight adds go into ONE gap of a group's last step.
-// A wave-uniform pointer, made PROVABLY uniform: where hipcc moves a scalar address chain to the vector ALU (k_trb_fused_w: `base + w * 4096`
-// ended up in VGPRs) a buffer descriptor built from it is "divergent" and EVERY load through it becomes a waterfall loop - four readfirstlanes,
-// two compares and a branch per load, 59 instead of 37 cycles per MFMA in that kernel's convolution (profiles/r5_25_trb_timeline.txt).
-template <typename T>
-__device__ __forceinline__ T* uniform_ptr(T* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (T*)(((unsigned long long)hi << 32) | lo);
-}
-
 // CM = 0: the B tile is FRAME-MAJOR in pair order (this file's loop).  CM = LD > 0: the B tile is CHANNEL-MAJOR [k row][LD frames] (the
 // transposed convolution of the training backward, train_wino_bwd.hpp): lane (p, g) reads k rows 16 c + 4 s + g at frames tE(p) + {-d, 0, d, 2 d}
 // as ds_read_b32 - the pointers are frame pointers of row g, a chunk is 16 rows further.

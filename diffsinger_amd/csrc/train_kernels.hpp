@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_trb_conv(const TrbConvParams p)
             const int row = 128 * wr + 64 * wk + 32 * mb + frag_row(r, h);
             // frames >= T are zero padding of y in the forward pass (net.py:69-71 pads the conv input): no gradient flows into them
             const float dy = ok ? fin[mb][r] : 0.f;
-            store4_wt(p.dx_out + (size_t)b * kC * p.TS, row * p.TS + t, ok ? rv[mb][r] * kTrInvSqrt2 + dy : 0.f);
+            store4_wt(uniform_ptr(p.dx_out + (size_t)b * kC * p.TS), row * p.TS + t, ok ? rv[mb][r] * kTrInvSqrt2 + dy : 0.f);      // (uniform_ptr: hipcc had this base in VGPRs - 32 waterfall loops)
             float s = dy;
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
             if (j == 0) p.dds_part[(size_t)tile * kC + row] = s;

@@ -17,7 +17,14 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden', 'kernel_isa_hashes.json')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '--cuda-device-only', '-S']
 
 
-def kernel_hashes():
+_LISTING = None
+
+
+def kernel_listing():
+    """{mangled kernel name: [normalised instruction lines]} (compiled once per process)"""
+    global _LISTING
+    if _LISTING is not None:
+        return _LISTING
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, 'dsd.s')
@@ -38,7 +45,24 @@ def kernel_hashes():
                     continue
                 t = re.sub(r';.*', '', t).strip()
                 funcs[cur].append(re.sub(r'\.LBB\d+_(\d+)', r'.LBB_\1', t))
-    return {k: hashlib.sha1('\n'.join(v).encode()).hexdigest() for k, v in funcs.items()}
+    _LISTING = funcs
+    return funcs
+
+
+def kernel_hashes():
+    return {k: hashlib.sha1('\n'.join(v).encode()).hexdigest() for k, v in kernel_listing().items()}
+
+
+def waterfall_loops():
+    """{kernel: count} of buffer loads / stores wrapped in a WATERFALL loop (s_and_saveexec in front of the instruction): hipcc emits one
+    per memory instruction whose buffer descriptor it could not prove wave-uniform - four v_readfirstlane, two v_cmp and a branch each, and
+    no interleaving with the MFMAs around it (round 5: every weight load of k_trb_fused_w, dsd_kernels.hpp uniform_ptr)."""
+    out = {}
+    for k, v in kernel_listing().items():
+        n = sum(1 for a, b in zip(v, v[1:]) if a.startswith('s_and_saveexec_b64') and re.match(r'buffer_(load|store|atomic)', b))
+        if n:
+            out[k] = n
+    return out
 
 
 if __name__ == '__main__':
