@@ -855,7 +855,8 @@ __global__ __launch_bounds__(256) void k_tr_wgrad_reduce(const TrWgParams p) {
     const int m = blockIdx.y, n = threadIdx.x;
     const float* src = p.part + (size_t)blockIdx.x * p.nsplit * (128 * 256) + m * 256 + n;
     float s = 0.f;
-    for (int k = 0; k < p.nsplit; ++k) s += src[(size_t)k * (128 * 256)];
+#pragma unroll 6
+    for (int k = 0; k < p.nsplit; ++k) s += src[(size_t)k * (128 * 256)];       // (the splits' loads in flight together, the additions in split order)
     d.out[(size_t)m * d.out_rs + (size_t)n * d.out_cs] = s;
     if (d.out_bias && n == 0) {
         const float* sb = p.part_b + (size_t)blockIdx.x * p.nsplit * 128 + m;
