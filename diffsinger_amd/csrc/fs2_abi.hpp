@@ -295,6 +295,7 @@ static int fs_wg_splits(int Co, int Ci, int KT) {
     int ns = 16;
     if (KT != 1) return ns;
     const int tiles = ((Co + 127) / 128) * ((Ci + 63) / 64);
+    if (tiles > 8) return ns;                   // (wider outputs keep 16: their partials would grow to tens of MiB per layer for little)
     while (ns < 64 && tiles * ns < 512) ns *= 2;
     return ns;
 }
