@@ -62,6 +62,10 @@ F_EVAL_EXEC = (L_LAYERS - 1) * F_LAYER_EXEC + (F_LAYER_EXEC - 2 * 256 * 256) + 2
 # products per 32-frame tile instead of three [512 x 256] x [256 x 32] - 524 288 multiply-add FLOP / frame / layer instead of 786 432
 F_EVAL_EXEC_WINO = F_EVAL_EXEC - L_LAYERS * (2 * 512 * 768 - 4 * 2 * 512 * 256 // 2)      # 15 810 560
 PEAK_FP32_MFMA_TFLOPS = 157.3
+# collectives of the bench's process group fail after this long instead of blocking for ever (a rank that died outside sharded_inference's own
+# status exchange, diffsinger_amd/dist.py _agree_or_raise)
+GROUP_TIMEOUT = __import__('datetime').timedelta(minutes=10)
+WEIGHT_BYTES = 15_086_416 * 4                              # 15 086 416 parameters = 60.3 MB, re-read every step
 
 
 def build_model(device):
@@ -247,20 +251,48 @@ def torch_rocm_eager_baseline(gd, cond, x_T):
             'note': 'context, extrapolated: the reference\'s own operator sequence on this GPU - not a target, not the product path'}
 
 
-def pmc_traffic(kernel: str, frames: int):
-    """HBM-side bytes per launch of the layer kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of tools/gpu_pmc.sh at this very shape, corrected as MI355X_MICROARCH.md prescribes; reduced by
-    tools/pmc_summary.py).  PMC counters cannot be read from inside this process, so the figure comes from the profile
-    of the same kernel + shape committed under profiles/; None when there is no matching profile."""
-    fname = 'loop_pmc.json' if kernel.startswith('k_loop') else 'layer_pmc.json'
+def evidence(fname: str, kernel_tag=None, **must):
+    """An evidence summary under profiles/ (PMC passes, in-kernel timelines: tools/pmc_summary.py, tools/loop_timeline.py) - but only if it
+    was measured on THE CODE THIS PROCESS RUNS.  A summary carries the build id of the library it was taken from (dsd_build_id: sha256 of
+    csrc/ + include/) and the hash of its kernel's device code (diffsinger_amd/kernel_isa.json).  Accepted: same build id as the loaded
+    library, or - the library was rebuilt since, for an edit elsewhere - the same device code of that kernel.  Anything else is refused:
+    returns (None, 'stale: ...') and the bench line says `traffic: null` rather than a number from another binary (every
+    round-5 summary was stamped with a round-4 commit).  Returns (json, source string)."""
     path = os.path.join(ROOT, 'profiles', fname)
     try:
         js = json.load(open(path))
-        if js.get('frames') != frames or js.get('kernel_tag') != kernel:
-            return None, None
-        return float(js['hbm_bytes_per_launch']['total']), f"profiles/{fname} ({js.get('round', '?')}): " + js['hbm_bytes_per_launch']['note']
-    except Exception:
-        return None, None
+    except (OSError, ValueError):
+        return None, f'no profiles/{fname}'
+    if kernel_tag is not None and js.get('kernel_tag') != kernel_tag:
+        return None, f"profiles/{fname} is about {js.get('kernel_tag')!r}, not {kernel_tag!r}"
+    for k, v in must.items():
+        if js.get(k) != v:
+            return None, f'profiles/{fname}: {k} = {js.get(k)!r}, this run has {v!r}'
+    from diffsinger_amd import _lib
+    from diffsinger_amd.build import kernel_isa
+    cur = _lib.build_id()
+    bid = js.get('build_id')
+    tag = f"profiles/{fname} (round {js.get('round', '?')}, build {str(bid)[:12]})"
+    if bid == cur:
+        return js, tag
+    name, isa = js.get('kernel_isa_name'), js.get('kernel_isa')
+    if name and isa and kernel_isa(cur).get(name) == isa:
+        return js, tag + f' - the library was rebuilt since ({cur[:12]}), the device code of {name} is unchanged (kernel_isa {isa[:12]})'
+    return None, f"stale: {tag} is not the loaded library ({cur[:12]}) and the kernel's device code does not match - rerun tools/gpu.sh"
+
+
+def pmc_traffic(kernel: str, frames: int):
+    """HBM-side bytes per launch of the benched kernel from the rocprofv3 --pmc passes under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs
+    at this very shape, corrected as MI355X_MICROARCH.md prescribes; tools/gpu.sh looppmc -> tools/pmc_summary.py).  PMC counters cannot be
+    read from inside this process, so the figure comes from the summary of the same kernel + shape - if `evidence` accepts it."""
+    fname = 'loop_pmc.json' if kernel.startswith('k_loop') else 'layer_pmc.json'
+    js, src = evidence(fname, kernel, frames=frames)
+    if js is None:
+        return None, src
+    try:
+        return float(js['hbm_bytes_per_launch']['total']), src + ': ' + js['hbm_bytes_per_launch']['note']
+    except (KeyError, TypeError, ValueError):
+        return None, src + ': no hbm_bytes_per_launch'
 
 
 def parity_check(device):
@@ -285,7 +317,7 @@ def _row_setup():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device, timeout=GROUP_TIMEOUT)
     return world, rank, device, dist
 
 
@@ -399,22 +431,23 @@ def main_vocoder(args):
         ms = ev0.elapsed_time(ev1) / reps
         flop = sum(2 * B * L * ch * ch * k * 6 for k in h['resblock_kernel_sizes'])          # useful FLOPs: 6 convolutions per resblock
         alg_bytes = 2 * B * ch * L * 4                                                          # the stage input read once, its output written once
-        traffic, traffic_src = None, 'no PMC pass of this kernel committed'
-        try:
-            pj = json.load(open(os.path.join(ROOT, 'profiles', 'voc_chain_32ch_pmc.json')))
-            traffic = pj['hbm_bytes_per_launch']['total']
-            traffic_src = (f"profiles/voc_chain_32ch_pmc.json (round {pj.get('round', '?')}, commit {pj.get('commit', '?')}): FETCH_SIZE KiB x 1024 x 2 "
-                           '(gfx950 wide-read correction) + WRITE_SIZE KiB x 1024 of one launch at this shape')
-        except Exception:
-            pass
-        kname = 'k_voc_chain<32,1,4>' if chained else 'k_voc_conv<4,4> x 18 (chains off)'
+        pj, traffic_src = evidence('voc_chain_32ch_pmc.json')
+        traffic = None
+        if pj is not None:
+            traffic = pj['hbm_bytes_per_launch']['total'] * pj.get('launches_per_stage', 3)
+            traffic_src += (': FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024, average over the launches of the stage '
+                            'at this shape x 3 launches')
+        kname = 'k_voc_chain<32, 1, 4, true> x 3 (one launch per resblock)' if chained else 'k_voc_conv<4,4> x 18 (chains off)'
         roof = {'bound': 'mfma', 'kernel': kname, 'achieved': flop / (ms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic if chained else None, 'traffic_unit': 'bytes/launch',
+                'frac': flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic if chained else None, 'traffic_unit': 'bytes/stage',
                 'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms, 'flop_per_launch': flop,
-                'note': 'achieved = USEFUL fp32 FLOPs of the 18 convolutions (2 x 32 x 32 x k per sample) / launch time incl. the torch.empty of the output and '
-                        'the ctypes call; the kernel executes 1.33 x that (a workgroup owns 384 samples + 2 x 60 of receptive field, 512 staged) on one 32-row '
-                        'MFMA block; 4 bytes / sample / channel in and out = 16 kFLOP/B: far above the ridge (20 FLOP/B), the matrix pipe is the roof. '
-                        'Round 2 ran the same stage as 18 launches of k_voc_conv<4,4> that moved 3.2 GB (0.36 of the HBM roof on the narrow stages)'}
+                'note': 'the resblock stage of the 32-channel stage (3 parallel resblocks x 3 conv pairs = 18 convolutions, kernels 3 / 7 / 11, dilations 1 / 3 / 5, '
+                        '8 x 65 536 samples): "launch" = the stage = three chain launches (one per resblock, the running sum handed on); achieved = USEFUL fp32 '
+                        'FLOPs of the 18 convolutions (2 x 32 x 32 x k per sample) / stage time incl. the torch.empty of the outputs and the ctypes calls; the '
+                        'kernels execute 1.22 x that (a workgroup stages 512 samples and owns 512 - 2 x 12 / 36 / 60 of them: the receptive field of ITS '
+                        'resblock) on one 32-row MFMA block, one LDS tile rewritten in place, two workgroups per CU (round 6; rounds 3-5: one launch per '
+                        'stage, two tiles, one workgroup per CU, 1.33 x); 4 bytes / sample / channel in and out per launch: far above the ridge (20 FLOP/B), '
+                        'the matrix pipe is the roof - at the 2.1 GHz the chip holds under fp32 MFMA load its peak is 137.6, not 157.3 TFLOP/s'}
         fpf = vocoder_flop_per_frame(h)
         value = world * B * T * args.steps / el
         res = {'metric': 'mel-frames/sec (whole node) through the HiFi-GAN generator, 80-bin mel -> 24 kHz waveform, hop 256, T=1024', 'value': value,
@@ -525,15 +558,12 @@ def main_train(args):
         else:
             roof = {'bound': 'mfma', 'kernel': 'k_fs_conv<2> (operator path)', 'achieved': None, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
                     'traffic': None, 'note': 'the fused stack is switched off (DSD_TRAIN_FUSED=0) or does not cover this DiffNet'}
-        try:        # fabric-side bytes of the same launch (two layers), from the round's separate --pmc passes over the training step
-            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'train_wgrad_pmc.json')))
-            if fused:
-                roof['traffic'] = pm['hbm_bytes_per_launch']['total']
-                roof['traffic_unit'] = 'bytes/launch'
-                roof['traffic_source'] = (f"profiles/train_wgrad_pmc.json ({pm.get('round', '?')}): FETCH_SIZE x 2 + WRITE_SIZE of k_tr_wgrad inside the training step; "
-                                          f"algorithmic: 118 MB of operands (da, y, cond, g, dx', dskip of two layers) + 31.5 MB of split-K partials per launch")
-        except (OSError, KeyError, ValueError):
-            pass
+        pm, pm_src = evidence('train_wgrad_pmc.json')      # fabric-side bytes of the same launch (two layers), from separate --pmc passes over the training step
+        if fused:
+            roof['traffic_unit'] = 'bytes/launch'
+            roof['traffic'] = pm['hbm_bytes_per_launch']['total'] if pm is not None else None
+            roof['traffic_source'] = pm_src + ('' if pm is None else ': FETCH_SIZE x 2 + WRITE_SIZE of k_tr_wgrad inside the training step; algorithmic: 118 MB of '
+                                              "operands (da, y, cond, g, dx', dskip of two layers) + 31.5 MB of split-K partials per launch")
         value = world * B * T * args.steps / el
         res = {'metric': 'frames/sec (whole node) through one denoiser training step: q_sample + DiffNet forward + L1 + backward, T=1024', 'value': value,
                'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
@@ -550,6 +580,177 @@ def main_train(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Compact figures for the rows AROUND the path, the off-shapes and the in-service noise path - inside the driver-run N = 1 line (VERDICT r5,
+# item 2: until round 6 every f-row number was a builder-kept file).  Each uses the workload of its own `--row` bench.
+# ------------------------------------------------------------------------------------------------------------
+F_CONV_LAYERS = L_LAYERS * 2 * 512 * 768                   # direct-form FLOP / frame of the 20 dilated convolutions (15 728 640)
+# training step, EXECUTED: forward and data-gradient half with the dilated convolution as Winograd F(2,3) (x 2/3 on that part), every weight
+# gradient in direct form (= the forward's GEMM FLOPs)
+F_TRAIN_EXEC = 2 * (F_TRAIN_FWD - F_CONV_LAYERS // 3) + F_TRAIN_FWD
+
+
+def _event_ms(fn, warm, steps):
+    for _ in range(warm):
+        fn()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        out = fn()
+    ev1.record()
+    ev1.synchronize()
+    return ev0.elapsed_time(ev1) / steps, (time.perf_counter() - t0) * 1e3 / steps, out
+
+
+def fs2_forward_flops(m, step):
+    """GEMM FLOPs of ONE forward of the HIP FastSpeech2, counted at its operators as it runs: every convolution / linear (2 B T Co Ci K) and
+    every attention core (QK^T + PV: 4 B T^2 C)."""
+    from diffsinger_amd import fs2 as F2
+    total = [0]
+    conv0, att0 = F2.conv1d_cm, F2.attention_cm
+
+    def conv(x, T, weight, *a, **kw):
+        total[0] += 2 * x.shape[0] * T * weight.shape[0] * weight.shape[1] * (weight.shape[2] if weight.dim() == 3 else 1)
+        return conv0(x, T, weight, *a, **kw)
+
+    def att(qkv, T, *a, **kw):
+        total[0] += 4 * qkv.shape[0] * T * T * (qkv.shape[1] // 3)
+        return att0(qkv, T, *a, **kw)
+
+    F2.conv1d_cm, F2.attention_cm = conv, att
+    try:
+        step()
+    finally:
+        F2.conv1d_cm, F2.attention_cm = conv0, att0
+    return total[0]
+
+
+def quick_rows(gd, device, warm=3, steps=10):
+    """rows: {fs2, vocoder, train}: ms per step (HIP events around `steps` steps after `warm`) and frac_row = FLOPs of the WHOLE row / time /
+    157.3 TFLOP/s - beside, not instead of, the dominant kernel's fraction the `--row` lines report."""
+    B, T = B_PER_GPU, T_FRAMES
+    rows = {}
+    # f1: FastSpeech2 forward, teacher-forced
+    try:
+        m, hp, tok, kw = _fs2_setup(B, T // 8, 8, device)
+        m = m.to(device)
+        tok = tok.to(device)
+        kw = {k: v.to(device) for k, v in kw.items()}
+        step = lambda: m(tok, infer=True, **{k: (v.clone() if k == 'f0' else v) for k, v in kw.items()})
+        with torch.no_grad():
+            flop = fs2_forward_flops(m, step)
+            ms, ms_wall, r = _event_ms(step, warm, steps)
+        assert r['mel_out'].shape == (B, T, 80) and bool(torch.isfinite(r['mel_out']).all())
+        rows['fs2'] = {'ms': ms, 'ms_wall': ms_wall, 'flop_row': flop, 'frac_row': flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                       'what': f'FastSpeech2 forward, teacher-forced, {B} x {T} mel frames (= `--row fs2`); flop_row = every convolution / linear / attention '
+                               'core of the forward (useful GEMM FLOPs, counted at the operators)'}
+        del m
+    except Exception as e:                                  # report, do not hide
+        rows['fs2'] = {'error': repr(e)[:300]}
+    # f2: HiFi-GAN generator
+    try:
+        from diffsinger_amd.vocoder import HifiGanGenerator
+        h = VOC_CONFIG
+        m = HifiGanGenerator(h)
+        m.remove_weight_norm()
+        g = torch.Generator().manual_seed(1234)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith('weight'):
+                    p.copy_(torch.randn(p.shape, generator=g) / (p[0].numel() if not n.startswith('ups') else p.shape[0] * 2) ** 0.5)
+        m = m.to(device).eval()
+        mel = torch.randn(B, 80, T, device=device, generator=torch.Generator(device=device).manual_seed(1234))
+        with torch.no_grad():
+            ms, ms_wall, wav = _event_ms(lambda: m(mel), warm, steps)
+        assert wav.shape == (B, 1, T * 256) and bool(torch.isfinite(wav).all())
+        flop = B * T * vocoder_flop_per_frame(h)
+        rows['vocoder'] = {'ms': ms, 'ms_wall': ms_wall, 'flop_row': flop, 'frac_row': flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                           'what': f'HifiGanGenerator of configs/tts/hifigan.yaml, {B} x {T} mel frames -> {B} x {T * 256} samples (= `--row vocoder`); flop_row = '
+                                   'USEFUL FLOPs of every convolution (the fused chains execute 1.1-1.2 x that: receptive-field overlap)'}
+        del m, mel, wav
+    except Exception as e:
+        rows['vocoder'] = {'error': repr(e)[:300]}
+    # f3: one p_losses forward + backward of the denoiser
+    try:
+        gd.train()
+        net = gd.denoise_fn
+        g = torch.Generator(device=device).manual_seed(1234)
+        x0 = torch.randn(B, 1, 80, T, device=device, generator=g).clamp(-1, 1)
+        cond = torch.randn(B, T, 256, device=device, generator=g).transpose(1, 2)
+        t = torch.randint(0, K_STEPS, (B,), device=device, generator=g)
+        noise = torch.randn(B, 1, 80, T, device=device, generator=g)
+
+        def step():
+            net.zero_grad(set_to_none=True)
+            loss = gd.p_losses(x0, t, cond, noise=noise)
+            loss.backward()
+            return loss
+
+        ms, ms_wall, loss = _event_ms(step, warm, steps)
+        assert bool(torch.isfinite(loss))
+        from diffsinger_amd import train_fused
+        fused = train_fused.enabled() and train_fused.supported(net)
+        wino = fused and train_fused.stack_conv() == 'wino'
+        flop = B * T * (F_TRAIN_EXEC if wino else 3 * F_TRAIN_FWD)
+        rows['train'] = {'ms': ms, 'ms_wall': ms_wall, 'flop_row': flop, 'frac_row': flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         'frac_row_direct_accounting': B * T * 3 * F_TRAIN_FWD / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         'what': f'q_sample + DiffNet forward + L1 + backward, {B} x {T} frames, no optimiser (= `--row train`); flop_row = EXECUTED GEMM FLOPs '
+                                 '(forward and data gradients with the dilated convolution as Winograd F(2,3), weight gradients in direct form)'}
+        net.zero_grad(set_to_none=True)
+    except Exception as e:
+        rows['train'] = {'error': repr(e)[:300]}
+    finally:
+        gd.eval()
+    return rows
+
+
+def offshape(gd, device, K=K_STEPS):
+    """The shapes that do NOT fill the chip: 1 x 512 - the reference's own evaluation shape, configs/tts/fs2.yaml:70 `max_eval_sentences: 1` -
+    and 3 x 1550 (147 of 256 CUs have a tile), K = 100 DDPM, explicit noise, one timed pass after one warm pass.  frac = executed FLOPs / time / 157.3."""
+    out = {}
+    for B, T in ((1, 512), (3, 1550)):
+        try:
+            g = torch.Generator(device=device).manual_seed(77 + T)
+            cond = torch.randn(B, T, 256, device=device, generator=g).transpose(1, 2)
+            x_T = torch.randn(B, 1, 80, T, device=device, generator=g)
+            noise = torch.randn(K, B, 1, 80, T, device=device, generator=g)
+            run = lambda: gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
+            eng = gd._engine(cond)
+            eng.set_loop_mode(2)                             # the library's own choice of path (the roofline leg above forces the persistent loop)
+            with torch.no_grad():
+                ms, ms_wall, mel = _event_ms(run, 1, 1)
+            assert bool(torch.isfinite(mel).all())
+            persistent = eng.loop_mode() == 1
+            wino = eng.conv_mode() == 1
+            f_exec = F_EVAL_EXEC_WINO if wino else F_EVAL_EXEC
+            gsplit = eng.lat_split()
+            out[f'{B}x{T}'] = {'ms': ms, 'mel_frames_per_s': B * T / (ms * 1e-3), 'frac': B * T * K * f_exec / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                               'flop_per_frame_per_evaluation': f_exec, 'tiles': B * ((T + 31) // 32),
+                               'path': ('k_loop_wino (persistent)' if wino else 'k_loop (persistent)') if persistent else
+                                       (f"row-split latency kernels, G = {gsplit}{', Winograd conv node' if wino else ''} (hipGraph)" if gsplit else 'k_layer (hipGraph)')}
+        except Exception as e:
+            out[f'{B}x{T}'] = {'error': repr(e)[:300]}
+    out['what'] = ('K = 100 DDPM per call (prepare + loop + denorm), explicit noise; frac = executed FLOP / time / 157.3 TFLOP/s with the convolution counted '
+                   'as the path executes it (dsd_get_conv_mode: Winograd F(2,3) on the persistent loop and on the latency kernels of G = 2 / 4 / 8)')
+    return out
+
+
+def inservice_noise(gd, cond, x_T, K, frames, steps=3):
+    """The rate a DiffSpeechTask user gets: the reference draws torch.randn inside every p_sample (usr/diff/shallow_diffusion_tts.py:38-41,
+    159-166); here `inference(noise=None)` draws in the loop's head (Philox + Box-Muller in the kernel) - the timed batch of the headline
+    with that path instead of pre-drawn noise."""
+    run = lambda: gd.inference(cond, x_T=x_T, noise=None, K_step=K, pndm_speedup=0, noise_seed=1234)
+    with torch.no_grad():
+        ms, ms_wall, mel = _event_ms(run, 1, steps)
+    assert bool(torch.isfinite(mel).all())
+    return {'value': frames / (ms * 1e-3), 'unit': 'mel-frames/s', 'ms_per_step': ms, 'steps': steps,
+            'what': 'the headline step with noise=None: every p_sample draws its N(0,1) noise inside the kernel (Philox 4x32-10 + Box-Muller, csrc/dsd_kernels.hpp) '
+                    'instead of reading a pre-drawn [K,B,1,M,T] tensor; not bit-comparable with the reference (different generator), same distribution '
+                    '(tests/test_gpu_surfaces.py)'}
 
 
 def _fs2_setup(B, T_txt, frames_per_phone, device, seed=7):
@@ -645,15 +846,11 @@ def main_fs2(args):
                 'algorithmic_bytes_per_launch': 4 * B * T * (256 + 1024) + 4 * 1024 * 256 * 9,
                 'note': 'ffn_1 of TransformerFFNLayer (Conv1d 256 -> 1024, k = 9, * k**-0.5, gelu fused): the largest contraction of the model; eager launch '
                         'incl. the output allocation and the ctypes call'}
-        try:                                                  # counters of THIS launch shape inside the whole forward (tools/gpu_fs2_prof.sh)
-            pj = json.load(open(os.path.join(ROOT, 'profiles', 'fs2_ffn1_pmc.json')))
-            roof['traffic'] = float(pj['hbm_bytes_per_launch']['total'])
-            roof['traffic_unit'] = 'bytes/launch'
-            roof['traffic_source'] = (f"profiles/fs2_ffn1_pmc.json (round {pj.get('round', '?')}, commit {pj.get('commit', '?')}): the k_fs_conv<2> dispatches "
-                                      'of at least 250 us of `bench.py --row fs2` = the four mel-rate ffn_1 launches per forward; FETCH_SIZE KiB x 1024 x 2 '
-                                      '(gfx950 wide-read correction) + WRITE_SIZE KiB x 1024')
-        except (OSError, KeyError, ValueError):
-            roof['note'] += '.  No PMC pass of this kernel is committed (profiles/fs2_ffn1_pmc.json)'
+        pj, pj_src = evidence('fs2_ffn1_pmc.json')            # counters of THIS launch shape inside the whole forward (tools/gpu.sh fs2pmc)
+        roof['traffic_unit'] = 'bytes/launch'
+        roof['traffic'] = float(pj['hbm_bytes_per_launch']['total']) if pj is not None else None
+        roof['traffic_source'] = pj_src + ('' if pj is None else ': the k_fs_conv<2> dispatches of at least 250 us of `bench.py --row fs2` = the four mel-rate '
+                                          'ffn_1 launches per forward; FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024')
         value = world * B * T * args.steps / el
         res = {'metric': 'mel-frames/sec (whole node) through FastSpeech2 (encoder, predictors, length regulator, decoder, mel_out), teacher-forced, T=1024',
                'value': value, 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
@@ -678,6 +875,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the labelled split-precision line (`secondary`) of the N = 1 run (~45 s, mostly its fp64 oracle)')
     ap.add_argument('--no-cfg5-shard', action='store_true', help='skip the configs[4] shard leg of the N = 1 line (~5 s)')
+    ap.add_argument('--no-extras', action='store_true', help='skip `rows` / `offshape` / `inservice_noise` of the N = 1 line (~6 s)')
     ap.add_argument('--tile', type=int, default=0, help='frames per workgroup of the layer kernel (0 auto, 32, 64)')
     ap.add_argument('--row', choices=['path', 'vocoder', 'train', 'fs2'], default='path',
                     help='path: the headline hot path (default); vocoder: SURVEY 8 row f2; train: row f3 (denoiser p_losses forward + backward); '
@@ -807,7 +1005,7 @@ def main_path(args):
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device, timeout=GROUP_TIMEOUT)
         assert dist.get_world_size() == args.gpus and dist.get_backend() == 'nccl'
     cfg = args.config or (5 if world > 1 else 2)
 
@@ -941,20 +1139,23 @@ def main_path(args):
             frames_k = frames
         if persistent:
             # where a launch spends its time: in-kernel s_memtime stamps of one layer phase and one head (tools/loop_timeline.py, same shape)
-            try:
-                tl = json.load(open(os.path.join(ROOT, 'profiles', 'loop_timeline.json')))
+            tl, tl_src = evidence('loop_timeline.json', kname)
+            if tl is not None:
                 ph, hd = tl['phase_cycles_mean'], tl['head_cycles_mean']
                 share = L_LAYERS * ph / (L_LAYERS * ph + hd)
                 note += (f'; per evaluation {L_LAYERS} layer phases of {ph:.0f} cycles ({tl["mfma_issue_ideal_per_phase"]} of MFMA issue) + a head of {hd:.0f} '
-                         f'cycles -> layers_ms {ms * share:.2f}, head_ms {ms * (1 - share):.2f} of this launch (profiles/loop_timeline.json, '
-                         f'round {tl.get("round", "?")})')
-            except Exception:
-                pass
+                         f'cycles -> layers_ms {ms * share:.2f}, head_ms {ms * (1 - share):.2f} of this launch ({tl_src})')
+            else:
+                note += f'; no in-kernel timeline quoted ({tl_src})'
         traffic, traffic_src = pmc_traffic(kname, frames_k)
         peak = 2500.0 / 6 if args.split else PEAK_FP32_MFMA_TFLOPS
         roof = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': peak,
                 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                 'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes,
+                'unavoidable_bytes_per_launch': int(K * (frames_k * 1984 + WEIGHT_BYTES)) if persistent else None,
+                'bytes_note': 'algorithmic = what THIS design moves per launch by construction (the hoisted conditioner projection 40 KiB / frame / evaluation, '
+                              'x / noise / x out, the weight stream once per launch-wide evaluation, the halo rows); unavoidable = SURVEY 8(d): K x (frames x 1 984 B '
+                              '[x in 320 + noise 320 + x out 320 + cond 1 024] + 60.3 MB of weights) - the floor of ANY implementation of the reference path',
                 'avg_launch_ms': ms, 'flop_per_launch': flop, 'achieved_ref_accounting': ref_acc, 'note': note}
         if persistent:
             roof['achieved_direct_accounting'] = direct_acc
@@ -1023,6 +1224,13 @@ def main_path(args):
                     res['secondary'] = {'error': repr(e)}
         else:
             res['parity'] = fixture
+        if world == 1 and cfg == 2 and not args.no_extras:
+            try:
+                res['inservice_noise'] = inservice_noise(gd, conds[0], x_T, K, B * T)
+                res['inservice_noise']['vs_explicit_noise'] = res['inservice_noise']['value'] / value
+            except Exception as e:
+                res['inservice_noise'] = {'error': repr(e)[:300]}
+            res['offshape'] = offshape(gd, device)
         if world == 1 and cfg == 2 and not args.no_cfg5_shard:
             # the N > 1 lines run BASELINE configs[4] (512 x T=2048, strong): one GPU's shard of the 8-GPU run - 64 utterances x T=2048 in
             # micro-batches of 16, no gather - sampled here after everything else, so that a 1/2/4/8 curve can be normalised on ONE workload
@@ -1043,6 +1251,8 @@ def main_path(args):
                                                 f'lines run; N x this is their ideal'}
             except Exception as e:
                 res['cfg5_shard_n1'] = {'error': repr(e)}
+        if world == 1 and cfg == 2 and not args.no_extras:
+            res['rows'] = quick_rows(gd, device)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

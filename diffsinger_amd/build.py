@@ -57,8 +57,55 @@ def up_to_date() -> bool:
     return binary_id() == source_hash()
 
 
+KERNEL_ISA = os.path.join(PKG, 'kernel_isa.json')
+_LLVM = '/opt/rocm/lib/llvm/bin'
+
+
+def kernel_isa_hashes(lib: str = LIB) -> dict:
+    """{demangled kernel name: sha1 of its gfx950 instructions} read back from the BUILT library (llvm-objdump of its device code, addresses and
+    encodings dropped).  The identity of one kernel's device code: an evidence file under profiles/ that carries it can be matched to the
+    library a process has loaded even when an edit elsewhere in csrc/ changed the library's build id."""
+    import hashlib
+    import re
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        cp = os.path.join(d, 'lib.so')
+        shutil.copy(lib, cp)                                          # objcopy rewrites its input
+        subprocess.run([f'{_LLVM}/llvm-objcopy', '--dump-section', f'.hip_fatbin={d}/fat.bin', cp], check=True, capture_output=True)
+        subprocess.run([f'{_LLVM}/clang-offload-bundler', '--unbundle', '--type=o', f'--input={d}/fat.bin',
+                        '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', f'--output={d}/dev.co'], check=True, capture_output=True)
+        txt = subprocess.run([f'{_LLVM}/llvm-objdump', '-d', '-C', '--no-show-raw-insn', f'{d}/dev.co'], check=True, capture_output=True, text=True).stdout
+    out = {}
+    heads = list(re.finditer(r'^[0-9a-f]+ <([^\n]+)>:$', txt, re.M))
+    for h, nxt in zip(heads, heads[1:] + [None]):
+        body = txt[h.end():nxt.start() if nxt else len(txt)]
+        ops = [re.sub(r'\s*//.*', '', ln).strip() for ln in body.splitlines()]
+        out[h.group(1).replace('dsd::', '').replace('void ', '')] = hashlib.sha1('\n'.join(o for o in ops if o).encode()).hexdigest()
+    return out
+
+
+def write_kernel_isa(lib: str = LIB) -> str:
+    """Sidecar of the built library: diffsinger_amd/kernel_isa.json = {build_id, kernels}.  Git-ignored like the .so, travels with it."""
+    import json
+    json.dump({'build_id': binary_id(lib), 'kernels': kernel_isa_hashes(lib)}, open(KERNEL_ISA, 'w'), indent=0)
+    return KERNEL_ISA
+
+
+def kernel_isa(build_id=None) -> dict:
+    """The sidecar's {kernel: sha1} if it belongs to the library with this build id (default: the built one), else {}."""
+    import json
+    try:
+        js = json.load(open(KERNEL_ISA))
+    except (OSError, ValueError):
+        return {}
+    return js.get('kernels', {}) if js.get('build_id') == (build_id or binary_id()) else {}
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if up_to_date() and not force:
+        if not kernel_isa():
+            write_kernel_isa()
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc] + FLAGS + [f'-DDSD_BUILD_ID_STR="{source_hash()}"', '-o', LIB] + SRC
@@ -66,6 +113,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     assert binary_id() == source_hash(), 'the built library does not carry the hash of the tree it was built from'
+    write_kernel_isa()
     return LIB
 
 

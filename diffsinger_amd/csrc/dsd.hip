@@ -620,7 +620,16 @@ static int launch_condproj(dsd_handle* h, bool wino, hipStream_t s) {
 }
 // called (outside any capture) in front of every consumer of cp: re-lays it when the batch was prepared for the other convolution
 static int ensure_cp(dsd_handle* h, bool wino, hipStream_t s) {
-    return (h->cp_wino == wino) ? DSD_OK : launch_condproj(h, wino, s);
+    if (h->cp_wino == wino) return DSD_OK;
+    // The re-layout flips HOST state (cp_wino) when it is ENQUEUED.  Under stream capture it would be recorded into the caller's graph and
+    // the flag would flip at capture time: later eager calls and replays would disagree with it and a loop could read cp in the wrong
+    // accumulator order without any error.  Refuse loudly: prepare / switch paths outside the capture.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(DSD_ERR_STATE, "the hoisted conditioner projection must change its layout for this path (%s order), and the stream is being captured: call "
+                    "dsd_prepare / the path switch (dsd_set_loop_mode, dsd_set_conv_mode) and one eager call BEFORE hipStreamBeginCapture",
+                    wino ? "Winograd-loop" : "direct");
+    return launch_condproj(h, wino, s);
 }
 
 extern "C" int dsd_prepare(dsd_handle* h, int32_t B, int32_t T, const float* cond, int64_t sb, int64_t sh, int64_t st, void* stream) {
@@ -1273,8 +1282,14 @@ extern "C" int dsd_set_conv_mode(dsd_handle* h, int32_t mode, int32_t touch_ahea
     return DSD_OK;
 }
 
-// 1 when the prepared batch runs the persistent loop with the Winograd convolution, 0 otherwise (direct form / another path)
-extern "C" int dsd_get_conv_mode(dsd_handle* h) { return (h && h->prepared && wino_applicable(h)) ? 1 : 0; }
+// 1 when the dilated convolution of the prepared batch runs as Winograd F(2,3): the persistent loop k_loop_wino, or the conv node of the
+// row-split latency kernels at G = 2 / 4 / 8 (k_lat_conv_w, launch_layer); 0: the direct form (mode 0, G = 16, per-layer kernels, split mode)
+extern "C" int dsd_get_conv_mode(dsd_handle* h) {
+    if (!h || !h->prepared) return 0;
+    if (wino_applicable(h)) return 1;
+    const int g = loop_applicable(h) ? 0 : lat_g(h);
+    return (h->conv_mode == 1 && h->w1w && !h->split_mode && (g == 2 || g == 4 || g == 8)) ? 1 : 0;
+}
 
 extern "C" int dsd_get_loop_mode(dsd_handle* h) { return (h && h->prepared && loop_applicable(h)) ? 1 : 0; }
 

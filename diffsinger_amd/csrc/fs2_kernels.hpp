@@ -326,7 +326,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_attn(const FsAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* vt = smem + w * (HD * LDV);                  // this wave's V tile / merge slice
+    constexpr int LDT = HD + 1;
+    static_assert(32 * LDT <= HD * LDV, "the key-major V tile fits the wave's merge slice");
+    float* vt = smem + w * (HD * LDV);                  // this wave's V tile (key-major [32][LDT]) / merge slice ([HD][LDV])
+    float* vtw = vt + 4 * (lane & 7) * LDT + (lane >> 3);           // this lane's write base: key 4 (lane % 8), row lane / 8
+    const float* vtr = vt + 4 * h * LDT + j;                        // this lane's read base: key 4 h, row j
     float* ml = smem + 4 * (HD * LDV);                  // [4 waves][32 queries][2] running max and sum
     const int tq0 = blockIdx.x * 32, hh = blockIdx.y, b = blockIdx.z;
     const float* qb = p.qkv + ((size_t)b * 3 * p.C + hh * HD) * p.TS;
@@ -342,15 +346,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_attn(const FsAttnParams p) {
     float qr[HD / 2];                                   // q[8c + 4h + s][tq0 + j] * scale, index 4c + s
 #pragma unroll
     for (int i = 0; i < HD / 2; ++i) qr[i] = fs_ldg32(rq, lk + tq0 * 4, (8 * (i >> 2) + (i & 3)) * row_b) * p.scale;
-    float m = -INFINITY, l = 0.f;
+    // Online softmax, round 6 (the densest loop of the library by vector work until then: 3.76 vector-ALU instructions per MFMA, each ~8 cycles
+    // of matrix time beside an fp32 MFMA - profiles/r5_32_isa_scan.txt):
+    //   * P = exp2(fma(S, log2 e, -m log2 e)): one fma + v_exp_f32 per element instead of libm's expf (~12 instructions);
+    //   * LAZY rescale: the running maximum m a query's P are taken against is raised only when a tile's maximum exceeds it by more than
+    //     kLazy (P <= e^kLazy = 245: no range problem in fp32) - then, and only then, o and l are multiplied by exp(m_old - m_new).  After the
+    //     first tile that is rare: the 64 multiplications of o per tile are gone from the common path (same value of O / L, other rounding);
+    //   * the key mask (tail of T, key_padding_mask) is ONE scalar test per tile: a tile inside T without a padded key takes no per-element
+    //     compare / select at all; the pad bytes of a tile are read once per wave (lane j <-> key tk0 + j) and turned into a ballot.
+    constexpr float kL2E = 1.4426950408889634f, kLazy = 5.5f;
+    float m = -INFINITY, l = 0.f;                       // m: the maximum the running sums are relative to (per query: both half-waves agree)
     f32x16 o[NMB];
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[mb][r] = 0.f;
     // k in groups of 16 loads, DOUBLE-BUFFERED (round 5): group g + 1 is requested before the MFMAs of group g are issued, and the first group of
-    // the NEXT key tile travels under the P V product - before, every group was loaded, waited for (vmcnt(0)) and multiplied in turn: 20 full
-    // drains in the tile loop, the matrix pipe busy 0.51 (the arithmetic and its order are unchanged: the same bits)
+    // the NEXT key tile travels under the P V product
     float kv[2][16];
     auto fetch_k = [&](int buf, int g16, int tk) {
 #pragma unroll
@@ -359,6 +371,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_attn(const FsAttnParams p) {
             kv[buf][u] = fs_ldg32(rk, lk + tk * 4, (8 * (i >> 2) + (i & 3)) * row_b);
         }
     };
+    const unsigned char* kpb = p.key_pad ? p.key_pad + (size_t)b * p.T : nullptr;
     if (32 * w < p.T) fetch_k(0, 0, 32 * w);
     for (int tk0 = 32 * w; tk0 < p.T; tk0 += 128) {
         // V tile -> registers in two halves (row idx >> 3, float4 column idx & 7): the first is requested before the S product and
@@ -371,14 +384,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_attn(const FsAttnParams p) {
                 vv[it] = fs_ldg128(rv, lv + tk0 * 4, (half * NV + it) * 8 * row_b);
             }
         };
+        // the V tile in LDS is KEY-major, vt[tk][LDT] with LDT = HD + 1 (round 6; rounds 2-5: [d][33]): every address of the writes below and of
+        // the P V product's reads is ONE per-lane base + a compile-time offset (ds_read_b32 / ds_write_b32 take 16 bits of it) - the [d][33] tile
+        // put a row block of 32 d 1 056 floats apart, beyond the 8-bit offsets of the paired LDS instructions, and cost an address addition per
+        // access: 73 v_add_u32 per key tile.  Reads: lanes j <-> consecutive d: conflict-free.
         auto store_v = [&](int half) {
 #pragma unroll
             for (int it = 0; it < NV; ++it) {
-                const int idx = (half * NV + it) * 64 + lane;
-                float* d = vt + (idx >> 3) * LDV + 4 * (idx & 7);
-                d[0] = vv[it].x; d[1] = vv[it].y; d[2] = vv[it].z; d[3] = vv[it].w;
+                float* d = vtw + (half * NV + it) * 8;            // row d = (half NV + it) 8 + lane / 8, keys 4 (lane % 8) + (0..3)
+                d[0] = vv[it].x; d[LDT] = vv[it].y; d[2 * LDT] = vv[it].z; d[3 * LDT] = vv[it].w;
             }
         };
+        unsigned padb = 0;
+        if (kpb && tk0 + j < p.T) padb = kpb[tk0 + j];  // (requested in front of the S product, used behind it)
         fetch_v(0);
         f32x16 s;
 #pragma unroll
@@ -394,42 +412,61 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_attn(const FsAttnParams p) {
         __builtin_amdgcn_wave_barrier();                // the previous tile's LDS reads of this wave are done (in-order LDS)
         store_v(0);
         fetch_v(1);
-        float mx = -INFINITY;
+        if (tk0 + 128 < p.T) fetch_k(0, 0, tk0 + 128); // the next tile's first k group: in flight under the softmax and the P V product
+        const unsigned long long padm = __ballot(padb != 0u);
+        const bool masked = (tk0 + 32 > p.T) || ((unsigned)padm != 0u);          // wave-uniform
+        if (masked) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tk = tk0 + frag_row(r, h);
-            const bool dead = (tk >= p.T) || (p.key_pad && p.key_pad[(size_t)b * p.T + tk]);
-            s[r] = dead ? -INFINITY : s[r];
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int tk = frag_row(r, h);
+                const bool dead = (tk0 + tk >= p.T) || (((unsigned)padm >> tk) & 1u);
+                s[r] = dead ? -INFINITY : s[r];
+            }
         }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+        // raise the reference maximum?  (first live tile: m = -inf, nothing accumulated yet; later: only by more than kLazy)
+        const bool raise = (mx > m + kLazy) || (m == -INFINITY && mx > -INFINITY);
+        if (__ballot(raise) != 0ull) {
+            const float mn = raise ? mx : m;
+            const float alpha = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m - mn) * kL2E);
+            l *= alpha;
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[mb][r] *= alpha;
+            m = mn;
+        }
+        const float m2 = (m == -INFINITY) ? 0.f : m * kL2E;      // (every key so far dead: the s are -inf, exp2(-inf - 0) = 0)
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = (s[r] == -INFINITY) ? 0.f : expf(s[r] - mn);
+            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], kL2E, -m2));
             ps += s[r];
         }
-        l = l * alpha + ps;
-        m = mn;
-#pragma unroll
-        for (int mb = 0; mb < NMB; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[mb][r] *= alpha;
+        l += ps;
         store_v(1);
-        if (tk0 + 128 < p.T) fetch_k(0, 0, tk0 + 128);         // the next tile's first k group, under the P V product
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // P V: 16 steps (key pairs of the k = 2 MFMA) x NMB row blocks; the A operands of step n + 1 are read from LDS while the MFMAs of step n
+        // issue (left to itself hipcc put every read directly in front of its MFMAs: read, s_waitcnt lgkmcnt(0), two MFMAs - the LDS latency
+        // exposed 32 times per tile)
+        float va[2][NMB];
+        auto lds_v = [&](float (&dst)[NMB], int n) {       // step n <-> key 8 (n / 4) + 4 h + n % 4: register s[n] of this lane
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int mb = 0; mb < NMB; ++mb) dst[mb] = vtr[(8 * (n >> 2) + (n & 3)) * LDT + 32 * mb];
+        };
+        lds_v(va[0], 0);
+        DSD_SB();
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int tk = 8 * c + 4 * h + st;
-                const float bv = s[4 * c + st];         // P[tk][tq = j]: the very register this lane computed it in
+        for (int n = 0; n < 16; ++n) {
+            if (n + 1 < 16) lds_v(va[(n + 1) & 1], n + 1);
 #pragma unroll
-                for (int mb = 0; mb < NMB; ++mb) o[mb] = mfma32(vt[(32 * mb + j) * LDV + tk], bv, o[mb]);
-            }
+            for (int mb = 0; mb < NMB; ++mb) o[mb] = mfma32(va[n & 1][mb], s[n], o[mb]);
+            DSD_SB();
+        }
     }
     // merge the four waves: O = sum_w O_w exp(m_w - M) / sum_w l_w exp(m_w - M)
     const float lt = l + __shfl_xor(l, 32, 64);
@@ -445,7 +482,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_fs_attn(const FsAttnParams p) {
     for (int q = 0; q < 4; ++q) { mw[q] = ml[(q * 32 + j) * 2]; M = fmaxf(M, mw[q]); }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        sc[q] = (mw[q] == -INFINITY) ? 0.f : expf(mw[q] - M);
+        sc[q] = (mw[q] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mw[q] - M) * 1.4426950408889634f);
         L += ml[(q * 32 + j) * 2 + 1] * sc[q];
     }
     const float inv = (L > 0.f) ? 1.f / L : 0.f;

@@ -76,7 +76,10 @@ static TrSave tr_save_layout(int B, int TS, int L) {
     const size_t ntiles = (size_t)B * TS / 32;
     TrSave s{};
     size_t o = 0;
-    s.w1p = o; o += L * kTrW3;
+    // ONE region for the dilated convolution's weights: a call packs either the direct fragments (w1p) or the Winograd-transformed stream
+    // (w1w, + prefetch slack) into it, never both (two always-allocated regions cost 40 MB per workspace at L = 20 and left the
+    // unused one holding stale bytes behind a live pointer)
+    s.w1p = o; s.w1w = o; o += std::max((size_t)L * kTrW3, (size_t)L * kWnSteps * (kWnStepBytes / 4) + kTrSlack);
     s.wcp = o; o += L * kTrW1;
     s.w2p = o; o += L * kTrW1 + kTrSlack;
     s.b1p = o; o += tr_al((size_t)L * 512);
@@ -88,7 +91,6 @@ static TrSave tr_save_layout(int B, int TS, int L) {
     s.bsum = o; o += 1024;
     s.iota = o; o += tr_al((size_t)B);
     s.flags = o; o += tr_al(ntiles + 64);       // phase flags + timeout word of the persistent forward (its halo buffers alias X)
-    s.w1w = o; o += (size_t)L * kWnSteps * (kWnStepBytes / 4) + kTrSlack;     // Winograd-transformed conv weights (train_loop_wino.hpp) + prefetch slack
     s.total = o;
     return s;
 }
@@ -101,7 +103,7 @@ static TrBwd tr_bwd_layout(int B, int TS, int L) {
     TrBwd s{};
     size_t o = 0;
     s.wotp = o; o += L * kTrW1;
-    s.wdtp = o; o += L * kTrW3 + kTrSlack;
+    s.wdtp = o; s.wdw = o; o += std::max((size_t)L * kTrW3, (size_t)L * kWnSteps * (kWnStepBytes / 4)) + kTrSlack;      // direct OR Winograd-transformed transposed conv weights (one per call)
     s.da = o; o += 2 * (2 * act);           // two slots each of da / g: the fused kernel of layer l reads da(l) and writes da(l - 1), g(l - 1)
     s.g = o; o += 2 * act;
     s.dxp0 = o; o += act;
@@ -109,7 +111,6 @@ static TrBwd tr_bwd_layout(int B, int TS, int L) {
     s.dds_part = o; o += tr_al((size_t)L * ntiles * kC);
     s.part = o; o += (size_t)kTrWgMaxTiles * kTrMaxSplit * 128 * 256;
     s.part_b = o; o += tr_al((size_t)kTrWgMaxTiles * kTrMaxSplit * 128);
-    s.wdw = o; o += (size_t)L * kWnSteps * (kWnStepBytes / 4) + kTrSlack;     // Winograd-transformed transposed conv weights (train_wino_bwd.hpp) + prefetch slack
     s.total = o;
     return s;
 }

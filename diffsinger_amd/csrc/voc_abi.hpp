@@ -51,19 +51,28 @@ static void voc_conv_launch(const VocConvParams& p, int B, hipStream_t s) {
     hipLaunchKernelGGL((k_voc_conv<NB, WT, HALO>), grid, dim3(kThreads), lds, s, p);
 }
 
-extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t rows, int32_t KT,
-                          int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in,
-                          float divide, int32_t act, void* stream) {
-    if (!in || !wpacked || !out) return fail(DSD_ERR_INVALID, "dsv_conv1d: null argument");
+static int voc_conv_fill(VocConvParams& p, const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t rows, int32_t KT,
+                         int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in, float divide,
+                         int32_t act, const char* who) {
+    if (!in || !wpacked || !out) return fail(DSD_ERR_INVALID, "%s: null argument", who);
     if (B < 1 || B > 65535 || Ci < 1 || rows < 1 || KT < 1 || dil < 1 || L_in < 1 || up < 1 || (rows % up) || pad < 0 || pad > kVocHaloWide ||
         (KT - 1) * dil - pad > kVocHaloWide || (KT - 1) * dil - pad < 0 || act < 0 || act > 1 || divide == 0.f || (int64_t)L_in * up > (1 << 30))
-        return fail(DSD_ERR_INVALID, "dsv_conv1d: bad shape (B=%d Ci=%d rows=%d K=%d pad=%d dil=%d L=%d up=%d act=%d); taps must stay within +-%d samples",
+        return fail(DSD_ERR_INVALID, "%s: bad shape (B=%d Ci=%d rows=%d K=%d pad=%d dil=%d L=%d up=%d act=%d); taps must stay within +-%d samples", who,
                     B, Ci, rows, KT, pad, dil, L_in, up, act, kVocHaloWide);
-    VocConvParams p{};
+    p = VocConvParams{};
     p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias; p.out = out; p.res = residual; p.sum_in = sum_in;
     p.Ci = Ci; p.rows = rows; p.KT = KT; p.pad = pad; p.dil = dil;
     p.Li = L_in; p.LSi = voc_ls(L_in); p.U = up; p.Lo = L_in * up; p.LSo = voc_ls(p.Lo);
     p.pre_slope = pre_slope; p.divide = divide; p.act = act;
+    return DSD_OK;
+}
+
+extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t rows, int32_t KT,
+                          int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in,
+                          float divide, int32_t act, void* stream) {
+    VocConvParams p{};
+    const int rc = voc_conv_fill(p, in, wpacked, bias, out, B, Ci, rows, KT, pad, dil, L_in, up, pre_slope, residual, sum_in, divide, act, "dsv_conv1d");
+    if (rc != DSD_OK) return rc;
     // narrow layers: one row block, the four waves split 512 samples; 64 rows: 2 x 2; wide (low-rate) layers: four row blocks x 32 samples
     const bool wide = pad > kVocHalo || (KT - 1) * dil - pad > kVocHalo;        // taps beyond the +-28 samples of the standard staging window
     if (wide) {
@@ -154,15 +163,34 @@ static int voc_chain_geometry(const dsv_chain_conv* convs, int nres, int npairs,
     return 0;
 }
 
-template <int C, int F, int NB>
+template <int C, int F, int NB, bool IP>
 static int voc_chain_launch(VocChainParams& p, const dsv_chain_conv* convs, int B, hipStream_t s) {
     if (voc_chain_geometry<C, F, NB>(convs, p.nres, p.npairs, &p.N, &p.Hh) != 0)
         return fail(DSD_ERR_INVALID, "dsv_resblock_chain: the chain does not fit the staged tile (ask dsv_chain_supported first)");
-    constexpr int lds = chain_lds_bytes<C, F, NB>();
-    if (first_on_device(300 + C)) HIP_TRY(hipFuncSetAttribute((const void*)k_voc_chain<C, F, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    constexpr int lds = chain_lds_bytes<C, F, NB, IP>();
+    if (first_on_device(300 + C + 1000 * NB + 10000 * (int)IP))
+        HIP_TRY(hipFuncSetAttribute((const void*)k_voc_chain<C, F, NB, IP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const dim3 grid((unsigned)((p.LS + p.N - 1) / p.N), (unsigned)B);
-    hipLaunchKernelGGL((k_voc_chain<C, F, NB>), grid, dim3(kThreads), lds, s, p);
+    hipLaunchKernelGGL((k_voc_chain<C, F, NB, IP>), grid, dim3(kThreads), lds, s, p);
     HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+// Which instantiation a channel count runs on: column blocks per wave NB (window = 128 NB F samples) and one tile in place / two tiles.
+// dsv_set_chain_variant is the A/B switch of the measurement (profiles/r6_*_voc_chain_variants.jsonl); every variant is bit-identical.
+struct ChainVariant { int nb, ip; };
+static ChainVariant g_chain_variant[3] = {{2, 1}, {2, 1}, {4, 1}};       // C = 8, 16, 32: the fastest of each (profiles/r6_02_voc_chain_variants_modes.jsonl, r6_03_voc_chain_variants.jsonl)
+static inline int chain_slot(int C) { return C == 8 ? 0 : C == 16 ? 1 : C == 32 ? 2 : -1; }
+static inline bool chain_variant_built(int C, int nb, int ip) {
+    if (C == 32) return nb == 4;                                         // <32,1,4,false> (rounds 3-5), <32,1,4,true>
+    return (nb == 2) || (nb == 4 && ip == 1);                            // <C,F,2,false> (rounds 3-5), <C,F,2,true>, <C,F,4,true>
+}
+
+extern "C" int dsv_set_chain_variant(int32_t C, int32_t nb, int32_t in_place) {
+    const int sl = chain_slot(C);
+    if (sl < 0 || !chain_variant_built(C, nb, in_place ? 1 : 0))
+        return fail(DSD_ERR_INVALID, "dsv_set_chain_variant: no kernel for C=%d with %d column blocks per wave, %s", C, nb, in_place ? "one tile in place" : "two tiles");
+    g_chain_variant[sl] = ChainVariant{nb, in_place ? 1 : 0};
     return DSD_OK;
 }
 
@@ -172,9 +200,12 @@ extern "C" int dsv_debug_chain_timeline(uint64_t* device_stamps) { g_chain_dbg =
 extern "C" int32_t dsv_chain_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs) {
     if (!convs || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs) return 0;
     int n = 0, hh = 0, rc = -1;
-    if (C == 8) rc = voc_chain_geometry<8, 4, 2>(convs, nres, npairs, &n, &hh);
-    else if (C == 16) rc = voc_chain_geometry<16, 2, 2>(convs, nres, npairs, &n, &hh);
-    else if (C == 32) rc = voc_chain_geometry<32, 1, 4>(convs, nres, npairs, &n, &hh);
+    const int sl = chain_slot(C);
+    if (sl < 0) return 0;
+    const int nb = g_chain_variant[sl].nb;
+    if (C == 8) rc = (nb == 4) ? voc_chain_geometry<8, 4, 4>(convs, nres, npairs, &n, &hh) : voc_chain_geometry<8, 4, 2>(convs, nres, npairs, &n, &hh);
+    else if (C == 16) rc = (nb == 4) ? voc_chain_geometry<16, 2, 4>(convs, nres, npairs, &n, &hh) : voc_chain_geometry<16, 2, 2>(convs, nres, npairs, &n, &hh);
+    else rc = voc_chain_geometry<32, 1, 4>(convs, nres, npairs, &n, &hh);
     return rc == 0 ? n : 0;
 }
 
@@ -184,6 +215,7 @@ extern "C" int dsv_resblock_chain(const float* in, const float* wpacked, const f
                                   int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream) {
     if (!in || !wpacked || !bias || !out || !convs) return fail(DSD_ERR_INVALID, "dsv_resblock_chain: null argument");
     if (in == out) return fail(DSD_ERR_INVALID, "dsv_resblock_chain: in and out must be different buffers (workgroups read their neighbours' samples)");
+    if (sum_in == out) return fail(DSD_ERR_INVALID, "dsv_resblock_chain: sum_in and out must be different buffers (out holds the running sum over the resblocks of the call)");
     if (!(pre_slope >= 0.f && pre_slope <= 1.f)) return fail(DSD_ERR_INVALID, "dsv_resblock_chain: pre_slope must be in [0, 1] (leaky_relu as max(v, slope v))");
     if (B < 1 || B > 65535 || L < 1 || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs || divide == 0.f || !dsv_chain_fold(C))
         return fail(DSD_ERR_INVALID, "dsv_resblock_chain: bad shape (B=%d C=%d L=%d nres=%d npairs=%d): 8, 16 or 32 channels, at most %d convolutions", B, C,
@@ -199,9 +231,15 @@ extern "C" int dsv_resblock_chain(const float* in, const float* wpacked, const f
         p.conv[i].woff = (int)(c.w_offset / 4); p.conv[i].boff = c.bias_offset; p.conv[i].KT = c.K + F - 1; p.conv[i].dil = c.dil;
         p.conv[i].pad = (c.K - 1) * c.dil / 2;
     }
-    if (C == 8) return voc_chain_launch<8, 4, 2>(p, convs, B, (hipStream_t)stream);
-    if (C == 16) return voc_chain_launch<16, 2, 2>(p, convs, B, (hipStream_t)stream);
-    return voc_chain_launch<32, 1, 4>(p, convs, B, (hipStream_t)stream);
+    const ChainVariant v = g_chain_variant[chain_slot(C)];
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 32) return v.ip ? voc_chain_launch<32, 1, 4, true>(p, convs, B, st) : voc_chain_launch<32, 1, 4, false>(p, convs, B, st);
+    if (C == 16) {
+        if (v.nb == 4) return voc_chain_launch<16, 2, 4, true>(p, convs, B, st);
+        return v.ip ? voc_chain_launch<16, 2, 2, true>(p, convs, B, st) : voc_chain_launch<16, 2, 2, false>(p, convs, B, st);
+    }
+    if (v.nb == 4) return voc_chain_launch<8, 4, 4, true>(p, convs, B, st);
+    return v.ip ? voc_chain_launch<8, 4, 2, true>(p, convs, B, st) : voc_chain_launch<8, 4, 2, false>(p, convs, B, st);
 }
 
 extern "C" int dsv_noise_conv(const float* har, const float* w, const float* bias, float* out, int32_t B, int32_t C, int32_t K, int32_t stride,

@@ -52,11 +52,53 @@ struct VocChainParams {
 
 template <int F, int NB> constexpr int chain_wpos() { return 128 * NB * F; }                     // samples a dilation-1 convolution covers
 template <int F, int NB> constexpr int chain_ld() { return chain_wpos<F, NB>() + 2 * kChainSlack; }
-template <int C, int F, int NB> constexpr int chain_lds_bytes() { return (2 * C * chain_ld<F, NB>() + 256) * (int)sizeof(float); }
+// IP = ONE tile, rewritten IN PLACE: a convolution's epilogue writes leaky_relu(result) over the tile the contraction just read (one more
+// barrier per convolution - behind the last MFMA, where the waves arrive together anyway).  Half the LDS: twice the workgroups per CU, or
+// twice the window (the receptive-field overlap of a 512-sample window is 1.33 x the useful FLOPs, of a 1024-sample window 1.13 x).
+template <int C, int F, int NB, bool IP> constexpr int chain_lds_bytes() { return ((IP ? 1 : 2) * C * chain_ld<F, NB>() + 256) * (int)sizeof(float); }
+template <int C, int F, int NB, bool IP> constexpr int chain_wg_per_cu() {
+    return (chain_lds_bytes<C, F, NB, IP>() <= 40 * 1024 && NB <= 2) ? 3 : (chain_lds_bytes<C, F, NB, IP>() <= 80 * 1024) ? 2 : 1;
+}
+
+// F consecutive floats (F = 1, 2, 4) of the row at byte offset `soff` (wave-uniform: an SGPR) behind a buffer descriptor, lane offset `voff` bytes
+template <int F>
+__device__ __forceinline__ void chain_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&d)[F]) {
+    if constexpr (F == 1) {
+        d[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    } else if constexpr (F == 2) {
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        const f32x2_ f = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+        d[0] = f.x; d[1] = f.y;
+    } else {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const f32x4_ f = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+        d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
+    }
+}
+template <int F>
+__device__ __forceinline__ void chain_st(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&d)[F]) {
+    if constexpr (F == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d[0]), r, voff, soff, 0);
+    } else if constexpr (F == 2) {
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        const f32x2_ f = {d[0], d[1]};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f), r, voff, soff, 0);
+    } else {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const f32x4_ f = {d[0], d[1], d[2], d[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, f), r, voff, soff, 0);
+    }
+}
 
 // K loop of one convolution: A fragments stream from global / L2 (6 register stages), B from the LDS tile with a lane-specific offset per
 // column block (pos(c) is not linear in the column once dil > 1) and a RUNNING chunk pointer (tap + 1, wrap to the next 8-channel group).
-template <int NB, int LD>
+// CONSTB (F == 1: pos(c) = c for every dilation): the column blocks of a wave sit 32 floats apart - compile-time ds_read offsets instead of
+// NB lane-offset additions per chunk (0.4 vector-ALU instructions per MFMA in rounds 3-5, profiles/r5_32_isa_scan.txt).
+template <int NB, int LD, bool CONSTB>
 struct ChainPipe {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned aoff;
@@ -97,7 +139,7 @@ struct ChainPipe {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) dst[s][nb] = bp[s * LD + boff[nb]];
+            for (int nb = 0; nb < NB; ++nb) dst[s][nb] = CONSTB ? bp[s * LD + 32 * nb] : bp[s * LD + boff[nb]];
     }
     __device__ __forceinline__ void pattern() {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -147,13 +189,13 @@ struct ChainPipe {
 };
 
 // grid (ceil(LS / N), B); 4 waves, wave w owns the columns [32 NB w, 32 NB (w + 1)) of every convolution
-template <int C, int F, int NB>
-__global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024) ? 2 : 1) void k_voc_chain(const VocChainParams p) {
+template <int C, int F, int NB, bool IP>
+__global__ __launch_bounds__(kThreads, (chain_wg_per_cu<C, F, NB, IP>())) void k_voc_chain(const VocChainParams p) {
     static_assert(C * F == 32 && (C % 8) == 0, "one 32-row MFMA block: 8 channels x 4, 16 x 2 or 32 x 1");
     constexpr int LD = chain_ld<F, NB>(), SLK = kChainSlack, NCOL4 = LD / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bufA = smem;                     // [C][LD] leaky_relu(y): input of convs1
-    float* bufT = smem + C * LD;            // [C][LD] leaky_relu(xt): input of convs2
+    float* bufT = IP ? smem : smem + C * LD;   // [C][LD] leaky_relu(xt): input of convs2 (IP: the same tile, rewritten in place)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * p.N, b = blockIdx.y;
@@ -164,20 +206,66 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
     const float* inb = p.in + (size_t)b * C * LS;
 
     // the scratch columns of T are read (for samples nobody needs) before anything wrote them: make them finite once
-    for (int idx = tid; idx < (C * LD + 256) / 4; idx += kThreads) *reinterpret_cast<float4*>(bufT + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (IP: every column of the one tile is staged from x; only the 256 floats behind it are cleared)
+    for (int idx = tid + (IP ? C * LD / 4 : 0); idx < (C * LD + 256) / 4; idx += kThreads) *reinterpret_cast<float4*>(bufT + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    f32x16 y[NB], sum[NB];
+    f32x16 y[NB];
+    // The running sum over the parallel resblocks lives in `out` itself (round 6; rounds 3-5 kept it in 16 NB registers): the workgroup owns the
+    // samples [t0, t0 + N) of every channel, writes y_0 there, then y_0 + y_1, then (sum_in + (y_0 + y_1 + y_2)) / divide - the additions of the
+    // one-convolution path in their order; the same lanes store and reload the same addresses (coherent inside a CU).  What it buys: the
+    // 64 registers that stood between the 32-channel kernel and two workgroups per CU.
+    // Register quad q of a column = rows 8 q + 4 h + (0..3) of the 32-row block = 4 / F channels x F consecutive samples from t = ws + c F:
+    // group g = 4 q / F + i of the lane holds channel (8 / F) q + i + (4 / F) h - the half-wave term goes into the lane's byte offset, the rest
+    // is a wave-uniform row offset; t0, N, Hh are multiples of 4 and LS of 32, so the F samples of a group are inside a range together.
+    const int tend = min(t0 + p.N, LS);
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * C * LS, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_sin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.sum_in ? p.sum_in + (size_t)b * C * LS : p.in), 0, 0x7ffffff0, 0x00020000);
+    const bool have_sin = p.sum_in != nullptr;
+    constexpr int NG = 16 / F;               // groups of F registers per column
+    auto flush = [&](bool first, bool last) {
+        // (nothing below depends on the convolution index: without the opaque zero hipcc computes the addresses once, in front of the loop,
+        // and keeps them in registers across every contraction)
+        int oz = 0;
+        asm volatile("" : "+v"(oz));
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb) {
+            const int t = ws + (cw + 32 * nb + j + oz) * F;
+            const bool ok = t >= t0 && t < tend;
+            const int voff = ((4 / F) * h * LS + (ok ? t : t0)) * 4;
+            float pv[NG][F], sv[NG][F];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum[nb][r] = 0.f;
+            for (int g = 0; g < NG; ++g) {                       // all the reads first
+                const int soff = ((8 / F) * (g * F / 4) + (g * F % 4) / F) * LS * 4;
+                if (!first) chain_ld<F>(r_out, voff, soff, pv[g]);
+                if (last && have_sin) chain_ld<F>(r_sin, voff, soff, sv[g]);
+            }
+            if (!ok) continue;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int soff = ((8 / F) * (g * F / 4) + (g * F % 4) / F) * LS * 4;
+                float v[F];
+#pragma unroll
+                for (int e = 0; e < F; ++e) {
+                    v[e] = y[nb][g * F + e];
+                    if (!first) v[e] = pv[g][e] + v[e];
+                    if (last) {
+                        if (have_sin) v[e] = sv[g][e] + v[e];
+                        if (p.divide != 1.f) v[e] = v[e] / p.divide;
+                        if (t + e >= L) v[e] = 0.f;
+                    }
+                }
+                chain_st<F>(r_out, voff, soff, v);
+            }
+        }
+    };
 
     const int total = p.nres * p.npairs * 2;
     // every sample this workgroup can write to a tile (columns SLK .. SLK + WPOS + F * dil) lies inside [0, L): no range masks in the epilogues
     const bool interior = (ws >= 0) && (ws + chain_wpos<F, NB>() + SLK <= L);
     const bool stamp = p.dbg != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0;
     auto mark = [&](int n, int k) { if (stamp) p.dbg[(n * 4 + w) * 4 + k] = __builtin_amdgcn_s_memtime(); };
-    ChainPipe<NB, LD> pipe(p.wp + p.conv[0].woff, lane);
+    ChainPipe<NB, LD, F == 1> pipe(p.wp + p.conv[0].woff, lane);
     pipe.start_a();
     int q = 0;                              // pair of the convolution n inside its resblock
 #pragma unroll 1
@@ -220,19 +308,14 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int t = ws + (cw + 32 * nb + j + oz) * F;
-                if constexpr (F == 4) {
+                const bool ok = t >= 0 && t < LS;
+                const int voff = ((4 / F) * h * LS + (ok ? t : 0)) * 4;
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (t >= 0 && t < LS) v = *reinterpret_cast<const float4*>(inb + (size_t)(2 * rg + h) * LS + t);
-                        set4(y[nb], rg, v);
-                    }
-                } else {
+                for (int g = 0; g < NG; ++g) {
+                    float v[F];
+                    chain_ld<F>(r_in, voff, ((8 / F) * (g * F / 4) + (g * F % 4) / F) * LS * 4, v);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = frag_row(r, h), co = row / F, e = row % F;
-                        y[nb][r] = (t + e >= 0 && t + e < LS) ? inb[(size_t)co * LS + t + e] : 0.f;
-                    }
+                    for (int e = 0; e < F; ++e) y[nb][g * F + e] = ok ? v[e] : 0.f;
                 }
             }
             __syncthreads();
@@ -251,17 +334,6 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
             rel[nb] = g * (F * dil) + (c - g * dil);
             boff[nb] = rel[nb] - rel[0];
         }
-        // the bias of this lane's channels through SCALAR loads (constant address space: s_load, lgkmcnt): a vector load issued here and used in the
-        // epilogue made hipcc wait for the next convolution's weight prefetch (vmcnt counts in order) - an L2 round trip in front of every epilogue
-        typedef const __attribute__((address_space(4))) float cfloat;
-        cfloat* bias_c = (cfloat*)(p.bias + cv.boff);
-        float bv[16 / F];
-#pragma unroll
-        for (int i = 0; i < 16 / F; ++i) {
-            const int c0 = (((i * F) & 3) + 8 * ((i * F) >> 2)) / F;            // frag_row(i F, 0) / F; the other half-wave: + 4 / F
-            const float b0 = bias_c[c0], b1 = bias_c[c0 + 4 / F];
-            bv[i] = h ? b1 : b0;
-        }
         f32x16 acc[1][NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -277,6 +349,22 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
             pipe.start_a();
         }
         const bool last_of_res = (ci == 1 && q == p.npairs - 1);        // the last convolution of a resblock feeds no further one
+        if constexpr (IP) {
+            // in place: nobody may write the tile before every wave has read its last operand of THIS convolution
+            if (!last_of_res) __syncthreads();
+        }
+        // the bias of this lane's channels through SCALAR loads (constant address space: s_load, lgkmcnt): a vector load issued here and used in the
+        // epilogue made hipcc wait for the next convolution's weight prefetch (vmcnt counts in order) - an L2 round trip in front of every epilogue.
+        // Requested BEHIND the contraction (round 6): 16 / F registers less while it runs
+        typedef const __attribute__((address_space(4))) float cfloat;
+        cfloat* bias_c = (cfloat*)(p.bias + cv.boff);
+        float bv[16 / F];
+#pragma unroll
+        for (int i = 0; i < 16 / F; ++i) {
+            const int c0 = (((i * F) & 3) + 8 * ((i * F) >> 2)) / F;            // frag_row(i F, 0) / F; the other half-wave: + 4 / F
+            const float b0 = bias_c[c0], b1 = bias_c[c0 + 4 / F];
+            bv[i] = h ? b1 : b0;
+        }
         // Epilogue: v = acc + bias (+ y -> the new y), leaky_relu(v) -> the other tile.  The first version spent 6 650 cycles per convolution here
         // (64 values x ~100 cycles of index / mask arithmetic, profiles/r10_voc_chain_timeline.txt): row and step of a register are compile-time
         // constants up to the half-wave term, which moves into the lane's base pointer; tiles whose every writable sample lies inside [0, L) -
@@ -336,11 +424,7 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
         mark(n, 3);
         if (ci == 1) {
             if (last_of_res) {
-                const bool first = (n == 2 * p.npairs - 1);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sum[nb][r] = first ? y[nb][r] : sum[nb][r] + y[nb][r];
+                flush(n == 2 * p.npairs - 1, n == total - 1);
                 q = 0;
             } else {
                 ++q;
@@ -348,46 +432,6 @@ __global__ __launch_bounds__(kThreads, (chain_lds_bytes<C, F, NB>() <= 80 * 1024
         }
     }
 
-    // out = (sum_in + sum) / divide for the samples [t0, t0 + N) of this workgroup, zero in [L, LS)
-    float* outb = p.out + (size_t)b * C * LS;
-    const float* sinb = p.sum_in ? p.sum_in + (size_t)b * C * LS : nullptr;
-    const int tend = min(t0 + p.N, LS);
-    if constexpr (F == 4) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int t = ws + (cw + 32 * nb + j) * 4;
-            if (t < t0 || t >= tend) continue;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int co = 2 * rg + h;
-                const size_t o = (size_t)co * LS + t;
-                float4 v = get4(sum[nb], rg);
-                if (sinb) { const float4 s4 = *reinterpret_cast<const float4*>(sinb + o); v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w; }
-                if (p.divide != 1.f) { v.x = v.x / p.divide; v.y = v.y / p.divide; v.z = v.z / p.divide; v.w = v.w / p.divide; }
-                if (t + 0 >= L) v.x = 0.f;
-                if (t + 1 >= L) v.y = 0.f;
-                if (t + 2 >= L) v.z = 0.f;
-                if (t + 3 >= L) v.w = 0.f;
-                *reinterpret_cast<float4*>(outb + o) = v;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int c = cw + 32 * nb + j;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = frag_row(r, h), co = row / F, e = row % F;
-                const int t = ws + c * F + e;
-                if (t < t0 || t >= tend) continue;
-                const size_t o = (size_t)co * LS + t;
-                float v = sum[nb][r];
-                if (sinb) v = sinb[o] + v;
-                if (p.divide != 1.f) v = v / p.divide;
-                outb[o] = (t < L) ? v : 0.f;
-            }
-        }
-    }
 }
 
 }  // namespace dsd

@@ -32,6 +32,7 @@ constexpr int kVocHalo = 28;               // taps reach +-25 samples (kernel 11
 constexpr int kVocHaloWide = 48;           // second instantiation of k_voc_conv: taps up to +-48 samples (the official v3 generator: kernel 7 at
                                            // dilation 12 = 36), hifigan.py:104-179 accepts any config
 constexpr int kVocLdsBudget = 72 * 1024;   // two workgroups per CU
+constexpr int kVocStageBatch = 8;          // staging loads a thread keeps in flight
 
 template <int NB, int WT> constexpr int voc_span() { return 32 * NB * WT; }                    // samples per workgroup
 template <int NB, int WT, int HALO = kVocHalo> constexpr int voc_ld() { return voc_span<NB, WT>() + 2 * HALO; }  // LDS row stride
@@ -81,8 +82,8 @@ struct VocTapB {
 __device__ __forceinline__ float voc_lrelu(float v, float slope) { return (v > 0.f) ? v : v * slope; }
 
 // Workgroup = WR = 4 / WT row blocks of 32 x (WT * NB * 32) samples of one utterance.  Wave w: row block (w % WR), time part (w / WR).
-template <int NB, int WT, int HALO = kVocHalo>
-__global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p) {
+template <int NB, int WT, int HALO>
+__device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
     constexpr int LD = voc_ld<NB, WT, HALO>(), SPAN = voc_span<NB, WT>(), SLAB = voc_slab<NB, WT, HALO>(), WR = 4 / WT;
     constexpr int NCOL4 = LD / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [SLAB][LD]
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w % WR, wt = w / WR;
     const int t0 = blockIdx.x * SPAN, b = blockIdx.y;
-    const int rb = blockIdx.z * WR + wr;                             // this wave's 32-row block
+    const int rb = bz * WR + wr;                                     // this wave's 32-row block
     const int nrb = (p.rows + 31) / 32;
     const int rbc = (rb < nrb) ? rb : nrb - 1;                       // waves past the last block walk valid memory and store nothing
     const int ci8 = (p.Ci + 7) / 8;
@@ -106,15 +107,30 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
         const int nc = min(SLAB, p.Ci - c0);
         const int nc8 = (nc + 7) / 8 * 8;                            // rows [nc, nc8) are staged as zeros (their weights are zero too)
         // stage channels [c0, c0 + nc) x samples [t0 - halo, t0 + SPAN + halo), zero outside [0, LSi), leaky_relu applied here
-        for (int idx = tid; idx < nc8 * NCOL4; idx += kThreads) {
-            const int row = idx / NCOL4, g = idx - row * NCOL4;
-            const int t = t0 - HALO + 4 * g;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nc && t >= 0 && t < p.LSi) {
-                v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + row) * p.LSi + t);
-                v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+        // (eight loads per thread in flight before the first LDS write: a load -> write -> load chain pays the memory latency once per float4 -
+        // 12 round trips for a 64-channel slab, ~16 us of every launch of the 64-channel stage in rounds 2-5, profiles/r57_vocoder_kernel_stats.txt)
+        const int nstage = nc8 * NCOL4;
+        for (int i0 = 0; i0 < nstage; i0 += kVocStageBatch * kThreads) {
+            float4 sv[kVocStageBatch];
+#pragma unroll
+            for (int i = 0; i < kVocStageBatch; ++i) {
+                const int idx = i0 + i * kThreads + tid;
+                const int row = idx / NCOL4, g = idx - row * NCOL4;
+                const int t = t0 - HALO + 4 * g;
+                const bool ok = idx < nstage && row < nc && t >= 0 && t < p.LSi;
+                const float4 v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + (ok ? row : 0)) * p.LSi + (ok ? t : 0));
+                sv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
+            DSD_SB();
+#pragma unroll
+            for (int i = 0; i < kVocStageBatch; ++i) {
+                const int idx = i0 + i * kThreads + tid;
+                const int row = idx / NCOL4, g = idx - row * NCOL4;
+                float4 v = sv[i];
+                v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+                if (idx < nstage) *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
+            }
+            DSD_SB();
         }
         __syncthreads();
         const int nch = (nc8 / 8) * p.KT;
@@ -189,6 +205,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
             if (ok) p.out[((size_t)b * Co + cov[r]) * p.LSo + n] = (n < p.Lo) ? v : 0.f;
         }
     }
+}
+
+template <int NB, int WT, int HALO = kVocHalo>
+__global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p) {
+    voc_conv_body<NB, WT, HALO>(p, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -324,15 +345,28 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv_fold(const VocFoldPara
     const int nc8 = (p.Ci + 7) / 8 * 8;
     const float* inb = p.in + (size_t)b * p.Ci * p.LS;
     const float slope = p.pre_slope;
-    for (int idx = tid; idx < nc8 * NCOL4; idx += kThreads) {
-        const int row = idx / NCOL4, g = idx - row * NCOL4;
-        const int t = t_org + 4 * g;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < p.Ci && t >= 0 && t < p.LS) {
-            v = *reinterpret_cast<const float4*>(inb + (size_t)row * p.LS + t);
-            v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+    const int nstage = nc8 * NCOL4;
+    for (int i0 = 0; i0 < nstage; i0 += kVocStageBatch * kThreads) {          // loads in flight in batches, as in k_voc_conv
+        float4 sv[kVocStageBatch];
+#pragma unroll
+        for (int i = 0; i < kVocStageBatch; ++i) {
+            const int idx = i0 + i * kThreads + tid;
+            const int row = idx / NCOL4, g = idx - row * NCOL4;
+            const int t = t_org + 4 * g;
+            const bool ok = idx < nstage && row < p.Ci && t >= 0 && t < p.LS;
+            const float4 v = *reinterpret_cast<const float4*>(inb + (size_t)(ok ? row : 0) * p.LS + (ok ? t : 0));
+            sv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
+        DSD_SB();
+#pragma unroll
+        for (int i = 0; i < kVocStageBatch; ++i) {
+            const int idx = i0 + i * kThreads + tid;
+            const int row = idx / NCOL4, g = idx - row * NCOL4;
+            float4 v = sv[i];
+            v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+            if (idx < nstage) *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
+        }
+        DSD_SB();
     }
     __syncthreads();
     int pos[NB], boff[NB];

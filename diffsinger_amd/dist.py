@@ -103,14 +103,64 @@ def pad_stack(tensors: Sequence[torch.Tensor], T: int) -> torch.Tensor:
     return out
 
 
+class ShardFailed(RuntimeError):
+    """Raised on EVERY rank of a sharded call when the shard of at least one rank failed: `.rank` is the lowest failed rank (on that rank the
+    original exception is the __cause__)."""
+
+    def __init__(self, rank: int, here: bool, detail: str = ''):
+        self.rank = rank
+        super().__init__(f'sharded inference: the shard of rank {rank} failed' + (f' ({detail})' if here and detail else '') +
+                         ('' if here else ' - this rank\'s shard was fine; nothing was gathered'))
+
+
+def _agree_or_raise(err: Optional[BaseException], rank: int, world: int, group, device):
+    """A failed rank must not leave the others blocked in the gather (rounds 2-5: it raised before `dist.gather`, the other ranks waited in the
+    collective for ever).  Before every gather the ranks exchange ONE int - all_reduce(MIN) over `rank if failed else world` - and on any
+    failure every rank raises the same ShardFailed naming the lowest failed rank; nobody enters the gather."""
+    if world == 1:
+        if err is not None:
+            raise err
+        return
+    dev = _collective_device(group) if device is None else device
+    st = torch.tensor([rank if err is not None else world], dtype=torch.int32, device=dev)
+    dist.all_reduce(st, op=dist.ReduceOp.MIN, group=group)
+    bad = int(st.item())
+    if bad < world:
+        if err is not None:
+            raise ShardFailed(bad, bad == rank, f'{type(err).__name__}: {err}') from err
+        raise ShardFailed(bad, False)
+
+
+# How many following shards a handle stays pinned on the hipGraph path after a shard had to be repeated there (ADVICE r5: restoring the
+# caller's mode at once re-arms the persistent loop - dsd_set_loop_mode clears the handle's own 16-call parking - against a foreign kernel
+# that may still hold CUs: every later shard would run into the seconds-long spin bound again)
+PIN_SHARDS_AFTER_RETRY = 4
+
+
+def _engine_of(model):
+    return getattr(getattr(model, 'denoise_fn', None), '_engine', None)
+
+
+def _unpin_if_due(model):
+    eng = _engine_of(model)
+    pin = getattr(eng, '_dist_pin', None) if eng is not None else None
+    if pin is None:
+        return
+    pin['left'] -= 1
+    if pin['left'] <= 0:
+        eng.set_loop_mode(pin['prev'])                   # (an explicit choice re-arms the persistent path)
+        eng._dist_pin = None
+
+
 def _run_checked(model, run_shard, rank):
     """run_shard() with the loud-failure contract of the persistent loops (include/dsd.h dsd_check): a loop starved by a foreign kernel
     raises 'spin bound'; every rank must still arrive at the collective, so the shard is repeated - with the engine PINNED on the per-layer
-    hipGraph path (loop mode 0: no co-residency requirement) for the whole retry and its mode restored afterwards.  (The handle parks itself
+    hipGraph path (loop mode 0: no co-residency requirement) for the whole retry AND the next PIN_SHARDS_AFTER_RETRY shards, then its mode restored.  (The handle parks itself
     after a report, but only for 16 sampling calls: a shard of more micro-batches than that - 96 ragged utterances in micro-batches of 8 -
     would re-arm the persistent loop in the middle of the retry, against the same foreign kernel: ADVICE r4.)  Loops of LATER micro-batches
     may have been enqueued against the same foreign kernel and latch their timeout after the report: drain the stream and swallow those
     late reports before every retry."""
+    _unpin_if_due(model)
     try:
         return run_shard()
     except RuntimeError as e:
@@ -119,15 +169,14 @@ def _run_checked(model, run_shard, rank):
         first = e
     import warnings
     warnings.warn(f'rank {rank}: {first}  -- repeating the shard on the hipGraph path')
-    eng = getattr(getattr(model, 'denoise_fn', None), '_engine', None)
-    prev = eng.requested_loop_mode() if eng is not None and hasattr(eng, 'requested_loop_mode') else None
+    eng = _engine_of(model)
+    pin = getattr(eng, '_dist_pin', None) if eng is not None else None
+    prev = pin['prev'] if pin else (eng.requested_loop_mode() if eng is not None and hasattr(eng, 'requested_loop_mode') else None)
     if prev is not None:
         eng.set_loop_mode(0)
-    try:
-        return _retry_shard(model, run_shard, first)
-    finally:
-        if prev is not None:
-            eng.set_loop_mode(prev)                      # (an explicit choice also re-arms the persistent path for the next shard)
+        # stays pinned for the next shards too; _unpin_if_due restores the caller's mode
+        eng._dist_pin = {'prev': prev, 'left': PIN_SHARDS_AFTER_RETRY}
+    return _retry_shard(model, run_shard, first)
 
 
 def _retry_shard(model, run_shard, first):
@@ -184,8 +233,13 @@ def sharded_inference(model, conds: Sequence[torch.Tensor], *, micro_batch: int 
             model.check_loops()             # ONE wait per shard: a persistent loop starved by a foreign kernel must not reach the gather as NaN
         return outs
 
-    outs = _run_checked(model, run_shard, rank)
     some = next(c for c in conds if c is not None)          # a rank only needs ITS utterances' conditioners; the others may be None
+    outs, err = None, None
+    try:
+        outs = _run_checked(model, run_shard, rank)
+    except Exception as e:                                  # noqa: BLE001 - whatever it was, the other ranks must hear of it
+        err = e
+    _agree_or_raise(err, rank, world, group, some.device if dist.is_initialized() and dist.get_backend(group) == 'nccl' else None)
     T = some.shape[-1]
     local = torch.cat(outs) if outs else torch.zeros(0, T, model.mel_bins, device=some.device)
     if world == 1:
@@ -211,7 +265,12 @@ def _sharded_inference_ragged(model, conds, lengths, world, rank, micro_batch, m
             model.check_loops()
         return outs
 
-    outs = _run_checked(model, run_shard, rank)
+    outs, err = None, None
+    try:
+        outs = _run_checked(model, run_shard, rank)
+    except Exception as e:                                  # noqa: BLE001
+        err = e
+    _agree_or_raise(err, rank, world, group, some.device if dist.is_initialized() and dist.get_backend(group) == 'nccl' else None)
     # every rank knows every rank's utterances and lengths (the plan is a function of `lengths` and `world`): one gather of flat
     # [frames, M] buffers padded to the heaviest rank, no lengths collective
     seq = [[i for bt, r in zip(batches, owner) if r == rr for i in bt] for rr in range(world)]

@@ -118,7 +118,8 @@ class DenoiserEngine:
         _lib.check(self.lib.dsd_set_conv_mode(self._h, int(m), int(touch_ahead)), 'dsd_set_conv_mode')
 
     def conv_mode(self) -> int:
-        """1 if the prepared batch runs the persistent loop with the Winograd convolution, else 0."""
+        """1 if the dilated convolution of the prepared batch runs as Winograd F(2,3) - on the persistent loop (loop_mode() == 1) or on the
+        latency kernels at G = 2 / 4 / 8 (lat_split()) - else 0 (include/dsd.h dsd_get_conv_mode)."""
         return self.lib.dsd_get_conv_mode(self._h)
 
     def set_loop_mode(self, mode: int):

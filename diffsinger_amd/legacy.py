@@ -37,13 +37,11 @@ class GaussianDiffusion(_ShallowGaussianDiffusion):
             raise RuntimeError('no FastSpeech2 attached (self.fs2): run inside the reference tree, pass fs2=, or call '
                                'sample(cond) with a precomputed conditioner')
         if not infer:
-            # :296-311 - t ~ U[0, num_timesteps), L1 / L2 on the predicted noise with the `mel2ph != 0` non-padding factor
-            from .fs2 import FastSpeech2 as HipFS2
-            if isinstance(self.fs2, HipFS2):                    # the HIP FastSpeech2 has no autograd: a frozen conditioner here
-                with torch.no_grad():
-                    ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=True)
-            else:
-                ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=False)
+            # :296-311 - fs2(skip_decoder=True, infer=False) UNDER AUTOGRAD (the reference's inside its tree, or the HIP one: its backward runs on
+            # HIP kernels since round 3, diffsinger_amd/fs2.py), t ~ U[0, num_timesteps), L1 / L2 on the predicted noise with the `mel2ph != 0`
+            # non-padding factor: the diffusion loss back-propagates through `cond` into a trainable FastSpeech2, as in DiffFsTask
+            # (usr/task.py:19-24, :56-84); a frozen one (requires_grad False) costs no graph
+            ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=True, infer=False)
             cond = ret['decoder_inp'].transpose(1, 2)
             b = txt_tokens.shape[0]
             t = torch.randint(0, self.num_timesteps, (b,), device=txt_tokens.device).long()

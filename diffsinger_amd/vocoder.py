@@ -80,10 +80,13 @@ class DsvChainConv(_C.Structure):
     _fields_ = [('w_offset', _C.c_int64), ('bias_offset', _C.c_int32), ('K', _C.c_int32), ('dil', _C.c_int32), ('reserved', _C.c_int32)]
 
 
-# How the ResBlock1 chains of a stage are launched (csrc/voc_chain.hpp): None = the whole stage - three parallel resblocks of three conv pairs
-# each - as ONE launch wherever the library supports it (8 / 16 / 32 channels; wider stages: one launch per convolution) - the fastest grouping
-# measured (profiles/r07_voc_chain_ab.jsonl); 'stage' / 'resblock' / 'pair' force that grouping; 'off' = one launch per convolution everywhere
-# (the A/B switch of the measurement and of the bit-identity tests).
+# How the ResBlock1 chains of a stage are launched (csrc/voc_chain.hpp): None = one launch per RESBLOCK (three conv pairs; the three parallel
+# resblocks of a stage run one after the other, the running sum handed on through `sum_in`) wherever the library supports it (8 / 16 / 32
+# channels; wider stages: one launch per convolution).  A launch's halo is the receptive field of ITS chain: 12 / 36 / 60 samples for the
+# kernel-3 / 7 / 11 resblocks instead of 60 for all three in a whole-stage launch - the fastest grouping since round 6 (32 channels: 1.51 ms
+# against 1.59 for the stage, 16: 0.91 / 0.95, 8: 0.595 / 0.60, profiles/r6_02_voc_chain_variants_modes.jsonl; rounds 3-5: the stage, r07).
+# 'stage' / 'resblock' / 'pair' force that grouping; 'off' = one launch per convolution everywhere (the A/B switch of the measurement and of
+# the bit-identity tests).
 _CHAIN_MODE = None
 
 
@@ -383,7 +386,7 @@ class HifiGanGenerator(nn.Module):
         if e is not None:
             C, nres, npairs = e['C'], e['nres'], e['npairs']
             if mode is None:
-                mode = 'stage'
+                mode = 'resblock'
             sub = lambda r0, q0, nr, nq: (DsvChainConv * (nr * nq * 2))(*[e['descs'][(r * npairs + q) * 2 + k] for r in range(r0, r0 + nr)
                                                                        for q in range(q0, q0 + nq) for k in range(2)])
             ops, nk = self._ops, float(self.num_kernels)

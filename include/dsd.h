@@ -187,11 +187,14 @@ int dsd_get_lat_split(dsd_handle* h);
  *     weights instead of six - 2/3 of the convolution's fp32 multiplications, the same dtype (exact-fp32 MFMA, fp32 transforms: weights summed
  *     in fp64 and rounded once at load, inputs one fp32 add).  Results differ from the direct form by reduction order and those roundings
  *     (~1e-5 on a K = 100 loop against a 1e-4 budget; tests/test_gpu_wino.py).
- *   0 the direct K = 768 contraction (k_loop): bit-identical to loop modes 0 and the G = 2 / 4 latency kernels.
- * Every other path (per-layer kernels, latency kernels, dsd_denoise / dsd_p_sample / training) evaluates the direct form.  touch_ahead: steps
+ *   0 the direct K = 768 contraction (k_loop): bit-identical to loop mode 0 and to the G = 2 / 4 latency kernels of this mode.
+ * The row-split latency kernels follow the same switch at G = 2 / 4 / 8 (their conv node is k_lat_conv_w, reading the loop's transformed
+ * weights; round 5) - so dsd_denoise / dsd_p_sample / the sampling calls on a SMALL batch change with it too; G = 16, the per-layer kernels
+ * (loop mode 0) and the training operators always evaluate the direct form, and with mode 0 every path does.  touch_ahead: steps
  * (16 KiB of the transformed-weight stream) the waves of an XCD fetch into their L2 ahead of themselves, 0 = off, -1 = keep (default 16) - a
  * tuning knob of tools/, results do not depend on it.
- * dsd_get_conv_mode: 1 if the prepared batch runs the persistent loop with the Winograd form.  Environment: DSD_CONV=direct|winograd at dsd_create. */
+ * dsd_get_conv_mode: 1 if the prepared batch's convolution runs in the Winograd form - on the persistent loop (dsd_get_loop_mode = 1) or on the
+ * latency kernels at G = 2 / 4 / 8 (dsd_get_lat_split) - else 0.  Environment: DSD_CONV=direct|winograd at dsd_create. */
 int dsd_set_conv_mode(dsd_handle* h, int32_t mode, int32_t touch_ahead);
 int dsd_get_conv_mode(dsd_handle* h);
 

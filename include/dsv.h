@@ -71,7 +71,7 @@ int dsv_conv1d_folded(const float* in, const float* wpacked, const float* bias, 
  *     for r < nres:  y = x ; for q < npairs:  xt = conv[r][q][0](leaky_relu(y)) ; xt = conv[r][q][1](leaky_relu(xt)) ; y = xt + y
  *     out = (sum_in + y_0 + y_1 + ...) / divide            (sum_in may be NULL: the running `xs` of resblocks that ran before this call)
  * for C = 8, 16 or 32 channels (C * F == 32 with the fold F = dsv_chain_fold(C) = 4, 2, 1 of dsv_conv1d_folded).  in, out, sum_in:
- * [B][C][LS(L)], in != out.  convs: HOST array [nres][npairs][2] - the first convolution of a pair at dilation `dil`, the second at 1
+ * [B][C][LS(L)], in != out, sum_in != out (out carries the running sum over the call's resblocks while it runs).  convs: HOST array [nres][npairs][2] - the first convolution of a pair at dilation `dil`, the second at 1
  * ('same' padding, K odd); w_offset = float offset of its packed weight inside `wpacked` (each piece = dsv_pack_weight(rows = 32,
  * Ci = C, K + F - 1) of the F shifted copies W'[co * F + e][ci][s] = w[co][ci][s - e], pieces at multiples of 256 floats, the buffer
  * ending with the slack dsv_packed_floats includes), bias_offset = float offset of its bias [C] inside `bias`.  A workgroup owns N output
@@ -89,6 +89,11 @@ int32_t dsv_chain_fold(int32_t C);
 int32_t dsv_chain_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs);
 int dsv_resblock_chain(const float* in, const float* wpacked, const float* bias, float* out, const float* sum_in, int32_t B, int32_t C,
                        int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream);
+/* A/B switch of the measurement: which instantiation of the chain kernel C = 8 / 16 / 32 channels run on - `nb` column blocks of 32 per wave
+ * (a workgroup's window is 128 * nb * F samples; 2 or 4) and ONE LDS tile rewritten in place (in_place = 1: half the LDS, twice the workgroups
+ * per CU or twice the window) or the two tiles of rounds 3-5 (in_place = 0).  Every variant evaluates the same sums in the same order: the
+ * results do not depend on it.  dsv_chain_supported answers for the variant in force.  Process-wide, not thread-safe (a test / bench switch). */
+int dsv_set_chain_variant(int32_t C, int32_t nb, int32_t in_place);
 /* Measurement hook: DEVICE buffer of 18 * 4 * 4 uint64 (or NULL to switch it off) - the following dsv_resblock_chain launches record the
  * shader clock of ONE workgroup (the middle tile of utterance 0) per convolution n and wave w at [n][w][0..3] = {convolution start,
  * contraction done, epilogue done, barrier passed}. */

@@ -1,4 +1,6 @@
 """GPU-side test plumbing: build the HIP modules with the oracle's seeded weights for a golden case."""
+import functools
+
 import torch
 
 import diffsinger_amd
@@ -55,3 +57,27 @@ def run_hip_case(name, use_graph=True, tile=0, split=False, loop_mode=None, lat_
             out = gd.inference(cond, x_T=inp['x_T'].cuda(), K_step=k_step, pndm_speedup=case['interval'])
     torch.cuda.synchronize()
     return out.cpu().numpy()
+
+
+@functools.lru_cache(maxsize=None)
+def lj_k100_case(rows=(0, 5)):
+    """ONE full-size input of BASELINE configs[1] (8 x 1024, K = 100 DDPM, preset lj_ds_beta6, seed 2024) shared by every test of the GPU suite
+    that needs a K = 100 oracle row of that preset (five tests ran their own ~25-60 s CPU oracle), with the oracle's mel
+    for `rows` - computed ONCE per session, the rows as one oracle batch (usr/diff/shallow_diffusion_tts.py:248-276 on identical
+    (x_T, cond, noise[K]); rows of a batch are independent: SURVEY 8c measured 9.5e-7 between B = 1 and B = 2 on the reference itself)."""
+    from oracle import diffnet_oracle as O
+    pre = H.presets()['lj_ds_beta6']
+    cfg = H.net_config(pre)
+    B, T, K = 8, 1024, 100
+    g = torch.Generator().manual_seed(2024)
+    cond = torch.randn(B, T, 256, generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, generator=g)
+    noise = torch.randn(K, B, 1, 80, T, generator=g)
+    sch = O.make_schedule(H.betas_for(pre))
+    smin = torch.tensor(pre['spec_min'], dtype=torch.float32)[None, None, :]
+    smax = torch.tensor(pre['spec_max'], dtype=torch.float32)[None, None, :]
+    idx = list(rows)
+    with torch.no_grad():
+        want = O.infer_mel(H.oracle_params(cfg), cfg, sch, cond[idx], smin, smax, k_step=K, noises=list(noise[:, idx]), x_T=x_T[idx])
+    return dict(B=B, T=T, K=K, cond=cond, x_T=x_T, noise=noise, want={b: want[i:i + 1] for i, b in enumerate(idx)}, cfg=cfg, pre=pre, sch=sch,
+                smin=smin, smax=smax)

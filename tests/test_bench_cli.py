@@ -51,4 +51,58 @@ def test_gpus_n_without_a_launcher_starts_the_ranks_itself():
     out = r.stderr + r.stdout
     assert r.returncode != 0
     assert 'torch.distributed.run' in out and '--nproc-per-node=2' in out
-    assert '[rank 0 of 2]' in out and '[rank 1 of 2]' in out
+    # the launcher tears the other rank down as soon as one has failed: under load only one of the two may get to print its line
+    assert '[rank 0 of 2]' in out or '[rank 1 of 2]' in out
+
+
+def test_evidence_refuses_a_summary_of_another_binary(tmp_path, monkeypatch):
+    """every round-5 PMC summary under profiles/ was stamped with a round-4 commit.  Summaries now carry the build id of the
+    library they were measured on and the hash of their kernel's device code; bench.py quotes one only if it matches the library it has
+    loaded (same build id, or the same device code of that kernel after a rebuild) - else `traffic: null` and the reason."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    from diffsinger_amd import _lib
+    from diffsinger_amd.build import kernel_isa, write_kernel_isa
+    cur = _lib.build_id()
+    if not kernel_isa(cur):
+        write_kernel_isa()
+    isa = kernel_isa(cur)
+    name = 'k_loop_wino<1, 4>(LoopWinoParams)'
+    assert name in isa and len(isa) > 100
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    os.makedirs(tmp_path / 'profiles')
+    js = {'kernel_tag': 'k_loop_wino<1, 4>', 'frames': 8192, 'round': 'rX', 'hbm_bytes_per_launch': {'total': 7.0, 'note': 'n'}, 'build_id': cur}
+    put = lambda: json.dump(js, open(tmp_path / 'profiles' / 'loop_pmc.json', 'w'))
+    put()
+    t, src = bench.pmc_traffic('k_loop_wino<1, 4>', 8192)
+    assert t == 7.0 and 'round rX' in src and cur[:12] in src
+    assert bench.pmc_traffic('k_loop_wino<1, 4>', 4096)[0] is None and bench.pmc_traffic('k_loop<1>', 8192)[0] is None      # another shape / kernel
+    js['build_id'] = 'deadbeef' * 8
+    put()
+    t, src = bench.pmc_traffic('k_loop_wino<1, 4>', 8192)
+    assert t is None and src.startswith('stale:') and 'deadbeefdead' in src
+    js.update(kernel_isa_name=name, kernel_isa=isa[name])           # the library was rebuilt for an edit elsewhere: this kernel's code is the same
+    put()
+    t, src = bench.pmc_traffic('k_loop_wino<1, 4>', 8192)
+    assert t == 7.0 and 'device code' in src
+    js['kernel_isa'] = '0' * 40
+    put()
+    assert bench.pmc_traffic('k_loop_wino<1, 4>', 8192)[0] is None
+    os.remove(tmp_path / 'profiles' / 'loop_pmc.json')
+    assert bench.pmc_traffic('k_loop_wino<1, 4>', 8192) == (None, 'no profiles/loop_pmc.json')
+
+
+def test_the_n1_line_has_rows_offshape_and_inservice_noise_legs():
+    """the driver-run line carries compact figures for the rows around the path, the off-shapes and the in-service noise path.
+    CPU: the legs exist, are wired into the N = 1 line, can be switched off, and their FLOP accounting is what DESIGN section 10 says."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = _run('--help')
+    assert '--no-extras' in r.stdout
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for key in ("res['rows'] = quick_rows(", "res['offshape'] = offshape(", "res['inservice_noise'] = inservice_noise("):
+        assert key in src
+    assert bench.F_TRAIN_EXEC == 2 * (26_427_392 - 15_728_640 // 3) + 26_427_392 and bench.F_CONV_LAYERS == 15_728_640
+    assert bench.WEIGHT_BYTES == 60_345_664 and bench.F_EVAL_EXEC_WINO == 15_810_560
+    assert not [f for f in os.listdir(os.path.join(ROOT, 'tools')) if f.startswith('gpu_') and f.endswith('.sh')], 'ONE GPU script: tools/gpu.sh'

@@ -108,3 +108,63 @@ def test_shard_maps_are_a_partition():
             assert sorted(flat) == list(range(n))
             inv = unshard_order(n, w)
             assert [flat[inv[i]] for i in range(n)] == list(range(n))
+
+
+class _FailingSampler(_FakeSampler):
+    def __init__(self, fail):
+        self.fail = fail
+
+    def inference(self, cond, x_T=None):
+        if self.fail:
+            raise ValueError('synthetic failure of this rank\'s sampler')
+        return super().inference(cond, x_T=x_T)
+
+
+def _failing_worker(rank, world, port, bad_rank, ragged, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        g = torch.Generator().manual_seed(3)
+        conds = [torch.randn(4, 7 + (3 * i if ragged else 0), generator=g) for i in range(7)]
+        from diffsinger_amd.dist import ShardFailed
+        try:
+            sharded_inference(_FailingSampler(rank == bad_rank), conds, micro_batch=2, dst=0)
+            q.put((rank, 'returned'))
+        except ShardFailed as e:
+            q.put((rank, 'ShardFailed', e.rank, type(e.__cause__).__name__ if e.__cause__ is not None else None, str(e)))
+        # the group is still usable: nobody is stuck in a half-entered gather
+        out = sharded_inference(_FakeSampler(), conds, micro_batch=2, dst=0)
+        q.put((rank, 'second call', out is not None))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('ragged', [False, True])
+def test_a_failed_rank_fails_every_rank_instead_of_hanging_the_gather(ragged):
+    """a rank whose sampler raised used to leave before `dist.gather`; the others blocked in the collective for ever.  World 3
+    over gloo, rank 1's sampler raises: every rank gets the same ShardFailed naming rank 1 (the failed rank with its own exception as the
+    cause), nobody enters the gather, and the next sharded call on the same group works."""
+    world, bad = 3, 1
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, bad, ragged, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, 'a rank hung or crashed'
+    got = []
+    while not q.empty():
+        got.append(q.get())
+    first = {g[0]: g for g in got if g[1] != 'second call'}
+    assert set(first) == {0, 1, 2}
+    for r, g in first.items():
+        assert g[1] == 'ShardFailed' and g[2] == bad, g
+        assert (g[3] == 'ValueError') == (r == bad), g
+        assert f'rank {bad}' in g[4]
+    second = {g[0]: g[2] for g in got if g[1] == 'second call'}
+    assert second == {0: True, 1: False, 2: False}

@@ -166,5 +166,15 @@ def test_shard_retry_pins_the_engine_off_the_persistent_path_for_more_micro_batc
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         assert _run_checked(m, run_shard, 0) == 'mels'
-    assert eng.requested_loop_mode() == 2                # restored
     assert eng.calls_log[0] is True and not any(eng.calls_log[1:])      # one starved loop, then 24 micro-batches on the per-layer path
+    # the caller's mode is NOT restored at once (dsd_set_loop_mode would clear the handle's parking and every following shard would
+    # run into the seconds-long spin bound again while the foreign kernel is still there): the engine stays pinned for the next
+    # PIN_SHARDS_AFTER_RETRY shards, then the mode comes back
+    from diffsinger_amd.dist import PIN_SHARDS_AFTER_RETRY
+    assert eng.requested_loop_mode() == 0
+    for k in range(PIN_SHARDS_AFTER_RETRY - 1):
+        n0 = len(eng.calls_log)
+        assert _run_checked(m, run_shard, 0) == 'mels' and eng.requested_loop_mode() == 0 and not any(eng.calls_log[n0:])
+    eng.sample = lambda: eng.calls_log.append('free')   # the foreign kernel has gone
+    assert _run_checked(m, run_shard, 0) == 'mels'
+    assert eng.requested_loop_mode() == 2                # restored, the persistent path re-armed

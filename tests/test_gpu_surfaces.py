@@ -179,6 +179,14 @@ def test_legacy_gaussian_diffusion_forward_both_branches():
         want_loss = ((noise - rec).abs() * (inp['mel2ph'] != 0).float().unsqueeze(1)).mean()
     print(f'legacy GaussianDiffusion.forward(infer=False): loss {float(loss):.7f}, oracle {float(want_loss):.7f}')
     assert abs(float(loss) - float(want_loss)) <= 2e-6 * max(1.0, abs(float(want_loss)))
+    # the loss back-propagates through `cond` into a trainable FastSpeech2 (usr/diff/diffusion.py:296-311 under DiffFsTask, usr/task.py:56-84):
+    # round 5 still froze the HIP FastSpeech2 here
+    gd.zero_grad(set_to_none=True)
+    loss.backward()
+    enc = [(n, q.grad) for n, q in gd.fs2.named_parameters() if n.startswith('encoder.') and q.requires_grad]
+    assert enc and all(g_ is not None and bool(torch.isfinite(g_).all()) for _, g_ in enc)
+    assert sum(float(g_.abs().sum()) for _, g_ in enc) > 0, 'no gradient reached the FastSpeech2 encoder through the conditioner'
+    assert all(q.grad is not None for q in gd.denoise_fn.parameters())
 
 
 def test_two_handles_on_two_streams_are_serialised_not_starved():

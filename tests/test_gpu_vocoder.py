@@ -255,6 +255,9 @@ def test_spec2wav_wrapper_and_own_draws():
 
 # ---- fused ResBlock1 chains (csrc/voc_chain.hpp, dsv_resblock_chain) ----------------------------------------------------------------
 
+DEFAULT_CHAIN_VARIANT = {8: (2, 1), 16: (2, 1), 32: (4, 1)}       # csrc/voc_abi.hpp g_chain_variant
+
+
 @pytest.fixture
 def chain_default():
     from diffsinger_amd import vocoder
@@ -285,6 +288,39 @@ def test_resblock_chain_is_bit_identical_to_the_single_convolutions(stage, L, mo
     assert torch.equal(got, want), float((got - want).abs().max())
 
 
+CHAIN_VARIANTS = [(32, 4, 0), (32, 4, 1), (16, 2, 0), (16, 2, 1), (16, 4, 1), (8, 2, 0), (8, 2, 1), (8, 4, 1)]
+
+
+@pytest.mark.parametrize('C,nb,ip', CHAIN_VARIANTS)
+@pytest.mark.parametrize('mode', ['stage', 'pair'])
+def test_every_chain_variant_is_bit_identical(C, nb, ip, mode, chain_default):
+    """dsv_set_chain_variant (include/dsv.h): the window (nb column blocks per wave) and one tile rewritten in place / two tiles select
+    between instantiations of the same sums in the same order - several tiles with a partial last one, and with a running sum coming in."""
+    lib = _lib.load()
+    stage = {32: 1, 16: 2, 8: 3}[C]
+    case = dict(nsf=False, B=2, T=8, seed=41 + stage)
+    h, p, m = _generator(case)
+    m(torch.zeros(1, 80, 4, device=DEV))
+    L = {32: 1500, 16: 3001, 8: 5000}[C]
+    g = torch.Generator().manual_seed(7 * C + nb + ip)
+    x = _cm(torch.randn(3, C, L, generator=g), L).to(DEV)
+    chain_default.set_chain_mode('off')
+    want = m._stage_resblocks(stage, x, L)
+    try:
+        assert lib.dsv_set_chain_variant(C, nb, ip) == 0, lib.dsd_last_error()
+        chain_default.set_chain_mode(mode)
+        got = m._stage_resblocks(stage, x, L)
+        again = m._stage_resblocks(stage, x, L)
+        torch.cuda.synchronize()
+    finally:
+        for c in (8, 16, 32):
+            lib.dsv_set_chain_variant(c, *DEFAULT_CHAIN_VARIANT[c])
+    assert float(got[:, :, L:].abs().max()) == 0
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert torch.equal(again, got)
+    assert lib.dsv_set_chain_variant(32, 2, 1) != 0 and lib.dsv_set_chain_variant(64, 4, 1) != 0
+
+
 @pytest.mark.parametrize('mode', [None, 'stage', 'resblock', 'pair'])
 def test_generator_with_fused_chains_equals_the_unfused_generator(mode, chain_default):
     case = dict(nsf=True, B=3, T=150, seed=77)
@@ -313,3 +349,6 @@ def test_chain_entry_point_refuses_what_it_cannot_tile():
     x = torch.zeros(1, 8, 64, device=DEV)
     assert lib.dsv_resblock_chain(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 1, 8, 64, 1, 1, ok, 0.1, 1.0, None) != 0
     assert b'different buffers' in lib.dsd_last_error()
+    y = torch.zeros(1, 8, 64, device=DEV)
+    assert lib.dsv_resblock_chain(x.data_ptr(), x.data_ptr(), x.data_ptr(), y.data_ptr(), y.data_ptr(), 1, 8, 64, 1, 1, ok, 0.1, 1.0, None) != 0
+    assert b'sum_in and out' in lib.dsd_last_error()

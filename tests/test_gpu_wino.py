@@ -173,7 +173,7 @@ def test_default_path_choice_with_the_winograd_loop():
         cond = torch.randn(B, T, 256, device='cuda').transpose(1, 2)
         eng = gd._engine(cond)
         assert (eng.lat_split(), eng.loop_mode()) == (lat, loop), ((B, T), eng.lat_split(), eng.loop_mode())
-        assert eng.conv_mode() == loop
+        assert eng.conv_mode() == (1 if loop or lat in (2, 4, 8) else 0)      # the latency kernels of G = 2 / 4 / 8 run k_lat_conv_w (include/dsd.h)
     cond = torch.randn(3, 5000, 256, device='cuda').transpose(1, 2)       # 157 tiles per utterance: one utterance per persistent launch = 61 % of the chip
     eng = gd._engine(cond)
     assert eng.lat_split() == 0 and eng.loop_mode() == 0 and eng.conv_mode() == 0      # per-layer kernels: 471 tiles = 92 % of two grid waves
@@ -260,3 +260,77 @@ def test_one_utterance_k100_on_the_winograd_latency_kernels_vs_oracle_and_timing
         print(f'1 x {T}, K = 100 on the latency kernels G = {G}: Winograd {ms["winograd"]:.1f} ms, direct {ms["direct"]:.1f} ms per call; max-abs mel difference '
               f'{d:.3e}' + (f'; Winograd vs oracle {err:.3e}' if err is not None else ''))
         assert d <= 5e-5 and bool(torch.isfinite(outs['winograd']).all())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# Parity margin under stress: Winograd's error grows with the activation magnitude (the transformed operands d0 - d2,
+# d1 + d2 ... are sums of activations, the transformed weights sums of taps), and every other parity figure of this repo is taken at
+# N(0, kaiming) weights and N(0, 1) conditioners (the reference ships no checkpoint).  Here the residual stack's weights AND the conditioner
+# are scaled: x 4 puts the gate pre-activations at ~16 x their usual range.  What the first version of this test (r6_04) showed: at x 4 a K-step
+# loop is CHAOTIC - the exact-fp32 direct loop ends 2.6 from the oracle on a mel of range ~10, the Winograd loop 3.1, each 2.8 from the other:
+# saturated gates amplify any rounding difference (including the reference's own reduction order) by orders of magnitude per step, so a K-step
+# comparison there measures the network's conditioning, not an implementation.  The margin is therefore taken where it is defined: ONE
+# evaluation through the loop (K = 1: x_T -> the t = 0 step -> mel), and the growth over K is reported beside it for both forms.
+# ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('sampler', ['ddpm', 'plms'])
+def test_parity_margin_with_scaled_weights_and_conditioner(sampler):
+    from oracle import diffnet_oracle as O
+    from diffsinger_amd.synth import make_inputs
+    from tests.gpu_helpers import build_hip
+    preset = {'ddpm': 'lj_ds_beta6', 'plms': 'opencpop_ds1000'}[sampler]               # dilation cycle 1 / cycle 4 (d = 1, 2, 4, 8)
+    B, T = 8, 256                                                                         # 64 tiles on the persistent loop (forced)
+    rows = []
+    for scale_w in (1.0, 2.0, 4.0):
+        for K in ((1, 4, 16) if sampler == 'ddpm' else (1000,)):
+            gd, cfg, pre = build_hip(preset, K)
+            p = {k: v.clone() for k, v in H.oracle_params(cfg).items()}
+            scaled = [k for k in p if k.startswith('residual_layers.') and k.endswith('weight')]
+            assert len(scaled) == 4 * cfg.residual_layers
+            for k in scaled:
+                p[k] *= scale_w
+            gd.denoise_fn.load_state_dict(p, strict=True)
+            inp = make_inputs(900 + K, B, T, n_noise=K if sampler == 'ddpm' else 0)
+            inp['cond'] = inp['cond'] * scale_w
+            sch = O.make_schedule(H.betas_for(pre))
+            smin = torch.tensor(pre['spec_min'], dtype=torch.float32)[None, None, :]
+            smax = torch.tensor(pre['spec_max'], dtype=torch.float32)[None, None, :]
+            cond = inp['cond'].transpose(1, 2).contiguous().cuda().transpose(1, 2)
+            eng = gd._engine(cond)
+            eng.set_loop_mode(1)
+            intervals = (1000,) if sampler == 'plms' else (0,)                           # PLMS: ONE iteration = two evaluations (x_T -> x_0 in one step)
+            for interval in intervals:
+                outs = {}
+                for conv in ('winograd', 'direct'):
+                    eng.set_conv_mode(conv)
+                    assert eng.loop_mode() == 1 and eng.conv_mode() == (1 if conv == 'winograd' else 0)
+                    with torch.no_grad():
+                        if sampler == 'ddpm':
+                            outs[conv] = gd.inference(cond, x_T=inp['x_T'].cuda(), noise=inp['noise'].cuda(), K_step=K, pndm_speedup=0).cpu()
+                        else:
+                            outs[conv] = gd.inference(cond, x_T=inp['x_T'].cuda(), K_step=K, pndm_speedup=interval).cpu()
+                    assert eng.loop_timeouts() == 0
+                eng.set_conv_mode('winograd')
+                with torch.no_grad():
+                    if sampler == 'ddpm':
+                        want = O.infer_mel(p, cfg, sch, inp['cond'], smin, smax, k_step=K, noises=list(inp['noise']), x_T=inp['x_T'])
+                    else:
+                        want = torch.cat([O.infer_mel(p, cfg, sch, inp['cond'][b:b + 1], smin, smax, k_step=K, x_T=inp['x_T'][b:b + 1], pndm_interval=interval)
+                                          for b in range(B)])                             # (the reference's PLMS is B = 1 only)
+                scale = max(1.0, float(want.abs().max())) if sampler == 'plms' else 1.0  # PLMS has no clamp: graded relative to max|mel| (quirk 4)
+                e = {k: float((v - want).abs().max()) / scale for k, v in outs.items()}
+                rows.append((scale_w, K, e['winograd'], e['direct']))
+                evals = K if sampler == 'ddpm' else 2
+                print(f'{sampler} ({preset}, {B} x {T}), stack weights and cond x {scale_w:g}, {evals} evaluation(s): max-abs mel err vs the oracle: Winograd loop '
+                      f'{e["winograd"]:.3e} (margin {1e-4 / max(e["winograd"], 1e-12):.1f} x under 1e-4), direct loop {e["direct"]:.3e}')
+                assert bool(torch.isfinite(outs['winograd']).all())
+                # Measured (profiles/r6_06_stress.txt): x 1 - both forms 4.8e-7 (1 evaluation) ... 1.9e-6 (16); x 2 - 1.1e-5 / 6.9e-6 (1), 6.3e-5 / 5.3e-5
+                # (4), 1.8e-2 / 2.1e-2 (16); x 4 - ONE evaluation is already 5.8e-2 / 4.7e-2 from the oracle in BOTH forms: with 16 x the
+                # activation range the 20-layer stack amplifies a rounding difference ~1e5 x per evaluation - no fp32 implementation (the
+                # reference on another BLAS included) is determinate there.  What is asserted: the budget wherever the direct form keeps it,
+                # and everywhere that the Winograd form is no further from the oracle than ~2 x the exact-fp32 direct form.
+                if e['direct'] <= 5e-5:
+                    assert e['winograd'] <= 1e-4
+                assert e['winograd'] <= 3.0 * max(e['direct'], 2e-6), (scale_w, evals, e)
+                if scale_w == 1.0:
+                    assert e['winograd'] <= 1e-5
+            del gd

@@ -7,7 +7,9 @@ line is config 2 only; the others are parity-test cases whose speed is still wor
   cfg5   ONE GPU's shard of config 5: 64 utterances x T=2048, K=100 DDPM, in micro-batches of 16 (what each of 8 ranks does
          before the RCCL gather)
 
-    python tools/bench_configs.py [reps]
+    python tools/bench_configs.py [reps] [--parity]
+--parity: instead of the rates, the oracle over ALL rows of cfg3 (16 x 1024, K = 60) and cfg4 (32 x 1024, 26 evaluations)
+on the box's host cores (1-2 min) against the batch the Winograd loop produced - one JSON line per config with the worst row.
 A "pass" = dsd_prepare (hoisted conditioner projection) + the sampling graph + denorm, inputs resident in HBM."""
 import json
 import os
@@ -92,7 +94,61 @@ def run(name, preset, B, T, k_step, sampler, reps, interval=0, shallow=False, mi
     torch.cuda.empty_cache()
 
 
+def parity(name, preset, B, T, k_step, sampler, interval=0, shallow=False):
+    """Every row of the batch against the oracle on identical inputs (usr/diff/shallow_diffusion_tts.py:248-276): DDPM / shallow rows as
+    oracle batches of 4, PLMS per utterance (the reference's PLMS is B = 1 only; graded relative to max|mel|, quirk 4)."""
+    from oracle import diffnet_oracle as O
+    from tests import helpers as H
+    from diffsinger_amd.synth import make_inputs
+    gd, pre = build(preset, k_step)
+    cfg = H.net_config(pre)
+    p = {k: v.detach().cpu().float().contiguous() for k, v in gd.denoise_fn.state_dict().items()}
+    sch = O.make_schedule(H.betas_for(pre))
+    smin = torch.tensor(pre['spec_min'], dtype=torch.float32)[None, None, :]
+    smax = torch.tensor(pre['spec_max'], dtype=torch.float32)[None, None, :]
+    inp = make_inputs(4242 + k_step + interval, B, T, n_noise=k_step if sampler == 'ddpm' else 0, with_fs2_mel=shallow, spec_min=pre['spec_min'],
+                      spec_max=pre['spec_max'])
+    cond = inp['cond'].transpose(1, 2).contiguous().cuda().transpose(1, 2)
+    with torch.no_grad():
+        if sampler == 'plms':
+            out = gd.inference(cond, x_T=inp['x_T'].cuda(), K_step=k_step, pndm_speedup=interval)
+        elif shallow:
+            out = gd.inference(cond, fs2_mels=inp['fs2_mel'].cuda(), q_noise=inp['q_noise'].cuda(), noise=inp['noise'].cuda(), K_step=k_step,
+                               pndm_speedup=0, gaussian_start=False)
+        else:
+            out = gd.inference(cond, x_T=inp['x_T'].cuda(), noise=inp['noise'].cuda(), K_step=k_step, pndm_speedup=0)
+    out = out.cpu()
+    eng = gd.denoise_fn.engine()
+    assert eng.loop_mode() == 1 and eng.loop_timeouts() == 0
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    errs, t0 = [], time.perf_counter()
+    step = 1 if sampler == 'plms' else 4
+    with torch.no_grad():
+        for b in range(0, B, step):
+            sl = slice(b, b + step)
+            if sampler == 'plms':
+                want = O.infer_mel(p, cfg, sch, inp['cond'][sl], smin, smax, k_step=k_step, x_T=inp['x_T'][sl], pndm_interval=interval)
+            elif shallow:
+                want = O.infer_mel(p, cfg, sch, inp['cond'][sl], smin, smax, k_step=k_step, noises=list(inp['noise'][:, sl]), fs2_mel=inp['fs2_mel'][sl],
+                                   q_noise=inp['q_noise'][sl])
+            else:
+                want = O.infer_mel(p, cfg, sch, inp['cond'][sl], smin, smax, k_step=k_step, noises=list(inp['noise'][:, sl]), x_T=inp['x_T'][sl])
+            for i in range(want.shape[0]):
+                scale = max(1.0, float(want[i].abs().max())) if sampler == 'plms' else 1.0
+                errs.append(float((out[b + i] - want[i]).abs().max()) / scale)
+    print(json.dumps({'config': name, 'preset': preset, 'B': B, 'T': T, 'sampler': sampler, 'rows_checked': len(errs), 'max_err_over_rows': max(errs),
+                      'median_err': sorted(errs)[len(errs) // 2], 'worst_row': errs.index(max(errs)), 'tolerance': 1e-4,
+                      'graded': 'relative to max|mel| of the row (PLMS has no clamp)' if sampler == 'plms' else 'max-abs de-normalised mel',
+                      'kernel': 'k_loop_wino' if eng.conv_mode() == 1 else 'k_loop', 'oracle_seconds': time.perf_counter() - t0, 'pass': max(errs) <= 1e-4}), flush=True)
+    del gd
+    torch.cuda.empty_cache()
+
+
 if __name__ == '__main__':
+    if '--parity' in sys.argv:
+        parity('cfg3 shallow K=60 (Opencpop cascade, cycle 4)', 'opencpop_ds60_rel', 16, 1024, 60, 'ddpm', shallow=True)
+        parity('cfg4 PLMS speedup 40 (26 evals)', 'opencpop_ds1000', 32, 1024, 1000, 'plms', interval=40)
+        sys.exit(0)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     run('cfg2 DiffSpeech K=100 DDPM', 'lj_ds_beta6', 8, 1024, 100, 'ddpm', reps)
     run('cfg3 shallow K=60 (Opencpop cascade, cycle 4)', 'opencpop_ds60_rel', 16, 1024, 60, 'ddpm', reps, shallow=True)

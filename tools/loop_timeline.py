@@ -25,7 +25,7 @@ noise = torch.randn(K, B, 80, T, device=dev, generator=g)
 eng = gd._engine(cond)
 eng.set_loop_mode(1)
 eng.set_conv_mode(CONV, TOUCH)
-WINO = eng.conv_mode() == 1
+WINO = eng.loop_mode() == 1 and eng.conv_mode() == 1
 SPLIT = '--split' in sys.argv
 if SPLIT:
     sys.argv.remove('--split')
@@ -76,6 +76,15 @@ for phase in PHASES or ((43, 44, 63) if not SPLIT else (43, 44, 63, 83)):
 print('timeouts', eng.loop_timeouts())
 if len(sys.argv) > 1:
     import json
+    from diffsinger_amd.build import binary_id, kernel_isa
+    for kv in sys.argv[2:]:                              # round=<tag> ...
+        k_, v_ = kv.split('=', 1)
+        summary[k_] = v_
+    kname = ('k_loop_wino<1, 4>' if WINO else 'k_loop<1>') if not SPLIT else None
+    summary['kernel_tag'], summary['build_id'] = kname, binary_id()
+    hits = {n: h for n, h in kernel_isa().items() if kname and n.startswith(kname)}
+    if len(hits) == 1:
+        (summary['kernel_isa_name'], summary['kernel_isa']), = hits.items()
     summary['phase_cycles_mean'] = sum(summary['phase_cycles']) / len(summary['phase_cycles'])
     summary['head_cycles_mean'] = sum(summary['head_cycles']) / len(summary['head_cycles'])
     summary['shape'] = {'B': B, 'T': T, 'layers': 20}

@@ -40,7 +40,7 @@ for (B, T) in shapes:
         assert eng.loop_timeouts() == 0 and bool(torch.isfinite(out).all())
         if ref is None:
             ref = out
-        wino = eng.conv_mode() == 1
+        wino = eng.loop_mode() == 1 and eng.conv_mode() == 1
         f = bench.F_EVAL_EXEC_WINO if wino else bench.F_EVAL_EXEC
         tf = B * T * K * f / (ms * 1e-3) / 1e12
         print(json.dumps({'shape': [B, T], 'conv': conv, 'touch': touch, 'kernel': 'k_loop_wino' if wino else 'k_loop', 'launches': eng.loop_launches(),
