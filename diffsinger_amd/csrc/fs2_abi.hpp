@@ -259,6 +259,57 @@ extern "C" int dsf_to_channel_major(const float* x, int64_t stride_b, int64_t st
     return DSD_OK;
 }
 
+extern "C" int dsf_positions(const int64_t* tokens, const float* x, int32_t* pos, int32_t B, int32_t T, int32_t C, int32_t padding_idx, void* stream) {
+    if ((!tokens && !x) || !pos || B < 1 || B > 65535 || T < 1 || (x && C < 1))
+        return fail(DSD_ERR_INVALID, "dsf_positions: bad argument (tokens or x, pos; B=%d T=%d C=%d)", B, T, C);
+    FsPosParams p{};
+    p.tok = (const long long*)tokens; p.x = x; p.pos = pos; p.T = T; p.C = C; p.pad = padding_idx;
+    hipLaunchKernelGGL(k_fs_positions, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_input_cm(const int64_t* tokens, const float* emb, float emb_scale, const float* add0, const float* add1, const float* add2, const float* x,
+                            const int32_t* pos, const float* pos_table, const float* alpha_dev, const uint8_t* padding_mask, float* xc, float* keep,
+                            uint8_t* pad_out, int32_t B, int32_t T, int32_t C, int32_t padding_idx, int32_t mask_mode, void* stream) {
+    if ((!tokens) == (!x) || (tokens && !emb) || !xc || !keep || !pad_out || (pos && !pos_table))
+        return fail(DSD_ERR_INVALID, "dsf_input_cm: exactly one of tokens (+ emb) / x, and xc, keep, pad_out");
+    if (B < 1 || B > 65535 || T < 1 || C < 4 || (C & 3) || C > kFsInMaxC || mask_mode < 0 || mask_mode > 1)
+        return fail(DSD_ERR_INVALID, "dsf_input_cm: bad shape (B=%d T=%d C=%d mask_mode=%d; C a multiple of 4, <= %d)", B, T, C, mask_mode, kFsInMaxC);
+    FsInputParams p{};
+    p.tok = (const long long*)tokens; p.emb = emb; p.emb_scale = emb_scale; p.add[0] = add0; p.add[1] = add1; p.add[2] = add2; p.x = x;
+    p.pos = pos; p.pos_tab = pos_table; p.alpha = alpha_dev; p.pad_in = padding_mask; p.xc = xc; p.keep = keep; p.pad_out = pad_out;
+    p.T = T; p.TS = fs_ts(T); p.C = C; p.pad = padding_idx; p.mask_mode = mask_mode;
+    const size_t lds = (size_t)C * 33 * sizeof(float);
+    if (first_on_device(60)) HIP_TRY(hipFuncSetAttribute((const void*)k_fs_input_cm, hipFuncAttributeMaxDynamicSharedMemorySize, kFsInMaxC * 33 * (int)sizeof(float)));
+    hipLaunchKernelGGL(k_fs_input_cm, dim3((unsigned)(p.TS / 32), (unsigned)B), dim3(256), lds, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_gather_frames(const float* enc, const int64_t* mel2ph, const float* spk, float* out, float* out_masked, int32_t B, int32_t T, int32_t T_src,
+                                 int32_t C, void* stream) {
+    if (!enc || !mel2ph || !out || B < 1 || B > 65535 || T < 1 || T_src < 1 || C < 4 || (C & 3))
+        return fail(DSD_ERR_INVALID, "dsf_gather_frames: bad argument (B=%d T=%d T_src=%d C=%d; C a multiple of 4)", B, T, T_src, C);
+    FsGatherParams p{};
+    p.enc = enc; p.mel2ph = (const long long*)mel2ph; p.spk = spk; p.out1 = out; p.out2 = out_masked; p.T = T; p.Tp = T_src; p.C = C;
+    hipLaunchKernelGGL(k_fs_gather_frames, dim3((unsigned)((T + 7) / 8), (unsigned)B), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_sum_embed(const float* dec, const int64_t* idx1, const float* tab1, const float* add1, const int64_t* idx2, const float* tab2, const float* spk,
+                             const int64_t* mel2ph, float* out, int32_t B, int32_t T, int32_t C, void* stream) {
+    if (!dec || !mel2ph || !out || (idx1 && !tab1) || (idx2 && !tab2) || (idx1 && add1) || B < 1 || B > 65535 || T < 1 || C < 4 || (C & 3))
+        return fail(DSD_ERR_INVALID, "dsf_sum_embed: bad argument (B=%d T=%d C=%d; C a multiple of 4)", B, T, C);
+    FsSumEmbedParams p{};
+    p.dec = dec; p.idx1 = (const long long*)idx1; p.tab1 = tab1; p.add1 = add1; p.idx2 = (const long long*)idx2; p.tab2 = tab2; p.spk = spk;
+    p.mel2ph = (const long long*)mel2ph; p.out = out; p.T = T; p.C = C;
+    hipLaunchKernelGGL(k_fs_sum_embed, dim3((unsigned)((T + 7) / 8), (unsigned)B), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
 extern "C" int dsf_from_channel_major(const float* in, float* out, int32_t B, int32_t C, int32_t T, void* stream) {
     if (!in || !out || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_from_channel_major: bad argument");
     const int TS = fs_ts(T);

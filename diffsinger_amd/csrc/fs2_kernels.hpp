@@ -293,6 +293,225 @@ __global__ __launch_bounds__(kThreads) void k_fs_ln(const FsLnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Index / mask glue of the forward as FOUR kernels (round 6; rounds 1-5 left it to ~110 torch launches = 0.5 ms of a 3.2 ms forward:
+// profiles/r6_05_fs2_kernel_stats.txt).  Every value is the one the torch ops produce: the same operations in the same order, one
+// rounding each (the library is built with -ffp-contract=off); positions, indices and masks are integers.
+//   k_fs_positions   utils/__init__.py:145-157 make_positions: pos = cumsum(x != pad) * (x != pad) + pad along the frame axis, for a token
+//                    tensor (FastspeechEncoder.forward_embedding, tts_modules.py:338-346) or for channel 0 of a float tensor
+//                    (FFTBlocks.forward: embed_positions(x[..., 0]), tts_modules.py:291)
+//   k_fs_input_cm    the front end of FFTBlocks.forward (tts_modules.py:288-296) and of FastspeechEncoder / FastspeechMIDIEncoder
+//                    .forward_embedding (:338-346, diffsinger_midi/fs2.py:20-28): token embedding * sqrt(H) (+ up to three more
+//                    embeddings) (+ sinusoidal positions [* alpha]), the padding mask (given, or `x.abs().sum(-1).eq(0)`), `* nonpadding`,
+//                    and the [B,T,C] -> channel-major transposition - writes xc [B][C][TS], keep [B][T] and the u8 key-padding mask
+//   k_fs_gather_frames   the length regulator's gather, fs2.py:128-134: decoder_inp = gather(pad(encoder_out), mel2ph) and
+//                    pitch_inp = (decoder_inp + spk_embed_f0) * (mel2ph > 0)
+//   k_fs_sum_embed   fs2.py:136-141: ((decoder_inp + pitch_embed[idx]) [+ energy_embed[idx]] + spk_embed) * (mel2ph > 0)
+// ------------------------------------------------------------------------------------------------------------
+struct FsPosParams {
+    const long long* tok;   // [B][T] int64 tokens, or nullptr
+    const float* x;         // [B][T][C] float (channel 0 is tested), used when tok == nullptr
+    int* pos;               // [B][T]
+    int T, C, pad;
+};
+
+// one workgroup per utterance; thread k owns the k-th contiguous piece of the frame axis
+__global__ __launch_bounds__(256) void k_fs_positions(const FsPosParams p) {
+    __shared__ int part[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int per = (p.T + 255) / 256;
+    const int i0 = min(p.T, tid * per), i1 = min(p.T, i0 + per);
+    auto nz = [&](int t) -> bool {
+        return p.tok ? (p.tok[(size_t)b * p.T + t] != (long long)p.pad) : (p.x[((size_t)b * p.T + t) * p.C] != (float)p.pad);
+    };
+    int s = 0;
+    for (int t = i0; t < i1; ++t) s += nz(t) ? 1 : 0;
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+    int c = part[tid];
+    for (int t = i0; t < i1; ++t) {
+        const bool z = nz(t);
+        c += z ? 1 : 0;
+        p.pos[(size_t)b * p.T + t] = (z ? c : 0) + p.pad;
+    }
+}
+
+constexpr int kFsInMaxC = 512;             // hidden size of the front end (LDS tile [C][33])
+struct FsInputParams {
+    const long long* tok;   // [B][T] tokens (mode "embedding") or nullptr (mode "tensor")
+    const float* emb;       // [V][C] token embedding table
+    float emb_scale;        // sqrt(C)
+    const float* add[3];    // up to three [B][T][C] tensors added in this order (MIDI pitch / duration / slur embeddings), or nullptr
+    const float* x;         // [B][T][C] input tensor (mode "tensor")
+    const int* pos;         // [B][T] positions or nullptr (no positional embedding)
+    const float* pos_tab;   // [n_pos][C] sinusoidal table
+    const float* alpha;     // DEVICE scalar the positional embedding is multiplied by (pos_embed_alpha), or nullptr (no factor)
+    const unsigned char* pad_in;   // [B][T] given padding mask (nonzero = padded) or nullptr: computed as "every channel of the frame is zero"
+    float* xc;              // [B][C][TS]
+    float* keep;            // [B][T]
+    unsigned char* pad_out; // [B][T]
+    int T, TS, C, pad;
+    int mask_mode;          // 1: the padding mask is applied (xc = value * (1 - padding)); 0: no mask (keep = 1, pad_out = 0: PitchPredictor)
+};
+
+// grid (TS / 32, B); 4 waves, wave w builds the frames 8 w .. 8 w + 7 of the tile (a lane <-> four consecutive channels: 16-byte accesses, 1 KiB
+// per wave instruction), then the tile leaves channel-major
+__global__ __launch_bounds__(256) void k_fs_input_cm(const FsInputParams p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // [C][33]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int t0 = blockIdx.x * 32, b = blockIdx.y, C = p.C;
+    const float alpha = p.alpha ? p.alpha[0] : 1.f;
+    constexpr int NQ = kFsInMaxC / 256;
+    // every load of the wave's eight frames is requested before the first is used (a frame at a time would pay the memory latency eight times)
+    float4 v[8][NQ];
+    bool padded[8];
+#pragma unroll
+    for (int ff = 0; ff < 8; ++ff) {
+        const int t = t0 + 8 * w + ff;
+        const bool tv = t < p.T;
+        const size_t bt = (size_t)b * p.T + (tv ? t : 0);
+        const long long tk = p.tok ? p.tok[bt] : 0;
+        const int ps = p.pos ? p.pos[bt] : 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = 256 * q + 4 * lane;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tv && c < C) {
+                if (p.tok) {
+                    const float4 e = *reinterpret_cast<const float4*>(p.emb + (size_t)tk * C + c);
+                    a = make_float4(p.emb_scale * e.x, p.emb_scale * e.y, p.emb_scale * e.z, p.emb_scale * e.w);
+#pragma unroll
+                    for (int e3 = 0; e3 < 3; ++e3)
+                        if (p.add[e3]) { const float4 d = *reinterpret_cast<const float4*>(p.add[e3] + bt * C + c); a.x = a.x + d.x; a.y = a.y + d.y; a.z = a.z + d.z; a.w = a.w + d.w; }
+                } else {
+                    a = *reinterpret_cast<const float4*>(p.x + bt * C + c);
+                }
+            }
+            v[ff][q] = a;
+        }
+        bool pd = !tv;
+        if (tv && p.mask_mode) {
+            if (p.pad_in) pd = p.pad_in[bt] != 0;
+            else if (p.tok) pd = tk == (long long)p.pad;
+            else {
+                bool nzq = false;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) nzq = nzq || v[ff][q].x != 0.f || v[ff][q].y != 0.f || v[ff][q].z != 0.f || v[ff][q].w != 0.f;
+                pd = __ballot(nzq) == 0ull;                 // x.abs().sum(-1).eq(0): a sum of magnitudes is zero iff every one is
+            }
+        }
+        padded[ff] = pd;
+        if (p.pos && tv) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = 256 * q + 4 * lane;
+                if (c < C) {
+                    const float4 pe = *reinterpret_cast<const float4*>(p.pos_tab + (size_t)ps * C + c);
+                    float4& a = v[ff][q];
+                    if (p.alpha) { a.x = a.x + alpha * pe.x; a.y = a.y + alpha * pe.y; a.z = a.z + alpha * pe.z; a.w = a.w + alpha * pe.w; }
+                    else { a.x = a.x + pe.x; a.y = a.y + pe.y; a.z = a.z + pe.z; a.w = a.w + pe.w; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ff = 0; ff < 8; ++ff) {
+        const int f = 8 * w + ff, t = t0 + f;
+        const bool tv = t < p.T;
+        const float kp = padded[ff] ? 0.f : 1.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = 256 * q + 4 * lane;
+            if (c < C) {
+                const float4 a = v[ff][q];
+                tile[(c + 0) * 33 + f] = tv ? a.x * kp : 0.f; tile[(c + 1) * 33 + f] = tv ? a.y * kp : 0.f;
+                tile[(c + 2) * 33 + f] = tv ? a.z * kp : 0.f; tile[(c + 3) * 33 + f] = tv ? a.w * kp : 0.f;
+            }
+        }
+        if (lane == 0 && tv) { p.keep[(size_t)b * p.T + t] = kp; p.pad_out[(size_t)b * p.T + t] = padded[ff] ? 1 : 0; }
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;                    // 32 frames x 8 channel rows per pass
+    for (int c = ty; c < C; c += 8) p.xc[((size_t)b * C + c) * p.TS + t0 + tx] = tile[c * 33 + tx];
+}
+
+struct FsGatherParams {
+    const float* enc;       // [B][Tp][C] encoder output
+    const long long* mel2ph;// [B][T], 0 = padding frame, k = phone k - 1
+    const float* spk;       // [B][C] speaker embedding added for out2, or nullptr (the reference adds the integer 0)
+    float* out1;            // [B][T][C] decoder_inp = gather(pad(enc), mel2ph)
+    float* out2;            // [B][T][C] (out1 + spk) * (mel2ph > 0), or nullptr
+    int T, Tp, C;
+};
+
+// grid (ceil(T / 8), B); a wave per frame row, lanes <-> float4 of channels
+__global__ __launch_bounds__(256) void k_fs_gather_frames(const FsGatherParams p) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    for (int f = w; f < 8; f += 4) {
+        const int t = blockIdx.x * 8 + f;
+        if (t >= p.T) return;
+        const long long m = p.mel2ph[(size_t)b * p.T + t];
+        const bool live = m > 0;
+        const float* src = p.enc + ((size_t)b * p.Tp + (live ? (size_t)(m - 1) : 0)) * p.C;
+        for (int c = 4 * lane; c < p.C; c += 256) {
+            float4 v = live ? *reinterpret_cast<const float4*>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const size_t o = ((size_t)b * p.T + t) * p.C + c;
+            *reinterpret_cast<float4*>(p.out1 + o) = v;
+            if (p.out2) {
+                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.spk) s4 = *reinterpret_cast<const float4*>(p.spk + (size_t)b * p.C + c);
+                const float kp = live ? 1.f : 0.f;
+                v.x = (v.x + s4.x) * kp; v.y = (v.y + s4.y) * kp; v.z = (v.z + s4.z) * kp; v.w = (v.w + s4.w) * kp;
+                *reinterpret_cast<float4*>(p.out2 + o) = v;
+            }
+        }
+    }
+}
+
+struct FsSumEmbedParams {
+    const float* dec;       // [B][T][C]
+    const long long* idx1;  // [B][T] rows of tab1 (pitch), or nullptr
+    const float* tab1;      // [n][C]
+    const float* add1;      // [B][T][C] a ready embedding instead of (idx1, tab1), or nullptr
+    const long long* idx2;  // [B][T] rows of tab2 (energy), or nullptr
+    const float* tab2;
+    const float* spk;       // [B][C] or nullptr (the reference adds the integer 0)
+    const long long* mel2ph;// [B][T]
+    float* out;             // [B][T][C]
+    int T, C;
+};
+
+__global__ __launch_bounds__(256) void k_fs_sum_embed(const FsSumEmbedParams p) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    for (int f = w; f < 8; f += 4) {
+        const int t = blockIdx.x * 8 + f;
+        if (t >= p.T) return;
+        const size_t bt = (size_t)b * p.T + t;
+        const float kp = (p.mel2ph[bt] > 0) ? 1.f : 0.f;
+        for (int c = 4 * lane; c < p.C; c += 256) {
+            const size_t o = bt * p.C + c;
+            float4 v = *reinterpret_cast<const float4*>(p.dec + o);
+            if (p.idx1 || p.add1) {
+                const float4 e = p.add1 ? *reinterpret_cast<const float4*>(p.add1 + o) : *reinterpret_cast<const float4*>(p.tab1 + (size_t)p.idx1[bt] * p.C + c);
+                v.x = v.x + e.x; v.y = v.y + e.y; v.z = v.z + e.z; v.w = v.w + e.w;
+            }
+            if (p.idx2) {
+                const float4 e = *reinterpret_cast<const float4*>(p.tab2 + (size_t)p.idx2[bt] * p.C + c);
+                v.x = v.x + e.x; v.y = v.y + e.y; v.z = v.z + e.z; v.w = v.w + e.w;
+            }
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.spk) s4 = *reinterpret_cast<const float4*>(p.spk + (size_t)b * p.C + c);
+            v.x = (v.x + s4.x) * kp; v.y = (v.y + s4.y) * kp; v.z = (v.z + s4.z) * kp; v.w = (v.w + s4.w) * kp;
+            *reinterpret_cast<float4*>(p.out + o) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // self-attention core: one wave per (32-query tile, head, utterance)
 // ------------------------------------------------------------------------------------------------------------
 struct FsAttnParams {

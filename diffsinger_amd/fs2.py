@@ -188,6 +188,84 @@ def _from_cm_raw(x_cm: torch.Tensor, T: int) -> torch.Tensor:
 # the layout changes are each other's adjoints.  The fused epilogues of the inference convolution (scale, activation, residual, padding mask)
 # are torch element-wise ops here - glue, not contractions.
 # --------------------------------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------------------------------
+# the index / mask glue of the forward as four operators (include/dsf.h; inference only - under autograd the torch ops below them run)
+# --------------------------------------------------------------------------------------------------------------
+_GLUE = True
+
+
+def set_glue(on: bool):
+    """A/B switch of the tests and of the measurement: False = the index / mask glue as the reference's torch op sequence (rounds 1-5)."""
+    global _GLUE
+    _GLUE = bool(on)
+
+
+def _glue_ok(*tensors) -> bool:
+    """The fused glue operators apply: no autograd graph is being recorded and every tensor lives on a HIP device."""
+    return _GLUE and (not torch.is_grad_enabled()) and all(t is None or (torch.is_tensor(t) and t.is_cuda) for t in tensors)
+
+
+def positions_op(tokens: Optional[torch.Tensor] = None, x: Optional[torch.Tensor] = None, padding_idx: int = 0) -> torch.Tensor:
+    """make_positions (utils/__init__.py:145-157) of an int64 token tensor [B,T] or of channel 0 of a float tensor [B,T,C] -> int32 [B,T]."""
+    src = tokens if tokens is not None else x
+    B, T = src.shape[:2]
+    pos = torch.empty(B, T, device=src.device, dtype=torch.int32)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().dsf_positions(tokens.data_ptr() if tokens is not None else None, x.data_ptr() if x is not None else None, pos.data_ptr(),
+                                             B, T, x.shape[2] if x is not None else 0, int(padding_idx), _stream(src.device)), 'dsf_positions')
+    return pos
+
+
+def input_cm_op(*, tokens=None, emb=None, emb_scale=1.0, adds=(), x=None, pos=None, pos_table=None, alpha=None, padding_mask=None, padding_idx=0, mask=True):
+    """dsf_input_cm: (xc [B][C][TS], keep [B][T], key-padding mask u8 [B][T]) of an FFT stack's input."""
+    src = tokens if tokens is not None else x
+    B, T = src.shape[:2]
+    C = emb.shape[1] if tokens is not None else x.shape[2]
+    dev = src.device
+    xc = torch.empty(B, C, padded_frames(T), device=dev, dtype=torch.float32)
+    keep = torch.empty(B, T, device=dev, dtype=torch.float32)
+    pad = torch.empty(B, T, device=dev, dtype=torch.uint8)
+    adds = [a for a in adds if torch.is_tensor(a)]
+    assert len(adds) <= 3 and all(a.shape == (B, T, C) and a.is_contiguous() and a.dtype == torch.float32 for a in adds)
+    ap = [a.data_ptr() for a in adds] + [None] * (3 - len(adds))
+    pm = None
+    if padding_mask is not None:
+        pm = padding_mask.contiguous()
+        pm = pm.view(torch.uint8) if pm.dtype == torch.bool else pm.to(torch.uint8)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().dsf_input_cm(tokens.data_ptr() if tokens is not None else None, emb.data_ptr() if emb is not None else None, float(emb_scale),
+                                            ap[0], ap[1], ap[2], x.data_ptr() if x is not None else None, pos.data_ptr() if pos is not None else None,
+                                            pos_table.data_ptr() if pos_table is not None else None, alpha.data_ptr() if alpha is not None else None,
+                                            pm.data_ptr() if pm is not None else None, xc.data_ptr(), keep.data_ptr(), pad.data_ptr(), B, T, C,
+                                            int(padding_idx), int(bool(mask)), _stream(dev)), 'dsf_input_cm')
+    return xc, keep, pad
+
+
+def gather_frames_op(enc: torch.Tensor, mel2ph: torch.Tensor, spk):
+    """fs2.py:128-134: (decoder_inp, (decoder_inp + spk) * (mel2ph > 0)); spk: [B,1,C] tensor or the integer 0."""
+    B, Tp, C = enc.shape
+    T = mel2ph.shape[1]
+    out = torch.empty(B, T, C, device=enc.device, dtype=torch.float32)
+    masked = torch.empty_like(out)
+    spk2 = spk.reshape(B, C).contiguous() if torch.is_tensor(spk) else None
+    with torch.cuda.device(enc.device):
+        _lib.check(_lib.load().dsf_gather_frames(enc.data_ptr(), mel2ph.data_ptr(), spk2.data_ptr() if spk2 is not None else None, out.data_ptr(),
+                                                 masked.data_ptr(), B, T, Tp, C, _stream(enc.device)), 'dsf_gather_frames')
+    return out, masked
+
+
+def sum_embed_op(dec: torch.Tensor, mel2ph: torch.Tensor, *, idx1=None, tab1=None, add1=None, idx2=None, tab2=None, spk=None):
+    """fs2.py:136-141: (((decoder_inp + pitch embedding) + energy embedding) + spk) * (mel2ph > 0)."""
+    B, T, C = dec.shape
+    out = torch.empty_like(dec)
+    spk2 = spk.reshape(B, C).contiguous() if torch.is_tensor(spk) else None
+    p = lambda t: t.data_ptr() if t is not None else None
+    with torch.cuda.device(dec.device):
+        _lib.check(_lib.load().dsf_sum_embed(dec.data_ptr(), p(idx1), p(tab1), p(add1), p(idx2), p(tab2), p(spk2), mel2ph.data_ptr(), out.data_ptr(), B, T, C,
+                                             _stream(dec.device)), 'dsf_sum_embed')
+    return out
+
+
 def _needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
@@ -341,12 +419,17 @@ class SinusoidalPositionalEmbedding(nn.Module):
             emb[padding_idx, :] = 0
         return emb
 
-    def forward(self, input, **kwargs):
-        bsz, seq_len = input.shape[:2]
+    def table(self, seq_len: int) -> torch.Tensor:
+        """The sinusoidal table, grown / moved exactly as forward() does it (common_layers.py:135-141)."""
         max_pos = self.padding_idx + 1 + seq_len
         if max_pos > self.weights.size(0):
             self.weights = self.get_embedding(max_pos, self.embedding_dim, self.padding_idx)
         self.weights = self.weights.to(self._float_tensor)
+        return self.weights
+
+    def forward(self, input, **kwargs):
+        bsz, seq_len = input.shape[:2]
+        self.table(seq_len)
         positions = make_positions(input, self.padding_idx)
         return self.weights.index_select(0, positions.view(-1)).view(bsz, seq_len, -1).detach()
 
@@ -449,6 +532,15 @@ class FFTBlocks(nn.Module):
         """FFTBlocks.forward (tts_modules.py:288-314), eval mode.  x [B,T,C] -> channel-major [B][C][TS] (and T, keep)."""
         _need_hip(x, 'FFTBlocks')
         T = x.shape[1]
+        if _glue_ok(x, padding_mask) and x.dtype == torch.float32 and not (self.use_pos_embed and self.training and hparams['dropout'] > 0):
+            # padding mask, positions, positional embedding, `* nonpadding` and the transposition: two launches (dsf_positions, dsf_input_cm)
+            x = x.contiguous()
+            pos = tab = None
+            if self.use_pos_embed:
+                pos, tab = positions_op(x=x, padding_idx=self.embed_positions.padding_idx), self.embed_positions.table(T)
+            xc, keep, pad_u8 = input_cm_op(x=x, pos=pos, pos_table=tab, alpha=self.pos_embed_alpha if self.use_pos_embed else None,
+                                           padding_mask=padding_mask)
+            return self.layers_cm(xc, T, keep, pad_u8)
         padding_mask = x.abs().sum(-1).eq(0) if padding_mask is None else padding_mask
         keep = (~padding_mask).float().contiguous()
         pad_u8 = padding_mask.to(torch.uint8).contiguous()
@@ -456,6 +548,9 @@ class FFTBlocks(nn.Module):
             x = x + self.pos_embed_alpha * self.embed_positions(x[..., 0])
             x = _drop(x, hparams['dropout'], self.training)                          # tts_modules.py:293
         xc = to_cm(x * keep[:, :, None])
+        return self.layers_cm(xc, T, keep, pad_u8)
+
+    def layers_cm(self, xc, T, keep, pad_u8):
         for layer in self.layers:
             xc = layer.op.forward_cm(xc, T, keep, pad_u8)
         if self.layer_norm is not None:
@@ -486,7 +581,23 @@ class FastspeechEncoder(FFTBlocks):
             x = x + self.embed_positions(txt_tokens)
         return _drop(x, hparams['dropout'], self.training)                           # tts_modules.py:346
 
+    def _embed_cm(self, txt_tokens, adds=()):
+        """forward_embedding + the front end of FFTBlocks.forward as two launches (inference; None: not applicable - rel_pos, dropout, CPU)."""
+        if not _glue_ok(txt_tokens, *adds) or hparams.get('rel_pos') or (self.training and hparams['dropout'] > 0) or txt_tokens.dtype != torch.int64:
+            return None
+        T = txt_tokens.shape[1]
+        tok = txt_tokens.contiguous()
+        pos = tab = None
+        if hparams['use_pos_embed']:
+            pos, tab = positions_op(tokens=tok, padding_idx=self.padding_idx), self.embed_positions.table(T)
+        xc, keep, pad_u8 = input_cm_op(tokens=tok, emb=self.embed_tokens.weight, emb_scale=self.embed_scale, adds=adds, pos=pos, pos_table=tab,
+                                       padding_idx=self.padding_idx)
+        return self.layers_cm(xc, T, keep, pad_u8)
+
     def forward(self, txt_tokens):
+        fast = self._embed_cm(txt_tokens)
+        if fast is not None:
+            return from_cm(fast[0], fast[1])
         return FFTBlocks.forward(self, self.forward_embedding(txt_tokens), txt_tokens.eq(self.padding_idx))
 
 
@@ -502,6 +613,11 @@ class FastspeechMIDIEncoder(FastspeechEncoder):
         return _drop(x, hparams['dropout'], self.training)                           # diffsinger_midi/fs2.py:28
 
     def forward(self, txt_tokens, midi_embedding, midi_dur_embedding, slur_embedding):
+        adds = (midi_embedding, midi_dur_embedding, slur_embedding)
+        if all(torch.is_tensor(a) and a.dim() == 3 and a.is_contiguous() and a.dtype == torch.float32 for a in adds if torch.is_tensor(a)):
+            fast = self._embed_cm(txt_tokens, tuple(a for a in adds if torch.is_tensor(a)))       # (scale * E + midi) + dur) + slur, in this order
+            if fast is not None:
+                return from_cm(fast[0], fast[1])
         x = self.forward_embedding(txt_tokens, midi_embedding, midi_dur_embedding, slur_embedding)
         return FFTBlocks.forward(self, x, txt_tokens.eq(self.padding_idx))
 
@@ -597,8 +713,14 @@ class PitchPredictor(nn.Module):
     def forward(self, xs):
         """tts_modules.py:215-229.  xs [B,T,idim] -> [B,T,odim]."""
         T = xs.shape[1]
-        xs = xs + self.pos_embed_alpha * self.embed_positions(xs[..., 0])
-        xc = _run_pred_convs(self.conv, self._packs, to_cm(xs), T, None)
+        if _glue_ok(xs) and xs.dtype == torch.float32 and xs.shape[2] % 4 == 0:
+            xs = xs.contiguous()                                   # positions + positional embedding + transposition: two launches
+            xc0, _, _ = input_cm_op(x=xs, pos=positions_op(x=xs, padding_idx=self.embed_positions.padding_idx), pos_table=self.embed_positions.table(T),
+                                    alpha=self.pos_embed_alpha, mask=False)
+        else:
+            xs = xs + self.pos_embed_alpha * self.embed_positions(xs[..., 0])
+            xc0 = to_cm(xs)
+        xc = _run_pred_convs(self.conv, self._packs, xc0, T, None)
         return from_cm(conv1d_cm(xc, T, self.linear.weight, self._plin, self.linear.bias), T)
 
 
@@ -743,9 +865,25 @@ class FastSpeech2(nn.Module):
         spk_dur, spk_f0, spk = self._speaker(spk_embed, spk_embed_dur_id, spk_embed_f0_id)
         dur_inp = (encoder_out + spk_dur) * src_nonpadding
         mel2ph = self.add_dur(dur_inp, mel2ph, txt_tokens, ret)
+        tgt_nonpadding = (mel2ph > 0).float()[:, :, None]
+        if _glue_ok(encoder_out, mel2ph) and mel2ph.dtype == torch.int64 and encoder_out.shape[-1] % 4 == 0:
+            # fs2.py:128-141 as two launches: the length regulator's gather (+ the predictors' masked input), then every embedding, the speaker
+            # embedding and the mask in one pass over [B,T,H] (the pad / repeat / gather / add / mul sequence of the reference moved ~100 MB)
+            enc_c, m2p = encoder_out.contiguous(), mel2ph.contiguous()
+            decoder_inp, pitch_inp = gather_frames_op(enc_c, m2p, spk_f0)
+            idx1 = tab1 = idx2 = tab2 = None
+            if hparams['use_pitch_embed']:
+                idx1 = self.add_pitch(pitch_inp, f0, uv, mel2ph, ret, encoder_out=(encoder_out + spk_f0) * src_nonpadding, want_index=True).contiguous()
+                tab1 = self.pitch_embed.weight
+            if hparams.get('use_energy_embed'):
+                idx2, tab2 = self.add_energy(pitch_inp, energy, ret, want_index=True).contiguous(), self.energy_embed.weight
+            ret['decoder_inp'] = decoder_inp = sum_embed_op(decoder_inp, m2p, idx1=idx1, tab1=tab1, idx2=idx2, tab2=tab2, spk=spk)
+            if skip_decoder:
+                return ret
+            ret['mel_out'] = self.run_decoder(decoder_inp, tgt_nonpadding, ret, infer=infer, **kwargs)
+            return ret
         decoder_inp = F.pad(encoder_out, [0, 0, 1, 0])
         decoder_inp = torch.gather(decoder_inp, 1, mel2ph[..., None].repeat([1, 1, encoder_out.shape[-1]]))
-        tgt_nonpadding = (mel2ph > 0).float()[:, :, None]
         pitch_inp = (decoder_inp + spk_f0) * tgt_nonpadding
         if hparams['use_pitch_embed']:
             decoder_inp = decoder_inp + self.add_pitch(pitch_inp, f0, uv, mel2ph, ret, encoder_out=(encoder_out + spk_f0) * src_nonpadding)
@@ -776,17 +914,17 @@ class FastSpeech2(nn.Module):
         ret['mel2ph'] = mel2ph
         return mel2ph
 
-    def add_energy(self, decoder_inp, energy, ret):
-        """fs2.py:174-181."""
+    def add_energy(self, decoder_inp, energy, ret, want_index=False):
+        """fs2.py:174-181.  want_index: the rows of energy_embed instead of the embedding (the fused glue of _forward looks them up itself)."""
         decoder_inp = self._scale_grad(decoder_inp)
         ret['energy_pred'] = energy_pred = self.energy_predictor(decoder_inp)[:, :, 0]
         if energy is None:
             energy = energy_pred
         energy = torch.clamp(energy * 256 // 4, max=255).long()
-        return self.energy_embed(energy)
+        return energy if want_index else self.energy_embed(energy)
 
-    def add_pitch(self, decoder_inp, f0, uv, mel2ph, ret, encoder_out=None):
-        """fs2.py:183-231."""
+    def add_pitch(self, decoder_inp, f0, uv, mel2ph, ret, encoder_out=None, want_index=False):
+        """fs2.py:183-231.  want_index: the rows of pitch_embed instead of the embedding."""
         if hparams['pitch_type'] == 'ph':                                # :184-196: predicted and quantised per phone, gathered to the frames
             pitch_pred_inp = self._scale_grad(encoder_out)
             pitch_padding = encoder_out.sum().abs() == 0
@@ -795,7 +933,8 @@ class FastSpeech2(nn.Module):
                 f0 = pitch_pred[:, :, 0]
             ret['f0_denorm'] = f0_denorm = denorm_f0(f0, None, hparams, pitch_padding=pitch_padding)
             pitch = F.pad(f0_to_coarse(f0_denorm), [1, 0])
-            return self.pitch_embed(torch.gather(pitch, 1, mel2ph))
+            idx = torch.gather(pitch, 1, mel2ph)
+            return idx if want_index else self.pitch_embed(idx)
         decoder_inp = self._scale_grad(decoder_inp)
         pitch_padding = mel2ph == 0
         given = f0 is not None
@@ -822,7 +961,7 @@ class FastSpeech2(nn.Module):
         if pitch_padding is not None and not given:
             f0[pitch_padding] = 0           # the reference's in-place edit of the pitch_pred view (:225-226)
         pitch = f0_to_coarse(f0_denorm)
-        return self.pitch_embed(pitch)
+        return pitch if want_index else self.pitch_embed(pitch)
 
     def run_decoder(self, decoder_inp, tgt_nonpadding, ret, infer, **kwargs):
         xc, T, keep = self.decoder.forward_cm(decoder_inp)                                      # fs2.py:233-237

@@ -83,6 +83,31 @@ int dsf_to_channel_major(const float* x, int64_t stride_b, int64_t stride_c, int
                          int32_t T, void* stream);
 int dsf_from_channel_major(const float* in, float* out /* [B][T][C] contiguous */, int32_t B, int32_t C, int32_t T, void* stream);
 
+/* The index / mask glue of FastSpeech2.forward as four operators (round 6).  Every value is the one the reference's tensor ops produce -
+ * the same operations in the same order, one rounding each; positions, indices and masks are integers.
+ * dsf_positions      utils/__init__.py:145-157 make_positions along the frame axis: pos = cumsum(v != pad) * (v != pad) + pad, v = the int64
+ *                    tokens [B][T] (FastspeechEncoder.forward_embedding, tts_modules.py:338-346) or, tokens NULL, channel 0 of the float
+ *                    tensor x [B][T][C] (FFTBlocks.forward: embed_positions(x[..., 0]), tts_modules.py:291).  pos [B][T] int32.
+ * dsf_input_cm       the front end of FFTBlocks.forward (tts_modules.py:288-296) and of FastspeechEncoder / FastspeechMIDIEncoder
+ *                    .forward_embedding: value = emb_scale * emb[token] (+ add0 + add1 + add2, in this order; each [B][T][C] or NULL)  -  or the
+ *                    tensor x [B][T][C] (tokens NULL)  -  (+ pos_table[pos], times *alpha_dev when that DEVICE scalar is given); padding =
+ *                    padding_mask [B][T] (nonzero = padded) if given, else token == padding_idx, else "every channel of x's frame is zero"
+ *                    (x.abs().sum(-1).eq(0)); xc [B][C][TS] = value * (1 - padding) channel-major (zero in [T,TS)), keep [B][T] = 1 - padding,
+ *                    pad_out [B][T] u8 = padding (the key_padding_mask of dsf_attention); mask_mode 0: no mask at all (keep = 1, pad_out = 0 - the
+ *                    front end of PitchPredictor.forward, tts_modules.py:215-229).  C a multiple of 4, <= 512.
+ * dsf_gather_frames  fs2.py:128-134: out [B][T][C] = gather(pad(enc [B][T_src][C]), mel2ph) (mel2ph [B][T] int64: 0 = padding frame, k = phone
+ *                    k - 1) and, if out_masked is given, out_masked = (out + spk [B][C] or 0) * (mel2ph > 0).
+ * dsf_sum_embed      fs2.py:136-141: out = (((dec + tab1[idx1] or add1) + tab2[idx2]) + spk or 0) * (mel2ph > 0); idx [B][T] int64, tab [n][C];
+ *                    every optional operand may be NULL. */
+int dsf_positions(const int64_t* tokens, const float* x, int32_t* pos, int32_t B, int32_t T, int32_t C, int32_t padding_idx, void* stream);
+int dsf_input_cm(const int64_t* tokens, const float* emb, float emb_scale, const float* add0, const float* add1, const float* add2, const float* x,
+                 const int32_t* pos, const float* pos_table, const float* alpha_dev, const uint8_t* padding_mask, float* xc, float* keep,
+                 uint8_t* pad_out, int32_t B, int32_t T, int32_t C, int32_t padding_idx, int32_t mask_mode, void* stream);
+int dsf_gather_frames(const float* enc, const int64_t* mel2ph, const float* spk, float* out, float* out_masked, int32_t B, int32_t T, int32_t T_src,
+                      int32_t C, void* stream);
+int dsf_sum_embed(const float* dec, const int64_t* idx1, const float* tab1, const float* add1, const int64_t* idx2, const float* tab2, const float* spk,
+                  const int64_t* mel2ph, float* out, int32_t B, int32_t T, int32_t C, void* stream);
+
 /* dsf_conv1d / dsf_conv1d_dilated pick their kernel by grid size: launches with at most one workgroup for every second CU (the phone-rate
  * encoder, everything of a single utterance) run 64-row workgroups whose waves split the contraction (k_fs_conv_ks; partial sums added in a
  * fixed order - results differ from the other kernel by summation order only).  mode: -1 by grid size (default), 0 never, 1 wherever the

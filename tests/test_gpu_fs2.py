@@ -185,3 +185,57 @@ def test_fs2_feeds_the_diffusion_hot_path():
     assert ret['mel_out'].shape == (B, T, 80) and ret['fs2_mel'].shape == (B, T, 80)
     assert bool(torch.isfinite(ret['mel_out']).all())
     assert float(ret['mel_out'][inp['mel2ph'].to(d) == 0].abs().max()) == 0       # `* (mel2ph > 0)` (:273)
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_fused_glue_equals_the_torch_op_sequence_bit_for_bit(name):
+    """Round 6: the index / mask glue of the forward (positions, padding masks, embeddings, the length regulator's gather, `* nonpadding`, the
+    [B,T,C] -> channel-major transposition) runs as four HIP operators (include/dsf.h dsf_positions / dsf_input_cm / dsf_gather_frames /
+    dsf_sum_embed) instead of ~110 torch launches.  They perform the reference's operations in the reference's order: every output of the
+    forward - all 11 reference-generated cases: frame / phone / cwt pitch, speaker ids / d-vectors, energy, MIDI encoder, predicted
+    durations - must carry the SAME BITS as with the torch op sequence (fs2.set_glue(False))."""
+    from diffsinger_amd import fs2
+    try:
+        fs2.set_glue(True)
+        fast = _run_hip(name)
+        fs2.set_glue(False)
+        slow = _run_hip(name)
+    finally:
+        fs2.set_glue(True)
+    assert set(fast) == set(slow)
+    for k in sorted(fast):
+        assert fast[k].shape == slow[k].shape and fast[k].dtype == slow[k].dtype, k
+        np.testing.assert_array_equal(fast[k], slow[k], err_msg=f'{name}:{k}')
+
+
+def test_glue_operators_edge_cases():
+    """dsf_positions / dsf_input_cm on ragged, partly and fully padded utterances, T not a multiple of 32, a given padding mask; against
+    the torch expressions they replace (utils/__init__.py:145-157, tts_modules.py:288-296)."""
+    from diffsinger_amd import fs2
+    d = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, T, C = 4, 77, 256
+    tok = torch.randint(1, 60, (B, T), generator=g)
+    tok[1, 50:] = 0
+    tok[2, :] = 0                                              # an empty utterance
+    tok[3, 10:20] = 0                                          # padding in the middle (positions skip it)
+    want_pos = fs2.make_positions(tok, 0)
+    got = fs2.positions_op(tokens=tok.to(d), padding_idx=0).cpu()
+    assert torch.equal(got.long(), want_pos)
+    x = torch.randn(B, T, C, generator=g)
+    x[1, 50:] = 0
+    x[2] = 0
+    x[3, 5, 0] = 0                                             # channel 0 zero, the frame is not: positions skip it, the mask keeps it
+    got = fs2.positions_op(x=x.to(d), padding_idx=0).cpu()
+    assert torch.equal(got.long(), fs2.make_positions(x[..., 0], 0))
+    emb = fs2.SinusoidalPositionalEmbedding(C, 0, init_size=200)
+    alpha = torch.tensor([0.7])
+    for mask in (None, tok.eq(0)):
+        pm = x.abs().sum(-1).eq(0) if mask is None else mask
+        keep = (~pm).float()
+        want = (x + alpha * emb(x[..., 0])) * keep[:, :, None]
+        tab = emb.table(T).to(d)
+        xc, kp, pu = fs2.input_cm_op(x=x.to(d), pos=fs2.positions_op(x=x.to(d)), pos_table=tab, alpha=alpha.to(d),
+                                     padding_mask=None if mask is None else mask.to(d))
+        assert torch.equal(fs2.from_cm(xc, T).cpu(), want) and torch.equal(kp.cpu(), keep) and torch.equal(pu.cpu().bool(), pm)
+        assert xc.shape[2] == 96 and float(xc[:, :, T:].abs().max()) == 0
