@@ -28,7 +28,7 @@ SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf
                'dsf_conv1d_dilated', 'dsf_set_conv_split', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad',
                'dsf_train_add_step', 'dsf_train_rowsum', 'dsf_train_gate', 'dsf_train_gate_bwd', 'dsf_train_res_skip', 'dsf_train_res_skip_bwd',
                'dsf_channel_affine', 'dsf_group_norm', 'dsf_adamw_step',
-               'dsf_stack_workspace_floats', 'dsf_set_stack_mode', 'dsf_set_stack_conv', 'dsf_get_stack_conv', 'dsf_debug_trb_timeline', 'dsf_stack_offsets', 'dsf_stack_forward', 'dsf_stack_backward', 'dsf_wgrad2_workspace_floats', 'dsf_conv1d_wgrad2', 'dsf_wgrad_probe', 'dsf_wgrad_probe_read']
+               'dsf_stack_workspace_floats', 'dsf_set_stack_mode', 'dsf_set_stack_conv', 'dsf_get_stack_conv', 'dsf_set_wgrad_dual', 'dsf_debug_trb_timeline', 'dsf_stack_offsets', 'dsf_stack_forward', 'dsf_stack_backward', 'dsf_wgrad2_workspace_floats', 'dsf_conv1d_wgrad2', 'dsf_wgrad_probe', 'dsf_wgrad_probe_read']
 
 # every symbol include/dsv.h declares (the HiFi-GAN / NSF-HiFi-GAN generator ops)
 SYMBOLS_VOC = ['dsv_padded_samples', 'dsv_packed_floats', 'dsv_pack_weight', 'dsv_pad_rows', 'dsv_conv1d', 'dsv_noise_conv', 'dsv_sine_source',

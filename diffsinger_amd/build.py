@@ -18,7 +18,12 @@ LIB = os.path.join(PKG, 'libdsdenoise.so')
 # -ffp-contract=off: hipcc's default (fast) fuses a*b+c into FMA wherever it likes, also across the __fmul_rn / __fadd_rn
 # "intrinsics" (plain operators to the optimiser) - the sampler arithmetic must round every product like the reference's
 # tensor ops do, and the persistent loop and the per-layer kernels must stay bit-identical (explicit fmaf / MFMA are unaffected)
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off']
+# -amdgpu-mfma-vgpr-form=1 (round 6): MFMA results in the ARCHITECTURAL register file wherever they fit.  hipcc's default for a kernel that may
+# use all 512 registers (one wave per SIMD) is the accumulation-register form - every accumulator the vector ALU touches afterwards (output
+# transform, gate, residual, epilogues) then crosses between the two files with v_accvgpr_read / _write, 8 cycles of matrix time each beside
+# fp32 MFMAs.  Same source, same results; A/B on one box (profiles/r6_09_*): k_loop 127.95 -> 126.19 ms, k_loop_wino 101.9 -> 101.0 ms (and its
+# 15 spilled dwords -> 8, k_loop's 43 -> 0), the training step 5.26 -> 5.17 ms, vocoder / FastSpeech2 unchanged.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 
 
 _ID_TAG = b'DSD_BUILD_ID='

@@ -134,7 +134,8 @@ struct dsd_handle {
     // K = 768 contraction (k_loop: bit-identical to the per-layer kernels).  Every other path evaluates the direct form.
     int conv_mode = 1;
     float4* w1w = nullptr;            // transformed conv weights U0..U3 of all layers in consumption order [L][128 steps][w4][r4][lane64]
-    int wino_touch = 16;              // steps (16 KiB each) the L2 touch of that stream runs in front, 0 = off
+    int wino_touch = 32;              // steps (16 KiB each) the L2 touch of that stream runs in front, 0 = off (16 in round 5; 32: 101.3 ms against 102.0 over
+                                      // four A/B pairs on one box, profiles/r6_10_wino_ab_touch.jsonl - inside the noise, never behind)
     bool cp_wino = false;             // layout of the prepared batch's cp: the Winograd loop's accumulator order, or the 32x32 fragment order
 
     // EXPERIMENT (dsd_split.hpp): residual layers on the bf16 matrix pipe with fp32-class accuracy; per-layer kernel path only

@@ -44,6 +44,11 @@ extern "C" int dsf_set_stack_conv(int32_t mode) {
     return DSD_OK;
 }
 extern "C" int dsf_get_stack_conv(void) { return g_tr_stack_conv; }
+// The dilated convolution's WEIGHT gradient in the fused backward: 1 (default, where the stack's convolution runs as Winograd: every dilation 1, 2, 4
+// or 8 and dsf_set_stack_conv(1)) the Winograd F(2,3) dual - four products over frame PAIRS instead of three over the frames
+// (train_kernels.hpp k_tr_wgrad / k_tr_wgrad_reduce_dual); 0 the three tap tiles of rounds 2-5 (the A/B switch and the anchor of the tests)
+static int g_tr_wgrad_dual = 1;
+extern "C" int dsf_set_wgrad_dual(int32_t on) { g_tr_wgrad_dual = on ? 1 : 0; return DSD_OK; }
 // developer hook (tools/trb_timeline.py): s_memtime stamps of the Winograd data-gradient kernel, [workgroup][wave 4][8] per launch (the last launch wins)
 static unsigned long long* g_trb_dbg = nullptr;
 extern "C" int dsf_debug_trb_timeline(uint64_t* device_stamps) { g_trb_dbg = (unsigned long long*)device_stamps; return DSD_OK; }
@@ -176,8 +181,20 @@ static TrProbe& tr_probe() { static TrProbe p; return p; }
 // fix: some B operand is not padded against its tap shift (k_tr_wgrad<true>)
 static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int T, int TS, bool fix) {
     wp.B = B; wp.T = T; wp.TS = TS;
-    wp.nsplit = tr_nsplit(ndesc, B * TS / 32);
-    const int total = ndesc * wp.nsplit;
+    const int nc = wp.nc, np = ndesc - nc;                  // Winograd-dual products (the first nc descriptors, four per 128-row tile) / plain tiles
+    if (nc) {
+        // a dual step covers 64 frames, a plain step 32: half the splits for the dual products balances the workgroups, and
+        // ns_c (nc + 2 np) <= CUs fills the chip once (two layers: 32 products x 4 + 16 tiles x 8 = 256 workgroups of 32 steps at 8 x 1024)
+        const int ncu = tr_ncu();
+        int nsc = std::max(1, ncu / std::max(nc + 2 * np, 1));
+        nsc = std::min(nsc, kTrMaxSplit / 2);
+        wp.ns_c = std::max(1, std::min(nsc, B * ((TS + 63) / 64)));
+        wp.nsplit = std::max(1, std::min(2 * wp.ns_c, B * TS / 32));
+    } else {
+        wp.ns_c = 0;
+        wp.nsplit = tr_nsplit(ndesc, B * TS / 32);
+    }
+    const int total = nc * wp.ns_c + np * wp.nsplit;
     wp.ndesc = ndesc; wp.xcd_q = total / 8; wp.xcd_r = total % 8;
     TrProbe& pr = tr_probe();
     const bool probe = pr.on && !fix;
@@ -196,9 +213,10 @@ static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int 
     if (probe) {
         HIP_TRY(hipEventRecord(pr.ev[pr.used].second, s));
         ++pr.used;
-        pr.flops += 2.0 * 128 * 256 * (double)ndesc * (double)B * (double)T;
+        pr.flops += 2.0 * 128 * 256 * ((double)np + 0.5 * (double)nc) * (double)B * (double)T;     // EXECUTED: a dual product contracts T / 2 pairs
     }
-    hipLaunchKernelGGL(k_tr_wgrad_reduce, dim3((unsigned)ndesc, 128), dim3(256), 0, s, wp);
+    if (nc) hipLaunchKernelGGL(k_tr_wgrad_reduce_dual, dim3((unsigned)(nc / 4), 128), dim3(256), 0, s, wp);
+    if (np) hipLaunchKernelGGL(k_tr_wgrad_reduce, dim3((unsigned)np, 128), dim3(256), 0, s, wp);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }
@@ -414,30 +432,45 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         return p;
     };
     // a layer's weight gradients: 12 (dilated conv: 4 row tiles x 3 taps) + 4 (conditioner projection) + 4 or 2 (output projection) tiles
-    auto wgrad_tiles = [&](int l, TrWgParams& wp, int& nd) -> int {
+    // pass 0: the dilated convolution's tiles - as the four products of the Winograd dual per 128-row tile (they must be the FIRST descriptors of a
+    // launch: tr_wgrad_launch gives them their own split count) or, with the dual off, as the three tap tiles; pass 1: the 1 x 1 projections
+    const bool dual = wino && g_tr_wgrad_dual;
+    auto wgrad_tiles = [&](int l, TrWgParams& wp, int& nd, int pass) -> int {
         const bool last = (l == L - 1);
         const float* da = da_of(l);
         const float* dxp_in = last ? nullptr : dx_of(l);
         const float* y = sws + lay.Y + (size_t)l * lay.Y_l + kTrYPad;
         const int yrs = TS + 2 * kTrYPad;
         const int dil = w->dilations[l];
-        for (int mt = 0; mt < 4; ++mt)
-            for (int tap = 0; tap < 3; ++tap) {
-                TrWgTile& d = wp.tile[nd++];
-                d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = y; d.b_bstride = (long long)kC * yrs; d.b_rs = yrs; d.shift = (tap - 1) * dil;
-                d.out = g->dilated_conv_w[l] + (size_t)mt * 128 * 3 * kC + tap; d.out_rs = 3 * kC; d.out_cs = 3;
-                d.out_bias = (tap == 0) ? g->dilated_conv_b[l] + mt * 128 : nullptr; d.a_scale = 1.f;
-            }
+        if (pass == 0) {
+            for (int mt = 0; mt < 4; ++mt)
+                for (int k = 0; k < (dual ? 4 : 3); ++k) {
+                    TrWgTile& d = wp.tile[nd++];
+                    d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = y; d.b_bstride = (long long)kC * yrs; d.b_rs = yrs;
+                    d.out_rs = 3 * kC; d.out_cs = 3; d.a_scale = 1.f;
+                    if (dual) {          // product k of the tile: `out` = the tile's tap 0 (the reduction writes all three taps), the bias rides on P1 (row sums of E + O)
+                        d.prod = k; d.shift = dil;
+                        d.out = g->dilated_conv_w[l] + (size_t)mt * 128 * 3 * kC;
+                        d.out_bias = (k == 1) ? g->dilated_conv_b[l] + mt * 128 : nullptr;
+                        ++wp.nc;
+                    } else {
+                        d.prod = -1; d.shift = (k - 1) * dil;
+                        d.out = g->dilated_conv_w[l] + (size_t)mt * 128 * 3 * kC + k;
+                        d.out_bias = (k == 0) ? g->dilated_conv_b[l] + mt * 128 : nullptr;
+                    }
+                }
+            return DSD_OK;
+        }
         for (int mt = 0; mt < 4; ++mt) {
             TrWgTile& d = wp.tile[nd++];
-            d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = cond; d.b_bstride = (long long)kC * TS; d.b_rs = TS; d.shift = 0;
+            d.a = da + (size_t)mt * 128 * TS; d.a_bstride = da_bs; d.bsrc = cond; d.b_bstride = (long long)kC * TS; d.b_rs = TS; d.shift = 0; d.prod = -1;
             d.out = g->cond_w[l] + (size_t)mt * 128 * kC; d.out_rs = kC; d.out_cs = 1; d.out_bias = g->cond_b[l] + mt * 128; d.a_scale = 1.f;
         }
         for (int mt = last ? 2 : 0; mt < 4; ++mt) {
             TrWgTile& d = wp.tile[nd++];
             if (mt < 2) { d.a = dxp_in + (size_t)mt * 128 * TS; d.a_scale = kTrInvSqrt2; }
             else { d.a = dskip + (size_t)(mt - 2) * 128 * TS; d.a_scale = 1.f; }
-            d.a_bstride = (long long)kC * TS; d.bsrc = g_of(l); d.b_bstride = (long long)kC * TS; d.b_rs = TS; d.shift = 0;
+            d.a_bstride = (long long)kC * TS; d.bsrc = g_of(l); d.b_bstride = (long long)kC * TS; d.b_rs = TS; d.shift = 0; d.prod = -1;
             d.out = g->out_w[l] + (size_t)mt * 128 * kC; d.out_rs = kC; d.out_cs = 1; d.out_bias = g->out_b[l] + mt * 128;
         }
         if (last) {          // the residual half of the last layer's output projection is dead (net.py:126 reads the skips only): zero gradient
@@ -455,7 +488,8 @@ extern "C" int dsf_stack_backward(const float* dskip, const float* cond, const d
         if (!npend) return DSD_OK;
         TrWgParams wp{};
         int nd = 0;
-        for (int i = 0; i < npend; ++i) DSD_TRY(wgrad_tiles(pending[i], wp, nd));
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i = 0; i < npend; ++i) DSD_TRY(wgrad_tiles(pending[i], wp, nd, pass));
         npend = 0;
         wp.part = bws + bl.part; wp.part_b = bws + bl.part_b;
         return tr_wgrad_launch(s, wp, nd, B, T, TS, false);
@@ -528,7 +562,7 @@ extern "C" int dsf_conv1d_wgrad2(const float* dy, const float* x, float* dw, flo
             TrWgTile& d = wp.tile[nd];
             d.a = dy + (size_t)mt * 128 * TS; d.a_bstride = (long long)Co * TS;
             d.bsrc = x + (size_t)nt * 256 * TS; d.b_bstride = (long long)Ci * TS; d.b_rs = TS;
-            d.shift = (tap - (KT - 1) / 2) * dil;
+            d.shift = (tap - (KT - 1) / 2) * dil; d.prod = -1;
             d.out = dw + ((size_t)mt * 128 * Ci + (size_t)nt * 256) * KT + tap; d.out_rs = Ci * KT; d.out_cs = KT;
             d.out_bias = (db && tap == 0 && nt == 0) ? db + mt * 128 : nullptr; d.a_scale = 1.f;
         }

@@ -585,16 +585,36 @@ struct TrWgTile {
     long long a_bstride, b_bstride;
     int shift, out_rs, out_cs, b_rs;
     float a_scale;
+    int prod;                   // -1: a plain tile (frames contracted as they are); 0..3: product P_prod of the Winograd dual of a 3-tap dilated
+                                // convolution's weight gradient (below), contracted over frame PAIRS; shift = the dilation d in {1, 2, 4, 8}
 };
-constexpr int kTrWgMaxTiles = 40;        // the weight gradients of TWO layers per launch (2 x 20 tiles x 6 frame splits = 240 workgroups)
+// The Winograd F(2,3) DUAL for the convolution's weight gradient (round 6).  dW_k[m][n] = sum_t a[m][t] y[n][t + (k - 1) d], k = 0, 1, 2: three
+// products over the frames.  Over a frame PAIR (tE, tO = tE + d) with e = a[tE], f = a[tO], d0..d3 = y[tE - d], y[tE], y[tO], y[tO + d]:
+//     e d0 + f d1 = Q0 + Q1 + Q2      e d1 + f d2 = Q1 - Q2      e d2 + f d3 = Q1 + Q2 + Q3
+//     Q0 = e (d0 - d2)    Q1 = (e + f) (d1 + d2) / 2    Q2 = (e - f) (d2 - d1) / 2    Q3 = f (d3 - d1)
+// FOUR products over the pairs (half as many as frames) instead of three over the frames: 2/3 of the multiplications of 12 of a layer's 20
+// weight-gradient tiles.  A workgroup computes ONE product of one 128-row tile: it stages 64 frames per step, forms its operand pair
+//     P0: E . (y[tE - d] - y[tO])    P1: (E + O) . (y[tE] + y[tO])    P2: (E - O) . (y[tO] - y[tE])    P3: O . (y[tE] - y[tO + d])
+// in registers on the way into LDS (32 pairs per step: the LDS tiles, the fragment reads and the MFMA loop are those of a plain tile), and
+// k_tr_wgrad_reduce_dual back-transforms  dW_0 = P0 + (P1 + P2) / 2,  dW_1 = (P1 - P2) / 2,  dW_2 = (P1 + P2) / 2 - P3.  Pairs: a 64-frame step
+// splits into blocks of 2 d frames, pair p = blk d + i <-> tE = 2 d blk + i (the forward's pair order, csrc/dsd_loop_wino.hpp); a thread forms
+// the pairs 4 q .. 4 q + 3 (q = tid & 7) of its rows from two or three ALIGNED 16-byte loads (d = 1, 2: the frames 8 q - 4 .. 8 q + 11, the
+// E / O split is a register permutation; d = 4, 8: E, O and their +- d neighbours are whole float4).  The bias gradient (row sums of a) is
+// the row sum of P1's operand E + O.
+constexpr int kTrWgMaxTiles = 48;        // two layers per launch: 2 x (16 dual products + 8 plain tiles)
 struct TrWgParams {
     TrWgTile tile[kTrWgMaxTiles];
-    float* part;                // [ntile_desc][nsplit][128][256]
-    float* part_b;              // [ntile_desc][nsplit][128]
-    int nsplit, B, T, TS;
-    int ndesc, xcd_q, xcd_r;    // 1-D grid of ndesc * nsplit workgroups, XCD x takes a contiguous range of (split, tile) pairs: the workgroups
+    float* part;                // split-K partials [partial tile][128][256]: descriptor n < nc: n * ns_c + split; else nc * ns_c + (n - nc) * nsplit + split
+    float* part_b;              // the same indices, [128] each
+    int nsplit, B, T, TS;       // nsplit: frame splits of the PLAIN tiles
+    int ndesc, xcd_q, xcd_r;    // 1-D grid of nc * ns_c + (ndesc - nc) * nsplit workgroups, XCD x takes a contiguous range of (split, tile) pairs: the workgroups
                                 // behind one L2 contract (nearly) the same frames, so every operand line is fetched from the fabric by ~1.3 L2s, not 8
+    int nc, ns_c;               // the first nc descriptors are dual products, ns_c splits each (a pair step covers 64 frames: half the steps of a
+                                // plain tile, so ns_c = nsplit / 2 balances the workgroups)
 };
+__host__ __device__ __forceinline__ int tr_wg_part_index(const TrWgParams& p, int desc, int split) {
+    return desc < p.nc ? desc * p.ns_c + split : p.nc * p.ns_c + (desc - p.nc) * p.nsplit + split;
+}
 constexpr int kTrWgLD = 36;
 constexpr int kTrWgStage = (128 + 256) * kTrWgLD;
 constexpr int kTrWgLdsBytes = 2 * kTrWgStage * (int)sizeof(float);
@@ -624,13 +644,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
     constexpr int LD = kTrWgLD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = xcd_item(blockIdx.x, p.xcd_q, p.xcd_r);
-    const int split = item / p.ndesc, desc = item - split * p.ndesc;
+    const int n_dual = p.nc * p.ns_c;
+    const bool dual = !FIX && item < n_dual;                // (wave-uniform) one product of a convolution's Winograd-dual weight gradient
+    const int jt = dual ? item : item - n_dual, nd_cls = dual ? p.nc : p.ndesc - p.nc, ns_cls = dual ? p.ns_c : p.nsplit;
+    const int split = jt / nd_cls, desc = (dual ? 0 : p.nc) + jt - split * nd_cls;
     const TrWgTile& d = p.tile[desc];
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w & 1, wn = w >> 1;
-    const int tiles_per_utt = p.TS / 32, ntile = p.B * tiles_per_utt;
-    const int per = (ntile + p.nsplit - 1) / p.nsplit;
+    const int tiles_per_utt = dual ? (p.TS + 63) / 64 : p.TS / 32, ntile = p.B * tiles_per_utt;     // steps: 64 frames = 32 pairs / 32 frames
+    const int per = (ntile + ns_cls - 1) / ns_cls;
     const int tile_lo = split * per, tile_hi = min(ntile, tile_lo + per);
     f32x16 acc[2][4];
 #pragma unroll
@@ -819,11 +842,176 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
             DSD_SB();
         }
     };
+    // ---- the Winograd-dual step: 64 frames -> 32 pairs per step, operands formed in registers on the way into LDS ------------------------------
+    // DS: 1, 2 (E / O interleaved inside 8 frames: a register permutation) or 4 (d = 4, 8: E, O and their neighbours are whole float4)
+    float4 pa[4][2], pb[8][3];
+    auto loop_dual = [&](auto ds_c, auto pr_c, auto bias_c) {
+        constexpr int DS = decltype(ds_c)::value, PR = decltype(pr_c)::value;
+        constexpr bool BIAS = decltype(bias_c)::value;
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const int dd = d.shift;                             // the dilation
+        int e0;                                             // frame (inside the step) of the E float4 of this thread's pairs 4 sg .. 4 sg + 3
+        if constexpr (DS >= 4) { const int pq = 4 * sg, blk = pq / dd; e0 = 2 * dd * blk + (pq - blk * dd); } else e0 = 8 * sg;
+        const int o1 = (DS >= 4) ? e0 + dd : e0 + 4;        // second float4: O (d >= 4) / frames 8 q + 4 .. + 7
+        // third float4 of the B operand: P0 reaches back (y[tE - d]), P3 reaches forward (y[tO + d])
+        // (d = 1, 2: only the last / first one or two frames of the neighbouring float4 are needed - a 4- or 8-byte load, kept in .x / .x, .y)
+        const int o2 = (PR == 0) ? ((DS >= 4) ? e0 - dd : e0 - DS) : ((DS >= 4) ? e0 + 2 * dd : e0 + 8);
+        constexpr bool B3 = (PR == 0 || PR == 3);
+        const unsigned avo0 = (unsigned)(srow * p.TS + e0) * 4u, avo1 = (unsigned)(srow * p.TS + o1) * 4u;
+        // (the B descriptor's base sits 16 floats in front of the step: o2 reaches back to frame -8, and a NEGATIVE lane offset is not an address
+        // 8 frames earlier but an out-of-range offset of a raw buffer - the load returns 0.  Found by tools/diag_wgrad_dual.py: tap 0 wrong in every
+        // step but an utterance's first, where the zeros were the padding anyway)
+        constexpr int kBack = 16;
+        const unsigned bvo0 = (unsigned)(srow * b_rs + e0 + kBack) * 4u, bvo1 = (unsigned)(srow * b_rs + o1 + kBack) * 4u, bvo2 = (unsigned)(srow * b_rs + o2 + kBack) * 4u;
+        auto ld = [&](const __amdgpu_buffer_rsrc_t& r, unsigned vo, int so) -> float4 {
+            const f32x4_ f = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, so, 0));
+            return make_float4(f.x, f.y, f.z, f.w);
+        };
+        // The step's staging is spread over its first three MFMA groups (32 MFMAs each) so that every group carries a share the interleave pattern
+        // can place between its MFMAs: group 0 - A (4 row slots: form, write, request the next step's), group 1 - B row slots 0-3, group 2 - B row
+        // slots 4-7; the barrier sits in front of group 3 as in the plain step.  (The first version formed and wrote everything in front of group 0:
+        // ~120 vector instructions and 12 LDS writes in a row with the matrix pipe idle - 185 us per launch, no faster than the three tap tiles.)
+        __amdgpu_buffer_rsrc_t ra, rb;
+        unsigned a0 = 0, a1 = 0, b0 = 0, b1 = 0, b2 = 0;
+        auto next_step = [&]() {
+            const int b = __builtin_amdgcn_readfirstlane(f_b), t0 = __builtin_amdgcn_readfirstlane(f_tn * 64);
+            {
+                const int adv = (f_tile + 1 < tile_hi) ? 1 : 0;
+                f_tile += adv;
+                const int tn1 = f_tn + adv, wrap = (tn1 == tiles_per_utt) ? 1 : 0;
+                f_tn = wrap ? 0 : tn1;
+                f_b += wrap;
+            }
+            ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.a + (size_t)b * d.a_bstride + t0), 0, 0x7ffffff0, 0x00020000);
+            rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bsrc + (size_t)b * d.b_bstride + t0 - kBack), 0, 0x7ffffff0, 0x00020000);
+            // the second half of an utterance's last step may lie behind its rows (TS = 32 mod 64): those threads ask for an offset beyond the
+            // descriptor's range - a raw buffer load answers 0 there: zero operands, no select in the step
+            const bool dead = (t0 + 32 >= p.TS) && (sg >= 4);
+            const unsigned oob = 0xfffffff0u;
+            a0 = dead ? oob : avo0; a1 = dead ? oob : avo1;
+            b0 = dead ? oob : bvo0; b1 = dead ? oob : bvo1; b2 = dead ? oob : bvo2;
+        };
+        auto fetch_a = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (PR != 3 || DS < 4) pa[q][0] = ld(ra, a0, q * (32 * 4) * p.TS);
+                if (PR != 0 || DS < 4) pa[q][1] = ld(ra, a1, q * (32 * 4) * p.TS);
+            }
+        };
+        auto fetch_b = [&](int q0) {
+#pragma unroll
+            for (int q = q0; q < q0 + 4; ++q) {
+                if (!(PR == 0 && DS >= 4)) pb[q][0] = ld(rb, b0, q * (32 * 4) * b_rs);
+                if (!(PR == 3 && DS >= 4)) pb[q][1] = ld(rb, b1, q * (32 * 4) * b_rs);
+                if (B3) {
+                    if constexpr (DS >= 4) pb[q][2] = ld(rb, b2, q * (32 * 4) * b_rs);
+                    else if constexpr (DS == 2) {
+                        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                        const f32x2_ f = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(rb, (int)b2, q * (32 * 4) * b_rs, 0));
+                        pb[q][2].x = f.x; pb[q][2].y = f.y;
+                    } else pb[q][2].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)b2, q * (32 * 4) * b_rs, 0));
+                }
+            }
+        };
+        // E / O of four pairs from the two float4 (frames 8 q .. 8 q + 7; d >= 4: they ARE E and O)
+        auto eo = [&](const float4& l0, const float4& l1, float4& e, float4& o) {
+            if constexpr (DS == 1) { e = make_float4(l0.x, l0.z, l1.x, l1.z); o = make_float4(l0.y, l0.w, l1.y, l1.w); }
+            else if constexpr (DS == 2) { e = make_float4(l0.x, l0.y, l1.x, l1.y); o = make_float4(l0.z, l0.w, l1.z, l1.w); }
+            else { e = l0; o = l1; }
+        };
+        auto f4sub = [](const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+        auto f4add = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+        auto stash_a = [&](int buf, float live) {
+            float* As = smem + buf * kTrWgStage;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 e, o, v;
+                if constexpr (DS >= 4) { e = pa[q][0]; o = pa[q][1]; } else eo(pa[q][0], pa[q][1], e, o);
+                v = (PR == 0) ? e : (PR == 1) ? f4add(e, o) : (PR == 2) ? f4sub(e, o) : o;
+                *reinterpret_cast<float4*>(As + (srow + 32 * q) * LD + 4 * sg) = v;
+                if (BIAS) bsum[q] += live * ((v.x + v.y) + (v.z + v.w));
+            }
+        };
+        auto stash_b = [&](int buf, int q0) {
+            float* Bs = smem + buf * kTrWgStage + 128 * LD;
+#pragma unroll
+            for (int q = q0; q < q0 + 4; ++q) {
+                float4 v;
+                if constexpr (DS >= 4) {
+                    // pb[.][0] = y[tE], [1] = y[tO], [2] = y[tE - d] (P0) / y[tO + d] (P3)
+                    v = (PR == 0) ? f4sub(pb[q][2], pb[q][1]) : (PR == 1) ? f4add(pb[q][0], pb[q][1]) : (PR == 2) ? f4sub(pb[q][1], pb[q][0]) : f4sub(pb[q][0], pb[q][2]);
+                } else {
+                    float4 e, o;
+                    eo(pb[q][0], pb[q][1], e, o);
+                    const float4 &l0 = pb[q][0], &l1 = pb[q][1], &x2 = pb[q][2];
+                    if constexpr (PR == 1) v = f4add(e, o);
+                    else if constexpr (PR == 2) v = f4sub(o, e);
+                    else if constexpr (PR == 0) {           // y[tE - d] - y[tO]; x2 = frames 8 q - 4 .. 8 q - 1
+                        const float4 m = (DS == 1) ? make_float4(x2.x, l0.y, l0.w, l1.y) : make_float4(x2.x, x2.y, l0.z, l0.w);      // x2 = y[8 q - d ..]
+                        v = f4sub(m, o);
+                    } else {                                // y[tE] - y[tO + d]; x2 = frames 8 q + 8 .. 8 q + 11
+                        const float4 n = (DS == 1) ? make_float4(l0.z, l1.x, l1.z, x2.x) : make_float4(l1.x, l1.y, x2.x, x2.y);
+                        v = f4sub(e, n);
+                    }
+                }
+                *reinterpret_cast<float4*>(Bs + (srow + 32 * q) * LD + 4 * sg) = v;
+            }
+        };
+        next_step(); fetch_a(); fetch_b(0); fetch_b(4);
+        stash_a(0, 1.f); stash_b(0, 0); stash_b(0, 4);
+        next_step(); fetch_a(); fetch_b(0); fetch_b(4);
+        __syncthreads();
+        frags(0, 0, 0);
+        for (int k = 0; k < nstep; ++k) {
+            const int cur = k & 1;
+            const float live = (k + 1 < nstep) ? 1.f : 0.f;
+            frags(1, cur, 1);
+            stash_a(cur ^ 1, live);
+            next_step();                                     // (scalar: the descriptors and offsets of the step behind the one in the registers)
+            fetch_a();
+            mma(0);
+            tr_interleave<2, true, true, true>(0);
+            DSD_SB();
+            frags(0, cur, 2);
+            stash_b(cur ^ 1, 0);
+            fetch_b(0);
+            mma(1);
+            tr_interleave<3, true, true, true>(0);
+            DSD_SB();
+            frags(1, cur, 3);
+            stash_b(cur ^ 1, 4);
+            fetch_b(4);
+            mma(0);
+            tr_interleave<3, true, true, true>(0);
+            DSD_SB();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            frags(0, cur ^ 1, 0);
+            mma(1);
+            tr_interleave<0, false, false, true>(0);
+            DSD_SB();
+        }
+    };
+    auto dual_dispatch = [&](auto ds_c) {
+        using T_ = std::true_type; using F_ = std::false_type;
+        if (d.prod == 0) loop_dual(ds_c, std::integral_constant<int, 0>{}, F_{});
+        else if (d.prod == 1) { if (has_bias) loop_dual(ds_c, std::integral_constant<int, 1>{}, T_{}); else loop_dual(ds_c, std::integral_constant<int, 1>{}, F_{}); }
+        else if (d.prod == 2) loop_dual(ds_c, std::integral_constant<int, 2>{}, F_{});
+        else loop_dual(ds_c, std::integral_constant<int, 3>{}, F_{});
+    };
     if (nstep > 0) {
-        if (FIX || has_bias) loop(std::true_type{});
-        else loop(std::false_type{});
+        if constexpr (!FIX) {
+            if (dual) {
+                if (d.shift == 1) dual_dispatch(std::integral_constant<int, 1>{});
+                else if (d.shift == 2) dual_dispatch(std::integral_constant<int, 2>{});
+                else dual_dispatch(std::integral_constant<int, 4>{});
+            } else if (has_bias) loop(std::true_type{});
+            else loop(std::false_type{});
+        } else {
+            loop(std::true_type{});
+        }
     }
-    float* out = p.part + ((size_t)desc * p.nsplit + split) * (128 * 256);       // wave-uniform; write-through: the reduction kernel reads it next
+    float* out = p.part + (size_t)tr_wg_part_index(p, desc, split) * (128 * 256);       // wave-uniform; write-through: the reduction kernel reads it next
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -835,7 +1023,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_tr_wgrad(const TrWgParams p) {
         for (int q = 0; q < 4; ++q) {
             float sb = FIX ? bsum[q] : bsum[q] * a_scale;
             sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64); sb += __shfl_xor(sb, 4, 64);
-            if (sg == 0) p.part_b[((size_t)desc * p.nsplit + split) * 128 + srow + 32 * q] = sb;
+            if (sg == 0) p.part_b[(size_t)tr_wg_part_index(p, desc, split) * 128 + srow + 32 * q] = sb;
         }
     }
 }
@@ -850,19 +1038,48 @@ __global__ void k_tr_zero_pads(float* __restrict__ y, size_t rows, int rs) {
 }
 
 // dW = sum over the splits, in split order; one thread per element of a 128 x 256 tile, grid (tile descriptor, 128)
+// grid (plain descriptors, 128): the descriptors [nc, ndesc)
 __global__ __launch_bounds__(256) void k_tr_wgrad_reduce(const TrWgParams p) {
-    const TrWgTile& d = p.tile[blockIdx.x];
+    const int desc = p.nc + blockIdx.x;
+    const TrWgTile& d = p.tile[desc];
     const int m = blockIdx.y, n = threadIdx.x;
-    const float* src = p.part + (size_t)blockIdx.x * p.nsplit * (128 * 256) + m * 256 + n;
+    const float* src = p.part + (size_t)tr_wg_part_index(p, desc, 0) * (128 * 256) + m * 256 + n;
     float s = 0.f;
 #pragma unroll 6
     for (int k = 0; k < p.nsplit; ++k) s += src[(size_t)k * (128 * 256)];       // (the splits' loads in flight together, the additions in split order)
     d.out[(size_t)m * d.out_rs + (size_t)n * d.out_cs] = s;
     if (d.out_bias && n == 0) {
-        const float* sb = p.part_b + (size_t)blockIdx.x * p.nsplit * 128 + m;
+        const float* sb = p.part_b + (size_t)tr_wg_part_index(p, desc, 0) * 128 + m;
         float t = 0.f;
         for (int k = 0; k < p.nsplit; ++k) t += sb[(size_t)k * 128];
         d.out_bias[m] = t;
+    }
+}
+
+// grid (nc / 4, 128): the four products of one 128-row tile (descriptors 4 g .. 4 g + 3 = P0 .. P3, each summed over its splits in split
+// order) back-transformed into the three tap gradients; descriptor 4 g carries `out` (tap 0: taps are out + 1, out + 2) and 4 g + 1 the bias
+__global__ __launch_bounds__(256) void k_tr_wgrad_reduce_dual(const TrWgParams p) {
+    const int g = blockIdx.x, m = blockIdx.y, n = threadIdx.x;
+    float P[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float* src = p.part + (size_t)tr_wg_part_index(p, 4 * g + i, 0) * (128 * 256) + m * 256 + n;
+        float s = 0.f;
+        for (int k = 0; k < p.ns_c; ++k) s += src[(size_t)k * (128 * 256)];
+        P[i] = s;
+    }
+    const TrWgTile& d = p.tile[4 * g];
+    const float hs = 0.5f * (P[1] + P[2]);
+    float* o = d.out + (size_t)m * d.out_rs + (size_t)n * d.out_cs;
+    o[0] = P[0] + hs;
+    o[1] = 0.5f * (P[1] - P[2]);
+    o[2] = hs - P[3];
+    const TrWgTile& d1 = p.tile[4 * g + 1];
+    if (d1.out_bias && n == 0) {
+        const float* sb = p.part_b + (size_t)tr_wg_part_index(p, 4 * g + 1, 0) * 128 + m;
+        float t = 0.f;
+        for (int k = 0; k < p.ns_c; ++k) t += sb[(size_t)k * 128];
+        d1.out_bias[m] = t;
     }
 }
 

@@ -66,6 +66,7 @@ def _bind(lib):
     lib.dsf_set_stack_mode.argtypes = [i32]
     lib.dsf_set_stack_conv.argtypes = [i32]
     lib.dsf_get_stack_conv.argtypes = []
+    lib.dsf_set_wgrad_dual.argtypes = [i32]
     lib.dsf_stack_offsets.argtypes = [i32, i32, i32, i32, C.POINTER(i64), i32]
     lib.dsf_stack_forward.argtypes = [vp, vp, vp, C.POINTER(DsfStackWeights), i32, i32, i32, vp, vp, vp]
     lib.dsf_stack_backward.argtypes = [vp, vp, C.POINTER(DsfStackWeights), i32, i32, i32, vp, vp, C.POINTER(DsfStackGrads), vp, vp]
@@ -92,6 +93,14 @@ def set_stack_conv(mode):
     _bind(lib)
     m = {'wino': 1, 'direct': 0}.get(mode, mode)
     _lib.check(lib.dsf_set_stack_conv(int(m)), 'dsf_set_stack_conv')
+
+
+def set_wgrad_dual(on: bool):
+    """The dilated convolution's weight gradient as the Winograd F(2,3) dual over frame pairs (include/dsf.h dsf_set_wgrad_dual; default on where
+    the stack's convolution runs as Winograd) or as the three tap products of rounds 2-5 (the A/B switch of tests and tools)."""
+    lib = _lib.load()
+    _bind(lib)
+    _lib.check(lib.dsf_set_wgrad_dual(int(bool(on))), 'dsf_set_wgrad_dual')
 
 
 def stack_conv() -> str:

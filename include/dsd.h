@@ -191,7 +191,7 @@ int dsd_get_lat_split(dsd_handle* h);
  * The row-split latency kernels follow the same switch at G = 2 / 4 / 8 (their conv node is k_lat_conv_w, reading the loop's transformed
  * weights; round 5) - so dsd_denoise / dsd_p_sample / the sampling calls on a SMALL batch change with it too; G = 16, the per-layer kernels
  * (loop mode 0) and the training operators always evaluate the direct form, and with mode 0 every path does.  touch_ahead: steps
- * (16 KiB of the transformed-weight stream) the waves of an XCD fetch into their L2 ahead of themselves, 0 = off, -1 = keep (default 16) - a
+ * (16 KiB of the transformed-weight stream) the waves of an XCD fetch into their L2 ahead of themselves, 0 = off, -1 = keep (default 32) - a
  * tuning knob of tools/, results do not depend on it.
  * dsd_get_conv_mode: 1 if the prepared batch's convolution runs in the Winograd form - on the persistent loop (dsd_get_loop_mode = 1) or on the
  * latency kernels at G = 2 / 4 / 8 (dsd_get_lat_split) - else 0.  Environment: DSD_CONV=direct|winograd at dsd_create. */

@@ -201,6 +201,13 @@ int dsf_set_stack_mode(int32_t mode);
  * per-layer launches).  The saved tensors keep their layouts; the workspace sizes do not depend on it. */
 int dsf_set_stack_conv(int32_t mode);
 int dsf_get_stack_conv(void);
+/* The weight gradient of the dilated convolution inside dsf_stack_backward (process-wide): 1 (default; in force where the stack's convolution
+ * runs as Winograd, see dsf_set_stack_conv) the Winograd F(2,3) DUAL - for a frame pair (tE, tO = tE + d) with e = da[tE], f = da[tO] and
+ * d0..d3 = y[tE - d], y[tE], y[tO], y[tO + d] the three tap gradients are Q0 + Q1 + Q2, Q1 - Q2, Q1 + Q2 + Q3 of the FOUR products
+ * Q0 = e (d0 - d2), Q1 = (e + f)(d1 + d2) / 2, Q2 = (e - f)(d2 - d1) / 2, Q3 = f (d3 - d1) contracted over the pairs: 2/3 of the multiplications of
+ * usr/diff/net.py:61's weight gradient, fp32 throughout (one add per operand, exact-fp32 MFMA), within the tests' 3e-6 of float64 autograd;
+ * 0 the three tap products over the frames (rounds 2-5).  The workspace sizes do not depend on it. */
+int dsf_set_wgrad_dual(int32_t on);
 /* Developer hook (tools/trb_timeline.py): s_memtime stamps of the Winograd data-gradient kernel of layer 1, [workgroup][wave 4][8] uint64 per launch
  * (NULL switches it off).  Not part of the operator surface. */
 int dsf_debug_trb_timeline(uint64_t* device_stamps);

@@ -93,12 +93,14 @@ def _frag_to_rows(frag, ntiles):
 def stack_conv(request):
     """the convolution of the persistent forward for one test (dsf_set_stack_conv), the default restored behind it"""
     from diffsinger_amd import train_fused
-    train_fused.set_stack_conv(request.param)
+    train_fused.set_stack_conv('wino' if request.param == 'wino-taps' else request.param)
+    train_fused.set_wgrad_dual(request.param != 'wino-taps')      # 'wino-taps': the Winograd convolutions with the weight gradient as three tap products (rounds 2-5)
     yield request.param
     train_fused.set_stack_conv('wino')
+    train_fused.set_wgrad_dual(True)
 
 
-@pytest.mark.parametrize('stack_conv', ['wino', 'direct'], indirect=True)
+@pytest.mark.parametrize('stack_conv', ['wino', 'wino-taps', 'direct'], indirect=True)
 @pytest.mark.parametrize('B,T,L,cycle', [(2, 50, 3, 4), (3, 96, 5, 1), (2, 70, 20, 4), (1, 5, 1, 1), (1, 32, 2, 4), (4, 33, 2, 2), (9, 129, 4, 3), (1, 8300, 2, 4)])
 def test_stack_forward_and_backward(B, T, L, cycle, stack_conv):
     """(the short shapes take the persistent forward: with the Winograd convolution, csrc/train_loop_wino.hpp, and with the direct one; the
@@ -107,7 +109,7 @@ def test_stack_forward_and_backward(B, T, L, cycle, stack_conv):
     from diffsinger_amd import _lib, fs2, train_fused
     lib = _lib.load()
     train_fused._bind(lib)
-    assert train_fused.stack_conv() == stack_conv
+    assert train_fused.stack_conv() == ('wino' if stack_conv == 'wino-taps' else stack_conv)
     ws, dils = _make_stack(L, cycle, seed=L + T)
     g = torch.Generator().manual_seed(5 + T)
     x0 = torch.relu(torch.randn(B, 256, T, generator=g))

@@ -393,3 +393,103 @@ def test_training_backward_reads_stay_inside_the_da_tile():
             tE = frame_of_pair(p, e)
             assert 8 + tE - d >= 0 and 8 + tE + 2 * d < 48
     assert (2 * C + 16) * 48 * 4 <= (2 * C * 48 + 4 * 32 * 64) * 4      # chunk 16 of K half 1 = rows 512 .. 527: the exchange buffer behind the tile
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# the Winograd F(2,3) DUAL of the convolution's weight gradient (csrc/train_kernels.hpp k_tr_wgrad, loop_dual / k_tr_wgrad_reduce_dual)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+def _dual_thread_operands(a_rows, y_rows, t0, sg, d, prod, TS, ypad):
+    """What ONE staging thread (pair quad sg = tid & 7) of a dual step writes to LDS for its rows: the operand values of the pairs 4 sg .. 4 sg + 3
+    of the 64-frame step at t0, formed from aligned float4 loads exactly as loop_dual forms them.  a_rows [R][TS] (da: zero in [T, TS)),
+    y_rows [R'][TS + 2 ypad] (the saved y with ypad zero floats on both sides; column ypad = frame 0)."""
+    ds = d if d < 4 else 4
+    if ds >= 4:
+        pq = 4 * sg
+        blk = pq // d
+        e0 = 2 * d * blk + (pq - blk * d)
+        o1 = e0 + d
+        o2 = e0 - d if prod == 0 else e0 + 2 * d
+    else:
+        e0, o1 = 8 * sg, 8 * sg + 4
+        o2 = e0 - ds if prod == 0 else e0 + 8                               # a 4- / 8-byte load: the d frames in front of / behind the 8
+    dead = (t0 + 32 >= TS) and sg >= 4                                    # the half of an utterance's last step that lies behind its rows
+    sh = -32 if dead else 0
+
+    def f4(rows, col0, off, n=4):                                         # an ALIGNED load of n floats at frame t0 + off
+        c = col0 + t0 + off + sh
+        assert c % n == 0 and c >= 0 and c + n <= rows.shape[1], (c, rows.shape)
+        return rows[:, c:c + n]
+
+    def eo(l0, l1):
+        if ds == 1:
+            return np.stack([l0[:, 0], l0[:, 2], l1[:, 0], l1[:, 2]], 1), np.stack([l0[:, 1], l0[:, 3], l1[:, 1], l1[:, 3]], 1)
+        if ds == 2:
+            return np.stack([l0[:, 0], l0[:, 1], l1[:, 0], l1[:, 1]], 1), np.stack([l0[:, 2], l0[:, 3], l1[:, 2], l1[:, 3]], 1)
+        return l0, l1
+
+    ae, ao = eo(f4(a_rows, 0, e0), f4(a_rows, 0, o1))
+    A = [ae, ae + ao, ae - ao, ao][prod]
+    l0, l1 = f4(y_rows, ypad, e0), f4(y_rows, ypad, o1)
+    x2 = f4(y_rows, ypad, o2, 4 if ds >= 4 else ds) if prod in (0, 3) else None
+    if ds >= 4:
+        Bv = [x2 - l1 if prod == 0 else None, l0 + l1, l1 - l0, l0 - x2 if prod == 3 else None][prod]
+    else:
+        e, o = eo(l0, l1)
+        if prod == 1:
+            Bv = e + o
+        elif prod == 2:
+            Bv = o - e
+        elif prod == 0:
+            m = np.stack([x2[:, 0], l0[:, 1], l0[:, 3], l1[:, 1]], 1) if ds == 1 else np.stack([x2[:, 0], x2[:, 1], l0[:, 2], l0[:, 3]], 1)
+            Bv = m - o
+        else:
+            n = np.stack([l0[:, 2], l1[:, 0], l1[:, 2], x2[:, 0]], 1) if ds == 1 else np.stack([l1[:, 0], l1[:, 1], x2[:, 0], x2[:, 1]], 1)
+            Bv = e - n
+    if dead:
+        A, Bv = np.zeros_like(A), np.zeros_like(Bv)
+    return A, Bv
+
+
+@pytest.mark.parametrize('d', [1, 2, 4, 8])
+@pytest.mark.parametrize('T', [64, 96, 70, 33, 200])
+def test_weight_gradient_dual_index_algebra(d, T):
+    """The four pair products, staged thread by thread as k_tr_wgrad's dual step stages them (aligned 16-byte loads, the E / O permutation for
+    d = 1, 2, whole float4 for d = 4, 8, the +- d neighbours, the dead half of a step behind TS), summed over the steps and back-transformed
+    as k_tr_wgrad_reduce_dual does - against the three tap gradients dW_k[m][n] = sum_t a[m][t] y[n][t + (k - 1) d] in float64."""
+    rng = np.random.default_rng(100 * d + T)
+    TS, ypad = (T + 31) // 32 * 32, 8
+    R, Rb = 6, 5
+    a = np.zeros((R, TS))
+    a[:, :T] = rng.standard_normal((R, T))
+    y = np.zeros((Rb, TS + 2 * ypad))
+    y[:, ypad:ypad + T] = rng.standard_normal((Rb, T))
+    want = np.zeros((3, R, Rb))
+    for k in range(3):
+        for t in range(T):
+            tt = t + (k - 1) * d
+            if 0 <= tt < T:
+                want[k] += np.outer(a[:, t], y[:, ypad + tt])
+    P = np.zeros((4, R, Rb))
+    seen = set()
+    for t0 in range(0, TS, 64):
+        for prod in range(4):
+            for sg in range(8):
+                A, Bv = _dual_thread_operands(a, y, t0, sg, d, prod, TS, ypad)
+                P[prod] += A @ Bv.T
+        # every frame of the step belongs to exactly one pair of exactly one thread
+        ds = d if d < 4 else 4
+        for sg in range(8):
+            if ds >= 4:
+                pq = 4 * sg
+                blk = pq // d
+                e0 = 2 * d * blk + (pq - blk * d)
+                fr = [t0 + e0 + i for i in range(4)] + [t0 + e0 + d + i for i in range(4)]
+            else:
+                fr = [t0 + 8 * sg + i for i in range(8)]
+            for f in fr:
+                assert f not in seen
+                seen.add(f)
+    assert seen == set(range(0, (TS + 63) // 64 * 64))
+    hs = 0.5 * (P[1] + P[2])
+    got = np.stack([P[0] + hs, 0.5 * (P[1] - P[2]), hs - P[3]])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)

@@ -91,6 +91,9 @@ trainpmc)
 parity)
     timeout 1500 python tools/bench_configs.py 1 --parity > $O/configs_parity.jsonl 2> $O/configs_parity.err
     cut -c1-300 $O/configs_parity.jsonl; tail -3 $O/configs_parity.err ;;
+touch)
+    for rep in 1 2; do timeout 300 python tools/wino_ab.py --touch=16,32,48,24,16,32 2>/dev/null | grep "^{" >> $O/wino_ab_touch.jsonl; done
+    cut -c1-210 $O/wino_ab_touch.jsonl ;;
 sweep)
     timeout 600 python tools/shape_sweep.py 3 1x512,1x1000,1x1550,4x777,2x2048,3x1550,1x5000,1x8000,6x1024,8x1024,3x5000,16x2048 > $O/shape_sweep.jsonl 2> $O/shape_sweep.err
     timeout 600 python tools/bench_configs.py 3 > $O/configs_throughput.jsonl 2> $O/configs_throughput.err

@@ -13,8 +13,10 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from diffsinger_amd.build import FLAGS as _LIB_FLAGS  # noqa: E402
 GOLDEN = os.path.join(ROOT, 'tests', 'golden', 'kernel_isa_hashes.json')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '--cuda-device-only', '-S']
+FLAGS = [f for f in _LIB_FLAGS if f != '-shared'] + ['--cuda-device-only', '-S']       # the library's own flags, device-only assembly
 
 
 _LISTING = None

@@ -21,7 +21,8 @@ for (B, T) in shapes:
     eng = gd._engine(cond)
     eng.set_loop_mode(1)
     ref = None
-    variants = [('direct', -1)] + [('winograd', t) for t in (16, 0, 8, 32)]
+    touches = next((tuple(int(v) for v in a[8:].split(',')) for a in sys.argv if a.startswith('--touch=')), (16, 0, 8, 32))
+    variants = [('direct', -1)] + [('winograd', t) for t in touches]
     if len(shapes) > 1:
         variants = [('direct', -1), ('winograd', -1)]
     for conv, touch in variants:
@@ -46,4 +47,4 @@ for (B, T) in shapes:
         print(json.dumps({'shape': [B, T], 'conv': conv, 'touch': touch, 'kernel': 'k_loop_wino' if wino else 'k_loop', 'launches': eng.loop_launches(),
                           'ms_per_call': round(ms, 3), 'mel_frames_per_s': round(B * T / ms * 1e3, 1), 'tflops_executed': round(tf, 2),
                           'frac_fp32_mfma_peak': round(tf / bench.PEAK_FP32_MFMA_TFLOPS, 4), 'max_abs_x_vs_direct': float((out - ref).abs().max())}), flush=True)
-    eng.set_conv_mode('winograd', 16)
+    eng.set_conv_mode('winograd', 32)
