@@ -551,10 +551,12 @@ def main_train(args):
             achieved = flop / (ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': 'k_tr_wgrad<false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_launch_ms': ms, 'flop_per_launch': flop, 'launches_timed': n_launch,
-                    'note': 'every weight gradient of two residual layers per launch (dilated conv 3 taps, conditioner projection, output projection: '
-                            '2 x 20 output tiles of 128 x 256, contracted over the frames in 6 splits = 240 workgroups); average over the launches of '
-                            '3 steps, events on the launch stream around each launch (they include the gap to the previous kernel); the split-K '
-                            'reduction kernel behind it is not part of the figure.  Kernel times of the whole step: profiles/train_kernel_stats.txt'}
+                    'note': 'every weight gradient of two residual layers per launch: the dilated convolution as the Winograd F(2,3) DUAL (four products over '
+                            'frame PAIRS per 128-row tile instead of three over the frames: 32 products x 4 frame splits) + conditioner and output projection '
+                            '(16 tiles x 8 splits) = 256 workgroups; flop_per_launch = EXECUTED (a dual product contracts T / 2 pairs); average over the '
+                            'launches of 3 steps, events on the launch stream around each launch (they include the gap to the previous kernel); the two '
+                            'reduction kernels behind it (split-K sums + the dual\'s back-transform) are not part of the figure.  Kernel times of the whole '
+                            'step: profiles/r6_*_train_kernel_stats.txt'}
         else:
             roof = {'bound': 'mfma', 'kernel': 'k_fs_conv<2> (operator path)', 'achieved': None, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
                     'traffic': None, 'note': 'the fused stack is switched off (DSD_TRAIN_FUSED=0) or does not cover this DiffNet'}
@@ -572,7 +574,8 @@ def main_train(args):
                                       f'batch={B} x T={T} per GPU, forward + backward on the ' + ('fused residual-stack kernels (csrc/train_kernels.hpp)' if fused else 'HIP training operators'), 'preset': PRESET,
                           'conv': (train_fused.stack_conv() + ' (the persistent forward AND the transposed convolution of the backward)') if fused else 'direct',
                           'optimizer': 'not included (diffsinger_amd/train_dist.py)', 'sharding': 'replicas (no gradient exchange in this bench)'},
-               'roofline': roof, 'model_tflops_gemm': world * B * T * 3 * F_TRAIN_FWD * args.steps / el / 1e12}
+               'roofline': roof, 'model_tflops_gemm': world * B * T * 3 * F_TRAIN_FWD * args.steps / el / 1e12,
+               'frac_row_executed': world * B * T * F_TRAIN_EXEC * args.steps / el / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline_train()
             res['speedup_vs_cpu_baseline'] = value / res['cpu_baseline']['value']
@@ -587,9 +590,10 @@ def main_train(args):
 # item 2: until round 6 every f-row number was a builder-kept file).  Each uses the workload of its own `--row` bench.
 # ------------------------------------------------------------------------------------------------------------
 F_CONV_LAYERS = L_LAYERS * 2 * 512 * 768                   # direct-form FLOP / frame of the 20 dilated convolutions (15 728 640)
-# training step, EXECUTED: forward and data-gradient half with the dilated convolution as Winograd F(2,3) (x 2/3 on that part), every weight
-# gradient in direct form (= the forward's GEMM FLOPs)
-F_TRAIN_EXEC = 2 * (F_TRAIN_FWD - F_CONV_LAYERS // 3) + F_TRAIN_FWD
+# training step, EXECUTED: forward, data gradients and (round 6: the Winograd dual over frame pairs) weight gradients all run the dilated convolution
+# on 2/3 of its multiplications; the 1 x 1 projections are what they are
+F_TRAIN_EXEC = 3 * (F_TRAIN_FWD - F_CONV_LAYERS // 3)
+F_TRAIN_EXEC_TAPS = 2 * (F_TRAIN_FWD - F_CONV_LAYERS // 3) + F_TRAIN_FWD      # dsf_set_wgrad_dual(0): the weight gradient as three tap products (round 5)
 
 
 def _event_ms(fn, warm, steps):
@@ -699,7 +703,7 @@ def quick_rows(gd, device, warm=3, steps=10):
         rows['train'] = {'ms': ms, 'ms_wall': ms_wall, 'flop_row': flop, 'frac_row': flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          'frac_row_direct_accounting': B * T * 3 * F_TRAIN_FWD / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          'what': f'q_sample + DiffNet forward + L1 + backward, {B} x {T} frames, no optimiser (= `--row train`); flop_row = EXECUTED GEMM FLOPs '
-                                 '(forward and data gradients with the dilated convolution as Winograd F(2,3), weight gradients in direct form)'}
+                                 '(forward, data gradients and weight gradients with the dilated convolution as Winograd F(2,3) / its dual over frame pairs)'}
         net.zero_grad(set_to_none=True)
     except Exception as e:
         rows['train'] = {'error': repr(e)[:300]}

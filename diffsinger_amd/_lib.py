@@ -8,7 +8,7 @@ import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdsdenoise.so')
 
-DSD_ABI_VERSION = 5
+DSD_ABI_VERSION = 6
 
 # every symbol include/dsd.h declares (tests check the .so exports exactly these)
 SYMBOLS = [

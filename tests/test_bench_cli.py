@@ -103,6 +103,6 @@ def test_the_n1_line_has_rows_offshape_and_inservice_noise_legs():
     src = open(os.path.join(ROOT, 'bench.py')).read()
     for key in ("res['rows'] = quick_rows(", "res['offshape'] = offshape(", "res['inservice_noise'] = inservice_noise("):
         assert key in src
-    assert bench.F_TRAIN_EXEC == 2 * (26_427_392 - 15_728_640 // 3) + 26_427_392 and bench.F_CONV_LAYERS == 15_728_640
+    assert bench.F_TRAIN_EXEC == 3 * (26_427_392 - 15_728_640 // 3) and bench.F_CONV_LAYERS == 15_728_640
     assert bench.WEIGHT_BYTES == 60_345_664 and bench.F_EVAL_EXEC_WINO == 15_810_560
     assert not [f for f in os.listdir(os.path.join(ROOT, 'tools')) if f.startswith('gpu_') and f.endswith('.sh')], 'ONE GPU script: tools/gpu.sh'
