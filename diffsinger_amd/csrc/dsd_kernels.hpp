@@ -90,7 +90,11 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NMB][NB], const float4 (
 // block and its filter block / a residual block and its skip block (the row-split kernels of dsd_lat.hpp).
 // BV: the B tile is FRAME-MAJOR ([frame][k], k contiguous; dsd_loop_fm.hpp): the four k values of a chunk a lane needs (k = 4h + s) are
 // ONE aligned ds_read_b128 instead of four ds_read_b32 at a stride of LD.
-template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff, int MBS = 1, bool BV = false>
+// VOL (round 6, the vocoder's one-convolution kernel): the 4 NB ds_read_b32 of a chunk as VOLATILE accesses.  hipcc pairs plain ones into
+// ds_read2_b32, whose 8-bit offsets do not reach across a tile row wider than 1 KiB: one v_add_u32 per row for a new base, 3-5 vector-ALU
+// instructions per chunk - each paid in matrix time beside an fp32 MFMA (tools/mfma_filler_probe.hip).  Volatile accesses are not merged: the
+// row offset sits in the 16-bit offset field of each ds_read_b32.  Same values, same order of arithmetic.
+template <int NMB, int NB, int LD, int ASTRIDE, int STAGES, typename BOff, int MBS = 1, bool BV = false, bool VOL = false>
 struct GemmPipe {
     static_assert(STAGES == 3 || STAGES == 6, "register rotation period is 6");
     static_assert(!BV || NB == 1, "frame-major B tiles are one 32-frame block wide");
@@ -126,6 +130,13 @@ struct GemmPipe {
         if constexpr (BV) {
             const float4 v = *reinterpret_cast<const float4*>(bp);
             dst[0][0] = v.x; dst[1][0] = v.y; dst[2][0] = v.z; dst[3][0] = v.w;
+        } else if constexpr (VOL) {
+            typedef const volatile __attribute__((address_space(3))) float lds_cvf;
+            lds_cvf* vp = (lds_cvf*)bp;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) dst[s][nb] = vp[s * LD + nb * 32];
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -144,7 +155,7 @@ struct GemmPipe {
 #pragma unroll
         for (int i = 0; i < NDS; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, VOL ? 2 : 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NMB * NB - NMB - NDS, 0);
     }
@@ -226,9 +237,9 @@ __device__ __forceinline__ void gemm_k(f32x16 (&acc)[NMB][NB], const float4* __r
     pipe.start();
     pipe.run(acc, 0, n);
 }
-template <int NMB, int NB, int LD, int ASTRIDE, typename BOff>
+template <int NMB, int NB, int LD, int ASTRIDE, bool VOL = false, typename BOff>
 __device__ __forceinline__ void gemm_k_blocks(f32x16 (&acc)[NMB][NB], const float4* __restrict__ abase_uniform, int lane, int n, BOff bof) {
-    GemmPipe<NMB, NB, LD, ASTRIDE, 6, BOff> pipe(abase_uniform, lane, n, bof);
+    GemmPipe<NMB, NB, LD, ASTRIDE, 6, BOff, 1, false, VOL> pipe(abase_uniform, lane, n, bof);
     pipe.start();
     pipe.run_blocks(acc, n);
 }

@@ -136,18 +136,24 @@ struct ChainPipe {
         cur += adv ? step : 0;
         tap = adv ? (wrap ? 0 : tap + 1) : tap;
         left -= adv ? 1 : 0;
+        // VOLATILE LDS loads (round 6): left alone, hipcc pairs the sixteen ds_read_b32 of a chunk into ds_read2_b32, whose two 8-bit offsets
+        // do not reach across a tile row - one v_add_u32 per row for a new base, 4-5 vector-ALU instructions per chunk, each paid in matrix
+        // time (tools/mfma_filler_probe.hip: 8 cycles beside an fp32 MFMA).  A volatile access is not merged: ds_read_b32 with the row and
+        // block offsets in its own 16-bit offset field, ONE vector instruction per chunk (the advance of the running pointer).
+        typedef const volatile __attribute__((address_space(3))) float lds_cvf;
+        lds_cvf* vp = (lds_cvf*)bp;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) dst[s][nb] = CONSTB ? bp[s * LD + 32 * nb] : bp[s * LD + boff[nb]];
+            for (int nb = 0; nb < NB; ++nb) dst[s][nb] = CONSTB ? vp[s * LD + 32 * nb] : vp[s * LD + boff[nb]];
     }
     __device__ __forceinline__ void pattern() {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
 #pragma unroll
-        for (int i = 0; i < 2 * NB; ++i) {
+        for (int i = 0; i < 2 * NB; ++i) {                      // (4 NB single ds_read_b32 per chunk: two behind each of 2 NB MFMAs)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - 1 - 2 * NB, 0);
     }

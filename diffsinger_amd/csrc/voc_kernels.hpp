@@ -136,7 +136,7 @@ __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
         const int nch = (nc8 / 8) * p.KT;
         const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
         VocTapB<LD> bof(smem + 4 * h * LD + HALO + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch);
-        gemm_k_blocks<1, NB, LD, 64>(acc, ap, lane, nch, bof);
+        gemm_k_blocks<1, NB, LD, 64, true>(acc, ap, lane, nch, bof);
         __syncthreads();
     }
     if (rb >= nrb) return;
