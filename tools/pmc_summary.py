@@ -87,7 +87,7 @@ def from_db(root, kern):
     return acc, dur
 
 
-def provenance(kern):
+def provenance(kern, tag=None):
     """Which binary the counters belong to: the build id of the library in this tree (dsd_build_id: sha256 of csrc/ + include/) and the hash
     of THE KERNEL'S device code (diffsinger_amd/kernel_isa.json, written by the build) - bench.py refuses a summary that matches neither the
     library it has loaded nor that kernel in it."""
@@ -95,6 +95,11 @@ def provenance(kern):
     from diffsinger_amd.build import binary_id, kernel_isa
     out = {'build_id': binary_id()}
     hits = {n: h for n, h in kernel_isa().items() if kern in n}
+    if len(hits) > 1 and tag:
+        # 'k_loop_wino' names two instantiations; the kernel_tag of the summary ('k_loop_wino<1, 4>', possibly followed by a note in
+        # parentheses) names the one that ran - r6_16's loop_pmc.json went unstamped without this and the next rebuild orphaned it
+        t = tag.split(' (')[0]
+        hits = {n: h for n, h in hits.items() if n.startswith(t)}
     if len(hits) == 1:
         (out['kernel_isa_name'], out['kernel_isa']), = hits.items()
     return out
@@ -124,7 +129,7 @@ def main(root, kern, out_txt, out_json, *extras):
     for kv in extras:                       # e.g. frames=8192 kernel_tag='k_layer<1,false>' round=r01b
         k, v = kv.split('=', 1)
         js[k] = int(v) if v.isdigit() else v
-    js.update(provenance(kern))
+    js.update(provenance(kern, js.get('kernel_tag') if isinstance(js.get('kernel_tag'), str) else None))
     if min_us > 0:
         lines.insert(1, f'# only dispatches of at least {min_us:g} us (one shape of the kernel)')
     if 'FETCH_SIZE' in avg and 'WRITE_SIZE' in avg:
