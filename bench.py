@@ -454,7 +454,7 @@ def main_vocoder(args):
                'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': f'SURVEY 8 row f2: HifiGanGenerator of configs/tts/hifigan.yaml (128 -> 8 channels, x256), batch={B} x T={T} mel '
-                                      f'frames per GPU -> {B} x {T * 256} samples', 'resblock_chains': 'one launch per stage for the 32 / 16 / 8-channel stages (k_voc_chain)' if chained else 'off: one launch per convolution',
+                                      f'frames per GPU -> {B} x {T * 256} samples', 'resblock_chains': 'one chain launch per resblock (three per stage) for the 32 / 16 / 8-channel stages (k_voc_chain, one LDS tile rewritten in place)' if chained else 'off: one launch per convolution',
                           'sharding': 'replicas (no exchange step in this row)'},
                'roofline': roof, 'model_tflops': world * B * T * fpf * args.steps / el / 1e12, 'flop_per_mel_frame': fpf,
                'x_realtime_24k': value * 256 / 24000,
