@@ -2,6 +2,7 @@
 // the library stays one translation unit (shares the error string, the HIP_TRY macros and the operand-packing kernel).
 #include "voc_kernels.hpp"
 #include "voc_chain.hpp"
+#include "voc_chain16.hpp"
 #include "pwg_kernels.hpp"
 
 #include "../../include/dsv.h"
@@ -240,6 +241,79 @@ extern "C" int dsv_resblock_chain(const float* in, const float* wpacked, const f
     }
     if (v.nb == 4) return voc_chain_launch<8, 4, 4, true>(p, convs, B, st);
     return v.ip ? voc_chain_launch<8, 4, 2, true>(p, convs, B, st) : voc_chain_launch<8, 4, 2, false>(p, convs, B, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the narrow stages on the 16-row matrix shape (voc_chain16.hpp)
+// ------------------------------------------------------------------------------------------------------------
+template <int C, int F, int NBLK>
+static int voc_chain16_geometry(const dsv_chain_conv* convs, int nres, int npairs, int* N_out, int* Hh_out) {
+    constexpr int NCOL = 256 * NBLK;
+    int hh = 0, cover = NCOL * F;
+    for (int r = 0; r < nres; ++r) {
+        int h = 0;
+        for (int i = 0; i < 2 * npairs; ++i) {
+            const dsv_chain_conv& c = convs[r * 2 * npairs + i];
+            const int pad = (c.K - 1) * c.dil / 2;
+            if (c.K < 1 || !(c.K & 1) || c.dil < 1 || pad > kVocHalo || F * c.dil > kChainSlack || ((i & 1) && c.dil != 1)) return -1;
+            h += pad;
+            cover = std::min(cover, (NCOL / c.dil) * F * c.dil);
+        }
+        hh = std::max(hh, h);
+    }
+    hh = (hh + 3) / 4 * 4;
+    const int n = (cover - 2 * hh) / 32 * 32;
+    if (n < 64) return -1;
+    *N_out = n; *Hh_out = hh;
+    return 0;
+}
+
+extern "C" int32_t dsv_chain16_fold(int32_t C) { return C == 16 ? 1 : C == 8 ? 2 : 0; }
+
+extern "C" int32_t dsv_chain16_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs) {
+    if (!convs || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs) return 0;
+    int n = 0, hh = 0, rc = -1;
+    if (C == 16) rc = voc_chain16_geometry<16, 1, 2>(convs, nres, npairs, &n, &hh);
+    else if (C == 8) rc = voc_chain16_geometry<8, 2, 2>(convs, nres, npairs, &n, &hh);
+    return rc == 0 ? n : 0;
+}
+
+template <int C, int F, int NBLK>
+static int voc_chain16_launch(VocChainParams& p, const dsv_chain_conv* convs, int B, hipStream_t s) {
+    if (voc_chain16_geometry<C, F, NBLK>(convs, p.nres, p.npairs, &p.N, &p.Hh) != 0)
+        return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: the chain does not fit the staged tile (ask dsv_chain16_supported first)");
+    constexpr int lds = chain16_lds_bytes<C, F, NBLK>();
+    if (first_on_device(400 + C))
+        HIP_TRY(hipFuncSetAttribute((const void*)k_voc_chain16<C, F, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const dim3 grid((unsigned)((p.LS + p.N - 1) / p.N), (unsigned)B);
+    hipLaunchKernelGGL((k_voc_chain16<C, F, NBLK>), grid, dim3(kThreads), lds, s, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsv_resblock_chain16(const float* in, const float* wpacked16, const float* bias, float* out, const float* sum_in, int32_t B, int32_t C,
+                                    int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream) {
+    if (!in || !wpacked16 || !bias || !out || !convs) return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: null argument");
+    if (in == out) return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: in and out must be different buffers (workgroups read their neighbours' samples)");
+    if (sum_in == out) return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: sum_in and out must be different buffers (out holds the running sum over the resblocks of the call)");
+    if (!(pre_slope >= 0.f && pre_slope <= 1.f)) return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: pre_slope must be in [0, 1] (leaky_relu as max(v, slope v))");
+    const int F = dsv_chain16_fold(C);
+    if (B < 1 || B > 65535 || L < 1 || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs || divide == 0.f || !F)
+        return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: bad shape (B=%d C=%d L=%d nres=%d npairs=%d): 8 or 16 channels, at most %d convolutions", B, C,
+                    L, nres, npairs, kChainMaxConvs);
+    VocChainParams p{};
+    p.in = in; p.out = out; p.sum_in = sum_in; p.wp = reinterpret_cast<const float4*>(wpacked16); p.bias = bias;
+    p.L = L; p.LS = voc_ls(L); p.nres = nres; p.npairs = npairs; p.slope = pre_slope; p.divide = divide; p.dbg = nullptr;
+    for (int i = 0; i < nres * npairs * 2; ++i) {
+        const dsv_chain_conv& c = convs[i];
+        if (c.w_offset < 0 || (c.w_offset % 512) || c.bias_offset < 0)
+            return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: convolution %d: weight offsets are multiples of 512 floats (whole chunks)", i);
+        p.conv[i].woff = (int)(c.w_offset / 4); p.conv[i].boff = c.bias_offset; p.conv[i].KT = c.K + F - 1; p.conv[i].dil = c.dil;
+        p.conv[i].pad = (c.K - 1) * c.dil / 2;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) return voc_chain16_launch<16, 1, 2>(p, convs, B, st);
+    return voc_chain16_launch<8, 2, 2>(p, convs, B, st);
 }
 
 extern "C" int dsv_noise_conv(const float* har, const float* w, const float* bias, float* out, int32_t B, int32_t C, int32_t K, int32_t stride,

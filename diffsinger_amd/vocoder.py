@@ -72,6 +72,22 @@ def fold_weight(w: torch.Tensor, F: int) -> torch.Tensor:
     return wf.reshape(co * F, ci, k + F - 1).contiguous()
 
 
+def pack_chain16(w: torch.Tensor, F: int) -> torch.Tensor:
+    """Conv1d weight [C][C][K] (C * F == 16) -> the A operand of csrc/voc_chain16.hpp (include/dsv.h dsv_resblock_chain16): the F-fold W'[16][C][KT]
+    (KT = K + F - 1) as chunks (8-channel group g, tap s) of two fragment rows [half][lane 64][4]: lane l carries row l % 16 (the four 16 x 16
+    blocks of v_mfma_f32_16x16x1_4B_f32 multiply the same filter), value j = 4 half + i is channel 8 g + (j >> 1) + 4 (j & 1) - the order in which
+    the one-convolution kernels' four 32x32x2 MFMAs of a chunk visit their k = 0 / 1 halves.  Returns a flat float tensor of (C / 8) KT 512."""
+    wf = fold_weight(w, F) if F > 1 else w.contiguous()
+    rows, ci, kt = wf.shape
+    assert rows == 16 and ci % 8 == 0
+    order = torch.tensor([(j >> 1) + 4 * (j & 1) for j in range(8)], device=w.device)
+    g = wf.reshape(16, ci // 8, 8, kt)[:, :, order, :]                      # [row][g][j][s]
+    g = g.permute(1, 3, 2, 0).reshape(ci // 8, kt, 2, 4, 16)                # [g][s][half][i][row]
+    g = g.permute(0, 1, 2, 4, 3)                                           # [g][s][half][row][i]
+    g = g.unsqueeze(3).expand(ci // 8, kt, 2, 4, 16, 4)                     # [g][s][half][blk][row][i]: lane = 16 blk + row
+    return g.reshape(-1).contiguous()
+
+
 import ctypes as _C
 
 
@@ -88,6 +104,15 @@ class DsvChainConv(_C.Structure):
 # 'stage' / 'resblock' / 'pair' force that grouping; 'off' = one launch per convolution everywhere (the A/B switch of the measurement and of
 # the bit-identity tests).
 _CHAIN_MODE = None
+# The 16- and 8-channel stages on the 16-row matrix shape (csrc/voc_chain16.hpp, round 6): one launch per resblock like the default above,
+# 12.5 % / 20 % less matrix work, the same bits.  Applies in the default chain mode only; set_chain16(False) is the A/B switch.
+_CHAIN16 = True
+
+
+def set_chain16(on: bool):
+    global _CHAIN16
+    _CHAIN16 = bool(on)
+
 
 
 def set_chain_mode(mode):
@@ -173,6 +198,21 @@ class _HipOps:
         with torch.cuda.device(x.device):
             _lib.check(self.lib.dsv_resblock_chain(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr(), self._p(sum_in), B, C, L, nres, npairs,
                                                    descs, float(pre_slope), float(divide), self._s(x.device)), 'dsv_resblock_chain')
+        return out
+
+    def chain16_fold(self, C: int) -> int:
+        return int(self.lib.dsv_chain16_fold(C))
+
+    def chain16_supported(self, C, nres, npairs, descs) -> int:
+        return int(self.lib.dsv_chain16_supported(C, nres, npairs, descs))
+
+    def resblock_chain16(self, x, L, wp16, bias, C, nres, npairs, descs, sum_in=None, divide=1.0, pre_slope=LRELU_SLOPE):
+        B = x.shape[0]
+        assert x.shape[1] == C and x.shape[2] == padded_samples(L) and x.is_contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.dsv_resblock_chain16(x.data_ptr(), wp16.data_ptr(), bias.data_ptr(), out.data_ptr(), self._p(sum_in), B, C, L, nres, npairs,
+                                                     descs, float(pre_slope), float(divide), self._s(x.device)), 'dsv_resblock_chain16')
         return out
 
     def noise_conv(self, har, L_har, w, bias, stride, pad, L_out):
@@ -378,10 +418,49 @@ class HifiGanGenerator(nn.Module):
         self._packed[f'chain{i}'] = (tag, entry)
         return entry
 
+    def _chain_prep16(self, i: int):
+        """Stage i's ResBlock1 convolutions for the 16-row chain kernel (pack_chain16): one weight buffer + 1 536 floats of prefetch slack, one
+        bias buffer, a descriptor per convolution.  None: not a ResBlock1 stage of 8 / 16 channels.  Cached per parameter version."""
+        rbs = [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)]
+        if any(rb.kind != '1' for rb in rbs) or len({len(rb.dils) for rb in rbs}) != 1:
+            return None
+        C = rbs[0].convs1[0].wshape()[0]
+        F = self._ops.chain16_fold(C)
+        if not F:
+            return None
+        convs = [(c, d if which == 0 else 1) for rb in rbs for q, d in enumerate(rb.dils) for which, c in ((0, rb.convs1[q]), (1, rb.convs2[q]))]
+        tag = tuple(c.tag() for c, _ in convs)
+        hit = self._packed.get(f'chain16_{i}')
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        pieces = [pack_chain16(c.plain_weight().to(torch.float32), F) for c, _ in convs]
+        dev = convs[0][0].bias.device
+        wp = torch.cat(pieces + [torch.zeros(1536, device=dev, dtype=torch.float32)])
+        bias = torch.stack([c.bias.detach().to(torch.float32) for c, _ in convs])
+        descs = (DsvChainConv * len(convs))()
+        off = 0
+        for n, ((c, d), pc) in enumerate(zip(convs, pieces)):
+            descs[n] = DsvChainConv(off, n * C, int(c.wshape()[2]), int(d), 0)
+            off += pc.numel()
+        entry = dict(wp=wp, bias=bias, descs=descs, C=C, npairs=len(rbs[0].dils), nres=len(rbs))
+        self._packed[f'chain16_{i}'] = (tag, entry)
+        return entry
+
     def _stage_resblocks(self, i: int, x, L):
         """x = (sum_j resblock_{i, j}(x)) / num_kernels (hifigan.py:161-166): fused chains where the library offers them, else one launch per
         convolution.  Every grouping gives the same bits."""
         mode = _CHAIN_MODE
+        if mode is None and _CHAIN16:
+            e16 = self._chain_prep16(i)
+            if e16 is not None:
+                C, nres, npairs, ops = e16['C'], e16['nres'], e16['npairs'], self._ops
+                sub16 = lambda r: (DsvChainConv * (npairs * 2))(*[e16['descs'][(r * npairs + q) * 2 + k] for q in range(npairs) for k in range(2)])
+                if all(ops.chain16_supported(C, 1, npairs, sub16(r)) for r in range(nres)):
+                    acc = None
+                    for r in range(nres):
+                        acc = ops.resblock_chain16(x, L, e16['wp'], e16['bias'], C, 1, npairs, sub16(r), sum_in=acc,
+                                                   divide=float(self.num_kernels) if r == nres - 1 else 1.0)
+                    return acc
         e = self._chain_prep(i) if mode != 'off' else None
         if e is not None:
             C, nres, npairs = e['C'], e['nres'], e['npairs']

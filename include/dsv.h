@@ -99,6 +99,19 @@ int dsv_set_chain_variant(int32_t C, int32_t nb, int32_t in_place);
  * contraction done, epilogue done, barrier passed}. */
 int dsv_debug_chain_timeline(uint64_t* device_stamps);
 
+/* The same chains for the NARROW stages (16 and 8 channels) on a 16-row matrix shape (csrc/voc_chain16.hpp, round 6): no fold at 16 channels,
+ * a 2-fold at 8 (dsv_chain16_fold) instead of the 2- / 4-fold of dsv_resblock_chain - 12.5 % / 20 % less matrix work, the same sums in the same
+ * order (bit-identical to dsv_conv1d / dsv_conv1d_folded and to dsv_resblock_chain).  `wpacked16`: per convolution the filter folded F =
+ * dsv_chain16_fold(C) times (W'[co F + e][ci][s] = w[co][ci][s - e], K + F - 1 taps, 16 rows) as chunks [ci8 * (K + F - 1) + s] of two 1 KiB
+ * fragment rows [half 2][lane 64][4 floats]: lane l carries row l % 16, value i of half h = W'[row][8 ci8 + ch][s] with ch = (j >> 1) + 4 (j & 1),
+ * j = 4 h + i (diffsinger_amd/vocoder.py pack_chain16 builds it); w_offset in floats, a multiple of 512; the buffer must extend 1 536 floats
+ * beyond the last convolution (prefetch overrun).  Everything else - in / out / sum_in / bias / convs / pre_slope / divide - as dsv_resblock_chain;
+ * dsv_chain16_supported returns N (0: use dsv_resblock_chain or the single convolutions). */
+int32_t dsv_chain16_fold(int32_t C);
+int32_t dsv_chain16_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs);
+int dsv_resblock_chain16(const float* in, const float* wpacked16, const float* bias, float* out, const float* sum_in, int32_t B, int32_t C,
+                         int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream);
+
 /* noise_convs[i] (hifigan.py:124-130, :158-160): the strided Conv1d(1 -> C, kernel K, stride, padding) over the harmonic
  * source.  har [B][LS(L_har)], w [C][K] (the torch weight [C][1][K]), bias [C] or NULL, out [B][C][LS(L_out)];
  * L_out must equal (L_har + 2 * pad - K) / stride + 1. */

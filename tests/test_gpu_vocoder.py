@@ -262,8 +262,10 @@ DEFAULT_CHAIN_VARIANT = {8: (2, 1), 16: (2, 1), 32: (4, 1)}       # csrc/voc_abi
 def chain_default():
     from diffsinger_amd import vocoder
     vocoder.set_chain_mode(None)
+    vocoder.set_chain16(True)
     yield vocoder
     vocoder.set_chain_mode(None)
+    vocoder.set_chain16(True)
 
 
 @pytest.mark.parametrize('stage,L', [(3, 5000), (3, 896), (3, 33), (2, 3001), (2, 640), (1, 1500), (1, 449), (0, 300)])
@@ -286,6 +288,50 @@ def test_resblock_chain_is_bit_identical_to_the_single_convolutions(stage, L, mo
     torch.cuda.synchronize()
     assert torch.isfinite(got).all() and float(got[:, :, L:].abs().max() if got.shape[2] > L else 0) == 0
     assert torch.equal(got, want), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize('stage,L', [(3, 5000), (3, 1024), (3, 896), (3, 33), (2, 3001), (2, 640), (2, 512), (2, 7)])
+def test_chain16_is_bit_identical_to_the_single_convolutions_and_to_the_32_row_chains(stage, L, chain_default):
+    """csrc/voc_chain16.hpp (round 6): the 16- / 8-channel stages on v_mfma_f32_16x16x1_4B_f32 - no fold / a 2-fold instead of the 2- / 4-fold
+    of the 32-row chains - visit every output sample's contributions in the one-convolution kernels' order and that MFMA shape accumulates
+    like theirs (profiles/r6_25_mfma_shape_probe.jsonl): the same BITS as one launch per convolution and as the 32-row chain kernels, with a
+    running sum coming in (resblocks 1, 2), on several tiles with a partial last one, exactly one tile, and a tile shorter than the halo."""
+    case = dict(nsf=False, B=2, T=8, seed=41 + stage)
+    h, p, m = _generator(case)
+    m(torch.zeros(1, 80, 4, device=DEV))
+    C = 128 >> (stage + 1)
+    g = torch.Generator().manual_seed(100 * stage + L)
+    x = _cm(torch.randn(3, C, L, generator=g), L).to(DEV)
+    chain_default.set_chain_mode('off')
+    want = m._stage_resblocks(stage, x, L)
+    chain_default.set_chain_mode(None)
+    chain_default.set_chain16(False)
+    chains32 = m._stage_resblocks(stage, x, L)
+    chain_default.set_chain16(True)
+    assert m._chain_prep16(stage) is not None
+    got = m._stage_resblocks(stage, x, L)
+    again = m._stage_resblocks(stage, x, L)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and float(got[:, :, L:].abs().max() if got.shape[2] > L else 0) == 0
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert torch.equal(got, chains32) and torch.equal(again, got)
+
+
+def test_chain16_entry_point_contract():
+    from diffsinger_amd.vocoder import DsvChainConv
+    lib = _lib.load()
+    assert lib.dsv_chain16_fold(16) == 1 and lib.dsv_chain16_fold(8) == 2 and lib.dsv_chain16_fold(32) == 0
+    ok = (DsvChainConv * 2)(DsvChainConv(0, 0, 11, 5, 0), DsvChainConv(6144, 8, 11, 1, 0))
+    assert lib.dsv_chain16_supported(8, 1, 1, ok) > 0 and lib.dsv_chain16_supported(16, 1, 1, ok) > 0 and lib.dsv_chain16_supported(32, 1, 1, ok) == 0
+    wide = (DsvChainConv * 2)(DsvChainConv(0, 0, 7, 12, 0), DsvChainConv(4096, 8, 7, 1, 0))           # 36 samples of reach: beyond the staged halo
+    assert lib.dsv_chain16_supported(8, 1, 1, wide) == 0
+    x = torch.zeros(1, 8, 1024, device=DEV)
+    bad = (DsvChainConv * 2)(DsvChainConv(100, 0, 3, 1, 0), DsvChainConv(2048, 8, 3, 1, 0))          # offset not a whole chunk
+    wp = torch.zeros(8192, device=DEV)
+    b = torch.zeros(16, device=DEV)
+    out = torch.empty_like(x)
+    assert lib.dsv_resblock_chain16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), out.data_ptr(), None, 1, 8, 1000, 1, 1, bad, 0.1, 1.0, None) != 0
+    assert lib.dsv_resblock_chain16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), x.data_ptr(), None, 1, 8, 1000, 1, 1, ok, 0.1, 1.0, None) != 0     # in == out
 
 
 CHAIN_VARIANTS = [(32, 4, 0), (32, 4, 1), (16, 2, 0), (16, 2, 1), (16, 4, 1), (8, 2, 0), (8, 2, 1), (8, 4, 1)]
