@@ -32,7 +32,7 @@ SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf
 
 # every symbol include/dsv.h declares (the HiFi-GAN / NSF-HiFi-GAN generator ops)
 SYMBOLS_VOC = ['dsv_padded_samples', 'dsv_packed_floats', 'dsv_pack_weight', 'dsv_pad_rows', 'dsv_conv1d', 'dsv_noise_conv', 'dsv_sine_source',
-               'dsv_fold_factor', 'dsv_set_fold', 'dsv_conv1d_folded', 'dsv_chain_fold', 'dsv_chain_supported', 'dsv_resblock_chain', 'dsv_chain16_fold', 'dsv_chain16_supported', 'dsv_resblock_chain16', 'dsv_set_chain_variant', 'dsv_debug_chain_timeline',
+               'dsv_fold_factor', 'dsv_set_fold', 'dsv_conv1d_folded', 'dsv_chain_fold', 'dsv_chain_supported', 'dsv_resblock_chain', 'dsv_resblock_chain_multi', 'dsv_resblock_chain_sum', 'dsv_set_chain_variant', 'dsv_debug_chain_timeline',
                'dsv_pwg_first', 'dsv_pwg_upsample', 'dsv_pwg_layer']
 
 _fp = C.POINTER(C.c_float)
@@ -179,11 +179,8 @@ def load():
     lib.dsv_chain_supported.argtypes = [i32, i32, i32, vp]
     lib.dsv_chain_supported.restype = i32
     lib.dsv_resblock_chain.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, f32, f32, vp]
-    lib.dsv_chain16_fold.argtypes = [i32]
-    lib.dsv_chain16_fold.restype = i32
-    lib.dsv_chain16_supported.argtypes = [i32, i32, i32, vp]
-    lib.dsv_chain16_supported.restype = i32
-    lib.dsv_resblock_chain16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, f32, f32, vp]
+    lib.dsv_resblock_chain_multi.argtypes = [vp, vp, vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, f32, vp]
+    lib.dsv_resblock_chain_sum.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, f32, f32, vp]
     lib.dsv_set_chain_variant.argtypes = [i32, i32, i32]
     lib.dsv_debug_chain_timeline.argtypes = [vp]
     lib.dsv_noise_conv.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

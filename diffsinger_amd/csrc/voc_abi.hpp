@@ -2,7 +2,6 @@
 // the library stays one translation unit (shares the error string, the HIP_TRY macros and the operand-packing kernel).
 #include "voc_kernels.hpp"
 #include "voc_chain.hpp"
-#include "voc_chain16.hpp"
 #include "pwg_kernels.hpp"
 
 #include "../../include/dsv.h"
@@ -76,6 +75,16 @@ extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bi
     if (rc != DSD_OK) return rc;
     // narrow layers: one row block, the four waves split 512 samples; 64 rows: 2 x 2; wide (low-rate) layers: four row blocks x 32 samples
     const bool wide = pad > kVocHalo || (KT - 1) * dil - pad > kVocHalo;        // taps beyond the +-28 samples of the standard staging window
+    // rows > 64 on a LONG axis (the 64 -> 32 transposed convolution of the shipped generator: 256 polyphase rows x 8 192 input samples per
+    // utterance): four row blocks x NB 32-sample blocks per workgroup - a weight fragment feeds 4 NB MFMAs instead of 4 and the +-28-sample
+    // staging halo is paid once per 32 NB samples (round 6: 4 096 workgroups of 2 us of matrix work each were 8 latency-bound rounds).
+    // Same chunk order, same bits.
+    const long tall_wgs = (long)((p.LSi + 127) / 128) * B * ((rows + 127) / 128);
+    if (!wide && rows > 64 && tall_wgs >= 512) {
+        voc_conv_launch<4, 1, kVocHalo>(p, B, (hipStream_t)stream);
+        HIP_TRY(hipGetLastError());
+        return DSD_OK;
+    }
     if (wide) {
         if (rows <= 32) voc_conv_launch<4, 4, kVocHaloWide>(p, B, (hipStream_t)stream);
         else if (rows <= 64) voc_conv_launch<2, 2, kVocHaloWide>(p, B, (hipStream_t)stream);
@@ -244,76 +253,83 @@ extern "C" int dsv_resblock_chain(const float* in, const float* wpacked, const f
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// the narrow stages on the 16-row matrix shape (voc_chain16.hpp)
+// several independent resblocks of a stage in ONE launch + the launch that sums them (voc_chain.hpp, MG instantiations)
 // ------------------------------------------------------------------------------------------------------------
-template <int C, int F, int NBLK>
-static int voc_chain16_geometry(const dsv_chain_conv* convs, int nres, int npairs, int* N_out, int* Hh_out) {
-    constexpr int NCOL = 256 * NBLK;
-    int hh = 0, cover = NCOL * F;
-    for (int r = 0; r < nres; ++r) {
-        int h = 0;
-        for (int i = 0; i < 2 * npairs; ++i) {
-            const dsv_chain_conv& c = convs[r * 2 * npairs + i];
-            const int pad = (c.K - 1) * c.dil / 2;
-            if (c.K < 1 || !(c.K & 1) || c.dil < 1 || pad > kVocHalo || F * c.dil > kChainSlack || ((i & 1) && c.dil != 1)) return -1;
-            h += pad;
-            cover = std::min(cover, (NCOL / c.dil) * F * c.dil);
-        }
-        hh = std::max(hh, h);
+static int voc_chain_fill_convs(VocChainParams& p, const dsv_chain_conv* convs, int n, int F, const char* who) {
+    for (int i = 0; i < n; ++i) {
+        const dsv_chain_conv& c = convs[i];
+        if (c.w_offset < 0 || (c.w_offset % 256) || c.bias_offset < 0)
+            return fail(DSD_ERR_INVALID, "%s: convolution %d: weight offsets are multiples of 256 floats (whole chunks)", who, i);
+        p.conv[i].woff = (int)(c.w_offset / 4); p.conv[i].boff = c.bias_offset; p.conv[i].KT = c.K + F - 1; p.conv[i].dil = c.dil;
+        p.conv[i].pad = (c.K - 1) * c.dil / 2;
     }
-    hh = (hh + 3) / 4 * 4;
-    const int n = (cover - 2 * hh) / 32 * 32;
-    if (n < 64) return -1;
-    *N_out = n; *Hh_out = hh;
-    return 0;
+    return DSD_OK;
 }
 
-extern "C" int32_t dsv_chain16_fold(int32_t C) { return C == 16 ? 1 : C == 8 ? 2 : 0; }
-
-extern "C" int32_t dsv_chain16_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs) {
-    if (!convs || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs) return 0;
-    int n = 0, hh = 0, rc = -1;
-    if (C == 16) rc = voc_chain16_geometry<16, 1, 2>(convs, nres, npairs, &n, &hh);
-    else if (C == 8) rc = voc_chain16_geometry<8, 2, 2>(convs, nres, npairs, &n, &hh);
-    return rc == 0 ? n : 0;
-}
-
-template <int C, int F, int NBLK>
-static int voc_chain16_launch(VocChainParams& p, const dsv_chain_conv* convs, int B, hipStream_t s) {
-    if (voc_chain16_geometry<C, F, NBLK>(convs, p.nres, p.npairs, &p.N, &p.Hh) != 0)
-        return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: the chain does not fit the staged tile (ask dsv_chain16_supported first)");
-    constexpr int lds = chain16_lds_bytes<C, F, NBLK>();
-    if (first_on_device(400 + C))
-        HIP_TRY(hipFuncSetAttribute((const void*)k_voc_chain16<C, F, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    const dim3 grid((unsigned)((p.LS + p.N - 1) / p.N), (unsigned)B);
-    hipLaunchKernelGGL((k_voc_chain16<C, F, NBLK>), grid, dim3(kThreads), lds, s, p);
+template <int C, int F, int NB>
+static int voc_chain_launch_groups(VocChainParams& p, const dsv_chain_conv* convs, int B, hipStream_t s, const char* who) {
+    long blocks = 0;
+    for (int g = 0; g < p.ngroups; ++g) {
+        VocChainGroup& G = p.grp[g];
+        if (voc_chain_geometry<C, F, NB>(convs + (size_t)g * 2 * p.npairs, 1, p.npairs, &G.N, &G.Hh) != 0)
+            return fail(DSD_ERR_INVALID, "%s: resblock %d does not fit the staged tile (ask dsv_chain_supported first)", who, g);
+        G.tiles = (p.LS + G.N - 1) / G.N;
+        G.first = (int)blocks;
+        blocks += (long)B * G.tiles;
+    }
+    if (blocks > 0x7fffffffL) return fail(DSD_ERR_INVALID, "%s: too many workgroups", who);
+    constexpr int lds = chain_lds_bytes<C, F, NB, true>();
+    if (first_on_device(500 + C))
+        HIP_TRY(hipFuncSetAttribute((const void*)k_voc_chain<C, F, NB, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((k_voc_chain<C, F, NB, true, true>), dim3((unsigned)blocks), dim3(kThreads), lds, s, p);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }
 
-extern "C" int dsv_resblock_chain16(const float* in, const float* wpacked16, const float* bias, float* out, const float* sum_in, int32_t B, int32_t C,
-                                    int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream) {
-    if (!in || !wpacked16 || !bias || !out || !convs) return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: null argument");
-    if (in == out) return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: in and out must be different buffers (workgroups read their neighbours' samples)");
-    if (sum_in == out) return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: sum_in and out must be different buffers (out holds the running sum over the resblocks of the call)");
-    if (!(pre_slope >= 0.f && pre_slope <= 1.f)) return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: pre_slope must be in [0, 1] (leaky_relu as max(v, slope v))");
-    const int F = dsv_chain16_fold(C);
-    if (B < 1 || B > 65535 || L < 1 || nres < 1 || npairs < 1 || nres * npairs * 2 > kChainMaxConvs || divide == 0.f || !F)
-        return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: bad shape (B=%d C=%d L=%d nres=%d npairs=%d): 8 or 16 channels, at most %d convolutions", B, C,
-                    L, nres, npairs, kChainMaxConvs);
+static int voc_chain_groups(VocChainParams& p, const dsv_chain_conv* convs, int B, int C, hipStream_t s, const char* who) {
+    if (C == 32) return voc_chain_launch_groups<32, 1, 4>(p, convs, B, s, who);
+    if (C == 16) return voc_chain_launch_groups<16, 2, 2>(p, convs, B, s, who);
+    return voc_chain_launch_groups<8, 4, 2>(p, convs, B, s, who);
+}
+
+extern "C" int dsv_resblock_chain_multi(const float* in, const float* wpacked, const float* bias, float* const* outs, int32_t B, int32_t C, int32_t L,
+                                        int32_t ngroups, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, void* stream) {
+    if (!in || !wpacked || !bias || !outs || !convs) return fail(DSD_ERR_INVALID, "dsv_resblock_chain_multi: null argument");
+    if (!(pre_slope >= 0.f && pre_slope <= 1.f)) return fail(DSD_ERR_INVALID, "dsv_resblock_chain_multi: pre_slope must be in [0, 1] (leaky_relu as max(v, slope v))");
+    if (B < 1 || B > 65535 || L < 1 || ngroups < 1 || ngroups > kChainMaxGroups || npairs < 1 || ngroups * npairs * 2 > kChainMaxConvs || !dsv_chain_fold(C))
+        return fail(DSD_ERR_INVALID, "dsv_resblock_chain_multi: bad shape (B=%d C=%d L=%d ngroups=%d npairs=%d): 8, 16 or 32 channels, at most %d resblocks and %d convolutions",
+                    B, C, L, ngroups, npairs, kChainMaxGroups, kChainMaxConvs);
     VocChainParams p{};
-    p.in = in; p.out = out; p.sum_in = sum_in; p.wp = reinterpret_cast<const float4*>(wpacked16); p.bias = bias;
-    p.L = L; p.LS = voc_ls(L); p.nres = nres; p.npairs = npairs; p.slope = pre_slope; p.divide = divide; p.dbg = nullptr;
-    for (int i = 0; i < nres * npairs * 2; ++i) {
-        const dsv_chain_conv& c = convs[i];
-        if (c.w_offset < 0 || (c.w_offset % 512) || c.bias_offset < 0)
-            return fail(DSD_ERR_INVALID, "dsv_resblock_chain16: convolution %d: weight offsets are multiples of 512 floats (whole chunks)", i);
-        p.conv[i].woff = (int)(c.w_offset / 4); p.conv[i].boff = c.bias_offset; p.conv[i].KT = c.K + F - 1; p.conv[i].dil = c.dil;
-        p.conv[i].pad = (c.K - 1) * c.dil / 2;
+    p.in = in; p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias;
+    p.L = L; p.LS = voc_ls(L); p.nres = 1; p.npairs = npairs; p.slope = pre_slope; p.divide = 1.f; p.dbg = nullptr;
+    p.ngroups = ngroups;
+    for (int g = 0; g < ngroups; ++g) {
+        if (!outs[g] || outs[g] == in) return fail(DSD_ERR_INVALID, "dsv_resblock_chain_multi: outs[%d] is null or the input", g);
+        for (int k = 0; k < g; ++k)
+            if (outs[k] == outs[g]) return fail(DSD_ERR_INVALID, "dsv_resblock_chain_multi: outs[%d] == outs[%d] (every resblock writes its own buffer)", k, g);
+        p.grp[g].out = outs[g]; p.grp[g].final = 0;
     }
-    hipStream_t st = (hipStream_t)stream;
-    if (C == 16) return voc_chain16_launch<16, 1, 2>(p, convs, B, st);
-    return voc_chain16_launch<8, 2, 2>(p, convs, B, st);
+    const int rc = voc_chain_fill_convs(p, convs, ngroups * npairs * 2, dsv_chain_fold(C), "dsv_resblock_chain_multi");
+    if (rc != DSD_OK) return rc;
+    return voc_chain_groups(p, convs, B, C, (hipStream_t)stream, "dsv_resblock_chain_multi");
+}
+
+extern "C" int dsv_resblock_chain_sum(const float* in, const float* wpacked, const float* bias, float* out, const float* sum_in, const float* sum_in2,
+                                      int32_t own_last, int32_t B, int32_t C, int32_t L, int32_t npairs, const dsv_chain_conv* convs, float pre_slope,
+                                      float divide, void* stream) {
+    if (!in || !wpacked || !bias || !out || !convs || !sum_in || !sum_in2) return fail(DSD_ERR_INVALID, "dsv_resblock_chain_sum: null argument");
+    if (in == out || sum_in == out || sum_in2 == out) return fail(DSD_ERR_INVALID, "dsv_resblock_chain_sum: out must differ from in, sum_in and sum_in2");
+    if (!(pre_slope >= 0.f && pre_slope <= 1.f)) return fail(DSD_ERR_INVALID, "dsv_resblock_chain_sum: pre_slope must be in [0, 1] (leaky_relu as max(v, slope v))");
+    if (B < 1 || B > 65535 || L < 1 || npairs < 1 || npairs * 2 > kChainMaxConvs || divide == 0.f || !dsv_chain_fold(C))
+        return fail(DSD_ERR_INVALID, "dsv_resblock_chain_sum: bad shape (B=%d C=%d L=%d npairs=%d): 8, 16 or 32 channels", B, C, L, npairs);
+    VocChainParams p{};
+    p.in = in; p.out = out; p.sum_in = sum_in; p.sum_in2 = sum_in2; p.own_last = own_last ? 1 : 0;
+    p.wp = reinterpret_cast<const float4*>(wpacked); p.bias = bias;
+    p.L = L; p.LS = voc_ls(L); p.nres = 1; p.npairs = npairs; p.slope = pre_slope; p.divide = divide; p.dbg = nullptr;
+    p.ngroups = 1; p.grp[0].out = out; p.grp[0].final = 1;
+    const int rc = voc_chain_fill_convs(p, convs, npairs * 2, dsv_chain_fold(C), "dsv_resblock_chain_sum");
+    if (rc != DSD_OK) return rc;
+    return voc_chain_groups(p, convs, B, C, (hipStream_t)stream, "dsv_resblock_chain_sum");
 }
 
 extern "C" int dsv_noise_conv(const float* har, const float* w, const float* bias, float* out, int32_t B, int32_t C, int32_t K, int32_t stride,

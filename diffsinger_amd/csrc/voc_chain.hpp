@@ -36,6 +36,14 @@ struct VocChainConv {
     int dil, pad;           // pad = (K - 1) * dil / 2
 };
 
+constexpr int kChainMaxGroups = 3;
+struct VocChainGroup {
+    float* out;             // [B][C][LS]: this group's result
+    int first, tiles;       // first block of the group, tiles per utterance (ceil(LS / N))
+    int N, Hh;              // its chain's output samples per workgroup and halo
+    int final;              // 0: out = the raw y of the chain; 1: out = the summed, divided, masked result (sum_in / sum_in2 / own_last / divide)
+};
+
 struct VocChainParams {
     const float* in;        // [B][C][LS]
     float* out;             // [B][C][LS]
@@ -48,6 +56,12 @@ struct VocChainParams {
     float slope, divide;
     unsigned long long* dbg;                // optional s_memtime stamps of ONE workgroup (dsv_debug_chain_timeline): [conv][wave 4][4]
     VocChainConv conv[kChainMaxConvs];      // [res][pair][2]
+    // MG instantiations only (round 6: several INDEPENDENT single-resblock chains in one launch, and the launch that sums them)
+    const float* sum_in2;   // a second summand of the final result: ((sum_in + y) + sum_in2) / divide, or ((sum_in + sum_in2) + y) / divide (own_last)
+    int own_last;
+    int ngroups;            // 1 .. kChainMaxGroups; the grid is ONE-dimensional: group g owns the blocks [grp[g].first, grp[g].first + B * grp[g].tiles)
+                            // and the convolutions conv[2 npairs g ...]
+    VocChainGroup grp[3];
 };
 
 template <int F, int NB> constexpr int chain_wpos() { return 128 * NB * F; }                     // samples a dilation-1 convolution covers
@@ -195,7 +209,12 @@ struct ChainPipe {
 };
 
 // grid (ceil(LS / N), B); 4 waves, wave w owns the columns [32 NB w, 32 NB (w + 1)) of every convolution
-template <int C, int F, int NB, bool IP>
+// MG (round 6): the launch holds several INDEPENDENT single-resblock chains (p.grp[]: each with its own tile size, halo and output buffer) - the
+// workgroups of the first group are dispatched first.  A launch of W workgroups on S co-resident slots costs ceil(W / S) rounds
+// (profiles/r6_27_voc_tail_probe.jsonl: a staircase), so three dependent launches pay three partial rounds; with the longest chain first and a
+// short one behind it in the same grid the short workgroups fill the long ones' last round.  No workgroup waits for another: the groups write
+// separate buffers and the sum is formed by the NEXT launch (sum_in / sum_in2) behind an ordinary kernel boundary.
+template <int C, int F, int NB, bool IP, bool MG = false>
 __global__ __launch_bounds__(kThreads, (chain_wg_per_cu<C, F, NB, IP>())) void k_voc_chain(const VocChainParams p) {
     static_assert(C * F == 32 && (C % 8) == 0, "one 32-row MFMA block: 8 channels x 4, 16 x 2 or 32 x 1");
     constexpr int LD = chain_ld<F, NB>(), SLK = kChainSlack, NCOL4 = LD / 4;
@@ -204,8 +223,20 @@ __global__ __launch_bounds__(kThreads, (chain_wg_per_cu<C, F, NB, IP>())) void k
     float* bufT = IP ? smem : smem + C * LD;   // [C][LD] leaky_relu(xt): input of convs2 (IP: the same tile, rewritten in place)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t0 = blockIdx.x * p.N, b = blockIdx.y;
-    const int ws = t0 - p.Hh;               // sample of tile column SLK
+    int t0, b, ws, gidx = 0;                // ws: sample of tile column SLK
+    if constexpr (MG) {
+        const int bid = blockIdx.x;
+        if (p.ngroups > 1 && bid >= p.grp[1].first) gidx = 1;
+        if (p.ngroups > 2 && bid >= p.grp[2].first) gidx = 2;
+        const int local = bid - p.grp[gidx].first, tiles = p.grp[gidx].tiles;
+        b = __builtin_amdgcn_readfirstlane(local / tiles);         // (the division runs on the vector ALU: without this every buffer descriptor
+                                                                    // derived from b is a waterfall loop - tests/test_verified_isa.py)
+        t0 = (local - b * tiles) * p.grp[gidx].N;
+        ws = t0 - p.grp[gidx].Hh;
+    } else {
+        t0 = blockIdx.x * p.N; b = blockIdx.y;
+        ws = t0 - p.Hh;
+    }
     const int cw = w * (32 * NB);
     const int L = p.L, LS = p.LS;
     const float slope = p.slope;
@@ -223,9 +254,9 @@ __global__ __launch_bounds__(kThreads, (chain_wg_per_cu<C, F, NB, IP>())) void k
     // Register quad q of a column = rows 8 q + 4 h + (0..3) of the 32-row block = 4 / F channels x F consecutive samples from t = ws + c F:
     // group g = 4 q / F + i of the lane holds channel (8 / F) q + i + (4 / F) h - the half-wave term goes into the lane's byte offset, the rest
     // is a wave-uniform row offset; t0, N, Hh are multiples of 4 and LS of 32, so the F samples of a group are inside a range together.
-    const int tend = min(t0 + p.N, LS);
+    const int tend = min(t0 + p.N, LS);       // (MG: flush_mg has its own)
     const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb), 0, 0x7ffffff0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * C * LS, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((MG ? const_cast<float*>(p.in) : p.out) + (size_t)b * C * LS, 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_sin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.sum_in ? p.sum_in + (size_t)b * C * LS : p.in), 0, 0x7ffffff0, 0x00020000);
     const bool have_sin = p.sum_in != nullptr;
     constexpr int NG = 16 / F;               // groups of F registers per column
@@ -266,12 +297,61 @@ __global__ __launch_bounds__(kThreads, (chain_wg_per_cu<C, F, NB, IP>())) void k
         }
     };
 
-    const int total = p.nres * p.npairs * 2;
+    // MG: one resblock per workgroup.  The group's record (tile size, output buffer, role) is read from the kernel arguments again HERE - scalar
+    // loads behind an opaque copy of the group index - instead of living in registers across the contractions (the 32-channel kernel has
+    // none to spare).  A final group forms the stage's result from two summands in the order of `xs += resblock(x)`.
+    auto flush_mg = [&]() {
+        int oz = 0, gz = gidx;
+        asm volatile("" : "+v"(oz));
+        asm volatile("" : "+s"(gz));
+        float* const gout = p.grp[gz].out;
+        const int tend_g = min(t0 + p.grp[gz].N, LS);
+        const bool fin = p.grp[gz].final != 0;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(gout + (size_t)b * C * LS, 0, 0x7ffffff0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((fin ? p.sum_in : p.in) + (size_t)b * C * LS), 0, 0x7ffffff0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((fin ? p.sum_in2 : p.in) + (size_t)b * C * LS), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int t = ws + (cw + 32 * nb + j + oz) * F;
+            const bool ok = t >= t0 && t < tend_g;
+            const int voff = ((4 / F) * h * LS + (ok ? t : t0)) * 4;
+            float av[NG][F], bv2[NG][F];
+            if (fin) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {                   // all the reads first
+                    const int soff = ((8 / F) * (g * F / 4) + (g * F % 4) / F) * LS * 4;
+                    chain_ld<F>(ra, voff, soff, av[g]);
+                    chain_ld<F>(rb, voff, soff, bv2[g]);
+                }
+            }
+            if (!ok) continue;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int soff = ((8 / F) * (g * F / 4) + (g * F % 4) / F) * LS * 4;
+                float v[F];
+#pragma unroll
+                for (int e = 0; e < F; ++e) {
+                    v[e] = y[nb][g * F + e];
+                    if (fin) {
+                        // (s + y) + s2, or with this resblock as the last of the three (s + s2) + y
+                        if (p.own_last) { const float t2 = av[g][e] + bv2[g][e]; v[e] = t2 + v[e]; }
+                        else { v[e] = av[g][e] + v[e]; v[e] = bv2[g][e] + v[e]; }
+                        if (p.divide != 1.f) v[e] = v[e] / p.divide;
+                        if (t + e >= L) v[e] = 0.f;
+                    }
+                }
+                chain_st<F>(ro, voff, soff, v);
+            }
+        }
+    };
+
+    const int total = (MG ? 1 : p.nres) * p.npairs * 2;
+    const int n0 = MG ? gidx * 2 * p.npairs : 0;          // the group's first convolution in conv[]
     // every sample this workgroup can write to a tile (columns SLK .. SLK + WPOS + F * dil) lies inside [0, L): no range masks in the epilogues
     const bool interior = (ws >= 0) && (ws + chain_wpos<F, NB>() + SLK <= L);
-    const bool stamp = p.dbg != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0;
+    const bool stamp = !MG && p.dbg != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0;
     auto mark = [&](int n, int k) { if (stamp) p.dbg[(n * 4 + w) * 4 + k] = __builtin_amdgcn_s_memtime(); };
-    ChainPipe<NB, LD, F == 1> pipe(p.wp + p.conv[0].woff, lane);
+    ChainPipe<NB, LD, F == 1> pipe(p.wp + p.conv[n0].woff, lane);
     pipe.start_a();
     int q = 0;                              // pair of the convolution n inside its resblock
 #pragma unroll 1
@@ -327,7 +407,7 @@ __global__ __launch_bounds__(kThreads, (chain_wg_per_cu<C, F, NB, IP>())) void k
             __syncthreads();
         }
         mark(n, 0);
-        const VocChainConv cv = p.conv[n];
+        const VocChainConv cv = p.conv[n0 + n];
         const float* src = ci ? bufT : bufA;
         float* dst = ci ? bufA : bufT;
         const int dil = cv.dil;
@@ -351,7 +431,7 @@ __global__ __launch_bounds__(kThreads, (chain_wg_per_cu<C, F, NB, IP>())) void k
         pipe.run_blocks(acc, nch);
         mark(n, 1);
         if (n + 1 < total) {                // the next convolution's weights: requested now, used behind the epilogue and the barrier
-            pipe.set_a(p.wp + p.conv[n + 1].woff);
+            pipe.set_a(p.wp + p.conv[n0 + n + 1].woff);
             pipe.start_a();
         }
         const bool last_of_res = (ci == 1 && q == p.npairs - 1);        // the last convolution of a resblock feeds no further one
@@ -430,7 +510,8 @@ __global__ __launch_bounds__(kThreads, (chain_wg_per_cu<C, F, NB, IP>())) void k
         mark(n, 3);
         if (ci == 1) {
             if (last_of_res) {
-                flush(n == 2 * p.npairs - 1, n == total - 1);
+                if constexpr (MG) { flush_mg(); return; }     // (one resblock per workgroup: no path from these stores back into the K loop)
+                else flush(n == 2 * p.npairs - 1, n == total - 1);
                 q = 0;
             } else {
                 ++q;

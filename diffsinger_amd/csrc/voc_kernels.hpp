@@ -32,7 +32,8 @@ constexpr int kVocHalo = 28;               // taps reach +-25 samples (kernel 11
 constexpr int kVocHaloWide = 48;           // second instantiation of k_voc_conv: taps up to +-48 samples (the official v3 generator: kernel 7 at
                                            // dilation 12 = 36), hifigan.py:104-179 accepts any config
 constexpr int kVocLdsBudget = 72 * 1024;   // two workgroups per CU
-constexpr int kVocStageBatch = 8;          // staging loads a thread keeps in flight
+constexpr int kVocStageBatch = 12;         // staging loads a thread keeps in flight (round 6: 8 -> 12 - the 64-channel slab of k_voc_conv<2, 2> is 11.5
+                                           // float4 per thread: ONE round trip to memory instead of two)
 
 template <int NB, int WT> constexpr int voc_span() { return 32 * NB * WT; }                    // samples per workgroup
 template <int NB, int WT, int HALO = kVocHalo> constexpr int voc_ld() { return voc_span<NB, WT>() + 2 * HALO; }  // LDS row stride
@@ -103,6 +104,27 @@ __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
         for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
     const float* inb = p.in + (size_t)b * p.Ci * p.LSi;
     const float slope = p.pre_slope;
+    // A plain convolution's residual / running-sum operands (the second convolution of every ResBlock1 pair) are requested HERE, in front of
+    // the weight prefetch and the staging loads (round 6): their round trip to memory ran behind the contraction, with nothing to hide under.
+    // Only for the narrow tiles (NB <= 2: 16 NB registers per operand).
+    constexpr bool PRE = (NB <= 2);
+    float rpre[PRE ? NB : 1][16], spre[PRE ? NB : 1][16];
+    const bool pre = PRE && p.U == 1 && rb < nrb && (p.res || p.sum_in);
+    if constexpr (PRE) {
+        if (pre) {
+            const int qp = t0 + wt * (32 * NB) + j;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb * 32 + frag_row(r, h), n = qp + 32 * nb;
+                    const bool ok = row < p.rows && n < p.LSo;
+                    const size_t o = ((size_t)b * p.rows + (ok ? row : 0)) * p.LSo + (ok ? n : 0);
+                    rpre[nb][r] = p.res ? p.res[o] : 0.f;
+                    spre[nb][r] = p.sum_in ? p.sum_in[o] : 0.f;
+                }
+        }
+    }
     for (int c0 = 0; c0 < p.Ci; c0 += SLAB) {
         const int nc = min(SLAB, p.Ci - c0);
         const int nc8 = (nc + 7) / 8 * 8;                            // rows [nc, nc8) are staged as zeros (their weights are zero too)
@@ -110,6 +132,14 @@ __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
         // (eight loads per thread in flight before the first LDS write: a load -> write -> load chain pays the memory latency once per float4 -
         // 12 round trips for a 64-channel slab, ~16 us of every launch of the 64-channel stage in rounds 2-5, profiles/r57_vocoder_kernel_stats.txt)
         const int nstage = nc8 * NCOL4;
+        // the weight stream depends on nothing the kernel computes: its first chunks are requested in FRONT of the staging loads (round 6; vector
+        // memory returns in order - the staging wait covers them - and their L2 / Infinity-Cache latency, ~1.5 us of every launch, leaves the
+        // critical path)
+        const int nch = (nc8 / 8) * p.KT;
+        const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
+        VocTapB<LD> bof(smem + 4 * h * LD + HALO + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch);
+        GemmPipe<1, NB, LD, 64, 6, VocTapB<LD>, 1, false, true> pipe(ap, lane, nch, bof);
+        pipe.start_a();
         for (int i0 = 0; i0 < nstage; i0 += kVocStageBatch * kThreads) {
             float4 sv[kVocStageBatch];
 #pragma unroll
@@ -133,10 +163,8 @@ __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
             DSD_SB();
         }
         __syncthreads();
-        const int nch = (nc8 / 8) * p.KT;
-        const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
-        VocTapB<LD> bof(smem + 4 * h * LD + HALO + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch);
-        gemm_k_blocks<1, NB, LD, 64, true>(acc, ap, lane, nch, bof);
+        pipe.start_b();
+        pipe.run_blocks(acc, nch);
         __syncthreads();
     }
     if (rb >= nrb) return;
@@ -170,7 +198,33 @@ __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
         }
         return;
     }
-    // general phase count (1: plain convolution, lanes j write consecutive samples; 2: two channels x two phases per register quad)
+    if (U == 2) {
+        // registers (r, r + 1), r even, of this lane are the two phases of ONE output channel (row = 2 co + phase): 8-byte accesses, the lanes
+        // of a half wave write 256 contiguous bytes (round 6; the scalar form below wrote every second float per instruction and spent ~2 900
+        // vector instructions per wave on its index arithmetic - the stride-2 transposed convolutions ran at a third of their memory roof)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = (q0 + 32 * nb) * 2;
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                const int row = rb * 32 + frag_row(2 * rp, h);
+                const int co = row >> 1;
+                if (row >= p.rows || n >= p.LSo) continue;
+                const size_t o = ((size_t)b * Co + co) * p.LSo + n;
+                const float bv = p.bias ? p.bias[co] : 0.f;
+                float2 v = make_float2(acc[0][nb][2 * rp] + bv, acc[0][nb][2 * rp + 1] + bv);
+                if (p.res) { const float2 r2 = *reinterpret_cast<const float2*>(p.res + o); v.x += r2.x; v.y += r2.y; }
+                if (p.sum_in) { const float2 s2 = *reinterpret_cast<const float2*>(p.sum_in + o); v.x = s2.x + v.x; v.y = s2.y + v.y; }
+                if (p.divide != 1.f) { v.x = v.x / p.divide; v.y = v.y / p.divide; }
+                if (p.act == VOC_ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); }
+                if (n + 0 >= p.Lo) v.x = 0.f;
+                if (n + 1 >= p.Lo) v.y = 0.f;
+                *reinterpret_cast<float2*>(p.out + o) = v;
+            }
+        }
+        return;
+    }
+    // general phase count (1: plain convolution, lanes j write consecutive samples)
     float bv[16];
     int cov[16], phv[16];
 #pragma unroll
@@ -185,13 +239,23 @@ __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
     for (int nb = 0; nb < NB; ++nb) {
         const int q = q0 + 32 * nb;
         float rv[16], sv[16];
+        bool have = false;
+        if constexpr (PRE) {
+            if (pre) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {                               // all the reads first
-            const int n = q * U + phv[r];
-            const bool ok = (rb * 32 + frag_row(r, h) < p.rows) && n < p.LSo;
-            const size_t o = ((size_t)b * Co + cov[r]) * p.LSo + (ok ? n : 0);
-            rv[r] = (p.res && ok) ? p.res[o] : 0.f;
-            sv[r] = (p.sum_in && ok) ? p.sum_in[o] : 0.f;
+                for (int r = 0; r < 16; ++r) { rv[r] = rpre[nb][r]; sv[r] = spre[nb][r]; }
+                have = true;
+            }
+        }
+        if (!have) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                           // all the reads first
+                const int n = q * U + phv[r];
+                const bool ok = (rb * 32 + frag_row(r, h) < p.rows) && n < p.LSo;
+                const size_t o = ((size_t)b * Co + cov[r]) * p.LSo + (ok ? n : 0);
+                rv[r] = (p.res && ok) ? p.res[o] : 0.f;
+                sv[r] = (p.sum_in && ok) ? p.sum_in[o] : 0.f;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -72,22 +72,6 @@ def fold_weight(w: torch.Tensor, F: int) -> torch.Tensor:
     return wf.reshape(co * F, ci, k + F - 1).contiguous()
 
 
-def pack_chain16(w: torch.Tensor, F: int) -> torch.Tensor:
-    """Conv1d weight [C][C][K] (C * F == 16) -> the A operand of csrc/voc_chain16.hpp (include/dsv.h dsv_resblock_chain16): the F-fold W'[16][C][KT]
-    (KT = K + F - 1) as chunks (8-channel group g, tap s) of two fragment rows [half][lane 64][4]: lane l carries row l % 16 (the four 16 x 16
-    blocks of v_mfma_f32_16x16x1_4B_f32 multiply the same filter), value j = 4 half + i is channel 8 g + (j >> 1) + 4 (j & 1) - the order in which
-    the one-convolution kernels' four 32x32x2 MFMAs of a chunk visit their k = 0 / 1 halves.  Returns a flat float tensor of (C / 8) KT 512."""
-    wf = fold_weight(w, F) if F > 1 else w.contiguous()
-    rows, ci, kt = wf.shape
-    assert rows == 16 and ci % 8 == 0
-    order = torch.tensor([(j >> 1) + 4 * (j & 1) for j in range(8)], device=w.device)
-    g = wf.reshape(16, ci // 8, 8, kt)[:, :, order, :]                      # [row][g][j][s]
-    g = g.permute(1, 3, 2, 0).reshape(ci // 8, kt, 2, 4, 16)                # [g][s][half][i][row]
-    g = g.permute(0, 1, 2, 4, 3)                                           # [g][s][half][row][i]
-    g = g.unsqueeze(3).expand(ci // 8, kt, 2, 4, 16, 4)                     # [g][s][half][blk][row][i]: lane = 16 blk + row
-    return g.reshape(-1).contiguous()
-
-
 import ctypes as _C
 
 
@@ -104,22 +88,55 @@ class DsvChainConv(_C.Structure):
 # 'stage' / 'resblock' / 'pair' force that grouping; 'off' = one launch per convolution everywhere (the A/B switch of the measurement and of
 # the bit-identity tests).
 _CHAIN_MODE = None
-# The 16- and 8-channel stages on the 16-row matrix shape (csrc/voc_chain16.hpp, round 6): one launch per resblock like the default above,
-# 12.5 % / 20 % less matrix work, the same bits.  Applies in the default chain mode only; set_chain16(False) is the A/B switch.
-_CHAIN16 = True
-
-
-def set_chain16(on: bool):
-    global _CHAIN16
-    _CHAIN16 = bool(on)
-
+# Round 6: None additionally MERGES two of the stage's resblocks into one launch (dsv_resblock_chain_multi) and lets the third form the sum
+# (dsv_resblock_chain_sum) wherever `_merge_plan` models fewer rounds than for one launch per resblock; 'resblock' is the plain form.
+# 'merged' forces the merge, 'merged0' / 'merged1' / 'merged2' with that resblock as the summing launch (tests: every split gives the same bits).
 
 
 def set_chain_mode(mode):
     global _CHAIN_MODE
-    if mode not in (None, 'stage', 'resblock', 'pair', 'off'):
+    if mode not in (None, 'stage', 'resblock', 'pair', 'off', 'merged', 'merged0', 'merged1', 'merged2'):
         raise ValueError(mode)
     _CHAIN_MODE = mode
+
+
+def _merge_plan(W, d, slots, min_gain=0.03):
+    """Which resblock of a stage to leave out of the merged launch.  A chain launch of W workgroups on `slots` co-resident places takes
+    ceil(W / slots) rounds of its workgroup time d (profiles/r6_27_voc_tail_probe.jsonl); a merged launch - longest chain first - is list
+    scheduling of its workgroups on the slots.  W[r], d[r]: workgroups and relative workgroup time of resblock r.  Returns (solo, order of
+    the merged groups) for the split with the smallest modelled time, or None when no split beats three launches by `min_gain`."""
+    import math
+    n = len(W)
+    if n != 3:
+        return None
+    rounds = lambda w: math.ceil(w / slots)
+    separate = sum(rounds(W[r]) * d[r] for r in range(n))
+
+    def merged_time(groups):                                      # list scheduling: every workgroup takes the slot that is free first
+        import heapq
+        free = [(0.0, slots)]                                     # (time, slots that become free then)
+        end = 0.0
+        for r in groups:
+            left = W[r]
+            while left > 0:
+                t, c = heapq.heappop(free)
+                k = min(c, left)
+                left -= k
+                heapq.heappush(free, (t + d[r], k))
+                end = max(end, t + d[r])
+                if k < c:
+                    heapq.heappush(free, (t, c - k))
+        return end
+
+    best = None
+    for solo in range(n):
+        groups = sorted((r for r in range(n) if r != solo), key=lambda r: -d[r])
+        t = merged_time(groups) + rounds(W[solo]) * d[solo]
+        if best is None or t < best[0]:
+            best = (t, solo, groups)
+    if best[0] > (1.0 - min_gain) * separate:
+        return None
+    return best[1], best[2]
 
 
 class _HipOps:
@@ -200,19 +217,25 @@ class _HipOps:
                                                    descs, float(pre_slope), float(divide), self._s(x.device)), 'dsv_resblock_chain')
         return out
 
-    def chain16_fold(self, C: int) -> int:
-        return int(self.lib.dsv_chain16_fold(C))
+    def resblock_chain_multi(self, x, L, wp, bias, C, npairs, descs, ngroups, pre_slope=LRELU_SLOPE):
+        """`ngroups` independent resblocks (descs: [ngroups][npairs][2]) in one launch; returns their raw outputs, one buffer each."""
+        B = x.shape[0]
+        assert x.shape[1] == C and x.shape[2] == padded_samples(L) and x.is_contiguous()
+        outs = [torch.empty_like(x) for _ in range(ngroups)]
+        ptrs = (_C.c_void_p * ngroups)(*[o.data_ptr() for o in outs])
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.dsv_resblock_chain_multi(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), ptrs, B, C, L, ngroups, npairs, descs,
+                                                         float(pre_slope), self._s(x.device)), 'dsv_resblock_chain_multi')
+        return outs
 
-    def chain16_supported(self, C, nres, npairs, descs) -> int:
-        return int(self.lib.dsv_chain16_supported(C, nres, npairs, descs))
-
-    def resblock_chain16(self, x, L, wp16, bias, C, nres, npairs, descs, sum_in=None, divide=1.0, pre_slope=LRELU_SLOPE):
+    def resblock_chain_sum(self, x, L, wp, bias, C, npairs, descs, sum_in, sum_in2, own_last, divide, pre_slope=LRELU_SLOPE):
         B = x.shape[0]
         assert x.shape[1] == C and x.shape[2] == padded_samples(L) and x.is_contiguous()
         out = torch.empty_like(x)
         with torch.cuda.device(x.device):
-            _lib.check(self.lib.dsv_resblock_chain16(x.data_ptr(), wp16.data_ptr(), bias.data_ptr(), out.data_ptr(), self._p(sum_in), B, C, L, nres, npairs,
-                                                     descs, float(pre_slope), float(divide), self._s(x.device)), 'dsv_resblock_chain16')
+            _lib.check(self.lib.dsv_resblock_chain_sum(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr(), sum_in.data_ptr(), sum_in2.data_ptr(),
+                                                       int(bool(own_last)), B, C, L, npairs, descs, float(pre_slope), float(divide), self._s(x.device)),
+                       'dsv_resblock_chain_sum')
         return out
 
     def noise_conv(self, har, L_har, w, bias, stride, pad, L_out):
@@ -418,49 +441,33 @@ class HifiGanGenerator(nn.Module):
         self._packed[f'chain{i}'] = (tag, entry)
         return entry
 
-    def _chain_prep16(self, i: int):
-        """Stage i's ResBlock1 convolutions for the 16-row chain kernel (pack_chain16): one weight buffer + 1 536 floats of prefetch slack, one
-        bias buffer, a descriptor per convolution.  None: not a ResBlock1 stage of 8 / 16 channels.  Cached per parameter version."""
-        rbs = [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)]
-        if any(rb.kind != '1' for rb in rbs) or len({len(rb.dils) for rb in rbs}) != 1:
-            return None
-        C = rbs[0].convs1[0].wshape()[0]
-        F = self._ops.chain16_fold(C)
-        if not F:
-            return None
-        convs = [(c, d if which == 0 else 1) for rb in rbs for q, d in enumerate(rb.dils) for which, c in ((0, rb.convs1[q]), (1, rb.convs2[q]))]
-        tag = tuple(c.tag() for c, _ in convs)
-        hit = self._packed.get(f'chain16_{i}')
-        if hit is not None and hit[0] == tag:
-            return hit[1]
-        pieces = [pack_chain16(c.plain_weight().to(torch.float32), F) for c, _ in convs]
-        dev = convs[0][0].bias.device
-        wp = torch.cat(pieces + [torch.zeros(1536, device=dev, dtype=torch.float32)])
-        bias = torch.stack([c.bias.detach().to(torch.float32) for c, _ in convs])
-        descs = (DsvChainConv * len(convs))()
-        off = 0
-        for n, ((c, d), pc) in enumerate(zip(convs, pieces)):
-            descs[n] = DsvChainConv(off, n * C, int(c.wshape()[2]), int(d), 0)
-            off += pc.numel()
-        entry = dict(wp=wp, bias=bias, descs=descs, C=C, npairs=len(rbs[0].dils), nres=len(rbs))
-        self._packed[f'chain16_{i}'] = (tag, entry)
-        return entry
+    def _merge_plan_for(self, i: int, e, B: int, L: int, force: bool = False):
+        """_merge_plan for stage i at batch B, length L (cached per shape): workgroups per resblock from dsv_chain_supported's tile size, relative
+        workgroup time = its chunks (C / 8 x folded taps per convolution) + 1.5 chunk times per convolution of epilogue / barrier / restart
+        (the fit of profiles/r6_27_voc_tail_probe.jsonl), slots = 256 CUs x the co-resident workgroups of the instantiation."""
+        key = (i, B, L, force)
+        hit = self._packed.get('merge_plans', {})
+        if key in hit:
+            return hit[key]
+        C, nres, npairs, ops = e['C'], e['nres'], e['npairs'], self._ops
+        F = ops.chain_fold(C)
+        plan = None
+        Ns = [ops.chain_supported(C, 1, npairs, (DsvChainConv * (npairs * 2))(*[e['descs'][(r * npairs + q) * 2 + k] for q in range(npairs) for k in range(2)]))
+              for r in range(nres)]
+        if all(Ns):
+            LS = padded_samples(L)
+            W = [B * ((LS + n - 1) // n) for n in Ns]
+            d = [sum((C // 8) * (e['descs'][(r * npairs + q) * 2 + k].K + F - 1) + 1.5 * (C // 8) for q in range(npairs) for k in range(2)) for r in range(nres)]
+            slots = 256 * (2 if C == 32 else 3)
+            plan = _merge_plan(W, d, slots, min_gain=-1e9 if force else 0.03)
+        hit[key] = plan
+        self._packed['merge_plans'] = hit
+        return plan
 
     def _stage_resblocks(self, i: int, x, L):
         """x = (sum_j resblock_{i, j}(x)) / num_kernels (hifigan.py:161-166): fused chains where the library offers them, else one launch per
         convolution.  Every grouping gives the same bits."""
         mode = _CHAIN_MODE
-        if mode is None and _CHAIN16:
-            e16 = self._chain_prep16(i)
-            if e16 is not None:
-                C, nres, npairs, ops = e16['C'], e16['nres'], e16['npairs'], self._ops
-                sub16 = lambda r: (DsvChainConv * (npairs * 2))(*[e16['descs'][(r * npairs + q) * 2 + k] for q in range(npairs) for k in range(2)])
-                if all(ops.chain16_supported(C, 1, npairs, sub16(r)) for r in range(nres)):
-                    acc = None
-                    for r in range(nres):
-                        acc = ops.resblock_chain16(x, L, e16['wp'], e16['bias'], C, 1, npairs, sub16(r), sum_in=acc,
-                                                   divide=float(self.num_kernels) if r == nres - 1 else 1.0)
-                    return acc
         e = self._chain_prep(i) if mode != 'off' else None
         if e is not None:
             C, nres, npairs = e['C'], e['nres'], e['npairs']
@@ -469,9 +476,27 @@ class HifiGanGenerator(nn.Module):
             sub = lambda r0, q0, nr, nq: (DsvChainConv * (nr * nq * 2))(*[e['descs'][(r * npairs + q) * 2 + k] for r in range(r0, r0 + nr)
                                                                        for q in range(q0, q0 + nq) for k in range(2)])
             ops, nk = self._ops, float(self.num_kernels)
+            per_resblock = all(ops.chain_supported(C, 1, npairs, sub(r, 0, 1, npairs)) for r in range(nres))
+            plan = None
+            if nres == 3 and per_resblock:
+                if mode in ('merged0', 'merged1', 'merged2'):                     # tests: that resblock as the summing launch
+                    solo = int(mode[6])
+                    plan = (solo, sorted((r for r in range(3) if r != solo), reverse=True))
+                elif mode == 'merged' or _CHAIN_MODE is None:
+                    plan = self._merge_plan_for(i, e, x.shape[0], L, force=mode == 'merged')
+            if mode.startswith('merged'):
+                mode = 'resblock'
+            if plan is not None and mode == 'resblock':
+                # two resblocks in ONE launch, longest first, each to its own buffer; the third forms xs = y_0 + y_1 + y_2 in that order with
+                # its own y first / second - (s + y) + s2 - or last - (s + s2) + y
+                solo, groups = plan
+                descs2 = (DsvChainConv * (2 * npairs * 2))(*[e['descs'][(r * npairs + q) * 2 + k] for r in groups for q in range(npairs) for k in range(2)])
+                ys = dict(zip(groups, ops.resblock_chain_multi(x, L, e['wp'], e['bias'], C, npairs, descs2, 2)))
+                a, b = (ys[r] for r in sorted(groups))
+                return ops.resblock_chain_sum(x, L, e['wp'], e['bias'], C, npairs, sub(solo, 0, 1, npairs), a, b, solo == 2, nk)
             if mode == 'stage' and ops.chain_supported(C, nres, npairs, e['descs']):
                 return ops.resblock_chain(x, L, e['wp'], e['bias'], C, nres, npairs, e['descs'], divide=nk)
-            if mode in ('stage', 'resblock') and all(ops.chain_supported(C, 1, npairs, sub(r, 0, 1, npairs)) for r in range(nres)):
+            if mode in ('stage', 'resblock') and per_resblock:
                 acc = None
                 for r in range(nres):
                     acc = ops.resblock_chain(x, L, e['wp'], e['bias'], C, 1, npairs, sub(r, 0, 1, npairs), sum_in=acc,

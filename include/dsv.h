@@ -89,6 +89,21 @@ int32_t dsv_chain_fold(int32_t C);
 int32_t dsv_chain_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs);
 int dsv_resblock_chain(const float* in, const float* wpacked, const float* bias, float* out, const float* sum_in, int32_t B, int32_t C,
                        int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream);
+/* The parallel resblocks of a stage as TWO launches instead of one per resblock (round 6).  A chain launch of W workgroups on S co-resident
+ * slots (256 CUs x 2 or 3) takes ceil(W / S) rounds, not W / S (profiles/r6_27_voc_tail_probe.jsonl): three dependent launches pay three
+ * partial last rounds.  dsv_resblock_chain_multi runs `ngroups` (1 .. 3) INDEPENDENT single-resblock chains in one grid - group g =
+ * convs[g][npairs][2] over the whole input, its raw y_g (no sum, no division, NOT zeroed in [L, LS)) to outs[g] (a HOST array of device
+ * pointers, all different, none the input); the workgroups of group 0 are dispatched first: pass the longest chain first, so that the
+ * short workgroups of a later group fill its last round.  dsv_resblock_chain_sum then runs ONE more resblock and forms the stage's result
+ * in the order of `xs += resblock(x)` (hifigan.py:161-166): out = ((sum_in + y) + sum_in2) / divide - this resblock first or second of
+ * three - or, own_last != 0, ((sum_in + sum_in2) + y) / divide; zero in [L, LS).  No workgroup waits for another; an ordinary kernel
+ * boundary orders the two launches.  Same sums in the same order as dsv_resblock_chain: bit-identical.  Which resblock to leave for the
+ * second launch is the caller's choice (diffsinger_amd/vocoder.py _merge_plan: the split with the fewest modelled rounds). */
+int dsv_resblock_chain_multi(const float* in, const float* wpacked, const float* bias, float* const* outs, int32_t B, int32_t C, int32_t L,
+                             int32_t ngroups, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, void* stream);
+int dsv_resblock_chain_sum(const float* in, const float* wpacked, const float* bias, float* out, const float* sum_in, const float* sum_in2,
+                           int32_t own_last, int32_t B, int32_t C, int32_t L, int32_t npairs, const dsv_chain_conv* convs, float pre_slope,
+                           float divide, void* stream);
 /* A/B switch of the measurement: which instantiation of the chain kernel C = 8 / 16 / 32 channels run on - `nb` column blocks of 32 per wave
  * (a workgroup's window is 128 * nb * F samples; 2 or 4) and ONE LDS tile rewritten in place (in_place = 1: half the LDS, twice the workgroups
  * per CU or twice the window) or the two tiles of rounds 3-5 (in_place = 0).  Every variant evaluates the same sums in the same order: the
@@ -98,19 +113,6 @@ int dsv_set_chain_variant(int32_t C, int32_t nb, int32_t in_place);
  * shader clock of ONE workgroup (the middle tile of utterance 0) per convolution n and wave w at [n][w][0..3] = {convolution start,
  * contraction done, epilogue done, barrier passed}. */
 int dsv_debug_chain_timeline(uint64_t* device_stamps);
-
-/* The same chains for the NARROW stages (16 and 8 channels) on a 16-row matrix shape (csrc/voc_chain16.hpp, round 6): no fold at 16 channels,
- * a 2-fold at 8 (dsv_chain16_fold) instead of the 2- / 4-fold of dsv_resblock_chain - 12.5 % / 20 % less matrix work, the same sums in the same
- * order (bit-identical to dsv_conv1d / dsv_conv1d_folded and to dsv_resblock_chain).  `wpacked16`: per convolution the filter folded F =
- * dsv_chain16_fold(C) times (W'[co F + e][ci][s] = w[co][ci][s - e], K + F - 1 taps, 16 rows) as chunks [ci8 * (K + F - 1) + s] of two 1 KiB
- * fragment rows [half 2][lane 64][4 floats]: lane l carries row l % 16, value i of half h = W'[row][8 ci8 + ch][s] with ch = (j >> 1) + 4 (j & 1),
- * j = 4 h + i (diffsinger_amd/vocoder.py pack_chain16 builds it); w_offset in floats, a multiple of 512; the buffer must extend 1 536 floats
- * beyond the last convolution (prefetch overrun).  Everything else - in / out / sum_in / bias / convs / pre_slope / divide - as dsv_resblock_chain;
- * dsv_chain16_supported returns N (0: use dsv_resblock_chain or the single convolutions). */
-int32_t dsv_chain16_fold(int32_t C);
-int32_t dsv_chain16_supported(int32_t C, int32_t nres, int32_t npairs, const dsv_chain_conv* convs);
-int dsv_resblock_chain16(const float* in, const float* wpacked16, const float* bias, float* out, const float* sum_in, int32_t B, int32_t C,
-                         int32_t L, int32_t nres, int32_t npairs, const dsv_chain_conv* convs, float pre_slope, float divide, void* stream);
 
 /* noise_convs[i] (hifigan.py:124-130, :158-160): the strided Conv1d(1 -> C, kernel K, stride, padding) over the harmonic
  * source.  har [B][LS(L_har)], w [C][K] (the torch weight [C][1][K]), bias [C] or NULL, out [B][C][LS(L_out)];

@@ -262,17 +262,16 @@ DEFAULT_CHAIN_VARIANT = {8: (2, 1), 16: (2, 1), 32: (4, 1)}       # csrc/voc_abi
 def chain_default():
     from diffsinger_amd import vocoder
     vocoder.set_chain_mode(None)
-    vocoder.set_chain16(True)
     yield vocoder
     vocoder.set_chain_mode(None)
-    vocoder.set_chain16(True)
 
 
 @pytest.mark.parametrize('stage,L', [(3, 5000), (3, 896), (3, 33), (2, 3001), (2, 640), (1, 1500), (1, 449), (0, 300)])
-@pytest.mark.parametrize('mode', ['stage', 'resblock', 'pair'])
+@pytest.mark.parametrize('mode', ['stage', 'resblock', 'pair', 'merged0', 'merged1', 'merged2'])
 def test_resblock_chain_is_bit_identical_to_the_single_convolutions(stage, L, mode, chain_default):
     """One stage's `(sum_j resblock_j(x)) / 3` (hifigan.py:161-166, :54-61) with the ResBlock1 chains fused in LDS - the whole stage, one
-    resblock, or one conv pair per launch - against one launch per convolution: same chunk order, same epilogue arithmetic -> the same BITS.
+    resblock, or one conv pair per launch, or (round 6) two resblocks merged into one launch and the third (0, 1 or 2) forming the sum -
+    against one launch per convolution: same chunk order, same epilogue arithmetic -> the same BITS.
     Ragged lengths: several tiles with a partial last one, exactly one tile, a tile shorter than the halo; stage 0 (64 channels) has no chain
     kernel and must fall through unchanged."""
     case = dict(nsf=False, B=2, T=8, seed=41 + stage)
@@ -290,48 +289,30 @@ def test_resblock_chain_is_bit_identical_to_the_single_convolutions(stage, L, mo
     assert torch.equal(got, want), float((got - want).abs().max())
 
 
-@pytest.mark.parametrize('stage,L', [(3, 5000), (3, 1024), (3, 896), (3, 33), (2, 3001), (2, 640), (2, 512), (2, 7)])
-def test_chain16_is_bit_identical_to_the_single_convolutions_and_to_the_32_row_chains(stage, L, chain_default):
-    """csrc/voc_chain16.hpp (round 6): the 16- / 8-channel stages on v_mfma_f32_16x16x1_4B_f32 - no fold / a 2-fold instead of the 2- / 4-fold
-    of the 32-row chains - visit every output sample's contributions in the one-convolution kernels' order and that MFMA shape accumulates
-    like theirs (profiles/r6_25_mfma_shape_probe.jsonl): the same BITS as one launch per convolution and as the 32-row chain kernels, with a
-    running sum coming in (resblocks 1, 2), on several tiles with a partial last one, exactly one tile, and a tile shorter than the halo."""
-    case = dict(nsf=False, B=2, T=8, seed=41 + stage)
-    h, p, m = _generator(case)
-    m(torch.zeros(1, 80, 4, device=DEV))
-    C = 128 >> (stage + 1)
-    g = torch.Generator().manual_seed(100 * stage + L)
-    x = _cm(torch.randn(3, C, L, generator=g), L).to(DEV)
-    chain_default.set_chain_mode('off')
-    want = m._stage_resblocks(stage, x, L)
-    chain_default.set_chain_mode(None)
-    chain_default.set_chain16(False)
-    chains32 = m._stage_resblocks(stage, x, L)
-    chain_default.set_chain16(True)
-    assert m._chain_prep16(stage) is not None
-    got = m._stage_resblocks(stage, x, L)
-    again = m._stage_resblocks(stage, x, L)
-    torch.cuda.synchronize()
-    assert torch.isfinite(got).all() and float(got[:, :, L:].abs().max() if got.shape[2] > L else 0) == 0
-    assert torch.equal(got, want), float((got - want).abs().max())
-    assert torch.equal(got, chains32) and torch.equal(again, got)
-
-
-def test_chain16_entry_point_contract():
-    from diffsinger_amd.vocoder import DsvChainConv
+def test_merged_chain_entry_points_contract_and_plan():
+    """dsv_resblock_chain_multi / dsv_resblock_chain_sum (include/dsv.h): argument checks, and the host model that picks the split
+    (diffsinger_amd.vocoder._merge_plan) on the bench shape - 1 096 / 1 264 / 1 368 workgroups of kernel 3 / 7 / 11 on 512 slots: kernel 11 and
+    kernel 3 share a launch (4.8 rounds' worth instead of 3 + 3), kernel 7 sums."""
+    from diffsinger_amd.vocoder import DsvChainConv, _merge_plan
+    import ctypes
+    assert _merge_plan([1096, 1264, 1368], [6 * 18, 6 * 34, 6 * 50], 512) == (1, [2, 0])
+    assert _merge_plan([512, 512, 512], [1.0, 2.0, 3.0], 512) is None                      # whole rounds: nothing to gain
     lib = _lib.load()
-    assert lib.dsv_chain16_fold(16) == 1 and lib.dsv_chain16_fold(8) == 2 and lib.dsv_chain16_fold(32) == 0
-    ok = (DsvChainConv * 2)(DsvChainConv(0, 0, 11, 5, 0), DsvChainConv(6144, 8, 11, 1, 0))
-    assert lib.dsv_chain16_supported(8, 1, 1, ok) > 0 and lib.dsv_chain16_supported(16, 1, 1, ok) > 0 and lib.dsv_chain16_supported(32, 1, 1, ok) == 0
-    wide = (DsvChainConv * 2)(DsvChainConv(0, 0, 7, 12, 0), DsvChainConv(4096, 8, 7, 1, 0))           # 36 samples of reach: beyond the staged halo
-    assert lib.dsv_chain16_supported(8, 1, 1, wide) == 0
-    x = torch.zeros(1, 8, 1024, device=DEV)
-    bad = (DsvChainConv * 2)(DsvChainConv(100, 0, 3, 1, 0), DsvChainConv(2048, 8, 3, 1, 0))          # offset not a whole chunk
-    wp = torch.zeros(8192, device=DEV)
-    b = torch.zeros(16, device=DEV)
+    x = torch.zeros(1, 32, 1024, device=DEV)
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    wp, b = torch.zeros(65536, device=DEV), torch.zeros(128, device=DEV)
+    d = (DsvChainConv * 4)(DsvChainConv(0, 0, 3, 1, 0), DsvChainConv(3072, 32, 3, 1, 0), DsvChainConv(6144, 64, 3, 3, 0), DsvChainConv(9216, 96, 3, 1, 0))
+    outs = (ctypes.c_void_p * 2)(o1.data_ptr(), o2.data_ptr())
+    same = (ctypes.c_void_p * 2)(o1.data_ptr(), o1.data_ptr())
+    isin = (ctypes.c_void_p * 2)(o1.data_ptr(), x.data_ptr())
+    call = lambda ptrs, ng: lib.dsv_resblock_chain_multi(x.data_ptr(), wp.data_ptr(), b.data_ptr(), ptrs, 1, 32, 1000, ng, 1, d, 0.1, None)
+    assert call(outs, 2) == 0
+    assert call(same, 2) != 0 and call(isin, 2) != 0 and call(outs, 4) != 0 and call(outs, 0) != 0
     out = torch.empty_like(x)
-    assert lib.dsv_resblock_chain16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), out.data_ptr(), None, 1, 8, 1000, 1, 1, bad, 0.1, 1.0, None) != 0
-    assert lib.dsv_resblock_chain16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), x.data_ptr(), None, 1, 8, 1000, 1, 1, ok, 0.1, 1.0, None) != 0     # in == out
+    summ = lambda o, a, c: lib.dsv_resblock_chain_sum(x.data_ptr(), wp.data_ptr(), b.data_ptr(), o, a, c, 0, 1, 32, 1000, 1, d, 0.1, 3.0, None)
+    assert summ(out.data_ptr(), o1.data_ptr(), o2.data_ptr()) == 0
+    assert summ(o1.data_ptr(), o1.data_ptr(), o2.data_ptr()) != 0 and summ(out.data_ptr(), None, o2.data_ptr()) != 0 and summ(x.data_ptr(), o1.data_ptr(), o2.data_ptr()) != 0
+    torch.cuda.synchronize()
 
 
 CHAIN_VARIANTS = [(32, 4, 0), (32, 4, 1), (16, 2, 0), (16, 2, 1), (16, 4, 1), (8, 2, 0), (8, 2, 1), (8, 4, 1)]

@@ -10,7 +10,7 @@ import torch
 
 import bench
 from diffsinger_amd import _lib
-from diffsinger_amd.vocoder import HifiGanGenerator, padded_samples, set_chain_mode, set_chain16
+from diffsinger_amd.vocoder import HifiGanGenerator, padded_samples, set_chain_mode
 
 VARIANTS = {32: [(4, 0), (4, 1)], 16: [(2, 0), (2, 1), (4, 1)], 8: [(2, 0), (2, 1), (4, 1)]}
 
@@ -44,7 +44,6 @@ def main():
         return ev0.elapsed_time(ev1) / reps
 
     best = {}
-    set_chain16(False)
     for stage, C in ((1, 32), (2, 16), (3, 8)):
         L = T * {1: 64, 2: 128, 3: 256}[stage]
         x = torch.randn(B, C, padded_samples(L), device=dev)
@@ -66,23 +65,27 @@ def main():
                                   'frac_fp32_peak': flop / ms / 1e9 / bench.PEAK_FP32_MFMA_TFLOPS, 'bit_identical_to_single_convs': same}), flush=True)
                 if C not in best or ms < best[C][0]:
                     best[C] = (ms, nb, ip, mode)
-        if C in (16, 8):                                   # the 16-row matrix shape (csrc/voc_chain16.hpp): default chain mode, one launch per resblock
-            set_chain_mode(None)
-            set_chain16(True)
+        # round 6: two resblocks merged into one launch (the default variants' MG instantiation), every choice of the summing resblock, and the
+        # default (None: the split vocoder._merge_plan picks, or one launch per resblock)
+        nb0, ip0 = {32: (4, 1), 16: (2, 1), 8: (2, 1)}[C]
+        assert lib.dsv_set_chain_variant(C, nb0, ip0) == 0
+        for mode in ('resblock', 'merged0', 'merged1', 'merged2', None, 'resblock', None):
+            set_chain_mode(mode)
             got = m._stage_resblocks(stage, x, L)
             same = bool(torch.equal(got, want))
             ms = timed(lambda: m._stage_resblocks(stage, x, L))
-            print(json.dumps({'stage': stage, 'C': C, 'variant': 'k_voc_chain16 (16-row MFMA, one launch per resblock)', 'ms': ms, 'tflops_useful': flop / ms / 1e9,
+            plan = m._merge_plan_for(stage, m._chain_prep(stage), B, L) if mode is None else None
+            print(json.dumps({'stage': stage, 'C': C, 'nb': nb0, 'in_place': ip0, 'mode': mode or 'default', 'plan': plan, 'ms': ms, 'tflops_useful': flop / ms / 1e9,
                               'frac_fp32_peak': flop / ms / 1e9 / bench.PEAK_FP32_MFMA_TFLOPS, 'bit_identical_to_single_convs': same}), flush=True)
-            set_chain16(False)
     print(json.dumps({'best': {str(C): best[C] for C in best}}), flush=True)
     for C, (_, nb, ip, mode) in best.items():
         lib.dsv_set_chain_variant(C, nb, ip)
     set_chain_mode(None)
-    set_chain16(False)
-    print(json.dumps({'generator_forward_ms': timed(lambda: m(mel)), 'chain_mode': 'default (resblock)', 'chain16': False, 'variants': {str(C): best[C][1:3] for C in best}}), flush=True)
-    set_chain16(True)
-    print(json.dumps({'generator_forward_ms': timed(lambda: m(mel)), 'chain_mode': 'default (resblock)', 'chain16': True}), flush=True)
+    print(json.dumps({'generator_forward_ms': timed(lambda: m(mel)), 'chain_mode': 'default', 'variants': {str(C): best[C][1:3] for C in best}}), flush=True)
+    set_chain_mode('resblock')
+    print(json.dumps({'generator_forward_ms': timed(lambda: m(mel)), 'chain_mode': 'resblock (no merge)'}), flush=True)
+    set_chain_mode(None)
+    print(json.dumps({'generator_forward_ms': timed(lambda: m(mel)), 'chain_mode': 'default'}), flush=True)
 
 
 if __name__ == '__main__':
