@@ -98,6 +98,44 @@ extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bi
     return DSD_OK;
 }
 
+template <int NB, int WT, int HALO>
+static void voc_conv_multi_launch(const VocConvMulti& m, int ngroups, int B, hipStream_t s) {
+    if (first_on_device(600 + 10 * NB + WT + 1000 * (HALO != kVocHalo))) {
+        (void)hipFuncSetAttribute((const void*)k_voc_conv_multi<NB, WT, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, voc_lds_bytes<NB, WT, HALO>());
+    }
+    constexpr int SPAN = voc_span<NB, WT>();
+    const size_t lds = (size_t)voc_lds_bytes<NB, WT, HALO>();
+    const dim3 grid((unsigned)((m.g[0].LSi + SPAN - 1) / SPAN), (unsigned)B, (unsigned)(m.zc * ngroups));
+    hipLaunchKernelGGL((k_voc_conv_multi<NB, WT, HALO>), grid, dim3(kThreads), lds, s, m);
+}
+
+extern "C" int dsv_conv1d_multi(int32_t ngroups, const dsv_conv_desc* d, int32_t B, int32_t Ci, int32_t rows, int32_t L_in, int32_t up,
+                                float pre_slope, void* stream) {
+    if (!d || ngroups < 1 || ngroups > kVocMultiMax) return fail(DSD_ERR_INVALID, "dsv_conv1d_multi: 1 .. %d convolutions", kVocMultiMax);
+    VocConvMulti m{};
+    bool wide = false;
+    for (int g = 0; g < ngroups; ++g) {
+        const int rc = voc_conv_fill(m.g[g], d[g].in, d[g].wpacked, d[g].bias, d[g].out, B, Ci, rows, d[g].K, d[g].pad, d[g].dil, L_in, up, pre_slope,
+                                     d[g].residual, d[g].sum_in, d[g].divide, d[g].act, "dsv_conv1d_multi");
+        if (rc != DSD_OK) return rc;
+        wide = wide || d[g].pad > kVocHalo || (d[g].K - 1) * d[g].dil - d[g].pad > kVocHalo;
+        for (int k = 0; k < ngroups; ++k) {
+            if (k != g && d[k].out == d[g].out) return fail(DSD_ERR_INVALID, "dsv_conv1d_multi: convolutions %d and %d write the same buffer", k, g);
+            if (d[k].out == d[g].in || d[k].out == d[g].residual || d[k].out == d[g].sum_in)
+                return fail(DSD_ERR_INVALID, "dsv_conv1d_multi: the output of convolution %d is an operand of convolution %d (the convolutions of a call must be independent)", k, g);
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // the instantiation dsv_conv1d picks for this shape (same tiles, same chunk order: the same bits)
+    const long tall_wgs = (long)((m.g[0].LSi + 127) / 128) * B * ((rows + 127) / 128);
+    if (!wide && rows > 64 && tall_wgs >= 512) { m.zc = (rows + 127) / 128; voc_conv_multi_launch<4, 1, kVocHalo>(m, ngroups, B, st); }
+    else if (rows <= 32) { m.zc = 1; if (wide) voc_conv_multi_launch<4, 4, kVocHaloWide>(m, ngroups, B, st); else voc_conv_multi_launch<4, 4, kVocHalo>(m, ngroups, B, st); }
+    else if (rows <= 64) { m.zc = 1; if (wide) voc_conv_multi_launch<2, 2, kVocHaloWide>(m, ngroups, B, st); else voc_conv_multi_launch<2, 2, kVocHalo>(m, ngroups, B, st); }
+    else { m.zc = (rows + 127) / 128; if (wide) voc_conv_multi_launch<1, 1, kVocHaloWide>(m, ngroups, B, st); else voc_conv_multi_launch<1, 1, kVocHalo>(m, ngroups, B, st); }
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
 static int g_voc_fold = 1;       // dsv_set_fold: the A/B switch of the measurement (narrow layers on the unfolded kernel)
 
 extern "C" int dsv_set_fold(int32_t on) { g_voc_fold = on ? 1 : 0; return DSD_OK; }

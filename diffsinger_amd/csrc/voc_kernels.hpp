@@ -276,6 +276,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
     voc_conv_body<NB, WT, HALO>(p, blockIdx.z);
 }
 
+// Several INDEPENDENT convolutions of the same shape (B, Ci, rows, L, up) in ONE launch (round 6): the three parallel resblocks of a stage
+// are three chains of six convolutions; level by level their convolutions depend on nothing of each other.  On the 64-channel stage of the
+// shipped generator - no chain kernel: a 64-channel tile with its receptive field does not fit the LDS - a convolution is 512 workgroups =
+// exactly one round of co-resident workgroups, all of them staging, contracting and storing at the same time.  Three convolutions in one
+// grid (group = blockIdx.z / zc, the longest kernel first) pay the kernel boundary once, and the workgroups of the second and third round
+// stage under the contractions of the round before: 125 us against 3 x 45 (profiles/r6_31_vocoder_kernel_stats.txt).
+// (A variant built for three workgroups per CU - 168 registers, the LDS slab sized by the channel count - spilled 85 registers; not kept.)
+constexpr int kVocMultiMax = 3;
+struct VocConvMulti {
+    VocConvParams g[kVocMultiMax];
+    int zc;                 // row-block groups of one convolution (blockIdx.z = group * zc + bz)
+};
+
+template <int NB, int WT, int HALO = kVocHalo>
+__global__ __launch_bounds__(kThreads, 2) void k_voc_conv_multi(const VocConvMulti m) {
+    const int grp = blockIdx.z / m.zc;
+    voc_conv_body<NB, WT, HALO>(m.g[grp], (int)blockIdx.z - grp * m.zc);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Narrow layers (Co <= 16): F output samples folded into the 32 MFMA rows
 // ------------------------------------------------------------------------------------------------------------

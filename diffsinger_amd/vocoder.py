@@ -80,6 +80,13 @@ class DsvChainConv(_C.Structure):
     _fields_ = [('w_offset', _C.c_int64), ('bias_offset', _C.c_int32), ('K', _C.c_int32), ('dil', _C.c_int32), ('reserved', _C.c_int32)]
 
 
+class DsvConvDesc(_C.Structure):
+    """include/dsv.h dsv_conv_desc"""
+    _fields_ = [('in_', _C.c_void_p), ('wpacked', _C.c_void_p), ('bias', _C.c_void_p), ('out', _C.c_void_p), ('residual', _C.c_void_p),
+                ('sum_in', _C.c_void_p), ('K', _C.c_int32), ('pad', _C.c_int32), ('dil', _C.c_int32), ('act', _C.c_int32), ('divide', _C.c_float),
+                ('reserved', _C.c_int32)]
+
+
 # How the ResBlock1 chains of a stage are launched (csrc/voc_chain.hpp): None = one launch per RESBLOCK (three conv pairs; the three parallel
 # resblocks of a stage run one after the other, the running sum handed on through `sum_in`) wherever the library supports it (8 / 16 / 32
 # channels; wider stages: one launch per convolution).  A launch's halo is the receptive field of ITS chain: 12 / 36 / 60 samples for the
@@ -180,6 +187,21 @@ class _HipOps:
                                            float(pre_slope), self._p(residual), self._p(sum_in), float(divide), int(act), self._s(x.device)),
                        'dsv_conv1d')
         return out
+
+    def conv_multi(self, xs, L_in, items, up=1, pre_slope=1.0):
+        """Independent convolutions of one shape in ONE launch (dsv_conv1d_multi): xs[g] through items[g] = dict(wp, bias, rows, ci, k, pad, dil
+        [, residual, sum_in, divide, act]); returns the outputs.  The first item's workgroups are dispatched first."""
+        B, rows, ci = xs[0].shape[0], items[0]['rows'], items[0]['ci']
+        outs, descs = [], (DsvConvDesc * len(xs))()
+        for g, (x, it) in enumerate(zip(xs, items)):
+            assert x.shape == xs[0].shape and x.shape[1] == ci and x.shape[2] == padded_samples(L_in) and x.is_contiguous() and it['rows'] == rows and it['ci'] == ci
+            out = torch.empty(B, rows // up, padded_samples(L_in * up), device=x.device, dtype=torch.float32)
+            outs.append(out)
+            descs[g] = DsvConvDesc(x.data_ptr(), it['wp'].data_ptr(), self._p(it.get('bias')), out.data_ptr(), self._p(it.get('residual')),
+                                   self._p(it.get('sum_in')), it['k'], it['pad'], it['dil'], int(it.get('act', 0)), float(it.get('divide', 1.0)), 0)
+        with torch.cuda.device(xs[0].device):
+            _lib.check(self.lib.dsv_conv1d_multi(len(xs), descs, B, ci, rows, L_in, up, float(pre_slope), self._s(xs[0].device)), 'dsv_conv1d_multi')
+        return outs
 
     def fold_factor(self, co, ci, k, dil) -> int:
         return int(self.lib.dsv_fold_factor(co, ci, k, dil))
@@ -512,11 +534,53 @@ class HifiGanGenerator(nn.Module):
                                                divide=nk if (last and r == nres - 1) else 1.0)
                     acc = y
                 return acc
+        if _CHAIN_MODE is None:
+            y = self._stage_resblocks_by_level(i, x, L)
+            if y is not None:
+                return y
         acc = None
         for j in range(self.num_kernels):                            # xs = rb0(x); xs += rb1(x); ...; x = xs / num_kernels
             last = j == self.num_kernels - 1
             acc = self._resblock(i * self.num_kernels + j, x, L, acc, float(self.num_kernels) if last else 1.0)
         return acc
+
+    def _stage_resblocks_by_level(self, i: int, x, L):
+        """The stage's parallel ResBlock1 as chains advanced LEVEL BY LEVEL (round 6; stages without a chain kernel - 64 channels on the shipped
+        generator): the j-th resblocks' convolutions of a level are independent, so they share ONE launch (dsv_conv1d_multi, the largest kernel
+        first) - 3 + 2 merged launches and the three convolutions that carry the running sum `xs +=` instead of 18.  Every convolution is the
+        one `_resblock` runs, operand for operand: the same bits.  None: the stage does not qualify (ResBlock2, folded layers, one resblock)."""
+        nk, ops = self.num_kernels, self._ops
+        rbs = [self.resblocks[i * nk + j] for j in range(nk)]
+        if nk < 2 or nk > 3 or not hasattr(ops, 'conv_multi') or any(rb.kind != '1' for rb in rbs) or len({len(rb.dils) for rb in rbs}) != 1:
+            return None
+        convs = [c for rb in rbs for q in range(len(rb.dils)) for c in (rb.convs1[q], rb.convs2[q])]
+        if len({c.wshape()[:2] for c in convs}) != 1:
+            return None
+        for rb in rbs:
+            for q, d in enumerate(rb.dils):
+                for c, dd in ((rb.convs1[q], d), (rb.convs2[q], 1)):
+                    co, ci, k = c.wshape()
+                    if get_padding(k, dd) > MAX_REACH or ops.fold_factor(co, ci, k, dd) != 1:
+                        return None
+        order = sorted(range(nk), key=lambda j: -rbs[j].convs1[0].wshape()[2])          # the largest kernel's workgroups first
+        n = len(rbs[0].dils)
+
+        def item(j, which, q, dil, **kw):
+            conv = (rbs[j].convs1 if which == 1 else rbs[j].convs2)[q]
+            e = self._prep(f'rb{i * nk + j}.c{which}.{q}', conv, fold=1)
+            return dict(wp=e['wp'], bias=e['bias'], rows=e['rows'], ci=e['ci'], k=e['k'], pad=get_padding(e['k'], dil), dil=dil, **kw)
+
+        xr = {j: x for j in range(nk)}
+        for q in range(n):
+            xt = dict(zip(order, ops.conv_multi([xr[j] for j in order], L, [item(j, 1, q, rbs[j].dils[q]) for j in order], pre_slope=LRELU_SLOPE)))
+            if q < n - 1:
+                xr = dict(zip(order, ops.conv_multi([xt[j] for j in order], L, [item(j, 2, q, 1, residual=xr[j]) for j in order], pre_slope=LRELU_SLOPE)))
+            else:
+                acc = None
+                for j in range(nk):                                  # xs = rb0(x); xs += rb1(x); ...; x = xs / num_kernels
+                    acc = self._conv(f'rb{i * nk + j}.c2.{q}', rbs[j].convs2[q], xt[j], L, dil=1, pre_slope=LRELU_SLOPE, residual=xr[j], sum_in=acc,
+                                     divide=float(nk) if j == nk - 1 else 1.0)
+                return acc
 
     def _resblock(self, idx: int, x, L, sum_in, divide):
         """One ResBlock on x; its last convolution also adds the block output into `sum_in` (xs += ...) and divides."""

@@ -51,6 +51,27 @@ int dsv_conv1d(const float* in, const float* wpacked, const float* bias, float* 
                int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in,
                float divide, int32_t act, void* stream);
 
+/* `ngroups` (1 .. 3) INDEPENDENT convolutions of the same shape (B, Ci, rows, L_in, up, pre_slope) in ONE launch (round 6) - the
+ * convolutions of the parallel resblocks of a stage, level by level (hifigan.py:161-166: `resblocks[i * num_kernels + j](x)` for j = 0, 1, 2
+ * read the same x and depend on nothing of each other until `xs +=`).  Convolution g is exactly dsv_conv1d(d[g].in, d[g].wpacked, ...,
+ * d[g].act) - kernel size, padding, dilation, residual, running sum, divisor and activation are its own; the workgroups of d[0] are
+ * dispatched first (pass the largest kernel first).  No output may be an operand of another convolution of the call.  On the 64-channel
+ * stage of the shipped generator a convolution is one round of co-resident workgroups and a launch costs 15-19 us beyond its matrix time:
+ * three convolutions per launch pay that once.  Same tiles, same chunk order as dsv_conv1d: bit-identical. */
+typedef struct dsv_conv_desc {
+    const float* in;
+    const float* wpacked;
+    const float* bias;
+    float* out;
+    const float* residual;
+    const float* sum_in;
+    int32_t K, pad, dil, act;
+    float divide;
+    int32_t reserved;
+} dsv_conv_desc;
+int dsv_conv1d_multi(int32_t ngroups, const dsv_conv_desc* d, int32_t B, int32_t Ci, int32_t rows, int32_t L_in, int32_t up, float pre_slope,
+                     void* stream);
+
 /* The same convolution (up = 1, 'same' padding pad = (K-1) * dil / 2, K odd) for the NARROW layers, Co <= 16 - the 16- and 8-channel
  * resblocks and conv_post of the shipped generator: F output samples are folded into the 32 MFMA rows so that no row multiplies
  * zeros.  dsv_fold_factor returns the F the library wants for such a layer (4: Co <= 8, 2: Co <= 16, 1: use dsv_conv1d; also 1

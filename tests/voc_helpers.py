@@ -46,6 +46,11 @@ class HeaderFormulaOps:
         out[:, :, :Lo] = v
         return out
 
+    def conv_multi(self, xs, L_in, items, up=1, pre_slope=1.0):
+        """dsv_conv1d_multi: convolution g is dsv_conv1d on its own operands."""
+        return [self.conv(x, L_in, it['wp'], it.get('bias'), it['rows'], it['ci'], it['k'], it['pad'], it['dil'], up=up, pre_slope=pre_slope,
+                          residual=it.get('residual'), sum_in=it.get('sum_in'), divide=it.get('divide', 1.0), act=it.get('act', 0)) for x, it in zip(xs, items)]
+
     def chain_fold(self, C):
         return 0                                                      # the fused ResBlock1 chains (dsv_resblock_chain) exist on the device only
 
