@@ -411,12 +411,14 @@ def main_vocoder(args):
     assert torch.equal(wav_g, wav), 'graph replay differs from the eager forward'
     el_g, _ = _row_time(lambda: gm(mel), args, world, device, dist)
     if rank == 0:
-        # dominant kernel: the fused resblock stage of the 32-channel stage - ONE launch of k_voc_chain<32,1,4> = 3 resblocks x 3 conv pairs
-        # (18 convolutions, kernels 3 / 7 / 11, dilations 1 / 3 / 5) over 8 x 65 536 samples, 40 % of the forward - timed with events on the
-        # launch stream.  With the chains fused the row is bound by the fp32 matrix pipe, not by HBM any more (its traffic is the PMC figure).
+        # dominant kernel: the fused resblock stage of the 32-channel stage - k_voc_chain<32,1,4>: 3 resblocks x 3 conv pairs (18 convolutions,
+        # kernels 3 / 7 / 11, dilations 1 / 3 / 5) over 8 x 65 536 samples as TWO launches (round 6: two resblocks merged into one grid, the third
+        # forms the sum), 36 % of the forward - timed with events on the launch stream.  With the chains fused the row is bound by the fp32
+        # matrix pipe, not by HBM any more (its traffic is the PMC figure).
         chained = args.chain != 'off' and m._chain_prep(1) is not None
         stage, ch = 1, 32
         L = T * 64
+        merged = chained and args.chain == 'default' and m._merge_plan_for(stage, m._chain_prep(stage), B, L) is not None
         x = torch.randn(B, ch, padded_samples(L), device=device)
         x[:, :, L:] = 0
         launch = lambda: m._stage_resblocks(stage, x, L)
@@ -434,15 +436,19 @@ def main_vocoder(args):
         pj, traffic_src = evidence('voc_chain_32ch_pmc.json')
         traffic = None
         if pj is not None:
-            traffic = pj['hbm_bytes_per_launch']['total'] * pj.get('launches_per_stage', 3)
+            nl = pj.get('launches_per_stage', 2 if merged else 3)
+            traffic = pj['hbm_bytes_per_launch']['total'] * nl
             traffic_src += (': FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024, average over the launches of the stage '
-                            'at this shape x 3 launches')
-        kname = 'k_voc_chain<32, 1, 4, true> x 3 (one launch per resblock)' if chained else 'k_voc_conv<4,4> x 18 (chains off)'
+                            f'at this shape x {nl} launches')
+        kname = ('k_voc_chain<32, 1, 4, true, true> x 2 (two resblocks merged into one launch, longest first; the third sums)' if merged else
+                 'k_voc_chain<32, 1, 4, true> x 3 (one launch per resblock)' if chained else 'k_voc_conv<4,4> x 18 (chains off)')
         roof = {'bound': 'mfma', 'kernel': kname, 'achieved': flop / (ms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic if chained else None, 'traffic_unit': 'bytes/stage',
                 'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms, 'flop_per_launch': flop,
                 'note': 'the resblock stage of the 32-channel stage (3 parallel resblocks x 3 conv pairs = 18 convolutions, kernels 3 / 7 / 11, dilations 1 / 3 / 5, '
-                        '8 x 65 536 samples): "launch" = the stage = three chain launches (one per resblock, the running sum handed on); achieved = USEFUL fp32 '
+                        '8 x 65 536 samples): "launch" = the stage = two chain launches (round 6: the kernel-11 and the kernel-3 resblock in ONE grid, longest '
+                        'first, each to its own buffer; the kernel-7 resblock forms the sum - a launch costs whole rounds of co-resident workgroups, three '
+                        'dependent launches paid three partial ones: profiles/r6_27_voc_tail_probe.jsonl; `--chain resblock` = the three-launch form); achieved = USEFUL fp32 '
                         'FLOPs of the 18 convolutions (2 x 32 x 32 x k per sample) / stage time incl. the torch.empty of the outputs and the ctypes calls; the '
                         'kernels execute 1.22 x that (a workgroup stages 512 samples and owns 512 - 2 x 12 / 36 / 60 of them: the receptive field of ITS '
                         'resblock) on one 32-row MFMA block, one LDS tile rewritten in place, two workgroups per CU (round 6; rounds 3-5: one launch per '
@@ -454,7 +460,7 @@ def main_vocoder(args):
                'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': f'SURVEY 8 row f2: HifiGanGenerator of configs/tts/hifigan.yaml (128 -> 8 channels, x256), batch={B} x T={T} mel '
-                                      f'frames per GPU -> {B} x {T * 256} samples', 'resblock_chains': 'one chain launch per resblock (three per stage) for the 32 / 16 / 8-channel stages (k_voc_chain, one LDS tile rewritten in place)' if chained else 'off: one launch per convolution',
+                                      f'frames per GPU -> {B} x {T * 256} samples', 'resblock_chains': ('two chain launches per stage for the 32 / 16 / 8-channel stages (k_voc_chain, one LDS tile rewritten in place; two resblocks merged into one grid, the third sums), the 64-channel stage level by level (k_voc_conv_multi: 8 launches)' if merged else 'one chain launch per resblock (three per stage) for the 32 / 16 / 8-channel stages (k_voc_chain, one LDS tile rewritten in place)') if chained else 'off: one launch per convolution',
                           'sharding': 'replicas (no exchange step in this row)'},
                'roofline': roof, 'model_tflops': world * B * T * fpf * args.steps / el / 1e12, 'flop_per_mel_frame': fpf,
                'x_realtime_24k': value * 256 / 24000,
@@ -889,7 +895,7 @@ def main():
                          '(512 utterances x T=2048 sharded across the GPUs, strong scaling; the default at --gpus > 1)')
     ap.add_argument('--conv-split', type=int, choices=[-1, 0, 1], default=-1,
                     help='--row fs2 A/B: kernel choice of the FastSpeech2 convolutions (-1 by grid size = the product, 0 never the K-split kernel, 1 always)')
-    ap.add_argument('--chain', choices=['default', 'off', 'stage', 'resblock', 'pair'], default='default',
+    ap.add_argument('--chain', choices=['default', 'off', 'stage', 'resblock', 'pair', 'merged'], default='default',
                     help='--row vocoder: how the ResBlock1 chains are launched (diffsinger_amd.vocoder.set_chain_mode); default = by channel count')
     ap.add_argument('--conv', choices=['winograd', 'direct'], default=None,
                     help='convolution of the persistent loop: winograd F(2,3) (the default of the library) or the direct K = 768 form (A/B, rounds 1-4)')
