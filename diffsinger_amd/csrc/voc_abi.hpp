@@ -317,7 +317,7 @@ static int voc_chain_launch_groups(VocChainParams& p, const dsv_chain_conv* conv
     }
     if (blocks > 0x7fffffffL) return fail(DSD_ERR_INVALID, "%s: too many workgroups", who);
     constexpr int lds = chain_lds_bytes<C, F, NB, true>();
-    if (first_on_device(500 + C))
+    if (first_on_device(500 + C + 1000 * NB))
         HIP_TRY(hipFuncSetAttribute((const void*)k_voc_chain<C, F, NB, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL((k_voc_chain<C, F, NB, true, true>), dim3((unsigned)blocks), dim3(kThreads), lds, s, p);
     HIP_TRY(hipGetLastError());
@@ -325,9 +325,11 @@ static int voc_chain_launch_groups(VocChainParams& p, const dsv_chain_conv* conv
 }
 
 static int voc_chain_groups(VocChainParams& p, const dsv_chain_conv* convs, int B, int C, hipStream_t s, const char* who) {
+    // (the window of dsv_set_chain_variant; always the one-tile-in-place form)
     if (C == 32) return voc_chain_launch_groups<32, 1, 4>(p, convs, B, s, who);
-    if (C == 16) return voc_chain_launch_groups<16, 2, 2>(p, convs, B, s, who);
-    return voc_chain_launch_groups<8, 4, 2>(p, convs, B, s, who);
+    const int nb = g_chain_variant[chain_slot(C)].nb;
+    if (C == 16) return nb == 4 ? voc_chain_launch_groups<16, 2, 4>(p, convs, B, s, who) : voc_chain_launch_groups<16, 2, 2>(p, convs, B, s, who);
+    return nb == 4 ? voc_chain_launch_groups<8, 4, 4>(p, convs, B, s, who) : voc_chain_launch_groups<8, 4, 2>(p, convs, B, s, who);
 }
 
 extern "C" int dsv_resblock_chain_multi(const float* in, const float* wpacked, const float* bias, float* const* outs, int32_t B, int32_t C, int32_t L,

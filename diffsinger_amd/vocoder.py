@@ -465,8 +465,10 @@ class HifiGanGenerator(nn.Module):
 
     def _merge_plan_for(self, i: int, e, B: int, L: int, force: bool = False):
         """_merge_plan for stage i at batch B, length L (cached per shape): workgroups per resblock from dsv_chain_supported's tile size, relative
-        workgroup time = its chunks (C / 8 x folded taps per convolution) + 1.5 chunk times per convolution of epilogue / barrier / restart
-        (the fit of profiles/r6_27_voc_tail_probe.jsonl), slots = 256 CUs x the co-resident workgroups of the instantiation."""
+        workgroup time = its chunks (C / 8 x folded taps per convolution) + 5.5 chunk times per convolution of epilogue / barrier / restart
+        (the fit of profiles/r6_27_voc_tail_probe.jsonl: 6.0 / 5.6 / 4.5 at 32 / 16 / 8 channels), slots = 256 CUs x the co-resident workgroups
+        of the default instantiation.  The model ignores that a partial round runs faster than a full one: at 16 channels it prefers the
+        kernel-3 resblock as the summing launch where the kernel-7 one measures 1.3 % better (profiles/r6_32_voc_chain_variants.jsonl)."""
         key = (i, B, L, force)
         hit = self._packed.get('merge_plans', {})
         if key in hit:
@@ -479,7 +481,7 @@ class HifiGanGenerator(nn.Module):
         if all(Ns):
             LS = padded_samples(L)
             W = [B * ((LS + n - 1) // n) for n in Ns]
-            d = [sum((C // 8) * (e['descs'][(r * npairs + q) * 2 + k].K + F - 1) + 1.5 * (C // 8) for q in range(npairs) for k in range(2)) for r in range(nres)]
+            d = [sum((C // 8) * (e['descs'][(r * npairs + q) * 2 + k].K + F - 1) + 5.5 for q in range(npairs) for k in range(2)) for r in range(nres)]
             slots = 256 * (2 if C == 32 else 3)
             plan = _merge_plan(W, d, slots, min_gain=-1e9 if force else 0.03)
         hit[key] = plan

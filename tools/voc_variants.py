@@ -67,16 +67,17 @@ def main():
                     best[C] = (ms, nb, ip, mode)
         # round 6: two resblocks merged into one launch (the default variants' MG instantiation), every choice of the summing resblock, and the
         # default (None: the split vocoder._merge_plan picks, or one launch per resblock)
-        nb0, ip0 = {32: (4, 1), 16: (2, 1), 8: (2, 1)}[C]
-        assert lib.dsv_set_chain_variant(C, nb0, ip0) == 0
-        for mode in ('resblock', 'merged0', 'merged1', 'merged2', None, 'resblock', None):
-            set_chain_mode(mode)
-            got = m._stage_resblocks(stage, x, L)
-            same = bool(torch.equal(got, want))
-            ms = timed(lambda: m._stage_resblocks(stage, x, L))
-            plan = m._merge_plan_for(stage, m._chain_prep(stage), B, L) if mode is None else None
-            print(json.dumps({'stage': stage, 'C': C, 'nb': nb0, 'in_place': ip0, 'mode': mode or 'default', 'plan': plan, 'ms': ms, 'tflops_useful': flop / ms / 1e9,
-                              'frac_fp32_peak': flop / ms / 1e9 / bench.PEAK_FP32_MFMA_TFLOPS, 'bit_identical_to_single_convs': same}), flush=True)
+        for nb0, ip0 in {32: [(4, 1)], 16: [(4, 1), (2, 1)], 8: [(4, 1), (2, 1)]}[C]:          # (the last one stays in force)
+            assert lib.dsv_set_chain_variant(C, nb0, ip0) == 0
+            m._packed.pop('merge_plans', None)
+            for mode in ('resblock', 'merged0', 'merged1', 'merged2', None, 'resblock', None):
+                set_chain_mode(mode)
+                got = m._stage_resblocks(stage, x, L)
+                same = bool(torch.equal(got, want))
+                ms = timed(lambda: m._stage_resblocks(stage, x, L))
+                plan = m._merge_plan_for(stage, m._chain_prep(stage), B, L) if mode is None else None
+                print(json.dumps({'stage': stage, 'C': C, 'nb': nb0, 'in_place': ip0, 'mode': mode or 'default', 'plan': plan, 'ms': ms, 'tflops_useful': flop / ms / 1e9,
+                                  'frac_fp32_peak': flop / ms / 1e9 / bench.PEAK_FP32_MFMA_TFLOPS, 'bit_identical_to_single_convs': same}), flush=True)
     print(json.dumps({'best': {str(C): best[C] for C in best}}), flush=True)
     for C, (_, nb, ip, mode) in best.items():
         lib.dsv_set_chain_variant(C, nb, ip)
