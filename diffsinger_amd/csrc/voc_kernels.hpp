@@ -282,7 +282,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p)
 // exactly one round of co-resident workgroups, all of them staging, contracting and storing at the same time.  Three convolutions in one
 // grid (group = blockIdx.z / zc, the longest kernel first) pay the kernel boundary once, and the workgroups of the second and third round
 // stage under the contractions of the round before: 125 us against 3 x 45 (profiles/r6_31_vocoder_kernel_stats.txt).
-// (A variant built for three workgroups per CU - 168 registers, the LDS slab sized by the channel count - spilled 85 registers; not kept.)
+// (A variant built for three workgroups per CU - 168 registers: no operand prefetch, the phase count a compile-time 1, six staging loads in
+// flight, the LDS slab sized by the channel count, 28 registers spilled - measured 3.670 against 3.651 ms for the row, r6_33: not kept.)
 constexpr int kVocMultiMax = 3;
 struct VocConvMulti {
     VocConvParams g[kVocMultiMax];

@@ -111,7 +111,7 @@ def _merge_plan(W, d, slots, min_gain=0.03):
     """Which resblock of a stage to leave out of the merged launch.  A chain launch of W workgroups on `slots` co-resident places takes
     ceil(W / slots) rounds of its workgroup time d (profiles/r6_27_voc_tail_probe.jsonl); a merged launch - longest chain first - is list
     scheduling of its workgroups on the slots.  W[r], d[r]: workgroups and relative workgroup time of resblock r.  Returns (solo, order of
-    the merged groups) for the split with the smallest modelled time, or None when no split beats three launches by `min_gain`."""
+    the merged groups), or None when the modelled time does not beat three launches by `min_gain`."""
     import math
     n = len(W)
     if n != 3:
@@ -135,15 +135,16 @@ def _merge_plan(W, d, slots, min_gain=0.03):
                     heapq.heappush(free, (t, c - k))
         return end
 
-    best = None
-    for solo in range(n):
-        groups = sorted((r for r in range(n) if r != solo), key=lambda r: -d[r])
-        t = merged_time(groups) + rounds(W[solo]) * d[solo]
-        if best is None or t < best[0]:
-            best = (t, solo, groups)
-    if best[0] > (1.0 - min_gain) * separate:
+    # the summing launch: the resblock of MEDIAN workgroup time - the longest and the shortest chain share the merged grid, so that the short
+    # workgroups fill the long ones' last round.  (Measured on the bench shape, every choice per stage, profiles/r6_30 / r6_32_voc_chain_variants.jsonl:
+    # the median is the fastest at 32, 16 and 8 channels; the model alone - it ignores that a partial round runs faster - preferred the
+    # shortest chain as the summing launch at 16 channels, 1.3 % slower.)  The model decides only WHETHER to merge.
+    solo = sorted(range(n), key=lambda r: d[r])[n // 2]
+    groups = sorted((r for r in range(n) if r != solo), key=lambda r: -d[r])
+    t = merged_time(groups) + rounds(W[solo]) * d[solo]
+    if t > (1.0 - min_gain) * separate:
         return None
-    return best[1], best[2]
+    return solo, groups
 
 
 class _HipOps:
@@ -467,8 +468,7 @@ class HifiGanGenerator(nn.Module):
         """_merge_plan for stage i at batch B, length L (cached per shape): workgroups per resblock from dsv_chain_supported's tile size, relative
         workgroup time = its chunks (C / 8 x folded taps per convolution) + 5.5 chunk times per convolution of epilogue / barrier / restart
         (the fit of profiles/r6_27_voc_tail_probe.jsonl: 6.0 / 5.6 / 4.5 at 32 / 16 / 8 channels), slots = 256 CUs x the co-resident workgroups
-        of the default instantiation.  The model ignores that a partial round runs faster than a full one: at 16 channels it prefers the
-        kernel-3 resblock as the summing launch where the kernel-7 one measures 1.3 % better (profiles/r6_32_voc_chain_variants.jsonl)."""
+        of the default instantiation."""
         key = (i, B, L, force)
         hit = self._packed.get('merge_plans', {})
         if key in hit:

@@ -289,6 +289,46 @@ def test_resblock_chain_is_bit_identical_to_the_single_convolutions(stage, L, mo
     assert torch.equal(got, want), float((got - want).abs().max())
 
 
+@pytest.mark.parametrize('C,L', [(64, 300), (64, 1000), (32, 515), (128, 77)])
+def test_conv1d_multi_is_bit_identical_to_the_single_launches(C, L):
+    """dsv_conv1d_multi (include/dsv.h, round 6): three independent convolutions of one shape - kernels 11 / 7 / 3 at dilations 5 / 3 / 1, one with a
+    residual, one with residual + running sum + divisor - in ONE launch against three dsv_conv1d launches: the same BITS (same tiles, same chunk
+    order); ragged lengths, every tiling (<2,2> at 64 rows, <4,4> at 32, <1,1> at 128); and the argument contract."""
+    import ctypes
+    from diffsinger_amd.vocoder import DsvConvDesc
+    ops = _HipOps()
+    g = torch.Generator().manual_seed(C + L)
+    B = 2
+    xs, items = [], []
+    for k, dil in ((11, 5), (7, 3), (3, 1)):
+        w = (torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(DEV)
+        xs.append(_cm(torch.randn(B, C, L, generator=g), L).to(DEV))
+        items.append(dict(wp=ops.pack(w), bias=torch.randn(C, generator=g).to(DEV), rows=C, ci=C, k=k, pad=(k - 1) * dil // 2, dil=dil))
+    items[1]['residual'] = _cm(torch.randn(B, C, L, generator=g), L).to(DEV)
+    items[2]['residual'] = _cm(torch.randn(B, C, L, generator=g), L).to(DEV)
+    items[2]['sum_in'] = _cm(torch.randn(B, C, L, generator=g), L).to(DEV)
+    items[2]['divide'] = 3.0
+    want = [ops.conv(x, L, it['wp'], it['bias'], C, C, it['k'], it['pad'], it['dil'], pre_slope=0.1, residual=it.get('residual'), sum_in=it.get('sum_in'),
+                     divide=it.get('divide', 1.0)) for x, it in zip(xs, items)]
+    got = ops.conv_multi(xs, L, items, pre_slope=0.1)
+    two = ops.conv_multi(xs[:2], L, items[:2], pre_slope=0.1)
+    torch.cuda.synchronize()
+    for a, b in zip(got + two, want + want[:2]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    lib = _lib.load()
+    mk = lambda i, out, **kw: DsvConvDesc(kw.get('inp', xs[i].data_ptr()), items[i]['wp'].data_ptr(), items[i]['bias'].data_ptr(), out, kw.get('res'), None,
+                                         items[i]['k'], items[i]['pad'], items[i]['dil'], 0, 1.0, 0)
+    o0, o1 = torch.empty_like(xs[0]), torch.empty_like(xs[0])
+    call = lambda *d: lib.dsv_conv1d_multi(len(d), (DsvConvDesc * len(d))(*d), B, C, C, L, 1, 0.1, None)
+    assert call(mk(0, o0.data_ptr()), mk(1, o1.data_ptr())) == 0
+    assert call(mk(0, o0.data_ptr()), mk(1, o0.data_ptr())) != 0                                  # two convolutions, one output
+    assert call(mk(0, o0.data_ptr()), mk(1, o1.data_ptr(), inp=o0.data_ptr())) != 0              # an output is another convolution's input
+    assert call(mk(0, o0.data_ptr()), mk(1, o1.data_ptr(), res=o0.data_ptr())) != 0              # ... or its residual
+    assert lib.dsv_conv1d_multi(0, (DsvConvDesc * 1)(mk(0, o0.data_ptr())), B, C, C, L, 1, 0.1, None) != 0
+    assert lib.dsv_conv1d_multi(4, (DsvConvDesc * 4)(*[mk(0, o0.data_ptr())] * 4), B, C, C, L, 1, 0.1, None) != 0
+    torch.cuda.synchronize()
+
+
 def test_merged_chain_entry_points_contract_and_plan():
     """dsv_resblock_chain_multi / dsv_resblock_chain_sum (include/dsv.h): argument checks, and the host model that picks the split
     (diffsinger_amd.vocoder._merge_plan) on the bench shape - 1 096 / 1 264 / 1 368 workgroups of kernel 3 / 7 / 11 on 512 slots: kernel 11 and
