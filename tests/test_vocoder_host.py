@@ -250,3 +250,52 @@ def test_denoise_post_filter_matches_an_independent_stft_and_is_identity_at_zero
                 assert float(np.abs(got[edge:m - edge] - wav[edge:m - edge]).max()) < 2e-5     # no subtraction: the filter is the identity
             else:
                 assert float(np.abs(got).mean()) < float(np.abs(wav).mean())                  # energy went down
+
+
+def test_merge_plan_counts_rounds():
+    """diffsinger_amd.vocoder._merge_plan (round 6): a chain launch of W workgroups on S co-resident places costs ceil(W / S) rounds
+    (profiles/r6_27_voc_tail_probe.jsonl).  The bench shape at 32 channels - 1 096 / 1 264 / 1 368 workgroups of the kernel-3 / 7 / 11 resblocks
+    on 512 places - pays 3 + 3 + 3 rounds as three launches; with kernel 11 and kernel 3 in one grid the short workgroups fill the long ones'
+    last round.  The summing launch is the resblock of median workgroup time; whole rounds gain nothing and are left alone."""
+    from diffsinger_amd.vocoder import _merge_plan
+    assert _merge_plan([1096, 1264, 1368], [6 * 18, 6 * 34, 6 * 50], 512) == (1, [2, 0])
+    assert _merge_plan([2192, 2528, 2736], [81.0, 129.0, 177.0], 768) == (1, [2, 0])
+    assert _merge_plan([512, 512, 512], [1.0, 2.0, 3.0], 512) is None                       # three whole rounds
+    assert _merge_plan([1096, 1264, 1368], [3.0, 2.0, 1.0], 512)[0] == 1                    # median by TIME, longest group first
+    assert _merge_plan([1096, 1264, 1368], [3.0, 2.0, 1.0], 512)[1] == [0, 2]
+    assert _merge_plan([100, 100], [1.0, 2.0], 512) is None                                 # two resblocks: nothing to leave for the sum
+
+
+def test_level_by_level_resblocks_equal_the_sequential_form():
+    """HifiGanGenerator._stage_resblocks_by_level (round 6: the stages without a chain kernel advance their three parallel ResBlock1 level by
+    level, the convolutions of a level in one dsv_conv1d_multi launch) against `_resblock` one after the other - on the header-formula
+    emulation the two are the same torch calls on the same operands: equal bits; a ResBlock2 generator does not qualify."""
+    import diffsinger_amd.vocoder as V
+    cfg = dict(CONFIG)
+    m = HifiGanGenerator(cfg)
+    m.remove_weight_norm()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    m._ops = HeaderFormulaOps()
+    L = 90
+    C = cfg['upsample_initial_channel'] // 2
+    x = torch.zeros(2, C, V.padded_samples(L))
+    x[:, :, :L] = torch.randn(2, C, L, generator=g)
+    got = m._stage_resblocks_by_level(0, x, L)
+    assert got is not None
+    acc = None
+    for j in range(m.num_kernels):
+        acc = m._resblock(j, x, L, acc, float(m.num_kernels) if j == m.num_kernels - 1 else 1.0)
+    assert torch.equal(got, acc)
+    V.set_chain_mode('off')
+    try:
+        assert torch.equal(m._stage_resblocks(0, x, L), acc)
+    finally:
+        V.set_chain_mode(None)
+    assert torch.equal(m._stage_resblocks(0, x, L), acc)
+    m2 = HifiGanGenerator(dict(cfg, resblock='2'))
+    m2.remove_weight_norm()
+    m2._ops = HeaderFormulaOps()
+    assert m2._stage_resblocks_by_level(0, x, L) is None
