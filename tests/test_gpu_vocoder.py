@@ -406,6 +406,32 @@ def test_generator_with_fused_chains_equals_the_unfused_generator(mode, chain_de
     assert torch.equal(got, want), float((got - want).abs().max())
 
 
+@pytest.mark.parametrize('dils,B,T', [([[1, 3, 5], [1, 6, 12], [1, 3, 5]], 2, 40), ([[1, 3, 5], [1, 3, 5], [1, 3, 5]], 1, 7), ([[1, 2], [2, 6], [3, 4]], 3, 33)])
+def test_default_launch_forms_on_other_configs_equal_the_unfused_generator(dils, B, T, chain_default):
+    """The default launch forms of round 6 - merged chain launches, the level-by-level 64-channel stage - against one launch per convolution
+    on generators beyond the shipped one (hifigan.py:104-179 accepts any config): a kernel-7 resblock at dilation 12 (reach 36: no chain
+    kernel for ITS stage's resblocks -> the stages fall back, the wide-window instantiations of dsv_conv1d_multi run), one utterance of 7
+    frames (every launch a partial tile), two conv pairs per resblock.  Same bits."""
+    h = dict(CONFIG, use_pitch_embed=False, resblock_dilation_sizes=dils)
+    m = HifiGanGenerator(h)
+    m.remove_weight_norm()
+    g = torch.Generator().manual_seed(B * 100 + T)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 / max(1, p[0].numel()) ** 0.5 if n.endswith('weight') else 0.1))
+    m = m.to(DEV).eval()
+    mel = torch.randn(B, 80, T, generator=g).to(DEV)
+    chain_default.set_chain_mode('off')
+    want = m(mel)
+    chain_default.set_chain_mode(None)
+    got = m(mel)
+    again = m(mel)
+    torch.cuda.synchronize()
+    assert torch.isfinite(want).all() and float(want.abs().max()) > 1e-3
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert torch.equal(again, got)
+
+
 def test_chain_entry_point_refuses_what_it_cannot_tile():
     from diffsinger_amd.vocoder import DsvChainConv
     lib = _lib.load()
