@@ -432,6 +432,29 @@ def test_default_launch_forms_on_other_configs_equal_the_unfused_generator(dils,
     assert torch.equal(again, got)
 
 
+@pytest.mark.parametrize('stage', [0, 1, 2, 3])
+def test_default_launch_forms_at_the_bench_shape(stage, chain_default):
+    """8 x 1024 mel frames (bench.py --row vocoder): the stage's resblocks in the default form - several ROUNDS of co-resident workgroups per
+    launch, the merged grid's groups meeting in the middle of a round (stage 0: three convolutions per launch) - against one launch per
+    convolution.  The small cases above never fill the chip once."""
+    case = dict(nsf=False, B=2, T=8, seed=7)
+    h, p, m = _generator(case)
+    m(torch.zeros(1, 80, 4, device=DEV))
+    C = 128 >> (stage + 1)
+    L = 1024 * [8, 64, 128, 256][stage]
+    g = torch.Generator(device=DEV).manual_seed(stage)
+    x = torch.zeros(8, C, padded_samples(L), device=DEV)
+    x[:, :, :L] = torch.randn(8, C, L, generator=g, device=DEV)
+    chain_default.set_chain_mode('off')
+    want = m._stage_resblocks(stage, x, L)
+    chain_default.set_chain_mode(None)
+    if stage:
+        assert m._merge_plan_for(stage, m._chain_prep(stage), 8, L) is not None          # the bench shape IS merged
+    got = m._stage_resblocks(stage, x, L)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
 def test_chain_entry_point_refuses_what_it_cannot_tile():
     from diffsinger_amd.vocoder import DsvChainConv
     lib = _lib.load()
