@@ -87,7 +87,18 @@ def from_db(root, kern):
     return acc, dur
 
 
-def provenance(kern, tag=None):
+def observed_kernels(root, kern):
+    """The kernel names (as rocprofv3 wrote them) of the dispatches the counters were averaged over."""
+    names = set()
+    for path in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
+        with open(path, newline='') as f:
+            for row in csv.DictReader(f):
+                if kern in row.get('Kernel_Name', ''):
+                    names.add(row['Kernel_Name'])
+    return names
+
+
+def provenance(kern, tag=None, observed=()):
     """Which binary the counters belong to: the build id of the library in this tree (dsd_build_id: sha256 of csrc/ + include/) and the hash
     of THE KERNEL'S device code (diffsinger_amd/kernel_isa.json, written by the build) - bench.py refuses a summary that matches neither the
     library it has loaded nor that kernel in it."""
@@ -100,6 +111,14 @@ def provenance(kern, tag=None):
         # parentheses) names the one that ran - r6_16's loop_pmc.json went unstamped without this and the next rebuild orphaned it
         t = tag.split(' (')[0]
         hits = {n: h for n, h in hits.items() if n.startswith(t)}
+    if len(hits) > 1 and observed:
+        # 'k_voc_chain<32' names three instantiations (two tiles / one tile in place / merged groups); the one that RAN is in the counter csv
+        # (round 6: the merged chain launches went unstamped and any later rebuild would have orphaned their PMC figures)
+        norm = lambda x: x.replace('void ', '').replace('dsd::', '').replace(' ', '')
+        obs = {norm(o) for o in observed}
+        ran = {n: h for n, h in hits.items() if any(norm(n).split('(')[0] in o for o in obs)}
+        if ran:
+            hits = ran
     if len(hits) == 1:
         (out['kernel_isa_name'], out['kernel_isa']), = hits.items()
     return out
@@ -129,7 +148,7 @@ def main(root, kern, out_txt, out_json, *extras):
     for kv in extras:                       # e.g. frames=8192 kernel_tag='k_layer<1,false>' round=r01b
         k, v = kv.split('=', 1)
         js[k] = int(v) if v.isdigit() else v
-    js.update(provenance(kern, js.get('kernel_tag') if isinstance(js.get('kernel_tag'), str) else None))
+    js.update(provenance(kern, js.get('kernel_tag') if isinstance(js.get('kernel_tag'), str) else None, observed_kernels(root, kern) if src == 'csv' else ()))
     if min_us > 0:
         lines.insert(1, f'# only dispatches of at least {min_us:g} us (one shape of the kernel)')
     if 'FETCH_SIZE' in avg and 'WRITE_SIZE' in avg:
