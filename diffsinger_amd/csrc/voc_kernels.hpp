@@ -82,94 +82,13 @@ struct VocTapB {
 
 __device__ __forceinline__ float voc_lrelu(float v, float slope) { return (v > 0.f) ? v : v * slope; }
 
-// Workgroup = WR = 4 / WT row blocks of 32 x (WT * NB * 32) samples of one utterance.  Wave w: row block (w % WR), time part (w / WR).
-template <int NB, int WT, int HALO>
-__device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
-    constexpr int LD = voc_ld<NB, WT, HALO>(), SPAN = voc_span<NB, WT>(), SLAB = voc_slab<NB, WT, HALO>(), WR = 4 / WT;
-    constexpr int NCOL4 = LD / 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // [SLAB][LD]
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w % WR, wt = w / WR;
-    const int t0 = blockIdx.x * SPAN, b = blockIdx.y;
-    const int rb = bz * WR + wr;                                     // this wave's 32-row block
-    const int nrb = (p.rows + 31) / 32;
-    const int rbc = (rb < nrb) ? rb : nrb - 1;                       // waves past the last block walk valid memory and store nothing
-    const int ci8 = (p.Ci + 7) / 8;
-    const int nchunk_total = ci8 * p.KT;
-    f32x16 acc[1][NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
-    const float* inb = p.in + (size_t)b * p.Ci * p.LSi;
-    const float slope = p.pre_slope;
-    // A plain convolution's residual / running-sum operands (the second convolution of every ResBlock1 pair) are requested HERE, in front of
-    // the weight prefetch and the staging loads (round 6): their round trip to memory ran behind the contraction, with nothing to hide under.
-    // Only for the narrow tiles (NB <= 2: 16 NB registers per operand).
-    constexpr bool PRE = (NB <= 2);
-    float rpre[PRE ? NB : 1][16], spre[PRE ? NB : 1][16];
-    const bool pre = PRE && p.U == 1 && rb < nrb && (p.res || p.sum_in);
-    if constexpr (PRE) {
-        if (pre) {
-            const int qp = t0 + wt * (32 * NB) + j;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rb * 32 + frag_row(r, h), n = qp + 32 * nb;
-                    const bool ok = row < p.rows && n < p.LSo;
-                    const size_t o = ((size_t)b * p.rows + (ok ? row : 0)) * p.LSo + (ok ? n : 0);
-                    rpre[nb][r] = p.res ? p.res[o] : 0.f;
-                    spre[nb][r] = p.sum_in ? p.sum_in[o] : 0.f;
-                }
-        }
-    }
-    for (int c0 = 0; c0 < p.Ci; c0 += SLAB) {
-        const int nc = min(SLAB, p.Ci - c0);
-        const int nc8 = (nc + 7) / 8 * 8;                            // rows [nc, nc8) are staged as zeros (their weights are zero too)
-        // stage channels [c0, c0 + nc) x samples [t0 - halo, t0 + SPAN + halo), zero outside [0, LSi), leaky_relu applied here
-        // (eight loads per thread in flight before the first LDS write: a load -> write -> load chain pays the memory latency once per float4 -
-        // 12 round trips for a 64-channel slab, ~16 us of every launch of the 64-channel stage in rounds 2-5, profiles/r57_vocoder_kernel_stats.txt)
-        const int nstage = nc8 * NCOL4;
-        // the weight stream depends on nothing the kernel computes: its first chunks are requested in FRONT of the staging loads (round 6; vector
-        // memory returns in order - the staging wait covers them - and their L2 / Infinity-Cache latency, ~1.5 us of every launch, leaves the
-        // critical path)
-        const int nch = (nc8 / 8) * p.KT;
-        const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
-        VocTapB<LD> bof(smem + 4 * h * LD + HALO + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch);
-        GemmPipe<1, NB, LD, 64, 6, VocTapB<LD>, 1, false, true> pipe(ap, lane, nch, bof);
-        pipe.start_a();
-        for (int i0 = 0; i0 < nstage; i0 += kVocStageBatch * kThreads) {
-            float4 sv[kVocStageBatch];
-#pragma unroll
-            for (int i = 0; i < kVocStageBatch; ++i) {
-                const int idx = i0 + i * kThreads + tid;
-                const int row = idx / NCOL4, g = idx - row * NCOL4;
-                const int t = t0 - HALO + 4 * g;
-                const bool ok = idx < nstage && row < nc && t >= 0 && t < p.LSi;
-                const float4 v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + (ok ? row : 0)) * p.LSi + (ok ? t : 0));
-                sv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            DSD_SB();
-#pragma unroll
-            for (int i = 0; i < kVocStageBatch; ++i) {
-                const int idx = i0 + i * kThreads + tid;
-                const int row = idx / NCOL4, g = idx - row * NCOL4;
-                float4 v = sv[i];
-                v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
-                if (idx < nstage) *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
-            }
-            DSD_SB();
-        }
-        __syncthreads();
-        pipe.start_b();
-        pipe.run_blocks(acc, nch);
-        __syncthreads();
-    }
-    if (rb >= nrb) return;
+// The fused tail of a convolution: bias, residual, running sum, divisor, tanh, zero beyond L, in the store form of its phase count
+// (voc_conv_body and the pipelined kernel of voc_pipe.hpp share it).  acc: this wave's 32 rows x NB 32-sample blocks; q0: input-rate sample of
+// column j of block 0; rpre / spre: a plain convolution's residual / running-sum operands if they were requested in front of the contraction.
+template <int NB, bool PRE>
+__device__ __forceinline__ void voc_conv_epilogue(const VocConvParams& p, f32x16 (&acc)[1][NB], int rb, int b, int q0, int h, bool pre,
+                                                  const float (&rpre)[PRE ? NB : 1][16], const float (&spre)[PRE ? NB : 1][16]) {
     const int U = p.U, Co = p.rows / U;
-    const int q0 = t0 + wt * (32 * NB) + j;                          // input-rate sample index of frame block 0
     if ((U & 3) == 0) {
         // rows 8 rg + 4 h + (0..3) of this lane are 4 consecutive phases of ONE output channel: 16-byte accesses
 #pragma unroll
@@ -269,6 +188,96 @@ __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
             if (ok) p.out[((size_t)b * Co + cov[r]) * p.LSo + n] = (n < p.Lo) ? v : 0.f;
         }
     }
+}
+
+// Workgroup = WR = 4 / WT row blocks of 32 x (WT * NB * 32) samples of one utterance.  Wave w: row block (w % WR), time part (w / WR).
+template <int NB, int WT, int HALO>
+__device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
+    constexpr int LD = voc_ld<NB, WT, HALO>(), SPAN = voc_span<NB, WT>(), SLAB = voc_slab<NB, WT, HALO>(), WR = 4 / WT;
+    constexpr int NCOL4 = LD / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [SLAB][LD]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w % WR, wt = w / WR;
+    const int t0 = blockIdx.x * SPAN, b = blockIdx.y;
+    const int rb = bz * WR + wr;                                     // this wave's 32-row block
+    const int nrb = (p.rows + 31) / 32;
+    const int rbc = (rb < nrb) ? rb : nrb - 1;                       // waves past the last block walk valid memory and store nothing
+    const int ci8 = (p.Ci + 7) / 8;
+    const int nchunk_total = ci8 * p.KT;
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+    const float* inb = p.in + (size_t)b * p.Ci * p.LSi;
+    const float slope = p.pre_slope;
+    // A plain convolution's residual / running-sum operands (the second convolution of every ResBlock1 pair) are requested HERE, in front of
+    // the weight prefetch and the staging loads (round 6): their round trip to memory ran behind the contraction, with nothing to hide under.
+    // Only for the narrow tiles (NB <= 2: 16 NB registers per operand).
+    constexpr bool PRE = (NB <= 2);
+    float rpre[PRE ? NB : 1][16], spre[PRE ? NB : 1][16];
+    const bool pre = PRE && p.U == 1 && rb < nrb && (p.res || p.sum_in);
+    if constexpr (PRE) {
+        if (pre) {
+            const int qp = t0 + wt * (32 * NB) + j;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb * 32 + frag_row(r, h), n = qp + 32 * nb;
+                    const bool ok = row < p.rows && n < p.LSo;
+                    const size_t o = ((size_t)b * p.rows + (ok ? row : 0)) * p.LSo + (ok ? n : 0);
+                    rpre[nb][r] = p.res ? p.res[o] : 0.f;
+                    spre[nb][r] = p.sum_in ? p.sum_in[o] : 0.f;
+                }
+        }
+    }
+    for (int c0 = 0; c0 < p.Ci; c0 += SLAB) {
+        const int nc = min(SLAB, p.Ci - c0);
+        const int nc8 = (nc + 7) / 8 * 8;                            // rows [nc, nc8) are staged as zeros (their weights are zero too)
+        // stage channels [c0, c0 + nc) x samples [t0 - halo, t0 + SPAN + halo), zero outside [0, LSi), leaky_relu applied here
+        // (eight loads per thread in flight before the first LDS write: a load -> write -> load chain pays the memory latency once per float4 -
+        // 12 round trips for a 64-channel slab, ~16 us of every launch of the 64-channel stage in rounds 2-5, profiles/r57_vocoder_kernel_stats.txt)
+        const int nstage = nc8 * NCOL4;
+        // the weight stream depends on nothing the kernel computes: its first chunks are requested in FRONT of the staging loads (round 6; vector
+        // memory returns in order - the staging wait covers them - and their L2 / Infinity-Cache latency, ~1.5 us of every launch, leaves the
+        // critical path)
+        const int nch = (nc8 / 8) * p.KT;
+        const float4* ap = p.wp + ((size_t)rbc * nchunk_total + (size_t)(c0 / 8) * p.KT) * 64;
+        VocTapB<LD> bof(smem + 4 * h * LD + HALO + wt * (32 * NB) + j - p.pad, p.KT, p.dil, nch);
+        GemmPipe<1, NB, LD, 64, 6, VocTapB<LD>, 1, false, true> pipe(ap, lane, nch, bof);
+        pipe.start_a();
+        for (int i0 = 0; i0 < nstage; i0 += kVocStageBatch * kThreads) {
+            float4 sv[kVocStageBatch];
+#pragma unroll
+            for (int i = 0; i < kVocStageBatch; ++i) {
+                const int idx = i0 + i * kThreads + tid;
+                const int row = idx / NCOL4, g = idx - row * NCOL4;
+                const int t = t0 - HALO + 4 * g;
+                const bool ok = idx < nstage && row < nc && t >= 0 && t < p.LSi;
+                const float4 v = *reinterpret_cast<const float4*>(inb + (size_t)(c0 + (ok ? row : 0)) * p.LSi + (ok ? t : 0));
+                sv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            DSD_SB();
+#pragma unroll
+            for (int i = 0; i < kVocStageBatch; ++i) {
+                const int idx = i0 + i * kThreads + tid;
+                const int row = idx / NCOL4, g = idx - row * NCOL4;
+                float4 v = sv[i];
+                v.x = voc_lrelu(v.x, slope); v.y = voc_lrelu(v.y, slope); v.z = voc_lrelu(v.z, slope); v.w = voc_lrelu(v.w, slope);
+                if (idx < nstage) *reinterpret_cast<float4*>(smem + row * LD + 4 * g) = v;
+            }
+            DSD_SB();
+        }
+        __syncthreads();
+        pipe.start_b();
+        pipe.run_blocks(acc, nch);
+        __syncthreads();
+    }
+    if (rb >= nrb) return;
+    const int q0 = t0 + wt * (32 * NB) + j;                          // input-rate sample index of frame block 0
+    voc_conv_epilogue<NB, PRE>(p, acc, rb, b, q0, h, pre, rpre, spre);
 }
 
 template <int NB, int WT, int HALO = kVocHalo>
