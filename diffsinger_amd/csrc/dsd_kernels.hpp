@@ -219,29 +219,6 @@ struct GemmPipe {
         if (kc + 4 >= end) return;
         step<4>(acc, it);
     }
-    // run_blocks in pieces (round 6, voc_pipe.hpp): ONE whole group of six chunks as a basic block - the caller issues unrelated loads between two
-    // groups without draining the pipeline - and the rest of the stream from group it0 on.  run_group(0), run_group(1), run_from(2, end) walk
-    // the chunks exactly as run_blocks(end) does.
-    __device__ __forceinline__ void run_group(f32x16 (&acc)[NMB][NB], int it) {
-        step<0>(acc, it); step<1>(acc, it); step<2>(acc, it); step<3>(acc, it); step<4>(acc, it); step<5>(acc, it);
-    }
-    __device__ __forceinline__ void run_from(f32x16 (&acc)[NMB][NB], int it0, int end) {
-        int it = it0;
-        for (; 6 * it + 6 <= end; ++it) {
-            step<0>(acc, it); step<1>(acc, it); step<2>(acc, it); step<3>(acc, it); step<4>(acc, it); step<5>(acc, it);
-        }
-        const int kc = 6 * it;
-        if (kc >= end) return;
-        step<0>(acc, it);
-        if (kc + 1 >= end) return;
-        step<1>(acc, it);
-        if (kc + 2 >= end) return;
-        step<2>(acc, it);
-        if (kc + 3 >= end) return;
-        step<3>(acc, it);
-        if (kc + 4 >= end) return;
-        step<4>(acc, it);
-    }
 };
 
 // B functor of a plain [k][frame] LDS tile: chunk kc at base + kc * 8 rows (clamped: the prefetch of the chunk behind

@@ -2,7 +2,6 @@
 // the library stays one translation unit (shares the error string, the HIP_TRY macros and the operand-packing kernel).
 #include "voc_kernels.hpp"
 #include "voc_chain.hpp"
-#include "voc_pipe.hpp"
 #include "pwg_kernels.hpp"
 
 #include "../../include/dsv.h"
@@ -52,53 +51,6 @@ static void voc_conv_launch(const VocConvParams& p, int B, hipStream_t s) {
     hipLaunchKernelGGL((k_voc_conv<NB, WT, HALO>), grid, dim3(kThreads), lds, s, p);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// the persistent double-buffered form of the convolution launches (voc_pipe.hpp)
-// ------------------------------------------------------------------------------------------------------------
-static int voc_device_cus() {
-    static std::mutex mu;
-    static std::map<int, int> cus;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cus.find(dev);
-    if (it != cus.end()) return it->second;
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 1;
-    cus[dev] = n;
-    return n;
-}
-
-static int g_voc_pipe = 1;       // dsv_set_pipe: the A/B switch of the measurement
-extern "C" int dsv_set_pipe(int32_t on) { g_voc_pipe = on ? 1 : 0; return DSD_OK; }
-
-// Launches the `ngroups` convolutions g[] (one shape) on k_voc_conv_pipe if the shape qualifies: the whole channel slab fits one LDS slab,
-// and every CU gets at least two tiles (a single tile per workgroup has nothing to overlap: k_voc_conv's two co-resident workgroups are
-// the better form then).  Returns false (nothing launched) otherwise.
-template <int NB, int WT, int HALO>
-static bool voc_pipe_try(const VocConvParams* g, int ngroups, int B, hipStream_t s) {
-    static const int env_on = [] { const char* e = getenv("DSV_PIPE"); return e ? atoi(e) : 1; }();          // DSV_PIPE=0: the A/B of a whole process
-    if (!g_voc_pipe || !env_on) return false;
-    constexpr int WR = 4 / WT, SPAN = voc_span<NB, WT>();
-    const VocConvParams& p0 = g[0];
-    const int slab8 = (p0.Ci + 7) / 8 * 8;
-    if (slab8 > pipe_slab<NB, WT, HALO>() || (int64_t)p0.Ci * p0.LSi * 4 >= (int64_t)1 << 31) return false;
-    VocPipeParams m{};
-    m.ngroups = ngroups; m.B = B;
-    m.tiles = (p0.LSi + SPAN - 1) / SPAN;
-    m.zc = (p0.rows + 32 * WR - 1) / (32 * WR);
-    const int64_t per = (int64_t)m.tiles * B * m.zc;
-    const int ncu = voc_device_cus();
-    if (per * ngroups < 2 * (int64_t)ncu || per * ngroups > 0x7fffffff) return false;
-    m.per_group = (int)per; m.nitems = (int)(per * ngroups); m.slab8 = slab8;
-    for (int i = 0; i < ngroups; ++i) m.g[i] = g[i];
-    const int lds = 2 * slab8 * voc_ld<NB, WT, HALO>() * 4;
-    if (first_on_device(800 + 10 * NB + WT + 1000 * (HALO != kVocHalo)))
-        (void)hipFuncSetAttribute((const void*)k_voc_conv_pipe<NB, WT, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kVocPipeLds);
-    hipLaunchKernelGGL((k_voc_conv_pipe<NB, WT, HALO>), dim3((unsigned)std::min<int64_t>(m.nitems, ncu)), dim3(kThreads), (size_t)lds, s, m);
-    return true;
-}
-
 static int voc_conv_fill(VocConvParams& p, const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t rows, int32_t KT,
                          int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in, float divide,
                          int32_t act, const char* who) {
@@ -128,21 +80,19 @@ extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bi
     // staging halo is paid once per 32 NB samples (round 6: 4 096 workgroups of 2 us of matrix work each were 8 latency-bound rounds).
     // Same chunk order, same bits.
     const long tall_wgs = (long)((p.LSi + 127) / 128) * B * ((rows + 127) / 128);
-    hipStream_t st = (hipStream_t)stream;
-    // every tiling first tries its persistent double-buffered form (voc_pipe.hpp: same tiles, same chunk order, the same bits)
     if (!wide && rows > 64 && tall_wgs >= 512) {
-        if (!voc_pipe_try<4, 1, kVocHalo>(&p, 1, B, st)) voc_conv_launch<4, 1, kVocHalo>(p, B, st);
+        voc_conv_launch<4, 1, kVocHalo>(p, B, (hipStream_t)stream);
         HIP_TRY(hipGetLastError());
         return DSD_OK;
     }
     if (wide) {
-        if (rows <= 32) { if (!voc_pipe_try<4, 4, kVocHaloWide>(&p, 1, B, st)) voc_conv_launch<4, 4, kVocHaloWide>(p, B, st); }
-        else if (rows <= 64) { if (!voc_pipe_try<2, 2, kVocHaloWide>(&p, 1, B, st)) voc_conv_launch<2, 2, kVocHaloWide>(p, B, st); }
-        else if (!voc_pipe_try<1, 1, kVocHaloWide>(&p, 1, B, st)) voc_conv_launch<1, 1, kVocHaloWide>(p, B, st);
+        if (rows <= 32) voc_conv_launch<4, 4, kVocHaloWide>(p, B, (hipStream_t)stream);
+        else if (rows <= 64) voc_conv_launch<2, 2, kVocHaloWide>(p, B, (hipStream_t)stream);
+        else voc_conv_launch<1, 1, kVocHaloWide>(p, B, (hipStream_t)stream);
     } else {
-        if (rows <= 32) { if (!voc_pipe_try<4, 4, kVocHalo>(&p, 1, B, st)) voc_conv_launch<4, 4, kVocHalo>(p, B, st); }
-        else if (rows <= 64) { if (!voc_pipe_try<2, 2, kVocHalo>(&p, 1, B, st)) voc_conv_launch<2, 2, kVocHalo>(p, B, st); }
-        else if (!voc_pipe_try<1, 1, kVocHalo>(&p, 1, B, st)) voc_conv_launch<1, 1, kVocHalo>(p, B, st);
+        if (rows <= 32) voc_conv_launch<4, 4, kVocHalo>(p, B, (hipStream_t)stream);
+        else if (rows <= 64) voc_conv_launch<2, 2, kVocHalo>(p, B, (hipStream_t)stream);
+        else voc_conv_launch<1, 1, kVocHalo>(p, B, (hipStream_t)stream);
     }
     HIP_TRY(hipGetLastError());
     return DSD_OK;
@@ -178,12 +128,10 @@ extern "C" int dsv_conv1d_multi(int32_t ngroups, const dsv_conv_desc* d, int32_t
     hipStream_t st = (hipStream_t)stream;
     // the instantiation dsv_conv1d picks for this shape (same tiles, same chunk order: the same bits)
     const long tall_wgs = (long)((m.g[0].LSi + 127) / 128) * B * ((rows + 127) / 128);
-#define DSV_MULTI(NB_, WT_, H_) do { if (!voc_pipe_try<NB_, WT_, H_>(m.g, ngroups, B, st)) voc_conv_multi_launch<NB_, WT_, H_>(m, ngroups, B, st); } while (0)
-    if (!wide && rows > 64 && tall_wgs >= 512) { m.zc = (rows + 127) / 128; DSV_MULTI(4, 1, kVocHalo); }
-    else if (rows <= 32) { m.zc = 1; if (wide) DSV_MULTI(4, 4, kVocHaloWide); else DSV_MULTI(4, 4, kVocHalo); }
-    else if (rows <= 64) { m.zc = 1; if (wide) DSV_MULTI(2, 2, kVocHaloWide); else DSV_MULTI(2, 2, kVocHalo); }
-    else { m.zc = (rows + 127) / 128; if (wide) DSV_MULTI(1, 1, kVocHaloWide); else DSV_MULTI(1, 1, kVocHalo); }
-#undef DSV_MULTI
+    if (!wide && rows > 64 && tall_wgs >= 512) { m.zc = (rows + 127) / 128; voc_conv_multi_launch<4, 1, kVocHalo>(m, ngroups, B, st); }
+    else if (rows <= 32) { m.zc = 1; if (wide) voc_conv_multi_launch<4, 4, kVocHaloWide>(m, ngroups, B, st); else voc_conv_multi_launch<4, 4, kVocHalo>(m, ngroups, B, st); }
+    else if (rows <= 64) { m.zc = 1; if (wide) voc_conv_multi_launch<2, 2, kVocHaloWide>(m, ngroups, B, st); else voc_conv_multi_launch<2, 2, kVocHalo>(m, ngroups, B, st); }
+    else { m.zc = (rows + 127) / 128; if (wide) voc_conv_multi_launch<1, 1, kVocHaloWide>(m, ngroups, B, st); else voc_conv_multi_launch<1, 1, kVocHalo>(m, ngroups, B, st); }
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

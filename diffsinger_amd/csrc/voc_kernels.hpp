@@ -83,7 +83,7 @@ struct VocTapB {
 __device__ __forceinline__ float voc_lrelu(float v, float slope) { return (v > 0.f) ? v : v * slope; }
 
 // The fused tail of a convolution: bias, residual, running sum, divisor, tanh, zero beyond L, in the store form of its phase count
-// (voc_conv_body and the pipelined kernel of voc_pipe.hpp share it).  acc: this wave's 32 rows x NB 32-sample blocks; q0: input-rate sample of
+// (voc_conv_body; the persistent pipelined form measured in r6_36 / r6_37 shared it - git 4b97f88).  acc: this wave's 32 rows x NB 32-sample blocks; q0: input-rate sample of
 // column j of block 0; rpre / spre: a plain convolution's residual / running-sum operands if they were requested in front of the contraction.
 template <int NB, bool PRE>
 __device__ __forceinline__ void voc_conv_epilogue(const VocConvParams& p, f32x16 (&acc)[1][NB], int rb, int b, int q0, int h, bool pre,

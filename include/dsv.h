@@ -72,12 +72,6 @@ typedef struct dsv_conv_desc {
 int dsv_conv1d_multi(int32_t ngroups, const dsv_conv_desc* d, int32_t B, int32_t Ci, int32_t rows, int32_t L_in, int32_t up, float pre_slope,
                      void* stream);
 
-/* A/B switch of the measurement (round 6): dsv_conv1d / dsv_conv1d_multi launches whose every CU gets at least two tiles run as a PERSISTENT,
- * double-buffered pipeline (csrc/voc_pipe.hpp: one workgroup per CU, the next tile's staging loads in flight under the contraction of the
- * current one, its stores under the next) - the same tiles, the same chunk order, the same bits; 0 = always the one-tile-per-workgroup kernel.
- * Process-wide, not thread-safe. */
-int dsv_set_pipe(int32_t on);
-
 /* The same convolution (up = 1, 'same' padding pad = (K-1) * dil / 2, K odd) for the NARROW layers, Co <= 16 - the 16- and 8-channel
  * resblocks and conv_post of the shipped generator: F output samples are folded into the 32 MFMA rows so that no row multiplies
  * zeros.  dsv_fold_factor returns the F the library wants for such a layer (4: Co <= 8, 2: Co <= 16, 1: use dsv_conv1d; also 1

@@ -329,60 +329,6 @@ def test_conv1d_multi_is_bit_identical_to_the_single_launches(C, L):
     torch.cuda.synchronize()
 
 
-PIPE_CASES = [
-    dict(ci=64, rows=64, k=7, dil=3, L=8192, B=8, res=True, acc=True, div=3.0),     # the 64-channel resblock convolution: 512 tiles of <2,2>
-    dict(ci=64, rows=64, k=11, dil=5, L=8100, B=9, res=True),                       # ragged: a partial last tile, 9 utterances on 256 CUs
-    dict(ci=64, rows=64, k=3, dil=1, L=16384, B=4),                                 # 24 chunks: the three-gap form at its shortest
-    dict(ci=64, rows=256, k=2, dil=1, L=8192, B=8, up=8),                           # the 64 -> 32 upsampling (polyphase, 16-byte stores): <4,1>
-    dict(ci=32, rows=32, k=2, dil=1, L=65536, B=4, up=2),                           # the 32 -> 16 upsampling (8-byte stores): <4,4>, 16 chunks... the short form
-    dict(ci=16, rows=16, k=2, dil=1, L=65536, B=8, up=2),                           # half the rows of the block empty
-    dict(ci=128, rows=512, k=2, dil=1, L=1024, B=8, up=8),                          # the 128 -> 64 upsampling: <1,1>, four row-block groups
-    dict(ci=64, rows=64, k=9, dil=12, L=8192, B=8, res=True),                       # the wide-window instantiation
-]
-
-
-@pytest.mark.parametrize('c', PIPE_CASES, ids=lambda c: f"ci{c['ci']}r{c['rows']}k{c['k']}d{c['dil']}L{c['L']}B{c['B']}")
-def test_pipelined_convolution_is_bit_identical_to_the_one_tile_kernel(c):
-    """csrc/voc_pipe.hpp (round 6): launches whose every CU gets at least two tiles run as a persistent double-buffered pipeline - the same
-    tiles, chunk order and fused tail as k_voc_conv: the same BITS, on every tiling, with every store form, ragged lengths and batch sizes
-    that do not divide the CUs; dsv_set_pipe(0) is the reference.  Then three convolutions in one dsv_conv1d_multi call."""
-    lib = _lib.load()
-    ops = _HipOps()
-    g = torch.Generator(device=DEV).manual_seed(c['ci'] + c['L'])
-    B, L, ci, rows, k, dil, up = c['B'], c['L'], c['ci'], c['rows'], c['k'], c['dil'], c.get('up', 1)
-    w = torch.randn(rows, ci, k, generator=g, device=DEV) / (ci * k) ** 0.5
-    bias = torch.randn(rows // up, generator=g, device=DEV)
-    x = torch.zeros(B, ci, padded_samples(L), device=DEV)
-    x[:, :, :L] = torch.randn(B, ci, L, generator=g, device=DEV)
-    mk = lambda: torch.cat([torch.randn(B, rows // up, L * up, generator=g, device=DEV), torch.zeros(B, rows // up, padded_samples(L * up) - L * up, device=DEV)], 2)
-    res = mk() if c.get('res') else None
-    acc = mk() if c.get('acc') else None
-    pad = (k - 1) * dil // 2 if up == 1 else 0
-    if up > 1:
-        pad = 1                                                                     # polyphase form: taps q + t - 1 (diffsinger_amd.vocoder.polyphase_weight)
-    wp = ops.pack(w)
-    kw = dict(up=up, pre_slope=0.1, residual=res, sum_in=acc, divide=c.get('div', 1.0))
-    try:
-        assert lib.dsv_set_pipe(0) == 0
-        want = ops.conv(x, L, wp, bias, rows, ci, k, pad, dil, **kw)
-        assert lib.dsv_set_pipe(1) == 0
-        got = ops.conv(x, L, wp, bias, rows, ci, k, pad, dil, **kw)
-        again = ops.conv(x, L, wp, bias, rows, ci, k, pad, dil, **kw)
-        if up == 1:
-            items = [dict(wp=wp, bias=bias, rows=rows, ci=ci, k=k, pad=pad, dil=dil, residual=res), dict(wp=wp, bias=bias, rows=rows, ci=ci, k=k, pad=pad, dil=dil),
-                     dict(wp=wp, bias=bias, rows=rows, ci=ci, k=k, pad=pad, dil=dil, residual=res, sum_in=acc, divide=c.get('div', 1.0))]
-            multi = ops.conv_multi([x, x, x], L, items, pre_slope=0.1)
-        torch.cuda.synchronize()
-    finally:
-        lib.dsv_set_pipe(1)
-    assert torch.isfinite(want).all() and float(want.abs().max()) > 0.1
-    assert torch.equal(got, want), float((got - want).abs().max())
-    assert torch.equal(again, got)
-    if up == 1:
-        assert torch.equal(multi[2], want)
-        assert torch.equal(multi[0], ops.conv(x, L, wp, bias, rows, ci, k, pad, dil, pre_slope=0.1, residual=res))
-
-
 def test_merged_chain_entry_points_contract_and_plan():
     """dsv_resblock_chain_multi / dsv_resblock_chain_sum (include/dsv.h): argument checks, and the host model that picks the split
     (diffsinger_amd.vocoder._merge_plan) on the bench shape - 1 096 / 1 264 / 1 368 workgroups of kernel 3 / 7 / 11 on 512 slots: kernel 11 and

@@ -103,13 +103,6 @@ probes)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/hbm_probe tools/hbm_probe.hip && timeout 120 /tmp/hbm_probe > $O/hbm_probe.txt 2>&1
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_filler_probe tools/mfma_filler_probe.hip && timeout 180 /tmp/mfma_filler_probe > $O/mfma_filler_probe.jsonl 2>&1
     tail -8 $O/mfma_probe4.txt; tail -4 $O/hbm_probe.txt ;;
-pipeab)    # the persistent double-buffered convolution (csrc/voc_pipe.hpp) against the one-tile kernel, per (kernel, grid)
-    for on in 1 0; do
-        ( cd /tmp && DSV_PIPE=$on timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_pipe$on -o t -- python $R/bench.py --row vocoder --steps 5 --warmup 2 --no-cpu-baseline > $O/trace_pipe$on.log 2>&1 )
-        python tools/trace_by_grid.py $O/trace_pipe$on k_voc > $O/voc_by_grid_pipe$on.txt 2>> $O/trace_pipe$on.log
-        rm -rf $O/trace_pipe$on
-    done
-    head -30 $O/voc_by_grid_pipe1.txt | cut -c1-140; head -30 $O/voc_by_grid_pipe0.txt | cut -c1-140 ;;
 *) echo "unknown section $sec" ;;
 esac; done
 du -sh $O
