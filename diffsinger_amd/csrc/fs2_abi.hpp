@@ -310,6 +310,38 @@ extern "C" int dsf_sum_embed(const float* dec, const int64_t* idx1, const float*
     return DSD_OK;
 }
 
+extern "C" int dsf_token_masks(const int64_t* v, float* gt0, uint8_t* eq0, float* ne0, int64_t n, void* stream) {
+    if (!v || (!gt0 && !eq0 && !ne0) || n < 1 || n > ((int64_t)1 << 38)) return fail(DSD_ERR_INVALID, "dsf_token_masks: bad argument (v, one output at least, n=%lld)", (long long)n);
+    FsTokMaskParams p{};
+    p.v = (const long long*)v; p.gt0 = gt0; p.eq0 = eq0; p.ne0 = ne0; p.n = n;
+    hipLaunchKernelGGL(k_fs_token_masks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_pitch_coarse(const float* f0, int64_t stride_b, int64_t stride_t, const float* uv_f, const uint8_t* uv_u8, const int64_t* mel2ph,
+                                float* f0_denorm, float* tmp, int64_t* coarse, int32_t B, int32_t T, int32_t norm, float f0_mean, float f0_std,
+                                double f0_mel_min, double f0_mel_max, int32_t f0_bin, int32_t stage, int32_t pow_in, void* stream) {
+    if (!f0 || B < 1 || T < 1 || norm < 1 || norm > 2 || stage < 0 || stage > 2 || (uv_f && uv_u8) || f0_bin < 3 || !(f0_mel_max > f0_mel_min))
+        return fail(DSD_ERR_INVALID, "dsf_pitch_coarse: bad argument (B=%d T=%d norm=%d stage=%d f0_bin=%d)", B, T, norm, stage, f0_bin);
+    if ((stage != 2 && !f0_denorm) || (stage != 0 && !tmp) || (stage != 1 && !coarse) || (pow_in && norm != 2))
+        return fail(DSD_ERR_INVALID, "dsf_pitch_coarse: stage %d needs f0_denorm (0, 1), tmp (1, 2), coarse (0, 2); pow_in only with norm 2", stage);
+    FsPitchParams p{};
+    p.f0 = f0; p.sb = stride_b; p.st = stride_t; p.uv_f = uv_f; p.uv_u8 = uv_u8; p.mel2ph = (const long long*)mel2ph;
+    p.f0_denorm = f0_denorm; p.tmp = tmp; p.coarse = (long long*)coarse; p.T = T; p.norm = norm; p.stage = stage; p.pow_in = pow_in ? 1 : 0;
+    p.n = (long long)B * T;
+    p.base = 2.0f; p.mean = f0_mean; p.std = f0_std;
+    // the scalars as ATen's kernels see them: a Python / numpy double narrowed to the tensor's fp32, the divisor as its fp32 reciprocal
+    p.inv700 = 1.0f / 700.0f;
+    p.mel_min = (float)f0_mel_min;
+    p.scale = (float)(f0_bin - 2);
+    p.inv_range = 1.0f / (float)(f0_mel_max - f0_mel_min);
+    p.top = (float)(f0_bin - 1);
+    hipLaunchKernelGGL(k_fs_pitch_coarse, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
 extern "C" int dsf_from_channel_major(const float* in, float* out, int32_t B, int32_t C, int32_t T, void* stream) {
     if (!in || !out || B < 1 || C < 1 || T < 1) return fail(DSD_ERR_INVALID, "dsf_from_channel_major: bad argument");
     const int TS = fs_ts(T);

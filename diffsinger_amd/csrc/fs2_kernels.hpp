@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void k_fs_ln(const FsLnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Index / mask glue of the forward as FOUR kernels (round 6; rounds 1-5 left it to ~110 torch launches = 0.5 ms of a 3.2 ms forward:
+// Index / mask glue of the forward as FOUR kernels (+ two more further down: k_fs_token_masks, k_fs_pitch_coarse) (round 6; rounds 1-5 left it to ~110 torch launches = 0.5 ms of a 3.2 ms forward:
 // profiles/r6_05_fs2_kernel_stats.txt).  Every value is the one the torch ops produce: the same operations in the same order, one
 // rounding each (the library is built with -ffp-contract=off); positions, indices and masks are integers.
 //   k_fs_positions   utils/__init__.py:145-157 make_positions: pos = cumsum(x != pad) * (x != pad) + pad along the frame axis, for a token
@@ -509,6 +509,83 @@ __global__ __launch_bounds__(256) void k_fs_sum_embed(const FsSumEmbedParams p) 
             *reinterpret_cast<float4*>(p.out + o) = v;
         }
     }
+}
+
+// The rest of the forward's glue (round 6, second half: profiles/r6_39_fs2_glue_trace.txt - 35 torch launches of 2-6 us were left between
+// the encoder and the decoder, 22 of them the pitch quantisation):
+//   k_fs_token_masks   the masks every stage derives from an int64 index tensor: (v > 0).float() (fs2.py:98, :127), v == 0 (fs2.py:157, :199)
+//                      and (~(v == 0)).float() (DurationPredictor.forward, tts_modules.py:109-118) in one pass
+//   k_fs_pitch_coarse  utils/pitch_utils.py:64-77 denorm_f0 (pitch_norm 'standard' / 'log', the uv and padding masks) followed by
+//                      utils/pitch_utils.py:21-30 f0_to_coarse, every operation as the torch elementwise kernels evaluate it: one fp32 rounding
+//                      per operation in the reference's order, a division by a Python scalar as the multiplication by its fp32 reciprocal
+//                      (ATen div_true_kernel_cuda), pow / log through the device library (__ocml_pow_f32 / __ocml_log_f32, the functions ATen's
+//                      pow_tensor_tensor_kernel and log_kernel_cuda call).  stage 1 / 2 split the kernel around the logarithm and pow_in takes the
+//                      power from the caller: the forms the host falls back to if a torch build's device library ever rounds differently
+//                      (tests/test_gpu_fs2.py compares every float of the working range).
+struct FsTokMaskParams {
+    const long long* v;     // [n] int64
+    float* gt0;             // [n] (v > 0) as float, or nullptr
+    unsigned char* eq0;     // [n] (v == 0), or nullptr
+    float* ne0;             // [n] (v != 0) as float, or nullptr
+    long long n;
+};
+
+__global__ __launch_bounds__(256) void k_fs_token_masks(const FsTokMaskParams p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const long long v = p.v[i];
+    if (p.gt0) p.gt0[i] = (v > 0) ? 1.f : 0.f;
+    if (p.eq0) p.eq0[i] = (v == 0) ? 1 : 0;
+    if (p.ne0) p.ne0[i] = (v == 0) ? 0.f : 1.f;
+}
+
+struct FsPitchParams {
+    const float* f0;                // [B][T] through (sb, st) element strides: normalised f0 (pow_in: the caller's 2 ** f0, contiguous)
+    long long sb, st;
+    const float* uv_f;              // [B][T] float (uv > 0 = unvoiced) or nullptr
+    const unsigned char* uv_u8;     // [B][T] bool / u8 or nullptr
+    const long long* mel2ph;        // [B][T]: frames with mel2ph == 0 are padding, or nullptr
+    float* f0_denorm;               // [B][T] out (stage 0 / 1)
+    float* tmp;                     // [B][T]: 1 + f0_denorm / 700 (stage 1: out; stage 2: its logarithm, in)
+    long long* coarse;              // [B][T] out (stage 0 / 2)
+    int T, norm, stage, pow_in;     // norm: 1 standard, 2 log
+    long long n;
+    float base, mean, std;          // 2 (a run-time value: the generic path of the device library's pow, as ATen runs it)
+    float inv700, mel_min, scale, inv_range, top;
+};
+
+__global__ __launch_bounds__(256) void k_fs_pitch_coarse(const FsPitchParams p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    float c;
+    if (p.stage != 2) {
+        const long long b = i / p.T, t = i - b * p.T;
+        const float x = p.f0[b * p.sb + t * p.st];
+        float d = x;
+        if (p.norm == 1) { d = x * p.std; d = d + p.mean; }
+        else if (!p.pow_in) d = powf(p.base, x);
+        bool z = false;
+        if (p.uv_f) z = p.uv_f[i] > 0.f;
+        if (p.uv_u8) z = z || (p.uv_u8[i] != 0);
+        if (p.mel2ph) z = z || (p.mel2ph[i] == 0);
+        if (z) d = 0.f;
+        p.f0_denorm[i] = d;
+        float a = d * p.inv700;
+        a = a + 1.0f;
+        if (p.stage == 1) { p.tmp[i] = a; return; }
+        c = logf(a);
+    } else {
+        c = p.tmp[i];
+    }
+    float m = c * 1127.0f;
+    float v = m - p.mel_min;
+    v = v * p.scale;
+    v = v * p.inv_range;
+    v = v + 1.0f;
+    m = (m > 0.f) ? v : m;
+    m = (m <= 1.0f) ? 1.0f : m;
+    m = (m > p.top) ? p.top : m;
+    p.coarse[i] = (long long)(m + 0.5f);
 }
 
 // ------------------------------------------------------------------------------------------------------------

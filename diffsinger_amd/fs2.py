@@ -266,6 +266,64 @@ def sum_embed_op(dec: torch.Tensor, mel2ph: torch.Tensor, *, idx1=None, tab1=Non
     return out
 
 
+def token_masks_op(v: torch.Tensor, *, gt0=False, eq0=False, ne0=False):
+    """dsf_token_masks on an int64 index tensor (txt_tokens, mel2ph): ((v > 0).float(), v == 0 [bool], (~(v == 0)).float()), None where not asked for."""
+    v = v.contiguous()
+    o_gt = torch.empty(v.shape, device=v.device, dtype=torch.float32) if gt0 else None
+    o_eq = torch.empty(v.shape, device=v.device, dtype=torch.bool) if eq0 else None
+    o_ne = torch.empty(v.shape, device=v.device, dtype=torch.float32) if ne0 else None
+    p = lambda t: t.data_ptr() if t is not None else None
+    with torch.cuda.device(v.device):
+        _lib.check(_lib.load().dsf_token_masks(v.data_ptr(), p(o_gt), p(o_eq), p(o_ne), v.numel(), _stream(v.device)), 'dsf_token_masks')
+    return o_gt, o_eq, o_ne
+
+
+# How much of the pitch quantisation runs inside dsf_pitch_coarse: the device library's pow / log (the functions ATen's kernels call; compared over
+# every float of the working range in tests/test_gpu_fs2.py) or, switched off, torch's own kernels around the split stages of the operator.
+_PITCH_NATIVE = {'pow': True, 'log': True}
+
+
+def set_pitch_native(pow: bool = True, log: bool = True):
+    _PITCH_NATIVE['pow'], _PITCH_NATIVE['log'] = bool(pow), bool(log)
+
+
+def _pitch_fusable(f0, uv, hp) -> bool:
+    return (_glue_ok(f0, uv) and torch.is_tensor(f0) and f0.dtype == torch.float32 and f0.dim() == 2 and hp['pitch_norm'] in ('standard', 'log')
+            and (uv is None or not hp['use_uv'] or (uv.shape == f0.shape and uv.dtype in (torch.float32, torch.bool, torch.uint8))))
+
+
+def pitch_coarse_op(f0: torch.Tensor, uv, mel2ph, hp):
+    """denorm_f0 + f0_to_coarse (utils/pitch_utils.py:64-77, :21-30) of f0 [B,T] (any strides) as ONE launch: (f0_denorm float [B,T], coarse int64 [B,T]).
+    uv: float / bool [B,T] or None; mel2ph: int64 [B,T] whose zeros are padding frames, or None."""
+    B, T = f0.shape
+    dev = f0.device
+    norm = 1 if hp['pitch_norm'] == 'standard' else 2
+    native_pow = _PITCH_NATIVE['pow'] or norm == 1
+    src = f0 if native_pow else (2 ** f0).contiguous()
+    uv = uv if (uv is not None and hp['use_uv']) else None
+    uv_f = uv.contiguous() if (uv is not None and uv.dtype == torch.float32) else None
+    uv_b = uv.contiguous() if (uv is not None and uv.dtype != torch.float32) else None
+    m2p = mel2ph.contiguous() if mel2ph is not None else None
+    den = torch.empty(B, T, device=dev, dtype=torch.float32)
+    coarse = torch.empty(B, T, device=dev, dtype=torch.int64)
+    tmp = None if _PITCH_NATIVE['log'] else torch.empty(B, T, device=dev, dtype=torch.float32)
+    p = lambda t: t.data_ptr() if t is not None else None
+    mean, std = (float(hp['f0_mean']), float(hp['f0_std'])) if norm == 1 else (0.0, 1.0)
+    lib = _lib.load()
+
+    def run(stage):
+        _lib.check(lib.dsf_pitch_coarse(src.data_ptr(), src.stride(0), src.stride(1), p(uv_f), p(uv_b), p(m2p), den.data_ptr(), p(tmp), coarse.data_ptr(), B, T,
+                                        norm, mean, std, float(f0_mel_min), float(f0_mel_max), f0_bin, stage, int(not native_pow), _stream(dev)), 'dsf_pitch_coarse')
+    with torch.cuda.device(dev):
+        if tmp is None:
+            run(0)
+        else:
+            run(1)
+            tmp.log_()
+            run(2)
+    return den, coarse
+
+
 def _needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
@@ -667,10 +725,10 @@ class DurationPredictor(nn.Module):
         self._packs = [PackedWeight() for _ in range(n_layers)]
         self._plin = PackedWeight()
 
-    def _forward(self, xs, x_masks, is_inference):
-        """tts_modules.py:107-120.  xs [B,T,idim]; x_masks [B,T] bool (True = pad)."""
+    def _forward(self, xs, x_masks, is_inference, keep=None):
+        """tts_modules.py:107-120.  xs [B,T,idim]; x_masks [B,T] bool (True = pad); keep: (~x_masks).float() if the caller has it (dsf_token_masks)."""
         T = xs.shape[1]
-        keep = (~x_masks).float().contiguous()
+        keep = (~x_masks).float().contiguous() if keep is None else keep
         xc = _run_pred_convs(self.conv, self._packs, to_cm(xs), T, keep)
         y = from_cm(conv1d_cm(xc, T, self.linear.weight, self._plin, self.linear.bias, keep=keep), T)        # [B,T,1]
         if is_inference:
@@ -678,11 +736,11 @@ class DurationPredictor(nn.Module):
             return dur, y
         return y.squeeze(-1)
 
-    def forward(self, xs, x_masks=None):
-        return self._forward(xs, x_masks, False)
+    def forward(self, xs, x_masks=None, keep=None):
+        return self._forward(xs, x_masks, False, keep)
 
-    def inference(self, xs, x_masks=None):
-        return self._forward(xs, x_masks, True)
+    def inference(self, xs, x_masks=None, keep=None):
+        return self._forward(xs, x_masks, True, keep)
 
 
 class LengthRegulator(nn.Module):
@@ -861,19 +919,35 @@ class FastSpeech2(nn.Module):
                  spk_embed_f0_id=None, **kwargs):
         ret = {}
         encoder_out = self._encode(txt_tokens, **kwargs)                                        # [B,T_txt,H]
-        src_nonpadding = (txt_tokens > 0).float()[:, :, None]
         spk_dur, spk_f0, spk = self._speaker(spk_embed, spk_embed_dur_id, spk_embed_f0_id)
-        dur_inp = (encoder_out + spk_dur) * src_nonpadding
-        mel2ph = self.add_dur(dur_inp, mel2ph, txt_tokens, ret)
-        tgt_nonpadding = (mel2ph > 0).float()[:, :, None]
-        if _glue_ok(encoder_out, mel2ph) and mel2ph.dtype == torch.int64 and encoder_out.shape[-1] % 4 == 0:
+        glue = _glue_ok(encoder_out, txt_tokens) and txt_tokens.dtype == torch.int64 and encoder_out.dtype == torch.float32 and encoder_out.shape[-1] % 4 == 0
+        if glue:
+            # fs2.py:98-101 / :157 / tts_modules.py:109: the three masks of the phone axis in one launch, `(encoder_out + spk) * nonpadding` in one
+            # (dsf_sum_embed without tables computes exactly that) - seven torch launches before
+            enc_c, tok_c = encoder_out.contiguous(), txt_tokens.contiguous()
+            src_np, src_padding, src_keep = token_masks_op(tok_c, gt0=True, eq0=True, ne0=True)
+            src_nonpadding = src_np[:, :, None]
+            masked_enc = lambda s_: sum_embed_op(enc_c, tok_c, spk=s_ if torch.is_tensor(s_) else None)
+            dur_inp = masked_enc(spk_dur)
+            mel2ph = self.add_dur(dur_inp, mel2ph, txt_tokens, ret, src_padding=src_padding, keep=src_keep)
+        else:
+            src_nonpadding = (txt_tokens > 0).float()[:, :, None]
+            dur_inp = (encoder_out + spk_dur) * src_nonpadding
+            mel2ph = self.add_dur(dur_inp, mel2ph, txt_tokens, ret)
+        if glue and _glue_ok(mel2ph) and mel2ph.dtype == torch.int64:
             # fs2.py:128-141 as two launches: the length regulator's gather (+ the predictors' masked input), then every embedding, the speaker
             # embedding and the mask in one pass over [B,T,H] (the pad / repeat / gather / add / mul sequence of the reference moved ~100 MB)
-            enc_c, m2p = encoder_out.contiguous(), mel2ph.contiguous()
+            m2p = mel2ph.contiguous()
+            tgt_np, tgt_padding, _ = token_masks_op(m2p, gt0=True, eq0=True)
+            tgt_nonpadding = tgt_np[:, :, None]
             decoder_inp, pitch_inp = gather_frames_op(enc_c, m2p, spk_f0)
             idx1 = tab1 = idx2 = tab2 = None
             if hparams['use_pitch_embed']:
-                idx1 = self.add_pitch(pitch_inp, f0, uv, mel2ph, ret, encoder_out=(encoder_out + spk_f0) * src_nonpadding, want_index=True).contiguous()
+                # the phone-rate input of the 'ph' / 'cwt' pitch paths (fs2.py:146); with no speaker embedding it IS the duration predictor's input
+                enc_f0 = None
+                if hparams['pitch_type'] in ('ph', 'cwt'):
+                    enc_f0 = dur_inp if (not torch.is_tensor(spk_f0) and not torch.is_tensor(spk_dur)) else masked_enc(spk_f0)
+                idx1 = self.add_pitch(pitch_inp, f0, uv, m2p, ret, encoder_out=enc_f0, want_index=True, pitch_padding=tgt_padding).contiguous()
                 tab1 = self.pitch_embed.weight
             if hparams.get('use_energy_embed'):
                 idx2, tab2 = self.add_energy(pitch_inp, energy, ret, want_index=True).contiguous(), self.energy_embed.weight
@@ -882,6 +956,7 @@ class FastSpeech2(nn.Module):
                 return ret
             ret['mel_out'] = self.run_decoder(decoder_inp, tgt_nonpadding, ret, infer=infer, **kwargs)
             return ret
+        tgt_nonpadding = (mel2ph > 0).float()[:, :, None]
         decoder_inp = F.pad(encoder_out, [0, 0, 1, 0])
         decoder_inp = torch.gather(decoder_inp, 1, mel2ph[..., None].repeat([1, 1, encoder_out.shape[-1]]))
         pitch_inp = (decoder_inp + spk_f0) * tgt_nonpadding
@@ -902,15 +977,16 @@ class FastSpeech2(nn.Module):
             return x
         return x.detach() + hparams['predictor_grad'] * (x - x.detach())
 
-    def add_dur(self, dur_input, mel2ph, txt_tokens, ret):
-        src_padding = txt_tokens == 0
+    def add_dur(self, dur_input, mel2ph, txt_tokens, ret, src_padding=None, keep=None):
+        """fs2.py:151-172.  src_padding / keep: `txt_tokens == 0` and its float complement if the caller has them (dsf_token_masks)."""
+        src_padding = (txt_tokens == 0) if src_padding is None else src_padding
         dur_input = self._scale_grad(dur_input)
         if mel2ph is None:
-            dur, xs = self.dur_predictor.inference(dur_input, src_padding)
+            dur, xs = self.dur_predictor.inference(dur_input, src_padding, keep=keep)
             ret['dur'], ret['dur_choice'] = xs, dur
             mel2ph = self.length_regulator(dur, src_padding).detach()
         else:
-            ret['dur'] = self.dur_predictor(dur_input, src_padding)
+            ret['dur'] = self.dur_predictor(dur_input, src_padding, keep=keep)
         ret['mel2ph'] = mel2ph
         return mel2ph
 
@@ -923,8 +999,8 @@ class FastSpeech2(nn.Module):
         energy = torch.clamp(energy * 256 // 4, max=255).long()
         return energy if want_index else self.energy_embed(energy)
 
-    def add_pitch(self, decoder_inp, f0, uv, mel2ph, ret, encoder_out=None, want_index=False):
-        """fs2.py:183-231.  want_index: the rows of pitch_embed instead of the embedding."""
+    def add_pitch(self, decoder_inp, f0, uv, mel2ph, ret, encoder_out=None, want_index=False, pitch_padding=None):
+        """fs2.py:183-231.  want_index: the rows of pitch_embed instead of the embedding; pitch_padding: `mel2ph == 0` if the caller has it."""
         if hparams['pitch_type'] == 'ph':                                # :184-196: predicted and quantised per phone, gathered to the frames
             pitch_pred_inp = self._scale_grad(encoder_out)
             pitch_padding = encoder_out.sum().abs() == 0
@@ -936,10 +1012,11 @@ class FastSpeech2(nn.Module):
             idx = torch.gather(pitch, 1, mel2ph)
             return idx if want_index else self.pitch_embed(idx)
         decoder_inp = self._scale_grad(decoder_inp)
-        pitch_padding = mel2ph == 0
+        pitch_padding = (mel2ph == 0) if pitch_padding is None else pitch_padding
+        have_padding = True
         given = f0 is not None
         if hparams['pitch_type'] == 'cwt':
-            pitch_padding = None
+            pitch_padding, have_padding = None, False
             ret['cwt'] = cwt_out = self.cwt_predictor[1](self.cwt_predictor[0](decoder_inp))
             s = encoder_out[:, 0, :]
             st = self.cwt_stats_layers
@@ -957,10 +1034,14 @@ class FastSpeech2(nn.Module):
                 f0 = pitch_pred[:, :, 0]
             if hparams['use_uv'] and uv is None:
                 uv = pitch_pred[:, :, 1] > 0
-        ret['f0_denorm'] = f0_denorm = denorm_f0(f0, uv, hparams, pitch_padding=pitch_padding)
+        if _pitch_fusable(f0, uv, hparams) and _glue_ok(mel2ph):
+            # denorm_f0 + f0_to_coarse, 22 elementwise launches of the reference's op sequence, as one (dsf_pitch_coarse): the same values
+            ret['f0_denorm'], pitch = pitch_coarse_op(f0, uv, mel2ph if have_padding else None, hparams)
+        else:
+            ret['f0_denorm'] = f0_denorm = denorm_f0(f0, uv, hparams, pitch_padding=pitch_padding)
+            pitch = f0_to_coarse(f0_denorm)
         if pitch_padding is not None and not given:
             f0[pitch_padding] = 0           # the reference's in-place edit of the pitch_pred view (:225-226)
-        pitch = f0_to_coarse(f0_denorm)
         return pitch if want_index else self.pitch_embed(pitch)
 
     def run_decoder(self, decoder_inp, tgt_nonpadding, ret, infer, **kwargs):

@@ -108,6 +108,24 @@ int dsf_gather_frames(const float* enc, const int64_t* mel2ph, const float* spk,
 int dsf_sum_embed(const float* dec, const int64_t* idx1, const float* tab1, const float* add1, const int64_t* idx2, const float* tab2, const float* spk,
                   const int64_t* mel2ph, float* out, int32_t B, int32_t T, int32_t C, void* stream);
 
+/* The rest of the forward's glue (round 6, second half; 35 torch launches of 2-6 us were left between the encoder and the decoder).
+ * dsf_token_masks    the masks derived from an int64 index tensor v [n] (txt_tokens, mel2ph): gt0 = (v > 0) as float (fs2.py:98, :127),
+ *                    eq0 = (v == 0) as u8 / bool (fs2.py:157, :199), ne0 = (~(v == 0)) as float (DurationPredictor.forward,
+ *                    tts_modules.py:109-118); every output optional (NULL), one at least.
+ * dsf_pitch_coarse   utils/pitch_utils.py:64-77 denorm_f0 followed by :21-30 f0_to_coarse on f0 [B][T] (element strides stride_b, stride_t):
+ *                        d = f0 * f0_std + f0_mean (norm 1: pitch_norm 'standard') | 2 ** f0 (norm 2: 'log');   d = 0 where uv > 0 (uv_f float
+ *                        or uv_u8 bool, [B][T] contiguous, at most one of them) or mel2ph == 0 (each optional)           -> f0_denorm [B][T]
+ *                        m = 1127 * log(1 + d / 700);  m = (m - f0_mel_min) * (f0_bin - 2) / (f0_mel_max - f0_mel_min) + 1 where m > 0;
+ *                        m = 1 where m <= 1;  m = f0_bin - 1 where m > f0_bin - 1;  coarse = int64(m + 0.5)                 -> coarse [B][T]
+ *                    every operation in fp32 in this order, one rounding each, a division by a scalar as the multiplication by its fp32
+ *                    reciprocal - the values of the reference's tensor ops on the device.  stage 0: all of it.  stage 1: up to tmp = 1 + d / 700
+ *                    (writes f0_denorm and tmp); stage 2: from tmp = the caller's log(tmp) on (writes coarse); pow_in (norm 2): f0 already
+ *                    holds 2 ** f0 - the split forms for a host whose tensor library's log / pow round differently from this library's. */
+int dsf_token_masks(const int64_t* v, float* gt0, uint8_t* eq0, float* ne0, int64_t n, void* stream);
+int dsf_pitch_coarse(const float* f0, int64_t stride_b, int64_t stride_t, const float* uv_f, const uint8_t* uv_u8, const int64_t* mel2ph,
+                     float* f0_denorm, float* tmp, int64_t* coarse, int32_t B, int32_t T, int32_t norm, float f0_mean, float f0_std,
+                     double f0_mel_min, double f0_mel_max, int32_t f0_bin, int32_t stage, int32_t pow_in, void* stream);
+
 /* dsf_conv1d / dsf_conv1d_dilated pick their kernel by grid size: launches with at most one workgroup for every second CU (the phone-rate
  * encoder, everything of a single utterance) run 64-row workgroups whose waves split the contraction (k_fs_conv_ks; partial sums added in a
  * fixed order - results differ from the other kernel by summation order only).  mode: -1 by grid size (default), 0 never, 1 wherever the

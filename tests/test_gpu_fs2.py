@@ -208,6 +208,81 @@ def test_fused_glue_equals_the_torch_op_sequence_bit_for_bit(name):
         np.testing.assert_array_equal(fast[k], slow[k], err_msg=f'{name}:{k}')
 
 
+@torch.no_grad()
+def test_token_masks_operator():
+    """dsf_token_masks: (v > 0).float(), v == 0, (~(v == 0)).float() of an int64 index tensor in one launch (fs2.py:98, :127, :157, :199;
+    tts_modules.py:109) - zeros, negative values, a length that is no multiple of the workgroup."""
+    from diffsinger_amd import fs2
+    d = _dev()
+    g = torch.Generator().manual_seed(3)
+    v = torch.randint(-2, 5, (3, 1001), generator=g)
+    gt, eq, ne = fs2.token_masks_op(v.to(d), gt0=True, eq0=True, ne0=True)
+    assert eq.dtype == torch.bool
+    assert torch.equal(gt.cpu(), (v > 0).float()) and torch.equal(eq.cpu(), v == 0) and torch.equal(ne.cpu(), (~(v == 0)).float())
+    gt2, eq2, ne2 = fs2.token_masks_op(v.to(d), eq0=True)
+    assert gt2 is None and ne2 is None and torch.equal(eq2.cpu(), v == 0)
+
+
+@pytest.mark.parametrize('norm', ['log', 'standard'])
+@torch.no_grad()
+def test_pitch_coarse_operator_equals_the_torch_op_sequence_bit_for_bit(norm):
+    """dsf_pitch_coarse = denorm_f0 + f0_to_coarse (utils/pitch_utils.py:64-77, :21-30; 22 elementwise launches of the reference's op sequence on
+    the device) as one launch: f0_denorm and the quantised pitch carry the SAME BITS - voiced / unvoiced (float and bool uv), padding frames,
+    a strided f0 view (the predictor's column), values below and above the quantiser's range, both normalisations; and the split forms
+    (torch's own pow / log kernels around the operator's stages)."""
+    from diffsinger_amd import fs2
+    d = _dev()
+    g = torch.Generator().manual_seed(11)
+    B, T = 5, 1531
+    hp = dict(pitch_norm=norm, use_uv=True, f0_mean=214.0, f0_std=63.5)
+    if norm == 'log':
+        f0 = torch.rand(B, T, generator=g) * 9 + 3                      # 8 Hz ... 4 kHz: both clamps of the quantiser
+    else:
+        f0 = torch.randn(B, T, generator=g) * 3
+    f0[0, :7] = torch.tensor([0.0, -0.0, 1e-30, -5.0, 20.0, 1.0, 7.123])
+    pred = torch.stack([f0, torch.randn(B, T, generator=g)], -1).to(d)    # [B,T,2]: column 0 is a strided view like pitch_pred[:, :, 0]
+    uv_f = (torch.rand(B, T, generator=g) > 0.7).float()
+    mel2ph = torch.randint(0, 4, (B, T), generator=g)
+    for f0_in, uv, m2p in ((f0.to(d), uv_f.to(d), mel2ph.to(d)), (pred[:, :, 0], pred[:, :, 1] > 0, None), (f0.to(d), None, mel2ph.to(d)),
+                           (f0.to(d), uv_f.to(d).bool(), None)):
+        want_den = fs2.denorm_f0(f0_in.clone(), uv, hp, pitch_padding=(m2p == 0) if m2p is not None else None)
+        want = fs2.f0_to_coarse(want_den.clone())
+        assert fs2._pitch_fusable(f0_in, uv, hp)
+        for native in ((True, True), (False, True), (True, False), (False, False)):
+            try:
+                fs2.set_pitch_native(*native)
+                den, got = fs2.pitch_coarse_op(f0_in, uv, m2p, hp)
+            finally:
+                fs2.set_pitch_native(True, True)
+            assert got.dtype == torch.int64 and int(got.min()) >= 1 and int(got.max()) <= 255
+            assert torch.equal(den, want_den), (native, float((den - want_den).abs().max()))
+            assert torch.equal(got, want), (native, int((got != want).sum()))
+    assert int(want.min()) == 1 and (norm != 'log' or int(want.max()) == 255)
+
+
+@torch.no_grad()
+def test_pitch_coarse_every_float_of_the_working_range():
+    """The two transcendental steps of dsf_pitch_coarse go through the device library (__ocml_pow_f32 / __ocml_log_f32) as ATen's kernels do.
+    EVERY float32 in [1, 14] as the exponent of `2 ** f0` (2 Hz ... 16 kHz: 31.5 M values) and, through them, the arguments of the logarithm
+    (1 + f0 / 700 in [1, 24.4]) gives the bits of the torch op sequence; if a torch build ever links a device library that rounds differently,
+    this is the test that says so (and fs2.set_pitch_native switches to torch's own kernels around the operator's stages)."""
+    from diffsinger_amd import fs2
+    d = _dev()
+    hp = dict(pitch_norm='log', use_uv=False)
+    lo, hi = 0x3F800000, 0x41600000
+    step = 1 << 22
+    bad_den = bad_idx = 0
+    for a in range(lo, hi + 1, step):
+        n = min(step, hi + 1 - a)
+        f0 = (torch.arange(n, device=d, dtype=torch.int32) + a).view(torch.float32).view(1, n)
+        want_den = fs2.denorm_f0(f0, None, hp)
+        want = fs2.f0_to_coarse(want_den.clone())
+        den, got = fs2.pitch_coarse_op(f0, None, None, hp)
+        bad_den += int((den.view(torch.int32) != want_den.view(torch.int32)).sum())
+        bad_idx += int((got != want).sum())
+    assert bad_den == 0 and bad_idx == 0, (bad_den, bad_idx)
+
+
 def test_glue_operators_edge_cases():
     """dsf_positions / dsf_input_cm on ragged, partly and fully padded utterances, T not a multiple of 32, a given padding mask; against
     the torch expressions they replace (utils/__init__.py:145-157, tts_modules.py:288-296)."""
