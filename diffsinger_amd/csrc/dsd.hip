@@ -612,9 +612,10 @@ static bool wino_applicable(const dsd_handle* h);
 // cp[l] = Wc_l cond + bc_l + bd_l of the prepared batch (condT stays in the workspace), in the 32x32 fragment order every per-layer / latency
 // kernel and k_loop read - or in the accumulator order of the Winograd loop (dsd_loop_wino.hpp)
 static int launch_condproj(dsd_handle* h, bool wino, hipStream_t s) {
-    CondProjParams p{h->condT, h->wcp, h->b1p, h->cp, h->TS, h->ntile32, h->ntiles, wino ? 1 : 0, {}};
+    CondProjParams p{h->condT, h->wcp, h->b1p, h->cp, h->TS, h->ntile32, h->ntiles, h->L, wino ? 1 : 0, {}};
     for (int l = 0; l < h->L; ++l) p.dil[l] = (unsigned char)h->dil[l];
-    hipLaunchKernelGGL(k_condproj, dim3((unsigned)h->ntiles, h->L), dim3(kThreads), kC * 32 * 4, s, p);
+    const int G = condproj_groups(p.dil, h->L, h->ntiles);
+    hipLaunchKernelGGL(k_condproj, dim3((unsigned)h->ntiles, (unsigned)G), dim3(kThreads), condproj_lds(h->L, G), s, p);
     HIP_TRY(hipGetLastError());
     h->cp_wino = wino;
     return DSD_OK;

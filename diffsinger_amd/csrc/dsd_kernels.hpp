@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace dsd {
 
@@ -109,6 +110,11 @@ struct GemmPipe {
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(abase_uniform), 0, 0x7ffffff0, 0x00020000)),
           aoff((unsigned)lane * 16u), n(n_), bof(bof_) {}
 
+    // the same pipeline over another A stream (k_condproj walks several layers: the next layer's first chunks are requested before this layer's
+    // results are stored)
+    __device__ __forceinline__ void rebase(const float4* abase_uniform) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(abase_uniform), 0, 0x7ffffff0, 0x00020000);
+    }
     // buffer_load_dwordx4 v, voffset(lane), rsrc, soffset(chunk) offset:imm(row block): the chunk walk is one SALU
     // value, there is no per-lane 64-bit address arithmetic in the loop.  Prefetches run up to STAGES-1 chunks past
     // the end of the stream: the weight buffers carry that much slack (kWeightSlack) and the values are never used.
@@ -660,18 +666,25 @@ struct CondProjParams {
     const float4* b1p;      // [L][w4][mb4][h2][q4]  (dilated_conv.bias + conditioner_projection.bias)
     float4* cp;             // [L][ntiles][w4][mb4][q4][lane64], or (wino) [L][ntiles][w4][accumulator 2][rb 8][lane64]
     int TS, ntile32, ntiles_total;
+    int L;                  // layers
     int wino;               // 1: the INITIAL VALUES of the Winograd loop's two accumulator sets (dsd_loop_wino.hpp), in its accumulator order: for
                             // the pair p of a layer with dilation d, (cp[tE] + cp[tO]) / 2 and (cp[tE] - cp[tO]) / 2 - the loop's output transform
                             // (sum / difference of the sets) turns them back into cp[tE] and cp[tO]
     unsigned char dil[64];
 };
 
+// Grid (tiles, G): workgroup (tile, y) projects the tile for the layers y, y + G, y + 2 G, ... < L.  G = L is one layer per workgroup (small
+// batches: as many workgroups as possible).  Round 6 (profiles/r6_42_train_glue_trace.txt: 430 us of a 5 ms training step at 0.65 of the
+// matrix peak): for batches that fill the chip anyway the host launches G = the period of the dilation cycle, so that a workgroup stages its
+// conditioner tile - and, Winograd order, re-lays it for the ONE dilation its layers share - once for L / G layers instead of once per layer
+// (5 120 x 32 KiB of staging -> 1 024 x 32 KiB at L = 20), with the weight stream of the next layer requested while the stores of this one
+// drain.  The same contraction per (layer, tile): the same bits.
 __global__ __launch_bounds__(kThreads, 2) void k_condproj(const CondProjParams p) {
     constexpr int LD = 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x, l = blockIdx.y;
+    const int tile = blockIdx.x;
     const int b = tile / p.ntile32, t0 = (tile % p.ntile32) * 32;
     const float* src = p.condT + (size_t)b * kC * p.TS + t0;
 #pragma unroll
@@ -680,22 +693,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_condproj(const CondProjParams p
         *reinterpret_cast<float4*>(smem + row * LD + 4 * q) =
             *reinterpret_cast<const float4*>(src + (size_t)row * p.TS + 4 * q);
     }
-    f32x16 acc[4][1];
-    const float4* bl = p.b1p + (((size_t)l * 4 + w) * 4) * 8 + h * 4;
-    // (Winograd order: columns 16 .. 31 are differences of two frames - the biases cancel there)
-    const float bsel = (p.wino && j >= 16) ? 0.f : 1.f;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bv = bl[mb * 8 + q];
-            set4(acc[mb][0], q, make_float4(bv.x * bsel, bv.y * bsel, bv.z * bsel, bv.w * bsel));
-        }
+    // the bias rows of this workgroup's layers (2 KiB each: [w4][mb4][h2][q4] float4) behind the tile: the accumulators' initial values then come
+    // from LDS, not from a global load in front of every contraction
+    for (int i = tid, li = 0; ; i += kThreads) {
+        li = i >> 7;
+        const int l = (int)blockIdx.y + li * (int)gridDim.y;
+        if (l >= p.L) break;
+        reinterpret_cast<float4*>(smem + kC * LD)[i] = p.b1p[(size_t)l * 128 + (i & 127)];
+    }
     __syncthreads();
     if (p.wino) {
         // the conditioner tile in the loop's pair order: column c < 16 = (cond[tE(c)] + cond[tO(c)]) / 2, column 16 + c the half difference - by
-        // linearity the contraction then yields the half sum / half difference of the projection.  One thread per channel row.
-        const int e = __builtin_ctz((unsigned)p.dil[l]), d = 1 << e;
+        // linearity the contraction then yields the half sum / half difference of the projection.  One thread per channel row.  (Every layer of
+        // this workgroup has the dilation of its first one: the host's launch guarantees it.)
+        const int e = __builtin_ctz((unsigned)p.dil[blockIdx.y]), d = 1 << e;
         float* row = smem + tid * LD;
         float v[32], o[32];
 #pragma unroll
@@ -717,27 +728,72 @@ __global__ __launch_bounds__(kThreads, 2) void k_condproj(const CondProjParams p
         for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(row + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
         __syncthreads();
     }
-    const float4* ap = p.wcp + ((size_t)l * 4 + w) * (32 * 256);
+    // (Winograd order: columns 16 .. 31 are differences of two frames - the biases cancel there)
+    const float bsel = (p.wino && j >= 16) ? 0.f : 1.f;
     const float* cl = smem + 4 * h * LD + j;
-    gemm_k<4, 1, LD, 256>(acc, ap, lane, 32, TileB{cl, 8 * LD, 32});
-    if (p.wino) {
-        // Winograd loop: lane (pair pr, k group g) of v_mfma_f32_16x16x4_f32 holds, for accumulator set i (0: half sum, 1: half difference) and row
-        // block rb (16 rows; 0-3 gate, 4-7 filter), rows 4 g + {0..3}.  This lane's float4 (mb, q) = rows 32 (mb & 1) + 8 q + 4 h + {0..3} of the
-        // wave's 64 gate (mb < 2) / filter rows in column j = 16 i + pr: rb = 2 (mb & 1) + (q >> 1) (+ 4), g = 2 (q & 1) + h.
-        const int hf = j >> 4, pr = j & 15;
-        float4* out = p.cp + (((size_t)l * p.ntiles_total + tile) * 4 + w) * (2 * 8 * 64) + (size_t)hf * (8 * 64) + pr;
+    const float4* bias_l = reinterpret_cast<const float4*>(smem + kC * LD) + (w * 4) * 8 + h * 4;      // this lane's slice of layer slot 0
+    const int G = (int)gridDim.y;
+    GemmPipe<4, 1, LD, 256, 6, TileB> pipe(p.wcp + ((size_t)blockIdx.y * 4 + w) * (32 * 256), lane, 32, TileB{cl, 8 * LD, 32});
+    pipe.start_a();
+#pragma unroll 1
+    for (int l = blockIdx.y, li = 0; l < p.L; l += G, ++li) {
+        f32x16 acc[4][1];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) out[(2 * (mb & 1) + (q >> 1) + 4 * (mb >> 1)) * 64 + 16 * (2 * (q & 1) + h)] = get4(acc[mb][0], q);
-        return;
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = bias_l[li * 128 + mb * 8 + q];
+                set4(acc[mb][0], q, make_float4(bv.x * bsel, bv.y * bsel, bv.z * bsel, bv.w * bsel));
+            }
+        pipe.start_b();
+        pipe.run(acc, 0, 32);
+        // the next layer's weight stream is requested HERE, in front of this layer's stores: its first-touch latency ran in front of every
+        // contraction with both resident workgroups of a CU in the same phase (384 us for 279 us of matrix time, r6_45)
+        if (l + G < p.L) {
+            pipe.rebase(p.wcp + ((size_t)(l + G) * 4 + w) * (32 * 256));
+            pipe.start_a();
+        }
+        if (p.wino) {
+            // Winograd loop: lane (pair pr, k group g) of v_mfma_f32_16x16x4_f32 holds, for accumulator set i (0: half sum, 1: half difference) and row
+            // block rb (16 rows; 0-3 gate, 4-7 filter), rows 4 g + {0..3}.  This lane's float4 (mb, q) = rows 32 (mb & 1) + 8 q + 4 h + {0..3} of the
+            // wave's 64 gate (mb < 2) / filter rows in column j = 16 i + pr: rb = 2 (mb & 1) + (q >> 1) (+ 4), g = 2 (q & 1) + h.
+            const int hf = j >> 4, pr = j & 15;
+            float4* out = p.cp + (((size_t)l * p.ntiles_total + tile) * 4 + w) * (2 * 8 * 64) + (size_t)hf * (8 * 64) + pr;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[(2 * (mb & 1) + (q >> 1) + 4 * (mb >> 1)) * 64 + 16 * (2 * (q & 1) + h)] = get4(acc[mb][0], q);
+        } else {
+            float4* out = p.cp + (((size_t)l * p.ntiles_total + tile) * 4 + w) * (4 * 4 * 64) + lane;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[(mb * 4 + q) * 64] = get4(acc[mb][0], q);
+        }
     }
-    float4* out = p.cp + (((size_t)l * p.ntiles_total + tile) * 4 + w) * (4 * 4 * 64) + lane;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[(mb * 4 + q) * 64] = get4(acc[mb][0], q);
 }
+
+// grid.y of a k_condproj launch: a multiple of the period of the dilation cycle (every layer of a workgroup then shares its dilation) when the
+// batch fills the chip with that many workgroups per tile, else one layer per workgroup
+constexpr int kCondProjMaxLayers = 10;      // layers per workgroup: 32 KiB of tile + 20 KiB of bias rows stay under the 64 KiB default limit
+inline int condproj_groups(const unsigned char* dil, int L, int ntiles) {
+    const char* e = getenv("DSD_CP_GROUPS");                        // "layer": one layer per workgroup whatever the batch (the A/B of the tests)
+    if (e && e[0] == 'l') return L;
+    const int forced = e ? atoi(e) : 0;                             // a number: that many groups if the dilation cycle allows it (measurements)
+    int per = L;
+    for (int c = 1; c <= 8 && c < L; c *= 2) {
+        bool ok = true;
+        for (int l = c; l < L && ok; ++l) ok = dil[l] == dil[l - c];
+        if (ok) { per = c; break; }
+    }
+    // the smallest multiple of the period that gives every workgroup the same number of layers and the chip two workgroups per CU
+    if (forced > 0) return (forced < L && forced % per == 0 && L / forced <= kCondProjMaxLayers) ? forced : L;
+    for (int G = per; G < L; G += per)
+        if (L % G == 0 && (long)ntiles * G >= 512 && L / G <= kCondProjMaxLayers) return G;
+    return L;
+}
+// dynamic LDS of a k_condproj launch with G groups: the conditioner tile + 2 KiB of bias rows per layer of a workgroup
+inline size_t condproj_lds(int L, int G) { return (size_t)kC * 32 * 4 + (size_t)((L + G - 1) / G) * 2048; }
 
 // ------------------------------------------------------------------------------------------------------------
 // input projection + ReLU on a [kMPad][32] tile held in LDS (rows >= M are zero)

@@ -349,10 +349,11 @@ extern "C" int dsf_stack_forward(const float* x0, const float* cond, const float
     {
         CondProjParams p{};
         p.condT = cond; p.wcp = (const float4*)(ws + lay.wcp); p.b1p = (const float4*)(ws + lay.b1p); p.cp = (float4*)(ws + lay.cp);
-        p.TS = TS; p.ntile32 = ntile32; p.ntiles_total = ntiles;
+        p.TS = TS; p.ntile32 = ntile32; p.ntiles_total = ntiles; p.L = L;
         p.wino = wino ? 1 : 0;                      // the Winograd forward takes it as its accumulators' initial values (dsd_kernels.hpp)
         for (int l = 0; l < L; ++l) p.dil[l] = (unsigned char)w->dilations[l];
-        hipLaunchKernelGGL(k_condproj, dim3((unsigned)ntiles, (unsigned)L), dim3(kThreads), kC * 32 * 4, s, p);
+        const int G = condproj_groups(p.dil, L, ntiles);
+        hipLaunchKernelGGL(k_condproj, dim3((unsigned)ntiles, (unsigned)G), dim3(kThreads), condproj_lds(L, G), s, p);
         HIP_TRY(hipGetLastError());
     }
     {

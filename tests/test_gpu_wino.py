@@ -81,6 +81,49 @@ def test_winograd_loop_full_width_all_dilations(B, T, K):
     assert d <= 1e-5
 
 
+@pytest.mark.parametrize('preset', ['opencpop_ds60_rel', 'lj_ds_beta6'])
+def test_conditioner_projection_grouped_by_dilation_gives_the_same_bits(preset):
+    """Round 6: for batches that fill the chip a k_condproj workgroup stages (and, Winograd order, re-lays) its conditioner tile once for all
+    the layers of one dilation instead of once per layer (grid.y = a multiple of the dilation cycle's period; DSD_CP_GROUPS=layer keeps one
+    layer per workgroup).  The same contraction per (layer, tile): both accumulator orders, both presets (cycle 4 / cycle 1) - the same bits."""
+    import os
+    import diffsinger_amd
+    from diffsinger_amd import hparams
+    from diffsinger_amd.synth import presets
+    pre = presets()[preset]
+    hparams.clear()
+    diffsinger_amd.use_preset(preset)
+    torch.manual_seed(13)
+    net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+    torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+    B, T, K = 8, 1024, 3
+    gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=100, K_step=K, loss_type='l1', spec_min=pre['spec_min'],
+                                          spec_max=pre['spec_max']).cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(15)
+    cond = torch.randn(B, T, 256, device='cuda', generator=g).transpose(1, 2)
+    x_T = torch.randn(B, 1, 80, T, device='cuda', generator=g)
+    noise = torch.randn(K, B, 1, 80, T, device='cuda', generator=g)
+    eng = gd._engine(cond)
+    eng.set_loop_mode(1)
+    outs = {}
+    try:
+        for groups in ('layer', None):
+            if groups:
+                os.environ['DSD_CP_GROUPS'] = groups
+            else:
+                os.environ.pop('DSD_CP_GROUPS', None)
+            for mode in ('direct', 'winograd'):                     # every switch of the convolution re-lays cp: a fresh k_condproj launch
+                eng.set_conv_mode(mode)
+                with torch.no_grad():
+                    outs[groups, mode] = gd.inference(cond, x_T=x_T, noise=noise, K_step=K, pndm_speedup=0).cpu().numpy()
+                assert eng.loop_timeouts() == 0
+    finally:
+        os.environ.pop('DSD_CP_GROUPS', None)
+    for mode in ('direct', 'winograd'):
+        assert np.isfinite(outs[None, mode]).all()
+        np.testing.assert_array_equal(outs[None, mode], outs['layer', mode], err_msg=mode)
+
+
 def test_results_do_not_depend_on_the_touch_lead_and_seeded_noise_matches_explicit_noise():
     """The L2 touch computes nothing: every lead (and off) gives the same bits; the
     in-kernel Philox draw equals the explicit-noise loop fed with the same draws; replays are deterministic."""
