@@ -24,7 +24,7 @@ SYMBOLS = [
 SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf_conv1d', 'dsf_layer_norm', 'dsf_attention',
                'dsf_ln_bwd_workspace_floats', 'dsf_layer_norm_bwd', 'dsf_attention_bwd_workspace_floats', 'dsf_attention_bwd',
                'dsf_linear_rows_workspace_floats', 'dsf_linear_rows', 'dsf_linear_rows_bwd',
-               'dsf_to_channel_major', 'dsf_from_channel_major', 'dsf_positions', 'dsf_input_cm', 'dsf_gather_frames', 'dsf_sum_embed', 'dsf_token_masks', 'dsf_pitch_coarse', 'dsf_p_sample', 'dsf_denorm_spec',
+               'dsf_to_channel_major', 'dsf_from_channel_major', 'dsf_positions', 'dsf_input_cm', 'dsf_gather_frames', 'dsf_sum_embed', 'dsf_token_masks', 'dsf_pitch_coarse', 'dsf_q_sample_rows', 'dsf_l1_workspace_floats', 'dsf_l1_mean', 'dsf_l1_mean_bwd', 'dsf_p_sample', 'dsf_denorm_spec',
                'dsf_conv1d_dilated', 'dsf_set_conv_split', 'dsf_wgrad_workspace_floats', 'dsf_conv1d_wgrad', 'dsf_bias_grad',
                'dsf_train_add_step', 'dsf_train_rowsum', 'dsf_train_gate', 'dsf_train_gate_bwd', 'dsf_train_res_skip', 'dsf_train_res_skip_bwd',
                'dsf_channel_affine', 'dsf_group_norm', 'dsf_adamw_step',
@@ -148,6 +148,11 @@ def load():
     lib.dsf_gather_frames.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.dsf_sum_embed.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_token_masks.argtypes = [vp, vp, vp, vp, i64, vp]
+    lib.dsf_q_sample_rows.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, vp]
+    lib.dsf_l1_workspace_floats.argtypes = []
+    lib.dsf_l1_workspace_floats.restype = i64
+    lib.dsf_l1_mean.argtypes = [vp, vp, vp, vp, i64, vp]
+    lib.dsf_l1_mean_bwd.argtypes = [vp, vp, vp, vp, i64, vp]
     lib.dsf_pitch_coarse.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, C.c_double, C.c_double, i32, i32, i32, vp]
     lib.dsf_p_sample.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]
     lib.dsf_denorm_spec.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]

@@ -310,6 +310,37 @@ extern "C" int dsf_sum_embed(const float* dec, const int64_t* idx1, const float*
     return DSD_OK;
 }
 
+extern "C" int dsf_q_sample_rows(const float* x_start, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, float* out, int32_t B,
+                                 int64_t per_row, void* stream) {
+    if (!x_start || !noise || !t || !sqrt_ac || !sqrt_1mac || !out || B < 1 || B > 65535 || per_row < 4 || (per_row & 3) || per_row > ((int64_t)1 << 32))
+        return fail(DSD_ERR_INVALID, "dsf_q_sample_rows: bad argument (B=%d per_row=%lld; per_row a multiple of 4)", B, (long long)per_row);
+    const int per4 = (int)(per_row / 4);
+    hipLaunchKernelGGL(k_fs_q_sample_rows, dim3((unsigned)std::min(64, (per4 + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x_start, noise,
+                       (const long long*)t, sqrt_ac, sqrt_1mac, out, per4);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+constexpr int kL1Blocks = 256;
+extern "C" int64_t dsf_l1_workspace_floats(void) { return kL1Blocks; }
+
+extern "C" int dsf_l1_mean(const float* a, const float* b, float* workspace, float* out, int64_t n, void* stream) {
+    if (!a || !b || !workspace || !out || n < 1) return fail(DSD_ERR_INVALID, "dsf_l1_mean: bad argument");
+    const int nblk = (int)std::min<int64_t>(kL1Blocks, (n + 255) / 256);
+    hipLaunchKernelGGL(k_fs_l1_partial, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a, b, workspace, (size_t)n);
+    hipLaunchKernelGGL(k_fs_l1_final, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, (float)(1.0 / (double)n), out);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
+extern "C" int dsf_l1_mean_bwd(const float* a, const float* b, const float* grad_out, float* db, int64_t n, void* stream) {
+    if (!a || !b || !grad_out || !db || n < 1) return fail(DSD_ERR_INVALID, "dsf_l1_mean_bwd: bad argument");
+    hipLaunchKernelGGL(k_fs_l1_bwd, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, grad_out,
+                       (float)(1.0 / (double)n), db, (size_t)n);
+    HIP_TRY(hipGetLastError());
+    return DSD_OK;
+}
+
 extern "C" int dsf_token_masks(const int64_t* v, float* gt0, uint8_t* eq0, float* ne0, int64_t n, void* stream) {
     if (!v || (!gt0 && !eq0 && !ne0) || n < 1 || n > ((int64_t)1 << 38)) return fail(DSD_ERR_INVALID, "dsf_token_masks: bad argument (v, one output at least, n=%lld)", (long long)n);
     FsTokMaskParams p{};

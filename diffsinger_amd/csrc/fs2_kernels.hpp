@@ -812,6 +812,63 @@ __global__ void k_fs_p_sample(float* __restrict__ x, const float* __restrict__ e
     }
 }
 
+// The element-wise ends of GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:206-231) around the denoiser's training forward
+// (round 6: profiles/r6_42_train_glue_trace.txt - q_sample was five torch launches, the L1 loss and its backward nine):
+//   k_fs_q_sample_rows   x_noisy[b] = sqrt_alphas_cumprod[t_b] * x_start[b] + sqrt_one_minus_alphas_cumprod[t_b] * noise[b]  (:206-211; two
+//                        products and one sum, each rounded once, as the tensor ops)
+//   k_fs_l1_partial / k_fs_l1_final   mean |a - b| in a fixed order (per-thread strided sums, a tree per workgroup, one workgroup over the partials)
+//   k_fs_l1_bwd          d mean|a - b| / d b = -(sign(a - b) * (g / N)), g the DEVICE scalar arriving from autograd
+__global__ __launch_bounds__(256) void k_fs_q_sample_rows(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
+                                                          const float* __restrict__ tab_a, const float* __restrict__ tab_s, float* __restrict__ out, int per_row4) {
+    const int b = blockIdx.y;
+    const long long tb = t[b];
+    const float a = tab_a[tb], s = tab_s[tb];
+    const float4* x4 = reinterpret_cast<const float4*>(x0) + (size_t)b * per_row4;
+    const float4* n4 = reinterpret_cast<const float4*>(noise) + (size_t)b * per_row4;
+    float4* o4 = reinterpret_cast<float4*>(out) + (size_t)b * per_row4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < per_row4; i += gridDim.x * 256) {
+        const float4 x = x4[i], n = n4[i];
+        o4[i] = make_float4(__fadd_rn(__fmul_rn(a, x.x), __fmul_rn(s, n.x)), __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(s, n.y)),
+                            __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(s, n.z)), __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(s, n.w)));
+    }
+}
+
+__device__ __forceinline__ float fs_block_sum256(float v, float* sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] = __fadd_rn(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+__global__ __launch_bounds__(256) void k_fs_l1_partial(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial, size_t n) {
+    __shared__ float sh[256];
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc = __fadd_rn(acc, fabsf(__fsub_rn(a[i], b[i])));
+    const float tot = fs_block_sum256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_fs_l1_final(const float* __restrict__ partial, int nblk, float inv_n, float* __restrict__ out) {
+    __shared__ float sh[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc = __fadd_rn(acc, partial[i]);
+    const float tot = fs_block_sum256(acc, sh);
+    if (threadIdx.x == 0) out[0] = __fmul_rn(tot, inv_n);
+}
+
+__global__ __launch_bounds__(256) void k_fs_l1_bwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g, float inv_n,
+                                                   float* __restrict__ db, size_t n) {
+    const float gn = __fmul_rn(g[0], inv_n);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = __fsub_rn(a[i], b[i]);
+        const float sg = (d > 0.f) ? 1.f : (d < 0.f) ? -1.f : d;                    // torch.sign: 0 at 0, NaN stays NaN
+        db[i] = -__fmul_rn(gn, sg);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient of a Conv1d / Linear (training):
 //     dW[co][ci][tap] = sum_b sum_t dy[b][co][t] * x[b][ci][t + tap * dil - pad]

@@ -301,6 +301,62 @@ def diffnet_forward_train(net, spec: torch.Tensor, diffusion_step: torch.Tensor,
     return x[:, None, :, :T]
 
 
+_FUSED_ENDS = True
+
+
+def set_fused_ends(on: bool):
+    """A/B switch of the tests and of the measurement: False = q_sample and the L1 loss of p_losses as the reference's tensor expressions
+    (five + nine launches per step, rounds 2-5)."""
+    global _FUSED_ENDS
+    _FUSED_ENDS = bool(on)
+
+
+class _L1Mean(torch.autograd.Function):
+    """(noise - x_recon).abs().mean() (shallow_diffusion_tts.py:224-228) as two launches forward (sums in a fixed order) and one backward."""
+
+    @staticmethod
+    def forward(ctx, noise, x_recon):
+        lib = _lib.load()
+        n = noise.numel()
+        ws = torch.empty(int(lib.dsf_l1_workspace_floats()), device=noise.device, dtype=torch.float32)
+        out = torch.empty((), device=noise.device, dtype=torch.float32)
+        with torch.cuda.device(noise.device):
+            _lib.check(lib.dsf_l1_mean(noise.data_ptr(), x_recon.data_ptr(), ws.data_ptr(), out.data_ptr(), n, _stream(noise.device)), 'dsf_l1_mean')
+        ctx.save_for_backward(noise, x_recon)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        noise, x_recon = ctx.saved_tensors
+        g = g.contiguous()
+        db = torch.empty_like(x_recon)
+        with torch.cuda.device(noise.device):
+            _lib.check(_lib.load().dsf_l1_mean_bwd(noise.data_ptr(), x_recon.data_ptr(), g.data_ptr(), db.data_ptr(), noise.numel(), _stream(noise.device)),
+                       'dsf_l1_mean_bwd')
+        return None, db
+
+
+def _plain_f32(*ts) -> bool:
+    return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+
+
+def q_sample_rows(gd, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """q_sample (:206-211) with a step per utterance; one launch when nothing of it needs a gradient, else the tensor expression."""
+    B = x_start.shape[0]
+    per_row = x_start[0].numel()
+    if (_FUSED_ENDS and _plain_f32(x_start, noise, gd.sqrt_alphas_cumprod, gd.sqrt_one_minus_alphas_cumprod) and t.is_cuda and t.dtype == torch.int64
+            and t.shape == (B,) and noise.shape == x_start.shape and per_row % 4 == 0 and B <= 65535
+            and not (torch.is_grad_enabled() and (x_start.requires_grad or noise.requires_grad))):
+        out = torch.empty_like(x_start)
+        with torch.cuda.device(x_start.device):
+            _lib.check(_lib.load().dsf_q_sample_rows(x_start.data_ptr(), noise.data_ptr(), t.contiguous().data_ptr(), gd.sqrt_alphas_cumprod.data_ptr(),
+                                                     gd.sqrt_one_minus_alphas_cumprod.data_ptr(), out.data_ptr(), B, per_row, _stream(x_start.device)),
+                       'dsf_q_sample_rows')
+        return out
+    shape = (B, 1, 1, 1)
+    return gd.sqrt_alphas_cumprod.gather(-1, t).reshape(shape) * x_start + gd.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(shape) * noise
+
+
 def p_losses(gd, x_start: torch.Tensor, t: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tensor] = None,
              nonpadding: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:213-231)."""
@@ -310,15 +366,15 @@ def p_losses(gd, x_start: torch.Tensor, t: torch.Tensor, cond: torch.Tensor, noi
         raise NotImplementedError(f'p_losses: {type(gd.denoise_fn).__name__} has no training forward (DiffNet: the fused stack; FFT: forward_train)')
     if noise is None:
         noise = torch.randn_like(x_start)
-    shape = (x_start.shape[0], 1, 1, 1)
-    x_noisy = gd.sqrt_alphas_cumprod.gather(-1, t).reshape(shape) * x_start + \
-        gd.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(shape) * noise                    # q_sample :206-211
+    x_noisy = q_sample_rows(gd, x_start, t, noise)                                             # q_sample :206-211
     # the denoiser the registry returned (usr/diffsinger_task.py:23-27): DiffNet on the fused training stack, the FFT candidate on the
     # FastSpeech2 operators under autograd
     x_recon = diffnet_forward_train(gd.denoise_fn, x_noisy, t, cond, n_steps=gd.num_timesteps) if fused else gd.denoise_fn.forward_train(x_noisy, t, cond)
     if gd.loss_type == 'l1':
         if nonpadding is not None:
             return ((noise - x_recon).abs() * nonpadding.unsqueeze(1)).mean()
+        if _FUSED_ENDS and _plain_f32(noise, x_recon) and noise.shape == x_recon.shape and not (torch.is_grad_enabled() and noise.requires_grad):
+            return _L1Mean.apply(noise, x_recon)
         return (noise - x_recon).abs().mean()
     if gd.loss_type == 'l2':
         return F.mse_loss(noise, x_recon)

@@ -260,6 +260,45 @@ def test_p_losses_gradients_fused_equals_operator_path(monkeypatch):
     assert worst[1] <= 5e-5 and e_c <= 5e-5
 
 
+def test_fused_ends_of_p_losses_equal_the_tensor_expressions():
+    """Round 6: q_sample with a step per utterance (five torch launches) and the L1 loss with its backward (nine) run as dsf_q_sample_rows /
+    dsf_l1_mean / dsf_l1_mean_bwd.  x_noisy carries the bits of the tensor expression; the loss sums in another (fixed) order - within 1e-6 -
+    and its gradient -(sign(noise - x_recon) / N) is the same bits, so every parameter gradient is bit-identical to the torch ends'."""
+    import diffsinger_amd
+    from diffsinger_amd import hparams, train
+    from tests import helpers as H
+    pre = H.presets()['opencpop_ds60_rel']
+    res = {}
+    try:
+        for fused in (True, False):
+            train.set_fused_ends(fused)
+            hparams.clear()
+            diffsinger_amd.use_preset('opencpop_ds60_rel')
+            torch.manual_seed(7)
+            net = diffsinger_amd.DIFF_DECODERS['wavenet'](hparams)
+            torch.nn.init.normal_(net.output_projection.weight, std=0.02)
+            gd = diffsinger_amd.GaussianDiffusion(None, 80, net, timesteps=pre['timesteps'], K_step=pre['K_step'], loss_type='l1',
+                                                  spec_min=pre['spec_min'], spec_max=pre['spec_max']).cuda().train()
+            g = torch.Generator().manual_seed(3)
+            B, T = 3, 96                                                   # T a multiple of 32: x_recon is contiguous, the fused loss applies
+            x0 = torch.clamp(torch.randn(B, 1, 80, T, generator=g) * 0.5, -1, 1).cuda()
+            noise = torch.randn(B, 1, 80, T, generator=g).cuda()
+            cond = torch.randn(B, T, 256, generator=g).transpose(1, 2).cuda().requires_grad_(True)
+            t = torch.tensor([5, 40, 17]).cuda()
+            xn = train.q_sample_rows(gd, x0, t, noise)
+            loss = gd.p_losses(x0, t, cond, noise=noise)
+            assert (type(loss.grad_fn).__name__ == '_L1MeanBackward') == fused
+            (loss * 3.0).backward()                                        # a scaled loss: the upstream gradient is a device scalar, not 1
+            res[fused] = (xn.cpu(), float(loss), {k: p.grad.detach().cpu() for k, p in net.named_parameters()}, cond.grad.detach().cpu())
+    finally:
+        train.set_fused_ends(True)
+    assert torch.equal(res[True][0], res[False][0])
+    assert abs(res[True][1] - res[False][1]) <= 1e-6 * abs(res[False][1]) and res[False][1] > 0
+    for k, gref in res[False][2].items():
+        assert torch.equal(res[True][2][k], gref), k
+    assert torch.equal(res[True][3], res[False][3])
+
+
 def test_dcond_follows_the_weights_over_optimizer_steps(monkeypatch):
     """the packed Wc^T of the dcond convolution must be rebuilt when a STOCK torch optimiser changes the conditioner weights
     (joint FastSpeech2 training, usr/diffsinger_task.py:60-64): three optimiser steps with cond.requires_grad on the fused path and on the
