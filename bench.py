@@ -639,9 +639,11 @@ def fs2_forward_flops(m, step):
     return total[0]
 
 
-def quick_rows(gd, device, warm=3, steps=10):
+def quick_rows(gd, device, warm=5, steps=30):
     """rows: {fs2, vocoder, train}: ms per step (HIP events around `steps` steps after `warm`) and frac_row = FLOPs of the WHOLE row / time /
-    157.3 TFLOP/s - beside, not instead of, the dominant kernel's fraction the `--row` lines report."""
+    157.3 TFLOP/s - beside, not instead of, the dominant kernel's fraction the `--row` lines report.  5 warm + 30 timed steps (~0.35 s for the
+    three rows): with 3 + 10 the first steps of the window ran before the host was ahead of the device - the training row read 5.0-5.07 ms for
+    the 4.80-4.83 of a longer window on the same box, FastSpeech2 2.79-2.83 for 2.74-2.76 (profiles/r6_50_quick_rows_window.txt)."""
     B, T = B_PER_GPU, T_FRAMES
     rows = {}
     # f1: FastSpeech2 forward, teacher-forced

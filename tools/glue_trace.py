@@ -1,6 +1,6 @@
 """Developer tool (GPU): the kernel SEQUENCE of one FastSpeech2 forward / one denoiser training step / one HiFi-GAN generator forward at the bench shape (torch.profiler,
 device-side names in launch order, with duration and the idle gap in front) - which launches are still torch glue between the library's
-kernels.      python tools/glue_trace.py fs2|train|vocoder [preset]"""
+kernels.      python tools/glue_trace.py fs2|train|vocoder|path [preset]"""
 import os
 import sys
 
@@ -56,6 +56,24 @@ def main_train(preset='lj_ds_beta6', B=8, T=1024):
     trace(step, f'training step {preset} {B} x {T}')
 
 
+def main_path(B=8, T=1024, K=100):
+    import bench
+    dev = torch.device('cuda', 0)
+    gd, pre = bench.build_model(dev)
+    gd.eval()
+    g = torch.Generator(device=dev).manual_seed(1234)
+    conds = [torch.randn(B, T, 256, device=dev, generator=g).transpose(1, 2) for _ in range(2)]
+    x_T = torch.randn(B, 1, 80, T, device=dev, generator=g)
+    noise = torch.randn(K, B, 1, 80, T, device=dev, generator=g)
+    count = [0]
+
+    def step():
+        count[0] += 1
+        with torch.no_grad():
+            return gd.inference(conds[count[0] & 1], x_T=x_T, noise=noise, K_step=K, pndm_speedup=0)
+    trace(step, f'BASELINE configs[1] step: {B} x {T}, K = {K}')
+
+
 def main_vocoder(B=8, T=1024):
     import bench
     from diffsinger_amd.vocoder import HifiGanGenerator
@@ -89,4 +107,4 @@ def main(preset='lj_ds_beta6', B=8, T_txt=128, fpp=8):
 
 
 if __name__ == '__main__':
-    {'train': main_train, 'vocoder': main_vocoder}.get(sys.argv[1] if len(sys.argv) > 1 else 'fs2', main)(*sys.argv[2:])
+    {'train': main_train, 'vocoder': main_vocoder, 'path': main_path}.get(sys.argv[1] if len(sys.argv) > 1 else 'fs2', main)(*sys.argv[2:])

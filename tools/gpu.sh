@@ -45,7 +45,7 @@ bench)
     cut -c1-900 $O/bench_n1.json; tail -3 $O/bench_n1.err ;;
 rows)
     for row in vocoder fs2 train; do
-        timeout 300 python bench.py --row $row --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_row_$row.json 2> $O/bench_row_$row.err
+        timeout 300 python bench.py --row $row --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_row_$row.json 2> $O/bench_row_$row.err
         cut -c1-330 $O/bench_row_$row.json; echo
     done ;;
 voc)
