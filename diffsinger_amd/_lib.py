@@ -31,7 +31,7 @@ SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf
                'dsf_stack_workspace_floats', 'dsf_set_stack_mode', 'dsf_set_stack_conv', 'dsf_get_stack_conv', 'dsf_set_wgrad_dual', 'dsf_debug_trb_timeline', 'dsf_stack_offsets', 'dsf_stack_forward', 'dsf_stack_backward', 'dsf_wgrad2_workspace_floats', 'dsf_conv1d_wgrad2', 'dsf_wgrad_probe', 'dsf_wgrad_probe_read']
 
 # every symbol include/dsv.h declares (the HiFi-GAN / NSF-HiFi-GAN generator ops)
-SYMBOLS_VOC = ['dsv_padded_samples', 'dsv_packed_floats', 'dsv_pack_weight', 'dsv_pad_rows', 'dsv_conv1d', 'dsv_conv1d_multi', 'dsv_noise_conv', 'dsv_sine_source',
+SYMBOLS_VOC = ['dsv_padded_samples', 'dsv_packed_floats', 'dsv_pack_weight', 'dsv_pad_rows', 'dsv_conv1d', 'dsv_conv1d_multi', 'dsv_set_lean', 'dsv_noise_conv', 'dsv_sine_source',
                'dsv_fold_factor', 'dsv_set_fold', 'dsv_conv1d_folded', 'dsv_chain_fold', 'dsv_chain_supported', 'dsv_resblock_chain', 'dsv_resblock_chain_multi', 'dsv_resblock_chain_sum', 'dsv_set_chain_variant', 'dsv_debug_chain_timeline',
                'dsv_pwg_first', 'dsv_pwg_upsample', 'dsv_pwg_layer']
 
@@ -187,6 +187,7 @@ def load():
     lib.dsv_chain_supported.restype = i32
     lib.dsv_resblock_chain.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, f32, f32, vp]
     lib.dsv_conv1d_multi.argtypes = [i32, vp, i32, i32, i32, i32, i32, f32, vp]
+    lib.dsv_set_lean.argtypes = [i32]
     lib.dsv_resblock_chain_multi.argtypes = [vp, vp, vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, f32, vp]
     lib.dsv_resblock_chain_sum.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, f32, f32, vp]
     lib.dsv_set_chain_variant.argtypes = [i32, i32, i32]

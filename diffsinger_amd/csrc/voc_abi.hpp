@@ -51,6 +51,22 @@ static void voc_conv_launch(const VocConvParams& p, int B, hipStream_t s) {
     hipLaunchKernelGGL((k_voc_conv<NB, WT, HALO>), grid, dim3(kThreads), lds, s, p);
 }
 
+// the lean build for memory-shaped layers (voc_kernels.hpp): LDS by the channel count
+static int g_voc_lean = 1;       // dsv_set_lean: the A/B switch of the measurement
+extern "C" int dsv_set_lean(int32_t on) { g_voc_lean = on ? 1 : 0; return DSD_OK; }
+
+template <int NB, int WT>
+static bool voc_lean_try(const VocConvParams& p, int B, hipStream_t s) {
+    static const int env_on = [] { const char* e = getenv("DSV_LEAN"); return e ? atoi(e) : 1; }();
+    constexpr int WR = 4 / WT, SPAN = voc_span<NB, WT>(), LD = voc_ld<NB, WT, kVocHaloLean>();
+    const int ci8 = (p.Ci + 7) / 8 * 8;
+    if (!g_voc_lean || !env_on || p.pad > kVocHaloLean || (p.KT - 1) * p.dil - p.pad > kVocHaloLean || ci8 > voc_slab<NB, WT, kVocHaloLean>() || ci8 * LD * 4 > 40 * 1024)
+        return false;
+    const dim3 grid((unsigned)((p.LSi + SPAN - 1) / SPAN), (unsigned)B, (unsigned)((p.rows + 32 * WR - 1) / (32 * WR)));
+    hipLaunchKernelGGL((k_voc_conv_lean<NB, WT>), grid, dim3(kThreads), (size_t)ci8 * LD * 4, s, p);
+    return true;
+}
+
 static int voc_conv_fill(VocConvParams& p, const float* in, const float* wpacked, const float* bias, float* out, int32_t B, int32_t Ci, int32_t rows, int32_t KT,
                          int32_t pad, int32_t dil, int32_t L_in, int32_t up, float pre_slope, const float* residual, const float* sum_in, float divide,
                          int32_t act, const char* who) {
@@ -90,7 +106,10 @@ extern "C" int dsv_conv1d(const float* in, const float* wpacked, const float* bi
         else if (rows <= 64) voc_conv_launch<2, 2, kVocHaloWide>(p, B, (hipStream_t)stream);
         else voc_conv_launch<1, 1, kVocHaloWide>(p, B, (hipStream_t)stream);
     } else {
-        if (rows <= 32) voc_conv_launch<4, 4, kVocHalo>(p, B, (hipStream_t)stream);
+        if (rows <= 32) {
+            // the stride-2 transposed convolutions: the lean build (four and more workgroups per CU) where it applies
+            if (!(up == 2 && voc_lean_try<2, 4>(p, B, (hipStream_t)stream))) voc_conv_launch<4, 4, kVocHalo>(p, B, (hipStream_t)stream);
+        }
         else if (rows <= 64) voc_conv_launch<2, 2, kVocHalo>(p, B, (hipStream_t)stream);
         else voc_conv_launch<1, 1, kVocHalo>(p, B, (hipStream_t)stream);
     }

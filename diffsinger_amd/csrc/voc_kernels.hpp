@@ -191,7 +191,7 @@ __device__ __forceinline__ void voc_conv_epilogue(const VocConvParams& p, f32x16
 }
 
 // Workgroup = WR = 4 / WT row blocks of 32 x (WT * NB * 32) samples of one utterance.  Wave w: row block (w % WR), time part (w / WR).
-template <int NB, int WT, int HALO>
+template <int NB, int WT, int HALO, bool OPERANDS_AHEAD = true>
 __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
     constexpr int LD = voc_ld<NB, WT, HALO>(), SPAN = voc_span<NB, WT>(), SLAB = voc_slab<NB, WT, HALO>(), WR = 4 / WT;
     constexpr int NCOL4 = LD / 4;
@@ -215,7 +215,7 @@ __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
     // A plain convolution's residual / running-sum operands (the second convolution of every ResBlock1 pair) are requested HERE, in front of
     // the weight prefetch and the staging loads (round 6): their round trip to memory ran behind the contraction, with nothing to hide under.
     // Only for the narrow tiles (NB <= 2: 16 NB registers per operand).
-    constexpr bool PRE = (NB <= 2);
+    constexpr bool PRE = OPERANDS_AHEAD && (NB <= 2);              // (the lean build has no registers for them: its layers carry no residual)
     float rpre[PRE ? NB : 1][16], spre[PRE ? NB : 1][16];
     const bool pre = PRE && p.U == 1 && rb < nrb && (p.res || p.sum_in);
     if constexpr (PRE) {
@@ -283,6 +283,17 @@ __device__ __forceinline__ void voc_conv_body(const VocConvParams& p, int bz) {
 template <int NB, int WT, int HALO = kVocHalo>
 __global__ __launch_bounds__(kThreads, 2) void k_voc_conv(const VocConvParams p) {
     voc_conv_body<NB, WT, HALO>(p, blockIdx.z);
+}
+
+// The same body built LEAN for the memory-shaped layers (round 6, r6_52): the stride-2 transposed convolutions of the shipped generator
+// (32 -> 16 and 16 -> 8 channels: 64 / 32 reduction rows, 3.5 us of matrix work per tile beside 72 + 64 KiB of staging and stores) moved
+// 2.2 TB/s with two 240-register workgroups per CU all staging, contracting and storing in the same phase.  Half the tile (NB = 2: 256 samples),
+// a 4-sample halo (two polyphase taps reach 1 sample), the LDS slab sized by the channel count and at most 128 registers: four and more
+// workgroups per CU, whose phases drift apart over twice the rounds.  Same chunk order: the same bits.
+constexpr int kVocHaloLean = 4;
+template <int NB, int WT>
+__global__ __launch_bounds__(kThreads, 3) void k_voc_conv_lean(const VocConvParams p) {
+    voc_conv_body<NB, WT, kVocHaloLean, false>(p, blockIdx.z);
 }
 
 // Several INDEPENDENT convolutions of the same shape (B, Ci, rows, L, up) in ONE launch (round 6): the three parallel resblocks of a stage

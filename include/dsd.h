@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 /* 6 (round 6): dsd_get_conv_mode also reports the Winograd conv node of the latency kernels; dsv_set_chain_variant; dsv_resblock_chain refuses
- * sum_in == out; dsf_positions / dsf_input_cm / dsf_gather_frames / dsf_sum_embed / dsf_token_masks / dsf_pitch_coarse / dsf_q_sample_rows / dsf_l1_mean / dsf_l1_mean_bwd; dsf_set_wgrad_dual; dsv_resblock_chain_multi / dsv_resblock_chain_sum / dsv_conv1d_multi.  5 (round 5): dsd_set_conv_mode. */
+ * sum_in == out; dsf_positions / dsf_input_cm / dsf_gather_frames / dsf_sum_embed / dsf_token_masks / dsf_pitch_coarse / dsf_q_sample_rows / dsf_l1_mean / dsf_l1_mean_bwd; dsf_set_wgrad_dual; dsv_resblock_chain_multi / dsv_resblock_chain_sum / dsv_conv1d_multi / dsv_set_lean.  5 (round 5): dsd_set_conv_mode. */
 #define DSD_ABI_VERSION 6
 
 typedef struct dsd_handle dsd_handle;

@@ -72,6 +72,11 @@ typedef struct dsv_conv_desc {
 int dsv_conv1d_multi(int32_t ngroups, const dsv_conv_desc* d, int32_t B, int32_t Ci, int32_t rows, int32_t L_in, int32_t up, float pre_slope,
                      void* stream);
 
+/* A/B switch of the measurement (round 6): the stride-2 transposed convolutions (up = 2, rows <= 32, taps within 4 samples) run on a lean build
+ * of the same kernel - half the tile, LDS by the channel count, at most 128 registers: four and more workgroups per CU instead of two - the
+ * same chunk order, the same bits; 0 = the standard build.  Process-wide, not thread-safe. */
+int dsv_set_lean(int32_t on);
+
 /* The same convolution (up = 1, 'same' padding pad = (K-1) * dil / 2, K odd) for the NARROW layers, Co <= 16 - the 16- and 8-channel
  * resblocks and conv_post of the shipped generator: F output samples are folded into the 32 MFMA rows so that no row multiplies
  * zeros.  dsv_fold_factor returns the F the library wants for such a layer (4: Co <= 8, 2: Co <= 16, 1: use dsv_conv1d; also 1

@@ -329,6 +329,33 @@ def test_conv1d_multi_is_bit_identical_to_the_single_launches(C, L):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('ci,rows,L,B', [(32, 32, 65536, 4), (16, 16, 70001, 3), (8, 6, 4100, 9)])
+def test_lean_build_of_the_stride2_transposed_convolution_is_bit_identical(ci, rows, L, B):
+    """Round 6 (r6_52): the stride-2 transposed convolutions run on a lean build of k_voc_conv (half the tile, a 4-sample halo, LDS by the
+    channel count, three workgroups per CU instead of two: 64-69 -> 58-60 us per launch at the bench shape).  Same chunk order: the same BITS as
+    the standard build (dsv_set_lean(0)) - the shipped shapes, a ragged length, a row count that does not fill the block."""
+    lib = _lib.load()
+    ops = _HipOps()
+    g = torch.Generator(device=DEV).manual_seed(ci + L)
+    k, up = 2, 2
+    w = torch.randn(rows, ci, k, generator=g, device=DEV) / (ci * k) ** 0.5
+    bias = torch.randn(rows // up, generator=g, device=DEV)
+    x = torch.zeros(B, ci, padded_samples(L), device=DEV)
+    x[:, :, :L] = torch.randn(B, ci, L, generator=g, device=DEV)
+    wp = ops.pack(w)
+    try:
+        assert lib.dsv_set_lean(0) == 0
+        want = ops.conv(x, L, wp, bias, rows, ci, k, 1, 1, up=up, pre_slope=0.1)
+        assert lib.dsv_set_lean(1) == 0
+        got = ops.conv(x, L, wp, bias, rows, ci, k, 1, 1, up=up, pre_slope=0.1)
+        torch.cuda.synchronize()
+    finally:
+        lib.dsv_set_lean(1)
+    assert torch.isfinite(want).all() and float(want.abs().max()) > 0.1
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert got.shape[2] == L * up or float(got[:, :, L * up:].abs().max()) == 0
+
+
 def test_merged_chain_entry_points_contract_and_plan():
     """dsv_resblock_chain_multi / dsv_resblock_chain_sum (include/dsv.h): argument checks, and the host model that picks the split
     (diffsinger_amd.vocoder._merge_plan) on the bench shape - 1 096 / 1 264 / 1 368 workgroups of kernel 3 / 7 / 11 on 512 slots: kernel 11 and
