@@ -148,7 +148,7 @@ def load():
     lib.dsf_gather_frames.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.dsf_sum_embed.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.dsf_token_masks.argtypes = [vp, vp, vp, vp, i64, vp]
-    lib.dsf_q_sample_rows.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, vp]
+    lib.dsf_q_sample_rows.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, i64, vp]
     lib.dsf_l1_workspace_floats.argtypes = []
     lib.dsf_l1_workspace_floats.restype = i64
     lib.dsf_l1_mean.argtypes = [vp, vp, vp, vp, i64, vp]

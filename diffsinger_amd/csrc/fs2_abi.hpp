@@ -310,13 +310,13 @@ extern "C" int dsf_sum_embed(const float* dec, const int64_t* idx1, const float*
     return DSD_OK;
 }
 
-extern "C" int dsf_q_sample_rows(const float* x_start, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, float* out, int32_t B,
-                                 int64_t per_row, void* stream) {
-    if (!x_start || !noise || !t || !sqrt_ac || !sqrt_1mac || !out || B < 1 || B > 65535 || per_row < 4 || (per_row & 3) || per_row > ((int64_t)1 << 32))
+extern "C" int dsf_q_sample_rows(const float* x_start, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, int32_t n_steps,
+                                 float* out, int32_t B, int64_t per_row, void* stream) {
+    if (!x_start || !noise || !t || !sqrt_ac || !sqrt_1mac || !out || n_steps < 1 || B < 1 || B > 65535 || per_row < 4 || (per_row & 3) || per_row > ((int64_t)1 << 32))
         return fail(DSD_ERR_INVALID, "dsf_q_sample_rows: bad argument (B=%d per_row=%lld; per_row a multiple of 4)", B, (long long)per_row);
     const int per4 = (int)(per_row / 4);
     hipLaunchKernelGGL(k_fs_q_sample_rows, dim3((unsigned)std::min(64, (per4 + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x_start, noise,
-                       (const long long*)t, sqrt_ac, sqrt_1mac, out, per4);
+                       (const long long*)t, sqrt_ac, sqrt_1mac, out, per4, (int)n_steps);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

@@ -819,10 +819,12 @@ __global__ void k_fs_p_sample(float* __restrict__ x, const float* __restrict__ e
 //   k_fs_l1_partial / k_fs_l1_final   mean |a - b| in a fixed order (per-thread strided sums, a tree per workgroup, one workgroup over the partials)
 //   k_fs_l1_bwd          d mean|a - b| / d b = -(sign(a - b) * (g / N)), g the DEVICE scalar arriving from autograd
 __global__ __launch_bounds__(256) void k_fs_q_sample_rows(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
-                                                          const float* __restrict__ tab_a, const float* __restrict__ tab_s, float* __restrict__ out, int per_row4) {
+                                                          const float* __restrict__ tab_a, const float* __restrict__ tab_s, float* __restrict__ out, int per_row4,
+                                                          int n_steps) {
     const int b = blockIdx.y;
     const long long tb = t[b];
-    const float a = tab_a[tb], s = tab_s[tb];
+    const bool ok = tb >= 0 && tb < n_steps;                        // a step outside the schedule: NaN rows (torch.gather raises; this fails loudly too)
+    const float a = ok ? tab_a[tb] : __builtin_nanf(""), s = ok ? tab_s[tb] : __builtin_nanf("");
     const float4* x4 = reinterpret_cast<const float4*>(x0) + (size_t)b * per_row4;
     const float4* n4 = reinterpret_cast<const float4*>(noise) + (size_t)b * per_row4;
     float4* o4 = reinterpret_cast<float4*>(out) + (size_t)b * per_row4;

@@ -782,6 +782,18 @@ class PitchPredictor(nn.Module):
         return from_cm(conv1d_cm(xc, T, self.linear.weight, self._plin, self.linear.bias), T)
 
 
+def _hip_mlp(x, layers):
+    """A chain of _HipLinear layers on [B,C] / [B,T,C] input, channel-major in between: one layout change in and one out instead of a pair per
+    layer (the values of layer(layer(...)): the layout changes are each other's inverses)."""
+    x3 = x if x.dim() == 3 else x[:, None, :]
+    T = x3.shape[1]
+    xc = to_cm(x3)
+    for lin, act in layers:
+        xc = conv1d_cm(xc, T, lin.weight, lin._pack, lin.bias, act=act)
+    y = from_cm(xc, T)
+    return y if x.dim() == 3 else y[:, 0, :]
+
+
 class _HipLinear(nn.Linear):
     """nn.Linear whose forward on [B,T,C] / [B,C] inputs runs through the conv kernel (K = 1)."""
 
@@ -1020,7 +1032,7 @@ class FastSpeech2(nn.Module):
             ret['cwt'] = cwt_out = self.cwt_predictor[1](self.cwt_predictor[0](decoder_inp))
             s = encoder_out[:, 0, :]
             st = self.cwt_stats_layers
-            stats_out = st[4](st[2](st[0](s, act='relu'), act='relu'))
+            stats_out = _hip_mlp(s, ((st[0], 'relu'), (st[2], 'relu'), (st[4], 'none')))
             mean = ret['f0_mean'] = stats_out[:, 0]
             std = ret['f0_std'] = stats_out[:, 1]
             if f0 is None:

@@ -350,7 +350,8 @@ def q_sample_rows(gd, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tenso
         out = torch.empty_like(x_start)
         with torch.cuda.device(x_start.device):
             _lib.check(_lib.load().dsf_q_sample_rows(x_start.data_ptr(), noise.data_ptr(), t.contiguous().data_ptr(), gd.sqrt_alphas_cumprod.data_ptr(),
-                                                     gd.sqrt_one_minus_alphas_cumprod.data_ptr(), out.data_ptr(), B, per_row, _stream(x_start.device)),
+                                                     gd.sqrt_one_minus_alphas_cumprod.data_ptr(), int(gd.sqrt_alphas_cumprod.numel()), out.data_ptr(), B, per_row,
+                                                     _stream(x_start.device)),
                        'dsf_q_sample_rows')
         return out
     shape = (B, 1, 1, 1)

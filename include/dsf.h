@@ -129,12 +129,13 @@ int dsf_pitch_coarse(const float* f0, int64_t stride_b, int64_t stride_t, const 
 /* The element-wise ends of GaussianDiffusion.p_losses (usr/diff/shallow_diffusion_tts.py:206-231) around the denoiser's training forward (round 6).
  * dsf_q_sample_rows  :206-211 with a step per utterance: out[b] = sqrt_ac[t[b]] * x_start[b] + sqrt_1mac[t[b]] * noise[b]; x_start / noise / out
  *                    [B][per_row] contiguous, t [B] int64 on the device, the two schedule tables on the device; two products and a sum, each
- *                    rounded once (the values of the tensor expression).  per_row a multiple of 4.
+ *                    rounded once (the values of the tensor expression).  per_row a multiple of 4; a step outside [0, n_steps) (the tables' length) gives a row of
+ *                    NaN (the reference's gather raises).
  * dsf_l1_mean        :224-228 (loss_type 'l1', no mask): out[0] = mean |a - b| over n floats, summed in a fixed order (deterministic);
  *                    workspace of dsf_l1_workspace_floats() floats.
  * dsf_l1_mean_bwd    its gradient with respect to b: db = -(sign(a - b) * (grad_out[0] / n)), grad_out a DEVICE scalar. */
-int dsf_q_sample_rows(const float* x_start, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, float* out, int32_t B,
-                      int64_t per_row, void* stream);
+int dsf_q_sample_rows(const float* x_start, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, int32_t n_steps,
+                      float* out, int32_t B, int64_t per_row, void* stream);
 int64_t dsf_l1_workspace_floats(void);
 int dsf_l1_mean(const float* a, const float* b, float* workspace, float* out, int64_t n, void* stream);
 int dsf_l1_mean_bwd(const float* a, const float* b, const float* grad_out, float* db, int64_t n, void* stream);
