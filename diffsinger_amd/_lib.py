@@ -18,7 +18,7 @@ SYMBOLS = [
     'dsd_set_use_graph', 'dsd_set_layer_tile', 'dsd_time_layer_kernel', 'dsd_debug_layer_timeline', 'dsd_device_bytes',
     'dsd_get_layer_tile', 'dsd_set_loop_mode', 'dsd_get_loop_mode', 'dsd_loop_timeouts', 'dsd_debug_loop_timeline', 'dsd_set_noise_seed', 'dsd_philox_normal',
     'dsd_set_split_mode', 'dsd_get_split_mode', 'dsd_debug_layer', 'dsd_loop_launches', 'dsd_p_sample_ex', 'dsd_set_lat_split', 'dsd_get_lat_split', 'dsd_set_conv_mode', 'dsd_get_conv_mode',
-    'dsd_check', 'dsd_loop_parked', 'dsd_debug_hold_cus',
+    'dsd_check', 'dsd_loop_parked', 'dsd_debug_hold_cus', 'dsd_debug_condproj_groups',
 ]
 # every symbol include/dsf.h declares (the FastSpeech2 conditioner ops)
 SYMBOLS_FS2 = ['dsf_padded_frames', 'dsf_packed_floats', 'dsf_pack_weight', 'dsf_conv1d', 'dsf_layer_norm', 'dsf_attention',
@@ -110,6 +110,7 @@ def load():
     lib.dsd_check.argtypes = [h]
     lib.dsd_loop_parked.argtypes = [h]
     lib.dsd_debug_hold_cus.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dsd_debug_condproj_groups.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
     lib.dsd_set_lat_split.argtypes = [h, C.c_int32]
     lib.dsd_get_lat_split.argtypes = [h]
     lib.dsd_set_conv_mode.argtypes = [h, C.c_int32, C.c_int32]

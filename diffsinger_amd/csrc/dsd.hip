@@ -1317,6 +1317,13 @@ extern "C" int dsd_check(dsd_handle* h) {
     return check_sticky(h, "dsd_check");
 }
 
+extern "C" int32_t dsd_debug_condproj_groups(const uint8_t* dilations, int32_t L, int32_t ntiles, int64_t* lds_bytes) {
+    if (!dilations || L < 1 || L > 64 || ntiles < 1) return -1;
+    const int G = condproj_groups(dilations, L, ntiles);
+    if (lds_bytes) *lds_bytes = (int64_t)condproj_lds(L, G);
+    return G;
+}
+
 extern "C" int dsd_debug_hold_cus(int32_t device, int32_t n_workgroups, int32_t milliseconds, uint32_t* started, void* stream) {
     if (n_workgroups < 1 || n_workgroups > 4096 || milliseconds < 1 || milliseconds > 300000)
         return fail(DSD_ERR_INVALID, "dsd_debug_hold_cus: 1..4096 workgroups, 1..300000 ms");

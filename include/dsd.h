@@ -237,6 +237,12 @@ int dsd_loop_parked(dsd_handle* h);
  * word - the holders leave as soon as it is non-zero (or after `milliseconds`, whichever comes first). */
 int dsd_debug_hold_cus(int32_t device, int32_t n_workgroups, int32_t milliseconds, uint32_t* ctl, void* stream);
 
+/* Test hook (host logic only, no device work): grid.y of the hoisted conditioner projection's launch for a stack of L layers with these
+ * dilations and a batch of ntiles 32-frame tiles - a multiple of the dilation cycle's period such that every workgroup gets the same number
+ * (at most 10) of layers of ONE dilation and the chip two workgroups per CU, else L (one layer per workgroup); *lds_bytes: the launch's
+ * dynamic LDS.  The environment variable DSD_CP_GROUPS ("layer" / a number) overrides it, for A/B measurements.  -1: bad argument. */
+int32_t dsd_debug_condproj_groups(const uint8_t* dilations, int32_t L, int32_t ntiles, int64_t* lds_bytes);
+
 /* Frames per workgroup of the residual-layer kernel: 0 = choose from the batch size, 32 or 64. */
 int dsd_set_layer_tile(dsd_handle* h, int32_t frames);
 

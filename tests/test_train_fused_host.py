@@ -80,3 +80,31 @@ def test_fused_path_refuses_cpu_tensors():
                                           spec_min=[-6.0] * 80, spec_max=[0.0] * 80).train()
     with pytest.raises(RuntimeError):
         gd.p_losses(torch.zeros(1, 1, 80, 8), torch.zeros(1, dtype=torch.long), torch.zeros(1, 256, 8))
+
+
+def test_conditioner_projection_grouping_rule(monkeypatch):
+    """Host logic of the k_condproj launch (csrc/dsd_kernels.hpp condproj_groups, round 6): grid.y = a multiple of the dilation cycle's period
+    with equal layer counts (<= 10) per workgroup once the batch gives the chip two workgroups per CU; one layer per workgroup for small
+    batches, aperiodic dilations and under DSD_CP_GROUPS=layer."""
+    lib = _lib.load()
+    monkeypatch.delenv('DSD_CP_GROUPS', raising=False)
+
+    def groups(dil, ntiles):
+        lds = C.c_int64(0)
+        g = lib.dsd_debug_condproj_groups(bytes(dil), len(dil), ntiles, C.byref(lds))
+        assert lds.value == 256 * 32 * 4 + -(-len(dil) // g) * 2048 and lds.value <= 64 * 1024
+        return g
+    cyc4, cyc1 = [1, 2, 4, 8] * 5, [1] * 20
+    assert groups(cyc4, 256) == 4 and groups(cyc4, 128) == 4 and groups(cyc4, 1024) == 4        # BASELINE configs[1] / [3]: 5 layers per workgroup
+    assert groups(cyc4, 127) == 20 and groups(cyc4, 16) == 20                                  # 1 x 512: as many workgroups as there are
+    assert groups(cyc1, 256) == 2 and groups(cyc1, 512) == 2                                   # never more than 10 layers per workgroup
+    assert groups(cyc1, 255) == 4 and groups(cyc1, 100) == 10 and groups(cyc1, 40) == 20
+    assert groups([1, 2, 4, 8, 1, 2, 4], 1024) == 7                                            # 7 layers: no multiple of the period divides them
+    assert groups([1, 2, 4, 8, 2, 1, 4, 8], 4096) == 8                                         # aperiodic
+    assert groups([1, 2] * 10, 256) == 2 and groups([1, 2] * 3, 256) == 2
+    assert groups([4], 4096) == 1
+    monkeypatch.setenv('DSD_CP_GROUPS', 'layer')
+    assert groups(cyc4, 256) == 20
+    monkeypatch.setenv('DSD_CP_GROUPS', '10')
+    assert groups(cyc1, 16) == 10 and groups(cyc4, 256) == 20                                  # 10 is no multiple of the period 4: refused
+    assert lib.dsd_debug_condproj_groups(None, 20, 256, None) == -1
