@@ -215,8 +215,9 @@ static int tr_wgrad_launch(hipStream_t s, TrWgParams& wp, int ndesc, int B, int 
         ++pr.used;
         pr.flops += 2.0 * 128 * 256 * ((double)np + 0.5 * (double)nc) * (double)B * (double)T;     // EXECUTED: a dual product contracts T / 2 pairs
     }
-    if (nc) hipLaunchKernelGGL(k_tr_wgrad_reduce_dual, dim3((unsigned)(nc / 4), 128), dim3(256), 0, s, wp);
-    if (np) hipLaunchKernelGGL(k_tr_wgrad_reduce, dim3((unsigned)np, 128), dim3(256), 0, s, wp);
+    if (nc && np) hipLaunchKernelGGL(k_tr_wgrad_reduce_all, dim3((unsigned)(nc / 4 + np), 128), dim3(256), 0, s, wp);
+    else if (nc) hipLaunchKernelGGL(k_tr_wgrad_reduce_dual, dim3((unsigned)(nc / 4), 128), dim3(256), 0, s, wp);
+    else if (np) hipLaunchKernelGGL(k_tr_wgrad_reduce, dim3((unsigned)np, 128), dim3(256), 0, s, wp);
     HIP_TRY(hipGetLastError());
     return DSD_OK;
 }

@@ -1039,8 +1039,8 @@ __global__ void k_tr_zero_pads(float* __restrict__ y, size_t rows, int rs) {
 
 // dW = sum over the splits, in split order; one thread per element of a 128 x 256 tile, grid (tile descriptor, 128)
 // grid (plain descriptors, 128): the descriptors [nc, ndesc)
-__global__ __launch_bounds__(256) void k_tr_wgrad_reduce(const TrWgParams p) {
-    const int desc = p.nc + blockIdx.x;
+__device__ __forceinline__ void tr_wgrad_reduce_body(const TrWgParams& p, int bx) {
+    const int desc = p.nc + bx;
     const TrWgTile& d = p.tile[desc];
     const int m = blockIdx.y, n = threadIdx.x;
     const float* src = p.part + (size_t)tr_wg_part_index(p, desc, 0) * (128 * 256) + m * 256 + n;
@@ -1058,8 +1058,8 @@ __global__ __launch_bounds__(256) void k_tr_wgrad_reduce(const TrWgParams p) {
 
 // grid (nc / 4, 128): the four products of one 128-row tile (descriptors 4 g .. 4 g + 3 = P0 .. P3, each summed over its splits in split
 // order) back-transformed into the three tap gradients; descriptor 4 g carries `out` (tap 0: taps are out + 1, out + 2) and 4 g + 1 the bias
-__global__ __launch_bounds__(256) void k_tr_wgrad_reduce_dual(const TrWgParams p) {
-    const int g = blockIdx.x, m = blockIdx.y, n = threadIdx.x;
+__device__ __forceinline__ void tr_wgrad_reduce_dual_body(const TrWgParams& p, int bx) {
+    const int g = bx, m = blockIdx.y, n = threadIdx.x;
     float P[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1081,6 +1081,16 @@ __global__ __launch_bounds__(256) void k_tr_wgrad_reduce_dual(const TrWgParams p
         for (int k = 0; k < p.ns_c; ++k) t += sb[(size_t)k * 128];
         d1.out_bias[m] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void k_tr_wgrad_reduce(const TrWgParams p) { tr_wgrad_reduce_body(p, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void k_tr_wgrad_reduce_dual(const TrWgParams p) { tr_wgrad_reduce_dual_body(p, (int)blockIdx.x); }
+// both reductions of a weight-gradient launch in ONE grid (round 6: ten pairs of 6-7 us launches per training step): blocks [0, nc / 4) are the
+// dual groups, the rest the plain descriptors - the same sums in the same order
+__global__ __launch_bounds__(256) void k_tr_wgrad_reduce_all(const TrWgParams p) {
+    const int ng = p.nc / 4;
+    if ((int)blockIdx.x < ng) tr_wgrad_reduce_dual_body(p, (int)blockIdx.x);
+    else tr_wgrad_reduce_body(p, (int)blockIdx.x - ng);
 }
 
 }  // namespace dsd
